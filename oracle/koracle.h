@@ -1,0 +1,99 @@
+/*
+ * koracle.h -- CPU ORACLE for the kat hist / gcp / comp hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This directory is a plain-C restatement of the reference's algorithm (TGAC/KAT 2.4.2 + bundled
+ * Jellyfish 2.2.0).  It exists so that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg can check (and time) the HIP path against an independent CPU implementation.  Nothing in the
+ * product (kat_amd/, include/) may include, link, import or execute anything in oracle/.
+ *
+ * PINNING STATUS (see DESIGN.md "Oracle"):
+ *   - The reference itself is UNBUILDABLE in this image: every translation unit on the path
+ *     includes the autoconf-generated <config.h> (e.g. lib/src/input_handler.cc:19,
+ *     deps/jellyfish-2.2.0/include/jellyfish/mer_dna.hpp:21) and autotools are absent, so no
+ *     oracle/_ref binary exists and no reference output could be generated here.
+ *   - Pinned against the known answers the reference's own tests hold for this path:
+ *       tests/check_jellyfish.cc:38-116  (.jf header fields, 1889 records, k-mer lookups 3/1/1/1 and
+ *                                         canonical lookups 3/1/0/0 on tests/data/ecoli.header.jf27)
+ *       tests/check_compcounters.cc:30-62 (CompCounters arithmetic: distinct 4, total 60)
+ *       tests/data/kat.hist, scripts/test/resources/{hist1.hist,gcp1.mx,spectracn1.mx} (file formats)
+ *   - The reference holds NO golden hist/.mx/.stats outputs (its CLI tests only check exit codes,
+ *     tests/test_hist.sh, test_gcp.sh, test_comp.sh).  End-to-end numbers quoted in SURVEY.md 8(c)
+ *     (recorded by the survey stage from a hand-built reference binary) are used as additional
+ *     known answers in tests/test_oracle_known_answers.py, with that provenance stated there.
+ *     Beyond those, end-to-end parity of the text outputs is UNPINNED.
+ */
+#ifndef KORACLE_H
+#define KORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ko_table ko_table;
+
+enum { KO_OK = 0, KO_ERR_IO = 1, KO_ERR_FORMAT = 2, KO_ERR_FASTQ = 3, KO_ERR_K = 4, KO_ERR_MEM = 5 };
+
+/* --- k-mer helpers (mer_dna.hpp:46-63,100-108,235-258,436-446) --- */
+int      ko_encode(const char* s, unsigned k, uint64_t* out);   /* 0 ok, -1 if a non-ACGT char */
+void     ko_decode(uint64_t key, unsigned k, char* out /* k+1 */);
+uint64_t ko_revcomp(uint64_t key, unsigned k);
+uint64_t ko_canonical(uint64_t key, unsigned k);
+
+/* --- table --- */
+ko_table* ko_table_new(unsigned k, int canonical);
+void      ko_table_free(ko_table*);
+unsigned  ko_table_k(const ko_table*);
+uint64_t  ko_table_distinct(const ko_table*);
+uint64_t  ko_table_total(const ko_table*);
+uint64_t  ko_table_get(const ko_table*, uint64_t key);                 /* JellyfishHelper::getCount, canonical=false */
+void      ko_table_add(ko_table*, uint64_t key, uint64_t amount);
+/* sorted (ascending key) dump; arrays must hold ko_table_distinct() entries */
+void      ko_table_dump_sorted(const ko_table*, uint64_t* keys, uint64_t* counts);
+
+/* count every k-window of every maximal ACGTacgt run of a byte stream (mer_iterator.hpp:61-89) */
+void      ko_count_bases(ko_table*, const uint8_t* bases, size_t n);
+/* multi-threaded variant used for the CPU baseline timing (same result) */
+void      ko_count_bases_mt(ko_table*, const uint8_t* bases, size_t n, int threads);
+/* parse one FASTA/FASTQ(.gz) file into the 'N'-joined base stream (mer_overlap_sequence_parser.hpp:132-289) */
+int       ko_parse_file(const char* path, unsigned trim5p, uint8_t** bases, size_t* n);
+void      ko_free(void*);
+/* InputHandler::count over a group of files (lib/src/input_handler.cc:180-202) */
+int       ko_count_files(ko_table*, const char* const* paths, size_t n_paths, const uint16_t* trim5p);
+/* .jf (binary/sorted) reader: binary_dumper.hpp:94-119, generic_file_header.hpp:96-153 */
+int       ko_jf_load(const char* path, ko_table** out, uint64_t* n_records, char* header_json, size_t header_cap);
+
+/* --- reducers --- */
+/* Histogram::binSlice (src/histogram.cc:183-199) */
+void ko_hist(const ko_table*, uint64_t base, uint64_t ceil, uint64_t inc, uint64_t* out, size_t nb);
+/* Gcp::analyseSlice (src/gcp.cc:179-197); out is k rows x (cvg_bins+1), GC==k dropped (gcp.cc:93) */
+void ko_gcp(const ko_table*, double cvg_scale, uint32_t cvg_bins, uint64_t* out);
+/* Comp::compareSlice (src/comp.cc:387-484) + CompCounters (lib/src/comp_counters.cc:91-140).
+ * counters[13] order: hash1_total, hash2_total, hash3_total, hash1_distinct, hash2_distinct, hash3_distinct,
+ * hash1_only_total, hash2_only_total, hash1_only_distinct, hash2_only_distinct,
+ * shared_hash1_total, shared_hash2_total, shared_distinct.
+ * spectra: 4 x min(d1_bins,d2_bins): spectrum1, spectrum2, shared_spectrum1, shared_spectrum2. */
+void ko_comp(const ko_table* t1, const ko_table* t2, int canon1, int canon2,
+             double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
+             uint64_t* main_mx, uint64_t counters[13], uint64_t* spectra);
+
+/* --- writers (byte-exact text) --- */
+int ko_write_hist(const char* out_path, unsigned k, const char* const* paths, size_t n_paths,
+                  uint64_t base, uint64_t inc, const uint64_t* data, size_t nb);
+int ko_write_gcp(const char* out_path, unsigned k, const char* const* paths, size_t n_paths,
+                 uint32_t cvg_bins, const uint64_t* mx);
+int ko_write_comp_main(const char* out_path, unsigned k,
+                       const char* const* paths1, size_t n1, const char* const* paths2, size_t n2,
+                       uint32_t d1_bins, uint32_t d2_bins, const uint64_t* mx);
+int ko_write_comp_stats(const char* out_path, const char* hash1_path, const char* hash2_path,
+                        const uint64_t counters[13], const uint64_t* spectra, uint32_t spec_size);
+int ko_write_comp_hist(const char* out_path, unsigned k, const char* const* paths, size_t n_paths,
+                       const uint64_t* spectrum, uint32_t spec_size);
+/* distance metrics (lib/include/kat/distance_metrics.hpp:39-127): 0 Manhattan 1 Euclidean 2 Cosine 3 Canberra 4 Jaccard */
+double ko_distance(int which, const uint64_t* s1, const uint64_t* s2, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
