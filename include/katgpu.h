@@ -1,0 +1,160 @@
+/*
+ * katgpu.h -- C ABI of libkatgpu.so: the MI355X (gfx950) k-mer counting / spectra-reduction engine that
+ * drops in behind KAT's `hist` / `gcp` / `comp` hot path.
+ *
+ * KAT (TGAC/KAT 2.4.2) has no plugin/FFI layer: the seam is a handful of C++ call sites.  Each entry point
+ * below names the reference routine it replaces (paths relative to the KAT source tree; JF/ =
+ * deps/jellyfish-2.2.0/).  INTEGRATION.md shows the patch a KAT maintainer would apply.
+ *
+ * Conventions
+ *   - every function returns a katgpu_status (0 = ok); katgpu_last_error() gives the message the reference
+ *     would have thrown (same wording where the reference has one);
+ *   - handles are opaque; result buffers are caller-allocated HOST memory unless a parameter is named dev_*;
+ *   - one caller thread per ctx; a table is immutable once counting has finished, so reducers may be
+ *     called in any order, any number of times;
+ *   - k-mers are 2-bit packed, first base in the most significant bits, A=0 C=1 G=2 T=3
+ *     (JF/include/jellyfish/mer_dna.hpp:46-63,330-353).  This build supports 1 <= k <= 32.
+ *   - there is NO CPU fallback: without a gfx950 device katgpu_init fails with KATGPU_ERR_DEVICE.
+ */
+#ifndef KATGPU_H
+#define KATGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct katgpu_ctx katgpu_ctx;
+typedef struct katgpu_table katgpu_table;
+
+typedef enum katgpu_status {
+    KATGPU_OK = 0,
+    KATGPU_ERR_INVALID_ARG = 1,
+    KATGPU_ERR_IO = 2,          /* "Could not find input file at: ..."   lib/src/input_handler.cc:119-122 */
+    KATGPU_ERR_FORMAT = 3,      /* "Unsupported format"                  JF/include/jellyfish/mer_overlap_sequence_parser.hpp:184 */
+    KATGPU_ERR_FASTQ = 4,       /* "Invalid fastq sequence"              mer_overlap_sequence_parser.hpp:288 */
+    KATGPU_ERR_NOMEM = 5,       /* device allocation failed */
+    KATGPU_ERR_K = 6,           /* k outside 1..32 (reference: any k, JF/include/jellyfish/mer_dna.hpp:725) */
+    KATGPU_ERR_TABLE_FULL = 7,  /* "Hash full"                           JF/include/jellyfish/hash_counter.hpp:198-199 */
+    KATGPU_ERR_DEVICE = 8,      /* HIP runtime error / no gfx950 device */
+    KATGPU_ERR_MISMATCH = 9     /* tables with different k   lib/src/input_handler.cc:145-158 (validateMerLen) */
+} katgpu_status;
+
+/* ---- context ---------------------------------------------------------------------------------------- */
+/* device: HIP ordinal, or -1 for the current device. */
+int         katgpu_init(int device, katgpu_ctx** ctx);
+void        katgpu_shutdown(katgpu_ctx* ctx);
+const char* katgpu_last_error(const katgpu_ctx* ctx);
+const char* katgpu_version(void);
+/* wait for everything the ctx has queued on its HIP streams */
+int         katgpu_sync(katgpu_ctx* ctx);
+
+/* ---- counting: replaces InputHandler::count (lib/src/input_handler.cc:180-202) and everything below it:
+ *      JellyfishHelper::countSeqFile/countSlice (lib/src/jellyfish_helper.cc:219-246,202-211),
+ *      mer_overlap_sequence_parser (JF/.../mer_overlap_sequence_parser.hpp:132-289), mer_iterator
+ *      (JF/.../mer_iterator.hpp:61-89), hash_counter::add (JF/.../hash_counter.hpp:98-130),
+ *      large_hash::array::add/claim_key/add_val (JF/.../large_hash_array.hpp:298-302,513-601,733-744). ---- */
+
+/* One input group -> one table.  paths: FASTA/FASTQ, plain or gzip, told apart by their first byte.
+ * trim5p: per-file count of leading bases to ignore in every record, or NULL.
+ * size_hint: initial number of table slots (KAT's -H); 0 = size from the input.
+ * disable_grow: KAT's -g; when set a full table is KATGPU_ERR_TABLE_FULL instead of a regrow
+ * (hash_counter::double_size, JF/.../hash_counter.hpp:204-244). */
+int katgpu_count(katgpu_ctx* ctx, const char* const* paths, size_t n_paths, uint32_t k, int canonical,
+                 const uint16_t* trim5p, uint64_t size_hint, int disable_grow, katgpu_table** out);
+
+/* The same in steps (used by the batch/bench drivers and by multi-GPU sharding). */
+int katgpu_table_create(katgpu_ctx* ctx, uint32_t k, int canonical, uint64_t size_hint, int disable_grow,
+                        katgpu_table** out);
+int katgpu_count_files(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p);
+/* A base stream is what the reference's parser hands to mer_iterator: sequence bytes, records separated by any
+ * byte outside ACGTacgt (the reference inserts 'N', mer_overlap_sequence_parser.hpp:202,234).  Every k-window
+ * of every maximal ACGTacgt run is counted once. */
+int katgpu_count_bases_host(katgpu_table* t, const uint8_t* bases, size_t n);
+int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bases, size_t n);
+void katgpu_table_free(katgpu_table* t);
+
+/* distinct k-mers, sum of counts, slots allocated */
+int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t* total, uint64_t* capacity);
+uint32_t katgpu_table_k(const katgpu_table* t);
+int      katgpu_table_canonical(const katgpu_table* t);
+
+/* JellyfishHelper::getCount (lib/src/jellyfish_helper.cc:189-194) for a batch of packed k-mers. */
+int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n, int canonicalise, uint64_t* counts);
+/* All (key,count) pairs in unspecified order (the eager_iterator walk, JF/.../large_hash_iterator.hpp:28-65).
+ * Pass cap = 0 to query *n_out only. */
+int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* counts, size_t cap, size_t* n_out);
+
+/* ---- reducers ---------------------------------------------------------------------------------------- */
+
+/* Histogram::bin + merge (src/histogram.cc:162-199,146-160).  base/ceil from calcBase/calcCeil
+ * (src/histogram.hpp:172-178); nb = ceil + 1 - base. */
+int katgpu_hist(katgpu_table* t, uint64_t base, uint64_t ceil, uint64_t inc, uint64_t* out, size_t nb);
+
+/* Gcp::analyse + merge (src/gcp.cc:158-197,128-138).  out: k rows (GC count 0..k-1; GC == k is dropped exactly as
+ * the reference's k-row matrix drops it, src/gcp.cc:93) x (cvg_bins+1) columns, row-major. */
+int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, uint64_t* out);
+
+/* Comp::compare + merge (src/comp.cc:366-484,248-265) with CompCounters (lib/src/comp_counters.cc:91-140),
+ * two-input form.  canon1/canon2 are the `canonical` flags of the two InputHandlers (quirks kept: pass 1
+ * canonicalises the probe iff canon2, src/comp.cc:401; pass 2 always canonicalises, src/comp.cc:447).
+ * main_mx: d1_bins x d2_bins row-major [scaled count in 1][scaled count in 2].
+ * counters[13]: hash1_total, hash2_total, hash3_total, hash1_distinct, hash2_distinct, hash3_distinct,
+ *   hash1_only_total, hash2_only_total, hash1_only_distinct, hash2_only_distinct,
+ *   shared_hash1_total, shared_hash2_total, shared_distinct  (lib/include/kat/comp_counters.hpp).
+ * spectra: 4 x min(d1_bins,d2_bins): spectrum1, spectrum2, shared_spectrum1, shared_spectrum2. */
+int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int canon2,
+                double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
+                uint64_t* main_mx, uint64_t counters[13], uint64_t* spectra);
+
+/* ---- multi-GPU: owner-partitioned merge of per-GPU partial tables (no reference analogue: KAT is one
+ *      address space; this is the exchange step of BASELINE.json's north_star).  owner(kmer) depends only on the
+ *      canonical form of the k-mer, so both comp inputs and both strands land on the same rank. ---- */
+/* records per destination part */
+int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, uint64_t* sizes);
+/* write (key,count) records grouped by part into caller-provided DEVICE buffers of sum(sizes) entries;
+ * offsets[p] = exclusive prefix sum of sizes */
+int katgpu_table_partition(katgpu_table* t, uint32_t n_parts, const uint64_t* offsets,
+                           uint64_t* dev_keys, uint64_t* dev_counts);
+/* add n (key,count) records held in DEVICE memory into t (exact 64-bit sums) */
+int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_keys, const uint64_t* dev_counts, size_t n);
+int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, const uint64_t* counts, size_t n);
+
+/* ---- measurement ------------------------------------------------------------------------------------- */
+/* HIP-event timing of the kernels this ctx launched, per kernel class, accumulated since the last reset. */
+typedef enum katgpu_kernel {
+    KATGPU_K_COUNT = 0,      /* extract + canonicalise + insert */
+    KATGPU_K_REGROW = 1,
+    KATGPU_K_HIST = 2,
+    KATGPU_K_GCP = 3,
+    KATGPU_K_COMP_PASS1 = 4,
+    KATGPU_K_COMP_PASS2 = 5,
+    KATGPU_K_PARTITION = 6,
+    KATGPU_K_MERGE = 7,
+    KATGPU_K_NCLASSES = 8
+} katgpu_kernel;
+int katgpu_profile_reset(katgpu_ctx* ctx);
+int katgpu_profile_get(katgpu_ctx* ctx, int kernel_class, uint64_t* launches, double* total_ms, uint64_t* units);
+
+/* ---- device buffers + synthetic workload (bench / test support; not part of KAT's surface) ------------- */
+int katgpu_dev_alloc(katgpu_ctx* ctx, size_t bytes, void** dev_ptr);
+int katgpu_dev_free(katgpu_ctx* ctx, void* dev_ptr);
+int katgpu_dev_upload(katgpu_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int katgpu_dev_download(katgpu_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+int katgpu_dev_mem_info(katgpu_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
+/* Counter-based generator (SplitMix64), identical bit-for-bit to kat_amd/synth.py:
+ * genome: n output bytes of uniform ACGT bases -- with contig_len > 0 an 'N' follows every contig_len bases (the
+ * base stream of an assembly FASTA cut into contigs), with contig_len == 0 there are no separators; reads: n_reads records of read_len bases + 'N' separator each
+ * (stride read_len+1), sampled as PE fragments of `frag_len` from the genome with substitution-error
+ * rate err_ppm / 1e6.  first_read = global index of this shard's first read. */
+int katgpu_synth_genome_device(katgpu_ctx* ctx, uint8_t* dev_out, uint64_t n, uint64_t seed, uint64_t contig_len);
+int katgpu_synth_reads_device(katgpu_ctx* ctx, const uint8_t* dev_genome, uint64_t genome_len,
+                              uint8_t* dev_out, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                              uint32_t frag_len, uint32_t err_ppm, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KATGPU_H */

@@ -1,0 +1,9 @@
+"""kat_amd -- MI355X-native engine for the `kat hist` / `kat gcp` / `kat comp` hot path.
+
+csrc/      HIP kernels + C ABI (libkatgpu.so, declared in include/katgpu.h) + the C++ host mirror of KAT's
+           InputHandler / Histogram / Gcp / Comp (csrc/host, built into bin/katgpu)
+binding.py ctypes binding of the C ABI
+synth.py   seeded synthetic genome / read generator (host edition of the device generator)
+dist.py    one-process-per-GPU sharding + owner-partitioned merge over torch.distributed (RCCL)
+"""
+from .binding import Engine, Table, DeviceBuffer, KatGpuError, comp, hist_geometry, load_library, LIB_PATH, EXPORTS  # noqa: F401

@@ -1,0 +1,331 @@
+"""ctypes binding of libkatgpu.so (include/katgpu.h) -- the only way Python reaches the HIP engine.
+
+There is no CPU path here: if the shared library is missing, or no gfx950 device is visible, construction of
+`Engine` raises.  (The CPU oracle lives under oracle/ and is imported by tests and the bench baseline only.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkatgpu.so")
+
+KERNEL_CLASSES = ("count", "regrow", "hist", "gcp", "comp_pass1", "comp_pass2", "partition", "merge")
+
+STATUS = {
+    0: "ok", 1: "invalid argument", 2: "io", 3: "Unsupported format", 4: "Invalid fastq sequence",
+    5: "out of device memory", 6: "k unsupported", 7: "Hash full", 8: "device error", 9: "k mismatch",
+}
+
+# every symbol include/katgpu.h declares (tests check the .so exports all of them)
+EXPORTS = (
+    "katgpu_init", "katgpu_shutdown", "katgpu_last_error", "katgpu_version", "katgpu_sync",
+    "katgpu_count", "katgpu_table_create", "katgpu_count_files", "katgpu_count_bases_host",
+    "katgpu_count_bases_device", "katgpu_table_free", "katgpu_table_stats", "katgpu_table_k",
+    "katgpu_table_canonical", "katgpu_table_get", "katgpu_table_export", "katgpu_hist", "katgpu_gcp",
+    "katgpu_comp", "katgpu_table_partition_sizes", "katgpu_table_partition", "katgpu_table_merge_device",
+    "katgpu_table_merge_host", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
+    "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
+    "katgpu_synth_genome_device", "katgpu_synth_reads_device",
+)
+
+
+class KatGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("katgpu status %d (%s): %s" % (code, STATUS.get(code, "?"), msg))
+        self.code = code
+        self.message = msg
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libkatgpu.so and declare prototypes.  Needs the HIP runtime but not a GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "katgpu has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t
+    pp = C.POINTER(C.c_void_p)
+    cpp = C.POINTER(C.c_char_p)
+    pu64 = C.POINTER(C.c_uint64)
+    L.katgpu_init.argtypes = [C.c_int, pp]
+    L.katgpu_shutdown.argtypes = [vp]
+    L.katgpu_shutdown.restype = None
+    L.katgpu_last_error.argtypes = [vp]
+    L.katgpu_last_error.restype = C.c_char_p
+    L.katgpu_version.restype = C.c_char_p
+    L.katgpu_sync.argtypes = [vp]
+    L.katgpu_count.argtypes = [vp, cpp, sz, u32, C.c_int, C.POINTER(C.c_uint16), u64, C.c_int, pp]
+    L.katgpu_table_create.argtypes = [vp, u32, C.c_int, u64, C.c_int, pp]
+    L.katgpu_count_files.argtypes = [vp, cpp, sz, C.POINTER(C.c_uint16)]
+    L.katgpu_count_bases_host.argtypes = [vp, vp, sz]
+    L.katgpu_count_bases_device.argtypes = [vp, vp, sz]
+    L.katgpu_table_free.argtypes = [vp]
+    L.katgpu_table_free.restype = None
+    L.katgpu_table_stats.argtypes = [vp, pu64, pu64, pu64]
+    L.katgpu_table_k.argtypes = [vp]
+    L.katgpu_table_k.restype = u32
+    L.katgpu_table_canonical.argtypes = [vp]
+    L.katgpu_table_get.argtypes = [vp, vp, sz, C.c_int, vp]
+    L.katgpu_table_export.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
+    L.katgpu_hist.argtypes = [vp, u64, u64, u64, vp, sz]
+    L.katgpu_gcp.argtypes = [vp, C.c_double, u32, vp]
+    L.katgpu_comp.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, u32, u32, vp, vp, vp]
+    L.katgpu_table_partition_sizes.argtypes = [vp, u32, vp]
+    L.katgpu_table_partition.argtypes = [vp, u32, vp, vp, vp]
+    L.katgpu_table_merge_device.argtypes = [vp, vp, vp, sz]
+    L.katgpu_table_merge_host.argtypes = [vp, vp, vp, sz]
+    L.katgpu_profile_reset.argtypes = [vp]
+    L.katgpu_profile_get.argtypes = [vp, C.c_int, pu64, C.POINTER(C.c_double), pu64]
+    L.katgpu_dev_alloc.argtypes = [vp, sz, pp]
+    L.katgpu_dev_free.argtypes = [vp, vp]
+    L.katgpu_dev_upload.argtypes = [vp, vp, vp, sz]
+    L.katgpu_dev_download.argtypes = [vp, vp, vp, sz]
+    L.katgpu_dev_mem_info.argtypes = [vp, pu64, pu64]
+    L.katgpu_synth_genome_device.argtypes = [vp, vp, u64, u64, u64]
+    L.katgpu_synth_reads_device.argtypes = [vp, vp, u64, vp, u64, u64, u32, u32, u32, u64]
+    _lib = L
+    return L
+
+
+def hist_geometry(low, high):
+    """Histogram::calcBase / calcCeil / nb_buckets (KAT src/histogram.hpp:172-178, src/histogram.cc:68-70)."""
+    base = low - 1 if low > 1 else 1
+    ceil_ = high + 1
+    return base, ceil_, ceil_ + 1 - base
+
+
+def _cpaths(paths):
+    return (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths]), len(paths)
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by an Engine."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        engine._chk(engine.L.katgpu_dev_alloc(engine.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        assert offset + a.nbytes <= self.nbytes
+        self.engine._chk(self.engine.L.katgpu_dev_upload(self.engine.h, self.ptr + offset, a.ctypes.data, a.nbytes))
+
+    def download(self, dtype=np.uint8, count=None, offset=0):
+        dt = np.dtype(dtype)
+        n = (self.nbytes - offset) // dt.itemsize if count is None else count
+        out = np.empty(n, dt)
+        self.engine._chk(self.engine.L.katgpu_dev_download(self.engine.h, out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.engine.L.katgpu_dev_free(self.engine.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One katgpu context == one HIP device (one process per GPU)."""
+
+    def __init__(self, device=-1):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.katgpu_init(device, C.byref(h))
+        if rc:
+            raise KatGpuError(rc, "katgpu_init failed: no usable gfx950 device (katgpu has no CPU fallback)")
+        self.h = h.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.katgpu_shutdown(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise KatGpuError(rc, self.L.katgpu_last_error(self.h).decode(errors="replace"))
+
+    def sync(self):
+        self._chk(self.L.katgpu_sync(self.h))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def mem_info(self):
+        f, t = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.katgpu_dev_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    # ---- tables ----
+    def table(self, k, canonical=True, size_hint=0, disable_grow=False):
+        return Table(self, k, canonical, size_hint, disable_grow)
+
+    def count(self, paths, k, canonical=True, trim5p=None, size_hint=0, disable_grow=False):
+        """InputHandler::count for one input group."""
+        arr, n = _cpaths(paths)
+        tr = (C.c_uint16 * n)(*trim5p) if trim5p else None
+        h = C.c_void_p()
+        self._chk(self.L.katgpu_count(self.h, arr, n, k, int(bool(canonical)), tr, size_hint, int(bool(disable_grow)), C.byref(h)))
+        return Table(self, k, canonical, _handle=h.value)
+
+    # ---- profiling ----
+    def profile_reset(self):
+        self._chk(self.L.katgpu_profile_reset(self.h))
+
+    def profile(self):
+        out = {}
+        for i, name in enumerate(KERNEL_CLASSES):
+            n, ms, units = C.c_uint64(), C.c_double(), C.c_uint64()
+            self._chk(self.L.katgpu_profile_get(self.h, i, C.byref(n), C.byref(ms), C.byref(units)))
+            out[name] = {"launches": n.value, "ms": ms.value, "units": units.value}
+        return out
+
+    # ---- synthetic workload on the device ----
+    def synth_genome(self, n_bases, seed, contig_len=0):
+        """n_bases of genome; with contig_len > 0 the assembly base stream ('N' after every contig)."""
+        n_out = n_bases + (n_bases // contig_len if contig_len else 0)
+        buf = self.alloc(n_out)
+        self._chk(self.L.katgpu_synth_genome_device(self.h, buf.ptr, n_out, seed, contig_len))
+        return buf
+
+    def synth_reads(self, genome_buf, genome_len, first_read, n_reads, read_len=150, frag_len=350, err_ppm=2000, seed=1, out=None):
+        nbytes = n_reads * (read_len + 1)
+        buf = out if out is not None else self.alloc(nbytes)
+        assert buf.nbytes >= nbytes
+        self._chk(self.L.katgpu_synth_reads_device(self.h, genome_buf.ptr, genome_len, buf.ptr, first_read, n_reads,
+                                                   read_len, frag_len, err_ppm, seed))
+        return buf
+
+
+class Table:
+    """HBM-resident (k-mer -> count) table: the replacement for InputHandler::hash (a jellyfish LargeHashArray)."""
+
+    def __init__(self, engine, k, canonical=True, size_hint=0, disable_grow=False, _handle=None):
+        self.engine = engine
+        self.k = k
+        self.canonical = bool(canonical)
+        if _handle is None:
+            h = C.c_void_p()
+            engine._chk(engine.L.katgpu_table_create(engine.h, k, int(self.canonical), size_hint, int(bool(disable_grow)), C.byref(h)))
+            _handle = h.value
+        self.h = _handle
+
+    def free(self):
+        if getattr(self, "h", None) and getattr(self.engine, "h", None):
+            self.engine.L.katgpu_table_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    # ---- counting ----
+    def count_files(self, paths, trim5p=None):
+        arr, n = _cpaths(paths)
+        tr = (C.c_uint16 * n)(*trim5p) if trim5p else None
+        self.engine._chk(self.engine.L.katgpu_count_files(self.h, arr, n, tr))
+        return self
+
+    def count_bases(self, bases):
+        """bases: host uint8 array / bytes (copied through pinned staging) or a DeviceBuffer (counted in place)."""
+        if isinstance(bases, DeviceBuffer):
+            return self.count_bases_device(bases.ptr, bases.nbytes)
+        b = np.frombuffer(bases, dtype=np.uint8) if isinstance(bases, (bytes, bytearray)) else np.ascontiguousarray(bases, dtype=np.uint8)
+        self.engine._chk(self.engine.L.katgpu_count_bases_host(self.h, b.ctypes.data, b.size))
+        return self
+
+    def count_bases_device(self, dev_ptr, n):
+        self.engine._chk(self.engine.L.katgpu_count_bases_device(self.h, dev_ptr, n))
+        return self
+
+    # ---- inspection ----
+    def stats(self, want_total=True):
+        d, t, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.engine._chk(self.engine.L.katgpu_table_stats(self.h, C.byref(d), C.byref(t) if want_total else None, C.byref(c)))
+        return {"distinct": d.value, "total": t.value if want_total else None, "capacity": c.value}
+
+    def get(self, keys, canonicalise=False):
+        k = np.ascontiguousarray(keys, np.uint64)
+        out = np.zeros(k.size, np.uint64)
+        self.engine._chk(self.engine.L.katgpu_table_get(self.h, k.ctypes.data, k.size, int(bool(canonicalise)), out.ctypes.data))
+        return out
+
+    def export(self):
+        n = C.c_size_t()
+        self.engine._chk(self.engine.L.katgpu_table_export(self.h, None, None, 0, C.byref(n)))
+        keys = np.zeros(n.value, np.uint64)
+        counts = np.zeros(n.value, np.uint64)
+        if n.value:
+            self.engine._chk(self.engine.L.katgpu_table_export(self.h, keys.ctypes.data, counts.ctypes.data, n.value, C.byref(n)))
+        return keys, counts
+
+    def dump_sorted(self):
+        keys, counts = self.export()
+        order = np.argsort(keys, kind="stable")
+        return keys[order], counts[order]
+
+    # ---- reducers ----
+    def hist(self, low=1, high=10000, inc=1):
+        base, ceil_, nb = hist_geometry(low, high)
+        out = np.zeros(nb, np.uint64)
+        self.engine._chk(self.engine.L.katgpu_hist(self.h, base, ceil_, inc, out.ctypes.data, nb))
+        return out
+
+    def gcp(self, cvg_scale=1.0, cvg_bins=1000):
+        out = np.zeros((self.k, cvg_bins + 1), np.uint64)
+        self.engine._chk(self.engine.L.katgpu_gcp(self.h, cvg_scale, cvg_bins, out.ctypes.data))
+        return out
+
+    # ---- multi-GPU exchange ----
+    def partition_sizes(self, n_parts):
+        out = np.zeros(n_parts, np.uint64)
+        self.engine._chk(self.engine.L.katgpu_table_partition_sizes(self.h, n_parts, out.ctypes.data))
+        return out
+
+    def partition(self, n_parts, offsets, dev_keys_ptr, dev_counts_ptr):
+        off = np.ascontiguousarray(offsets, np.uint64)
+        self.engine._chk(self.engine.L.katgpu_table_partition(self.h, n_parts, off.ctypes.data, dev_keys_ptr, dev_counts_ptr))
+
+    def merge_device(self, dev_keys_ptr, dev_counts_ptr, n):
+        self.engine._chk(self.engine.L.katgpu_table_merge_device(self.h, dev_keys_ptr, dev_counts_ptr, n))
+
+    def merge_host(self, keys, counts):
+        k = np.ascontiguousarray(keys, np.uint64)
+        c = np.ascontiguousarray(counts, np.uint64)
+        assert k.size == c.size
+        self.engine._chk(self.engine.L.katgpu_table_merge_host(self.h, k.ctypes.data, c.ctypes.data, k.size))
+
+
+def comp(t1, t2, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001):
+    """Comp::compare + merge: (main matrix, 13 counters, 4 spectra)."""
+    ss = min(d1_bins, d2_bins)
+    mx = np.zeros((d1_bins, d2_bins), np.uint64)
+    cc = np.zeros(13, np.uint64)
+    sp = np.zeros((4, ss), np.uint64)
+    e = t1.engine
+    e._chk(e.L.katgpu_comp(t1.h, t2.h, int(t1.canonical), int(t2.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
+                           mx.ctypes.data, cc.ctypes.data, sp.ctypes.data))
+    return mx, cc, sp

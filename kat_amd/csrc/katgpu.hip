@@ -1,0 +1,718 @@
+// katgpu.hip -- C ABI of libkatgpu.so (include/katgpu.h): context, HBM-resident table lifecycle, kernel launches.
+// Host-side file ingest lives in kg_ingest.cpp.  gfx950 only; there is no CPU path in this library.
+#include "../../include/katgpu.h"
+#include "kg_ingest.hpp"
+#include "kg_kernels.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace kg;
+
+// ------------------------------------------------------------------ context ---------------------------
+
+struct katgpu_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;        // all kernels
+    hipStream_t copy_stream = nullptr;   // H2D staging
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    uint64_t prof_launches[KATGPU_K_NCLASSES] = {};
+    double prof_ms[KATGPU_K_NCLASSES] = {};
+    uint64_t prof_units[KATGPU_K_NCLASSES] = {};
+    // pending (not yet read back) event pairs: timing is resolved lazily so launches stay asynchronous
+    struct Pending { hipEvent_t a, b; int cls; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    // staging for file ingest: 2 pinned + 2 device buffers, allocated on first use
+    uint8_t* pinned[2] = {nullptr, nullptr};
+    uint8_t* dev_stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_free[2] = {nullptr, nullptr};   // kernel that read dev_stage[i] has finished
+    size_t stage_bytes = 0;
+};
+
+struct katgpu_table {
+    katgpu_ctx* ctx = nullptr;
+    DevTable d{};
+    int disable_grow = 0;
+    uint32_t n_ovf = 0;          // refreshed by refresh_counters()
+    uint64_t distinct = 0;       // idem (slots in use + all-ones key)
+    uint64_t ones = 0;
+    uint8_t carry[64];           // last k-1 bytes of the previous host batch of the current file
+    uint32_t carry_n = 0;
+};
+
+static int fail(katgpu_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return fail((c), _e == hipErrorOutOfMemory ? KATGPU_ERR_NOMEM : KATGPU_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" const char* katgpu_version(void) { return "katgpu 0.1 (gfx950)"; }
+
+extern "C" int katgpu_init(int device, katgpu_ctx** out) {
+    if (!out) return KATGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return KATGPU_ERR_DEVICE;   // no CPU fallback, by design
+    katgpu_ctx* c = new katgpu_ctx();
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return KATGPU_ERR_DEVICE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "katgpu: device %d is %s; this library is built for gfx950 only\n", device, prop.gcnArchName);
+        delete c; return KATGPU_ERR_DEVICE;
+    }
+    c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return KATGPU_ERR_DEVICE; }
+    *out = c;
+    return KATGPU_OK;
+}
+
+static void resolve_pending(katgpu_ctx* c) {
+    for (auto& p : c->pending) {
+        hipEventSynchronize(p.b);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->prof_ms[p.cls] += ms;
+        c->event_pool.push_back(p.a); c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+extern "C" void katgpu_shutdown(katgpu_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream); hipStreamSynchronize(c->copy_stream);
+    resolve_pending(c);
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (c->pinned[i]) hipHostFree(c->pinned[i]);
+        if (c->dev_stage[i]) hipFree(c->dev_stage[i]);
+        if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
+    }
+    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->stream); hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+extern "C" const char* katgpu_last_error(const katgpu_ctx* c) { return c ? c->err.c_str() : "no context"; }
+
+extern "C" int katgpu_sync(katgpu_ctx* c) {
+    if (!c) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KATGPU_OK;
+}
+
+// HIP events around a launch on the ctx stream; elapsed time is collected lazily.
+struct ScopedTimer {
+    katgpu_ctx* c; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(katgpu_ctx* c_, int cls_, uint64_t units) : c(c_), cls(cls_) {
+        auto take = [&]() { hipEvent_t e = nullptr; if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); } else hipEventCreate(&e); return e; };
+        a = take(); b = take();
+        hipEventRecord(a, c->stream);
+        c->prof_launches[cls] += 1; c->prof_units[cls] += units;
+    }
+    ~ScopedTimer() {
+        hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, cls});
+        if (c->pending.size() > 4096) resolve_pending(c);
+    }
+};
+
+extern "C" int katgpu_profile_reset(katgpu_ctx* c) {
+    if (!c) return KATGPU_ERR_INVALID_ARG;
+    resolve_pending(c);
+    memset(c->prof_launches, 0, sizeof c->prof_launches); memset(c->prof_units, 0, sizeof c->prof_units);
+    for (auto& m : c->prof_ms) m = 0;
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_profile_get(katgpu_ctx* c, int cls, uint64_t* launches, double* total_ms, uint64_t* units) {
+    if (!c || cls < 0 || cls >= KATGPU_K_NCLASSES) return KATGPU_ERR_INVALID_ARG;
+    resolve_pending(c);
+    if (launches) *launches = c->prof_launches[cls];
+    if (total_ms) *total_ms = c->prof_ms[cls];
+    if (units) *units = c->prof_units[cls];
+    return KATGPU_OK;
+}
+
+static int grid_for(katgpu_ctx* c, uint64_t items, int block, int per_cu) {
+    uint64_t need = (items + block - 1) / block;
+    uint64_t cap = (uint64_t)c->n_cu * per_cu;            // persistent-style: a few resident blocks per CU, grid-stride the rest
+    return (int)std::max<uint64_t>(1, std::min(need, cap));
+}
+
+// ------------------------------------------------------------------ table lifecycle ------------------
+
+static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out) {
+    DevTable d{};
+    d.cap = cap; d.k = k; d.canonical = canonical ? 1 : 0;
+    HIPCHK(c, hipMalloc(&d.keys, cap * sizeof(uint64_t)));
+    hipError_t e = hipMalloc(&d.counts, cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d.ovf_keys, OVF_CAP * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&d.ovf_hi, OVF_CAP * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&d.ctrs, CTR_WORDS * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        hipFree(d.keys); hipFree(d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
+        return fail(c, KATGPU_ERR_NOMEM, "device allocation of a %llu-slot table failed: %s", (unsigned long long)cap, hipGetErrorString(e));
+    }
+    HIPCHK(c, hipMemsetAsync(d.keys, 0xFF, cap * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(d.counts, 0, cap * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(d.ovf_hi, 0, OVF_CAP * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(d.ctrs, 0, CTR_WORDS * sizeof(uint64_t), c->stream));
+    *out = d;
+    return KATGPU_OK;
+}
+
+static void free_dev_table(DevTable& d) {
+    hipFree(d.keys); hipFree(d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
+    d = DevTable{};
+}
+
+extern "C" int katgpu_table_create(katgpu_ctx* c, uint32_t k, int canonical, uint64_t size_hint, int disable_grow, katgpu_table** out) {
+    if (!c || !out) return KATGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (k < 1 || k > 32) return fail(c, KATGPU_ERR_K, "k = %u unsupported: this build packs a k-mer into one 64-bit word (1 <= k <= 32)", k);
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t cap = std::max<uint64_t>(size_hint ? size_hint : (1u << 20), 1024);
+    katgpu_table* t = new katgpu_table();
+    t->ctx = c; t->disable_grow = disable_grow;
+    int rc = alloc_dev_table(c, k, canonical, cap, &t->d);
+    if (rc) { delete t; return rc; }
+    *out = t;
+    return KATGPU_OK;
+}
+
+extern "C" void katgpu_table_free(katgpu_table* t) {
+    if (!t) return;
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    free_dev_table(t->d);
+    delete t;
+}
+
+extern "C" uint32_t katgpu_table_k(const katgpu_table* t) { return t ? t->d.k : 0; }
+extern "C" int katgpu_table_canonical(const katgpu_table* t) { return t ? (int)t->d.canonical : 0; }
+
+// read the counter block back (one small D2H; synchronises the compute stream)
+static int refresh_counters(katgpu_table* t) {
+    katgpu_ctx* c = t->ctx;
+    uint64_t h[CTR_WORDS];
+    HIPCHK(c, hipMemcpyAsync(h, t->d.ctrs, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t d = 0;
+    for (int i = 0; i < CTR_NSTRIPES; ++i) d += h[CTR_DISTINCT0 + i];
+    t->ones = h[CTR_ONES];
+    t->distinct = d + (t->ones ? 1 : 0);
+    t->n_ovf = (uint32_t)h[CTR_OVF_USED];
+    if (h[CTR_FULL]) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
+    return KATGPU_OK;
+}
+
+// hash_counter::double_size (deps/jellyfish-2.2.0/include/jellyfish/hash_counter.hpp:204-244): allocate a larger array,
+// re-insert every (key,count), swap.  Here one grid-stride kernel instead of a barrier-synchronised thread team.
+static int regrow(katgpu_table* t, uint64_t new_cap) {
+    katgpu_ctx* c = t->ctx;
+    DevTable nd{};
+    int rc = alloc_dev_table(c, t->d.k, t->d.canonical, new_cap, &nd);
+    if (rc) return rc;
+    {
+        ScopedTimer tm(c, KATGPU_K_REGROW, t->d.cap);
+        hipLaunchKernelGGL(k_regrow, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, nd, t->d, t->n_ovf);
+    }
+    HIPCHK(c, hipMemcpyAsync(&nd.ctrs[CTR_ONES], &t->d.ctrs[CTR_ONES], sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_dev_table(t->d);
+    t->d = nd;
+    return refresh_counters(t);
+}
+
+// Make room for up to `incoming` new distinct k-mers (an upper bound: one per window start) at load <= 0.7.
+static int ensure_room(katgpu_table* t, uint64_t incoming) {
+    int rc = refresh_counters(t);
+    if (rc) return rc;
+    const uint64_t need = t->distinct + incoming;
+    if ((double)need <= 0.7 * (double)t->d.cap) return KATGPU_OK;
+    if (t->disable_grow) return fail(t->ctx, KATGPU_ERR_TABLE_FULL, "Hash full");
+    uint64_t new_cap = t->d.cap;
+    while ((double)need > 0.5 * (double)new_cap) new_cap *= 2;
+    return regrow(t, new_cap);
+}
+
+// ------------------------------------------------------------------ counting --------------------------
+
+static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
+    katgpu_ctx* c = t->ctx;
+    if (n < t->d.k) return KATGPU_OK;
+    const uint64_t n_chunks = (n + CHUNK_STARTS - 1) / CHUNK_STARTS;
+    const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * 8);
+    ScopedTimer tm(c, KATGPU_K_COUNT, n);
+    if ((reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0)
+        hipLaunchKernelGGL(k_count<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
+    else
+        hipLaunchKernelGGL(k_count<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
+    HIPCHK(c, hipGetLastError());
+    return KATGPU_OK;
+}
+
+// Count a resident base stream.  The stream is cut into sub-batches so that "distinct + sub-batch starts" stays under
+// the load limit (the table can then never fill in the middle of a launch); consecutive sub-batches overlap by k-1.
+extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
+    if (!t || (!dev_bases && n)) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t k = t->d.k;
+    if (n < k) return KATGPU_OK;
+    size_t pos = 0;
+    const size_t n_starts = n - k + 1;
+    while (pos < n_starts) {
+        int rc = refresh_counters(t);
+        if (rc) return rc;
+        // largest batch that provably fits; if even a minimal one does not, grow first
+        uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
+        uint64_t want = std::min<uint64_t>(n_starts - pos, (uint64_t)CHUNK_STARTS * 65536);   // <= 266 M starts per launch
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, CHUNK_STARTS))) {
+            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, CHUNK_STARTS)));
+            if (rc) return rc;
+            continue;
+        }
+        uint64_t starts = std::min(want, room);
+        if (starts < n_starts - pos) starts -= starts % 16;            // keep the next sub-batch 16-byte aligned
+        if (starts == 0) starts = std::min<uint64_t>(16, n_starts - pos);
+        rc = launch_count(t, dev_bases + pos, (size_t)(starts + k - 1));
+        if (rc) return rc;
+        pos += starts;
+    }
+    return refresh_counters(t);
+}
+
+static int ensure_staging(katgpu_ctx* c) {
+    if (c->stage_bytes) return KATGPU_OK;
+    const size_t bytes = (size_t)64 << 20;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(c, hipHostMalloc((void**)&c->pinned[i], bytes, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&c->dev_stage[i], bytes));
+        HIPCHK(c, hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming));
+    }
+    c->stage_bytes = bytes;
+    return KATGPU_OK;
+}
+
+// Host base stream -> device, double buffered: while the kernel of batch i runs, batch i+1 is copied.
+// Each staged batch starts with the previous batch's last k-1 bytes so windows across the cut are counted once.
+struct HostFeeder {
+    katgpu_table* t; katgpu_ctx* c; int cur = 0; size_t fill = 0; bool used[2] = {false, false};
+    static constexpr size_t HEAD = 32;        // carry area: keeps the payload 16-byte aligned
+    explicit HostFeeder(katgpu_table* t_) : t(t_), c(t_->ctx) {}
+    int begin() {
+        int rc = ensure_staging(c); if (rc) return rc;
+        return open_buffer();
+    }
+    int open_buffer() {
+        if (used[cur]) { hipError_t e = hipEventSynchronize(c->stage_free[cur]); if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e)); }
+        memset(c->pinned[cur], 'N', HEAD);
+        memcpy(c->pinned[cur] + HEAD - t->carry_n, t->carry, t->carry_n);
+        fill = HEAD;
+        return KATGPU_OK;
+    }
+    int push(const uint8_t* p, size_t n) {
+        while (n) {
+            size_t room = c->stage_bytes - fill, take = std::min(room, n);
+            memcpy(c->pinned[cur] + fill, p, take);
+            fill += take; p += take; n -= take;
+            if (fill == c->stage_bytes) { int rc = flush(); if (rc) return rc; }
+        }
+        return KATGPU_OK;
+    }
+    int flush() {
+        if (fill <= HEAD) return KATGPU_OK;
+        const uint32_t k = t->d.k;
+        const size_t payload = fill - HEAD;
+        // remember the tail for the next batch
+        uint8_t tail[64]; uint32_t tn = (uint32_t)std::min<size_t>(k - 1, payload + t->carry_n);
+        memcpy(tail, c->pinned[cur] + fill - tn, tn);
+        int rc = ensure_room(t, fill);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dev_stage[cur], c->pinned[cur], fill, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ev0, c->copy_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev0, 0));
+        rc = launch_count(t, c->dev_stage[cur], fill);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->stage_free[cur], c->stream));
+        used[cur] = true;
+        memcpy(t->carry, tail, tn); t->carry_n = tn;
+        cur ^= 1;
+        return open_buffer();
+    }
+    int end_of_file() {             // files of a group never join (mer_overlap_sequence_parser.hpp:151-155: have_seam = false)
+        static const uint8_t sep = 'N';
+        return push(&sep, 1);
+    }
+    int finish() {
+        int rc = flush(); if (rc) return rc;
+        t->carry_n = 0;
+        return refresh_counters(t);
+    }
+};
+
+extern "C" int katgpu_count_bases_host(katgpu_table* t, const uint8_t* bases, size_t n) {
+    if (!t || (!bases && n)) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(t->ctx, hipSetDevice(t->ctx->device));
+    t->carry_n = 0;
+    HostFeeder f(t);
+    int rc = f.begin(); if (rc) return rc;
+    rc = f.push(bases, n); if (rc) return rc;
+    return f.finish();
+}
+
+extern "C" int katgpu_count_files(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p) {
+    if (!t || !paths) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    t->carry_n = 0;
+    HostFeeder f(t);
+    int rc = f.begin(); if (rc) return rc;
+    for (size_t i = 0; i < n_paths; ++i) {
+        kg::SeqFileParser parser;
+        std::string err;
+        int prc = parser.open(paths[i], trim5p ? trim5p[i] : 0, &err);
+        if (prc) return fail(c, prc, "%s", err.c_str());
+        for (;;) {
+            const uint8_t* p; size_t n;
+            prc = parser.next(&p, &n, &err);
+            if (prc) return fail(c, prc, "%s", err.c_str());
+            if (!n) break;
+            rc = f.push(p, n); if (rc) return rc;
+        }
+        rc = f.end_of_file(); if (rc) return rc;
+    }
+    return f.finish();
+}
+
+extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_paths, uint32_t k, int canonical,
+                            const uint16_t* trim5p, uint64_t size_hint, int disable_grow, katgpu_table** out) {
+    if (!c || !out || !paths) return KATGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (size_hint == 0) {        // every input byte starts at most one new k-mer
+        uint64_t bytes = 0;
+        for (size_t i = 0; i < n_paths; ++i) bytes += kg::file_size_or_zero(paths[i]);
+        size_hint = std::max<uint64_t>(1u << 20, bytes);
+    }
+    katgpu_table* t = nullptr;
+    int rc = katgpu_table_create(c, k, canonical, size_hint, disable_grow, &t);
+    if (rc) return rc;
+    rc = katgpu_count_files(t, paths, n_paths, trim5p);
+    if (rc) { katgpu_table_free(t); return rc; }
+    *out = t;
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t* total, uint64_t* capacity) {
+    if (!t) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    if (distinct) *distinct = t->distinct;
+    if (capacity) *capacity = t->d.cap;
+    if (total) {
+        uint64_t* scratch = &t->d.ctrs[CTR_SCRATCH];
+        HIPCHK(c, hipMemsetAsync(scratch, 0, sizeof(uint64_t), c->stream));
+        hipLaunchKernelGGL(k_total, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, scratch);
+        uint64_t s = 0;
+        HIPCHK(c, hipMemcpyAsync(&s, scratch, sizeof s, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *total = s + t->ones;
+    }
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n, int canonicalise, uint64_t* counts) {
+    if (!t || (n && (!keys || !counts))) return KATGPU_ERR_INVALID_ARG;
+    if (!n) return KATGPU_OK;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    uint64_t *dk = nullptr, *dc = nullptr;
+    HIPCHK(c, hipMalloc(&dk, n * 8));
+    if (hipMalloc(&dc, n * 8) != hipSuccess) { hipFree(dk); return fail(c, KATGPU_ERR_NOMEM, "lookup buffers"); }
+    hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, c->stream);
+    hipLaunchKernelGGL(k_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, t->d, t->n_ovf, dk, (uint64_t)n, canonicalise, dc);
+    hipMemcpyAsync(counts, dc, n * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(dk); hipFree(dc);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
+// ------------------------------------------------------------------ partition / export / merge -------
+
+extern "C" int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, uint64_t* sizes) {
+    if (!t || !sizes || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n_parts * 8));
+    hipMemsetAsync(d, 0, n_parts * 8, c->stream);
+    {
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
+        hipLaunchKernelGGL(k_partition<0>, dim3(grid_for(c, t->d.cap + 1, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, (uint64_t*)nullptr, (uint64_t*)nullptr);
+    }
+    hipMemcpyAsync(sizes, d, n_parts * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_partition(katgpu_table* t, uint32_t n_parts, const uint64_t* offsets, uint64_t* dev_keys, uint64_t* dev_counts) {
+    if (!t || !offsets || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n_parts * 8));
+    hipMemcpyAsync(d, offsets, n_parts * 8, hipMemcpyHostToDevice, c->stream);
+    {
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
+        hipLaunchKernelGGL(k_partition<1>, dim3(grid_for(c, t->d.cap + 1, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, dev_keys, dev_counts);
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* counts, size_t cap, size_t* n_out) {
+    if (!t || !n_out) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    *n_out = (size_t)t->distinct;
+    if (cap == 0) return KATGPU_OK;
+    if (cap < t->distinct || !keys || !counts) return fail(c, KATGPU_ERR_INVALID_ARG, "export buffer too small: %zu < %llu", cap, (unsigned long long)t->distinct);
+    if (!t->distinct) return KATGPU_OK;
+    uint64_t *dk = nullptr, *dc = nullptr;
+    HIPCHK(c, hipMalloc(&dk, t->distinct * 8));
+    if (hipMalloc(&dc, t->distinct * 8) != hipSuccess) { hipFree(dk); return fail(c, KATGPU_ERR_NOMEM, "export buffers"); }
+    uint64_t zero = 0;
+    rc = katgpu_table_partition(t, 1, &zero, dk, dc);
+    if (!rc) {
+        hipMemcpy(keys, dk, t->distinct * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(counts, dc, t->distinct * 8, hipMemcpyDeviceToHost);
+    }
+    hipFree(dk); hipFree(dc);
+    return rc;
+}
+
+extern "C" int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_keys, const uint64_t* dev_counts, size_t n) {
+    if (!t || (n && (!dev_keys || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t pos = 0;
+    while (pos < n) {
+        int rc = refresh_counters(t); if (rc) return rc;
+        uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
+        uint64_t want = n - pos;
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
+            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
+            if (rc) return rc;
+            continue;
+        }
+        uint64_t take = std::min(want, room);
+        {
+            ScopedTimer tm(c, KATGPU_K_MERGE, take);
+            hipLaunchKernelGGL(k_merge, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->d, dev_keys + pos, dev_counts + pos, take);
+        }
+        pos += take;
+    }
+    return refresh_counters(t);
+}
+
+extern "C" int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, const uint64_t* counts, size_t n) {
+    if (!t || (n && (!keys || !counts))) return KATGPU_ERR_INVALID_ARG;
+    if (!n) return KATGPU_OK;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t *dk = nullptr, *dc = nullptr;
+    HIPCHK(c, hipMalloc(&dk, n * 8));
+    if (hipMalloc(&dc, n * 8) != hipSuccess) { hipFree(dk); return fail(c, KATGPU_ERR_NOMEM, "merge buffers"); }
+    hipMemcpy(dk, keys, n * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dc, counts, n * 8, hipMemcpyHostToDevice);
+    int rc = katgpu_table_merge_device(t, dk, dc, n);
+    hipFree(dk); hipFree(dc);
+    return rc;
+}
+
+// ------------------------------------------------------------------ reducers --------------------------
+
+static int reducer_grid(katgpu_ctx* c, uint64_t slots, int blocks_per_cu) { return grid_for(c, slots, 256, blocks_per_cu); }
+
+extern "C" int katgpu_hist(katgpu_table* t, uint64_t base, uint64_t ceil_, uint64_t inc, uint64_t* out, size_t nb) {
+    if (!t || !out || nb == 0 || inc == 0 || ceil_ < base || nb != ceil_ + 1 - base) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, nb * 8));
+    hipMemsetAsync(d, 0, nb * 8, c->stream);
+    const uint32_t lds_bins = (uint32_t)std::min<uint64_t>(nb, 16384);          // 64 KB of u32 -> two blocks per CU
+    {
+        ScopedTimer tm(c, KATGPU_K_HIST, t->d.cap);
+        hipLaunchKernelGGL(k_hist, dim3(reducer_grid(c, t->d.cap, 2)), dim3(256), lds_bins * sizeof(uint32_t), c->stream,
+                           t->d, t->n_ovf, base, ceil_, inc, (uint64_t)nb, d, lds_bins);
+    }
+    hipMemcpyAsync(out, d, nb * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, uint64_t* out) {
+    if (!t || !out) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    const size_t cells = (size_t)t->d.k * ((size_t)cvg_bins + 1);
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, cells * 8));
+    hipMemsetAsync(d, 0, cells * 8, c->stream);
+    const size_t lds = cells * sizeof(uint32_t);
+    const uint32_t use_lds = lds <= 150 * 1024 ? 1 : 0;                         // 160 KB LDS per CU
+    if (use_lds && lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_gcp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        ScopedTimer tm(c, KATGPU_K_GCP, t->d.cap);
+        hipLaunchKernelGGL(k_gcp, dim3(reducer_grid(c, t->d.cap, use_lds ? 1 : 8)), dim3(256), use_lds ? lds : 0, c->stream,
+                           t->d, t->n_ovf, cvg_scale, cvg_bins, d, use_lds);
+    }
+    HIPCHK(c, hipGetLastError());
+    hipMemcpyAsync(out, d, cells * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int canon2, double d1_scale, double d2_scale,
+                           uint32_t d1_bins, uint32_t d2_bins, uint64_t* main_mx, uint64_t counters[13], uint64_t* spectra) {
+    (void)canon1;
+    if (!t1 || !t2 || !main_mx || !counters || !spectra || d1_bins == 0 || d2_bins == 0) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t1->ctx;
+    if (t1->ctx != t2->ctx) return fail(c, KATGPU_ERR_INVALID_ARG, "tables belong to different contexts");
+    if (t1->d.k != t2->d.k)
+        return fail(c, KATGPU_ERR_MISMATCH, "Cannot process hashes that were created with different K-mer lengths.  Expected: %u.  Key length was %u", t1->d.k, t2->d.k);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t1); if (rc) return rc;
+    rc = refresh_counters(t2); if (rc) return rc;
+    const uint32_t ss = std::min(d1_bins, d2_bins);
+    const size_t mx_cells = (size_t)d1_bins * d2_bins, total = mx_cells + 13 + 4 * (size_t)ss;
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, total * 8));
+    hipMemsetAsync(d, 0, total * 8, c->stream);
+    CompArgs a{};
+    a.d1_scale = d1_scale; a.d2_scale = d2_scale; a.d1_bins = d1_bins; a.d2_bins = d2_bins; a.spec_size = ss;
+    a.canon_probe = canon2 ? 1 : 0;
+    a.main_mx = d; a.counters = d + mx_cells; a.spectra = d + mx_cells + 13;
+    const size_t lds1 = 16 * 8 + COMP_TILE * COMP_TILE * 4 + 3 * (size_t)ss * 4, lds2 = 16 * 8 + COMP_TILE * COMP_TILE * 4 + (size_t)ss * 4;
+    if (lds1 > 150 * 1024) { hipFree(d); return fail(c, KATGPU_ERR_INVALID_ARG, "min(d1_bins,d2_bins) = %u too large for the LDS-privatised spectra", ss); }
+    if (lds1 > 64 * 1024) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    }
+    {
+        ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap);
+        hipLaunchKernelGGL(k_comp<1>, dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
+    }
+    {
+        ScopedTimer tm(c, KATGPU_K_COMP_PASS2, t2->d.cap);
+        hipLaunchKernelGGL(k_comp<2>, dim3(reducer_grid(c, t2->d.cap + 1, 4)), dim3(256), lds2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    hipMemcpyAsync(main_mx, d, mx_cells * 8, hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(counters, d + mx_cells, 13 * 8, hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(spectra, d + mx_cells + 13, 4 * (size_t)ss * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
+// ------------------------------------------------------------------ device buffers + synthetic workload
+
+extern "C" int katgpu_dev_alloc(katgpu_ctx* c, size_t bytes, void** p) {
+    if (!c || !p) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(p, bytes ? bytes : 16));
+    return KATGPU_OK;
+}
+extern "C" int katgpu_dev_free(katgpu_ctx* c, void* p) {
+    if (!c) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(p));
+    return KATGPU_OK;
+}
+extern "C" int katgpu_dev_upload(katgpu_ctx* c, void* dst, const void* src, size_t n) {
+    if (!c) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KATGPU_OK;
+}
+extern "C" int katgpu_dev_download(katgpu_ctx* c, void* dst, const void* src, size_t n) {
+    if (!c) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KATGPU_OK;
+}
+extern "C" int katgpu_dev_mem_info(katgpu_ctx* c, uint64_t* free_b, uint64_t* total_b) {
+    if (!c) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(c, hipMemGetInfo(&f, &t));
+    if (free_b) *free_b = f;
+    if (total_b) *total_b = t;
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_synth_genome_device(katgpu_ctx* c, uint8_t* dev_out, uint64_t n, uint64_t seed, uint64_t contig_len) {
+    if (!c || !dev_out) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_synth_genome, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, dev_out, n, seed, contig_len);
+    HIPCHK(c, hipGetLastError());
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_synth_reads_device(katgpu_ctx* c, const uint8_t* dev_genome, uint64_t genome_len, uint8_t* dev_out,
+                                         uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint32_t frag_len,
+                                         uint32_t err_ppm, uint64_t seed) {
+    if (!c || !dev_genome || !dev_out || read_len == 0 || read_len > 1023 || frag_len < read_len || genome_len < frag_len)
+        return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t thresh = (uint32_t)(((uint64_t)err_ppm << 32) / 1000000ULL);
+    hipLaunchKernelGGL(k_synth_reads, dim3(grid_for(c, n_reads * (read_len + 1ULL), 256, 8)), dim3(256), 0, c->stream,
+                       dev_genome, genome_len, dev_out, first_read, n_reads, read_len, frag_len, thresh, seed);
+    HIPCHK(c, hipGetLastError());
+    return KATGPU_OK;
+}

@@ -1,0 +1,166 @@
+// kg_device.hpp -- device-side building blocks for gfx950: packed k-mer arithmetic and the HBM-resident
+// open-addressed count table.  CDNA4 only (wave64); no portability layer.
+//
+// Table layout ("KV12"): keys[cap] (u64, 0xFFFF..F = empty) and counts[cap] (u32) as two separate
+// arrays so that the slot scan of the reducers is two perfectly coalesced streams (8 B and 4 B per lane).
+// Counts are exact to 64 bits: a 32-bit carry is chained into a small side table, the same idea as
+// Jellyfish's "large" entries (deps/jellyfish-2.2.0/include/jellyfish/large_hash_array.hpp:668-700), and
+// the one key that collides with the empty marker (k = 32, all T, non-canonical) lives in a scalar.
+// The layout is free to differ from Jellyfish's bit-packed array because hist/gcp/comp are
+// order-independent sums over the multiset {(k-mer, count)}.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kg {
+
+constexpr uint64_t EMPTY = ~0ULL;
+constexpr uint32_t OVF_CAP = 4096;       // side table for 2^32 carries; a key needs > 4.29e9 hits to enter
+constexpr uint32_t MAX_PROBE = 1u << 14; // linear probes before the table is declared full
+
+// ctrs[] layout (u64 each)
+constexpr int CTR_DISTINCT0 = 0;   // 64 stripes, summed on the host
+constexpr int CTR_NSTRIPES = 64;
+constexpr int CTR_ONES = 64;       // count of the all-ones key
+constexpr int CTR_OVF_USED = 65;   // entries in the carry table
+constexpr int CTR_FULL = 66;       // != 0: an insert ran out of probes / carry table full
+constexpr int CTR_SCRATCH = 67;    // cursors / scratch for export & partition (8 words)
+constexpr int CTR_WORDS = 80;
+
+struct DevTable {
+    uint64_t* keys;
+    uint32_t* counts;
+    uint64_t cap;
+    uint64_t* ovf_keys;   // OVF_CAP
+    uint64_t* ovf_hi;     // OVF_CAP, units of 2^32
+    uint64_t* ctrs;       // CTR_WORDS
+    uint32_t k;
+    uint32_t canonical;
+};
+
+// ---- packed k-mer arithmetic (first base in the MSBs, A=0 C=1 G=2 T=3) ----
+
+__device__ __forceinline__ uint64_t kmer_mask(uint32_t k) { return k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1); }
+
+// reverse complement of a 2k-bit packed k-mer: bit-reverse the word (v_bfrev), swap the two bits of every
+// base back, complement, align down.  Same function as word_reverse_complement (mer_dna.hpp:100-108).
+__device__ __forceinline__ uint64_t kmer_revcomp(uint64_t x, uint32_t k) {
+    uint64_t r = __brevll(x);
+    r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+    r = ~r;
+    return r >> (64 - 2 * k);
+}
+
+__device__ __forceinline__ uint64_t kmer_canonical(uint64_t x, uint32_t k) {
+    uint64_t rc = kmer_revcomp(x, k);
+    return rc < x ? rc : x;
+}
+
+// #G + #C (str_utils.hpp:151-161 on the packed form): C = 01, G = 10 -> the two bits differ
+__device__ __forceinline__ uint32_t kmer_gc(uint64_t x, uint32_t k) {
+    return __popcll((x ^ (x >> 1)) & 0x5555555555555555ULL & kmer_mask(k));
+}
+
+// ---- hashing ----
+__device__ __host__ __forceinline__ uint64_t mix64(uint64_t x) {   // murmur3 finaliser: bijective, avalanching
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ uint64_t slot_of(uint64_t key, uint64_t cap) { return __umul64hi(mix64(key), cap); }
+// owner part of a k-mer for the multi-GPU merge: a second, independent mix of the CANONICAL form
+__device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t k, uint32_t n_parts) {
+    uint64_t c = kmer_canonical(key, k);
+    return (uint32_t)__umul64hi(mix64(c ^ 0x9E3779B97F4A7C15ULL), (uint64_t)n_parts);
+}
+
+// ---- carry side table ----
+__device__ inline void ovf_add(const DevTable& t, uint64_t key, uint64_t hi) {
+    uint32_t p = (uint32_t)(mix64(key) >> 40) & (OVF_CAP - 1);
+    for (uint32_t i = 0; i < OVF_CAP; ++i) {
+        uint64_t cur = atomicCAS((unsigned long long*)&t.ovf_keys[p], (unsigned long long)EMPTY, (unsigned long long)key);
+        if (cur == EMPTY) atomicAdd((unsigned long long*)&t.ctrs[CTR_OVF_USED], 1ULL);
+        if (cur == EMPTY || cur == key) { atomicAdd((unsigned long long*)&t.ovf_hi[p], (unsigned long long)hi); return; }
+        p = (p + 1) & (OVF_CAP - 1);
+    }
+    atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 2ULL);
+}
+__device__ inline uint64_t ovf_get(const DevTable& t, uint64_t key) {
+    uint32_t p = (uint32_t)(mix64(key) >> 40) & (OVF_CAP - 1);
+    for (uint32_t i = 0; i < OVF_CAP; ++i) {
+        uint64_t cur = t.ovf_keys[p];
+        if (cur == key) return t.ovf_hi[p];
+        if (cur == EMPTY) return 0;
+        p = (p + 1) & (OVF_CAP - 1);
+    }
+    return 0;
+}
+
+// full 64-bit count of an occupied slot
+__device__ __forceinline__ uint64_t slot_count(const DevTable& t, uint64_t pos, uint64_t key, uint32_t n_ovf) {
+    uint64_t c = t.counts[pos];
+    if (n_ovf) c += ovf_get(t, key) << 32;
+    return c;
+}
+
+// ---- insert-or-add: the replacement for array_base::add (large_hash_array.hpp:298-302) ----
+// Claim = CAS on the key word; add = returning 32-bit atomic add whose carry is chained.  The first look at a
+// slot is a plain load: keys are write-once, so a stale "empty" only costs the CAS we would have issued anyway.
+// new_distinct is accumulated per lane and flushed once per wave (one striped atomic instead of one per claim).
+__device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint64_t amount, uint32_t& new_distinct) {
+    if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)amount); return true; }
+    uint64_t pos = slot_of(key, t.cap);
+    for (uint32_t probe = 0; probe < MAX_PROBE; ++probe) {
+        uint64_t cur = t.keys[pos];
+        if (cur == EMPTY) {
+            cur = atomicCAS((unsigned long long*)&t.keys[pos], (unsigned long long)EMPTY, (unsigned long long)key);
+            if (cur == EMPTY) { ++new_distinct; cur = key; }
+        }
+        if (cur == key) {
+            uint32_t low = (uint32_t)amount;
+            uint64_t hi = amount >> 32;
+            uint32_t old = atomicAdd(&t.counts[pos], low);
+            if ((uint64_t)old + low > 0xFFFFFFFFULL) ++hi;
+            if (hi) ovf_add(t, key, hi);
+            return true;
+        }
+        if (++pos == t.cap) pos = 0;
+    }
+    atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 1ULL);
+    return false;
+}
+
+// ---- lookup: get_val_for_key (large_hash_array.hpp:358-376) on an immutable table ----
+__device__ __forceinline__ uint64_t table_get(const DevTable& t, uint64_t key, uint32_t n_ovf) {
+    if (key == EMPTY) return t.ctrs[CTR_ONES];
+    uint64_t pos = slot_of(key, t.cap);
+    for (uint64_t probe = 0; probe < t.cap; ++probe) {
+        uint64_t cur = t.keys[pos];
+        if (cur == key) return slot_count(t, pos, key, n_ovf);
+        if (cur == EMPTY) return 0;
+        if (++pos == t.cap) pos = 0;
+    }
+    return 0;
+}
+
+// flush a per-lane "new distinct" tally: wave reduction, lane 0 adds into one of 64 stripes
+__device__ __forceinline__ void flush_distinct(const DevTable& t, uint32_t new_distinct) {
+    uint32_t v = new_distinct;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) {
+        uint32_t stripe = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (CTR_NSTRIPES - 1);
+        atomicAdd((unsigned long long*)&t.ctrs[CTR_DISTINCT0 + stripe], (unsigned long long)v);
+    }
+}
+
+// ---- counter-based RNG shared with kat_amd/synth.py ----
+__device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __host__ __forceinline__ uint64_t rng2(uint64_t seed, uint64_t idx) {
+    return splitmix64(splitmix64(seed) ^ (idx * 0xD1342543DE82EF95ULL));
+}
+
+}  // namespace kg

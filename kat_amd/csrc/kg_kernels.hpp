@@ -1,0 +1,415 @@
+// kg_kernels.hpp -- the HIP kernels of the kat hist/gcp/comp hot path, written for gfx950 (CDNA4, wave64).
+//
+//  K1 k_count          extract + canonicalise + 2-bit pack + hash + insert      (replaces mer_iterator + hash_counter::add)
+//  K2 k_regrow         re-insert a table into a larger one                       (replaces hash_counter::double_size)
+//  K3 k_hist           slot scan -> histogram                                    (replaces Histogram::binSlice)
+//  K4 k_gcp            slot scan -> GC x coverage matrix                         (replaces Gcp::analyseSlice)
+//  K5 k_comp_pass1/2   slot scan + probe of the other table -> matrix, counters  (replaces Comp::compareSlice)
+//  K6 k_part_*         owner-partitioned export for the multi-GPU merge
+//  K7 k_merge          add (key,count) records into a table
+//
+// All of this is integer / byte work bound by HBM (random 8-16 B slot accesses for K1/K5, streaming for K3/K4);
+// none of it is a contraction, so no MFMA anywhere.
+#pragma once
+#include "kg_device.hpp"
+
+namespace kg {
+
+constexpr int COUNT_BLOCK = 256;                 // 4 waves
+constexpr int BASES_PER_LANE = 16;               // one 16-byte global load per lane
+constexpr int CHUNK_BYTES = COUNT_BLOCK * BASES_PER_LANE;        // 4096 bytes staged per block iteration
+constexpr int CHUNK_OVERLAP = 32;                // >= k-1 for k <= 32, keeps chunk starts 16-byte aligned
+constexpr int CHUNK_STARTS = CHUNK_BYTES - CHUNK_OVERLAP;        // 4064 window start positions per chunk
+constexpr int LANES_WITH_STARTS = CHUNK_STARTS / BASES_PER_LANE; // 254
+
+// 16 ASCII bytes -> 16 two-bit codes (MSB-first in a u32) + 16 "not ACGTacgt" flags (MSB-first in the low 16 bits).
+// code = x ^ (x >> 1) with x = (c >> 1) & 3 maps A,C,G,T (either case) to 0,1,2,3 (mer_dna.hpp:46-63).
+__device__ __forceinline__ void encode16(const uint32_t w[4], uint32_t& code, uint32_t& bad) {
+    code = 0; bad = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint32_t c = (w[q] >> (8 * b)) & 0xFF;
+            uint32_t u = c & 0xDF;                                   // fold case
+            uint32_t ok = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+            uint32_t x = (c >> 1) & 3;
+            code = (code << 2) | (x ^ (x >> 1));
+            bad = (bad << 1) | (ok ^ 1);
+        }
+    }
+}
+
+// K1.  One block iteration stages 4096 consecutive bytes of the base stream: each lane issues one coalesced 16-byte
+// load (1 KiB per wave instruction), packs it to 32 code bits + 16 validity bits and parks both in LDS.  After the
+// barrier lane t owns the 16 window starts [16t, 16t+16): it pulls three consecutive code words (48 bases) from
+// LDS into a 96-bit register window and slides it 16 times -- no per-base loop, no re-reading of HBM.  The
+// reverse complement is recomputed per window with v_bfrev (6 VALU ops) rather than rolled.
+template <bool ALIGNED>
+__global__ void __launch_bounds__(COUNT_BLOCK)
+k_count(DevTable t, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_chunks) {
+    __shared__ uint32_t s_code[COUNT_BLOCK + 2];
+    __shared__ uint32_t s_bad[COUNT_BLOCK + 2];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = t.k;
+    const bool canonical = t.canonical != 0;
+    uint32_t new_distinct = 0;
+    if (tid < 2) { s_code[COUNT_BLOCK + tid] = 0; s_bad[COUNT_BLOCK + tid] = 0xFFFF; }
+
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint64_t off = chunk * CHUNK_STARTS + (uint64_t)tid * BASES_PER_LANE;
+        uint32_t w[4];
+        if (ALIGNED && off + BASES_PER_LANE <= n) {
+            const uint4 v = *reinterpret_cast<const uint4*>(bases + off);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    uint64_t i = off + q * 4 + b;
+                    uint32_t c = i < n ? bases[i] : (uint32_t)'N';       // past the end == separator
+                    x |= c << (8 * b);
+                }
+                w[q] = x;
+            }
+        }
+        uint32_t code, bad;
+        encode16(w, code, bad);
+        s_code[tid] = code;
+        s_bad[tid] = bad;
+        __syncthreads();
+
+        if (tid < LANES_WITH_STARTS) {
+            uint64_t hi = ((uint64_t)s_code[tid] << 32) | s_code[tid + 1];   // bases 16t .. 16t+31
+            uint64_t lo = (uint64_t)s_code[tid + 2] << 32;                   // bases 16t+32 .. 16t+47
+            uint64_t m = ((uint64_t)s_bad[tid] << 48) | ((uint64_t)s_bad[tid + 1] << 32) | ((uint64_t)s_bad[tid + 2] << 16);
+            const uint32_t kshift = 64 - 2 * k, mshift = 64 - k;
+#pragma unroll 4
+            for (int j = 0; j < BASES_PER_LANE; ++j) {
+                if ((m >> mshift) == 0) {                                    // k valid bases from this start
+                    uint64_t fwd = hi >> kshift;
+                    uint64_t key = fwd;
+                    if (canonical) { uint64_t rc = kmer_revcomp(fwd, k); key = rc < fwd ? rc : fwd; }
+                    table_add(t, key, 1, new_distinct);
+                }
+                hi = (hi << 2) | (lo >> 62);
+                lo <<= 2;
+                m <<= 1;
+            }
+        }
+        __syncthreads();
+    }
+    flush_distinct(t, new_distinct);
+}
+
+// K2 / K7: add (key,count) records into a table.  src == another table's slots (regrow) or a record list (merge).
+__global__ void __launch_bounds__(256)
+k_regrow(DevTable dst, DevTable src, uint32_t src_n_ovf) {
+    uint32_t new_distinct = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < src.cap; i += stride) {
+        uint64_t key = src.keys[i];
+        if (key != EMPTY) table_add(dst, key, slot_count(src, i, key, src_n_ovf), new_distinct);
+    }
+    flush_distinct(dst, new_distinct);
+}
+
+__global__ void __launch_bounds__(256)
+k_merge(DevTable dst, const uint64_t* __restrict__ keys, const uint64_t* __restrict__ counts, uint64_t n) {
+    uint32_t new_distinct = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (counts[i]) table_add(dst, keys[i], counts[i], new_distinct);
+    flush_distinct(dst, new_distinct);
+}
+
+// Σ counts (table_stats "total")
+__global__ void __launch_bounds__(256)
+k_total(DevTable t, uint32_t n_ovf, uint64_t* out) {
+    uint64_t s = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.cap; i += stride) {
+        uint64_t key = t.keys[i];
+        if (key != EMPTY) s += slot_count(t, i, key, n_ovf);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long*)out, (unsigned long long)s);
+}
+
+// LDS-privatised increment with wave-level aggregation: lanes that hit the same bin as the wave's first active
+// lane are folded into one LDS atomic (ballot + popcount); the rest fall through to their own atomic.  K-mer
+// spectra are dominated by a handful of bins (singletons!), so this removes most same-address serialisation.
+__device__ __forceinline__ void lds_inc_aggregated(uint32_t* bins, uint32_t idx, bool active) {
+    unsigned long long live = __ballot(active);
+    if (!live) return;
+    int leader = __ffsll((long long)live) - 1;
+    uint32_t lead_idx = __shfl(idx, leader, 64);
+    bool same = active && idx == lead_idx;
+    unsigned long long peers = __ballot(same);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&bins[lead_idx], (uint32_t)__popcll(peers));
+    if (active && !same) atomicAdd(&bins[idx], 1u);
+}
+
+// K3.  Histogram::binSlice (src/histogram.cc:183-199).  The first lds_bins buckets live in LDS (u32, flushed once
+// per block); anything above goes straight to the global u64 array.
+__global__ void __launch_bounds__(256)
+k_hist(DevTable t, uint32_t n_ovf, uint64_t base, uint64_t ceil_, uint64_t inc, uint64_t nb,
+       unsigned long long* __restrict__ out, uint32_t lds_bins) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
+    for (uint32_t i = threadIdx.x; i < lds_bins; i += blockDim.x) s_bins[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t rounds = (t.cap + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {              // uniform trip count: the aggregation uses whole-wave ballots
+        uint64_t i = first + r * stride;
+        uint64_t key = i < t.cap ? t.keys[i] : EMPTY;
+        bool occ = key != EMPTY;
+        uint64_t idx = 0;
+        if (occ) {
+            uint64_t v = slot_count(t, i, key, n_ovf);
+            idx = v < base ? 0 : (v > ceil_ ? nb - 1 : (inc == 1 ? v - base : (v - base) / inc));
+        }
+        bool in_lds = occ && idx < lds_bins;
+        lds_inc_aggregated(s_bins, (uint32_t)idx, in_lds);
+        if (occ && !in_lds) atomicAdd(&out[idx], 1ULL);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // the all-ones key lives outside the slots
+        uint64_t v = t.ctrs[CTR_ONES];
+        if (v) { uint64_t idx = v < base ? 0 : (v > ceil_ ? nb - 1 : (v - base) / inc); atomicAdd(&out[idx], 1ULL); }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < lds_bins; i += blockDim.x)
+        if (s_bins[i]) atomicAdd(&out[i], (unsigned long long)s_bins[i]);
+}
+
+// ceil((double)count * scale) exactly as the host does it (src/gcp.cc:190, src/comp.hpp:303-306): one IEEE
+// double multiply, one ceil, no contraction possible.
+__device__ __forceinline__ uint64_t scale_count(uint64_t c, double scale) {
+    return c == 0 ? 0 : (uint64_t)ceil((double)c * scale);
+}
+
+// K4.  Gcp::analyseSlice (src/gcp.cc:179-197): row = popcount-based GC count, column = min(ceil(count*scale), bins).
+// The whole k x (bins+1) matrix is privatised in LDS as u32 when it fits (27 x 1001 x 4 B = 108 KB of the 160 KB).
+__global__ void __launch_bounds__(256)
+k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long long* __restrict__ out, uint32_t use_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
+    const uint32_t cols = bins + 1, k = t.k, cells = k * cols;
+    if (use_lds) { for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) s_bins[i] = 0; __syncthreads(); }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t rounds = (t.cap + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        uint64_t i = first + r * stride;
+        uint64_t key = i < t.cap ? t.keys[i] : EMPTY;
+        bool occ = key != EMPTY;
+        uint32_t cell = 0;
+        if (occ) {
+            uint32_t g = kmer_gc(key, k);
+            uint64_t pos = scale_count(slot_count(t, i, key, n_ovf), scale);
+            if (pos > bins) pos = bins;
+            occ = g < k;                                   // the reference's matrix has k rows: GC == k never printed
+            cell = g * cols + (uint32_t)pos;
+        }
+        if (use_lds) lds_inc_aggregated(s_bins, cell, occ);
+        else if (occ) atomicAdd(&out[cell], 1ULL);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t v = t.ctrs[CTR_ONES];                     // all-T 32-mer: GC count 0
+        if (v) { uint64_t pos = scale_count(v, scale); if (pos > bins) pos = bins; atomicAdd(&out[pos], 1ULL); }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x)
+            if (s_bins[i]) atomicAdd(&out[i], (unsigned long long)s_bins[i]);
+    }
+}
+
+// ---- K5: comp ----
+constexpr uint32_t COMP_TILE = 64;     // main-matrix cells [0,64) x [0,64) are privatised in LDS (u32)
+enum { CC_H1_TOTAL, CC_H2_TOTAL, CC_H3_TOTAL, CC_H1_DISTINCT, CC_H2_DISTINCT, CC_H3_DISTINCT, CC_H1_ONLY_TOTAL,
+       CC_H2_ONLY_TOTAL, CC_H1_ONLY_DISTINCT, CC_H2_ONLY_DISTINCT, CC_SH_H1_TOTAL, CC_SH_H2_TOTAL, CC_SH_DISTINCT };
+
+struct CompArgs {
+    double d1_scale, d2_scale;
+    uint32_t d1_bins, d2_bins, spec_size;
+    uint32_t canon_probe;            // pass 1: canonicalise the probe key iff input 2 is canonical (src/comp.cc:401)
+    unsigned long long* main_mx;     // d1_bins x d2_bins
+    unsigned long long* counters;    // 13
+    unsigned long long* spectra;     // 4 x spec_size
+};
+
+__device__ __forceinline__ uint32_t spectrum_bin(uint64_t c, uint32_t size) { return c >= size ? size - 1 : (uint32_t)c; }  // comp_counters.cc:130-140
+
+__device__ __forceinline__ void block_sum_u64(unsigned long long* s_acc, int slot, uint64_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_acc[slot], (unsigned long long)v);
+}
+
+// LDS carve: [0,16) u64 scalar accumulators | tile 64x64 u32 | spectra (2 per pass) u32
+template <int PASS>
+__global__ void __launch_bounds__(256)
+k_comp(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_raw);
+    uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_raw + 16 * sizeof(unsigned long long));
+    uint32_t* s_spec = s_tile + COMP_TILE * COMP_TILE;
+    const uint32_t n_spec = (PASS == 1 ? 3u : 1u) * a.spec_size;       // pass 1: spectrum1, shared1, shared2; pass 2: spectrum2
+    for (uint32_t i = threadIdx.x; i < 16; i += blockDim.x) s_acc[i] = 0;
+    for (uint32_t i = threadIdx.x; i < COMP_TILE * COMP_TILE; i += blockDim.x) s_tile[i] = 0;
+    for (uint32_t i = threadIdx.x; i < n_spec; i += blockDim.x) s_spec[i] = 0;
+    __syncthreads();
+
+    const uint32_t k = ta.k;
+    uint64_t a_total = 0, a_distinct = 0, a_only_total = 0, a_only_distinct = 0, sh_a = 0, sh_b = 0, sh_n = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n_slots = ta.cap + 1;                   // virtual slot cap == the all-ones key
+    const uint64_t rounds = (n_slots + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        uint64_t i = first + r * stride;
+        uint64_t key = EMPTY, ca = 0;
+        bool occ = false;
+        if (i < ta.cap) {
+            key = ta.keys[i];
+            occ = key != EMPTY;
+            if (occ) ca = slot_count(ta, i, key, na_ovf);
+        } else if (i == ta.cap) {
+            ca = ta.ctrs[CTR_ONES];
+            occ = ca != 0;
+        }
+        uint64_t cb = 0;
+        uint32_t cell = 0;
+        bool in_tile = false, in_mx = false;
+        if (occ) {
+            // pass 1: hash-1 key probed in hash 2, canonicalised iff input 2 is canonical (src/comp.cc:401)
+            // pass 2: hash-2 key probed in hash 1, ALWAYS canonicalised (src/comp.cc:447 passes a pointer as the bool)
+            uint64_t probe = (PASS == 2 || a.canon_probe) ? kmer_canonical(key, k) : key;
+            cb = table_get(tb, probe, nb_ovf);
+            a_total += ca; a_distinct += 1;
+            if (!cb) { a_only_total += ca; a_only_distinct += 1; }
+            if (PASS == 1) {
+                if (ca && cb) { sh_a += ca; sh_b += cb; sh_n += 1; }
+                uint64_t s1 = scale_count(ca, a.d1_scale), s2 = scale_count(cb, a.d2_scale);
+                if (s1 >= a.d1_bins) s1 = a.d1_bins - 1;
+                if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
+                in_mx = true;
+                in_tile = s1 < COMP_TILE && s2 < COMP_TILE;
+                cell = in_tile ? (uint32_t)(s1 * COMP_TILE + s2) : (uint32_t)(s1 * a.d2_bins + s2);
+            } else if (!cb) {                                                  // only k-mers absent from hash 1 (src/comp.cc:453-462)
+                uint64_t s2 = scale_count(ca, a.d2_scale);
+                if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
+                in_mx = true;
+                in_tile = s2 < COMP_TILE;
+                cell = (uint32_t)s2;                                            // row 0 in both the tile and the matrix
+            }
+        }
+        lds_inc_aggregated(s_tile, cell, in_mx && in_tile);
+        if (in_mx && !in_tile) atomicAdd(&a.main_mx[cell], 1ULL);
+        lds_inc_aggregated(s_spec, spectrum_bin(ca, a.spec_size), occ);                            // spectrum1 / spectrum2
+        if (PASS == 1) {
+            bool shared = occ && ca && cb;
+            lds_inc_aggregated(s_spec + a.spec_size, spectrum_bin(ca, a.spec_size), shared);         // shared_spectrum1
+            lds_inc_aggregated(s_spec + 2 * a.spec_size, spectrum_bin(cb, a.spec_size), shared);     // shared_spectrum2
+        }
+    }
+    block_sum_u64(s_acc, 0, a_total); block_sum_u64(s_acc, 1, a_distinct);
+    block_sum_u64(s_acc, 2, a_only_total); block_sum_u64(s_acc, 3, a_only_distinct);
+    if (PASS == 1) { block_sum_u64(s_acc, 4, sh_a); block_sum_u64(s_acc, 5, sh_b); block_sum_u64(s_acc, 6, sh_n); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (PASS == 1) {
+            atomicAdd(&a.counters[CC_H1_TOTAL], s_acc[0]); atomicAdd(&a.counters[CC_H1_DISTINCT], s_acc[1]);
+            atomicAdd(&a.counters[CC_H1_ONLY_TOTAL], s_acc[2]); atomicAdd(&a.counters[CC_H1_ONLY_DISTINCT], s_acc[3]);
+            atomicAdd(&a.counters[CC_SH_H1_TOTAL], s_acc[4]); atomicAdd(&a.counters[CC_SH_H2_TOTAL], s_acc[5]);
+            atomicAdd(&a.counters[CC_SH_DISTINCT], s_acc[6]);
+        } else {
+            atomicAdd(&a.counters[CC_H2_TOTAL], s_acc[0]); atomicAdd(&a.counters[CC_H2_DISTINCT], s_acc[1]);
+            atomicAdd(&a.counters[CC_H2_ONLY_TOTAL], s_acc[2]); atomicAdd(&a.counters[CC_H2_ONLY_DISTINCT], s_acc[3]);
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < COMP_TILE * COMP_TILE; i += blockDim.x) {
+        uint32_t v = s_tile[i];
+        if (!v) continue;
+        uint32_t r = i / COMP_TILE, c = i % COMP_TILE;
+        if (r < a.d1_bins && c < a.d2_bins) atomicAdd(&a.main_mx[(uint64_t)r * a.d2_bins + c], (unsigned long long)v);
+    }
+    for (uint32_t i = threadIdx.x; i < n_spec; i += blockDim.x) {
+        uint32_t v = s_spec[i];
+        if (!v) continue;
+        uint32_t which = i / a.spec_size, bin = i % a.spec_size;
+        uint32_t dst = PASS == 1 ? (which == 0 ? 0u : which + 1) : 1u;       // spectra order: s1, s2, shared1, shared2
+        atomicAdd(&a.spectra[(uint64_t)dst * a.spec_size + bin], (unsigned long long)v);
+    }
+}
+
+// ---- batch lookup (JellyfishHelper::getCount, lib/src/jellyfish_helper.cc:189-194) ----
+__global__ void __launch_bounds__(256)
+k_get(DevTable t, uint32_t n_ovf, const uint64_t* __restrict__ keys, uint64_t n, int canonicalise, uint64_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = table_get(t, canonicalise ? kmer_canonical(keys[i], t.k) : keys[i], n_ovf);
+}
+
+// ---- export / owner partition ----
+// mode 0: count records per part into sizes[]; mode 1: scatter records to cursors[part]++.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_partition(DevTable t, uint32_t n_ovf, uint32_t n_parts, unsigned long long* __restrict__ sizes_or_cursors,
+            uint64_t* __restrict__ out_keys, uint64_t* __restrict__ out_counts) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.cap; i += stride) {
+        uint64_t key = EMPTY, c = 0;
+        if (i < t.cap) { key = t.keys[i]; if (key == EMPTY) continue; c = slot_count(t, i, key, n_ovf); }
+        else { c = t.ctrs[CTR_ONES]; if (!c) continue; }
+        uint32_t part = n_parts > 1 ? owner_of(key, t.k, n_parts) : 0;
+        unsigned long long at = atomicAdd(&sizes_or_cursors[part], 1ULL);
+        if (MODE == 1) { out_keys[at] = key; out_counts[at] = c; }
+    }
+}
+
+// ---- synthetic workload (bench / tests), bit-identical to kat_amd/synth.py ----
+__device__ __forceinline__ uint32_t genome_code(uint64_t seed, uint64_t i) {
+    return (uint32_t)(rng2(seed, i >> 5) >> (2 * (i & 31))) & 3;
+}
+// contig_len == 0: n bases.  contig_len > 0: the assembly's base stream, an 'N' after every contig_len bases
+// (n counts output bytes, separators included).
+__global__ void __launch_bounds__(256)
+k_synth_genome(uint8_t* __restrict__ out, uint64_t n, uint64_t seed, uint64_t contig_len) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += stride) {
+        uint64_t i = x;
+        if (contig_len) {
+            uint64_t c = x / (contig_len + 1), j = x - c * (contig_len + 1);
+            if (j == contig_len) { out[x] = 'N'; continue; }
+            i = c * contig_len + j;
+        }
+        out[x] = "ACGT"[genome_code(seed, i)];
+    }
+}
+// one lane per base: reads are laid out with stride read_len+1 ('N' separator closes every record)
+__global__ void __launch_bounds__(256)
+k_synth_reads(const uint8_t* __restrict__ genome, uint64_t genome_len, uint8_t* __restrict__ out, uint64_t first_read,
+              uint64_t n_reads, uint32_t read_len, uint32_t frag_len, uint32_t err_thresh, uint64_t seed) {
+    const uint64_t rec = (uint64_t)read_len + 1, total = n_reads * rec;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += stride) {
+        uint64_t rl = x / rec;
+        uint32_t j = (uint32_t)(x - rl * rec);
+        if (j == read_len) { out[x] = 'N'; continue; }
+        uint64_t r = first_read + rl, pair = r >> 1, mate = r & 1;
+        uint64_t u = rng2(seed, pair);
+        uint64_t start = __umul64hi(u, genome_len - frag_len + 1);
+        uint64_t strand = splitmix64(u) >> 63;
+        bool fwd = (strand ^ mate) == 0;
+        uint8_t g = genome[fwd ? start + j : start + frag_len - 1 - j];
+        uint32_t code = ((g >> 1) & 3) ^ ((g >> 2) & 1);
+        if (!fwd) code = 3 - code;
+        uint64_t e = rng2(seed ^ 0x5EED5EED5EED5EEDULL, r * 1024 + j);
+        if ((uint32_t)e < err_thresh) code = (code + 1 + (uint32_t)((e >> 32) % 3)) & 3;
+        out[x] = "ACGT"[code];
+    }
+}
+
+}  // namespace kg

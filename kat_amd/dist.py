@@ -1,0 +1,119 @@
+"""One process per GPU: read sharding + owner-partitioned merge of the per-GPU partial tables over torch.distributed.
+
+KAT has no distributed path (one process, std::thread); this is the exchange step BASELINE.json's north_star asks
+for.  Each rank counts its own shard of the input into a LOCAL partial table.  Table layouts differ per GPU, so
+the merge is keyed, not element-wise: every (k-mer, count) record is routed to owner(k-mer) (a hash of the
+canonical form, kg_device.hpp: owner_of) with grouped point-to-point sends -- on RCCL that is one
+ncclGroupStart/End of ncclSend/ncclRecv pairs that drives all xGMI links of the fully connected node at once,
+which suits xGMI better than a ring all-reduce would -- and the owner adds the counts (exact integer sums, so the
+result is bit-identical to a single-GPU run).  Reducers then run on the owned shards and their small outputs
+(80 KB hist / 216 KB gcp / 8 MB comp matrix + counters) are summed with one all-reduce.
+
+The table object is duck-typed (`partition_sizes`, `partition_into`, `merge_from`, `new_like`) so that the CPU
+gloo tests can drive the same code with an oracle-backed stand-in; the product adapter is HipShard.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class HipShard:
+    """Adapter over a kat_amd.Table whose exchange buffers are torch CUDA tensors (plumbing only)."""
+
+    def __init__(self, table):
+        self.table = table
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def new_like(self, size_hint):
+        t = self.table
+        return HipShard(t.engine.table(t.k, t.canonical, size_hint=max(int(size_hint), 1024)))
+
+    def partition_sizes(self, n_parts):
+        return self.table.partition_sizes(n_parts).astype(np.int64)
+
+    def partition_into(self, n_parts, sizes):
+        total = int(sizes.sum())
+        keys = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+        counts = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+        offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+        torch.cuda.synchronize()
+        self.table.partition(n_parts, offsets, keys.data_ptr(), counts.data_ptr())
+        return keys, counts
+
+    def merge_from(self, keys, counts, n):
+        if n:
+            torch.cuda.synchronize()                 # the exchange ran on torch's stream, the merge runs on katgpu's
+            self.table.merge_device(keys.data_ptr(), counts.data_ptr(), int(n))
+
+    def empty_like(self, n):
+        return (torch.empty(max(n, 1), dtype=torch.int64, device=self.device),
+                torch.empty(max(n, 1), dtype=torch.int64, device=self.device))
+
+    def free(self):
+        self.table.free()
+
+
+def exchange_merge(shard, group=None, load=0.6):
+    """Route every record of `shard` to its owner rank; returns the owner shard (same duck type).
+
+    world_size == 1: the local table already is the owner table, returned as is.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return shard
+    rank = dist.get_rank(group)
+    sizes = shard.partition_sizes(world)                                   # records this rank holds for each owner
+    dev = shard.device
+    mine = torch.from_numpy(sizes).to(dev)
+    all_sizes = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(all_sizes, mine, group=group)
+    recv_sizes = np.array([int(s[rank]) for s in all_sizes], dtype=np.int64)   # what each peer sends to me
+    keys, counts = shard.partition_into(world, sizes)
+    send_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    recv_off = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
+    rkeys, rcounts = shard.empty_like(int(recv_off[-1]))
+    ops = []
+    for p in range(world):
+        if p == rank:
+            continue
+        if sizes[p]:
+            ops.append(dist.P2POp(dist.isend, keys[send_off[p]:send_off[p + 1]], p, group))
+            ops.append(dist.P2POp(dist.isend, counts[send_off[p]:send_off[p + 1]], p, group))
+        if recv_sizes[p]:
+            ops.append(dist.P2POp(dist.irecv, rkeys[recv_off[p]:recv_off[p + 1]], p, group))
+            ops.append(dist.P2POp(dist.irecv, rcounts[recv_off[p]:recv_off[p + 1]], p, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    # size the owner table from what is about to land in it (an upper bound on its distinct count)
+    owner = shard.new_like(int((int(recv_off[-1])) / load) + 1024)
+    s0, s1 = int(send_off[rank]), int(send_off[rank + 1])
+    owner.merge_from(keys[s0:s1], counts[s0:s1], s1 - s0)                   # my own part needs no wire
+    for r in reqs:
+        r.wait()
+    for p in range(world):
+        if p != rank and recv_sizes[p]:
+            r0, r1 = int(recv_off[p]), int(recv_off[p + 1])
+            owner.merge_from(rkeys[r0:r1], rcounts[r0:r1], r1 - r0)
+    return owner
+
+
+def allreduce_u64(arrays, device, group=None):
+    """Sum uint64 numpy result arrays over ranks (ThreadedSparseMatrix::mergeThreadedMatricies across GPUs)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return arrays
+    flat = np.concatenate([np.ascontiguousarray(a, np.uint64).reshape(-1) for a in arrays]).view(np.int64)
+    t = torch.from_numpy(flat.copy()).to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    res = t.cpu().numpy().view(np.uint64)
+    out, o = [], 0
+    for a in arrays:
+        n = int(np.prod(a.shape))
+        out.append(res[o:o + n].reshape(a.shape).copy())
+        o += n
+    return out
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous [lo, hi) of n_items for this rank (read pairs / contigs are independent units)."""
+    per, extra = divmod(n_items, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)

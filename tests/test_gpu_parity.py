@@ -1,0 +1,232 @@
+"""HIP path vs CPU oracle, bit-exact, through the C ABI (libkatgpu.so).  Sizes the oracle finishes in seconds."""
+import os
+
+import numpy as np
+import pytest
+
+import kat_amd
+from kat_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same_table(gt, ot):
+    gk, gc = gt.dump_sorted()
+    ok_, oc = ot.dump_sorted()
+    assert gk.size == ok_.size, "distinct differs: gpu %d oracle %d" % (gk.size, ok_.size)
+    assert np.array_equal(gk, ok_)
+    assert np.array_equal(gc, oc)
+    st = gt.stats()
+    assert st["distinct"] == ot.distinct and st["total"] == ot.total
+
+
+def assert_same_reducers(gt, ot):
+    for low, high, inc in ((1, 10000, 1), (5, 60, 1), (2, 100, 7), (1, 3, 1)):
+        assert np.array_equal(gt.hist(low, high, inc), ot.hist(low, high, inc)), (low, high, inc)
+    for scale, bins in ((1.0, 1000), (0.37, 50), (3.0, 20)):
+        assert np.array_equal(gt.gcp(scale, bins), ot.gcp(scale, bins)), (scale, bins)
+
+
+@pytest.mark.parametrize("k,canonical", [(27, True), (31, True), (17, True), (13, False), (32, True), (32, False), (1, True), (5, False)])
+def test_count_synthetic_reads(engine, ko, k, canonical):
+    g = synth.genome(30000, seed=11)
+    stream = synth.reads(g, 0, 3000, seed=3)
+    gt = engine.table(k, canonical).count_bases(stream)
+    ot = ko.Table(k, canonical).count_bases(stream)
+    assert_same_table(gt, ot)
+    assert_same_reducers(gt, ot)
+
+
+def test_reference_fastq_files(engine, ko, refdata):
+    paths = [os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")]
+    for k in (27, 17):
+        gt = engine.count(paths, k)
+        ot = ko.Table(k, True).count_files(paths)
+        assert_same_table(gt, ot)
+        assert_same_reducers(gt, ot)
+    # SURVEY.md 8(c) known answer (recorded by the survey stage from a hand-built reference binary): kat hist -m27
+    h = engine.count(paths, 27).hist()
+    assert [int(h[i]) for i in range(6)] == [111200, 11696, 2063, 737, 361, 128]
+
+
+def test_reference_fasta_files(engine, ko, refdata):
+    for name, expect in (("sect_length_test.fa", {1094: 18, 1095: 16}), ("sect_test.fa", {1: 26})):
+        p = [os.path.join(refdata, name)]
+        gt = engine.count(p, 27)
+        assert_same_table(gt, ko.Table(27, True).count_files(p))
+        h = gt.hist()
+        assert {i + 1: int(v) for i, v in enumerate(h) if v} == expect
+
+
+def test_comp_reference_reads(engine, ko, refdata):
+    p1 = [os.path.join(refdata, "ecoli_r1.1K.fastq")]
+    p2 = [os.path.join(refdata, "ecoli_r2.1K.fastq")]
+    for k, c1, c2 in ((13, True, True), (21, False, False), (21, True, False), (21, False, True)):
+        g1, g2 = engine.count(p1, k, c1), engine.count(p2, k, c2)
+        o1, o2 = ko.Table(k, c1).count_files(p1), ko.Table(k, c2).count_files(p2)
+        for args in ((1.0, 1.0, 1001, 1001), (0.5, 2.0, 30, 50), (1.0, 1.0, 5, 3)):
+            mx, cc, sp = kat_amd.comp(g1, g2, *args)
+            omx, occ, osp = ko.comp(o1, o2, *args)
+            assert np.array_equal(cc, occ), (k, c1, c2, args, cc, occ)
+            assert np.array_equal(sp, osp)
+            assert np.array_equal(mx, omx)
+    # comp -m13 stats block
+    mx, cc, sp = kat_amd.comp(engine.count(p1, 13), engine.count(p2, 13))
+    assert list(map(int, cc)) == [87929, 88000, 0, 80366, 80554, 0, 66743, 67516, 64113, 64301, 21186, 20484, 16253]
+    assert int(mx.max()) == 62111
+
+
+def test_edge_inputs(engine, ko):
+    k = 27
+    cases = [
+        b"",                                   # empty
+        b"ACGT",                               # shorter than k
+        b"A" * 26,                             # one short of a window
+        b"A" * 27,                             # exactly one window
+        b"N" * 100,
+        b"acgtACGTnACGT" * 40,                 # lower case + breaks
+        (b"ACGTTGCAAGGCTTAACCGGTTAGCAT" * 3 + b"R") * 5 + b"-" + b"TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT",
+        b"G" * 5000,                           # one k-mer, count 4974 (GC == k: dropped by gcp, quirk B1)
+        bytes(np.random.default_rng(5).choice(np.frombuffer(b"ACGTN\r acgt", dtype=np.uint8), size=70001)),
+    ]
+    for s in cases:
+        gt = engine.table(k, True).count_bases(s)
+        ot = ko.Table(k, True).count_bases(s)
+        assert_same_table(gt, ot)
+        assert_same_reducers(gt, ot)
+
+
+def test_ragged_sizes_and_alignment(engine, ko):
+    """Stream lengths around the 4064-start chunk and 16-byte lane granularity, device buffers at odd offsets."""
+    g = synth.genome(40000, seed=2)
+    k = 31
+    for n in (31, 32, 47, 4063, 4064, 4065, 4064 + 30, 4064 + 31, 8128, 8129, 12345, 40000):
+        s = g[:n]
+        assert_same_table(engine.table(k, True).count_bases(s), ko.Table(k, True).count_bases(s))
+    buf = engine.alloc(g.size + 64)
+    for off in (0, 1, 7, 16, 33):
+        buf.upload(g, offset=off)
+        gt = engine.table(k, True)
+        gt.count_bases_device(buf.ptr + off, g.size)
+        assert_same_table(gt, ko.Table(k, True).count_bases(g))
+
+
+def test_regrow_and_accumulate(engine, ko):
+    """Tiny size hint -> several regrows (hash_counter::double_size); several count calls accumulate into one table."""
+    g = synth.genome(200000, seed=9)
+    a = synth.reads(g, 0, 6000, seed=1)
+    b = synth.reads(g, 6000, 6000, seed=1)
+    gt = engine.table(27, True, size_hint=1024)
+    gt.count_bases(a)
+    gt.count_bases(b)
+    ot = ko.Table(27, True).count_bases(a).count_bases(b)
+    assert_same_table(gt, ot)
+    assert gt.stats()["capacity"] > 1024
+    assert engine.profile()["regrow"]["launches"] > 0
+    # -g / disable_hash_grow: a full table is an error, as in hash_counter.hpp:198-199
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        engine.table(27, True, size_hint=1024, disable_grow=True).count_bases(a)
+    assert ei.value.code == 7 and "Hash full" in ei.value.message
+
+
+def test_host_batching_seams(engine, ko):
+    """A host stream larger than one 64 MiB staging buffer: k-mers across the cut are counted exactly once."""
+    g = synth.genome(1 << 20, seed=4)
+    s = np.tile(np.concatenate([g, np.frombuffer(b"N", np.uint8)]), 70)[: (70 << 20)]   # > 64 MiB, highly repetitive
+    gt = engine.table(27, True, size_hint=1 << 22).count_bases(s)
+    ot = ko.Table(27, True).count_bases(s, threads=8)
+    assert_same_table(gt, ot)
+
+
+def test_table_get(engine, ko, refdata):
+    """JellyfishHelper::getCount semantics, incl. the known answers of the reference's tests/check_jellyfish.cc:62-91."""
+    jf = ko.Table.from_jf(os.path.join(refdata, "ecoli.header.jf27"))
+    keys, counts = jf.dump_sorted()
+    gt = engine.table(27, False)
+    gt.merge_host(keys, counts)
+    q = [ko.encode(s) for s in ("AGCTTTTCATTCTGACTGCAACGGGCA", "GCATAGCGCACAGACAGATAAAAATTA",
+                                "AATGAAAAAGGCGAACTGGTGGTGCTT", "CTCACCAATGTACATGGCCTTAATCTG")]
+    assert list(map(int, gt.get(q, canonicalise=False))) == [3, 1, 1, 1]
+    assert list(map(int, gt.get(q, canonicalise=True))) == [3, 1, 0, 0]
+    assert gt.stats()["distinct"] == 1889
+
+
+def test_exact_64bit_counts(engine, ko):
+    """Counts beyond 32 bits stay exact (Jellyfish chains overflow into 'large' entries, large_hash_array.hpp:668-700)."""
+    k = 21
+    keys = np.array([5, 77, 123456789, 5], dtype=np.uint64)
+    counts = np.array([0xFFFFFFFF, 3, (7 << 32) + 9, 2], dtype=np.uint64)
+    gt = engine.table(k, False)
+    gt.merge_host(keys, counts)
+    gt.count_bases(b"A" * 18 + b"CC" + b"N")          # AAAAAAAAAAAAAAAAAACCC? no: 20 bases -> no window; stays untouched
+    gt.merge_host(np.array([77], np.uint64), np.array([0xFFFFFFFE], np.uint64))
+    ot = ko.Table(k, False)
+    for kk, cc in ((5, 0xFFFFFFFF), (77, 3), (123456789, (7 << 32) + 9), (5, 2), (77, 0xFFFFFFFE)):
+        ot.add(kk, cc)
+    assert_same_table(gt, ot)
+    assert_same_reducers(gt, ot)
+    o2 = ko.Table(k, False)
+    o2.add(5, 1 << 33)
+    g2 = engine.table(k, False)
+    g2.merge_host(np.array([5], np.uint64), np.array([1 << 33], np.uint64))
+    mx, cc, sp = kat_amd.comp(gt, g2)
+    omx, occ, osp = ko.comp(ot, o2)
+    assert np.array_equal(cc, occ) and np.array_equal(mx, omx) and np.array_equal(sp, osp)
+
+
+def test_partition_merge_roundtrip(engine, ko):
+    """Owner partition -> merge rebuilds the same table; strands of a k-mer share an owner."""
+    g = synth.genome(50000, seed=21)
+    s = synth.reads(g, 0, 4000, seed=5)
+    k = 25
+    src = engine.table(k, False).count_bases(s)
+    n_parts = 8
+    sizes = src.partition_sizes(n_parts)
+    total = int(sizes.sum())
+    assert total == src.stats()["distinct"]
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    dk, dc = engine.alloc(total * 8), engine.alloc(total * 8)
+    src.partition(n_parts, offsets, dk.ptr, dc.ptr)
+    keys, counts = dk.download(np.uint64), dc.download(np.uint64)
+    owner = {}
+    for p in range(n_parts):
+        for key in keys[int(offsets[p]): int(offsets[p] + sizes[p])]:
+            can = ko.canonical(int(key), k)
+            assert owner.setdefault(can, p) == p
+    dst = engine.table(k, False)
+    for p in range(n_parts):
+        o, n = int(offsets[p]), int(sizes[p])
+        dst.merge_device(dk.ptr + 8 * o, dc.ptr + 8 * o, n)
+    assert_same_table(dst, ko.Table(k, False).count_bases(s))
+
+
+def test_device_generator_matches_numpy(engine):
+    G, n_reads = 100000, 5000
+    gd = engine.synth_genome(G, seed=42)
+    assert np.array_equal(gd.download(), synth.genome(G, seed=42))
+    rd = engine.synth_reads(gd, G, first_read=1234, n_reads=n_reads, seed=9)
+    assert np.array_equal(rd.download(), synth.reads(synth.genome(G, seed=42), 1234, n_reads, seed=9))
+    ad = engine.synth_genome(G, seed=42, contig_len=7000)
+    assert np.array_equal(ad.download(), synth.assembly_stream(G, 42, 7000))
+
+
+def test_errors(engine, tmp_path):
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        engine.table(33, True)
+    assert ei.value.code == 6
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        engine.count([str(tmp_path / "missing.fa")], 27)
+    assert ei.value.code == 2 and "Could not find input file at" in ei.value.message
+    bad = tmp_path / "bad.txt"
+    bad.write_text("hello\nworld\n")
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        engine.count([str(bad)], 27)
+    assert ei.value.code == 3 and "Unsupported format" in ei.value.message
+    fq = tmp_path / "bad.fq"
+    fq.write_text("@r1\nACGTACGT\n+\nIIII\n@r2\nACGT\n+\nIIII\n")
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        engine.count([str(fq)], 3)
+    assert ei.value.code == 4 and "Invalid fastq sequence" in ei.value.message
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        kat_amd.comp(engine.table(21, True), engine.table(27, True))
+    assert ei.value.code == 9
