@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--err-ppm", type=int, default=2000, help="substitution errors per million bases (0.2 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_500_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=8_000_000)
     return ap.parse_args()
 
 
@@ -195,7 +195,7 @@ def cpu_baseline(eng, a, k, L):
     from oracle import koracle as ko
     threads = os.cpu_count() or 1
     n = min(a.cpu_sample_reads, a.reads) & ~1
-    gs = min(a.genome, 5_000_000)
+    gs = min(a.genome, 20_000_000)
     g = eng.synth_genome(gs, seed=77)
     r = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=3)
     asm = eng.synth_genome(gs, seed=77, contig_len=100_000)

@@ -289,7 +289,9 @@ extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bas
         // largest batch that provably fits; if even a minimal one does not, grow first
         uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
         uint64_t want = std::min<uint64_t>(n_starts - pos, (uint64_t)CHUNK_STARTS * 65536);   // <= 266 M starts per launch
-        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, CHUNK_STARTS))) {
+        // As the table fills, launches shrink to the remaining room (each adds far fewer distinct k-mers than window
+        // starts on real coverage, so the room shrinks slowly); only when the room is down to 1/64 of the table do we grow.
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 64, CHUNK_STARTS))) {
             rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, CHUNK_STARTS)));
             if (rc) return rc;
             continue;

@@ -246,7 +246,8 @@ void ko_count_bases_mt(ko_table* t, const uint8_t* s, size_t n, int threads) {
     if (threads <= 1) { ko_count_bases(t, s, n); return; }
     if (n < t->k) return;
     const size_t nstart = n - t->k + 1;            /* number of window start positions */
-    const size_t block = (size_t)16 << 20;
+    size_t block = (size_t)16 << 20;              /* window starts per thread-team round */
+    if (block < ((size_t)threads << 20)) block = (size_t)threads << 20;
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
     mt_job* jobs = (mt_job*)malloc(sizeof(mt_job) * threads);
     for (size_t b0 = 0; b0 < nstart; b0 += block) {
