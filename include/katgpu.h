@@ -76,6 +76,12 @@ int katgpu_count_bases_host(katgpu_table* t, const uint8_t* bases, size_t n);
 int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bases, size_t n);
 void katgpu_table_free(katgpu_table* t);
 
+/* Host-only: run the ingest parser alone and return the base stream of one file (malloc'd; release with
+ * katgpu_free_host).  Needs no device; *err_msg (optional, static storage, valid until the next call on this thread)
+ * receives the message on failure.  This is what katgpu_count_files streams to the GPU. */
+int  katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** bases, size_t* n, const char** err_msg);
+void katgpu_free_host(void* p);
+
 /* distinct k-mers, sum of counts, slots allocated */
 int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t* total, uint64_t* capacity);
 uint32_t katgpu_table_k(const katgpu_table* t);

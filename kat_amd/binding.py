@@ -27,7 +27,7 @@ EXPORTS = (
     "katgpu_comp", "katgpu_table_partition_sizes", "katgpu_table_partition", "katgpu_table_merge_device",
     "katgpu_table_merge_host", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
-    "katgpu_synth_genome_device", "katgpu_synth_reads_device",
+    "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_free_host",
 )
 
 
@@ -91,8 +91,23 @@ def load_library():
     L.katgpu_dev_mem_info.argtypes = [vp, pu64, pu64]
     L.katgpu_synth_genome_device.argtypes = [vp, vp, u64, u64, u64]
     L.katgpu_synth_reads_device.argtypes = [vp, vp, u64, vp, u64, u64, u32, u32, u32, u64]
+    L.katgpu_parse_file.argtypes = [C.c_char_p, u32, pp, C.POINTER(sz), cpp]
+    L.katgpu_free_host.argtypes = [vp]
+    L.katgpu_free_host.restype = None
     _lib = L
     return L
+
+
+def parse_file(path, trim5p=0):
+    """Host-only ingest: FASTA/FASTQ(.gz) -> base stream (uint8 array).  Needs no GPU."""
+    L = load_library()
+    p, n, msg = C.c_void_p(), C.c_size_t(), C.c_char_p()
+    rc = L.katgpu_parse_file(os.fsencode(path), trim5p, C.byref(p), C.byref(n), C.byref(msg))
+    if rc:
+        raise KatGpuError(rc, (msg.value or b"").decode(errors="replace"))
+    out = np.frombuffer(C.string_at(p, n.value), dtype=np.uint8).copy() if n.value else np.zeros(0, np.uint8)
+    L.katgpu_free_host(p)
+    return out
 
 
 def hist_geometry(low, high):

@@ -1,0 +1,195 @@
+// input_handler.cc -- mirror of KAT's InputHandler (lib/src/input_handler.cc) + the file-type sniffing of
+// JellyfishHelper (lib/src/jellyfish_helper.cc:258-307).  count() is the drop-in boundary: where the reference builds a
+// jellyfish HashCounter and runs countSeqFile (input_handler.cc:180-202), this calls katgpu_count.
+#include "kat_host.hpp"
+
+#include <glob.h>
+#include <strings.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+namespace kat {
+
+// ---- engine singleton ----
+static katgpu_ctx* g_ctx = nullptr;
+
+katgpu_ctx* Engine::ctx() {
+    if (!g_ctx) {
+        int rc = katgpu_init(-1, &g_ctx);
+        if (rc) throw std::runtime_error("katgpu_init failed (status " + std::to_string(rc) + "): no gfx950 device; this build has no CPU path");
+    }
+    return g_ctx;
+}
+
+void Engine::shutdown() {
+    if (g_ctx) { katgpu_shutdown(g_ctx); g_ctx = nullptr; }
+}
+
+void Engine::check(int status) {
+    if (status == KATGPU_OK) return;
+    std::string msg = g_ctx ? katgpu_last_error(g_ctx) : "katgpu error";
+    switch (status) {
+    case KATGPU_ERR_IO: throw InputFileException(msg);                       // boost-derived in the reference -> exit code 4
+    case KATGPU_ERR_MISMATCH: throw JellyfishException(msg);
+    case KATGPU_ERR_FORMAT:                                                  // std::runtime_error in the reference -> exit code 5
+    case KATGPU_ERR_FASTQ:
+    case KATGPU_ERR_TABLE_FULL: throw std::runtime_error(msg);
+    default: throw std::runtime_error("katgpu status " + std::to_string(status) + ": " + msg);
+    }
+}
+
+// ---- InputHandler ----
+InputHandler::~InputHandler() {
+    if (hash) katgpu_table_free(hash);      // the reference releases its shared_ptr<HashCounter> here
+}
+
+void InputHandler::setMultipleInputs(const std::vector<std::string>& inputs) {
+    input = inputs;
+    trim5p.assign(inputs.size(), 0);
+}
+
+void InputHandler::set5pTrim(const std::vector<uint16_t>& trim_list) {      // lib/src/input_handler.cc:51-72
+    if (trim_list.empty()) trim5p.assign(input.size(), 0);
+    else if (trim_list.size() == 1 && input.size() > 1) trim5p.assign(input.size(), trim_list[0]);
+    else if (trim_list.size() == input.size()) trim5p = trim_list;
+    else throw InputFileException("Inconsistent number of inputs and trimming settings.  Please establish your inputs before trying to set trimming vector.  Also ensure you have the same number of input files to trimming settings.");
+}
+
+bool InputHandler::isPipe(const std::string& p) { return p.rfind("/proc", 0) == 0 || p.rfind("/dev", 0) == 0; }
+
+static std::string extension(const std::string& p) {
+    size_t slash = p.find_last_of('/');
+    std::string leaf = slash == std::string::npos ? p : p.substr(slash + 1);
+    size_t dot = leaf.find_last_of('.');
+    if (dot == std::string::npos || leaf == "." || leaf == "..") return "";
+    return leaf.substr(dot);
+}
+
+bool InputHandler::isSequenceFile(const std::string& filename) {            // lib/src/jellyfish_helper.cc:270-307
+    if (isPipe(filename)) return true;
+    std::string ext = extension(filename);
+    if (strcasecmp(ext.c_str(), ".gz") == 0) ext = extension(filename.substr(0, filename.find_last_of('.')));
+    static const char* seq_exts[] = {".fastq", ".fq", ".fasta", ".fa", ".fna", ".fas", ".scafSeq"};
+    for (const char* e : seq_exts) if (strcasecmp(ext.c_str(), e) == 0) return true;
+    char ch = 0;
+    std::fstream fin(filename, std::fstream::in);
+    fin >> ch;
+    return ch == '>' || ch == '@';
+}
+
+void InputHandler::validateInput() {                                        // lib/src/input_handler.cc:97-137
+    if (input.size() != trim5p.size()) throw InputFileException("Inconsistent number of inputs and trimming settings.");
+    for (const auto& p : input) {
+        struct stat st;
+        if (!isPipe(p) && stat(p.c_str(), &st) != 0)
+            throw InputFileException("Could not find input file at: " + p + "; please check the path and try again.");
+        mode = isSequenceFile(p) ? COUNT : LOAD;       // `start` is never cleared in the reference: the last file decides
+    }
+}
+
+std::string InputHandler::pathString() const {                              // lib/src/input_handler.cc:160-169
+    std::string s;
+    for (const auto& p : input) s += (isPipe(p) ? std::string("<pipe>") : p) + " ";
+    while (!s.empty() && isspace((unsigned char)s.back())) s.pop_back();
+    return s;
+}
+
+std::string InputHandler::fileName() const {                                // lib/src/input_handler.cc:171-178
+    std::string s;
+    for (const auto& p : input) {
+        size_t slash = p.find_last_of('/');
+        s += (slash == std::string::npos ? p : p.substr(slash + 1)) + " ";
+    }
+    while (!s.empty() && isspace((unsigned char)s.back())) s.pop_back();
+    return s;
+}
+
+void InputHandler::count(uint16_t threads) {                                // lib/src/input_handler.cc:180-202
+    (void)threads;          // -t sized the reference's std::thread team; the GPU engine owns its own parallelism
+    auto t0 = std::chrono::steady_clock::now();
+    std::cout << "Input " << index << " is a sequence file.  Counting kmers for input " << index << " (" << pathString() << ") ...";
+    std::cout.flush();
+    if (mode != COUNT)
+        throw JellyfishException("Input " + std::to_string(index) + " is a jellyfish hash: loading .jf files is not part of this build (SURVEY.md 8(f))");
+    std::vector<const char*> paths;
+    for (const auto& p : input) paths.push_back(p.c_str());
+    Engine::check(katgpu_count(Engine::ctx(), paths.data(), paths.size(), merLen, canonical ? 1 : 0, trim5p.data(), hashSize,
+                               disableHashGrow ? 1 : 0, &hash));
+    std::cout << " done.";
+    std::cout.flush();
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    char buf[64]; snprintf(buf, sizeof buf, "  Time taken: %.1fs\n\n", s);   // auto_cpu_timer(1, "  Time taken: %ws\n\n")
+    std::cout << buf;
+}
+
+std::shared_ptr<std::vector<std::string>> InputHandler::globFiles(const std::string& in) {       // :245-255
+    std::vector<std::string> v;
+    std::stringstream ss(in);
+    std::string tok;
+    size_t start = 0;
+    while (true) {                                          // boost::split on ' ' keeps empty tokens
+        size_t sp = in.find(' ', start);
+        v.push_back(in.substr(start, sp == std::string::npos ? std::string::npos : sp - start));
+        if (sp == std::string::npos) break;
+        start = sp + 1;
+    }
+    return globFiles(v);
+}
+
+std::shared_ptr<std::vector<std::string>> InputHandler::globFiles(const std::vector<std::string>& in) {   // :263-316
+    if (in.empty()) throw InputFileException("No input provided for this input group");
+    glob_t gb;
+    memset(&gb, 0, sizeof gb);
+    int i = 0;
+    for (const auto& g : in) {
+        int flags = GLOB_TILDE | GLOB_NOCHECK | GLOB_BRACE;
+        if (i > 0) flags |= GLOB_APPEND;
+        int ret = glob(g.c_str(), flags, nullptr, &gb);
+        if (ret != 0) {
+            throw InputFileException(std::string("Problem globbing input pattern: ") + g + ". Non-zero return code.  Error type: " +
+                                     (ret == GLOB_ABORTED ? "filesystem problem" : ret == GLOB_NOMATCH ? "no match of pattern" :
+                                      ret == GLOB_NOSPACE ? "no dynamic memory" : "unknown problem"));
+        }
+        ++i;
+    }
+    auto out = std::make_shared<std::vector<std::string>>();
+    for (size_t j = 0; j < gb.gl_pathc; ++j) out->push_back(gb.gl_pathv[j]);
+    if (gb.gl_pathc > 0) globfree(&gb);
+    if (out->empty()) out->push_back(in[0]);
+    return out;
+}
+
+// ---- filesystem helpers ----
+std::string parentOfAbsolute(const std::string& prefix) {
+    std::string abs = prefix;
+    if (abs.empty() || abs[0] != '/') {
+        char cwd[4096];
+        if (!getcwd(cwd, sizeof cwd)) throw FileSystemException("getcwd failed");
+        abs = std::string(cwd) + "/" + prefix;
+    }
+    size_t slash = abs.find_last_of('/');
+    return slash == 0 ? "/" : abs.substr(0, slash);
+}
+
+void ensureDirectoryExists(const std::string& dir) {                        // lib/include/kat/kat_fs.hpp:226-238
+    struct stat st;
+    if (stat(dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) return;
+    std::string acc;
+    std::stringstream ss(dir);
+    std::string part;
+    while (std::getline(ss, part, '/')) {
+        acc += part + "/";
+        if (part.empty()) continue;
+        if (stat(acc.c_str(), &st) != 0) mkdir(acc.c_str(), 0777);
+    }
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) throw FileSystemException("Could not create output directory: " + dir);
+}
+
+}  // namespace kat

@@ -1,0 +1,40 @@
+// kat_main.cc -- `katgpu hist|gcp|comp ...`: the dispatcher for the three KAT modes on the path, with KAT's exit codes
+// (src/kat.cc:178-305: option errors 1, KAT/boost exceptions 4, std::exception 5, const char* 6, anything else 7).
+#include "kat_host.hpp"
+
+#include <cstring>
+#include <iostream>
+
+static void usage() {
+    std::cout << "The K-mer Analysis Toolkit, MI355X engine (katgpu): hist | gcp | comp\n"
+                 "Usage: katgpu <mode> [options] <inputs>   (same options as `kat <mode>`; see INTEGRATION.md)\n";
+}
+
+int main(int argc, char* argv[]) {
+    int rc = 0;
+    try {
+        if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) { usage(); return 1; }
+        const std::string mode = argv[1];
+        if (mode == "hist") rc = kat::Histogram::main(argc - 1, argv + 1);
+        else if (mode == "gcp") rc = kat::Gcp::main(argc - 1, argv + 1);
+        else if (mode == "comp") rc = kat::Comp::main(argc - 1, argv + 1);
+        else throw kat::OptionError("Could not recognise mode string: " + mode + " (this build carries hist, gcp and comp)");
+    } catch (kat::OptionError& e) {
+        std::cerr << "Error: Parsing Command Line: " << e.what() << std::endl;
+        rc = 1;
+    } catch (kat::KatException& e) {
+        std::cerr << e.what() << std::endl;
+        rc = 4;
+    } catch (std::exception& e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+        rc = 5;
+    } catch (const char* msg) {
+        std::cerr << "Error: " << msg << std::endl;
+        rc = 6;
+    } catch (...) {
+        std::cerr << "Error: Exception of unknown type!" << std::endl;
+        rc = 7;
+    }
+    kat::Engine::shutdown();
+    return rc;
+}

@@ -7,6 +7,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace kg {
@@ -152,3 +153,26 @@ int SeqFileParser::next(const uint8_t** p, size_t* n, std::string* err) {
 }
 
 }  // namespace kg
+
+extern "C" int katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** bases, size_t* n, const char** err_msg) {
+    static thread_local std::string last;
+    if (!path || !bases || !n) return KATGPU_ERR_INVALID_ARG;
+    *bases = nullptr; *n = 0;
+    kg::SeqFileParser parser;
+    std::vector<uint8_t> all;
+    int rc = parser.open(path, trim5p, &last);
+    while (!rc) {
+        const uint8_t* p; size_t got;
+        rc = parser.next(&p, &got, &last);
+        if (rc || !got) break;
+        all.insert(all.end(), p, p + got);
+    }
+    if (rc) { if (err_msg) *err_msg = last.c_str(); return rc; }
+    *bases = (uint8_t*)malloc(all.size() ? all.size() : 1);
+    if (!*bases) return KATGPU_ERR_NOMEM;
+    memcpy(*bases, all.data(), all.size());
+    *n = all.size();
+    return KATGPU_OK;
+}
+
+extern "C" void katgpu_free_host(void* p) { free(p); }

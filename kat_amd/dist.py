@@ -117,3 +117,32 @@ def shard_range(n_items, rank, world):
     per, extra = divmod(n_items, world)
     lo = rank * per + min(rank, extra)
     return lo, lo + per + (1 if rank < extra else 0)
+
+
+# ---- host mirror of the device's owner function (kg_device.hpp: mix64 / owner_of), for tests and host-side routing ----
+def _mix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x ^ (x >> np.uint64(33))
+        x = x * np.uint64(0xff51afd7ed558ccd)
+        x = x ^ (x >> np.uint64(33))
+        x = x * np.uint64(0xc4ceb9fe1a85ec53)
+        x = x ^ (x >> np.uint64(33))
+    return x
+
+
+def _revcomp(keys, k):
+    x = np.asarray(keys, dtype=np.uint64)
+    out = np.zeros_like(x)
+    for i in range(k):                                   # base i (from the LSB) -> complemented, mirrored
+        b = (x >> np.uint64(2 * i)) & np.uint64(3)
+        out |= (np.uint64(3) - b) << np.uint64(2 * (k - 1 - i))
+    return out
+
+
+def owner_of(keys, k, n_parts):
+    """Part index of each packed k-mer: a hash of its CANONICAL form, so both strands and both comp inputs co-locate."""
+    from .synth import mulhi64
+    x = np.asarray(keys, dtype=np.uint64)
+    c = np.minimum(x, _revcomp(x, k))
+    return mulhi64(_mix64(c ^ np.uint64(0x9E3779B97F4A7C15)), np.uint64(n_parts)).astype(np.int64)

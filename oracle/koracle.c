@@ -339,7 +339,7 @@ static int skip_quals(mstream* s, size_t read_len) {
         while (got < want && s->pos < s->n) { uint8_t c = s->d[s->pos++]; got++; if (c == '\n') { saw_nl = 1; break; } }
         quals += got;
         if (saw_nl || got == want) ++read_len;      /* "if(is) ++read_len" compensates the consumed newline */
-        if (!saw_nl && s->pos >= s->n) { if (got != want) read_len = quals; break; }   /* EOF without newline: tolerated */
+        if (!saw_nl && s->pos >= s->n) break;       /* EOF without newline: tolerated iff the length is exact (checked below) */
     }
     ms_skip_newlines(s);
     if (quals == read_len && (ms_peek(s) == '@' || ms_peek(s) == -1)) return KO_OK;

@@ -1,0 +1,104 @@
+"""The C++ host mirror (kat_amd/bin/katgpu: InputHandler / Histogram / Gcp / Comp above the C ABI) writes the same bytes
+as the oracle's restatement of KAT's writers, on the reference's tests/data inputs and its own CLI test commands
+(tests/test_hist.sh, test_gcp.sh, test_comp.sh) and on generated PE reads + assembly."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kat_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "kat_amd", "bin", "katgpu")
+
+
+def run(args, cwd):
+    r = subprocess.run([EXE] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    return r
+
+
+def test_hist_cli(ko, refdata, tmp_path):
+    r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
+    r = run(["hist", "-m17", "-o", "temp/hist_test", r1, r2], tmp_path)            # tests/test_hist.sh
+    assert r.returncode == 0, r.stderr
+    assert "Running KAT in HIST mode" in r.stdout and "KAT HIST completed." in r.stdout
+    t = ko.Table(17, True).count_files([r1, r2])
+    ko.write_hist(str(tmp_path / "want"), 17, [r1, r2], 1, 10000, 1, t.hist())
+    assert (tmp_path / "temp" / "hist_test").read_bytes() == (tmp_path / "want").read_bytes()
+    # non-default geometry + non-canonical + default output name
+    r = run(["hist", "-m", "21", "-l", "3", "--high=50", "-i", "4", "-N", "-H", "5000", r1], tmp_path)
+    assert r.returncode == 0, r.stderr
+    t = ko.Table(21, False).count_files([r1])
+    ko.write_hist(str(tmp_path / "want2"), 21, [r1], 3, 50, 4, t.hist(3, 50, 4))
+    assert (tmp_path / "kat.hist").read_bytes() == (tmp_path / "want2").read_bytes()
+
+
+def test_gcp_cli(ko, refdata, tmp_path):
+    r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
+    r = run(["gcp", "-m17", "-o", "temp/gcp_test", r1, r2], tmp_path)              # tests/test_gcp.sh
+    assert r.returncode == 0, r.stderr
+    t = ko.Table(17, True).count_files([r1, r2])
+    ko.write_gcp(str(tmp_path / "want.mx"), 17, [r1, r2], 1000, t.gcp())
+    got = (tmp_path / "temp" / "gcp_test.mx").read_bytes()
+    assert got == (tmp_path / "want.mx").read_bytes()
+    assert b"# Columns:1001\n# Rows:17\n# MaxVal:21046\n" in got
+    r = run(["gcp", "-m", "27", "-x", "0.25", "-y", "40", "-o", "g2", r1], tmp_path)
+    assert r.returncode == 0, r.stderr
+    ko.write_gcp(str(tmp_path / "want2.mx"), 27, [r1], 40, ko.Table(27, True).count_files([r1]).gcp(0.25, 40))
+    assert (tmp_path / "g2.mx").read_bytes() == (tmp_path / "want2.mx").read_bytes()
+
+
+def test_comp_cli(ko, refdata, tmp_path):
+    r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
+    r = run(["comp", "-m13", "-v", "-n", "-h", "-o", "temp/density_test", r1, r2], tmp_path)   # tests/test_comp.sh (+ -h)
+    assert r.returncode == 0, r.stderr
+    t1, t2 = ko.Table(13, True).count_files([r1]), ko.Table(13, True).count_files([r2])
+    mx, cc, sp = ko.comp(t1, t2)
+    ko.write_comp(str(tmp_path / "want"), 13, [r1], [r2], 1001, 1001, mx, cc, sp, hists=True)
+    for suffix in ("-main.mx", ".stats", ".1.hist", ".2.hist"):
+        assert (tmp_path / "temp" / ("density_test" + suffix)).read_bytes() == (tmp_path / ("want" + suffix)).read_bytes(), suffix
+    assert (tmp_path / "want.stats").read_text() in r.stdout                     # stats block echoed to stdout (src/comp.cc:829-833)
+    # quoted glob group (tests/test_comp.sh: '${data}/ecoli_r?.1K.fastq') vs a FASTA, mixed canonical flags, scaling, small bins
+    asm = os.path.join(refdata, "sect_length_test.fa")
+    pattern = os.path.join(refdata, "ecoli_r?.1K.fastq")
+    r = run(["comp", "-m21", "-O", "-x", "0.5", "-y", "2", "-i", "40", "-j", "30", "-o", "glob_test", pattern, asm], tmp_path)
+    assert r.returncode == 0, r.stderr
+    t1, t2 = ko.Table(21, True).count_files([r1, r2]), ko.Table(21, False).count_files([asm])
+    mx, cc, sp = ko.comp(t1, t2, 0.5, 2.0, 40, 30)
+    ko.write_comp(str(tmp_path / "w2"), 21, [r1, r2], [asm], 40, 30, mx, cc, sp)
+    for suffix in ("-main.mx", ".stats"):
+        assert (tmp_path / ("glob_test" + suffix)).read_bytes() == (tmp_path / ("w2" + suffix)).read_bytes(), suffix
+
+
+def test_generated_pe_reads_vs_assembly(ko, tmp_path):
+    """Parity-scale version of BASELINE.json configs[3]: PE FASTQ + assembly FASTA written to disk, both sides read the files."""
+    g = synth.genome(300000, seed=20260927)
+    synth.write_fasta(str(tmp_path / "asm.fa"), g, contig_len=50000)
+    synth.write_fastq_pair(str(tmp_path / "lib_R1.fq"), str(tmp_path / "lib_R2.fq"), synth.reads(g, 0, 40000, seed=1))
+    r = run(["comp", "-m27", "-H", "3000000", "-o", "cmp", "lib_R?.fq", "asm.fa"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    p1, p2 = ["lib_R1.fq", "lib_R2.fq"], ["asm.fa"]
+    os.chdir(tmp_path)
+    t1, t2 = ko.Table(27, True).count_files(p1), ko.Table(27, True).count_files(p2)
+    mx, cc, sp = ko.comp(t1, t2)
+    ko.write_comp("want", 27, p1, p2, 1001, 1001, mx, cc, sp)
+    assert (tmp_path / "cmp-main.mx").read_bytes() == (tmp_path / "want-main.mx").read_bytes()
+    assert (tmp_path / "cmp.stats").read_bytes() == (tmp_path / "want.stats").read_bytes()
+
+
+def test_cli_exit_codes(refdata, tmp_path):
+    """src/kat.cc:286-302: option errors 1, KAT exceptions 4, std::exception 5."""
+    assert run(["hist", "--no-such-flag", "x.fa"], tmp_path).returncode == 1
+    r = run(["hist", "-m", "27", "does_not_exist.fa"], tmp_path)
+    assert r.returncode == 4 and "Could not find input file at: does_not_exist.fa" in r.stderr
+    r = run(["hist", "-l", "10", "-h", "5", os.path.join(refdata, "sect_test.fa")], tmp_path)
+    assert r.returncode == 4 and "High count value must be >= to low count value" in r.stderr
+    (tmp_path / "junk.fa").write_text("not a sequence file\n")
+    r = run(["hist", "-m", "27", "junk.fa"], tmp_path)
+    assert r.returncode == 5 and "Unsupported format" in r.stderr
+    r = run(["comp", "-m", "27", "-g", "-H", "1000", os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "sect_test.fa")], tmp_path)
+    assert r.returncode == 5 and "Hash full" in r.stderr
+    assert run(["sect", "x"], tmp_path).returncode == 1

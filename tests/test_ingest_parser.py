@@ -1,0 +1,97 @@
+"""The product's host ingest (kat_amd/csrc/kg_ingest.cpp, reached through the C ABI's katgpu_parse_file -- no GPU needed)
+against the oracle's parser and the naive record splitter: the base stream must be the records joined by 'N'."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import kat_amd
+from tests import naive
+from tests.test_oracle_vs_naive import write_messy_fasta, write_messy_fastq
+
+
+def stream_of(path):
+    return kat_amd.parse_file(str(path)).tobytes()
+
+
+def test_reference_data_files(ko, refdata):
+    for f in ("sect_test.fa", "sect_length_test.fa", "ecoli_r1.1K.fastq", "ecoli_r2.1K.fastq"):
+        p = os.path.join(refdata, f)
+        got = stream_of(p)
+        assert got == ko.parse_file(p).tobytes()
+        assert got == "N".join(naive.records(p)).encode("latin-1")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_messy_files(ko, tmp_path, seed):
+    rng = np.random.default_rng(seed)
+    fa, fq, fqm, gz = tmp_path / "m.fa", tmp_path / "m.fq", tmp_path / "mm.fq", tmp_path / "z.fq.gz"
+    write_messy_fasta(str(fa), rng)
+    write_messy_fastq(str(fq), rng)
+    write_messy_fastq(str(fqm), rng, multiline=True)
+    write_messy_fastq(str(gz), rng)
+    for p in (fa, fq, fqm, gz):
+        got = stream_of(p)
+        assert got == ko.parse_file(str(p)).tobytes(), p
+        assert got == "N".join(naive.records(str(p))).encode("latin-1"), p
+
+
+def test_edge_files(ko, tmp_path):
+    cases = {
+        "empty.fa": b"",
+        "header_only.fa": b">x\n",
+        "no_newline.fa": b">x\nACGT",
+        "crlf.fa": b">x\r\nACGT\r\nACGT\r\n>y\r\nTT\r\n",               # '\r' stays in the stream and breaks k-mers (quirk B8)
+        "blank_after_header.fa": b">a\n\n>ACGTACGT\nGG\n>c\nTT\n",       # blank line after a header: next line is sequence
+        "gt_inside.fa": b">a\nAC>GT\nAA\n",
+        "one.fq": b"@r\nACGT\n+\nIIII\n",
+        "no_final_newline.fq": b"@r\nACGT\n+\nIIII\n@s\nGG\n+\nII",       # tolerated (documented deviation)
+        "at_quality.fq": b"@r\nACGT\n+\n@III\n@s\nGGA\n+\n@@@\n",
+        "long_line.fa": b">x\n" + b"ACGT" * 6_000_000 + b"\n>y\nGATTACA\n",   # one 24 MB line: spans raw blocks
+    }
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        got = stream_of(p)
+        assert got == ko.parse_file(str(p)).tobytes(), name
+    assert stream_of(tmp_path / "crlf.fa") == b"ACGT\rACGT\rNTT\r"
+    assert stream_of(tmp_path / "blank_after_header.fa") == b">ACGTACGTGGNTT"
+    assert stream_of(tmp_path / "no_final_newline.fq") == b"ACGTNGG"
+    assert stream_of(tmp_path / "at_quality.fq") == b"ACGTNGGA"
+
+
+def test_trim5p(ko, tmp_path):
+    p = tmp_path / "t.fq"
+    p.write_bytes(b"@a\nACGTACGT\n+\nIIIIIIII\n@b\nTTGGCCAA\n+\nIIIIIIII\n")
+    assert kat_amd.parse_file(str(p), 3).tobytes() == b"TACGTNGCCAA" == ko.parse_file(str(p), 3).tobytes()
+    f = tmp_path / "t.fa"
+    f.write_bytes(b">a\nACGTACGT\nAAAA\n>b\nTTGGCCAA\n")
+    assert kat_amd.parse_file(str(f), 2).tobytes() == b"GTACGTAAAANGGCCAA" == ko.parse_file(str(f), 2).tobytes()
+
+
+def test_errors(ko, tmp_path):
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        kat_amd.parse_file(str(tmp_path / "nope.fa"))
+    assert ei.value.code == 2 and "Could not find input file at" in ei.value.message
+    bad = tmp_path / "bad.dat"
+    bad.write_bytes(b"hello\n")
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        kat_amd.parse_file(str(bad))
+    assert ei.value.code == 3 and ei.value.message == "Unsupported format"
+    with pytest.raises(ko.OracleError) as oi:
+        ko.parse_file(str(bad))
+    assert oi.value.code == 2
+    for name, data in (("short_q.fq", b"@r\nACGTACGT\n+\nIIII\n@s\nAC\n+\nII\n"), ("trunc.fq", b"@r\nACGT\n+\nII"),
+                       ("long_q.fq", b"@r\nACGT\n+\nIIIIIIII\n@s\nAC\n+\nII\n"), ("noplusq.fq", b"@r\nACGT\n+\n"),
+                       # an empty read: the blank line after the header makes the reference's parser read the '+' line as
+                       # sequence (mer_overlap_sequence_parser.hpp:254-258), and the record then fails the quality-length check
+                       ("empty_read.fq", b"@r\n\n+\n\n@s\nGGA\n+\nIII\n")):
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(kat_amd.KatGpuError) as ei:
+            kat_amd.parse_file(str(p))
+        assert ei.value.code == 4 and ei.value.message == "Invalid fastq sequence", name
+        with pytest.raises(ko.OracleError) as oi:
+            ko.parse_file(str(p))
+        assert oi.value.code == 3, name
