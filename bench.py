@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--err-ppm", type=int, default=2000, help="substitution errors per million bases (0.2 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="sync + print per-phase wall time (diagnostic; perturbs the timing)")
     ap.add_argument("--cpu-sample-reads", type=int, default=8_000_000)
     return ap.parse_args()
 
@@ -100,11 +101,25 @@ def main():
 
     results = {}
 
+    phases = {}
+
+    def mark(name, t_prev):
+        if a.phases:
+            eng.sync()
+            now = time.perf_counter()
+            phases[name] = phases.get(name, 0.0) + (now - t_prev)
+            return now
+        return t_prev
+
     def step():
+        tp = time.perf_counter()
         t1 = eng.table(k, True, size_hint=hint1)
+        tp = mark("alloc1", tp)
         t1.count_bases_device(reads.ptr, reads.nbytes)
+        tp = mark("count_reads", tp)
         t2 = eng.table(k, True, size_hint=hint2)
         t2.count_bases_device(asm_ptr, asm_bytes)
+        tp = mark("alloc2+count_asm", tp)
         if world > 1:
             s1, s2 = kdist.HipShard(t1), kdist.HipShard(t2)
             o1 = kdist.exchange_merge(s1)
@@ -112,13 +127,16 @@ def main():
             o2 = kdist.exchange_merge(s2)
             t2.free()
             t1, t2 = o1.table, o2.table
+            tp = mark("exchange", tp)
         mx, cc, sp = kat_amd.comp(t1, t2)
+        tp = mark("comp", tp)
         if world > 1:
             mx, cc, sp = kdist.allreduce_u64([mx, cc, sp], dev)
         results["mx"], results["cc"], results["sp"] = mx, cc, sp
         results["distinct1"] = t1.stats(want_total=False)["distinct"]
         t1.free()
         t2.free()
+        tp = mark("free", tp)
 
     for _ in range(a.warmup):
         step()
@@ -146,6 +164,8 @@ def main():
     cc = results["cc"]
     ok = int(cc[0]) == world * inst_reads and int(cc[1]) == inst_asm_total
 
+    if a.phases and rank == 0:
+        print("phases (s, summed over steps):", {n: round(v, 3) for n, v in phases.items()}, file=sys.stderr)
     if rank == 0:
         # ---- roofline of the dominant kernel (k_count), from HIP events recorded on katgpu's own stream ----
         pc = prof["count"]

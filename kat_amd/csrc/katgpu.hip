@@ -7,8 +7,11 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace kg;
@@ -34,6 +37,12 @@ struct katgpu_ctx {
     uint8_t* dev_stage[2] = {nullptr, nullptr};
     hipEvent_t stage_free[2] = {nullptr, nullptr};   // kernel that read dev_stage[i] has finished
     size_t stage_bytes = 0;
+    // Freed table arrays are parked here and handed out again to the next table of (nearly) the same size: on this
+    // driver a hipMalloc of tens of GB right after a hipFree of that much stalls for seconds (VRAM scrubbing), which
+    // would dominate a run that builds tables repeatedly.  Emptied by katgpu_shutdown or when an allocation fails.
+    struct Block { void* p; size_t bytes; };
+    std::vector<Block> pool;
+    std::unordered_map<void*, size_t> block_bytes;      // real size of every live pooled-class allocation
 };
 
 struct katgpu_table {
@@ -100,6 +109,8 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream); hipStreamSynchronize(c->copy_stream);
     resolve_pending(c);
+    for (auto& b : c->pool) hipFree(b.p);
+    c->pool.clear();
     for (auto e : c->event_pool) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (c->pinned[i]) hipHostFree(c->pinned[i]);
@@ -161,16 +172,57 @@ static int grid_for(katgpu_ctx* c, uint64_t items, int block, int per_cu) {
 
 // ------------------------------------------------------------------ table lifecycle ------------------
 
+static double now_ms() {
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+}
+static const bool g_trace = getenv("KATGPU_TRACE") != nullptr;
+
+static void pool_trim(katgpu_ctx* c) {
+    for (auto& b : c->pool) hipFree(b.p);
+    c->pool.clear();
+}
+
+static hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes) {
+    size_t got = bytes;
+    size_t* got_bytes = &got;
+    struct Reg { katgpu_ctx* c; void** p; size_t* b; ~Reg() { if (*p) c->block_bytes[*p] = *b; } } reg{c, p, got_bytes};
+    *p = nullptr;
+    int best = -1;
+    for (size_t i = 0; i < c->pool.size(); ++i)
+        if (c->pool[i].bytes >= bytes && c->pool[i].bytes <= bytes + bytes / 4 && (best < 0 || c->pool[i].bytes < c->pool[best].bytes)) best = (int)i;
+    if (best >= 0) {
+        *p = c->pool[best].p; *got_bytes = c->pool[best].bytes;
+        c->pool.erase(c->pool.begin() + best);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && !c->pool.empty()) { (void)hipGetLastError(); pool_trim(c); e = hipMalloc(p, bytes); }
+    *got_bytes = bytes;
+    return e;
+}
+
+static void pool_release(katgpu_ctx* c, void* p) {
+    if (!p) return;
+    auto it = c->block_bytes.find(p);
+    const size_t bytes = it == c->block_bytes.end() ? 0 : it->second;
+    if (it != c->block_bytes.end()) c->block_bytes.erase(it);
+    if (bytes < ((size_t)64 << 20) || c->pool.size() >= 8) { hipFree(p); return; }    // small blocks are not worth parking
+    c->pool.push_back({p, bytes});
+}
+
 static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out) {
     DevTable d{};
     d.cap = cap; d.k = k; d.canonical = canonical ? 1 : 0;
-    HIPCHK(c, hipMalloc(&d.keys, cap * sizeof(uint64_t)));
-    hipError_t e = hipMalloc(&d.counts, cap * sizeof(uint32_t));
+    const double t0 = now_ms();
+    HIPCHK(c, pool_alloc(c, (void**)&d.keys, cap * sizeof(uint64_t)));
+    if (g_trace) fprintf(stderr, "[katgpu] alloc keys %.1f GB: %.1f ms\n", cap * 8 / 1e9, now_ms() - t0);
+    hipError_t e = pool_alloc(c, (void**)&d.counts, cap * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&d.ovf_keys, OVF_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&d.ovf_hi, OVF_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&d.ctrs, CTR_WORDS * sizeof(uint64_t));
     if (e != hipSuccess) {
-        hipFree(d.keys); hipFree(d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
+        pool_release(c, d.keys); pool_release(c, d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
         return fail(c, KATGPU_ERR_NOMEM, "device allocation of a %llu-slot table failed: %s", (unsigned long long)cap, hipGetErrorString(e));
     }
     HIPCHK(c, hipMemsetAsync(d.keys, 0xFF, cap * sizeof(uint64_t), c->stream));
@@ -178,12 +230,14 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
     HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_hi, 0, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ctrs, 0, CTR_WORDS * sizeof(uint64_t), c->stream));
+    if (g_trace) { const double t1 = now_ms(); hipStreamSynchronize(c->stream); fprintf(stderr, "[katgpu] table alloc: mallocs+enqueue %.1f ms, memsets done after %.1f ms more\n", t1 - t0, now_ms() - t1); }
     *out = d;
     return KATGPU_OK;
 }
 
-static void free_dev_table(DevTable& d) {
-    hipFree(d.keys); hipFree(d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
+static void free_dev_table(katgpu_ctx* c, DevTable& d) {
+    pool_release(c, d.keys); pool_release(c, d.counts);
+    hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
     d = DevTable{};
 }
 
@@ -205,7 +259,7 @@ extern "C" void katgpu_table_free(katgpu_table* t) {
     if (!t) return;
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
-    free_dev_table(t->d);
+    free_dev_table(t->ctx, t->d);
     delete t;
 }
 
@@ -240,7 +294,7 @@ static int regrow(katgpu_table* t, uint64_t new_cap) {
     }
     HIPCHK(c, hipMemcpyAsync(&nd.ctrs[CTR_ONES], &t->d.ctrs[CTR_ONES], sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_dev_table(t->d);
+    free_dev_table(c, t->d);
     t->d = nd;
     return refresh_counters(t);
 }
