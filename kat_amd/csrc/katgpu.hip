@@ -52,6 +52,9 @@ struct katgpu_table {
     uint32_t n_ovf = 0;          // refreshed by refresh_counters()
     uint64_t distinct = 0;       // idem (slots in use + all-ones key)
     uint64_t ones = 0;
+    // overflow guard of the unchecked (no-return) +1 adds: no 32-bit counter exceeds count_bound + unchecked_adds
+    uint64_t count_bound = 0;    // largest counter value possible at the last sweep (0 for a fresh table)
+    uint64_t unchecked_adds = 0; // window starts launched through k_count since then
     uint8_t carry[64];           // last k-1 bytes of the previous host batch of the current file
     uint32_t carry_n = 0;
 };
@@ -313,9 +316,38 @@ static int ensure_room(katgpu_table* t, uint64_t incoming) {
 
 // ------------------------------------------------------------------ counting --------------------------
 
+// test hooks (tests/test_gpu_parity.py): shrink the sweep threshold / the launch size so small inputs exercise them
+static const uint64_t g_test_sweep_thr = getenv("KATGPU_TEST_SWEEP_THR") ? strtoull(getenv("KATGPU_TEST_SWEEP_THR"), nullptr, 10) : 0;
+static const uint64_t g_test_max_starts = getenv("KATGPU_TEST_MAX_STARTS") ? strtoull(getenv("KATGPU_TEST_MAX_STARTS"), nullptr, 10) : 0;
+
+// k_count adds with no-return atomics and cannot see a 32-bit wrap; make one impossible.  Invariant: every counter
+// <= count_bound + unchecked_adds.  When the next launch could break "<= 2^32-1", k_sweep moves multiples of thr out of
+// the large counters into the side table and reports the new maximum.
+static int maybe_sweep(katgpu_table* t, uint64_t next_starts) {
+    katgpu_ctx* c = t->ctx;
+    const uint64_t limit = g_test_sweep_thr ? 2 * g_test_sweep_thr - 1 : 0xFFFFFFFFULL;
+    if (t->count_bound + t->unchecked_adds + next_starts <= limit) return KATGPU_OK;
+    const uint32_t thr = g_test_sweep_thr ? (uint32_t)g_test_sweep_thr : 0x80000000u;
+    unsigned long long* scratch = (unsigned long long*)&t->d.ctrs[CTR_SCRATCH];
+    HIPCHK(c, hipMemsetAsync(scratch, 0, sizeof(uint64_t), c->stream));
+    {
+        ScopedTimer tm(c, KATGPU_K_REGROW, t->d.cap);
+        hipLaunchKernelGGL(k_sweep, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, thr, scratch);
+    }
+    uint64_t mx = 0;
+    HIPCHK(c, hipMemcpyAsync(&mx, scratch, sizeof mx, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    t->count_bound = mx;
+    t->unchecked_adds = 0;
+    return KATGPU_OK;
+}
+
 static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
     katgpu_ctx* c = t->ctx;
     if (n < t->d.k) return KATGPU_OK;
+    int src = maybe_sweep(t, n);
+    if (src) return src;
+    t->unchecked_adds += n;
     const uint64_t n_chunks = (n + CHUNK_STARTS - 1) / CHUNK_STARTS;
     const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * 8);
     ScopedTimer tm(c, KATGPU_K_COUNT, n);
@@ -343,6 +375,7 @@ extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bas
         // largest batch that provably fits; if even a minimal one does not, grow first
         uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
         uint64_t want = std::min<uint64_t>(n_starts - pos, (uint64_t)CHUNK_STARTS * 65536);   // <= 266 M starts per launch
+        if (g_test_max_starts) want = std::min<uint64_t>(want, g_test_max_starts);
         // As the table fills, launches shrink to the remaining room (each adds far fewer distinct k-mers than window
         // starts on real coverage, so the room shrinks slowly); only when the room is down to 1/64 of the table do we grow.
         if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 64, CHUNK_STARTS))) {
@@ -594,6 +627,7 @@ extern "C" int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_ke
             continue;
         }
         uint64_t take = std::min(want, room);
+        t->count_bound = 0xFFFFFFFFULL;          // merged amounts are arbitrary: the next k_count launch sweeps first
         {
             ScopedTimer tm(c, KATGPU_K_MERGE, take);
             hipLaunchKernelGGL(k_merge, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->d, dev_keys + pos, dev_counts + pos, take);

@@ -3,8 +3,9 @@
 //
 // Table layout ("KV12"): keys[cap] (u64, 0xFFFF..F = empty) and counts[cap] (u32) as two separate
 // arrays so that the slot scan of the reducers is two perfectly coalesced streams (8 B and 4 B per lane).
-// Counts are exact to 64 bits: a 32-bit carry is chained into a small side table, the same idea as
-// Jellyfish's "large" entries (deps/jellyfish-2.2.0/include/jellyfish/large_hash_array.hpp:668-700), and
+// Counts are exact to 64 bits: whatever does not fit the 32-bit slot counter is chained into a small side table
+// (key -> extra amount), the same idea as Jellyfish's "large" entries
+// (deps/jellyfish-2.2.0/include/jellyfish/large_hash_array.hpp:668-700): count = counts[slot] + extra[key].  and
 // the one key that collides with the empty marker (k = 32, all T, non-canonical) lives in a scalar.
 // The layout is free to differ from Jellyfish's bit-packed array because hist/gcp/comp are
 // order-independent sums over the multiset {(k-mer, count)}.
@@ -15,7 +16,7 @@
 namespace kg {
 
 constexpr uint64_t EMPTY = ~0ULL;
-constexpr uint32_t OVF_CAP = 4096;       // side table for 2^32 carries; a key needs > 4.29e9 hits to enter
+constexpr uint32_t OVF_CAP = 4096;       // side table for amounts beyond 32 bits; a key needs > 2.1e9 hits to enter
 constexpr uint32_t MAX_PROBE = 1u << 14; // linear probes before the table is declared full
 
 // ctrs[] layout (u64 each)
@@ -32,7 +33,7 @@ struct DevTable {
     uint32_t* counts;
     uint64_t cap;
     uint64_t* ovf_keys;   // OVF_CAP
-    uint64_t* ovf_hi;     // OVF_CAP, units of 2^32
+    uint64_t* ovf_hi;     // OVF_CAP, extra amount (added to the slot's 32-bit counter)
     uint64_t* ctrs;       // CTR_WORDS
     uint32_t k;
     uint32_t canonical;
@@ -74,7 +75,7 @@ __device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t k, uint32_t 
 }
 
 // ---- carry side table ----
-__device__ inline void ovf_add(const DevTable& t, uint64_t key, uint64_t hi) {
+__device__ inline void ovf_add(const DevTable& t, uint64_t key, uint64_t hi /* extra amount */) {
     uint32_t p = (uint32_t)(mix64(key) >> 40) & (OVF_CAP - 1);
     for (uint32_t i = 0; i < OVF_CAP; ++i) {
         uint64_t cur = atomicCAS((unsigned long long*)&t.ovf_keys[p], (unsigned long long)EMPTY, (unsigned long long)key);
@@ -98,7 +99,7 @@ __device__ inline uint64_t ovf_get(const DevTable& t, uint64_t key) {
 // full 64-bit count of an occupied slot
 __device__ __forceinline__ uint64_t slot_count(const DevTable& t, uint64_t pos, uint64_t key, uint32_t n_ovf) {
     uint64_t c = t.counts[pos];
-    if (n_ovf) c += ovf_get(t, key) << 32;
+    if (n_ovf) c += ovf_get(t, key);
     return c;
 }
 
@@ -120,7 +121,31 @@ __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint6
             uint64_t hi = amount >> 32;
             uint32_t old = atomicAdd(&t.counts[pos], low);
             if ((uint64_t)old + low > 0xFFFFFFFFULL) ++hi;
-            if (hi) ovf_add(t, key, hi);
+            if (hi) ovf_add(t, key, hi << 32);
+            return true;
+        }
+        if (++pos == t.cap) pos = 0;
+    }
+    atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 1ULL);
+    return false;
+}
+
+// +1 on the hot path of K1: same claim protocol, but the counter add is a NO-RETURN atomic, so a lane never waits for
+// it (measured on MI355X: load + returning add chain 12-15 G k-mers/s, load + no-return add 20.7 G/s; the L2 atomic
+// units saturate at ~22 G adds/s).  Without the returned value a 32-bit wrap cannot be seen here; the host instead
+// guarantees it cannot happen: before the adds launched since the last k_sweep could lift any counter past 2^32-1 it
+// runs k_sweep, which moves 2^31 from every counter >= 2^31 into the side table (katgpu.hip: maybe_sweep).
+__device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint32_t& new_distinct) {
+    if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], 1ULL); return true; }
+    uint64_t pos = slot_of(key, t.cap);
+    for (uint32_t probe = 0; probe < MAX_PROBE; ++probe) {
+        uint64_t cur = t.keys[pos];
+        if (cur == EMPTY) {
+            cur = atomicCAS((unsigned long long*)&t.keys[pos], (unsigned long long)EMPTY, (unsigned long long)key);
+            if (cur == EMPTY) { ++new_distinct; cur = key; }
+        }
+        if (cur == key) {
+            (void)__hip_atomic_fetch_add(&t.counts[pos], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }
         if (++pos == t.cap) pos = 0;

@@ -92,7 +92,7 @@ k_count(DevTable t, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_ch
                     uint64_t fwd = hi >> kshift;
                     uint64_t key = fwd;
                     if (canonical) { uint64_t rc = kmer_revcomp(fwd, k); key = rc < fwd ? rc : fwd; }
-                    table_add(t, key, 1, new_distinct);
+                    table_inc(t, key, new_distinct);
                 }
                 hi = (hi << 2) | (lo >> 62);
                 lo <<= 2;
@@ -123,6 +123,27 @@ k_merge(DevTable dst, const uint64_t* __restrict__ keys, const uint64_t* __restr
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         if (counts[i]) table_add(dst, keys[i], counts[i], new_distinct);
     flush_distinct(dst, new_distinct);
+}
+
+// Overflow guard for table_inc's unchecked 32-bit adds: every counter >= thr gives thr to the side table.  Reports the
+// largest counter left behind (scratch[0], atomicMax) so the host knows how many more unchecked adds are safe.
+__global__ void __launch_bounds__(256)
+k_sweep(DevTable t, uint32_t thr, unsigned long long* scratch) {
+    uint32_t mx = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.cap; i += stride) {
+        uint32_t c = t.counts[i];
+        if (c >= thr) {
+            uint64_t key = t.keys[i];
+            uint32_t take = (c / thr) * thr;
+            c -= take;
+            t.counts[i] = c;
+            ovf_add(t, key, take);
+        }
+        mx = c > mx ? c : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0) atomicMax(scratch, (unsigned long long)mx);
 }
 
 // Σ counts (table_stats "total")

@@ -230,3 +230,30 @@ def test_errors(engine, tmp_path):
     with pytest.raises(kat_amd.KatGpuError) as ei:
         kat_amd.comp(engine.table(21, True), engine.table(27, True))
     assert ei.value.code == 9
+
+
+def test_unchecked_add_sweep_guard(ko, tmp_path):
+    """k_count adds with no-return atomics; a host-side guard sweeps large counters into the side table before a 32-bit
+    wrap becomes possible.  The test hooks shrink the threshold (64) and the launch size so a small input runs through
+    hundreds of sweeps; the table must still equal the oracle's."""
+    import subprocess
+    import sys
+    g = synth.genome(3000, seed=13)
+    s = np.concatenate([np.frombuffer(b"A" * 3000 + b"N" + b"ACGT" * 500 + b"N", np.uint8), synth.reads(g, 0, 600, seed=2)])
+    np.save(tmp_path / "s.npy", s)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import kat_amd\n"
+        "s = np.load(%r)\n"
+        "e = kat_amd.Engine(0)\n"
+        "t = e.table(21, True, size_hint=1 << 14).count_bases(s)\n"
+        "k, c = t.dump_sorted(); np.savez(%r, k=k, c=c, h=t.hist(1, 5000, 1), regrow=e.profile()['regrow']['launches'])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "s.npy"), str(tmp_path / "out.npz"))
+    env = dict(os.environ, KATGPU_TEST_SWEEP_THR="64", KATGPU_TEST_MAX_STARTS="64")
+    subprocess.run([sys.executable, "-c", code], env=env, check=True, timeout=600)
+    got = np.load(tmp_path / "out.npz")
+    ot = ko.Table(21, True).count_bases(s)
+    ok_, oc = ot.dump_sorted()
+    assert np.array_equal(got["k"], ok_) and np.array_equal(got["c"], oc)
+    assert int(oc.max()) >= 2980 and np.array_equal(got["h"], ot.hist(1, 5000, 1))
+    assert int(got["regrow"]) > 100                     # sweeps are accounted under the regrow class

@@ -6,7 +6,7 @@
 #include <vector>
 using namespace kg;
 
-enum Mode { FULL = 0, EXTRACT_ONLY = 1, LOAD_ONLY = 2, ADD_NORET = 3, ADD_WG_SCOPE = 4, PLAIN_RMW = 5, ADD_ONLY_RET = 6, LOAD_NT = 7 };
+enum Mode { FULL = 0, EXTRACT_ONLY = 1, LOAD_ONLY = 2, ADD_NORET = 3, ADD_WG_SCOPE = 4, PLAIN_RMW = 5, ADD_ONLY_RET = 6, LOAD_NT = 7, LOAD_ADD_NORET = 8, PIPELINED = 9 };
 
 template <int MODE>
 __global__ void __launch_bounds__(COUNT_BLOCK)
@@ -30,6 +30,26 @@ u_count(DevTable t, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_ch
             uint64_t lo = (uint64_t)s_code[tid + 2] << 32;
             uint64_t m = ((uint64_t)s_bad[tid] << 48) | ((uint64_t)s_bad[tid + 1] << 32) | ((uint64_t)s_bad[tid + 2] << 16);
             const uint32_t kshift = 64 - 2 * k, mshift = 64 - k;
+            if (MODE == PIPELINED) {
+                uint64_t keyv[BASES_PER_LANE], posv[BASES_PER_LANE], cur[BASES_PER_LANE];
+                bool okv[BASES_PER_LANE];
+#pragma unroll
+                for (int j = 0; j < BASES_PER_LANE; ++j) {
+                    okv[j] = (m >> mshift) == 0;
+                    uint64_t fwd = hi >> kshift, rc = kmer_revcomp(fwd, k);
+                    keyv[j] = rc < fwd ? rc : fwd;
+                    posv[j] = slot_of(keyv[j], t.cap);
+                    hi = (hi << 2) | (lo >> 62); lo <<= 2; m <<= 1;
+                }
+#pragma unroll
+                for (int j = 0; j < BASES_PER_LANE; ++j) cur[j] = okv[j] ? t.keys[posv[j]] : 0;
+#pragma unroll
+                for (int j = 0; j < BASES_PER_LANE; ++j) {
+                    if (!okv[j]) continue;
+                    if (cur[j] == keyv[j]) atomicAdd(&t.counts[posv[j]], 1u);
+                    else table_add(t, keyv[j], 1, new_distinct);
+                }
+            } else
 #pragma unroll 4
             for (int j = 0; j < BASES_PER_LANE; ++j) {
                 if ((m >> mshift) == 0) {
@@ -46,6 +66,7 @@ u_count(DevTable t, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_ch
                         if (MODE == ADD_ONLY_RET) acc ^= atomicAdd(&t.counts[pos], 1u);
                         if (MODE == ADD_WG_SCOPE) __hip_atomic_fetch_add(&t.counts[pos], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (MODE == PLAIN_RMW) t.counts[pos] = t.counts[pos] + 1;
+                        if (MODE == LOAD_ADD_NORET) { if (t.keys[pos] == key) atomicAdd(&t.counts[pos], 1u); else acc ^= pos; }
                     }
                 }
                 hi = (hi << 2) | (lo >> 62); lo <<= 2; m <<= 1;
@@ -88,14 +109,16 @@ int main(int argc, char** argv) {
     unsigned long long* sink; CK(hipMalloc(&sink, 8)); CK(hipMemset(sink, 0, 8));
     const uint64_t nb = n_reads * 151, inst = n_reads * 124;
     printf("bases %llu, k-mer instances %llu, table %llu slots (%.1f MB)\n", (unsigned long long)nb, (unsigned long long)inst, (unsigned long long)t.cap, t.cap * 12 / 1e6);
-    for (int grid : {2048, 4096, 1536, 1024}) {
+    for (int grid : {2048, 1536}) {
         printf("grid %d\n", grid);
         for (int rep = 0; rep < 2; ++rep) {
             float f = run<FULL>(t, bases, nb, grid, sink, rep == 0);
             printf("  FULL%s          %8.2f ms  %6.2f G k-mers/s\n", rep ? " (2nd pass)" : " (1st pass)", f, inst / f / 1e6);
         }
-        const char* names[] = {"", "EXTRACT_ONLY", "LOAD_ONLY", "ADD_NORET", "ADD_WG_SCOPE", "PLAIN_RMW", "ADD_ONLY_RET", "LOAD_NT"};
-        float r[8];
+        const char* names[] = {"", "EXTRACT_ONLY", "LOAD_ONLY", "ADD_NORET", "ADD_WG_SCOPE", "PLAIN_RMW", "ADD_ONLY_RET", "LOAD_NT", "LOAD_ADD_NORET", "PIPELINED"};
+        float r[10];
+        r[8] = run<LOAD_ADD_NORET>(t, bases, nb, grid, sink, false);
+        r[9] = run<PIPELINED>(t, bases, nb, grid, sink, false);
         r[1] = run<EXTRACT_ONLY>(t, bases, nb, grid, sink, false);
         r[2] = run<LOAD_ONLY>(t, bases, nb, grid, sink, false);
         r[3] = run<ADD_NORET>(t, bases, nb, grid, sink, false);
@@ -103,7 +126,7 @@ int main(int argc, char** argv) {
         r[5] = run<PLAIN_RMW>(t, bases, nb, grid, sink, false);
         r[6] = run<ADD_ONLY_RET>(t, bases, nb, grid, sink, false);
         r[7] = run<LOAD_NT>(t, bases, nb, grid, sink, false);
-        for (int i = 1; i < 8; ++i) printf("  %-14s %8.2f ms  %6.2f G k-mers/s\n", names[i], r[i], inst / r[i] / 1e6);
+        for (int i = 1; i < 10; ++i) printf("  %-14s %8.2f ms  %6.2f G k-mers/s\n", names[i], r[i], inst / r[i] / 1e6);
     }
     return 0;
 }
