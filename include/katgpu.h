@@ -131,7 +131,7 @@ int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, const uint64_
 /* ---- measurement ------------------------------------------------------------------------------------- */
 /* HIP-event timing of the kernels this ctx launched, per kernel class, accumulated since the last reset. */
 typedef enum katgpu_kernel {
-    KATGPU_K_COUNT = 0,      /* extract + canonicalise + insert */
+    KATGPU_K_COUNT = 0,      /* direct counter: extract + canonicalise + insert (one atomic per k-mer) */
     KATGPU_K_REGROW = 1,
     KATGPU_K_HIST = 2,
     KATGPU_K_GCP = 3,
@@ -139,7 +139,10 @@ typedef enum katgpu_kernel {
     KATGPU_K_COMP_PASS2 = 5,
     KATGPU_K_PARTITION = 6,
     KATGPU_K_MERGE = 7,
-    KATGPU_K_NCLASSES = 8
+    KATGPU_K_PART_L1 = 8,    /* partitioned counter: extract + level-1 radix partition (histogram, scan, scatter) */
+    KATGPU_K_PART_L2 = 9,    /* level-2 partition: one run per table region */
+    KATGPU_K_PART_APPLY = 10,/* regions updated in LDS */
+    KATGPU_K_NCLASSES = 11
 } katgpu_kernel;
 int katgpu_profile_reset(katgpu_ctx* ctx);
 int katgpu_profile_get(katgpu_ctx* ctx, int kernel_class, uint64_t* launches, double* total_ms, uint64_t* units);

@@ -3,6 +3,7 @@
 #include "../../include/katgpu.h"
 #include "kg_ingest.hpp"
 #include "kg_kernels.hpp"
+#include "kg_partition.hpp"
 
 #include <algorithm>
 #include <cstdarg>
@@ -43,6 +44,10 @@ struct katgpu_ctx {
     struct Block { void* p; size_t bytes; };
     std::vector<Block> pool;
     std::unordered_map<void*, size_t> block_bytes;      // real size of every live pooled-class allocation
+    // scratch arena of the partitioned counter (level-1 / level-2 buffers, histograms); kept across calls
+    uint8_t* arena = nullptr;
+    size_t arena_bytes = 0;
+    bool part_attr_set = false;
 };
 
 struct katgpu_table {
@@ -114,6 +119,7 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
     resolve_pending(c);
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
+    if (c->arena) hipFree(c->arena);
     for (auto e : c->event_pool) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (c->pinned[i]) hipHostFree(c->pinned[i]);
@@ -200,7 +206,12 @@ static hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes) {
         return hipSuccess;
     }
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && !c->pool.empty()) { (void)hipGetLastError(); pool_trim(c); e = hipMalloc(p, bytes); }
+    if (e != hipSuccess && (!c->pool.empty() || c->arena)) {           // give cached scratch back and retry once
+        (void)hipGetLastError();
+        pool_trim(c);
+        if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+        e = hipMalloc(p, bytes);
+    }
     *got_bytes = bytes;
     return e;
 }
@@ -214,8 +225,18 @@ static void pool_release(katgpu_ctx* c, void* p) {
     c->pool.push_back({p, bytes});
 }
 
+static const uint32_t g_region_slots = getenv("KATGPU_TEST_REGION_SLOTS") ? (uint32_t)strtoul(getenv("KATGPU_TEST_REGION_SLOTS"), nullptr, 10) : REGION_SLOTS;
+
 static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out) {
     DevTable d{};
+    // capacity is a whole number of regions (kg_device.hpp: Probe); a table smaller than one region is a single short region
+    if (cap <= g_region_slots) { d.n_regions = 1; d.region_slots = (uint32_t)cap; }
+    else {
+        const uint64_t nr = (cap + g_region_slots - 1) / g_region_slots;
+        if (nr > 0x7FFFFFFFULL) return fail(c, KATGPU_ERR_NOMEM, "table of %llu slots exceeds the region index", (unsigned long long)cap);
+        d.n_regions = (uint32_t)nr; d.region_slots = g_region_slots;
+    }
+    cap = (uint64_t)d.n_regions * d.region_slots;
     d.cap = cap; d.k = k; d.canonical = canonical ? 1 : 0;
     const double t0 = now_ms();
     HIPCHK(c, pool_alloc(c, (void**)&d.keys, cap * sizeof(uint64_t)));
@@ -349,7 +370,9 @@ static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
     if (src) return src;
     t->unchecked_adds += n;
     const uint64_t n_chunks = (n + CHUNK_STARTS - 1) / CHUNK_STARTS;
-    const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * 8);
+    // 6 resident 256-thread blocks per CU is what k_count's 106 SGPRs admit (MI355X_MICROARCH.md, residency rule); a
+    // larger grid leaves a second, thinly populated wave of blocks: measured 12.7 (8/CU) vs 15.5 G k-mers/s (6/CU)
+    const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * 6);
     ScopedTimer tm(c, KATGPU_K_COUNT, n);
     if ((reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0)
         hipLaunchKernelGGL(k_count<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
@@ -357,6 +380,126 @@ static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
         hipLaunchKernelGGL(k_count<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
     HIPCHK(c, hipGetLastError());
     return KATGPU_OK;
+}
+
+
+// ------------------------------------------------------------------ partitioned counter (kg_partition.hpp) ----
+
+static const uint64_t g_part_min_starts = getenv("KATGPU_PART_MIN_STARTS") ? strtoull(getenv("KATGPU_PART_MIN_STARTS"), nullptr, 10) : (32ULL << 20);
+static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? strtoull(getenv("KATGPU_TEST_ROUND_ITEMS"), nullptr, 10) : 0;
+
+static bool part_geometry(const DevTable& d, PartGeom* g) {
+    g->R = d.n_regions; g->S = d.region_slots;
+    uint32_t p2 = 1;
+    while ((uint64_t)p2 * p2 < g->R) ++p2;
+    g->P2 = p2;
+    g->P1 = (g->R + p2 - 1) / p2;
+    return g->P1 <= MAX_PARTS && g->P2 <= MAX_PARTS && (size_t)g->S * 12 <= 150 * 1024;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Count a resident, 16-byte aligned base stream through partition rounds.  *done = number of window starts consumed
+// (all of them unless the geometry stops fitting, in which case the caller finishes with the direct kernel).
+static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n, size_t* done) {
+    katgpu_ctx* c = t->ctx;
+    const uint32_t k = t->d.k;
+    const size_t n_starts = n - k + 1;
+    *done = 0;
+    const uint32_t W = (uint32_t)c->n_cu;
+    if (!c->part_attr_set) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        c->part_attr_set = true;
+    }
+    // ---- arena: [hist1 | offs | l1_off | off2 | spill_n | L1 buffer | L2 buffer] ----
+    const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +
+                               align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) + 256;
+    size_t want_items = std::min<size_t>(n_starts, 0xFFFFFFFFULL - TILE_ITEMS);
+    if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
+    if (c->arena_bytes < small_bytes + 16 * std::min<size_t>(want_items, (size_t)64 << 20)) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        free_b += c->arena_bytes;
+        size_t bytes = std::min<size_t>(small_bytes + 16 * want_items, (size_t)(0.8 * (double)free_b));
+        if (bytes > c->arena_bytes) {
+            if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
+            if (bytes < small_bytes + 16 * ((size_t)1 << 20)) return KATGPU_OK;          // no room for a useful round: direct path
+            HIPCHK(c, hipMalloc((void**)&c->arena, bytes));
+            c->arena_bytes = bytes;
+        }
+    }
+    uint8_t* a = c->arena;
+    uint32_t* hist1 = (uint32_t*)a;               a += align_up((size_t)W * MAX_PARTS * 4, 256);
+    uint64_t* offs = (uint64_t*)a;                a += align_up((size_t)W * MAX_PARTS * 8, 256);
+    uint64_t* l1_off = (uint64_t*)a;              a += align_up((MAX_PARTS + 1) * 8, 256);
+    uint64_t* off2 = (uint64_t*)a;                a += align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256);
+    unsigned long long* spill_n = (unsigned long long*)a; a += 256;
+    const size_t round_items = std::min<size_t>(want_items, (c->arena_bytes - small_bytes) / 16);
+    uint64_t* l1_buf = (uint64_t*)a;
+    uint64_t* l2_buf = l1_buf + round_items;
+    if (round_items < ((size_t)1 << 20) && round_items < n_starts) return KATGPU_OK;
+
+    size_t pos = 0;
+    while (pos < n_starts) {
+        int rc = refresh_counters(t);
+        if (rc) return rc;
+        if ((double)t->distinct > 0.6 * (double)t->d.cap) {
+            if (t->disable_grow) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
+            rc = regrow(t, t->d.cap * 2);
+            if (rc) return rc;
+        }
+        PartGeom g;
+        if (!part_geometry(t->d, &g)) break;                                      // table too large for two levels: direct path
+        size_t m = std::min(n_starts - pos, round_items);
+        if (m < n_starts - pos) m -= m % L1_TILE_STARTS;                          // whole tiles, keeps the next round 16-byte aligned
+        const size_t nb = m + k - 1;
+        const uint8_t* p = dev_bases + pos;
+        rc = maybe_sweep(t, m);
+        if (rc) return rc;
+        t->unchecked_adds += m;
+        const uint64_t n_tiles = (m + L1_TILE_STARTS - 1) / L1_TILE_STARTS;
+        const uint64_t tiles_per_wg = (n_tiles + W - 1) / W;
+        {
+            ScopedTimer tm(c, KATGPU_K_PART_L1, m);
+            hipLaunchKernelGGL(k_p1_count, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
+            hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
+        }
+        uint64_t items = 0;
+        HIPCHK(c, hipMemcpyAsync(&items, &l1_off[g.P1], sizeof items, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (items > round_items) return fail(c, KATGPU_ERR_DEVICE, "partition round produced %llu items for a %zu-item buffer", (unsigned long long)items, round_items);
+        if (items) {
+            HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_L1, 0);
+                hipLaunchKernelGGL(k_p1_scatter, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
+            }
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_L2, items);
+                hipLaunchKernelGGL(k_p2, dim3(std::min<uint32_t>(g.P1, W)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2);
+            }
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
+                hipLaunchKernelGGL(k_p3_apply, dim3(std::min<uint32_t>(g.R, W)), dim3(PART_BLOCK), (size_t)g.S * 12, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n);
+            }
+            HIPCHK(c, hipGetLastError());
+            unsigned long long spilled = 0;
+            HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (spilled) {                         // regions that ran out of slots: make room, then the direct path
+                rc = ensure_room(t, spilled);
+                if (rc) return rc;
+                ScopedTimer tm(c, KATGPU_K_COUNT, spilled);
+                hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, spilled, 256, 6)), dim3(256), 0, c->stream, t->d, (const uint64_t*)l1_buf, (uint64_t)spilled);
+            }
+        }
+        pos += m;
+    }
+    *done = pos;
+    return refresh_counters(t);
 }
 
 // Count a resident base stream.  The stream is cut into sub-batches so that "distinct + sub-batch starts" stays under
@@ -369,6 +512,14 @@ extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bas
     if (n < k) return KATGPU_OK;
     size_t pos = 0;
     const size_t n_starts = n - k + 1;
+    // Large, aligned inputs go through the partitioned counter (no global atomic per k-mer); whatever it leaves (nothing,
+    // normally) and everything small goes through the direct kernel below.
+    if (n_starts >= g_part_min_starts && (reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0) {
+        size_t done = 0;
+        int prc = count_partitioned(t, dev_bases, n, &done);
+        if (prc) return prc;
+        pos = done;
+    }
     while (pos < n_starts) {
         int rc = refresh_counters(t);
         if (rc) return rc;

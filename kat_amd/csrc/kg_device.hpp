@@ -17,7 +17,7 @@ namespace kg {
 
 constexpr uint64_t EMPTY = ~0ULL;
 constexpr uint32_t OVF_CAP = 4096;       // side table for amounts beyond 32 bits; a key needs > 2.1e9 hits to enter
-constexpr uint32_t MAX_PROBE = 1u << 14; // linear probes before the table is declared full
+constexpr uint32_t REGION_SLOTS = 8192;  // default slots per region: 96 KB of LDS (8 B key + 4 B count) in the apply kernel
 
 // ctrs[] layout (u64 each)
 constexpr int CTR_DISTINCT0 = 0;   // 64 stripes, summed on the host
@@ -31,7 +31,9 @@ constexpr int CTR_WORDS = 80;
 struct DevTable {
     uint64_t* keys;
     uint32_t* counts;
-    uint64_t cap;
+    uint64_t cap;          // == n_regions * region_slots
+    uint32_t n_regions;    // a k-mer hashes to one region and probes (linearly, wrapping) only inside it, so a region
+    uint32_t region_slots; // is a self-contained little table that the partitioned counter can hold in LDS
     uint64_t* ovf_keys;   // OVF_CAP
     uint64_t* ovf_hi;     // OVF_CAP, extra amount (added to the slot's 32-bit counter)
     uint64_t* ctrs;       // CTR_WORDS
@@ -67,7 +69,24 @@ __device__ __host__ __forceinline__ uint64_t mix64(uint64_t x) {   // murmur3 fi
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
-__device__ __forceinline__ uint64_t slot_of(uint64_t key, uint64_t cap) { return __umul64hi(mix64(key), cap); }
+// home slot: region from the high product of the hash, offset inside the region from its low 32 bits
+__device__ __forceinline__ uint32_t region_of_hash(uint64_t h, uint32_t n_regions) { return (uint32_t)__umul64hi(h, (uint64_t)n_regions); }
+__device__ __forceinline__ uint32_t offset_of_hash(uint64_t h, uint32_t region_slots) { return __umulhi((uint32_t)h, region_slots); }
+struct Probe {
+    uint64_t base;   // first slot of the region
+    uint32_t s;      // current offset inside the region
+    uint32_t S;
+    __device__ __forceinline__ uint64_t pos() const { return base + s; }
+    __device__ __forceinline__ void next() { s = s + 1 == S ? 0 : s + 1; }
+};
+__device__ __forceinline__ Probe probe_start(const uint64_t key, uint32_t n_regions, uint32_t region_slots) {
+    const uint64_t h = mix64(key);
+    Probe p;
+    p.base = (uint64_t)region_of_hash(h, n_regions) * region_slots;
+    p.s = offset_of_hash(h, region_slots);
+    p.S = region_slots;
+    return p;
+}
 // owner part of a k-mer for the multi-GPU merge: a second, independent mix of the CANONICAL form
 __device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t k, uint32_t n_parts) {
     uint64_t c = kmer_canonical(key, k);
@@ -109,8 +128,9 @@ __device__ __forceinline__ uint64_t slot_count(const DevTable& t, uint64_t pos, 
 // new_distinct is accumulated per lane and flushed once per wave (one striped atomic instead of one per claim).
 __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint64_t amount, uint32_t& new_distinct) {
     if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)amount); return true; }
-    uint64_t pos = slot_of(key, t.cap);
-    for (uint32_t probe = 0; probe < MAX_PROBE; ++probe) {
+    Probe pr = probe_start(key, t.n_regions, t.region_slots);
+    for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
+        const uint64_t pos = pr.pos();
         uint64_t cur = t.keys[pos];
         if (cur == EMPTY) {
             cur = atomicCAS((unsigned long long*)&t.keys[pos], (unsigned long long)EMPTY, (unsigned long long)key);
@@ -124,7 +144,6 @@ __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint6
             if (hi) ovf_add(t, key, hi << 32);
             return true;
         }
-        if (++pos == t.cap) pos = 0;
     }
     atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 1ULL);
     return false;
@@ -137,8 +156,9 @@ __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint6
 // runs k_sweep, which moves 2^31 from every counter >= 2^31 into the side table (katgpu.hip: maybe_sweep).
 __device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint32_t& new_distinct) {
     if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], 1ULL); return true; }
-    uint64_t pos = slot_of(key, t.cap);
-    for (uint32_t probe = 0; probe < MAX_PROBE; ++probe) {
+    Probe pr = probe_start(key, t.n_regions, t.region_slots);
+    for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
+        const uint64_t pos = pr.pos();
         uint64_t cur = t.keys[pos];
         if (cur == EMPTY) {
             cur = atomicCAS((unsigned long long*)&t.keys[pos], (unsigned long long)EMPTY, (unsigned long long)key);
@@ -148,7 +168,6 @@ __device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint3
             (void)__hip_atomic_fetch_add(&t.counts[pos], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }
-        if (++pos == t.cap) pos = 0;
     }
     atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 1ULL);
     return false;
@@ -157,12 +176,12 @@ __device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint3
 // ---- lookup: get_val_for_key (large_hash_array.hpp:358-376) on an immutable table ----
 __device__ __forceinline__ uint64_t table_get(const DevTable& t, uint64_t key, uint32_t n_ovf) {
     if (key == EMPTY) return t.ctrs[CTR_ONES];
-    uint64_t pos = slot_of(key, t.cap);
-    for (uint64_t probe = 0; probe < t.cap; ++probe) {
+    Probe pr = probe_start(key, t.n_regions, t.region_slots);
+    for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
+        const uint64_t pos = pr.pos();
         uint64_t cur = t.keys[pos];
         if (cur == key) return slot_count(t, pos, key, n_ovf);
         if (cur == EMPTY) return 0;
-        if (++pos == t.cap) pos = 0;
     }
     return 0;
 }

@@ -1,0 +1,310 @@
+// kg_partition.hpp -- the partitioned counter: K1 without a DRAM/L2 atomic per k-mer.
+//
+// Measured on MI355X (tools/ubench_count.hip, profiles/): extracting + canonicalising + hashing k-mers runs at
+// ~490 G k-mers/s, random 8-byte loads at ~55 G/s, but device-scope atomic adds saturate the L2 atomic units at
+// ~22 G/s whatever the table size -- so the direct kernel (k_count: one atomic per instance) tops out near 15 G k-mers/s.
+// This path removes the per-instance global atomic.  The table is made of regions of `region_slots` slots with
+// region-local probing (kg_device.hpp: Probe); a round of the partitioned counter
+//   P1  radix-partitions the round's k-mers by the high part of their region index into P1 buckets  (8 B out / k-mer)
+//   P2  splits every bucket by the low part of the region index -> one contiguous run per region     (8 B in, 8 B out)
+//   P3  loads a region (96 KB) into LDS, applies its run with LDS atomics, writes the region back     (8 B in + 24 B/slot)
+// so HBM sees only streaming traffic.  Both partition levels are exact two-pass (histogram, scan, scatter) with
+// per-workgroup running cursors held in LDS: no global atomics, deterministic placement, no bucket can overflow.
+// A region that fills up in P3 (more distinct k-mers than slots) spills the k-mer to a list (held in the then-free
+// P1 buffer, so it can never overflow) that is inserted with the direct kernel's path after a regrow.
+#pragma once
+#include "kg_kernels.hpp"
+
+namespace kg {
+
+constexpr int PART_BLOCK = 1024;                              // 16 waves, one workgroup per CU
+constexpr int PART_ITEMS = 16;                                // k-mers per lane per tile
+constexpr int TILE_ITEMS = PART_BLOCK * PART_ITEMS;           // 16384
+constexpr int L1_TILE_BYTES = TILE_ITEMS;                     // bytes staged per tile (16 per lane)
+constexpr int L1_TILE_STARTS = L1_TILE_BYTES - CHUNK_OVERLAP; // 16352 window starts per tile
+constexpr int L1_LANES_WITH_STARTS = L1_TILE_STARTS / PART_ITEMS;   // 1022
+constexpr int MAX_PARTS = 1024;                               // buckets per level (one lane per bucket in the scans)
+
+struct PartGeom {
+    uint32_t R, S;     // regions, slots per region (the table's)
+    uint32_t P1, P2;   // region r -> level-1 bucket r / P2, level-2 bucket r % P2
+};
+
+// LDS carve of the partition kernels (dynamic shared memory, 16-byte aligned base)
+struct PartLds {
+    uint64_t staging[TILE_ITEMS];      // 128 KB: the tile's k-mers grouped by bucket
+    uint64_t cursor[MAX_PARTS];        // running output position of each bucket for THIS workgroup
+    uint32_t hist[MAX_PARTS];          // per-tile (scatter) or accumulated (count) bucket sizes
+    uint32_t off[MAX_PARTS];           // exclusive scan of hist
+    uint32_t wave_tot[32];
+    uint32_t code[PART_BLOCK + 2];
+    uint32_t bad[PART_BLOCK + 2];
+};
+
+// exclusive scan of v over the first MAX_PARTS lanes of a 1024-thread block (lane b holds bucket b); returns the
+// exclusive prefix, *total gets the grand total.  Two barriers inside.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t prefix = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < PART_BLOCK / 64; ++w) { uint32_t x = wave_tot[w]; if ((uint32_t)w < wave) prefix += x; tot += x; }
+    *total = tot;
+    __syncthreads();
+    return prefix + inc - v;
+}
+
+// Stage one tile of the base stream (16 bytes per lane) as 2-bit codes + validity flags in LDS.  Ends with a barrier.
+__device__ __forceinline__ void stage_tile_codes(PartLds& L, const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t off = tile_off + (uint64_t)tid * PART_ITEMS;
+    uint32_t w[4];
+    if (off + PART_ITEMS <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(bases + off);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { uint64_t i = off + q * 4 + b; x |= (i < n ? (uint32_t)bases[i] : (uint32_t)'N') << (8 * b); }
+            w[q] = x;
+        }
+    }
+    uint32_t code, bad;
+    encode16(w, code, bad);
+    L.code[tid] = code;
+    L.bad[tid] = bad;
+    if (tid < 2) { L.code[PART_BLOCK + tid] = 0; L.bad[PART_BLOCK + tid] = 0xFFFF; }
+    __syncthreads();
+}
+
+// The 16 k-mers whose windows start in this lane's 16 positions (canonical if asked); bit j of the result = window j valid.
+__device__ __forceinline__ uint32_t lane_kmers(const PartLds& L, uint32_t k, bool canonical, uint64_t (&key)[PART_ITEMS]) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t valid = 0;
+    if (tid >= L1_LANES_WITH_STARTS) return 0;
+    uint64_t hi = ((uint64_t)L.code[tid] << 32) | L.code[tid + 1];
+    uint64_t lo = (uint64_t)L.code[tid + 2] << 32;
+    uint64_t m = ((uint64_t)L.bad[tid] << 48) | ((uint64_t)L.bad[tid + 1] << 32) | ((uint64_t)L.bad[tid + 2] << 16);
+    const uint32_t kshift = 64 - 2 * k, mshift = 64 - k;
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        uint64_t fwd = hi >> kshift;
+        uint64_t kk = fwd;
+        if (canonical) { uint64_t rc = kmer_revcomp(fwd, k); kk = rc < fwd ? rc : fwd; }
+        key[j] = kk;
+        if ((m >> mshift) == 0) valid |= 1u << j;
+        hi = (hi << 2) | (lo >> 62);
+        lo <<= 2;
+        m <<= 1;
+    }
+    return valid;
+}
+
+// Counting-sort one tile's k-mers by bucket through LDS and append every bucket's run at this workgroup's cursor.
+// LEVEL 1: bucket = region / P2; LEVEL 2: bucket = region % P2.  All 1024 lanes must call it (barriers inside).
+template <int LEVEL>
+__device__ __forceinline__ void scatter_tile(PartLds& L, const PartGeom g, const uint64_t (&key)[PART_ITEMS], uint32_t valid,
+                                             uint64_t* __restrict__ out) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t P = LEVEL == 1 ? g.P1 : g.P2;
+    if (tid < MAX_PARTS) L.hist[tid] = 0;
+    __syncthreads();
+    uint32_t br[PART_ITEMS];                                  // bucket << 16 | rank inside the tile's bucket run
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        br[j] = 0;
+        if (valid >> j & 1) {
+            const uint32_t r = region_of_hash(mix64(key[j]), g.R);
+            const uint32_t b = LEVEL == 1 ? r / g.P2 : r % g.P2;
+            br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t total;
+    const uint32_t mine = tid < P ? L.hist[tid] : 0;
+    const uint32_t excl = block_exclusive_scan(mine, L.wave_tot, &total);
+    if (tid < MAX_PARTS) L.off[tid] = excl;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j)
+        if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = key[j];
+    __syncthreads();
+    // bucket-parallel copy-out: each wave walks its share of the buckets, lanes copy that bucket's run contiguously
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    for (uint32_t b = wave; b < P; b += PART_BLOCK / 64) {
+        const uint32_t cnt = L.hist[b], src = L.off[b];
+        const uint64_t dst = L.cursor[b];
+        for (uint32_t i = lane; i < cnt; i += 64) out[dst + i] = L.staging[src + i];
+    }
+    __syncthreads();
+    if (tid < P) L.cursor[tid] += L.hist[tid];
+    // (the next tile's first barrier orders this update before the next use)
+}
+
+// ---- level 1, pass A: per-workgroup bucket histogram of this round's k-mers.  hist1[w * P1 + b]. ----
+// Workgroup w owns tiles [w*tiles_per_wg, ...) in BOTH level-1 passes, which is what makes the precomputed per-workgroup
+// offsets valid.  The all-ones key (only k = 32, non-canonical poly-T) never enters a bucket: it is tallied here.
+__global__ void __launch_bounds__(PART_BLOCK)
+k_p1_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
+           uint32_t* __restrict__ hist1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
+    const uint32_t tid = threadIdx.x;
+    if (tid < MAX_PARTS) L.hist[tid] = 0;
+    uint32_t ones = 0;
+    const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
+    for (uint64_t tile = t0; tile < t1; ++tile) {
+        __syncthreads();
+        stage_tile_codes(L, bases, n, tile * L1_TILE_STARTS);
+        uint64_t key[PART_ITEMS];
+        const uint32_t valid = lane_kmers(L, t.k, t.canonical != 0, key);
+#pragma unroll
+        for (int j = 0; j < PART_ITEMS; ++j)
+            if (valid >> j & 1) {
+                if (key[j] == EMPTY) { ++ones; continue; }
+                atomicAdd(&L.hist[region_of_hash(mix64(key[j]), g.R) / g.P2], 1u);
+            }
+    }
+    __syncthreads();
+    if (tid < g.P1) hist1[(uint64_t)blockIdx.x * g.P1 + tid] = L.hist[tid];
+    for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
+    if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
+}
+
+// ---- level 1 scan: offs[w][b] = start of workgroup w's run inside bucket b; l1_off[b] = start of bucket b; l1_off[P1] = items ----
+__global__ void __launch_bounds__(PART_BLOCK)
+k_p1_scan(PartGeom g, uint32_t n_wg, const uint32_t* __restrict__ hist1, uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_off) {
+    __shared__ uint64_t s_base[MAX_PARTS + 1];
+    const uint32_t b = threadIdx.x;
+    uint64_t tot = 0;
+    if (b < g.P1) for (uint32_t w = 0; w < n_wg; ++w) tot += hist1[(uint64_t)w * g.P1 + b];
+    if (b < g.P1) s_base[b] = tot;
+    __syncthreads();
+    if (b == 0) {                                   // P1 <= 1024 entries: a serial scan is a few microseconds
+        uint64_t run = 0;
+        for (uint32_t i = 0; i < g.P1; ++i) { uint64_t v = s_base[i]; s_base[i] = run; run += v; }
+        s_base[g.P1] = run;
+    }
+    __syncthreads();
+    if (b < g.P1) l1_off[b] = s_base[b];
+    if (b == 0) l1_off[g.P1] = s_base[g.P1];
+    if (b < g.P1) {
+        uint64_t run = s_base[b];
+        for (uint32_t w = 0; w < n_wg; ++w) { offs[(uint64_t)w * g.P1 + b] = run; run += hist1[(uint64_t)w * g.P1 + b]; }
+    }
+}
+
+// ---- level 1, pass B: extract again (it is ~free) and scatter into the level-1 buckets ----
+__global__ void __launch_bounds__(PART_BLOCK)
+k_p1_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
+             const uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_buf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
+    const uint32_t tid = threadIdx.x;
+    if (tid < g.P1) L.cursor[tid] = offs[(uint64_t)blockIdx.x * g.P1 + tid];
+    const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
+    for (uint64_t tile = t0; tile < t1; ++tile) {
+        __syncthreads();
+        stage_tile_codes(L, bases, n, tile * L1_TILE_STARTS);
+        uint64_t key[PART_ITEMS];
+        uint32_t valid = lane_kmers(L, t.k, t.canonical != 0, key);
+#pragma unroll
+        for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);        // tallied in pass A
+        scatter_tile<1>(L, g, key, valid, l1_buf);
+    }
+}
+
+// ---- level 2: one workgroup per level-1 bucket: histogram by sub-bucket, scan, scatter.  off2[r] = start of region r's run. ----
+__global__ void __launch_bounds__(PART_BLOCK)
+k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
+     uint64_t* __restrict__ off2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
+        const uint64_t beg = l1_off[b1], end = l1_off[b1 + 1];
+        __syncthreads();
+        if (tid < MAX_PARTS) L.hist[tid] = 0;
+        __syncthreads();
+        for (uint64_t i = beg + tid; i < end; i += PART_BLOCK)                                  // pass A: coalesced 8 B per lane
+            atomicAdd(&L.hist[region_of_hash(mix64(l1_buf[i]), g.R) % g.P2], 1u);
+        __syncthreads();
+        // sub-bucket sizes fit 32 bits only per tile; accumulate the scan in 64 bits: lane b owns sub-bucket b
+        uint32_t total;
+        const uint32_t mine = tid < g.P2 ? L.hist[tid] : 0;
+        // a level-1 bucket can hold more than 2^32 items only for absurd rounds; the host caps a round at 2^32-1 items
+        const uint32_t excl = block_exclusive_scan(mine, L.wave_tot, &total);
+        if (tid < g.P2) {
+            L.cursor[tid] = beg + excl;
+            off2[(uint64_t)b1 * g.P2 + tid] = beg + excl;
+        }
+        if (b1 == g.P1 - 1 && tid == 0) off2[(uint64_t)g.P1 * g.P2] = end;
+        for (uint64_t tbeg = beg; tbeg < end; tbeg += TILE_ITEMS) {                            // pass B
+            uint64_t key[PART_ITEMS];
+            uint32_t valid = 0;
+#pragma unroll
+            for (int j = 0; j < PART_ITEMS; ++j) {
+                const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + tid;
+                key[j] = 0;
+                if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
+            }
+            __syncthreads();
+            scatter_tile<2>(L, g, key, valid, l2_buf);
+        }
+    }
+}
+
+// ---- level 3: apply a region's run to the region, in LDS ----
+// LDS: keys[S] (u64) | counts[S] (u32).  Insert = LDS CAS claim + LDS add (same protocol as table_inc, minus the HBM).
+__global__ void __launch_bounds__(PART_BLOCK)
+k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
+           uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
+    uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)g.S * 8);
+    const uint32_t tid = threadIdx.x, S = g.S;
+    uint32_t new_distinct = 0;
+    for (uint32_t r = blockIdx.x; r < g.R; r += gridDim.x) {
+        const uint64_t beg = off2[r], end = off2[r + 1];
+        if (beg == end) continue;                                                              // uniform per block
+        const uint64_t base = (uint64_t)r * S;
+        __syncthreads();
+        for (uint32_t i = tid; i < S; i += PART_BLOCK) { rk[i] = t.keys[base + i]; rc[i] = t.counts[base + i]; }
+        __syncthreads();
+        for (uint64_t i = beg + tid; i < end; i += PART_BLOCK) {
+            const unsigned long long key = l2_buf[i];
+            uint32_t s = offset_of_hash(mix64(key), S);
+            bool done = false;
+            for (uint32_t probe = 0; probe < S; ++probe) {
+                unsigned long long cur = rk[s];
+                if (cur == EMPTY) {
+                    cur = atomicCAS(&rk[s], (unsigned long long)EMPTY, key);
+                    if (cur == EMPTY) { ++new_distinct; cur = key; }
+                }
+                if (cur == key) { atomicAdd(&rc[s], 1u); done = true; break; }
+                s = s + 1 == S ? 0 : s + 1;
+            }
+            if (!done) spill[atomicAdd(spill_n, 1ULL)] = key;                                   // region full: direct path later
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < S; i += PART_BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
+    }
+    flush_distinct(t, new_distinct);
+}
+
+// spilled k-mers (count 1 each) through the direct path
+__global__ void __launch_bounds__(256)
+k_insert_keys(DevTable t, const uint64_t* __restrict__ keys, uint64_t n) {
+    uint32_t new_distinct = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) table_inc(t, keys[i], new_distinct);
+    flush_distinct(t, new_distinct);
+}
+
+}  // namespace kg

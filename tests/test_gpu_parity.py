@@ -246,7 +246,8 @@ def test_unchecked_add_sweep_guard(ko, tmp_path):
         "import kat_amd\n"
         "s = np.load(%r)\n"
         "e = kat_amd.Engine(0)\n"
-        "t = e.table(21, True, size_hint=1 << 14).count_bases(s)\n"
+        "b = e.alloc(s.size); b.upload(s)\n"
+        "t = e.table(21, True, size_hint=1 << 14).count_bases(b)\n"
         "k, c = t.dump_sorted(); np.savez(%r, k=k, c=c, h=t.hist(1, 5000, 1), regrow=e.profile()['regrow']['launches'])\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "s.npy"), str(tmp_path / "out.npz"))
     env = dict(os.environ, KATGPU_TEST_SWEEP_THR="64", KATGPU_TEST_MAX_STARTS="64")
