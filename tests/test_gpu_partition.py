@@ -1,0 +1,22 @@
+"""The partitioned counter (kg_partition.hpp: two-level radix partition + regions applied in LDS) vs the oracle.
+
+Production thresholds send only >= 32 M-start inputs down this path; the test hooks force it for small inputs with
+small regions / rounds so that multi-round accumulation, region spills, regrows and ragged tiles are all exercised at
+sizes the oracle finishes in seconds.  (tests/test_gpu_scale_properties.py runs it at production settings.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("region_slots,round_items", [(64, 100000), (1024, 3000000), (8192, 400000)])
+def test_partitioned_counter_matches_oracle(region_slots, round_items):
+    env = dict(os.environ, KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
+               KATGPU_TEST_ROUND_ITEMS=str(round_items))
+    r = subprocess.run([sys.executable, os.path.join(HERE, "partition_cases.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "partition cases ok" in r.stdout
