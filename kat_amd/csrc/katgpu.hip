@@ -393,6 +393,7 @@ static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
 
 static const uint64_t g_part_min_starts = getenv("KATGPU_PART_MIN_STARTS") ? strtoull(getenv("KATGPU_PART_MIN_STARTS"), nullptr, 10) : (32ULL << 20);
 static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? strtoull(getenv("KATGPU_TEST_ROUND_ITEMS"), nullptr, 10) : 0;
+static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 
 static bool part_geometry(const DevTable& d, PartGeom* g) {
     g->R = d.n_regions; g->S = d.region_slots;
@@ -423,7 +424,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     // ---- arena: [hist1 | offs | l1_off | off2 | spill_n | L1 buffer | L2 buffer] ----
     const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +
                                align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) + 256;
-    size_t want_items = std::min<size_t>(n_starts, 0xFFFFFFFFULL - TILE_ITEMS);
+    size_t want_items = n_starts;
     if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
     if (c->arena_bytes < small_bytes + 16 * std::min<size_t>(want_items, (size_t)64 << 20)) {
         size_t free_b = 0, total_b = 0;
@@ -463,9 +464,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         if (m < n_starts - pos) m -= m % L1_TILE_STARTS;                          // whole tiles, keeps the next round 16-byte aligned
         const size_t nb = m + k - 1;
         const uint8_t* p = dev_bases + pos;
-        rc = maybe_sweep(t, m);
-        if (rc) return rc;
-        t->unchecked_adds += m;
+        t->count_bound = 0xFFFFFFFFULL;          // the apply kernel chains its own carries; a later direct launch sweeps first
         const uint64_t n_tiles = (m + L1_TILE_STARTS - 1) / L1_TILE_STARTS;
         const uint64_t tiles_per_wg = (n_tiles + W - 1) / W;
         {
@@ -489,7 +488,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             }
             {
                 ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
-                hipLaunchKernelGGL(k_p3_apply, dim3(std::min<uint32_t>(g.R, W)), dim3(PART_BLOCK), (size_t)g.S * 12, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n);
+                hipLaunchKernelGGL(k_p3_apply, dim3(std::min<uint32_t>(g.R, W)), dim3(PART_BLOCK), (size_t)g.S * 12, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod);
             }
             HIPCHK(c, hipGetLastError());
             unsigned long long spilled = 0;
@@ -498,6 +497,9 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             if (spilled) {                         // regions that ran out of slots: make room, then the direct path
                 rc = ensure_room(t, spilled);
                 if (rc) return rc;
+                rc = maybe_sweep(t, spilled);
+                if (rc) return rc;
+                t->unchecked_adds += spilled;
                 ScopedTimer tm(c, KATGPU_K_COUNT, spilled);
                 hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, spilled, 256, 6)), dim3(256), 0, c->stream, t->d, (const uint64_t*)l1_buf, (uint64_t)spilled);
             }

@@ -58,6 +58,22 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     return prefix + inc - v;
 }
 
+// 64-bit variant (scratch: 16 u64 in LDS)
+__device__ __forceinline__ uint64_t block_exclusive_scan64(uint64_t v, uint64_t* wave_tot) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint64_t o = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
+    __syncthreads();                                  // every lane has read its own histogram word before scratch is written
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint64_t prefix = 0;
+#pragma unroll
+    for (int w = 0; w < PART_BLOCK / 64; ++w) { uint64_t x = wave_tot[w]; if ((uint32_t)w < wave) prefix += x; }
+    __syncthreads();
+    return prefix + inc - v;
+}
+
 // Stage one tile of the base stream (16 bytes per lane) as 2-bit codes + validity flags in LDS.  Ends with a barrier.
 __device__ __forceinline__ void stage_tile_codes(PartLds& L, const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off) {
     const uint32_t tid = threadIdx.x;
@@ -230,16 +246,16 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
     for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
         const uint64_t beg = l1_off[b1], end = l1_off[b1 + 1];
         __syncthreads();
-        if (tid < MAX_PARTS) L.hist[tid] = 0;
+        // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
+        // the cursor array is free until the scan, so it doubles as the histogram
+        unsigned long long* h64 = reinterpret_cast<unsigned long long*>(L.cursor);
+        if (tid < MAX_PARTS) h64[tid] = 0;
         __syncthreads();
-        for (uint64_t i = beg + tid; i < end; i += PART_BLOCK)                                  // pass A: coalesced 8 B per lane
-            atomicAdd(&L.hist[region_of_hash(mix64(l1_buf[i]), g.R) % g.P2], 1u);
+        for (uint64_t i = beg + tid; i < end; i += PART_BLOCK)                                  // coalesced 8 B per lane
+            atomicAdd(&h64[region_of_hash(mix64(l1_buf[i]), g.R) % g.P2], 1ULL);
         __syncthreads();
-        // sub-bucket sizes fit 32 bits only per tile; accumulate the scan in 64 bits: lane b owns sub-bucket b
-        uint32_t total;
-        const uint32_t mine = tid < g.P2 ? L.hist[tid] : 0;
-        // a level-1 bucket can hold more than 2^32 items only for absurd rounds; the host caps a round at 2^32-1 items
-        const uint32_t excl = block_exclusive_scan(mine, L.wave_tot, &total);
+        const uint64_t mine = tid < g.P2 ? h64[tid] : 0;
+        const uint64_t excl = block_exclusive_scan64(mine, reinterpret_cast<uint64_t*>(L.staging));
         if (tid < g.P2) {
             L.cursor[tid] = beg + excl;
             off2[(uint64_t)b1 * g.P2 + tid] = beg + excl;
@@ -264,7 +280,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 // LDS: keys[S] (u64) | counts[S] (u32).  Insert = LDS CAS claim + LDS add (same protocol as table_inc, minus the HBM).
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
-           uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n) {
+           uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
     uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)g.S * 8);
@@ -281,13 +297,20 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
             const unsigned long long key = l2_buf[i];
             uint32_t s = offset_of_hash(mix64(key), S);
             bool done = false;
-            for (uint32_t probe = 0; probe < S; ++probe) {
+            const bool force_spill = spill_mod && (i % spill_mod) == 0;                        // test hook: exercise the spill path
+            for (uint32_t probe = 0; probe < S && !force_spill; ++probe) {
                 unsigned long long cur = rk[s];
                 if (cur == EMPTY) {
                     cur = atomicCAS(&rk[s], (unsigned long long)EMPTY, key);
                     if (cur == EMPTY) { ++new_distinct; cur = key; }
                 }
-                if (cur == key) { atomicAdd(&rc[s], 1u); done = true; break; }
+                if (cur == key) {
+                    // LDS returning add: a 32-bit wrap is seen right here and chained into the side table, so a round may
+                    // carry any number of copies of one k-mer and needs no host-side overflow guard
+                    if (atomicAdd(&rc[s], 1u) == 0xFFFFFFFFu) ovf_add(t, key, 1ULL << 32);
+                    done = true;
+                    break;
+                }
                 s = s + 1 == S ? 0 : s + 1;
             }
             if (!done) spill[atomicAdd(spill_n, 1ULL)] = key;                                   // region full: direct path later
