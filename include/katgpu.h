@@ -139,10 +139,11 @@ typedef enum katgpu_kernel {
     KATGPU_K_COMP_PASS2 = 5,
     KATGPU_K_PARTITION = 6,
     KATGPU_K_MERGE = 7,
-    KATGPU_K_PART_L1 = 8,    /* partitioned counter: extract + level-1 radix partition (histogram, scan, scatter) */
-    KATGPU_K_PART_L2 = 9,    /* level-2 partition: one run per table region */
-    KATGPU_K_PART_APPLY = 10,/* regions updated in LDS */
-    KATGPU_K_NCLASSES = 11
+    KATGPU_K_PART_L1 = 8,    /* partitioned counter: extract + level-1 bucket histogram (k_p1_count + k_p1_scan) */
+    KATGPU_K_PART_L2 = 9,    /* level-2 partition: one run per table region (k_p2) */
+    KATGPU_K_PART_APPLY = 10,/* regions updated in LDS (k_p3_apply) */
+    KATGPU_K_PART_L1S = 11,  /* extract + level-1 scatter (k_p1_scatter) */
+    KATGPU_K_NCLASSES = 12
 } katgpu_kernel;
 int katgpu_profile_reset(katgpu_ctx* ctx);
 int katgpu_profile_get(katgpu_ctx* ctx, int kernel_class, uint64_t* launches, double* total_ms, uint64_t* units);

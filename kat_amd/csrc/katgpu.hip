@@ -433,7 +433,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         size_t bytes = std::min<size_t>(small_bytes + 16 * want_items, (size_t)(0.8 * (double)free_b));
         if (bytes > c->arena_bytes) {
             if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
-            if (bytes < small_bytes + 16 * ((size_t)1 << 20)) return KATGPU_OK;          // no room for a useful round: direct path
+            if (!g_test_round_items && bytes < small_bytes + 16 * ((size_t)1 << 20)) return KATGPU_OK;   // no room for a useful round: direct path
             HIPCHK(c, hipMalloc((void**)&c->arena, bytes));
             c->arena_bytes = bytes;
         }
@@ -479,7 +479,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         if (items) {
             HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
             {
-                ScopedTimer tm(c, KATGPU_K_PART_L1, 0);
+                ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
                 hipLaunchKernelGGL(k_p1_scatter, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
             }
             {
