@@ -236,11 +236,14 @@ static const uint32_t g_region_slots = getenv("KATGPU_TEST_REGION_SLOTS") ? (uin
 static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out) {
     DevTable d{};
     // capacity is a whole number of regions (kg_device.hpp: Probe); a table smaller than one region is a single short region
-    if (cap <= g_region_slots) { d.n_regions = 1; d.region_slots = (uint32_t)cap; }
+    if (cap <= g_region_slots) { d.n_regions = d.p1 = d.p2 = 1; d.region_slots = (uint32_t)cap; }
     else {
         const uint64_t nr = (cap + g_region_slots - 1) / g_region_slots;
-        if (nr > 0x7FFFFFFFULL) return fail(c, KATGPU_ERR_NOMEM, "table of %llu slots exceeds the region index", (unsigned long long)cap);
-        d.n_regions = (uint32_t)nr; d.region_slots = g_region_slots;
+        if (nr > 0x3FFFFFFFULL) return fail(c, KATGPU_ERR_NOMEM, "table of %llu slots exceeds the region index", (unsigned long long)cap);
+        uint32_t p2 = 1;
+        while ((uint64_t)p2 * p2 < nr) ++p2;                   // two radix digits of about the same size
+        d.p2 = p2; d.p1 = (uint32_t)((nr + p2 - 1) / p2);
+        d.n_regions = d.p1 * d.p2; d.region_slots = g_region_slots;
     }
     cap = (uint64_t)d.n_regions * d.region_slots;
     d.cap = cap; d.k = k; d.canonical = canonical ? 1 : 0;
@@ -396,11 +399,7 @@ static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? s
 static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 
 static bool part_geometry(const DevTable& d, PartGeom* g) {
-    g->R = d.n_regions; g->S = d.region_slots;
-    uint32_t p2 = 1;
-    while ((uint64_t)p2 * p2 < g->R) ++p2;
-    g->P2 = p2;
-    g->P1 = (g->R + p2 - 1) / p2;
+    g->R = d.n_regions; g->S = d.region_slots; g->P1 = d.p1; g->P2 = d.p2;
     return g->P1 <= MAX_PARTS && g->P2 <= MAX_PARTS && (size_t)g->S * 12 <= 150 * 1024;
 }
 

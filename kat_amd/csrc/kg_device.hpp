@@ -34,6 +34,7 @@ struct DevTable {
     uint64_t cap;          // == n_regions * region_slots
     uint32_t n_regions;    // a k-mer hashes to one region and probes (linearly, wrapping) only inside it, so a region
     uint32_t region_slots; // is a self-contained little table that the partitioned counter can hold in LDS
+    uint32_t p1, p2;       // n_regions == p1 * p2: region = b1 * p2 + b2, the two radix digits of the partitioned counter
     uint64_t* ovf_keys;   // OVF_CAP
     uint64_t* ovf_hi;     // OVF_CAP, extra amount (added to the slot's 32-bit counter)
     uint64_t* ctrs;       // CTR_WORDS
@@ -69,8 +70,11 @@ __device__ __host__ __forceinline__ uint64_t mix64(uint64_t x) {   // murmur3 fi
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
-// home slot: region from the high product of the hash, offset inside the region from its low 32 bits
-__device__ __forceinline__ uint32_t region_of_hash(uint64_t h, uint32_t n_regions) { return (uint32_t)__umul64hi(h, (uint64_t)n_regions); }
+// home slot from three disjoint bit fields of the 64-bit hash, each reduced with one 32-bit high multiply (no division):
+// level-1 digit from bits 63..32, level-2 digit from bits 43..12, offset inside the region from bits 31..0
+__device__ __forceinline__ uint32_t digit1_of_hash(uint64_t h, uint32_t p1) { return __umulhi((uint32_t)(h >> 32), p1); }
+__device__ __forceinline__ uint32_t digit2_of_hash(uint64_t h, uint32_t p2) { return __umulhi((uint32_t)(h >> 12), p2); }
+__device__ __forceinline__ uint32_t region_of_hash(uint64_t h, uint32_t p1, uint32_t p2) { return digit1_of_hash(h, p1) * p2 + digit2_of_hash(h, p2); }
 __device__ __forceinline__ uint32_t offset_of_hash(uint64_t h, uint32_t region_slots) { return __umulhi((uint32_t)h, region_slots); }
 struct Probe {
     uint64_t base;   // first slot of the region
@@ -79,10 +83,11 @@ struct Probe {
     __device__ __forceinline__ uint64_t pos() const { return base + s; }
     __device__ __forceinline__ void next() { s = s + 1 == S ? 0 : s + 1; }
 };
-__device__ __forceinline__ Probe probe_start(const uint64_t key, uint32_t n_regions, uint32_t region_slots) {
+__device__ __forceinline__ Probe probe_start(const uint64_t key, const DevTable& t) {
     const uint64_t h = mix64(key);
     Probe p;
-    p.base = (uint64_t)region_of_hash(h, n_regions) * region_slots;
+    const uint32_t region_slots = t.region_slots;
+    p.base = (uint64_t)region_of_hash(h, t.p1, t.p2) * region_slots;
     p.s = offset_of_hash(h, region_slots);
     p.S = region_slots;
     return p;
@@ -128,7 +133,7 @@ __device__ __forceinline__ uint64_t slot_count(const DevTable& t, uint64_t pos, 
 // new_distinct is accumulated per lane and flushed once per wave (one striped atomic instead of one per claim).
 __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint64_t amount, uint32_t& new_distinct) {
     if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)amount); return true; }
-    Probe pr = probe_start(key, t.n_regions, t.region_slots);
+    Probe pr = probe_start(key, t);
     for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
         const uint64_t pos = pr.pos();
         uint64_t cur = t.keys[pos];
@@ -156,7 +161,7 @@ __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint6
 // runs k_sweep, which moves 2^31 from every counter >= 2^31 into the side table (katgpu.hip: maybe_sweep).
 __device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint32_t& new_distinct) {
     if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], 1ULL); return true; }
-    Probe pr = probe_start(key, t.n_regions, t.region_slots);
+    Probe pr = probe_start(key, t);
     for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
         const uint64_t pos = pr.pos();
         uint64_t cur = t.keys[pos];
@@ -176,7 +181,7 @@ __device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint3
 // ---- lookup: get_val_for_key (large_hash_array.hpp:358-376) on an immutable table ----
 __device__ __forceinline__ uint64_t table_get(const DevTable& t, uint64_t key, uint32_t n_ovf) {
     if (key == EMPTY) return t.ctrs[CTR_ONES];
-    Probe pr = probe_start(key, t.n_regions, t.region_slots);
+    Probe pr = probe_start(key, t);
     for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
         const uint64_t pos = pr.pos();
         uint64_t cur = t.keys[pos];

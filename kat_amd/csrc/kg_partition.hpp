@@ -27,7 +27,7 @@ constexpr int MAX_PARTS = 1024;                               // buckets per lev
 
 struct PartGeom {
     uint32_t R, S;     // regions, slots per region (the table's)
-    uint32_t P1, P2;   // region r -> level-1 bucket r / P2, level-2 bucket r % P2
+    uint32_t P1, P2;   // region r = b1 * P2 + b2 (the table's p1, p2): level-1 bucket b1, level-2 bucket b2
 };
 
 // LDS carve of the partition kernels (dynamic shared memory, 16-byte aligned base)
@@ -74,11 +74,10 @@ __device__ __forceinline__ uint64_t block_exclusive_scan64(uint64_t v, uint64_t*
     return prefix + inc - v;
 }
 
-// Stage one tile of the base stream (16 bytes per lane) as 2-bit codes + validity flags in LDS.  Ends with a barrier.
-__device__ __forceinline__ void stage_tile_codes(PartLds& L, const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off) {
-    const uint32_t tid = threadIdx.x;
-    const uint64_t off = tile_off + (uint64_t)tid * PART_ITEMS;
-    uint32_t w[4];
+// One tile of the base stream is 16 bytes per lane.  The load is split from the staging so that the NEXT tile's load can be
+// in flight while the current tile is processed (one workgroup per CU: nothing else hides the ~2 us HBM latency).
+__device__ __forceinline__ void tile_load(const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off, uint32_t (&w)[4]) {
+    const uint64_t off = tile_off + (uint64_t)threadIdx.x * PART_ITEMS;
     if (off + PART_ITEMS <= n) {
         const uint4 v = *reinterpret_cast<const uint4*>(bases + off);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
@@ -91,6 +90,11 @@ __device__ __forceinline__ void stage_tile_codes(PartLds& L, const uint8_t* __re
             w[q] = x;
         }
     }
+}
+
+// 2-bit codes + validity flags of the loaded tile into LDS.  Ends with a barrier.
+__device__ __forceinline__ void tile_stage(PartLds& L, const uint32_t (&w)[4]) {
+    const uint32_t tid = threadIdx.x;
     uint32_t code, bad;
     encode16(w, code, bad);
     L.code[tid] = code;
@@ -136,8 +140,8 @@ __device__ __forceinline__ void scatter_tile(PartLds& L, const PartGeom g, const
     for (int j = 0; j < PART_ITEMS; ++j) {
         br[j] = 0;
         if (valid >> j & 1) {
-            const uint32_t r = region_of_hash(mix64(key[j]), g.R);
-            const uint32_t b = LEVEL == 1 ? r / g.P2 : r % g.P2;
+            const uint64_t h = mix64(key[j]);
+            const uint32_t b = LEVEL == 1 ? digit1_of_hash(h, g.P1) : digit2_of_hash(h, g.P2);
             br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
         }
     }
@@ -175,16 +179,21 @@ k_p1_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n
     if (tid < MAX_PARTS) L.hist[tid] = 0;
     uint32_t ones = 0;
     const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
+    uint32_t w[4], wn[4];
+    if (t0 < t1) tile_load(bases, n, t0 * L1_TILE_STARTS, w);
     for (uint64_t tile = t0; tile < t1; ++tile) {
+        if (tile + 1 < t1) tile_load(bases, n, (tile + 1) * L1_TILE_STARTS, wn);
         __syncthreads();
-        stage_tile_codes(L, bases, n, tile * L1_TILE_STARTS);
+        tile_stage(L, w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = wn[q];
         uint64_t key[PART_ITEMS];
         const uint32_t valid = lane_kmers(L, t.k, t.canonical != 0, key);
 #pragma unroll
         for (int j = 0; j < PART_ITEMS; ++j)
             if (valid >> j & 1) {
                 if (key[j] == EMPTY) { ++ones; continue; }
-                atomicAdd(&L.hist[region_of_hash(mix64(key[j]), g.R) / g.P2], 1u);
+                atomicAdd(&L.hist[digit1_of_hash(mix64(key[j]), g.P1)], 1u);
             }
     }
     __syncthreads();
@@ -225,9 +234,14 @@ k_p1_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
     const uint32_t tid = threadIdx.x;
     if (tid < g.P1) L.cursor[tid] = offs[(uint64_t)blockIdx.x * g.P1 + tid];
     const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
+    uint32_t w[4], wn[4];
+    if (t0 < t1) tile_load(bases, n, t0 * L1_TILE_STARTS, w);
     for (uint64_t tile = t0; tile < t1; ++tile) {
+        if (tile + 1 < t1) tile_load(bases, n, (tile + 1) * L1_TILE_STARTS, wn);
         __syncthreads();
-        stage_tile_codes(L, bases, n, tile * L1_TILE_STARTS);
+        tile_stage(L, w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = wn[q];
         uint64_t key[PART_ITEMS];
         uint32_t valid = lane_kmers(L, t.k, t.canonical != 0, key);
 #pragma unroll
@@ -251,8 +265,13 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
         unsigned long long* h64 = reinterpret_cast<unsigned long long*>(L.cursor);
         if (tid < MAX_PARTS) h64[tid] = 0;
         __syncthreads();
-        for (uint64_t i = beg + tid; i < end; i += PART_BLOCK)                                  // coalesced 8 B per lane
-            atomicAdd(&h64[region_of_hash(mix64(l1_buf[i]), g.R) % g.P2], 1ULL);
+        for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)8 * PART_BLOCK) {                   // 8 coalesced loads in flight per lane
+            uint64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint64_t i = i0 + (uint64_t)u * PART_BLOCK + tid; v[u] = i < end ? l1_buf[i] : EMPTY; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (v[u] != EMPTY) atomicAdd(&h64[digit2_of_hash(mix64(v[u]), g.P2)], 1ULL);
+        }
         __syncthreads();
         const uint64_t mine = tid < g.P2 ? h64[tid] : 0;
         const uint64_t excl = block_exclusive_scan64(mine, reinterpret_cast<uint64_t*>(L.staging));
@@ -291,10 +310,23 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
         if (beg == end) continue;                                                              // uniform per block
         const uint64_t base = (uint64_t)r * S;
         __syncthreads();
-        for (uint32_t i = tid; i < S; i += PART_BLOCK) { rk[i] = t.keys[base + i]; rc[i] = t.counts[base + i]; }
+        for (uint32_t i0 = 0; i0 < S; i0 += 4 * PART_BLOCK) {                                 // region in: 8 loads in flight per lane
+            uint64_t kk[4]; uint32_t cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * PART_BLOCK + tid; kk[u] = i < S ? t.keys[base + i] : 0; cc[u] = i < S ? t.counts[base + i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * PART_BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
+        }
         __syncthreads();
-        for (uint64_t i = beg + tid; i < end; i += PART_BLOCK) {
-            const unsigned long long key = l2_buf[i];
+        for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)8 * PART_BLOCK) {
+          unsigned long long batch[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const uint64_t i = i0 + (uint64_t)u * PART_BLOCK + tid; batch[u] = i < end ? l2_buf[i] : EMPTY; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * PART_BLOCK + tid;
+            const unsigned long long key = batch[u];
+            if (key == EMPTY) continue;
             uint32_t s = offset_of_hash(mix64(key), S);
             bool done = false;
             const bool force_spill = spill_mod && (i % spill_mod) == 0;                        // test hook: exercise the spill path
@@ -314,6 +346,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
                 s = s + 1 == S ? 0 : s + 1;
             }
             if (!done) spill[atomicAdd(spill_n, 1ULL)] = key;                                   // region full: direct path later
+          }
         }
         __syncthreads();
         for (uint32_t i = tid; i < S; i += PART_BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }

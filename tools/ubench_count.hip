@@ -38,7 +38,7 @@ u_count(DevTable t, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_ch
                     okv[j] = (m >> mshift) == 0;
                     uint64_t fwd = hi >> kshift, rc = kmer_revcomp(fwd, k);
                     keyv[j] = rc < fwd ? rc : fwd;
-                    posv[j] = probe_start(keyv[j], t.n_regions, t.region_slots).pos();
+                    posv[j] = probe_start(keyv[j], t).pos();
                     hi = (hi << 2) | (lo >> 62); lo <<= 2; m <<= 1;
                 }
 #pragma unroll
@@ -58,7 +58,7 @@ u_count(DevTable t, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_ch
                     uint64_t key = rc < fwd ? rc : fwd;
                     if (MODE == FULL) table_add(t, key, 1, new_distinct);
                     else {
-                        uint64_t pos = probe_start(key, t.n_regions, t.region_slots).pos();
+                        uint64_t pos = probe_start(key, t).pos();
                         if (MODE == EXTRACT_ONLY) acc ^= pos;
                         if (MODE == LOAD_ONLY) acc ^= t.keys[pos];
                         if (MODE == LOAD_NT) acc ^= __builtin_nontemporal_load(&t.keys[pos]);
@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_synth_reads, dim3(2048), dim3(256), 0, 0, g, genome, bases, 0ULL, n_reads, 150u, 350u, 0u, 1ULL);
     CK(hipDeviceSynchronize());
     DevTable t{};
-    t.region_slots = 8192; t.n_regions = (uint32_t)((uint64_t)(genome / 0.6) / 8192 + 1); t.cap = (uint64_t)t.n_regions * t.region_slots; t.k = k; t.canonical = 1;
+    t.region_slots = 8192; t.n_regions = (uint32_t)((uint64_t)(genome / 0.6) / 8192 + 1); t.p1 = 1; t.p2 = t.n_regions; t.cap = (uint64_t)t.n_regions * t.region_slots; t.k = k; t.canonical = 1;
     CK(hipMalloc(&t.keys, t.cap * 8)); CK(hipMalloc(&t.counts, t.cap * 4)); CK(hipMalloc(&t.ovf_keys, OVF_CAP * 8)); CK(hipMalloc(&t.ovf_hi, OVF_CAP * 8)); CK(hipMalloc(&t.ctrs, CTR_WORDS * 8));
     CK(hipMemset(t.ovf_keys, 0xFF, OVF_CAP * 8)); CK(hipMemset(t.ovf_hi, 0, OVF_CAP * 8));
     unsigned long long* sink; CK(hipMalloc(&sink, 8)); CK(hipMemset(sink, 0, 8));
