@@ -396,6 +396,7 @@ static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
 
 static const uint64_t g_part_min_starts = getenv("KATGPU_PART_MIN_STARTS") ? strtoull(getenv("KATGPU_PART_MIN_STARTS"), nullptr, 10) : (32ULL << 20);
 static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? strtoull(getenv("KATGPU_TEST_ROUND_ITEMS"), nullptr, 10) : 0;
+static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 1024;
 static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 
 static bool part_geometry(const DevTable& d, PartGeom* g) {
@@ -417,7 +418,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         c->part_attr_set = true;
     }
     // ---- arena: [hist1 | offs | l1_off | off2 | spill_n | L1 buffer | L2 buffer] ----
@@ -487,7 +489,15 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             }
             {
                 ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
-                hipLaunchKernelGGL(k_p3_apply, dim3(std::min<uint32_t>(g.R, W)), dim3(PART_BLOCK), (size_t)g.S * 12, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod);
+                // as many workgroups per CU as the regions' LDS footprint (and the 2048-thread limit) admits
+                const size_t lds = (size_t)g.S * 12;
+                const uint32_t blk = g_apply_block;
+                const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
+                const uint32_t grid = std::min<uint32_t>(g.R, W * per_cu);
+                if (blk == 512)
+                    hipLaunchKernelGGL(k_p3_apply<512>, dim3(grid), dim3(512), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod);
+                else
+                    hipLaunchKernelGGL(k_p3_apply<1024>, dim3(grid), dim3(1024), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod);
             }
             HIPCHK(c, hipGetLastError());
             unsigned long long spilled = 0;

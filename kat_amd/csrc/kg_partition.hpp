@@ -297,7 +297,8 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 
 // ---- level 3: apply a region's run to the region, in LDS ----
 // LDS: keys[S] (u64) | counts[S] (u32).  Insert = LDS CAS claim + LDS add (same protocol as table_inc, minus the HBM).
-__global__ void __launch_bounds__(PART_BLOCK)
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
            uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -310,21 +311,21 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
         if (beg == end) continue;                                                              // uniform per block
         const uint64_t base = (uint64_t)r * S;
         __syncthreads();
-        for (uint32_t i0 = 0; i0 < S; i0 += 4 * PART_BLOCK) {                                 // region in: 8 loads in flight per lane
+        for (uint32_t i0 = 0; i0 < S; i0 += 4 * BLOCK) {                                 // region in: 8 loads in flight per lane
             uint64_t kk[4]; uint32_t cc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * PART_BLOCK + tid; kk[u] = i < S ? t.keys[base + i] : 0; cc[u] = i < S ? t.counts[base + i] : 0; }
+            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * BLOCK + tid; kk[u] = i < S ? t.keys[base + i] : 0; cc[u] = i < S ? t.counts[base + i] : 0; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * PART_BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
+            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
         }
         __syncthreads();
-        for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)8 * PART_BLOCK) {
+        for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)8 * BLOCK) {
           unsigned long long batch[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const uint64_t i = i0 + (uint64_t)u * PART_BLOCK + tid; batch[u] = i < end ? l2_buf[i] : EMPTY; }
+          for (int u = 0; u < 8; ++u) { const uint64_t i = i0 + (uint64_t)u * BLOCK + tid; batch[u] = i < end ? l2_buf[i] : EMPTY; }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const uint64_t i = i0 + (uint64_t)u * PART_BLOCK + tid;
+            const uint64_t i = i0 + (uint64_t)u * BLOCK + tid;
             const unsigned long long key = batch[u];
             if (key == EMPTY) continue;
             uint32_t s = offset_of_hash(mix64(key), S);
@@ -349,7 +350,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
           }
         }
         __syncthreads();
-        for (uint32_t i = tid; i < S; i += PART_BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
+        for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
     }
     flush_distinct(t, new_distinct);
 }
