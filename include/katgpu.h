@@ -115,6 +115,14 @@ int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int canon2,
                 double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
                 uint64_t* main_mx, uint64_t counters[13], uint64_t* spectra);
 
+/* Three-input form (src/comp.cc:123-127,403-433,466-479): as katgpu_comp, plus the ends / middle / mixed matrices
+ * (each d1_bins x d2_bins, row = scaled count in input 1, column = scaled count in input 3) and hash3_total /
+ * hash3_distinct in counters[2] / counters[5]. */
+int katgpu_comp3(katgpu_table* t1, katgpu_table* t2, katgpu_table* t3, int canon1, int canon2, int canon3,
+                 double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
+                 uint64_t* main_mx, uint64_t* ends_mx, uint64_t* middle_mx, uint64_t* mixed_mx,
+                 uint64_t counters[13], uint64_t* spectra);
+
 /* ---- multi-GPU: owner-partitioned merge of per-GPU partial tables (no reference analogue: KAT is one
  *      address space; this is the exchange step of BASELINE.json's north_star).  owner(kmer) depends only on the
  *      canonical form of the k-mer, so both comp inputs and both strands land on the same rank. ---- */

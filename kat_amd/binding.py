@@ -24,7 +24,7 @@ EXPORTS = (
     "katgpu_count", "katgpu_table_create", "katgpu_count_files", "katgpu_count_bases_host",
     "katgpu_count_bases_device", "katgpu_table_free", "katgpu_table_stats", "katgpu_table_k",
     "katgpu_table_canonical", "katgpu_table_get", "katgpu_table_export", "katgpu_hist", "katgpu_gcp",
-    "katgpu_comp", "katgpu_table_partition_sizes", "katgpu_table_partition", "katgpu_table_merge_device",
+    "katgpu_comp", "katgpu_comp3", "katgpu_table_partition_sizes", "katgpu_table_partition", "katgpu_table_merge_device",
     "katgpu_table_merge_host", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
     "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_free_host",
@@ -78,6 +78,7 @@ def load_library():
     L.katgpu_hist.argtypes = [vp, u64, u64, u64, vp, sz]
     L.katgpu_gcp.argtypes = [vp, C.c_double, u32, vp]
     L.katgpu_comp.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, u32, u32, vp, vp, vp]
+    L.katgpu_comp3.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, u32, u32, vp, vp, vp, vp, vp, vp]
     L.katgpu_table_partition_sizes.argtypes = [vp, u32, vp]
     L.katgpu_table_partition.argtypes = [vp, u32, vp, vp, vp]
     L.katgpu_table_merge_device.argtypes = [vp, vp, vp, sz]
@@ -344,3 +345,16 @@ def comp(t1, t2, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001):
     e._chk(e.L.katgpu_comp(t1.h, t2.h, int(t1.canonical), int(t2.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
                            mx.ctypes.data, cc.ctypes.data, sp.ctypes.data))
     return mx, cc, sp
+
+
+def comp3(t1, t2, t3, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001):
+    """Three-input Comp::compare: (main, ends, middle, mixed, 13 counters, 4 spectra)."""
+    ss = min(d1_bins, d2_bins)
+    mxs = [np.zeros((d1_bins, d2_bins), np.uint64) for _ in range(4)]
+    cc = np.zeros(13, np.uint64)
+    sp = np.zeros((4, ss), np.uint64)
+    e = t1.engine
+    e._chk(e.L.katgpu_comp3(t1.h, t2.h, t3.h, int(t1.canonical), int(t2.canonical), int(t3.canonical), d1_scale, d2_scale,
+                            d1_bins, d2_bins, mxs[0].ctypes.data, mxs[1].ctypes.data, mxs[2].ctypes.data, mxs[3].ctypes.data,
+                            cc.ctypes.data, sp.ctypes.data))
+    return mxs[0], mxs[1], mxs[2], mxs[3], cc, sp

@@ -177,41 +177,48 @@ public:
 double distanceMetric(int which, const std::vector<uint64_t>& s1, const std::vector<uint64_t>& s2);
 const char* distanceName(int which);
 
-// src/comp.hpp (two-input form; the third input is a SURVEY.md 8(f) "next" row)
+// src/comp.hpp (two or three inputs)
 class Comp {
 public:
     Comp(const std::vector<std::string>& input1, const std::vector<std::string>& input2);
+    void setThirdInput(const std::vector<std::string>& input3);       // src/comp.cc:100-106
+    bool doThirdHash() const { return threeInputs; }
+    size_t inputSize() const { return threeInputs ? 3 : 2; }
     void setOutputPrefix(const std::string& p) { outputPrefix = p; }
     void setD1Scale(double s) { d1Scale = s; }
     void setD2Scale(double s) { d2Scale = s; }
     void setD1Bins(uint16_t b) { d1Bins = b; }
     void setD2Bins(uint16_t b) { d2Bins = b; }
     void setThreads(uint16_t t) { threads = t; }
-    void setMerLen(uint8_t m) { input[0].merLen = m; input[1].merLen = m; }    // uint8_t, as in src/comp.hpp:167-171
+    void setMerLen(uint8_t m) { for (auto& in : input) in.merLen = m; }         // uint8_t, as in src/comp.hpp:167-171
     uint16_t getMerLen() const { return input[0].merLen; }
     void setTrim(size_t i, const std::vector<uint16_t>& t) { input[i].set5pTrim(t); }
     void setCanonical(size_t i, bool c) { input[i].canonical = c; }
     void setHashSize(size_t i, uint64_t h) { input[i].hashSize = h; }
-    void setDumpHashes(bool d) { input[0].dumpHash = input[1].dumpHash = d; }
-    void setDisableHashGrow(bool d) { input[0].disableHashGrow = input[1].disableHashGrow = d; }
+    void setDumpHashes(bool d) { for (auto& in : input) in.dumpHash = d; }
+    void setDisableHashGrow(bool d) { for (auto& in : input) in.disableHashGrow = d; }
     void setDensityPlot(bool d) { densityPlot = d; }
     void setOutputHists(bool h) { outputHists = h; }
     void setVerbose(bool v) { verbose = v; }
     void execute();
     void save();
     void printMainMatrix(std::ostream& out);
+    void printEndsMatrix(std::ostream& out);
+    void printMiddleMatrix(std::ostream& out);
+    void printMixedMatrix(std::ostream& out);
     void printCounters(std::ostream& out) { comp_counters.printCounts(out); }
     void printHist(std::ostream& out, InputHandler& in, std::vector<uint64_t>& hist);
     static int main(int argc, char* argv[]);
 private:
     void compare();
-    InputHandler input[2];
+    InputHandler input[3];
+    bool threeInputs = false;
     std::string outputPrefix;
     double d1Scale = 1.0, d2Scale = 1.0;
     uint16_t d1Bins = 1001, d2Bins = 1001;
     uint16_t threads = 1;
     bool densityPlot = false, outputHists = false, verbose = false;
-    Matrix64 main_matrix;
+    Matrix64 main_matrix, ends_matrix, middle_matrix, mixed_matrix;
     CompCounters comp_counters;
 };
 

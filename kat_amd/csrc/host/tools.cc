@@ -204,12 +204,21 @@ Comp::Comp(const vector<string>& input1, const vector<string>& input2) {        
     outputPrefix = "kat-comp";
 }
 
+void Comp::setThirdInput(const vector<string>& input3) {                                          // src/comp.cc:100-106
+    input[2].setMultipleInputs(input3);
+    input[2].index = 3;
+    threeInputs = true;
+}
+
 void Comp::execute() {                                                                            // src/comp.cc:108-183
-    for (auto& in : input) in.validateInput();
+    for (size_t i = 0; i < inputSize(); i++) input[i].validateInput();
     ensureDirectoryExists(parentOfAbsolute(outputPrefix));
     main_matrix = Matrix64(d1Bins, d2Bins);
-    comp_counters = CompCounters(input[0].getSingleInput(), input[1].getSingleInput(), "", std::min(d1Bins, d2Bins));
-    for (auto& in : input) {                                    // sequentially, one input after the other (:139-143)
+    if (doThirdHash()) { ends_matrix = Matrix64(d1Bins, d2Bins); middle_matrix = Matrix64(d1Bins, d2Bins); mixed_matrix = Matrix64(d1Bins, d2Bins); }
+    comp_counters = CompCounters(input[0].getSingleInput(), input[1].getSingleInput(), doThirdHash() ? input[2].getSingleInput() : "",
+                                 std::min(d1Bins, d2Bins));
+    for (size_t i = 0; i < inputSize(); i++) {                  // sequentially, one input after the other (:139-143)
+        InputHandler& in = input[i];
         if (in.mode == InputHandler::COUNT) in.count(threads);
         else throw JellyfishException("loading a jellyfish hash is not part of this build (SURVEY.md 8(f)): " + in.getSingleInput());
     }
@@ -225,8 +234,13 @@ void Comp::compare() {                                                          
     const uint32_t ss = std::min(d1Bins, d2Bins);
     uint64_t counters[13];
     vector<uint64_t> spectra((size_t)4 * ss);
-    Engine::check(katgpu_comp(input[0].hash, input[1].hash, input[0].canonical, input[1].canonical, d1Scale, d2Scale, d1Bins, d2Bins,
-                              main_matrix.data(), counters, spectra.data()));
+    if (doThirdHash())
+        Engine::check(katgpu_comp3(input[0].hash, input[1].hash, input[2].hash, input[0].canonical, input[1].canonical, input[2].canonical,
+                                   d1Scale, d2Scale, d1Bins, d2Bins, main_matrix.data(), ends_matrix.data(), middle_matrix.data(),
+                                   mixed_matrix.data(), counters, spectra.data()));
+    else
+        Engine::check(katgpu_comp(input[0].hash, input[1].hash, input[0].canonical, input[1].canonical, d1Scale, d2Scale, d1Bins, d2Bins,
+                                  main_matrix.data(), counters, spectra.data()));
     comp_counters.loadDevice(counters, spectra.data());
     cout << " done.";
     cout.flush();
@@ -248,6 +262,24 @@ void Comp::printMainMatrix(std::ostream& out) {                                 
     main_matrix.printMatrix(out);
 }
 
+void Comp::printEndsMatrix(std::ostream& out) {                                                   // src/comp.cc:330-337
+    out << "# Each row represents K-mer frequency for: " << input[0].getSingleInput() << endl;
+    out << "# Each column represents K-mer frequency for sequence ends: " << input[2].getSingleInput() << endl;
+    ends_matrix.printMatrix(out);
+}
+
+void Comp::printMiddleMatrix(std::ostream& out) {                                                 // src/comp.cc:341-348
+    out << "# Each row represents K-mer frequency for: " << input[0].getSingleInput() << endl;
+    out << "# Each column represents K-mer frequency for sequence middles: " << input[1].getSingleInput() << endl;
+    middle_matrix.printMatrix(out);
+}
+
+void Comp::printMixedMatrix(std::ostream& out) {                                                  // src/comp.cc:352-358
+    out << "# Each row represents K-mer frequency for hash file 1: " << input[0].getSingleInput() << endl;
+    out << "# Each column represents K-mer frequency for mixed: " << input[1].getSingleInput() << " and " << input[2].getSingleInput() << endl;
+    mixed_matrix.printMatrix(out);
+}
+
 void Comp::printHist(std::ostream& out, InputHandler& in, vector<uint64_t>& hist) {               // src/comp.cc:235-246
     out << mme::KEY_TITLE << in.merLen << "-mer spectra for: " << in.pathString() << endl;
     out << mme::KEY_X_LABEL << in.merLen << "-mer frequency" << endl;
@@ -263,6 +295,17 @@ void Comp::save() {                                                             
     std::ofstream mx((outputPrefix + "-main.mx").c_str());
     printMainMatrix(mx);
     mx.close();
+    if (doThirdHash()) {                                                                          // src/comp.cc:197-213
+        std::ofstream e((outputPrefix + "-ends.mx").c_str());
+        printEndsMatrix(e);
+        e.close();
+        std::ofstream m((outputPrefix + "-middle.mx").c_str());
+        printMiddleMatrix(m);
+        m.close();
+        std::ofstream x((outputPrefix + "-mixed.mx").c_str());
+        printMixedMatrix(x);
+        x.close();
+    }
     std::ofstream st((outputPrefix + ".stats").c_str());
     printCounters(st);
     st.close();
@@ -300,8 +343,11 @@ int Comp::main(int argc, char* argv[]) {                                        
     if (pa.positional.size() < 2 || pa.positional[1].empty()) throw CompException("Nothing specified for input group 2");
     if (verbose) std::cerr << "Input 2: " << pa.positional[1] << endl << endl;
     auto vec2 = InputHandler::globFiles(pa.positional[1]);
-    if (pa.positional.size() > 2) throw CompException("kat comp with a third input (ends/middle/mixed matrices) is not part of this build (SURVEY.md 8(f))");
     Comp comp(*vec1, *vec2);
+    if (pa.positional.size() > 2 && !pa.positional[2].empty()) {
+        if (verbose) std::cerr << "Input 3: " << pa.positional[2] << endl << endl;
+        comp.setThirdInput(*InputHandler::globFiles(pa.positional[2]));
+    }
     comp.setOutputPrefix(pa.get("output_prefix", "kat-comp"));
     comp.setD1Scale(std::stod(pa.get("d1_scale", "1.0")));
     comp.setD2Scale(std::stod(pa.get("d2_scale", "1.0")));
@@ -313,6 +359,8 @@ int Comp::main(int argc, char* argv[]) {                                        
     comp.setMerLen((uint8_t)std::stoul(pa.get("mer_len", std::to_string(DEFAULT_MER_LEN))));
     comp.setCanonical(0, !pa.has("non_canonical_1"));
     comp.setCanonical(1, !pa.has("non_canonical_2"));
+    comp.setCanonical(2, !pa.has("non_canonical_3"));
+    comp.setHashSize(2, std::stoull(pa.get("hash_size_3", std::to_string(DEFAULT_HASH_SIZE))));
     comp.setHashSize(0, std::stoull(pa.get("hash_size_1", std::to_string(DEFAULT_HASH_SIZE))));
     comp.setHashSize(1, std::stoull(pa.get("hash_size_2", std::to_string(DEFAULT_HASH_SIZE))));
     comp.setDumpHashes(pa.has("dump_hashes"));

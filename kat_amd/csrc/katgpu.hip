@@ -915,6 +915,45 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     return KATGPU_OK;
 }
 
+extern "C" int katgpu_comp3(katgpu_table* t1, katgpu_table* t2, katgpu_table* t3, int canon1, int canon2, int canon3,
+                            double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins, uint64_t* main_mx,
+                            uint64_t* ends_mx, uint64_t* middle_mx, uint64_t* mixed_mx, uint64_t counters[13], uint64_t* spectra) {
+    if (!t3 || !ends_mx || !middle_mx || !mixed_mx) return KATGPU_ERR_INVALID_ARG;
+    int rc = katgpu_comp(t1, t2, canon1, canon2, d1_scale, d2_scale, d1_bins, d2_bins, main_mx, counters, spectra);
+    if (rc) return rc;
+    katgpu_ctx* c = t1->ctx;
+    if (t3->ctx != c) return fail(c, KATGPU_ERR_INVALID_ARG, "tables belong to different contexts");
+    if (t3->d.k != t1->d.k)
+        return fail(c, KATGPU_ERR_MISMATCH, "Cannot process hashes that were created with different K-mer lengths.  Expected: %u.  Key length was %u", t1->d.k, t3->d.k);
+    rc = refresh_counters(t3); if (rc) return rc;
+    const size_t cells = (size_t)d1_bins * d2_bins;
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, (3 * cells + 13) * 8));
+    hipMemsetAsync(d, 0, (3 * cells + 13) * 8, c->stream);
+    Comp3Args a{};
+    a.d1_scale = d1_scale; a.d2_scale = d2_scale; a.d1_bins = d1_bins; a.d2_bins = d2_bins;
+    a.canon2 = canon2 ? 1 : 0; a.canon3 = canon3 ? 1 : 0;
+    a.mx[0] = d; a.mx[1] = d + cells; a.mx[2] = d + 2 * cells;
+    {
+        ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap);
+        hipLaunchKernelGGL(k_comp3_pass1, dim3(reducer_grid(c, t1->d.cap + 1, 3)), dim3(256), 3 * COMP_TILE * COMP_TILE * sizeof(uint32_t), c->stream,
+                           t1->d, t1->n_ovf, t2->d, t2->n_ovf, t3->d, t3->n_ovf, a);
+        hipLaunchKernelGGL(k_comp3_pass3, dim3(reducer_grid(c, t3->d.cap + 1, 8)), dim3(256), 0, c->stream, t3->d, t3->n_ovf, d + 3 * cells);
+    }
+    HIPCHK(c, hipGetLastError());
+    uint64_t c3[13];
+    hipMemcpyAsync(ends_mx, d, cells * 8, hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(middle_mx, d + cells, cells * 8, hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(mixed_mx, d + 2 * cells, cells * 8, hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(c3, d + 3 * cells, sizeof c3, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    counters[CC_H3_TOTAL] = c3[CC_H3_TOTAL];
+    counters[CC_H3_DISTINCT] = c3[CC_H3_DISTINCT];
+    return KATGPU_OK;
+}
+
 // ------------------------------------------------------------------ device buffers + synthetic workload
 
 extern "C" int katgpu_dev_alloc(katgpu_ctx* c, size_t bytes, void** p) {

@@ -366,6 +366,70 @@ k_comp(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
     }
 }
 
+// ---- K5b: the third comp input (src/comp.cc:123-127,403-433,466-479) ----
+// Pass over hash 1 again with both other tables probed: the scaled counts decide which of the ends / middle / mixed
+// matrices the k-mer lands in.  Three 64x64 LDS tiles (the hot low-count corner), global atomics elsewhere.
+struct Comp3Args {
+    double d1_scale, d2_scale;
+    uint32_t d1_bins, d2_bins;
+    uint32_t canon2, canon3;         // probes canonicalised iff that input is canonical (src/comp.cc:401,404)
+    unsigned long long* mx[3];       // 0 ends, 1 middle, 2 mixed: each d1_bins x d2_bins
+};
+
+__global__ void __launch_bounds__(256)
+k_comp3_pass1(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, DevTable t3, uint32_t n3_ovf, Comp3Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_tiles[];      // 3 x 64 x 64
+    for (uint32_t i = threadIdx.x; i < 3 * COMP_TILE * COMP_TILE; i += blockDim.x) s_tiles[i] = 0;
+    __syncthreads();
+    const uint32_t k = t1.k;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t rounds = (t1.cap + 1 + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t i = first + r * stride;
+        uint64_t key = EMPTY, c1 = 0;
+        bool occ = false;
+        if (i < t1.cap) { key = t1.keys[i]; occ = key != EMPTY; if (occ) c1 = slot_count(t1, i, key, n1_ovf); }
+        else if (i == t1.cap) { c1 = t1.ctrs[CTR_ONES]; occ = c1 != 0; }
+        uint32_t which = 0, cell = 0;
+        bool in_tile = false;
+        if (occ) {
+            const uint64_t can = kmer_canonical(key, k);
+            const uint64_t c2 = table_get(t2, a.canon2 ? can : key, n2_ovf);
+            const uint64_t c3 = table_get(t3, a.canon3 ? can : key, n3_ovf);
+            uint64_t s1 = scale_count(c1, a.d1_scale), s2 = scale_count(c2, a.d2_scale), s3 = scale_count(c3, a.d2_scale);
+            if (s1 >= a.d1_bins) s1 = a.d1_bins - 1;
+            if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
+            if (s3 >= a.d2_bins) s3 = a.d2_bins - 1;
+            which = s2 == s3 ? 0u : (s3 > 0 ? 2u : 1u);                     // ends / mixed / middle (src/comp.cc:426-432)
+            in_tile = s1 < COMP_TILE && s3 < COMP_TILE;
+            cell = in_tile ? which * COMP_TILE * COMP_TILE + (uint32_t)(s1 * COMP_TILE + s3) : (uint32_t)(s1 * a.d2_bins + s3);
+        }
+        lds_inc_aggregated(s_tiles, cell, occ && in_tile);
+        if (occ && !in_tile) atomicAdd(&a.mx[which][cell], 1ULL);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 3 * COMP_TILE * COMP_TILE; i += blockDim.x) {
+        const uint32_t v = s_tiles[i];
+        if (!v) continue;
+        const uint32_t which = i / (COMP_TILE * COMP_TILE), rc = i % (COMP_TILE * COMP_TILE), rr = rc / COMP_TILE, cc = rc % COMP_TILE;
+        if (rr < a.d1_bins && cc < a.d2_bins) atomicAdd(&a.mx[which][(uint64_t)rr * a.d2_bins + cc], (unsigned long long)v);
+    }
+}
+
+// updateHash3Counters (lib/src/comp_counters.cc:113-117): hash3_total, hash3_distinct
+__global__ void __launch_bounds__(256)
+k_comp3_pass3(DevTable t3, uint32_t n3_ovf, unsigned long long* counters) {
+    uint64_t tot = 0, dis = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t3.cap; i += stride) {
+        if (i < t3.cap) { const uint64_t key = t3.keys[i]; if (key != EMPTY) { tot += slot_count(t3, i, key, n3_ovf); ++dis; } }
+        else { const uint64_t c = t3.ctrs[CTR_ONES]; if (c) { tot += c; ++dis; } }
+    }
+    for (int off = 32; off > 0; off >>= 1) { tot += __shfl_down(tot, off, 64); dis += __shfl_down(dis, off, 64); }
+    if ((threadIdx.x & 63) == 0 && dis) { atomicAdd(&counters[CC_H3_TOTAL], (unsigned long long)tot); atomicAdd(&counters[CC_H3_DISTINCT], (unsigned long long)dis); }
+}
+
 // ---- batch lookup (JellyfishHelper::getCount, lib/src/jellyfish_helper.cc:189-194) ----
 __global__ void __launch_bounds__(256)
 k_get(DevTable t, uint32_t n_ovf, const uint64_t* __restrict__ keys, uint64_t n, int canonicalise, uint64_t* __restrict__ out) {

@@ -522,6 +522,28 @@ void ko_comp(const ko_table* t1, const ko_table* t2, int canon1, int canon2,
     });
 }
 
+/* Comp::compareSlice with a third hash (src/comp.cc:403-433,466-479) */
+void ko_comp3(const ko_table* t1, const ko_table* t2, const ko_table* t3, int canon1, int canon2, int canon3,
+              double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
+              uint64_t* mx, uint64_t* ends, uint64_t* middle, uint64_t* mixed, uint64_t cc[13], uint64_t* spectra) {
+    const unsigned k = t1->k;
+    const size_t cells = (size_t)d1_bins * d2_bins;
+    ko_comp(t1, t2, canon1, canon2, d1_scale, d2_scale, d1_bins, d2_bins, mx, cc, spectra);
+    memset(ends, 0, cells * sizeof(uint64_t)); memset(middle, 0, cells * sizeof(uint64_t)); memset(mixed, 0, cells * sizeof(uint64_t));
+    FOR_EACH_ENTRY(t1, key, c1, {
+        uint64_t c2 = ko_table_get(t2, canon2 ? ko_canonical(key, k) : key);
+        uint64_t c3 = ko_table_get(t3, canon3 ? ko_canonical(key, k) : key);
+        uint64_t s1 = scale_counter(c1, d1_scale), s2 = scale_counter(c2, d2_scale), s3 = scale_counter(c3, d2_scale);
+        if (s1 >= d1_bins) s1 = d1_bins - 1;
+        if (s2 >= d2_bins) s2 = d2_bins - 1;
+        if (s3 >= d2_bins) s3 = d2_bins - 1;
+        if (s2 == s3) ends[s1 * d2_bins + s3]++;                 /* :426-427 */
+        else if (s3 > 0) mixed[s1 * d2_bins + s3]++;             /* :428-429 */
+        else middle[s1 * d2_bins + s3]++;                        /* :430-431 */
+    });
+    FOR_EACH_ENTRY(t3, key, c3, { (void)key; cc[H3_TOTAL] += c3; cc[H3_DISTINCT]++; });   /* updateHash3Counters :113-117 */
+}
+
 /* ------------------------------------------------------------------ distance metrics ------------- */
 /* lib/include/kat/distance_metrics.hpp:39-127.  Integer accumulation where the reference uses
  * uint64_t (Minkowski sum, :52-57; the Cosine products s1[i]*s2[i] are uint64 products added to a double, :85). */
@@ -658,14 +680,23 @@ int ko_write_comp_main(const char* out_path, unsigned k,
 /* CompCounters::printCounts, lib/src/comp_counters.cc:144-206 (two-input form: hash3_total == 0) */
 int ko_write_comp_stats(const char* out_path, const char* hash1_path, const char* hash2_path,
                         const uint64_t c[13], const uint64_t* spectra, uint32_t ss) {
+    return ko_write_comp_stats3(out_path, hash1_path, hash2_path, "", c, spectra, ss);
+}
+
+int ko_write_comp_stats3(const char* out_path, const char* hash1_path, const char* hash2_path, const char* hash3_path,
+                         const uint64_t c[13], const uint64_t* spectra, uint32_t ss) {
     FILE* f = fopen(out_path, "w");
     if (!f) return KO_ERR_IO;
     static const char* names[5] = {"Manhattan", "Euclidean", "Cosine", "Canberra", "Jaccard"};
+    const int h3 = c[H3_TOTAL] > 0;
     fprintf(f, "K-mer statistics for: \n");
     fprintf(f, " - Hash 1: "); quoted_path(f, hash1_path); fputc('\n', f);
     fprintf(f, " - Hash 2: "); quoted_path(f, hash2_path); fputc('\n', f);
+    if (h3) { fprintf(f, " - Hash 3: "); quoted_path(f, hash3_path); fputc('\n', f); }
     fprintf(f, "\nTotal K-mers in: \n - Hash 1: %llu\n - Hash 2: %llu\n", (unsigned long long)c[H1_TOTAL], (unsigned long long)c[H2_TOTAL]);
+    if (h3) fprintf(f, " - Hash 3: %llu\n", (unsigned long long)c[H3_TOTAL]);
     fprintf(f, "\nDistinct K-mers in:\n - Hash 1: %llu\n - Hash 2: %llu\n", (unsigned long long)c[H1_DISTINCT], (unsigned long long)c[H2_DISTINCT]);
+    if (h3) fprintf(f, " - Hash 3: %llu\n", (unsigned long long)c[H3_DISTINCT]);
     fprintf(f, "\nTotal K-mers only found in:\n - Hash 1: %llu\n - Hash 2: %llu\n", (unsigned long long)c[H1_ONLY_TOTAL], (unsigned long long)c[H2_ONLY_TOTAL]);
     fprintf(f, "\nDistinct K-mers only found in:\n - Hash 1: %llu\n - Hash 2: %llu\n\n", (unsigned long long)c[H1_ONLY_DISTINCT], (unsigned long long)c[H2_ONLY_DISTINCT]);
     fprintf(f, "Shared K-mers:\n - Total shared found in hash 1: %llu\n - Total shared found in hash 2: %llu\n - Distinct shared K-mers: %llu\n\n",
@@ -675,6 +706,26 @@ int ko_write_comp_stats(const char* out_path, const char* hash1_path, const char
     fprintf(f, "\nDistance between spectra 1 and 2 (shared k-mers):\n");
     for (int i = 0; i < 5; i++) fprintf(f, " - %s distance: %g\n", names[i], ko_distance(i, spectra + 2 * (size_t)ss, spectra + 3 * (size_t)ss, ss));
     fputc('\n', f);
+    fclose(f);
+    return KO_OK;
+}
+
+/* Comp::printEndsMatrix / printMiddleMatrix / printMixedMatrix, src/comp.cc:330-358 */
+int ko_write_comp_extra(const char* out_path, int which, const char* p1, const char* p2, const char* p3,
+                        uint32_t d1_bins, uint32_t d2_bins, const uint64_t* mx) {
+    FILE* f = fopen(out_path, "w");
+    if (!f) return KO_ERR_IO;
+    if (which == 0) {
+        fprintf(f, "# Each row represents K-mer frequency for: %s\n", p1);
+        fprintf(f, "# Each column represents K-mer frequency for sequence ends: %s\n", p3);
+    } else if (which == 1) {
+        fprintf(f, "# Each row represents K-mer frequency for: %s\n", p1);
+        fprintf(f, "# Each column represents K-mer frequency for sequence middles: %s\n", p2);
+    } else {
+        fprintf(f, "# Each row represents K-mer frequency for hash file 1: %s\n", p1);
+        fprintf(f, "# Each column represents K-mer frequency for mixed: %s and %s\n", p2, p3);
+    }
+    print_matrix(f, mx, d1_bins, d2_bins);
     fclose(f);
     return KO_OK;
 }

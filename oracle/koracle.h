@@ -78,6 +78,13 @@ void ko_comp(const ko_table* t1, const ko_table* t2, int canon1, int canon2,
              double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
              uint64_t* main_mx, uint64_t counters[13], uint64_t* spectra);
 
+/* three-input form (src/comp.cc:123-127,403-433,466-479): adds ends / middle / mixed matrices (each d1_bins x d2_bins)
+ * and counters[2] = hash3_total, counters[5] = hash3_distinct */
+void ko_comp3(const ko_table* t1, const ko_table* t2, const ko_table* t3, int canon1, int canon2, int canon3,
+              double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
+              uint64_t* main_mx, uint64_t* ends_mx, uint64_t* middle_mx, uint64_t* mixed_mx,
+              uint64_t counters[13], uint64_t* spectra);
+
 /* --- writers (byte-exact text) --- */
 int ko_write_hist(const char* out_path, unsigned k, const char* const* paths, size_t n_paths,
                   uint64_t base, uint64_t inc, const uint64_t* data, size_t nb);
@@ -88,6 +95,12 @@ int ko_write_comp_main(const char* out_path, unsigned k,
                        uint32_t d1_bins, uint32_t d2_bins, const uint64_t* mx);
 int ko_write_comp_stats(const char* out_path, const char* hash1_path, const char* hash2_path,
                         const uint64_t counters[13], const uint64_t* spectra, uint32_t spec_size);
+/* same with the " - Hash 3:" lines (printed iff hash3_total > 0, lib/src/comp_counters.cc:150-151,160-161,169-170) */
+int ko_write_comp_stats3(const char* out_path, const char* hash1_path, const char* hash2_path, const char* hash3_path,
+                         const uint64_t counters[13], const uint64_t* spectra, uint32_t spec_size);
+/* Comp::printEndsMatrix / printMiddleMatrix / printMixedMatrix (src/comp.cc:330-358); which: 0 ends, 1 middle, 2 mixed */
+int ko_write_comp_extra(const char* out_path, int which, const char* path1, const char* path2, const char* path3,
+                        uint32_t d1_bins, uint32_t d2_bins, const uint64_t* mx);
 int ko_write_comp_hist(const char* out_path, unsigned k, const char* const* paths, size_t n_paths,
                        const uint64_t* spectrum, uint32_t spec_size);
 /* distance metrics (lib/include/kat/distance_metrics.hpp:39-127): 0 Manhattan 1 Euclidean 2 Cosine 3 Canberra 4 Jaccard */

@@ -50,6 +50,10 @@ def lib():
     L.ko_gcp.argtypes = [C.c_void_p, C.c_double, C.c_uint32, C.c_void_p]
     L.ko_comp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
                           C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ko_comp3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ko_write_comp_stats3.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.ko_write_comp_extra.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.ko_encode.argtypes = [C.c_char_p, C.c_uint, u64p]
     L.ko_decode.argtypes = [C.c_uint64, C.c_uint, C.c_char_p]
     L.ko_revcomp.restype = C.c_uint64
@@ -246,3 +250,27 @@ def write_comp(prefix, k, paths1, paths2, d1_bins, d2_bins, mx, cc, sp, hists=Fa
     if hists:
         L.ko_write_comp_hist(os.fsencode(prefix + ".1.hist"), k, a1, n1, s[0].ctypes.data, ss)
         L.ko_write_comp_hist(os.fsencode(prefix + ".2.hist"), k, a2, n2, s[1].ctypes.data, ss)
+
+
+def comp3(t1, t2, t3, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001):
+    ss = min(d1_bins, d2_bins)
+    mxs = [np.zeros((d1_bins, d2_bins), np.uint64) for _ in range(4)]
+    cc = np.zeros(13, np.uint64)
+    sp = np.zeros((4, ss), np.uint64)
+    lib().ko_comp3(t1.h, t2.h, t3.h, int(t1.canonical), int(t2.canonical), int(t3.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
+                   mxs[0].ctypes.data, mxs[1].ctypes.data, mxs[2].ctypes.data, mxs[3].ctypes.data, cc.ctypes.data, sp.ctypes.data)
+    return mxs[0], mxs[1], mxs[2], mxs[3], cc, sp
+
+
+def write_comp3(prefix, k, paths1, paths2, paths3, d1_bins, d2_bins, mxs, cc, sp, hists=False):
+    """All files `kat comp` writes for three inputs: -main.mx, -ends.mx, -middle.mx, -mixed.mx, .stats (+ .N.hist)."""
+    write_comp(prefix, k, paths1, paths2, d1_bins, d2_bins, mxs[0], cc, sp, hists)
+    L = lib()
+    c = np.ascontiguousarray(cc, np.uint64)
+    s = np.ascontiguousarray(sp, np.uint64)
+    L.ko_write_comp_stats3(os.fsencode(prefix + ".stats"), os.fsencode(paths1[0]), os.fsencode(paths2[0]), os.fsencode(paths3[0]),
+                           c.ctypes.data, s.ctypes.data, min(d1_bins, d2_bins))
+    for which, name in enumerate(("-ends.mx", "-middle.mx", "-mixed.mx")):
+        m = np.ascontiguousarray(mxs[which + 1], np.uint64)
+        L.ko_write_comp_extra(os.fsencode(prefix + name), which, os.fsencode(paths1[0]), os.fsencode(paths2[0]), os.fsencode(paths3[0]),
+                              d1_bins, d2_bins, m.ctypes.data)

@@ -73,6 +73,20 @@ def test_comp_cli(ko, refdata, tmp_path):
         assert (tmp_path / ("glob_test" + suffix)).read_bytes() == (tmp_path / ("w2" + suffix)).read_bytes(), suffix
 
 
+def test_comp_three_inputs_cli(ko, refdata, tmp_path):
+    """`kat comp <reads1> <reads2> <asm>`: -main/-ends/-middle/-mixed .mx + .stats with the Hash 3 lines."""
+    r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
+    asm = os.path.join(refdata, "sect_length_test.fa")
+    r = run(["comp", "-m15", "-P", "-o", "three", r1, r2, asm], tmp_path)
+    assert r.returncode == 0, r.stderr
+    t = [ko.Table(15, True).count_files([r1]), ko.Table(15, True).count_files([r2]), ko.Table(15, False).count_files([asm])]
+    main, ends, middle, mixed, cc, sp = ko.comp3(t[0], t[1], t[2])
+    ko.write_comp3(str(tmp_path / "want"), 15, [r1], [r2], [asm], 1001, 1001, (main, ends, middle, mixed), cc, sp)
+    for suffix in ("-main.mx", "-ends.mx", "-middle.mx", "-mixed.mx", ".stats"):
+        assert (tmp_path / ("three" + suffix)).read_bytes() == (tmp_path / ("want" + suffix)).read_bytes(), suffix
+    assert b' - Hash 3: "' in (tmp_path / "three.stats").read_bytes()
+
+
 def test_generated_pe_reads_vs_assembly(ko, tmp_path):
     """Parity-scale version of BASELINE.json configs[3]: PE FASTQ + assembly FASTA written to disk, both sides read the files."""
     g = synth.genome(300000, seed=20260927)

@@ -258,3 +258,18 @@ def test_unchecked_add_sweep_guard(ko, tmp_path):
     assert np.array_equal(got["k"], ok_) and np.array_equal(got["c"], oc)
     assert int(oc.max()) >= 2980 and np.array_equal(got["h"], ot.hist(1, 5000, 1))
     assert int(got["regrow"]) > 100                     # sweeps are accounted under the regrow class
+
+
+def test_three_input_comp(engine, ko, refdata):
+    p = [os.path.join(refdata, f) for f in ("ecoli_r1.1K.fastq", "ecoli_r2.1K.fastq", "sect_length_test.fa")]
+    for k, flags in ((13, (True, True, True)), (17, (False, True, False))):
+        gt = [engine.count([p[i]], k, flags[i]) for i in range(3)]
+        ot = [ko.Table(k, flags[i]).count_files([p[i]]) for i in range(3)]
+        for args in ((1.0, 1.0, 1001, 1001), (0.3, 4.0, 20, 9)):
+            got = kat_amd.comp3(gt[0], gt[1], gt[2], *args)
+            want = ko.comp3(ot[0], ot[1], ot[2], *args)
+            for g, w, name in zip(got, want, ("main", "ends", "middle", "mixed", "counters", "spectra")):
+                assert np.array_equal(g, w), (k, flags, args, name)
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        kat_amd.comp3(engine.table(21, True), engine.table(21, True), engine.table(27, True))
+    assert ei.value.code == 9

@@ -129,3 +129,33 @@ def test_reducers_against_direct_python(ko):
             h2only += 1
     assert np.array_equal(mx, wmx) and int(cc[9]) == h2only
     assert int(cc[0]) == sum(d1.values()) and int(cc[1]) == sum(d2.values()) and int(cc[3]) == len(d1) and int(cc[4]) == len(d2)
+
+
+def test_three_input_comp_against_direct_python(ko):
+    """ends / middle / mixed matrices + hash-3 counters (src/comp.cc:403-433,466-479) restated directly."""
+    k = 9
+    rng = np.random.default_rng(11)
+    pool = rng.choice(4 ** k, size=900, replace=False)
+    d = [{}, {}, {}]
+    tabs = [ko.Table(k, False), ko.Table(k, True), ko.Table(k, False)]
+    for t, dd, keys, hi in ((0, d[0], pool[:600], 30), (1, d[1], pool[200:800], 200), (2, d[2], pool[400:], 60)):
+        for key in keys:
+            key = int(key)
+            if tabs[t].canonical:
+                key = ko.canonical(key, k)
+            c = int(rng.integers(1, hi))
+            tabs[t].add(key, c)
+            dd[key] = dd.get(key, 0) + c
+    main, ends, middle, mixed, cc, sp = ko.comp3(tabs[0], tabs[1], tabs[2], 1.0, 0.2, 25, 12)
+    m2, c2, s2 = ko.comp(tabs[0], tabs[1], 1.0, 0.2, 25, 12)
+    assert np.array_equal(main, m2) and np.array_equal(sp, s2)
+    sc = lambda c, s, n: min(int(np.ceil(c * s)) if c else 0, n - 1)
+    we, wmid, wmix = (np.zeros((25, 12), np.uint64) for _ in range(3))
+    for key, c1 in d[0].items():
+        c2_ = d[1].get(ko.canonical(key, k), 0)          # input 2 canonical -> probe canonicalised
+        c3_ = d[2].get(key, 0)                           # input 3 not canonical -> probe as is
+        s1, s2_, s3_ = sc(c1, 1.0, 25), sc(c2_, 0.2, 12), sc(c3_, 0.2, 12)
+        (we if s2_ == s3_ else wmix if s3_ > 0 else wmid)[s1, s3_] += 1
+    assert np.array_equal(ends, we) and np.array_equal(middle, wmid) and np.array_equal(mixed, wmix)
+    assert int(cc[2]) == sum(d[2].values()) and int(cc[5]) == len(d[2])
+    assert int(ends.sum() + middle.sum() + mixed.sum()) == len(d[0])
