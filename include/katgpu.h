@@ -93,6 +93,18 @@ int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n, int canoni
  * Pass cap = 0 to query *n_out only. */
 int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* counts, size_t cap, size_t* n_out);
 
+/* ---- Jellyfish hash files (.jf, "binary/sorted"): replaces HashLoader::loadHash / JellyfishHelper::dumpHash
+ *      (lib/src/jellyfish_helper.cc:97-187,248-256) and InputHandler::dump (lib/src/input_handler.cc:221-243).
+ *      Records are written sorted by (matrix x k-mer) & (size-1), then k-mer, with the matrix in the JSON header, counts
+ *      saturated to 4 bytes (lib/src/input_handler.cc:196) -- the layout jellyfish / KAT read.  Errors of the two
+ *      host-only calls (and of katgpu_jf_load before it touches the device) are reported by katgpu_jf_last_error(). ---- */
+int katgpu_jf_load(katgpu_ctx* ctx, const char* path, katgpu_table** out);     /* k and canonical come from the header */
+int katgpu_jf_dump(katgpu_table* t, const char* path);
+/* host only, no device needed */
+int katgpu_jf_write_records(const char* path, uint32_t k, int canonical, const uint64_t* keys, const uint64_t* counts, size_t n);
+int katgpu_jf_read_records(const char* path, uint32_t* k, int* canonical, uint64_t** keys, uint64_t** counts, size_t* n);  /* free with katgpu_free_host */
+const char* katgpu_jf_last_error(void);
+
 /* ---- reducers ---------------------------------------------------------------------------------------- */
 
 /* Histogram::bin + merge (src/histogram.cc:162-199,146-160).  base/ceil from calcBase/calcCeil

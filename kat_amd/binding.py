@@ -28,6 +28,7 @@ EXPORTS = (
     "katgpu_table_merge_host", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
     "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_free_host",
+    "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
 )
 
 
@@ -95,6 +96,11 @@ def load_library():
     L.katgpu_parse_file.argtypes = [C.c_char_p, u32, pp, C.POINTER(sz), cpp]
     L.katgpu_free_host.argtypes = [vp]
     L.katgpu_free_host.restype = None
+    L.katgpu_jf_load.argtypes = [vp, C.c_char_p, pp]
+    L.katgpu_jf_dump.argtypes = [vp, C.c_char_p]
+    L.katgpu_jf_write_records.argtypes = [C.c_char_p, u32, C.c_int, vp, vp, sz]
+    L.katgpu_jf_read_records.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(C.c_int), pp, pp, C.POINTER(sz)]
+    L.katgpu_jf_last_error.restype = C.c_char_p
     _lib = L
     return L
 
@@ -120,6 +126,31 @@ def hist_geometry(low, high):
 
 def _cpaths(paths):
     return (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths]), len(paths)
+
+
+def jf_read_records(path):
+    """Host-only .jf reader: (k, canonical, keys, counts)."""
+    L = load_library()
+    k, can, n = C.c_uint32(), C.c_int(), C.c_size_t()
+    pk, pc = C.c_void_p(), C.c_void_p()
+    rc = L.katgpu_jf_read_records(os.fsencode(path), C.byref(k), C.byref(can), C.byref(pk), C.byref(pc), C.byref(n))
+    if rc:
+        raise KatGpuError(rc, L.katgpu_jf_last_error().decode(errors="replace"))
+    keys = np.frombuffer(C.string_at(pk, n.value * 8), dtype=np.uint64).copy() if n.value else np.zeros(0, np.uint64)
+    counts = np.frombuffer(C.string_at(pc, n.value * 8), dtype=np.uint64).copy() if n.value else np.zeros(0, np.uint64)
+    L.katgpu_free_host(pk)
+    L.katgpu_free_host(pc)
+    return k.value, bool(can.value), keys, counts
+
+
+def jf_write_records(path, k, canonical, keys, counts):
+    """Host-only .jf writer (binary/sorted, 4-byte saturated counters)."""
+    L = load_library()
+    kk = np.ascontiguousarray(keys, np.uint64)
+    cc = np.ascontiguousarray(counts, np.uint64)
+    rc = L.katgpu_jf_write_records(os.fsencode(path), k, int(bool(canonical)), kk.ctypes.data, cc.ctypes.data, kk.size)
+    if rc:
+        raise KatGpuError(rc, L.katgpu_jf_last_error().decode(errors="replace"))
 
 
 class DeviceBuffer:
@@ -204,6 +235,14 @@ class Engine:
         h = C.c_void_p()
         self._chk(self.L.katgpu_count(self.h, arr, n, k, int(bool(canonical)), tr, size_hint, int(bool(disable_grow)), C.byref(h)))
         return Table(self, k, canonical, _handle=h.value)
+
+    def load_jf(self, path):
+        """HashLoader::loadHash: a .jf file -> table (k and canonical from its header)."""
+        h = C.c_void_p()
+        rc = self.L.katgpu_jf_load(self.h, os.fsencode(path), C.byref(h))
+        if rc:
+            raise KatGpuError(rc, self.L.katgpu_jf_last_error().decode(errors="replace"))
+        return Table(self, self.L.katgpu_table_k(h), bool(self.L.katgpu_table_canonical(h)), _handle=h.value)
 
     # ---- profiling ----
     def profile_reset(self):
@@ -302,6 +341,12 @@ class Table:
         keys, counts = self.export()
         order = np.argsort(keys, kind="stable")
         return keys[order], counts[order]
+
+    def dump_jf(self, path):
+        """InputHandler::dump: write the table as a Jellyfish binary/sorted hash."""
+        rc = self.engine.L.katgpu_jf_dump(self.h, os.fsencode(path))
+        if rc:
+            raise KatGpuError(rc, self.engine.L.katgpu_jf_last_error().decode(errors="replace") or self.engine.L.katgpu_last_error(self.engine.h).decode(errors="replace"))
 
     # ---- reducers ----
     def hist(self, low=1, high=10000, inc=1):

@@ -116,8 +116,6 @@ void InputHandler::count(uint16_t threads) {                                // l
     auto t0 = std::chrono::steady_clock::now();
     std::cout << "Input " << index << " is a sequence file.  Counting kmers for input " << index << " (" << pathString() << ") ...";
     std::cout.flush();
-    if (mode != COUNT)
-        throw JellyfishException("Input " + std::to_string(index) + " is a jellyfish hash: loading .jf files is not part of this build (SURVEY.md 8(f))");
     std::vector<const char*> paths;
     for (const auto& p : input) paths.push_back(p.c_str());
     Engine::check(katgpu_count(Engine::ctx(), paths.data(), paths.size(), merLen, canonical ? 1 : 0, trim5p.data(), hashSize,
@@ -127,6 +125,45 @@ void InputHandler::count(uint16_t threads) {                                // l
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     char buf[64]; snprintf(buf, sizeof buf, "  Time taken: %.1fs\n\n", s);   // auto_cpu_timer(1, "  Time taken: %ws\n\n")
     std::cout << buf;
+}
+
+void InputHandler::loadHash() {                                             // lib/src/input_handler.cc:204-219
+    auto t0 = std::chrono::steady_clock::now();
+    std::cout << "Loading hashes into memory...";
+    std::cout.flush();
+    int rc = katgpu_jf_load(Engine::ctx(), input[0].c_str(), &hash);
+    if (rc) throw JellyfishException(katgpu_jf_last_error());
+    canonical = katgpu_table_canonical(hash) != 0;                          // hashLoader->getCanonical() / getMerLen()
+    merLen = (uint16_t)katgpu_table_k(hash);
+    std::cout << " done.";
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    char buf[64]; snprintf(buf, sizeof buf, "  Time taken: %.1fs\n\n", s);
+    std::cout << buf;
+}
+
+void InputHandler::validateMerLen(uint16_t expected) {                      // lib/src/input_handler.cc:145-158
+    if (mode == LOAD && hash && katgpu_table_k(hash) != expected)
+        throw JellyfishException("Cannot process hashes that were created with different K-mer lengths.  Expected: " + std::to_string(expected) +
+                                 ".  Key length was " + std::to_string(katgpu_table_k(hash)) + " for : " + input[0]);
+}
+
+void InputHandler::dump(const std::string& outputPath, uint16_t threads) {  // lib/src/input_handler.cc:221-243
+    (void)threads;
+    struct stat st;
+    if (lstat(outputPath.c_str(), &st) == 0) unlink(outputPath.c_str());
+    if (mode == COUNT) {
+        auto t0 = std::chrono::steady_clock::now();
+        std::cout << "Dumping hash to " << outputPath << " ...";
+        std::cout.flush();
+        int rc = katgpu_jf_dump(hash, outputPath.c_str());
+        if (rc) throw JellyfishException(*katgpu_jf_last_error() ? katgpu_jf_last_error() : katgpu_last_error(Engine::ctx()));
+        std::cout << " done.";
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        char buf[64]; snprintf(buf, sizeof buf, "  Time taken: %.1fs\n\n", s);
+        std::cout << buf;
+    } else if (symlink(getSingleInput().c_str(), outputPath.c_str()) != 0) {
+        throw FileSystemException("Could not create symlink " + outputPath);
+    }
 }
 
 std::shared_ptr<std::vector<std::string>> InputHandler::globFiles(const std::string& in) {       // :245-255

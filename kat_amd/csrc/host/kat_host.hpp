@@ -87,6 +87,10 @@ public:
     void set5pTrim(const std::vector<uint16_t>& trim_list);
     void validateInput();                        // throws if an input is missing; sets mode
     void count(uint16_t threads);                // *** the drop-in boundary: katgpu_count ***
+    void loadHeader() {}                         // the header travels with katgpu_jf_load (lib/src/input_handler.cc:139-143)
+    void loadHash();                             // lib/src/input_handler.cc:204-219 -> katgpu_jf_load
+    void validateMerLen(uint16_t merLen);        // lib/src/input_handler.cc:145-158
+    void dump(const std::string& outputPath, uint16_t threads);   // lib/src/input_handler.cc:221-243 -> katgpu_jf_dump
     static std::shared_ptr<std::vector<std::string>> globFiles(const std::string& input);
     static std::shared_ptr<std::vector<std::string>> globFiles(const std::vector<std::string>& input);
     static bool isPipe(const std::string& p);

@@ -46,10 +46,10 @@ void Histogram::execute() {                                                     
     input.validateInput();
     ensureDirectoryExists(parentOfAbsolute(outputPrefix));
     if (input.mode == InputHandler::COUNT) input.count(threads);
-    else throw JellyfishException("loading a jellyfish hash is not part of this build (SURVEY.md 8(f)): " + input.getSingleInput());
+    else { input.loadHeader(); input.loadHash(); }
     data.assign(nb_buckets, 0);
     bin();
-    if (input.dumpHash) std::cerr << "Warning: -d/--dump_hash is not part of this build (.jf export is a SURVEY.md 8(f) row); ignored." << endl;
+    if (input.dumpHash) input.dump(outputPrefix + "-hash.jf" + std::to_string(input.merLen), threads);      // :105-108
     // merge(): nothing to do -- the device reduces into one array (the reference sums T per-thread histograms, :146-160)
 }
 
@@ -123,11 +123,11 @@ void Gcp::execute() {                                                           
     input.validateInput();
     ensureDirectoryExists(parentOfAbsolute(outputPrefix));
     if (input.mode == InputHandler::COUNT) input.count(threads);
-    else throw JellyfishException("loading a jellyfish hash is not part of this build (SURVEY.md 8(f)): " + input.getSingleInput());
+    else { input.loadHeader(); input.loadHash(); }
     // header->key_len() / 2 rows == k rows: GC count == k has no row (src/gcp.cc:93)
     gcp_mx = Matrix64(katgpu_table_k(input.hash), (uint32_t)cvgBins + 1);
     analyse();
-    if (input.dumpHash) std::cerr << "Warning: -d/--dump_hash is not part of this build (.jf export is a SURVEY.md 8(f) row); ignored." << endl;
+    if (input.dumpHash) input.dump(outputPrefix + "-hash.jf" + std::to_string(input.merLen), threads);      // :102-105
 }
 
 void Gcp::analyse() {                                                                             // src/gcp.cc:158-197
@@ -220,10 +220,20 @@ void Comp::execute() {                                                          
     for (size_t i = 0; i < inputSize(); i++) {                  // sequentially, one input after the other (:139-143)
         InputHandler& in = input[i];
         if (in.mode == InputHandler::COUNT) in.count(threads);
-        else throw JellyfishException("loading a jellyfish hash is not part of this build (SURVEY.md 8(f)): " + in.getSingleInput());
     }
+    bool anyLoad = false, allLoad = true;                        // :146-167
+    for (size_t i = 0; i < inputSize(); i++) {
+        if (input[i].mode == InputHandler::LOAD) { input[i].loadHeader(); anyLoad = true; }
+        else allLoad = false;
+    }
+    if (anyLoad)
+        for (size_t i = 0; i < inputSize(); i++) if (input[i].mode == InputHandler::LOAD) input[i].loadHash();
+    if (allLoad) setMerLen((uint8_t)katgpu_table_k(input[0].hash));
+    for (size_t i = 0; i < inputSize(); i++) input[i].validateMerLen(getMerLen());
     compare();
-    if (input[0].dumpHash) std::cerr << "Warning: -d/--dump_hashes is not part of this build (.jf export is a SURVEY.md 8(f) row); ignored." << endl;
+    if (input[0].dumpHash)                                       // :174-179
+        for (size_t i = 0; i < inputSize(); i++)
+            input[i].dump(outputPrefix + "-hash" + std::to_string(input[i].index) + ".jf" + std::to_string(getMerLen()), threads);
     // merge(): the reference's dense T-way map merge (:248-265) has no counterpart, the device produced one matrix
 }
 

@@ -87,6 +87,35 @@ def test_comp_three_inputs_cli(ko, refdata, tmp_path):
     assert b' - Hash 3: "' in (tmp_path / "three.stats").read_bytes()
 
 
+def test_jf_inputs_and_dump_cli(ko, refdata, tmp_path):
+    """A .jf input (LOAD mode, k from its header) and -d (dump the counted hash, reload it, same answer)."""
+    jf = os.path.join(refdata, "ecoli.header.jf27")
+    r = run(["hist", "-o", "jf.hist", jf], tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "Loading hashes into memory..." in r.stdout
+    ko.write_hist(str(tmp_path / "want"), 27, [jf], 1, 10000, 1, ko.Table.from_jf(jf).hist())
+    assert (tmp_path / "jf.hist").read_bytes() == (tmp_path / "want").read_bytes()
+    r1 = os.path.join(refdata, "ecoli_r1.1K.fastq")
+    r = run(["hist", "-m21", "-d", "-o", "d.hist", r1], tmp_path)
+    assert r.returncode == 0, r.stderr
+    dumped = tmp_path / "d.hist-hash.jf21"                                   # src/histogram.cc:105-108
+    assert dumped.exists()
+    r = run(["hist", "-o", "reload.hist", str(dumped)], tmp_path)
+    assert r.returncode == 0, r.stderr
+    body = lambda p: [l for l in p.read_text().split("\n") if not l.startswith("#")]
+    assert body(tmp_path / "d.hist") == body(tmp_path / "reload.hist")
+    # comp of a hash against reads, and of two hashes with different k -> KAT's validateMerLen error (exit 4)
+    r = run(["comp", "-m21", "-o", "c1", str(dumped), r1], tmp_path)
+    assert r.returncode == 0, r.stderr
+    t1, t2 = ko.Table.from_jf(str(dumped)), ko.Table(21, True).count_files([r1])
+    mx, cc, sp = ko.comp(t1, t2)
+    ko.write_comp(str(tmp_path / "wc1"), 21, [str(dumped)], [r1], 1001, 1001, mx, cc, sp)
+    assert (tmp_path / "c1-main.mx").read_bytes() == (tmp_path / "wc1-main.mx").read_bytes()
+    assert (tmp_path / "c1.stats").read_bytes() == (tmp_path / "wc1.stats").read_bytes()
+    r = run(["comp", "-o", "c2", str(dumped), jf], tmp_path)
+    assert r.returncode == 4 and "different K-mer lengths" in r.stderr
+
+
 def test_generated_pe_reads_vs_assembly(ko, tmp_path):
     """Parity-scale version of BASELINE.json configs[3]: PE FASTQ + assembly FASTA written to disk, both sides read the files."""
     g = synth.genome(300000, seed=20260927)

@@ -273,3 +273,28 @@ def test_three_input_comp(engine, ko, refdata):
     with pytest.raises(kat_amd.KatGpuError) as ei:
         kat_amd.comp3(engine.table(21, True), engine.table(21, True), engine.table(27, True))
     assert ei.value.code == 9
+
+
+def test_jf_load_query_dump(engine, ko, refdata, tmp_path):
+    """The reference's own .jf tests through the device table: load tests/data/ecoli.header.jf27, answer the queries of
+    tests/check_jellyfish.cc:62-91, count its records (:93-116), dump and reload (:158-180)."""
+    p = os.path.join(refdata, "ecoli.header.jf27")
+    t = engine.load_jf(p)
+    assert (t.k, t.canonical) == (27, False) and t.stats()["distinct"] == 1889
+    q = [ko.encode(s) for s in ("AGCTTTTCATTCTGACTGCAACGGGCA", "GCATAGCGCACAGACAGATAAAAATTA",
+                                "AATGAAAAAGGCGAACTGGTGGTGCTT", "CTCACCAATGTACATGGCCTTAATCTG")]
+    assert list(map(int, t.get(q, False))) == [3, 1, 1, 1] and list(map(int, t.get(q, True))) == [3, 1, 0, 0]
+    ot = ko.Table.from_jf(p)
+    assert_same_table(t, ot)
+    assert_same_reducers(t, ot)
+    out = str(tmp_path / "dump.jf27")
+    t.dump_jf(out)
+    back = engine.load_jf(out)
+    assert_same_table(back, ot)
+    assert list(map(int, back.get(q, False))) == [3, 1, 1, 1]
+    # a counted table survives dump -> load (counts below the 4-byte saturation)
+    g = synth.genome(20000, seed=3)
+    c = engine.table(21, True).count_bases(synth.reads(g, 0, 2000, seed=1))
+    c.dump_jf(str(tmp_path / "c.jf21"))
+    assert_same_table(engine.load_jf(str(tmp_path / "c.jf21")), ko.Table.from_jf(str(tmp_path / "c.jf21")))
+    assert_same_table(c, ko.Table.from_jf(str(tmp_path / "c.jf21")))
