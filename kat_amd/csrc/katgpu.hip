@@ -396,6 +396,7 @@ static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
 
 static const uint64_t g_part_min_starts = getenv("KATGPU_PART_MIN_STARTS") ? strtoull(getenv("KATGPU_PART_MIN_STARTS"), nullptr, 10) : (32ULL << 20);
 static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? strtoull(getenv("KATGPU_TEST_ROUND_ITEMS"), nullptr, 10) : 0;
+static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10) : 3;   // 0 = first edition (1024-thread, 1 per CU)
 static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 1024;
 static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 
@@ -413,7 +414,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const uint32_t k = t->d.k;
     const size_t n_starts = n - k + 1;
     *done = 0;
-    const uint32_t W = (uint32_t)c->n_cu;
+    const bool p1v2 = g_p1_wgs > 0;
+    const uint32_t W = (uint32_t)c->n_cu * (p1v2 ? std::min<uint32_t>(g_p1_wgs, 4) : 1);      // level-1 workgroups (rows of hist1 / offs)
+    const uint32_t W2 = (uint32_t)c->n_cu;                                                      // level-2 / apply: one per CU
+    const size_t tile_starts = p1v2 ? P1_TILE_STARTS : L1_TILE_STARTS;
     if (!c->part_attr_set) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
@@ -423,7 +427,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         c->part_attr_set = true;
     }
     // ---- arena: [hist1 | offs | l1_off | off2 | spill_n | L1 buffer | L2 buffer] ----
-    const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +
+    const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +   /* W <= 4 * CUs */
                                align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) + 256;
     size_t want_items = n_starts;
     if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
@@ -462,15 +466,16 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         PartGeom g;
         if (!part_geometry(t->d, &g)) break;                                      // table too large for two levels: direct path
         size_t m = std::min(n_starts - pos, round_items);
-        if (m < n_starts - pos) m -= m % L1_TILE_STARTS;                          // whole tiles, keeps the next round 16-byte aligned
+        if (m < n_starts - pos) m -= m % tile_starts;                             // whole tiles, keeps the next round 16-byte aligned
         const size_t nb = m + k - 1;
         const uint8_t* p = dev_bases + pos;
         t->count_bound = 0xFFFFFFFFULL;          // the apply kernel chains its own carries; a later direct launch sweeps first
-        const uint64_t n_tiles = (m + L1_TILE_STARTS - 1) / L1_TILE_STARTS;
+        const uint64_t n_tiles = (m + tile_starts - 1) / tile_starts;
         const uint64_t tiles_per_wg = (n_tiles + W - 1) / W;
         {
             ScopedTimer tm(c, KATGPU_K_PART_L1, m);
-            hipLaunchKernelGGL(k_p1_count, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
+            if (p1v2) hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
+            else hipLaunchKernelGGL(k_p1_count, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
             hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
         }
         uint64_t items = 0;
@@ -481,11 +486,12 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
-                hipLaunchKernelGGL(k_p1_scatter, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
+                if (p1v2) hipLaunchKernelGGL(k_p1v2_scatter, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
+                else hipLaunchKernelGGL(k_p1_scatter, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
             }
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-                hipLaunchKernelGGL(k_p2, dim3(std::min<uint32_t>(g.P1, W)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2);
+                hipLaunchKernelGGL(k_p2, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2);
             }
             {
                 ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
@@ -493,7 +499,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 const size_t lds = (size_t)g.S * 12;
                 const uint32_t blk = g_apply_block;
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
-                const uint32_t grid = std::min<uint32_t>(g.R, W * per_cu);
+                const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
                 if (blk == 512)
                     hipLaunchKernelGGL(k_p3_apply<512>, dim3(grid), dim3(512), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod);
                 else

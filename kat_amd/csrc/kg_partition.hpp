@@ -250,6 +250,197 @@ k_p1_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
     }
 }
 
+// =====================================================================================================================
+// Level 1, second edition: 512-thread workgroups that stage 2-byte tile POSITIONS instead of 8-byte k-mers.  The k-mer is
+// recomputed from the LDS-resident 2-bit codes when its run is copied out (three LDS words + shifts + v_bfrev, cheap),
+// which shrinks the workgroup's LDS from 156 KB to 36 KB: three or four workgroups share a CU and overlap each
+// other's barrier-separated phases (the 1024-thread edition above sits parked on barriers / memory 51 % of the time).
+constexpr int P1_BLOCK = 512;
+constexpr int P1_TILE_BYTES = P1_BLOCK * PART_ITEMS;              // 8192
+constexpr int P1_TILE_STARTS = P1_TILE_BYTES - CHUNK_OVERLAP;     // 8160
+constexpr int P1_LANES_WITH_STARTS = P1_TILE_STARTS / PART_ITEMS; // 510
+
+struct P1Lds {
+    uint64_t cursor[MAX_PARTS];
+    uint32_t hist[MAX_PARTS];
+    uint32_t off[MAX_PARTS];
+    uint32_t wave_tot[16];
+    uint32_t code[P1_BLOCK + 2];
+    uint32_t bad[P1_BLOCK + 2];
+    uint16_t pos[P1_TILE_BYTES];
+};
+
+struct LaneWindow {                       // the 96-bit sliding window of kg_kernels.hpp's K1, as an object
+    uint64_t hi, lo, m;
+    uint32_t kshift, mshift;
+    __device__ __forceinline__ void init(const uint32_t* code, const uint32_t* bad, uint32_t w, uint32_t k) {
+        hi = ((uint64_t)code[w] << 32) | code[w + 1];
+        lo = (uint64_t)code[w + 2] << 32;
+        m = ((uint64_t)bad[w] << 48) | ((uint64_t)bad[w + 1] << 32) | ((uint64_t)bad[w + 2] << 16);
+        kshift = 64 - 2 * k; mshift = 64 - k;
+    }
+    __device__ __forceinline__ bool valid() const { return (m >> mshift) == 0; }
+    __device__ __forceinline__ uint64_t fwd() const { return hi >> kshift; }
+    __device__ __forceinline__ void step() { hi = (hi << 2) | (lo >> 62); lo <<= 2; m <<= 1; }
+};
+
+__device__ __forceinline__ uint64_t canon_if(uint64_t fwd, uint32_t k, bool canonical) {
+    if (!canonical) return fwd;
+    const uint64_t rc = kmer_revcomp(fwd, k);
+    return rc < fwd ? rc : fwd;
+}
+
+// the k-mer whose window starts at tile position p, from the staged codes
+__device__ __forceinline__ uint64_t kmer_at(const uint32_t* code, uint32_t p, uint32_t k, bool canonical) {
+    const uint32_t w = p >> 4, o = p & 15;
+    uint64_t hi = ((uint64_t)code[w] << 32) | code[w + 1];
+    if (o) hi = (hi << (2 * o)) | ((uint64_t)code[w + 2] >> (32 - 2 * o));
+    return canon_if(hi >> (64 - 2 * k), k, canonical);
+}
+
+__device__ __forceinline__ void p1_tile_load(const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off, uint32_t (&w)[4]) {
+    const uint64_t off = tile_off + (uint64_t)threadIdx.x * PART_ITEMS;
+    if (off + PART_ITEMS <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(bases + off);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { uint64_t i = off + q * 4 + b; x |= (i < n ? (uint32_t)bases[i] : (uint32_t)'N') << (8 * b); }
+            w[q] = x;
+        }
+    }
+}
+
+__device__ __forceinline__ void p1_tile_stage(P1Lds& L, const uint32_t (&w)[4]) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t code, bad;
+    encode16(w, code, bad);
+    L.code[tid] = code;
+    L.bad[tid] = bad;
+    if (tid < 2) { L.code[P1_BLOCK + tid] = 0; L.bad[P1_BLOCK + tid] = 0xFFFF; }
+    __syncthreads();
+}
+
+// exclusive scan over 2 * P1_BLOCK logical entries (entry b and b + 512 per lane); three barriers
+__device__ __forceinline__ void p1_scan_pair(uint32_t v0, uint32_t v1, uint32_t* wave_tot, uint32_t& e0, uint32_t& e1) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t i0 = v0, i1 = v1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t a = __shfl_up(i0, d, 64), b = __shfl_up(i1, d, 64);
+        if (lane >= (uint32_t)d) { i0 += a; i1 += b; }
+    }
+    __syncthreads();
+    if (lane == 63) { wave_tot[wave] = i0; wave_tot[8 + wave] = i1; }
+    __syncthreads();
+    uint32_t p0 = 0, p1 = 0, t0 = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { uint32_t x = wave_tot[w], y = wave_tot[8 + w]; t0 += x; if ((uint32_t)w < wave) { p0 += x; p1 += y; } }
+    e0 = p0 + i0 - v0;
+    e1 = t0 + p1 + i1 - v1;
+}
+
+__global__ void __launch_bounds__(P1_BLOCK)
+k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
+             uint32_t* __restrict__ hist1) {
+    __shared__ uint32_t s_hist[MAX_PARTS];
+    __shared__ uint32_t s_code[P1_BLOCK + 2];
+    __shared__ uint32_t s_bad[P1_BLOCK + 2];
+    const uint32_t tid = threadIdx.x;
+    const bool canonical = t.canonical != 0;
+    for (uint32_t b = tid; b < MAX_PARTS; b += P1_BLOCK) s_hist[b] = 0;
+    uint32_t ones = 0;
+    const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
+    uint32_t w[4], wn[4];
+    if (t0 < t1) p1_tile_load(bases, n, t0 * P1_TILE_STARTS, w);
+    for (uint64_t tile = t0; tile < t1; ++tile) {
+        if (tile + 1 < t1) p1_tile_load(bases, n, (tile + 1) * P1_TILE_STARTS, wn);
+        __syncthreads();
+        uint32_t code, bad;
+        encode16(w, code, bad);
+        s_code[tid] = code; s_bad[tid] = bad;
+        if (tid < 2) { s_code[P1_BLOCK + tid] = 0; s_bad[P1_BLOCK + tid] = 0xFFFF; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = wn[q];
+        if (tid < P1_LANES_WITH_STARTS) {
+            LaneWindow lw;
+            lw.init(s_code, s_bad, tid, t.k);
+#pragma unroll 4
+            for (int j = 0; j < PART_ITEMS; ++j, lw.step()) {
+                if (!lw.valid()) continue;
+                const uint64_t key = canon_if(lw.fwd(), t.k, canonical);
+                if (key == EMPTY) { ++ones; continue; }
+                atomicAdd(&s_hist[digit1_of_hash(mix64(key), g.P1)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < g.P1; b += P1_BLOCK) hist1[(uint64_t)blockIdx.x * g.P1 + b] = s_hist[b];
+    for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
+    if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
+}
+
+__global__ void __launch_bounds__(P1_BLOCK)
+k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
+               const uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_buf) {
+    __shared__ __attribute__((aligned(16))) P1Lds L;
+    const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;
+    const bool canonical = t.canonical != 0;
+    for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] = offs[(uint64_t)blockIdx.x * P + b];
+    const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
+    uint32_t w[4], wn[4];
+    if (t0 < t1) p1_tile_load(bases, n, t0 * P1_TILE_STARTS, w);
+    for (uint64_t tile = t0; tile < t1; ++tile) {
+        if (tile + 1 < t1) p1_tile_load(bases, n, (tile + 1) * P1_TILE_STARTS, wn);
+        __syncthreads();                                   // previous tile's copy-out / cursor update done
+        for (uint32_t b = tid; b < MAX_PARTS; b += P1_BLOCK) L.hist[b] = 0;
+        p1_tile_stage(L, w);                               // ends with a barrier
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = wn[q];
+        // sweep 1: bucket and rank of every valid window of this lane
+        uint32_t br[PART_ITEMS];
+        uint32_t valid = 0;
+        if (tid < P1_LANES_WITH_STARTS) {
+            LaneWindow lw;
+            lw.init(L.code, L.bad, tid, k);
+#pragma unroll
+            for (int j = 0; j < PART_ITEMS; ++j, lw.step()) {
+                br[j] = 0;
+                if (!lw.valid()) continue;
+                const uint64_t key = canon_if(lw.fwd(), k, canonical);
+                if (key == EMPTY) continue;                                     // tallied by the count pass
+                const uint32_t b = digit1_of_hash(mix64(key), P);
+                br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+                valid |= 1u << j;
+            }
+        }
+        __syncthreads();
+        uint32_t e0, e1;
+        p1_scan_pair(tid < P ? L.hist[tid] : 0, tid + P1_BLOCK < P ? L.hist[tid + P1_BLOCK] : 0, L.wave_tot, e0, e1);
+        L.off[tid] = e0;
+        L.off[tid + P1_BLOCK] = e1;
+        __syncthreads();
+        // sweep 2: park the tile position of every k-mer in its bucket's run
+#pragma unroll
+        for (int j = 0; j < PART_ITEMS; ++j)
+            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = (uint16_t)(tid * PART_ITEMS + j);
+        __syncthreads();
+        // copy-out: a 16-lane group per bucket; the k-mer is recomputed from the codes, the run leaves as <= 128-byte pieces
+        const uint32_t grp = tid >> 4, l16 = tid & 15;
+        for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
+            const uint32_t cnt = L.hist[b], src = L.off[b];
+            const uint64_t dst = L.cursor[b];
+            for (uint32_t i = l16; i < cnt; i += 16) l1_buf[dst + i] = kmer_at(L.code, L.pos[src + i], k, canonical);
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] += L.hist[b];
+    }
+}
+
 // ---- level 2: one workgroup per level-1 bucket: histogram by sub-bucket, scan, scatter.  off2[r] = start of region r's run. ----
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
