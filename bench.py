@@ -117,14 +117,14 @@ def main():
         tp = mark("alloc1", tp)
         t1.count_bases_device(reads.ptr, reads.nbytes)
         tp = mark("count_reads", tp)
-        t2 = eng.table(k, True, size_hint=hint2)
+        t2 = eng.table(k, True, size_hint=hint2, like=t1)
         t2.count_bases_device(asm_ptr, asm_bytes)
         tp = mark("alloc2+count_asm", tp)
         if world > 1:
             s1, s2 = kdist.HipShard(t1), kdist.HipShard(t2)
             o1 = kdist.exchange_merge(s1)
             t1.free()
-            o2 = kdist.exchange_merge(s2)
+            o2 = kdist.exchange_merge(s2, grid_of=o1)
             t2.free()
             t1, t2 = o1.table, o2.table
             tp = mark("exchange", tp)

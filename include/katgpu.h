@@ -68,6 +68,10 @@ int katgpu_count(katgpu_ctx* ctx, const char* const* paths, size_t n_paths, uint
 /* The same in steps (used by the batch/bench drivers and by multi-GPU sharding). */
 int katgpu_table_create(katgpu_ctx* ctx, uint32_t k, int canonical, uint64_t size_hint, int disable_grow,
                         katgpu_table** out);
+/* As katgpu_table_create, but with the region grid of `like` (the table this one will be compared with): katgpu_comp then
+ * joins the two region against region in LDS instead of probing HBM.  Falls back to an own grid if the sizes are too far apart. */
+int katgpu_table_create_like(katgpu_ctx* ctx, const katgpu_table* like, uint32_t k, int canonical, uint64_t size_hint,
+                             int disable_grow, katgpu_table** out);
 int katgpu_count_files(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p);
 /* A base stream is what the reference's parser hands to mer_iterator: sequence bytes, records separated by any
  * byte outside ACGTacgt (the reference inserts 'N', mer_overlap_sequence_parser.hpp:202,234).  Every k-window

@@ -21,7 +21,7 @@ STATUS = {
 # every symbol include/katgpu.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "katgpu_init", "katgpu_shutdown", "katgpu_last_error", "katgpu_version", "katgpu_sync",
-    "katgpu_count", "katgpu_table_create", "katgpu_count_files", "katgpu_count_bases_host",
+    "katgpu_count", "katgpu_table_create", "katgpu_table_create_like", "katgpu_count_files", "katgpu_count_bases_host",
     "katgpu_count_bases_device", "katgpu_table_free", "katgpu_table_stats", "katgpu_table_k",
     "katgpu_table_canonical", "katgpu_table_get", "katgpu_table_export", "katgpu_hist", "katgpu_gcp",
     "katgpu_comp", "katgpu_comp3", "katgpu_table_partition_sizes", "katgpu_table_partition", "katgpu_table_merge_device",
@@ -65,6 +65,7 @@ def load_library():
     L.katgpu_sync.argtypes = [vp]
     L.katgpu_count.argtypes = [vp, cpp, sz, u32, C.c_int, C.POINTER(C.c_uint16), u64, C.c_int, pp]
     L.katgpu_table_create.argtypes = [vp, u32, C.c_int, u64, C.c_int, pp]
+    L.katgpu_table_create_like.argtypes = [vp, vp, u32, C.c_int, u64, C.c_int, pp]
     L.katgpu_count_files.argtypes = [vp, cpp, sz, C.POINTER(C.c_uint16)]
     L.katgpu_count_bases_host.argtypes = [vp, vp, sz]
     L.katgpu_count_bases_device.argtypes = [vp, vp, sz]
@@ -225,7 +226,12 @@ class Engine:
         return f.value, t.value
 
     # ---- tables ----
-    def table(self, k, canonical=True, size_hint=0, disable_grow=False):
+    def table(self, k, canonical=True, size_hint=0, disable_grow=False, like=None):
+        """like: a Table this one will be compared with -- it adopts that table's region grid (fast join in comp)."""
+        if like is not None:
+            h = C.c_void_p()
+            self._chk(self.L.katgpu_table_create_like(self.h, like.h, k, int(bool(canonical)), size_hint, int(bool(disable_grow)), C.byref(h)))
+            return Table(self, k, canonical, _handle=h.value)
         return Table(self, k, canonical, size_hint, disable_grow)
 
     def count(self, paths, k, canonical=True, trim5p=None, size_hint=0, disable_grow=False):

@@ -111,15 +111,21 @@ std::string InputHandler::fileName() const {                                // l
     return s;
 }
 
-void InputHandler::count(uint16_t threads) {                                // lib/src/input_handler.cc:180-202
+// `like` (comp only): the hash this one will be compared with; the new table adopts its region grid so that the
+// comparison can join region against region on the device (katgpu_table_create_like).
+void InputHandler::count(uint16_t threads, const katgpu_table* like) {      // lib/src/input_handler.cc:180-202
     (void)threads;          // -t sized the reference's std::thread team; the GPU engine owns its own parallelism
     auto t0 = std::chrono::steady_clock::now();
     std::cout << "Input " << index << " is a sequence file.  Counting kmers for input " << index << " (" << pathString() << ") ...";
     std::cout.flush();
     std::vector<const char*> paths;
     for (const auto& p : input) paths.push_back(p.c_str());
-    Engine::check(katgpu_count(Engine::ctx(), paths.data(), paths.size(), merLen, canonical ? 1 : 0, trim5p.data(), hashSize,
-                               disableHashGrow ? 1 : 0, &hash));
+    if (like) {
+        Engine::check(katgpu_table_create_like(Engine::ctx(), like, merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
+        Engine::check(katgpu_count_files(hash, paths.data(), paths.size(), trim5p.data()));
+    } else
+        Engine::check(katgpu_count(Engine::ctx(), paths.data(), paths.size(), merLen, canonical ? 1 : 0, trim5p.data(), hashSize,
+                                   disableHashGrow ? 1 : 0, &hash));
     std::cout << " done.";
     std::cout.flush();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

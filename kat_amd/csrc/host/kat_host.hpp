@@ -86,7 +86,7 @@ public:
     std::string fileName() const;
     void set5pTrim(const std::vector<uint16_t>& trim_list);
     void validateInput();                        // throws if an input is missing; sets mode
-    void count(uint16_t threads);                // *** the drop-in boundary: katgpu_count ***
+    void count(uint16_t threads, const katgpu_table* like = nullptr);   // *** the drop-in boundary: katgpu_count ***
     void loadHeader() {}                         // the header travels with katgpu_jf_load (lib/src/input_handler.cc:139-143)
     void loadHash();                             // lib/src/input_handler.cc:204-219 -> katgpu_jf_load
     void validateMerLen(uint16_t merLen);        // lib/src/input_handler.cc:145-158

@@ -219,7 +219,7 @@ void Comp::execute() {                                                          
                                  std::min(d1Bins, d2Bins));
     for (size_t i = 0; i < inputSize(); i++) {                  // sequentially, one input after the other (:139-143)
         InputHandler& in = input[i];
-        if (in.mode == InputHandler::COUNT) in.count(threads);
+        if (in.mode == InputHandler::COUNT) in.count(threads, i > 0 ? input[0].hash : nullptr);
     }
     bool anyLoad = false, allLoad = true;                        // :146-167
     for (size_t i = 0; i < inputSize(); i++) {

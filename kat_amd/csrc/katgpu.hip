@@ -231,12 +231,21 @@ static void pool_release(katgpu_ctx* c, void* p) {
     c->pool.push_back({p, bytes});
 }
 
+static const bool g_no_join = getenv("KATGPU_NO_JOIN") != nullptr;       // A/B switch: force comp's probe form
 static const uint32_t g_region_slots = getenv("KATGPU_TEST_REGION_SLOTS") ? (uint32_t)strtoul(getenv("KATGPU_TEST_REGION_SLOTS"), nullptr, 10) : REGION_SLOTS;
 
-static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out) {
+constexpr uint32_t MAX_REGION_SLOTS = 12288;        // 144 KB of LDS in the apply / join kernels
+
+// like_p1/like_p2 != 0: adopt that region grid (so that comp can join region against region) and take up the capacity in the
+// region size, if a region of the resulting size still fits LDS.
+static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1 = 0, uint32_t like_p2 = 0) {
     DevTable d{};
+    const uint64_t like_r = (uint64_t)like_p1 * like_p2;
     // capacity is a whole number of regions (kg_device.hpp: Probe); a table smaller than one region is a single short region
-    if (cap <= g_region_slots) { d.n_regions = d.p1 = d.p2 = 1; d.region_slots = (uint32_t)cap; }
+    if (like_r > 1 && (cap + like_r - 1) / like_r <= MAX_REGION_SLOTS) {
+        d.p1 = like_p1; d.p2 = like_p2; d.n_regions = (uint32_t)like_r;
+        d.region_slots = (uint32_t)std::max<uint64_t>((cap + like_r - 1) / like_r, 16);
+    } else if (cap <= g_region_slots) { d.n_regions = d.p1 = d.p2 = 1; d.region_slots = (uint32_t)cap; }
     else {
         const uint64_t nr = (cap + g_region_slots - 1) / g_region_slots;
         if (nr > 0x3FFFFFFFULL) return fail(c, KATGPU_ERR_NOMEM, "table of %llu slots exceeds the region index", (unsigned long long)cap);
@@ -288,6 +297,21 @@ extern "C" int katgpu_table_create(katgpu_ctx* c, uint32_t k, int canonical, uin
     return KATGPU_OK;
 }
 
+extern "C" int katgpu_table_create_like(katgpu_ctx* c, const katgpu_table* like, uint32_t k, int canonical, uint64_t size_hint,
+                                        int disable_grow, katgpu_table** out) {
+    if (!c || !out || !like) return KATGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (k < 1 || k > 32) return fail(c, KATGPU_ERR_K, "k = %u unsupported: this build packs a k-mer into one 64-bit word (1 <= k <= 32)", k);
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t cap = std::max<uint64_t>(size_hint ? size_hint : (1u << 20), 1024);
+    katgpu_table* t = new katgpu_table();
+    t->ctx = c; t->disable_grow = disable_grow;
+    int rc = alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2);
+    if (rc) { delete t; return rc; }
+    *out = t;
+    return KATGPU_OK;
+}
+
 extern "C" void katgpu_table_free(katgpu_table* t) {
     if (!t) return;
     hipSetDevice(t->ctx->device);
@@ -319,7 +343,7 @@ static int refresh_counters(katgpu_table* t) {
 static int regrow(katgpu_table* t, uint64_t new_cap) {
     katgpu_ctx* c = t->ctx;
     DevTable nd{};
-    int rc = alloc_dev_table(c, t->d.k, t->d.canonical, new_cap, &nd);
+    int rc = alloc_dev_table(c, t->d.k, t->d.canonical, new_cap, &nd, t->d.n_regions > 1 ? t->d.p1 : 0, t->d.n_regions > 1 ? t->d.p2 : 0);
     if (rc) return rc;
     {
         ScopedTimer tm(c, KATGPU_K_REGROW, t->d.cap);
@@ -903,13 +927,28 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     }
+    // Join form (region r of one table against region r of the other, in LDS) whenever the two tables share the region grid
+    // and the probe key equals the stored key; probe form (random HBM probes) otherwise.
+    const bool same_grid = t1->d.p1 == t2->d.p1 && t1->d.p2 == t2->d.p2 && t1->d.n_regions > 1 && !g_no_join;
+    const bool ident1 = t1->d.canonical || !canon2;          // pass 1 probes canonical(key) iff input 2 is canonical
+    const bool ident2 = t2->d.canonical != 0;                // pass 2 always probes canonical(key)
+    const size_t join1 = ((lds1 + 15) & ~(size_t)15) + (size_t)t2->d.region_slots * 12, join2 = ((lds2 + 15) & ~(size_t)15) + (size_t)t1->d.region_slots * 12;
+    auto join_grid = [&](size_t lds, uint32_t regions) { return std::min<uint32_t>(regions, (uint32_t)c->n_cu * (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 4))); };
     {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap);
-        hipLaunchKernelGGL(k_comp<1>, dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
+        if (same_grid && ident1 && join1 <= 150 * 1024) {
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            hipLaunchKernelGGL(k_comp_join<1>, dim3(join_grid(join1, t1->d.n_regions)), dim3(512), join1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
+        } else
+            hipLaunchKernelGGL(k_comp<1>, dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
     }
     {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS2, t2->d.cap);
-        hipLaunchKernelGGL(k_comp<2>, dim3(reducer_grid(c, t2->d.cap + 1, 4)), dim3(256), lds2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
+        if (same_grid && ident2 && join2 <= 150 * 1024) {
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            hipLaunchKernelGGL(k_comp_join<2>, dim3(join_grid(join2, t2->d.n_regions)), dim3(512), join2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
+        } else
+            hipLaunchKernelGGL(k_comp<2>, dim3(reducer_grid(c, t2->d.cap + 1, 4)), dim3(256), lds2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
     }
     HIPCHK(c, hipGetLastError());
     hipMemcpyAsync(main_mx, d, mx_cells * 8, hipMemcpyDeviceToHost, c->stream);

@@ -269,76 +269,51 @@ __device__ __forceinline__ void block_sum_u64(unsigned long long* s_acc, int slo
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_acc[slot], (unsigned long long)v);
 }
 
-// LDS carve: [0,16) u64 scalar accumulators | tile 64x64 u32 | spectra (2 per pass) u32
-template <int PASS>
-__global__ void __launch_bounds__(256)
-k_comp(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_raw);
-    uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_raw + 16 * sizeof(unsigned long long));
-    uint32_t* s_spec = s_tile + COMP_TILE * COMP_TILE;
-    const uint32_t n_spec = (PASS == 1 ? 3u : 1u) * a.spec_size;       // pass 1: spectrum1, shared1, shared2; pass 2: spectrum2
-    for (uint32_t i = threadIdx.x; i < 16; i += blockDim.x) s_acc[i] = 0;
-    for (uint32_t i = threadIdx.x; i < COMP_TILE * COMP_TILE; i += blockDim.x) s_tile[i] = 0;
-    for (uint32_t i = threadIdx.x; i < n_spec; i += blockDim.x) s_spec[i] = 0;
-    __syncthreads();
+// Per-lane running sums of one comp pass
+struct CompAcc { uint64_t a_total = 0, a_distinct = 0, a_only_total = 0, a_only_distinct = 0, sh_a = 0, sh_b = 0, sh_n = 0; };
 
-    const uint32_t k = ta.k;
-    uint64_t a_total = 0, a_distinct = 0, a_only_total = 0, a_only_distinct = 0, sh_a = 0, sh_b = 0, sh_n = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t n_slots = ta.cap + 1;                   // virtual slot cap == the all-ones key
-    const uint64_t rounds = (n_slots + stride - 1) / stride;
-    for (uint64_t r = 0; r < rounds; ++r) {
-        uint64_t i = first + r * stride;
-        uint64_t key = EMPTY, ca = 0;
-        bool occ = false;
-        if (i < ta.cap) {
-            key = ta.keys[i];
-            occ = key != EMPTY;
-            if (occ) ca = slot_count(ta, i, key, na_ovf);
-        } else if (i == ta.cap) {
-            ca = ta.ctrs[CTR_ONES];
-            occ = ca != 0;
-        }
-        uint64_t cb = 0;
-        uint32_t cell = 0;
-        bool in_tile = false, in_mx = false;
-        if (occ) {
-            // pass 1: hash-1 key probed in hash 2, canonicalised iff input 2 is canonical (src/comp.cc:401)
-            // pass 2: hash-2 key probed in hash 1, ALWAYS canonicalised (src/comp.cc:447 passes a pointer as the bool)
-            uint64_t probe = (PASS == 2 || a.canon_probe) ? kmer_canonical(key, k) : key;
-            cb = table_get(tb, probe, nb_ovf);
-            a_total += ca; a_distinct += 1;
-            if (!cb) { a_only_total += ca; a_only_distinct += 1; }
-            if (PASS == 1) {
-                if (ca && cb) { sh_a += ca; sh_b += cb; sh_n += 1; }
-                uint64_t s1 = scale_count(ca, a.d1_scale), s2 = scale_count(cb, a.d2_scale);
-                if (s1 >= a.d1_bins) s1 = a.d1_bins - 1;
-                if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
-                in_mx = true;
-                in_tile = s1 < COMP_TILE && s2 < COMP_TILE;
-                cell = in_tile ? (uint32_t)(s1 * COMP_TILE + s2) : (uint32_t)(s1 * a.d2_bins + s2);
-            } else if (!cb) {                                                  // only k-mers absent from hash 1 (src/comp.cc:453-462)
-                uint64_t s2 = scale_count(ca, a.d2_scale);
-                if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
-                in_mx = true;
-                in_tile = s2 < COMP_TILE;
-                cell = (uint32_t)s2;                                            // row 0 in both the tile and the matrix
-            }
-        }
-        lds_inc_aggregated(s_tile, cell, in_mx && in_tile);
-        if (in_mx && !in_tile) atomicAdd(&a.main_mx[cell], 1ULL);
-        lds_inc_aggregated(s_spec, spectrum_bin(ca, a.spec_size), occ);                            // spectrum1 / spectrum2
+// What one k-mer of the scanned table contributes once its count in the other table (cb) is known.  All lanes of the
+// wave call this together (the LDS increments are wave-aggregated with ballots); occ says whether the lane holds a k-mer.
+template <int PASS>
+__device__ __forceinline__ void comp_account(bool occ, uint64_t ca, uint64_t cb, const CompArgs& a, uint32_t* s_tile, uint32_t* s_spec, CompAcc& acc) {
+    uint32_t cell = 0;
+    bool in_tile = false, in_mx = false;
+    if (occ) {
+        acc.a_total += ca; acc.a_distinct += 1;
+        if (!cb) { acc.a_only_total += ca; acc.a_only_distinct += 1; }
         if (PASS == 1) {
-            bool shared = occ && ca && cb;
-            lds_inc_aggregated(s_spec + a.spec_size, spectrum_bin(ca, a.spec_size), shared);         // shared_spectrum1
-            lds_inc_aggregated(s_spec + 2 * a.spec_size, spectrum_bin(cb, a.spec_size), shared);     // shared_spectrum2
+            if (ca && cb) { acc.sh_a += ca; acc.sh_b += cb; acc.sh_n += 1; }
+            uint64_t s1 = scale_count(ca, a.d1_scale), s2 = scale_count(cb, a.d2_scale);
+            if (s1 >= a.d1_bins) s1 = a.d1_bins - 1;
+            if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
+            in_mx = true;
+            in_tile = s1 < COMP_TILE && s2 < COMP_TILE;
+            cell = in_tile ? (uint32_t)(s1 * COMP_TILE + s2) : (uint32_t)(s1 * a.d2_bins + s2);
+        } else if (!cb) {                                                  // only k-mers absent from hash 1 (src/comp.cc:453-462)
+            uint64_t s2 = scale_count(ca, a.d2_scale);
+            if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
+            in_mx = true;
+            in_tile = s2 < COMP_TILE;
+            cell = (uint32_t)s2;                                            // row 0 in both the tile and the matrix
         }
     }
-    block_sum_u64(s_acc, 0, a_total); block_sum_u64(s_acc, 1, a_distinct);
-    block_sum_u64(s_acc, 2, a_only_total); block_sum_u64(s_acc, 3, a_only_distinct);
-    if (PASS == 1) { block_sum_u64(s_acc, 4, sh_a); block_sum_u64(s_acc, 5, sh_b); block_sum_u64(s_acc, 6, sh_n); }
+    lds_inc_aggregated(s_tile, cell, in_mx && in_tile);
+    if (in_mx && !in_tile) atomicAdd(&a.main_mx[cell], 1ULL);
+    lds_inc_aggregated(s_spec, spectrum_bin(ca, a.spec_size), occ);                            // spectrum1 / spectrum2
+    if (PASS == 1) {
+        bool shared = occ && ca && cb;
+        lds_inc_aggregated(s_spec + a.spec_size, spectrum_bin(ca, a.spec_size), shared);         // shared_spectrum1
+        lds_inc_aggregated(s_spec + 2 * a.spec_size, spectrum_bin(cb, a.spec_size), shared);     // shared_spectrum2
+    }
+}
+
+// block-level flush of the accumulators, the matrix tile and the spectra (end of a comp kernel)
+template <int PASS>
+__device__ __forceinline__ void comp_flush(const CompArgs& a, unsigned long long* s_acc, uint32_t* s_tile, uint32_t* s_spec, const CompAcc& acc) {
+    const uint32_t n_spec = (PASS == 1 ? 3u : 1u) * a.spec_size;
+    block_sum_u64(s_acc, 0, acc.a_total); block_sum_u64(s_acc, 1, acc.a_distinct);
+    block_sum_u64(s_acc, 2, acc.a_only_total); block_sum_u64(s_acc, 3, acc.a_only_distinct);
+    if (PASS == 1) { block_sum_u64(s_acc, 4, acc.sh_a); block_sum_u64(s_acc, 5, acc.sh_b); block_sum_u64(s_acc, 6, acc.sh_n); }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (PASS == 1) {
@@ -364,6 +339,108 @@ k_comp(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
         uint32_t dst = PASS == 1 ? (which == 0 ? 0u : which + 1) : 1u;       // spectra order: s1, s2, shared1, shared2
         atomicAdd(&a.spectra[(uint64_t)dst * a.spec_size + bin], (unsigned long long)v);
     }
+}
+
+// LDS carve of both comp kernels: [0,16) u64 scalar accumulators | tile 64x64 u32 | spectra (3 or 1) u32 | (join: region)
+__device__ __forceinline__ void comp_lds_init(const CompArgs& a, int pass, unsigned long long* s_acc, uint32_t* s_tile, uint32_t* s_spec) {
+    const uint32_t n_spec = (pass == 1 ? 3u : 1u) * a.spec_size;
+    for (uint32_t i = threadIdx.x; i < 16; i += blockDim.x) s_acc[i] = 0;
+    for (uint32_t i = threadIdx.x; i < COMP_TILE * COMP_TILE; i += blockDim.x) s_tile[i] = 0;
+    for (uint32_t i = threadIdx.x; i < n_spec; i += blockDim.x) s_spec[i] = 0;
+    __syncthreads();
+}
+
+// K5 (probe form): scan one table, probe the other in HBM.  Used when the two tables' region grids differ or when the
+// probe key is not the stored key (mixed canonical flags).
+template <int PASS>
+__global__ void __launch_bounds__(256)
+k_comp(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_raw);
+    uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_raw + 16 * sizeof(unsigned long long));
+    uint32_t* s_spec = s_tile + COMP_TILE * COMP_TILE;
+    comp_lds_init(a, PASS, s_acc, s_tile, s_spec);
+    const uint32_t k = ta.k;
+    CompAcc acc;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n_slots = ta.cap + 1;                   // virtual slot cap == the all-ones key
+    const uint64_t rounds = (n_slots + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        uint64_t i = first + r * stride;
+        uint64_t key = EMPTY, ca = 0, cb = 0;
+        bool occ = false;
+        if (i < ta.cap) {
+            key = ta.keys[i];
+            occ = key != EMPTY;
+            if (occ) ca = slot_count(ta, i, key, na_ovf);
+        } else if (i == ta.cap) {
+            ca = ta.ctrs[CTR_ONES];
+            occ = ca != 0;
+        }
+        if (occ) {
+            // pass 1: hash-1 key probed in hash 2, canonicalised iff input 2 is canonical (src/comp.cc:401)
+            // pass 2: hash-2 key probed in hash 1, ALWAYS canonicalised (src/comp.cc:447 passes a pointer as the bool)
+            uint64_t probe = (PASS == 2 || a.canon_probe) ? kmer_canonical(key, k) : key;
+            cb = table_get(tb, probe, nb_ovf);
+        }
+        comp_account<PASS>(occ, ca, cb, a, s_tile, s_spec, acc);
+    }
+    comp_flush<PASS>(a, s_acc, s_tile, s_spec, acc);
+}
+
+// K5 (join form): when both tables share the region grid (p1 x p2) and the probe key IS the stored key, region r of
+// one table can only match region r of the other -- a partitioned hash join.  A persistent workgroup walks regions:
+// the probed table's region goes into LDS (coalesced), the scanned table's region streams past it, every probe is an
+// LDS probe.  HBM sees each table exactly once per pass, as a stream.
+template <int PASS>
+__global__ void __launch_bounds__(512)
+k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_raw);
+    uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_raw + 16 * sizeof(unsigned long long));
+    uint32_t* s_spec = s_tile + COMP_TILE * COMP_TILE;
+    const uint32_t n_spec = (PASS == 1 ? 3u : 1u) * a.spec_size;
+    const uint32_t Sa = ta.region_slots, Sb = tb.region_slots;
+    unsigned long long* rk = reinterpret_cast<unsigned long long*>(s_raw + ((16 * 8 + COMP_TILE * COMP_TILE * 4 + n_spec * 4 + 15) & ~15u));
+    uint32_t* rc = reinterpret_cast<uint32_t*>(rk + Sb);
+    comp_lds_init(a, PASS, s_acc, s_tile, s_spec);
+    CompAcc acc;
+    const uint32_t R = ta.n_regions;
+    for (uint32_t r = blockIdx.x; r < R; r += gridDim.x) {
+        __syncthreads();
+        const uint64_t bbase = (uint64_t)r * Sb, abase = (uint64_t)r * Sa;
+        for (uint32_t i = threadIdx.x; i < Sb; i += blockDim.x) { rk[i] = tb.keys[bbase + i]; rc[i] = tb.counts[bbase + i]; }
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < Sa; i0 += blockDim.x) {                  // uniform trip count: ballots inside comp_account
+            const uint32_t i = i0 + threadIdx.x;
+            uint64_t key = EMPTY, ca = 0, cb = 0;
+            bool occ = false;
+            if (i < Sa) { key = ta.keys[abase + i]; occ = key != EMPTY; }
+            if (occ) {
+                ca = slot_count(ta, abase + i, key, na_ovf);
+                uint32_t s = offset_of_hash(mix64(key), Sb);
+                for (uint32_t probe = 0; probe < Sb; ++probe) {
+                    const unsigned long long cur = rk[s];
+                    if (cur == key) { cb = rc[s]; if (nb_ovf) cb += ovf_get(tb, key); break; }
+                    if (cur == EMPTY) break;
+                    s = s + 1 == Sb ? 0 : s + 1;
+                }
+            }
+            comp_account<PASS>(occ, ca, cb, a, s_tile, s_spec, acc);
+        }
+    }
+    {   // the all-ones key lives outside the slots: one lane of block 0 takes it through the HBM path
+        uint64_t ca = 0, cb = 0;
+        bool occ = false;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ca = ta.ctrs[CTR_ONES];
+            occ = ca != 0;
+            if (occ) cb = table_get(tb, (PASS == 2 || a.canon_probe) ? kmer_canonical(EMPTY, ta.k) : EMPTY, nb_ovf);
+        }
+        comp_account<PASS>(occ, ca, cb, a, s_tile, s_spec, acc);
+    }
+    comp_flush<PASS>(a, s_acc, s_tile, s_spec, acc);
 }
 
 // ---- K5b: the third comp input (src/comp.cc:123-127,403-433,466-479) ----

@@ -24,9 +24,9 @@ class HipShard:
         self.table = table
         self.device = torch.device("cuda", torch.cuda.current_device())
 
-    def new_like(self, size_hint):
+    def new_like(self, size_hint, grid_of=None):
         t = self.table
-        return HipShard(t.engine.table(t.k, t.canonical, size_hint=max(int(size_hint), 1024)))
+        return HipShard(t.engine.table(t.k, t.canonical, size_hint=max(int(size_hint), 1024), like=grid_of.table if grid_of is not None else None))
 
     def partition_sizes(self, n_parts):
         return self.table.partition_sizes(n_parts).astype(np.int64)
@@ -53,8 +53,9 @@ class HipShard:
         self.table.free()
 
 
-def exchange_merge(shard, group=None, load=0.6):
+def exchange_merge(shard, group=None, load=0.6, grid_of=None):
     """Route every record of `shard` to its owner rank; returns the owner shard (same duck type).
+    grid_of: an owner shard whose region grid the new owner table should adopt (comp then joins region against region).
 
     world_size == 1: the local table already is the owner table, returned as is.
     """
@@ -84,7 +85,7 @@ def exchange_merge(shard, group=None, load=0.6):
             ops.append(dist.P2POp(dist.irecv, rcounts[recv_off[p]:recv_off[p + 1]], p, group))
     reqs = dist.batch_isend_irecv(ops) if ops else []
     # size the owner table from what is about to land in it (an upper bound on its distinct count)
-    owner = shard.new_like(int((int(recv_off[-1])) / load) + 1024)
+    owner = shard.new_like(int((int(recv_off[-1])) / load) + 1024) if grid_of is None else shard.new_like(int((int(recv_off[-1])) / load) + 1024, grid_of)
     s0, s1 = int(send_off[rank]), int(send_off[rank + 1])
     owner.merge_from(keys[s0:s1], counts[s0:s1], s1 - s0)                   # my own part needs no wire
     for r in reqs:

@@ -23,7 +23,7 @@ class OracleShard:
         self.table = table
         self.device = torch.device("cpu")
 
-    def new_like(self, size_hint):
+    def new_like(self, size_hint, grid_of=None):
         from oracle import koracle as ko
         return OracleShard(ko.Table(self.table.k, self.table.canonical))
 

@@ -298,3 +298,30 @@ def test_jf_load_query_dump(engine, ko, refdata, tmp_path):
     c.dump_jf(str(tmp_path / "c.jf21"))
     assert_same_table(engine.load_jf(str(tmp_path / "c.jf21")), ko.Table.from_jf(str(tmp_path / "c.jf21")))
     assert_same_table(c, ko.Table.from_jf(str(tmp_path / "c.jf21")))
+
+
+def test_comp_join_form(engine, ko):
+    """Tables that share a region grid (created with like=) are compared by the region-against-region LDS join; tables
+    with their own grids, or mixed canonical flags, by HBM probes.  Both must equal the oracle."""
+    g = synth.genome(150000, seed=17)
+    a = synth.reads(g, 0, 16000, seed=1)
+    b = np.concatenate([synth.stream_of_contigs(g[:90000], 30000), synth.reads(g, 40000, 3000, seed=9, err_ppm=20000)])
+    for k, c1, c2 in ((27, True, True), (21, False, False), (21, True, False), (21, False, True), (32, False, False)):
+        o1, o2 = ko.Table(k, c1).count_bases(a), ko.Table(k, c2).count_bases(b)
+        want = ko.comp(o1, o2, 1.0, 1.0, 201, 101)
+        for hint1, hint2 in ((1 << 21, 1 << 19), (1 << 21, 1 << 22), (1 << 15, 1 << 14)):
+            t1 = engine.table(k, c1, size_hint=hint1).count_bases(a)
+            t2 = engine.table(k, c2, size_hint=hint2, like=t1).count_bases(b)
+            got = kat_amd.comp(t1, t2, 1.0, 1.0, 201, 101)
+            for gg, ww, name in zip(got, want, ("main", "counters", "spectra")):
+                assert np.array_equal(gg, ww), (k, c1, c2, hint1, hint2, name)
+    # exactness past 32 bits through the join form
+    t1 = engine.table(21, True, size_hint=1 << 16)
+    t2 = engine.table(21, True, size_hint=1 << 15, like=t1)
+    o1, o2 = ko.Table(21, True), ko.Table(21, True)
+    for key, c in ((5, (3 << 32) + 7), (77, 12), (1234567, 1)):
+        key = ko.canonical(key, 21)
+        t1.merge_host([key], [c]); o1.add(key, c)
+        t2.merge_host([key], [c + (1 << 33)]); o2.add(key, c + (1 << 33))
+    got, want = kat_amd.comp(t1, t2), ko.comp(o1, o2)
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
