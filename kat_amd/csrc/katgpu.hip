@@ -231,6 +231,7 @@ static void pool_release(katgpu_ctx* c, void* p) {
     c->pool.push_back({p, bytes});
 }
 
+static const bool g_force_join = getenv("KATGPU_FORCE_JOIN") != nullptr;  // tests: take the join form whenever it is legal
 static const bool g_no_join = getenv("KATGPU_NO_JOIN") != nullptr;       // A/B switch: force comp's probe form
 static const uint32_t g_region_slots = getenv("KATGPU_TEST_REGION_SLOTS") ? (uint32_t)strtoul(getenv("KATGPU_TEST_REGION_SLOTS"), nullptr, 10) : REGION_SLOTS;
 
@@ -459,7 +460,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         free_b += c->arena_bytes;
-        size_t bytes = std::min<size_t>(small_bytes + 16 * want_items, (size_t)(0.8 * (double)free_b));
+        size_t bytes = std::min<size_t>(small_bytes + 16 * want_items, (size_t)(0.85 * (double)free_b));
         if (bytes > c->arena_bytes) {
             if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
             if (!g_test_round_items && bytes < small_bytes + 16 * ((size_t)1 << 20)) return KATGPU_OK;   // no room for a useful round: direct path
@@ -478,7 +479,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     uint64_t* l2_buf = l1_buf + round_items;
     if (!g_test_round_items && round_items < ((size_t)1 << 20) && round_items < n_starts) return KATGPU_OK;
 
+    // Rounds are sized in ITEMS (valid k-mers), not window starts: a cheap pre-count of a prefix measures items/starts
+    // (0.82 for 150 bp reads at k=27) so that the buffers are filled and the table is swept as few times as possible.
+    double items_per_start = 1.0;
     size_t pos = 0;
+    bool ratio_known = false;
     while (pos < n_starts) {
         int rc = refresh_counters(t);
         if (rc) return rc;
@@ -489,8 +494,27 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         }
         PartGeom g;
         if (!part_geometry(t->d, &g)) break;                                      // table too large for two levels: direct path
-        size_t m = std::min(n_starts - pos, round_items);
-        if (m < n_starts - pos) m -= m % tile_starts;                             // whole tiles, keeps the next round 16-byte aligned
+        if (!ratio_known && n_starts - pos > round_items && !g_test_round_items) {
+            const size_t probe_m = std::min<size_t>(n_starts - pos, (size_t)64 << 20) / tile_starts * tile_starts;
+            const uint64_t pt = probe_m / tile_starts, ptw = (pt + W - 1) / W;
+            if (p1v2) hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, dev_bases + pos, (uint64_t)(probe_m + k - 1), pt, ptw, hist1);
+            else hipLaunchKernelGGL(k_p1_count, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, dev_bases + pos, (uint64_t)(probe_m + k - 1), pt, ptw, hist1);
+            hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
+            uint64_t probe_items = 0;
+            HIPCHK(c, hipMemcpyAsync(&probe_items, &l1_off[g.P1], sizeof probe_items, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            // (the probe's all-ones tally must not count twice: the real count pass over the same prefix follows)
+            if (t->d.k == 32 && !t->d.canonical) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            items_per_start = std::max(0.05, (double)probe_items / (double)probe_m);
+            ratio_known = true;
+        }
+        size_t m = std::min(n_starts - pos, (size_t)((double)round_items / items_per_start * 0.98));
+        if (m < n_starts - pos) {
+            const size_t rounds_left = (n_starts - pos + m - 1) / m;               // balance the remaining rounds
+            m = (n_starts - pos + rounds_left - 1) / rounds_left;
+            m += tile_starts - m % tile_starts;                                    // whole tiles, keeps the next round 16-byte aligned
+            m = std::min(m, n_starts - pos);
+        }
         const size_t nb = m + k - 1;
         const uint8_t* p = dev_bases + pos;
         t->count_bound = 0xFFFFFFFFULL;          // the apply kernel chains its own carries; a later direct launch sweeps first
@@ -505,7 +529,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         uint64_t items = 0;
         HIPCHK(c, hipMemcpyAsync(&items, &l1_off[g.P1], sizeof items, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (items > round_items) return fail(c, KATGPU_ERR_DEVICE, "partition round produced %llu items for a %zu-item buffer", (unsigned long long)items, round_items);
+        if (items > round_items) {                      // denser than the prefix suggested: redo this round smaller
+            if (t->d.k == 32 && !t->d.canonical) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            items_per_start = std::min(1.0, (double)items / (double)m * 1.02);
+            continue;
+        }
         if (items) {
             HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
             {
@@ -933,10 +961,16 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     const bool ident1 = t1->d.canonical || !canon2;          // pass 1 probes canonical(key) iff input 2 is canonical
     const bool ident2 = t2->d.canonical != 0;                // pass 2 always probes canonical(key)
     const size_t join1 = ((lds1 + 15) & ~(size_t)15) + (size_t)t2->d.region_slots * 12, join2 = ((lds2 + 15) & ~(size_t)15) + (size_t)t1->d.region_slots * 12;
+    // the join streams BOTH tables (~2.2 TB/s measured); probing costs ~1.3 random sector reads per scanned k-mer (~55 G/s):
+    // a small table scanned against a big one is cheaper probed, a big one against a small one is cheaper joined
+    auto join_pays = [](const katgpu_table* scan, const katgpu_table* probe) {
+        if (scan->d.cap + probe->d.cap < ((uint64_t)64 << 20)) return true;        // small either way: take the join
+        return 12.0 * (double)(scan->d.cap + probe->d.cap) / 2.2e12 < 1.3 * (double)scan->distinct / 55e9;
+    };
     auto join_grid = [&](size_t lds, uint32_t regions) { return std::min<uint32_t>(regions, (uint32_t)c->n_cu * (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 4))); };
     {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap);
-        if (same_grid && ident1 && join1 <= 150 * 1024) {
+        if (same_grid && ident1 && join1 <= 150 * 1024 && (g_force_join || join_pays(t1, t2))) {
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             hipLaunchKernelGGL(k_comp_join<1>, dim3(join_grid(join1, t1->d.n_regions)), dim3(512), join1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
         } else
@@ -944,7 +978,7 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     }
     {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS2, t2->d.cap);
-        if (same_grid && ident2 && join2 <= 150 * 1024) {
+        if (same_grid && ident2 && join2 <= 150 * 1024 && (g_force_join || join_pays(t2, t1))) {
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             hipLaunchKernelGGL(k_comp_join<2>, dim3(join_grid(join2, t2->d.n_regions)), dim3(512), join2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
         } else
