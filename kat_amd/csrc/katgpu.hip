@@ -456,15 +456,16 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                                align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) + 256;
     size_t want_items = n_starts;
     if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
-    if (c->arena_bytes < small_bytes + 16 * std::min<size_t>(want_items, (size_t)64 << 20)) {
+    if (c->arena_bytes < small_bytes + 16 * want_items) {                        // the arena could be more useful than it is
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         free_b += c->arena_bytes;
         size_t bytes = std::min<size_t>(small_bytes + 16 * want_items, (size_t)(0.85 * (double)free_b));
-        if (bytes > c->arena_bytes) {
+        // re-allocate only for a substantially larger arena (fewer rounds): a fresh hipMalloc of this size is not free
+        if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 16 * std::min<size_t>(want_items, (size_t)64 << 20)) {
             if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
             if (!g_test_round_items && bytes < small_bytes + 16 * ((size_t)1 << 20)) return KATGPU_OK;   // no room for a useful round: direct path
-            HIPCHK(c, hipMalloc((void**)&c->arena, bytes));
+            if (hipMalloc((void**)&c->arena, bytes) != hipSuccess) { (void)hipGetLastError(); c->arena = nullptr; return KATGPU_OK; }   // direct path
             c->arena_bytes = bytes;
         }
     }
@@ -508,7 +509,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             items_per_start = std::max(0.05, (double)probe_items / (double)probe_m);
             ratio_known = true;
         }
-        size_t m = std::min(n_starts - pos, (size_t)((double)round_items / items_per_start * 0.98));
+        size_t m = n_starts - pos;                                                 // items <= starts: this always fits
+        if (m > round_items) m = std::min(m, (size_t)((double)round_items / items_per_start * 0.98));
         if (m < n_starts - pos) {
             const size_t rounds_left = (n_starts - pos + m - 1) / m;               // balance the remaining rounds
             m = (n_starts - pos + rounds_left - 1) / rounds_left;
@@ -529,6 +531,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         uint64_t items = 0;
         HIPCHK(c, hipMemcpyAsync(&items, &l1_off[g.P1], sizeof items, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (g_trace) fprintf(stderr, "[katgpu] partition round: %zu starts -> %llu items (buffer %zu items, arena %.1f GB, ratio %.3f)\n", m, (unsigned long long)items, round_items, c->arena_bytes / 1e9, items_per_start);
         if (items > round_items) {                      // denser than the prefix suggested: redo this round smaller
             if (t->d.k == 32 && !t->d.canonical) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
             items_per_start = std::min(1.0, (double)items / (double)m * 1.02);
