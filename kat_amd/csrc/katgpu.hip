@@ -447,8 +447,12 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         c->part_attr_set = true;
     }
     // ---- arena: [hist1 | offs | l1_off | off2 | spill_n | L1 buffer | L2 buffer] ----
@@ -555,10 +559,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 const uint32_t blk = g_apply_block;
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
-                if (blk == 512)
-                    hipLaunchKernelGGL(k_p3_apply<512>, dim3(grid), dim3(512), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod);
-                else
-                    hipLaunchKernelGGL(k_p3_apply<1024>, dim3(grid), dim3(1024), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod);
+#define KG_APPLY(B, N) hipLaunchKernelGGL((k_p3_apply<B, N>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod)
+                const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
+                if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
+                else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) KG_APPLY(1024, 8); else KG_APPLY(1024, 12); }
+#undef KG_APPLY
             }
             HIPCHK(c, hipGetLastError());
             unsigned long long spilled = 0;

@@ -488,7 +488,10 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 
 // ---- level 3: apply a region's run to the region, in LDS ----
 // LDS: keys[S] (u64) | counts[S] (u32).  Insert = LDS CAS claim + LDS add (same protocol as table_inc, minus the HBM).
-template <int BLOCK>
+// SPT = slots per lane held in registers while a region is prefetched (region_slots <= SPT * BLOCK).
+// Software pipeline: while region r's run is applied in LDS, region r' (the workgroup's next one) is already on its way
+// from HBM into registers, and r's write-back drains behind it -- the CU's memory pipe stays busy through the LDS phase.
+template <int BLOCK, int SPT>
 __global__ void __launch_bounds__(BLOCK)
 k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
            uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod) {
@@ -497,25 +500,37 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
     uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)g.S * 8);
     const uint32_t tid = threadIdx.x, S = g.S;
     uint32_t new_distinct = 0;
-    for (uint32_t r = blockIdx.x; r < g.R; r += gridDim.x) {
-        const uint64_t beg = off2[r], end = off2[r + 1];
-        if (beg == end) continue;                                                              // uniform per block
+    uint64_t kk[SPT]; uint32_t cc[SPT];
+    constexpr int BATCH = 4;                                      // k-mers of the run in flight per lane (registers are the limit)
+
+    auto next_region = [&](uint32_t from) {                       // first region >= from (stride gridDim) that received k-mers
+        uint32_t r = from;
+        while (r < g.R && off2[r] == off2[r + 1]) r += gridDim.x;
+        return r;
+    };
+    auto prefetch = [&](uint32_t r) {
         const uint64_t base = (uint64_t)r * S;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; kk[u] = i < S ? t.keys[base + i] : 0; cc[u] = i < S ? t.counts[base + i] : 0; }
+    };
+
+    uint32_t r = next_region(blockIdx.x);
+    if (r < g.R) prefetch(r);
+    while (r < g.R) {
+        const uint64_t beg = off2[r], end = off2[r + 1];
+        const uint64_t base = (uint64_t)r * S;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
         __syncthreads();
-        for (uint32_t i0 = 0; i0 < S; i0 += 4 * BLOCK) {                                 // region in: 8 loads in flight per lane
-            uint64_t kk[4]; uint32_t cc[4];
+        const uint32_t rn = next_region(r + gridDim.x);
+        bool prefetched = false;
+        for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)BATCH * BLOCK) {
+          unsigned long long batch[BATCH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * BLOCK + tid; kk[u] = i < S ? t.keys[base + i] : 0; cc[u] = i < S ? t.counts[base + i] : 0; }
+          for (int u = 0; u < BATCH; ++u) { const uint64_t i = i0 + (uint64_t)u * BLOCK + tid; batch[u] = i < end ? l2_buf[i] : EMPTY; }
+          if (!prefetched) { if (rn < g.R) prefetch(rn); prefetched = true; }     // issued AFTER the first batch: its wait does not cover these
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
-        }
-        __syncthreads();
-        for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)8 * BLOCK) {
-          unsigned long long batch[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { const uint64_t i = i0 + (uint64_t)u * BLOCK + tid; batch[u] = i < end ? l2_buf[i] : EMPTY; }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < BATCH; ++u) {
             const uint64_t i = i0 + (uint64_t)u * BLOCK + tid;
             const unsigned long long key = batch[u];
             if (key == EMPTY) continue;
@@ -542,6 +557,8 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
         }
         __syncthreads();
         for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
+        __syncthreads();                                          // LDS is overwritten with the next region at the loop top
+        r = rn;
     }
     flush_distinct(t, new_distinct);
 }
