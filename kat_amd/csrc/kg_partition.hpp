@@ -25,6 +25,12 @@ constexpr int L1_TILE_STARTS = L1_TILE_BYTES - CHUNK_OVERLAP; // 16352 window st
 constexpr int L1_LANES_WITH_STARTS = L1_TILE_STARTS / PART_ITEMS;   // 1022
 constexpr int MAX_PARTS = 1024;                               // buckets per level (one lane per bucket in the scans)
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope release fence, which on gfx950
+// lowers to s_waitcnt vmcnt(0): every barrier placed after a run of global STORES (copy-out, region write-back) would
+// stall the whole workgroup until those stores are acknowledged by L2.  Nothing in these kernels hands global data from
+// one lane to another inside a launch, so only LDS traffic has to be complete here.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct PartGeom {
     uint32_t R, S;     // regions, slots per region (the table's)
     uint32_t P1, P2;   // region r = b1 * P2 + b2 (the table's p1, p2): level-1 bucket b1, level-2 bucket b2
@@ -49,12 +55,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
     if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
+    lds_barrier();
     uint32_t prefix = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < PART_BLOCK / 64; ++w) { uint32_t x = wave_tot[w]; if ((uint32_t)w < wave) prefix += x; tot += x; }
     *total = tot;
-    __syncthreads();
+    lds_barrier();
     return prefix + inc - v;
 }
 
@@ -64,13 +70,13 @@ __device__ __forceinline__ uint64_t block_exclusive_scan64(uint64_t v, uint64_t*
     uint64_t inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { uint64_t o = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
-    __syncthreads();                                  // every lane has read its own histogram word before scratch is written
+    lds_barrier();                                  // every lane has read its own histogram word before scratch is written
     if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
+    lds_barrier();
     uint64_t prefix = 0;
 #pragma unroll
     for (int w = 0; w < PART_BLOCK / 64; ++w) { uint64_t x = wave_tot[w]; if ((uint32_t)w < wave) prefix += x; }
-    __syncthreads();
+    lds_barrier();
     return prefix + inc - v;
 }
 
@@ -100,7 +106,7 @@ __device__ __forceinline__ void tile_stage(PartLds& L, const uint32_t (&w)[4]) {
     L.code[tid] = code;
     L.bad[tid] = bad;
     if (tid < 2) { L.code[PART_BLOCK + tid] = 0; L.bad[PART_BLOCK + tid] = 0xFFFF; }
-    __syncthreads();
+    lds_barrier();
 }
 
 // The 16 k-mers whose windows start in this lane's 16 positions (canonical if asked); bit j of the result = window j valid.
@@ -134,7 +140,7 @@ __device__ __forceinline__ void scatter_tile(PartLds& L, const PartGeom g, const
     const uint32_t tid = threadIdx.x;
     const uint32_t P = LEVEL == 1 ? g.P1 : g.P2;
     if (tid < MAX_PARTS) L.hist[tid] = 0;
-    __syncthreads();
+    lds_barrier();
     uint32_t br[PART_ITEMS];                                  // bucket << 16 | rank inside the tile's bucket run
 #pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j) {
@@ -145,16 +151,16 @@ __device__ __forceinline__ void scatter_tile(PartLds& L, const PartGeom g, const
             br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
         }
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t total;
     const uint32_t mine = tid < P ? L.hist[tid] : 0;
     const uint32_t excl = block_exclusive_scan(mine, L.wave_tot, &total);
     if (tid < MAX_PARTS) L.off[tid] = excl;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j)
         if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = key[j];
-    __syncthreads();
+    lds_barrier();
     // bucket-parallel copy-out: each wave walks its share of the buckets, lanes copy that bucket's run contiguously
     const uint32_t lane = tid & 63, wave = tid >> 6;
     for (uint32_t b = wave; b < P; b += PART_BLOCK / 64) {
@@ -162,7 +168,7 @@ __device__ __forceinline__ void scatter_tile(PartLds& L, const PartGeom g, const
         const uint64_t dst = L.cursor[b];
         for (uint32_t i = lane; i < cnt; i += 64) out[dst + i] = L.staging[src + i];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < P) L.cursor[tid] += L.hist[tid];
     // (the next tile's first barrier orders this update before the next use)
 }
@@ -183,7 +189,7 @@ k_p1_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n
     if (t0 < t1) tile_load(bases, n, t0 * L1_TILE_STARTS, w);
     for (uint64_t tile = t0; tile < t1; ++tile) {
         if (tile + 1 < t1) tile_load(bases, n, (tile + 1) * L1_TILE_STARTS, wn);
-        __syncthreads();
+        lds_barrier();
         tile_stage(L, w);
 #pragma unroll
         for (int q = 0; q < 4; ++q) w[q] = wn[q];
@@ -196,7 +202,7 @@ k_p1_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n
                 atomicAdd(&L.hist[digit1_of_hash(mix64(key[j]), g.P1)], 1u);
             }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < g.P1) hist1[(uint64_t)blockIdx.x * g.P1 + tid] = L.hist[tid];
     for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
     if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
@@ -210,13 +216,13 @@ k_p1_scan(PartGeom g, uint32_t n_wg, const uint32_t* __restrict__ hist1, uint64_
     uint64_t tot = 0;
     if (b < g.P1) for (uint32_t w = 0; w < n_wg; ++w) tot += hist1[(uint64_t)w * g.P1 + b];
     if (b < g.P1) s_base[b] = tot;
-    __syncthreads();
+    lds_barrier();
     if (b == 0) {                                   // P1 <= 1024 entries: a serial scan is a few microseconds
         uint64_t run = 0;
         for (uint32_t i = 0; i < g.P1; ++i) { uint64_t v = s_base[i]; s_base[i] = run; run += v; }
         s_base[g.P1] = run;
     }
-    __syncthreads();
+    lds_barrier();
     if (b < g.P1) l1_off[b] = s_base[b];
     if (b == 0) l1_off[g.P1] = s_base[g.P1];
     if (b < g.P1) {
@@ -238,7 +244,7 @@ k_p1_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
     if (t0 < t1) tile_load(bases, n, t0 * L1_TILE_STARTS, w);
     for (uint64_t tile = t0; tile < t1; ++tile) {
         if (tile + 1 < t1) tile_load(bases, n, (tile + 1) * L1_TILE_STARTS, wn);
-        __syncthreads();
+        lds_barrier();
         tile_stage(L, w);
 #pragma unroll
         for (int q = 0; q < 4; ++q) w[q] = wn[q];
@@ -321,7 +327,7 @@ __device__ __forceinline__ void p1_tile_stage(P1Lds& L, const uint32_t (&w)[4]) 
     L.code[tid] = code;
     L.bad[tid] = bad;
     if (tid < 2) { L.code[P1_BLOCK + tid] = 0; L.bad[P1_BLOCK + tid] = 0xFFFF; }
-    __syncthreads();
+    lds_barrier();
 }
 
 // exclusive scan over 2 * P1_BLOCK logical entries (entry b and b + 512 per lane); three barriers
@@ -333,9 +339,9 @@ __device__ __forceinline__ void p1_scan_pair(uint32_t v0, uint32_t v1, uint32_t*
         uint32_t a = __shfl_up(i0, d, 64), b = __shfl_up(i1, d, 64);
         if (lane >= (uint32_t)d) { i0 += a; i1 += b; }
     }
-    __syncthreads();
+    lds_barrier();
     if (lane == 63) { wave_tot[wave] = i0; wave_tot[8 + wave] = i1; }
-    __syncthreads();
+    lds_barrier();
     uint32_t p0 = 0, p1 = 0, t0 = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) { uint32_t x = wave_tot[w], y = wave_tot[8 + w]; t0 += x; if ((uint32_t)w < wave) { p0 += x; p1 += y; } }
@@ -358,12 +364,12 @@ k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
     if (t0 < t1) p1_tile_load(bases, n, t0 * P1_TILE_STARTS, w);
     for (uint64_t tile = t0; tile < t1; ++tile) {
         if (tile + 1 < t1) p1_tile_load(bases, n, (tile + 1) * P1_TILE_STARTS, wn);
-        __syncthreads();
+        lds_barrier();
         uint32_t code, bad;
         encode16(w, code, bad);
         s_code[tid] = code; s_bad[tid] = bad;
         if (tid < 2) { s_code[P1_BLOCK + tid] = 0; s_bad[P1_BLOCK + tid] = 0xFFFF; }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int q = 0; q < 4; ++q) w[q] = wn[q];
         if (tid < P1_LANES_WITH_STARTS) {
@@ -378,7 +384,7 @@ k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     for (uint32_t b = tid; b < g.P1; b += P1_BLOCK) hist1[(uint64_t)blockIdx.x * g.P1 + b] = s_hist[b];
     for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
     if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
@@ -396,7 +402,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
     if (t0 < t1) p1_tile_load(bases, n, t0 * P1_TILE_STARTS, w);
     for (uint64_t tile = t0; tile < t1; ++tile) {
         if (tile + 1 < t1) p1_tile_load(bases, n, (tile + 1) * P1_TILE_STARTS, wn);
-        __syncthreads();                                   // previous tile's copy-out / cursor update done
+        lds_barrier();                                   // previous tile's copy-out / cursor update done
         for (uint32_t b = tid; b < MAX_PARTS; b += P1_BLOCK) L.hist[b] = 0;
         p1_tile_stage(L, w);                               // ends with a barrier
 #pragma unroll
@@ -418,17 +424,17 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                 valid |= 1u << j;
             }
         }
-        __syncthreads();
+        lds_barrier();
         uint32_t e0, e1;
         p1_scan_pair(tid < P ? L.hist[tid] : 0, tid + P1_BLOCK < P ? L.hist[tid + P1_BLOCK] : 0, L.wave_tot, e0, e1);
         L.off[tid] = e0;
         L.off[tid + P1_BLOCK] = e1;
-        __syncthreads();
+        lds_barrier();
         // sweep 2: park the tile position of every k-mer in its bucket's run
 #pragma unroll
         for (int j = 0; j < PART_ITEMS; ++j)
             if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = (uint16_t)(tid * PART_ITEMS + j);
-        __syncthreads();
+        lds_barrier();
         // copy-out: a 16-lane group per bucket; the k-mer is recomputed from the codes, the run leaves as <= 128-byte pieces
         const uint32_t grp = tid >> 4, l16 = tid & 15;
         for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
@@ -436,7 +442,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
             const uint64_t dst = L.cursor[b];
             for (uint32_t i = l16; i < cnt; i += 16) l1_buf[dst + i] = kmer_at(L.code, L.pos[src + i], k, canonical);
         }
-        __syncthreads();
+        lds_barrier();
         for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] += L.hist[b];
     }
 }
@@ -450,12 +456,12 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
     const uint32_t tid = threadIdx.x;
     for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
         const uint64_t beg = l1_off[b1], end = l1_off[b1 + 1];
-        __syncthreads();
+        lds_barrier();
         // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
         // the cursor array is free until the scan, so it doubles as the histogram
         unsigned long long* h64 = reinterpret_cast<unsigned long long*>(L.cursor);
         if (tid < MAX_PARTS) h64[tid] = 0;
-        __syncthreads();
+        lds_barrier();
         for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)8 * PART_BLOCK) {                   // 8 coalesced loads in flight per lane
             uint64_t v[8];
 #pragma unroll
@@ -463,7 +469,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (v[u] != EMPTY) atomicAdd(&h64[digit2_of_hash(mix64(v[u]), g.P2)], 1ULL);
         }
-        __syncthreads();
+        lds_barrier();
         const uint64_t mine = tid < g.P2 ? h64[tid] : 0;
         const uint64_t excl = block_exclusive_scan64(mine, reinterpret_cast<uint64_t*>(L.staging));
         if (tid < g.P2) {
@@ -480,7 +486,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
                 key[j] = 0;
                 if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
             }
-            __syncthreads();
+            lds_barrier();
             scatter_tile<2>(L, g, key, valid, l2_buf);
         }
     }
@@ -521,7 +527,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
         const uint64_t base = (uint64_t)r * S;
 #pragma unroll
         for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
-        __syncthreads();
+        lds_barrier();
         const uint32_t rn = next_region(r + gridDim.x);
         bool prefetched = false;
         for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)BATCH * BLOCK) {
@@ -555,9 +561,9 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
             if (!done) spill[atomicAdd(spill_n, 1ULL)] = key;                                   // region full: direct path later
           }
         }
-        __syncthreads();
+        lds_barrier();
         for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
-        __syncthreads();                                          // LDS is overwritten with the next region at the loop top
+        lds_barrier();                                          // LDS is overwritten with the next region at the loop top
         r = rn;
     }
     flush_distinct(t, new_distinct);
