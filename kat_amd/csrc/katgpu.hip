@@ -559,23 +559,13 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 const uint32_t blk = g_apply_block;
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
-#define KG_APPLY(B, N) hipLaunchKernelGGL((k_p3_apply<B, N>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, phase_cycles)
-                unsigned long long* phase_cycles = g_trace ? (unsigned long long*)&t->d.ctrs[CTR_SCRATCH + 2] : nullptr;
-                if (phase_cycles) HIPCHK(c, hipMemsetAsync(phase_cycles, 0, 3 * sizeof(uint64_t), c->stream));
+#define KG_APPLY(B, N) hipLaunchKernelGGL((k_p3_apply<B, N>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod)
                 const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
                 if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
                 else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) KG_APPLY(1024, 8); else KG_APPLY(1024, 12); }
 #undef KG_APPLY
             }
             HIPCHK(c, hipGetLastError());
-            if (g_trace) {
-                uint64_t ph[3];
-                HIPCHK(c, hipMemcpyAsync(ph, &t->d.ctrs[CTR_SCRATCH + 2], sizeof ph, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                const double tot = (double)(ph[0] + ph[1] + ph[2]);
-                fprintf(stderr, "[katgpu] apply phases (wave-0 cycles, all workgroups): fill %.1f%%  insert %.1f%%  write-back %.1f%%  (%.3g cycles)\n",
-                        100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, tot);
-            }
             unsigned long long spilled = 0;
             HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));

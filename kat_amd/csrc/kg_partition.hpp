@@ -494,19 +494,19 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 
 // ---- level 3: apply a region's run to the region, in LDS ----
 // LDS: keys[S] (u64) | counts[S] (u32).  Insert = LDS CAS claim + LDS add (same protocol as table_inc, minus the HBM).
-// SPT = region slots per lane (region_slots <= SPT * BLOCK): the region is loaded with SPT independent loads per lane.
-// Phase stamps (KATGPU_TRACE) show where a region's time goes: fill 3 %, applying the run 93 %, write-back 4 % -- so the
-// run loop is what is pipelined by hand, not the region traffic.
+// SPT = slots per lane held in registers while a region is prefetched (region_slots <= SPT * BLOCK).
+// Software pipeline: while region r's run is applied in LDS, region r' (the workgroup's next one) is already on its way
+// from HBM into registers, and r's write-back drains behind it -- the CU's memory pipe stays busy through the LDS phase.
 template <int BLOCK, int SPT>
 __global__ void __launch_bounds__(BLOCK)
 k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
-           uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod,
-           unsigned long long* __restrict__ phase_cycles /* optional: [fill, insert, write-back] cycles of wave 0, summed over workgroups */) {
+           uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
     uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)g.S * 8);
     const uint32_t tid = threadIdx.x, S = g.S;
     uint32_t new_distinct = 0;
+    uint64_t kk[SPT]; uint32_t cc[SPT];
     constexpr int BATCH = 4;                                      // k-mers of the run in flight per lane (registers are the limit)
 
     auto next_region = [&](uint32_t from) {                       // first region >= from (stride gridDim) that received k-mers
@@ -514,65 +514,44 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
         while (r < g.R && off2[r] == off2[r + 1]) r += gridDim.x;
         return r;
     };
-    uint64_t ph[3] = {0, 0, 0};
-    uint64_t t_prev = phase_cycles ? clock64() : 0;
-    auto stamp = [&](int which) { if (phase_cycles) { const uint64_t now = clock64(); ph[which] += now - t_prev; t_prev = now; } };
+    auto prefetch = [&](uint32_t r) {
+        const uint64_t base = (uint64_t)r * S;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; kk[u] = i < S ? t.keys[base + i] : 0; cc[u] = i < S ? t.counts[base + i] : 0; }
+    };
+
     uint32_t r = next_region(blockIdx.x);
+    if (r < g.R) prefetch(r);
     while (r < g.R) {
         const uint64_t beg = off2[r], end = off2[r + 1];
         const uint64_t base = (uint64_t)r * S;
-        {
-            uint64_t kk[SPT]; uint32_t cc[SPT];
 #pragma unroll
-            for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; kk[u] = i < S ? t.keys[base + i] : 0; cc[u] = i < S ? t.counts[base + i] : 0; }
-#pragma unroll
-            for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
-        }
+        for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
         lds_barrier();
-        stamp(0);
         const uint32_t rn = next_region(r + gridDim.x);
-        // The run is applied in batches of BATCH k-mers per lane, software-pipelined by hand: the next batch's loads are issued
-        // before the current batch is touched, and the first probe of all BATCH k-mers is in flight together (hash, LDS read,
-        // LDS add are independent across the batch); only collisions / claims fall into the serial slow path.
-        unsigned long long cur[BATCH], nxt[BATCH];
-        auto load_batch = [&](uint64_t i0, unsigned long long (&b)[BATCH]) {
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) { const uint64_t i = i0 + (uint64_t)u * BLOCK + tid; b[u] = i < end ? l2_buf[i] : EMPTY; }
-        };
-        load_batch(beg, cur);
+        bool prefetched = false;
         for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)BATCH * BLOCK) {
-          load_batch(i0 + (uint64_t)BATCH * BLOCK, nxt);                           // (all EMPTY past the end)
-          uint32_t sl[BATCH];
-          unsigned long long first[BATCH];
+          unsigned long long batch[BATCH];
 #pragma unroll
-          for (int u = 0; u < BATCH; ++u) { sl[u] = offset_of_hash(mix64(cur[u]), S); first[u] = rk[sl[u]]; }
-          uint32_t old[BATCH];
-          bool fast[BATCH];
+          for (int u = 0; u < BATCH; ++u) { const uint64_t i = i0 + (uint64_t)u * BLOCK + tid; batch[u] = i < end ? l2_buf[i] : EMPTY; }
+          if (!prefetched) { if (rn < g.R) prefetch(rn); prefetched = true; }     // issued AFTER the first batch: its wait does not cover these
 #pragma unroll
           for (int u = 0; u < BATCH; ++u) {
             const uint64_t i = i0 + (uint64_t)u * BLOCK + tid;
-            const bool force_spill = spill_mod && (i % spill_mod) == 0;                          // test hook: exercise the spill path
-            fast[u] = cur[u] != EMPTY && first[u] == cur[u] && !force_spill;
-            old[u] = fast[u] ? atomicAdd(&rc[sl[u]], 1u) : 0u;
-          }
-#pragma unroll
-          for (int u = 0; u < BATCH; ++u) {
-            const uint64_t i = i0 + (uint64_t)u * BLOCK + tid;
-            const unsigned long long key = cur[u];
+            const unsigned long long key = batch[u];
             if (key == EMPTY) continue;
-            // LDS returning add: a 32-bit wrap is seen right here and chained into the side table, so a round may carry any
-            // number of copies of one k-mer and needs no host-side overflow guard
-            if (fast[u]) { if (old[u] == 0xFFFFFFFFu) ovf_add(t, key, 1ULL << 32); continue; }
-            uint32_t s = sl[u];
+            uint32_t s = offset_of_hash(mix64(key), S);
             bool done = false;
-            const bool force_spill = spill_mod && (i % spill_mod) == 0;
+            const bool force_spill = spill_mod && (i % spill_mod) == 0;                        // test hook: exercise the spill path
             for (uint32_t probe = 0; probe < S && !force_spill; ++probe) {
-                unsigned long long c = rk[s];
-                if (c == EMPTY) {
-                    c = atomicCAS(&rk[s], (unsigned long long)EMPTY, key);
-                    if (c == EMPTY) { ++new_distinct; c = key; }
+                unsigned long long cur = rk[s];
+                if (cur == EMPTY) {
+                    cur = atomicCAS(&rk[s], (unsigned long long)EMPTY, key);
+                    if (cur == EMPTY) { ++new_distinct; cur = key; }
                 }
-                if (c == key) {
+                if (cur == key) {
+                    // LDS returning add: a 32-bit wrap is seen right here and chained into the side table, so a round may
+                    // carry any number of copies of one k-mer and needs no host-side overflow guard
                     if (atomicAdd(&rc[s], 1u) == 0xFFFFFFFFu) ovf_add(t, key, 1ULL << 32);
                     done = true;
                     break;
@@ -581,17 +560,12 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
             }
             if (!done) spill[atomicAdd(spill_n, 1ULL)] = key;                                   // region full: direct path later
           }
-#pragma unroll
-          for (int u = 0; u < BATCH; ++u) cur[u] = nxt[u];
         }
         lds_barrier();
-        stamp(1);
         for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
         lds_barrier();                                          // LDS is overwritten with the next region at the loop top
-        stamp(2);
         r = rn;
     }
-    if (phase_cycles && tid == 0) { atomicAdd(&phase_cycles[0], ph[0]); atomicAdd(&phase_cycles[1], ph[1]); atomicAdd(&phase_cycles[2], ph[2]); }
     flush_distinct(t, new_distinct);
 }
 
