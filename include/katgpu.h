@@ -50,6 +50,10 @@ const char* katgpu_last_error(const katgpu_ctx* ctx);
 const char* katgpu_version(void);
 /* wait for everything the ctx has queued on its HIP streams */
 int         katgpu_sync(katgpu_ctx* ctx);
+/* return cached device memory (parked table arrays, the partitioned counter's arena) to the driver; it is re-acquired on demand */
+int         katgpu_release_scratch(katgpu_ctx* ctx);
+/* borrow that arena as raw device scratch of at least `bytes` (valid until the next katgpu_count_* call on the context) */
+int         katgpu_scratch_acquire(katgpu_ctx* ctx, size_t bytes, void** dev_ptr, size_t* got_bytes);
 
 /* ---- counting: replaces InputHandler::count (lib/src/input_handler.cc:180-202) and everything below it:
  *      JellyfishHelper::countSeqFile/countSlice (lib/src/jellyfish_helper.cc:219-246,202-211),

@@ -20,7 +20,7 @@ STATUS = {
 
 # every symbol include/katgpu.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "katgpu_init", "katgpu_shutdown", "katgpu_last_error", "katgpu_version", "katgpu_sync",
+    "katgpu_init", "katgpu_shutdown", "katgpu_last_error", "katgpu_version", "katgpu_sync", "katgpu_release_scratch", "katgpu_scratch_acquire",
     "katgpu_count", "katgpu_table_create", "katgpu_table_create_like", "katgpu_count_files", "katgpu_count_bases_host",
     "katgpu_count_bases_device", "katgpu_table_free", "katgpu_table_stats", "katgpu_table_k",
     "katgpu_table_canonical", "katgpu_table_get", "katgpu_table_export", "katgpu_hist", "katgpu_gcp",
@@ -63,6 +63,8 @@ def load_library():
     L.katgpu_last_error.restype = C.c_char_p
     L.katgpu_version.restype = C.c_char_p
     L.katgpu_sync.argtypes = [vp]
+    L.katgpu_release_scratch.argtypes = [vp]
+    L.katgpu_scratch_acquire.argtypes = [vp, sz, pp, C.POINTER(sz)]
     L.katgpu_count.argtypes = [vp, cpp, sz, u32, C.c_int, C.POINTER(C.c_uint16), u64, C.c_int, pp]
     L.katgpu_table_create.argtypes = [vp, u32, C.c_int, u64, C.c_int, pp]
     L.katgpu_table_create_like.argtypes = [vp, vp, u32, C.c_int, u64, C.c_int, pp]
@@ -154,6 +156,15 @@ def jf_write_records(path, k, canonical, keys, counts):
         raise KatGpuError(rc, L.katgpu_jf_last_error().decode(errors="replace"))
 
 
+class ScratchView:
+    """nbytes of device memory owned by the engine, exposed through the CUDA array interface (uint8)."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr = ptr
+        self.nbytes = nbytes
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}
+
+
 class DeviceBuffer:
     """A raw HBM allocation owned by an Engine."""
 
@@ -216,6 +227,17 @@ class Engine:
 
     def sync(self):
         self._chk(self.L.katgpu_sync(self.h))
+
+    def release_scratch(self):
+        """Hand cached device memory (parked table arrays, partition arena) back to the driver."""
+        self._chk(self.L.katgpu_release_scratch(self.h))
+
+    def scratch(self, nbytes):
+        """Borrow the engine's arena as raw device scratch: an object torch / cupy can wrap without copying
+        (`torch.as_tensor(obj, device="cuda")` through __cuda_array_interface__)."""
+        p, got = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.katgpu_scratch_acquire(self.h, int(nbytes), C.byref(p), C.byref(got)))
+        return ScratchView(p.value, int(nbytes))
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

@@ -137,6 +137,37 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
     delete c;
 }
 
+// Give the parked table arrays and the partition arena back to the driver (they are re-acquired on demand).  Callers that
+// are about to allocate large buffers of their own on the same device (the multi-GPU exchange does) call this first.
+extern "C" int katgpu_release_scratch(katgpu_ctx* c) {
+    if (!c) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& b : c->pool) hipFree(b.p);
+    c->pool.clear();
+    if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+    return KATGPU_OK;
+}
+
+// Borrow the partitioned counter's arena as plain device scratch (grown to `bytes` if needed).  The multi-GPU exchange keeps
+// its send / receive records here instead of allocating next to an arena that already holds most of the free HBM.  Valid
+// until the next katgpu_count_* call on this context.
+extern "C" int katgpu_scratch_acquire(katgpu_ctx* c, size_t bytes, void** dev_ptr, size_t* got_bytes) {
+    if (!c || !dev_ptr) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->arena_bytes < bytes) {
+        if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+        for (auto& b : c->pool) hipFree(b.p);
+        c->pool.clear();
+        HIPCHK(c, hipMalloc((void**)&c->arena, bytes));
+        c->arena_bytes = bytes;
+    }
+    *dev_ptr = c->arena;
+    if (got_bytes) *got_bytes = c->arena_bytes;
+    return KATGPU_OK;
+}
+
 extern "C" const char* katgpu_last_error(const katgpu_ctx* c) { return c ? c->err.c_str() : "no context"; }
 
 extern "C" int katgpu_sync(katgpu_ctx* c) {

@@ -31,10 +31,25 @@ class HipShard:
     def partition_sizes(self, n_parts):
         return self.table.partition_sizes(n_parts).astype(np.int64)
 
-    def partition_into(self, n_parts, sizes):
+    def exchange_buffers(self, n_send, n_recv):
+        """Four int64 record arrays (send keys/counts, receive keys/counts).  They are views into katgpu's own arena when
+        torch can wrap it (after a large count the arena holds most of the free HBM, so allocating next to it would fail);
+        otherwise the arena is released and torch allocates."""
+        n_send, n_recv = max(int(n_send), 1), max(int(n_recv), 1)
+        eng = self.table.engine
+        try:
+            raw = torch.as_tensor(eng.scratch(16 * (n_send + n_recv) + 64), device=self.device).view(torch.int64)
+            return raw[:n_send], raw[n_send:2 * n_send], raw[2 * n_send:2 * n_send + n_recv], raw[2 * n_send + n_recv:2 * (n_send + n_recv)]
+        except Exception:
+            eng.release_scratch()
+            mk = lambda n: torch.empty(n, dtype=torch.int64, device=self.device)
+            return mk(n_send), mk(n_send), mk(n_recv), mk(n_recv)
+
+    def partition_into(self, n_parts, sizes, keys=None, counts=None):
         total = int(sizes.sum())
-        keys = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
-        counts = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+        if keys is None:
+            keys = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+            counts = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
         offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
         torch.cuda.synchronize()
         self.table.partition(n_parts, offsets, keys.data_ptr(), counts.data_ptr())
@@ -69,10 +84,14 @@ def exchange_merge(shard, group=None, load=0.6, grid_of=None):
     all_sizes = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(all_sizes, mine, group=group)
     recv_sizes = np.array([int(s[rank]) for s in all_sizes], dtype=np.int64)   # what each peer sends to me
-    keys, counts = shard.partition_into(world, sizes)
     send_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     recv_off = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
-    rkeys, rcounts = shard.empty_like(int(recv_off[-1]))
+    if hasattr(shard, "exchange_buffers"):
+        keys, counts, rkeys, rcounts = shard.exchange_buffers(int(send_off[-1]), int(recv_off[-1]))
+        keys, counts = shard.partition_into(world, sizes, keys, counts)
+    else:
+        keys, counts = shard.partition_into(world, sizes)
+        rkeys, rcounts = shard.empty_like(int(recv_off[-1]))
     ops = []
     for p in range(world):
         if p == rank:

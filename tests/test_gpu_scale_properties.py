@@ -86,5 +86,11 @@ def test_hipshard_torch_plumbing(engine):
     ka, ca = src.dump_sorted()
     kb, cb = dst.table.dump_sorted()
     assert np.array_equal(ka, kb) and np.array_equal(ca, cb)
+    # the exchange buffers are views into the engine's arena (no torch allocation next to it)
+    ks, cs, rk, rc = shard.exchange_buffers(int(sizes.sum()), 1000)
+    assert ks.is_cuda and ks.numel() == int(sizes.sum()) and rk.numel() == 1000
+    k2, c2 = shard.partition_into(4, sizes, ks, cs)
+    assert k2.data_ptr() == ks.data_ptr()
+    assert torch.equal(torch.sort(k2)[0], torch.sort(keys)[0]) and int(c2.sum()) == int(counts.sum())
     out = kdist.allreduce_u64([np.arange(5, dtype=np.uint64)], torch.device("cuda", 0))      # world 1: identity
     assert np.array_equal(out[0], np.arange(5, dtype=np.uint64))
