@@ -86,7 +86,7 @@ def exchange_merge(shard, group=None, load=0.6, grid_of=None):
     recv_sizes = np.array([int(s[rank]) for s in all_sizes], dtype=np.int64)   # what each peer sends to me
     send_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     recv_off = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
-    if hasattr(shard, "exchange_buffers"):
+    if callable(getattr(shard, "exchange_buffers", None)):
         keys, counts, rkeys, rcounts = shard.exchange_buffers(int(send_off[-1]), int(recv_off[-1]))
         keys, counts = shard.partition_into(world, sizes, keys, counts)
     else:
