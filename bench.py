@@ -59,6 +59,9 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
 
+    if world > 1:
+        # leave room next to the partition arena for the owner tables of the exchange (must be set before the library loads)
+        os.environ.setdefault("KATGPU_ARENA_FRACTION", "0.5")
     import torch
     import kat_amd
     from kat_amd import dist as kdist

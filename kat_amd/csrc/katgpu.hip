@@ -48,6 +48,7 @@ struct katgpu_ctx {
     uint8_t* arena = nullptr;
     size_t arena_bytes = 0;
     bool part_attr_set = false;
+    bool arena_borrowed = false;          // katgpu_scratch_acquire handed the arena out: it must not be freed behind the caller's back
     int count_blocks_per_cu = 6;
 };
 
@@ -146,6 +147,7 @@ extern "C" int katgpu_release_scratch(katgpu_ctx* c) {
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
     if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+    c->arena_borrowed = false;
     return KATGPU_OK;
 }
 
@@ -163,6 +165,7 @@ extern "C" int katgpu_scratch_acquire(katgpu_ctx* c, size_t bytes, void** dev_pt
         HIPCHK(c, hipMalloc((void**)&c->arena, bytes));
         c->arena_bytes = bytes;
     }
+    c->arena_borrowed = true;
     *dev_ptr = c->arena;
     if (got_bytes) *got_bytes = c->arena_bytes;
     return KATGPU_OK;
@@ -243,10 +246,10 @@ static hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes) {
         return hipSuccess;
     }
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && (!c->pool.empty() || c->arena)) {           // give cached scratch back and retry once
+    if (e != hipSuccess && (!c->pool.empty() || (c->arena && !c->arena_borrowed))) {    // give cached scratch back and retry once
         (void)hipGetLastError();
         pool_trim(c);
-        if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+        if (c->arena && !c->arena_borrowed) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
         e = hipMalloc(p, bytes);
     }
     *got_bytes = bytes;
@@ -452,6 +455,8 @@ static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
 
 static const uint64_t g_part_min_starts = getenv("KATGPU_PART_MIN_STARTS") ? strtoull(getenv("KATGPU_PART_MIN_STARTS"), nullptr, 10) : (32ULL << 20);
 static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? strtoull(getenv("KATGPU_TEST_ROUND_ITEMS"), nullptr, 10) : 0;
+// share of the free HBM the partition arena may take (multi-GPU runs leave room for the owner tables: bench.py sets 0.5)
+static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::min(0.95, std::max(0.05, atof(getenv("KATGPU_ARENA_FRACTION")))) : 0.85;
 static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10) : 3;   // 0 = first edition (1024-thread, 1 per CU)
 static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 1024;
 static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
@@ -470,6 +475,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const uint32_t k = t->d.k;
     const size_t n_starts = n - k + 1;
     *done = 0;
+    c->arena_borrowed = false;                    // a borrowed arena is only promised until the next count call
     const bool p1v2 = g_p1_wgs > 0;
     const uint32_t W = (uint32_t)c->n_cu * (p1v2 ? std::min<uint32_t>(g_p1_wgs, 4) : 1);      // level-1 workgroups (rows of hist1 / offs)
     const uint32_t W2 = (uint32_t)c->n_cu;                                                      // level-2 / apply: one per CU
@@ -495,7 +501,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         free_b += c->arena_bytes;
-        size_t bytes = std::min<size_t>(small_bytes + 16 * want_items, (size_t)(0.85 * (double)free_b));
+        size_t bytes = std::min<size_t>(small_bytes + 16 * want_items, (size_t)(g_arena_fraction * (double)free_b));
         // re-allocate only for a substantially larger arena (fewer rounds): a fresh hipMalloc of this size is not free
         if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 16 * std::min<size_t>(want_items, (size_t)64 << 20)) {
             if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
