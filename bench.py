@@ -224,8 +224,8 @@ def main():
 
 def cpu_baseline(eng, a, k, L):
     """The oracle (a C port of the reference algorithm, oracle/koracle.c) timed on this box's host cores over a BOUNDED
-    sample of the same workload: count sample reads + count a slice of the assembly (multi-threaded CAS table, like
-    Jellyfish) + comp (single-threaded scan/probe)."""
+    sample of the same workload: count sample reads + count a slice of the assembly (thread team over a shared CAS table,
+    like Jellyfish) + comp (T x compareSlice with private accumulators, merged under a lock, like KAT)."""
     from oracle import koracle as ko
     threads = os.cpu_count() or 1
     n = min(a.cpu_sample_reads, a.reads) & ~1
@@ -239,7 +239,7 @@ def cpu_baseline(eng, a, k, L):
     t0 = time.perf_counter()
     t1 = ko.Table(k, True).count_bases(rh, threads=threads)
     t2 = ko.Table(k, True).count_bases(ah, threads=threads)
-    ko.comp(t1, t2)
+    ko.comp(t1, t2, threads=threads)
     dt = time.perf_counter() - t0
     inst = n * (L - k + 1) + max(0, gs - (gs // 100_000) * (k - 1))
     return {"value": round(inst / dt, 1), "unit": "k-mers/s", "cores": threads, "kind": "port",

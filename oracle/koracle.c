@@ -133,11 +133,54 @@ static void table_grow(ko_table* t, uint64_t newcap) {
     free(ok); free(oc);
 }
 
-static void table_reserve(ko_table* t, uint64_t extra) {
+/* ---- thread team helper for the multi-threaded (CPU baseline) paths ---- */
+typedef void (*par_fn)(int tid, int nthreads, void* ctx);
+typedef struct { par_fn fn; int tid, n; void* ctx; } par_job;
+static void* par_tramp(void* a) { par_job* j = (par_job*)a; j->fn(j->tid, j->n, j->ctx); return NULL; }
+static void par_for(int threads, par_fn fn, void* ctx) {
+    if (threads <= 1) { fn(0, 1, ctx); return; }
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    par_job* jobs = (par_job*)malloc(sizeof(par_job) * threads);
+    for (int i = 0; i < threads; i++) { jobs[i] = (par_job){fn, i, threads, ctx}; pthread_create(&th[i], NULL, par_tramp, &jobs[i]); }
+    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    free(th); free(jobs);
+}
+
+/* parallel regrow (what hash_counter::double_size does with its thread team, hash_counter.hpp:204-244) */
+typedef struct { uint64_t *ok, *oc, ocap; ko_table* t; } grow_ctx;
+static void grow_init(int tid, int n, void* c) {
+    grow_ctx* g = (grow_ctx*)c;
+    uint64_t lo = g->t->cap / n * tid, hi = tid == n - 1 ? g->t->cap : g->t->cap / n * (tid + 1);
+    memset(g->t->keys + lo, 0xFF, (hi - lo) * 8); memset(g->t->counts + lo, 0, (hi - lo) * 8);
+}
+static void grow_move(int tid, int n, void* c) {
+    grow_ctx* g = (grow_ctx*)c;
+    uint64_t lo = g->ocap / n * tid, hi = tid == n - 1 ? g->ocap : g->ocap / n * (tid + 1), m = g->t->cap - 1;
+    for (uint64_t i = lo; i < hi; i++) {
+        if (g->ok[i] == KO_EMPTY) continue;
+        uint64_t p = mix64(g->ok[i]) & m;
+        for (;;) {
+            uint64_t exp = KO_EMPTY;
+            if (__atomic_compare_exchange_n(&g->t->keys[p], &exp, g->ok[i], 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { g->t->counts[p] = g->oc[i]; break; }
+            p = (p + 1) & m;
+        }
+    }
+}
+static void table_grow_mt(ko_table* t, uint64_t newcap, int threads) {
+    grow_ctx g = {t->keys, t->counts, t->cap, t};
+    t->keys = (uint64_t*)malloc(newcap * 8); t->counts = (uint64_t*)malloc(newcap * 8);
+    if (!t->keys || !t->counts) { fprintf(stderr, "koracle: out of memory\n"); abort(); }
+    t->cap = newcap;
+    par_for(threads, grow_init, &g);
+    par_for(threads, grow_move, &g);
+    free(g.ok); free(g.oc);
+}
+
+static void table_reserve(ko_table* t, uint64_t extra, int threads) {
     uint64_t need = t->distinct + extra;
     uint64_t cap = t->cap;
     while (need * 10 > cap * 6) cap <<= 1;
-    if (cap != t->cap) table_grow(t, cap);
+    if (cap != t->cap) { if (threads > 1) table_grow_mt(t, cap, threads); else table_grow(t, cap); }
 }
 
 void ko_table_add(ko_table* t, uint64_t key, uint64_t amount) {   /* hash_counter::add: hash_counter.hpp:98-130 */
@@ -247,12 +290,12 @@ void ko_count_bases_mt(ko_table* t, const uint8_t* s, size_t n, int threads) {
     if (n < t->k) return;
     const size_t nstart = n - t->k + 1;            /* number of window start positions */
     size_t block = (size_t)16 << 20;              /* window starts per thread-team round */
-    if (block < ((size_t)threads << 20)) block = (size_t)threads << 20;
+    if (block < ((size_t)threads << 18)) block = (size_t)threads << 18;
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
     mt_job* jobs = (mt_job*)malloc(sizeof(mt_job) * threads);
     for (size_t b0 = 0; b0 < nstart; b0 += block) {
         size_t b1 = b0 + block < nstart ? b0 + block : nstart;
-        table_reserve(t, b1 - b0);                 /* no growth while threads run */
+        table_reserve(t, b1 - b0, threads);        /* no growth while threads run */
         size_t per = (b1 - b0 + threads - 1) / threads;
         for (int i = 0; i < threads; i++) {
             size_t lo = b0 + per * i, hi = lo + per; if (lo > b1) lo = b1; if (hi > b1) hi = b1;
@@ -520,6 +563,66 @@ void ko_comp(const ko_table* t1, const ko_table* t2, int canon1, int canon2,
             mx[s2]++;                                                                    /* main_matrix[0][s2] */
         }
     });
+}
+
+/* Multi-threaded ko_comp for the CPU baseline: T x compareSlice over table slices with private accumulators, merged under
+ * a lock -- the structure of Comp::compare / compareSlice / merge (src/comp.cc:366-385,387-484,248-265). */
+typedef struct {
+    const ko_table *t1, *t2; int canon2; double d1_scale, d2_scale; uint32_t d1_bins, d2_bins;
+    uint64_t *mx, *cc, *spectra; pthread_mutex_t mu;
+} comp_ctx;
+
+static void comp_slice(int tid, int n, void* c) {
+    comp_ctx* x = (comp_ctx*)c;
+    const unsigned k = x->t1->k;
+    const uint32_t d1 = x->d1_bins, d2 = x->d2_bins;
+    const size_t ss = d1 < d2 ? d1 : d2, cells = (size_t)d1 * d2;
+    uint64_t* mx = (uint64_t*)calloc(cells, 8);
+    uint64_t* sp = (uint64_t*)calloc(4 * ss, 8);
+    uint64_t cc[13] = {0};
+    uint64_t lo = x->t1->cap / n * tid, hi = tid == n - 1 ? x->t1->cap : x->t1->cap / n * (tid + 1);
+    for (uint64_t i = lo; i <= hi; i++) {                       /* i == hi only for the last thread: the all-ones key */
+        uint64_t key, c1;
+        if (i < hi) { key = x->t1->keys[i]; if (key == KO_EMPTY) continue; c1 = x->t1->counts[i]; }
+        else { if (tid != n - 1 || !x->t1->ones_count) break; key = KO_EMPTY; c1 = x->t1->ones_count; }
+        uint64_t c2 = ko_table_get(x->t2, x->canon2 ? ko_canonical(key, k) : key);
+        cc[H1_TOTAL] += c1; cc[H1_DISTINCT]++; update_spectrum(sp, ss, c1);
+        if (!c2) { cc[H1_ONLY_TOTAL] += c1; cc[H1_ONLY_DISTINCT]++; }
+        if (c1 && c2) { cc[SH_H1_TOTAL] += c1; cc[SH_H2_TOTAL] += c2; cc[SH_DISTINCT]++; update_spectrum(sp + 2 * ss, ss, c1); update_spectrum(sp + 3 * ss, ss, c2); }
+        uint64_t s1 = scale_counter(c1, x->d1_scale), s2 = scale_counter(c2, x->d2_scale);
+        if (s1 >= d1) s1 = d1 - 1;
+        if (s2 >= d2) s2 = d2 - 1;
+        mx[s1 * d2 + s2]++;
+    }
+    lo = x->t2->cap / n * tid; hi = tid == n - 1 ? x->t2->cap : x->t2->cap / n * (tid + 1);
+    for (uint64_t i = lo; i <= hi; i++) {
+        uint64_t key, c2;
+        if (i < hi) { key = x->t2->keys[i]; if (key == KO_EMPTY) continue; c2 = x->t2->counts[i]; }
+        else { if (tid != n - 1 || !x->t2->ones_count) break; key = KO_EMPTY; c2 = x->t2->ones_count; }
+        uint64_t c1 = ko_table_get(x->t1, ko_canonical(key, k));
+        cc[H2_TOTAL] += c2; cc[H2_DISTINCT]++; update_spectrum(sp + ss, ss, c2);
+        if (!c1) {
+            cc[H2_ONLY_TOTAL] += c2; cc[H2_ONLY_DISTINCT]++;
+            uint64_t s2 = scale_counter(c2, x->d2_scale);
+            if (s2 >= d2) s2 = d2 - 1;
+            mx[s2]++;
+        }
+    }
+    pthread_mutex_lock(&x->mu);
+    for (size_t i = 0; i < cells; i++) x->mx[i] += mx[i];
+    for (size_t i = 0; i < 4 * ss; i++) x->spectra[i] += sp[i];
+    for (int i = 0; i < 13; i++) x->cc[i] += cc[i];
+    pthread_mutex_unlock(&x->mu);
+    free(mx); free(sp);
+}
+
+void ko_comp_mt(const ko_table* t1, const ko_table* t2, int canon1, int canon2, double d1_scale, double d2_scale,
+                uint32_t d1_bins, uint32_t d2_bins, uint64_t* mx, uint64_t cc[13], uint64_t* spectra, int threads) {
+    (void)canon1;
+    const size_t ss = d1_bins < d2_bins ? d1_bins : d2_bins;
+    memset(mx, 0, (size_t)d1_bins * d2_bins * 8); memset(cc, 0, 13 * 8); memset(spectra, 0, 4 * ss * 8);
+    comp_ctx x = {t1, t2, canon2, d1_scale, d2_scale, d1_bins, d2_bins, mx, cc, spectra, PTHREAD_MUTEX_INITIALIZER};
+    par_for(threads < 1 ? 1 : threads, comp_slice, &x);
 }
 
 /* Comp::compareSlice with a third hash (src/comp.cc:403-433,466-479) */

@@ -78,6 +78,11 @@ void ko_comp(const ko_table* t1, const ko_table* t2, int canon1, int canon2,
              double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
              uint64_t* main_mx, uint64_t counters[13], uint64_t* spectra);
 
+/* multi-threaded form for the CPU baseline (T x compareSlice + merge, src/comp.cc:366-385,248-265); same result */
+void ko_comp_mt(const ko_table* t1, const ko_table* t2, int canon1, int canon2,
+                double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
+                uint64_t* main_mx, uint64_t counters[13], uint64_t* spectra, int threads);
+
 /* three-input form (src/comp.cc:123-127,403-433,466-479): adds ends / middle / mixed matrices (each d1_bins x d2_bins)
  * and counters[2] = hash3_total, counters[5] = hash3_distinct */
 void ko_comp3(const ko_table* t1, const ko_table* t2, const ko_table* t3, int canon1, int canon2, int canon3,

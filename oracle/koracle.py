@@ -50,6 +50,8 @@ def lib():
     L.ko_gcp.argtypes = [C.c_void_p, C.c_double, C.c_uint32, C.c_void_p]
     L.ko_comp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
                           C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ko_comp_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.ko_comp3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ko_write_comp_stats3.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -206,13 +208,17 @@ def hist_geometry(low, high):
     return base, ceil_, ceil_ + 1 - base
 
 
-def comp(t1, t2, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001):
+def comp(t1, t2, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001, threads=1):
     ss = min(d1_bins, d2_bins)
     mx = np.zeros((d1_bins, d2_bins), np.uint64)
     cc = np.zeros(13, np.uint64)
     sp = np.zeros((4, ss), np.uint64)
-    lib().ko_comp(t1.h, t2.h, int(t1.canonical), int(t2.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
-                  mx.ctypes.data, cc.ctypes.data, sp.ctypes.data)
+    if threads > 1:
+        lib().ko_comp_mt(t1.h, t2.h, int(t1.canonical), int(t2.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
+                         mx.ctypes.data, cc.ctypes.data, sp.ctypes.data, threads)
+    else:
+        lib().ko_comp(t1.h, t2.h, int(t1.canonical), int(t2.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
+                      mx.ctypes.data, cc.ctypes.data, sp.ctypes.data)
     return mx, cc, sp
 
 
