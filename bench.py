@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--err-ppm", type=int, default=2000, help="substitution errors per million bases (0.2 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="sync + print per-phase wall time (diagnostic; perturbs the timing)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=8_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
     return ap.parse_args()
 
 
