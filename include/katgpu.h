@@ -97,6 +97,14 @@ int      katgpu_table_canonical(const katgpu_table* t);
 
 /* JellyfishHelper::getCount (lib/src/jellyfish_helper.cc:189-194) for a batch of packed k-mers. */
 int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n, int canonicalise, uint64_t* counts);
+/* Per-position coverage of a sequence: the loop of Sect::processSeq (src/sect.cc:516-535 -- validKmer + mer_dna +
+ * JellyfishHelper::getCount for every k-window) and of Cold::processSeq (src/cold.cc).  counts[i], i in [0, n-k], is the
+ * count of the window starting at bases[i], or 0 when that window holds any byte other than ACGTacgt; nothing is
+ * written when n < k.  Several records may be profiled in one call by joining them with any non-base byte.
+ * `canonicalise` is InputHandler::canonical.  The _device form takes device pointers and is asynchronous on the
+ * context's stream. */
+int katgpu_table_profile_host(katgpu_table* t, const char* bases, size_t n, int canonicalise, uint64_t* counts);
+int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_bases, size_t n, int canonicalise, uint64_t* dev_counts);
 /* All (key,count) pairs in unspecified order (the eager_iterator walk, JF/.../large_hash_iterator.hpp:28-65).
  * Pass cap = 0 to query *n_out only. */
 int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* counts, size_t cap, size_t* n_out);
@@ -171,7 +179,8 @@ typedef enum katgpu_kernel {
     KATGPU_K_PART_L2 = 9,    /* level-2 partition: one run per table region (k_p2) */
     KATGPU_K_PART_APPLY = 10,/* regions updated in LDS (k_p3_apply) */
     KATGPU_K_PART_L1S = 11,  /* extract + level-1 scatter (k_p1_scatter) */
-    KATGPU_K_NCLASSES = 12
+    KATGPU_K_PROFILE = 12,   /* per-position lookups (k_profile) */
+    KATGPU_K_NCLASSES = 13
 } katgpu_kernel;
 int katgpu_profile_reset(katgpu_ctx* ctx);
 int katgpu_profile_get(katgpu_ctx* ctx, int kernel_class, uint64_t* launches, double* total_ms, uint64_t* units);

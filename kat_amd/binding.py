@@ -23,7 +23,8 @@ EXPORTS = (
     "katgpu_init", "katgpu_shutdown", "katgpu_last_error", "katgpu_version", "katgpu_sync", "katgpu_release_scratch", "katgpu_scratch_acquire",
     "katgpu_count", "katgpu_table_create", "katgpu_table_create_like", "katgpu_count_files", "katgpu_count_bases_host",
     "katgpu_count_bases_device", "katgpu_table_free", "katgpu_table_stats", "katgpu_table_k",
-    "katgpu_table_canonical", "katgpu_table_get", "katgpu_table_export", "katgpu_hist", "katgpu_gcp",
+    "katgpu_table_canonical", "katgpu_table_get", "katgpu_table_profile_host", "katgpu_table_profile_device",
+    "katgpu_table_export", "katgpu_hist", "katgpu_gcp",
     "katgpu_comp", "katgpu_comp3", "katgpu_table_partition_sizes", "katgpu_table_partition", "katgpu_table_merge_device",
     "katgpu_table_merge_host", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
@@ -78,6 +79,8 @@ def load_library():
     L.katgpu_table_k.restype = u32
     L.katgpu_table_canonical.argtypes = [vp]
     L.katgpu_table_get.argtypes = [vp, vp, sz, C.c_int, vp]
+    L.katgpu_table_profile_host.argtypes = [vp, vp, sz, C.c_int, vp]
+    L.katgpu_table_profile_device.argtypes = [vp, vp, sz, C.c_int, vp]
     L.katgpu_table_export.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
     L.katgpu_hist.argtypes = [vp, u64, u64, u64, vp, sz]
     L.katgpu_gcp.argtypes = [vp, C.c_double, u32, vp]
@@ -355,6 +358,23 @@ class Table:
         out = np.zeros(k.size, np.uint64)
         self.engine._chk(self.engine.L.katgpu_table_get(self.h, k.ctypes.data, k.size, int(bool(canonicalise)), out.ctypes.data))
         return out
+
+    def profile(self, seq, canonicalise=None):
+        """Per-position coverage of `seq` (bytes / str / uint8 array): u64[len-k+1], 0 for windows with a non-base."""
+        if isinstance(seq, str):
+            seq = seq.encode()
+        b = np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else np.ascontiguousarray(seq, np.uint8)
+        out = np.zeros(max(0, b.size - self.k + 1), np.uint64)
+        canon = self.canonical if canonicalise is None else canonicalise
+        self.engine._chk(self.engine.L.katgpu_table_profile_host(self.h, b.ctypes.data, b.size, int(bool(canon)), out.ctypes.data))
+        return out
+
+    def profile_device(self, dev_bases, n, dev_counts, canonicalise=None):
+        """Device-resident form: `dev_bases` / `dev_counts` are DeviceBuffers or raw device addresses."""
+        canon = self.canonical if canonicalise is None else canonicalise
+        pb = getattr(dev_bases, "ptr", dev_bases)
+        pc = getattr(dev_counts, "ptr", dev_counts)
+        self.engine._chk(self.engine.L.katgpu_table_profile_device(self.h, pb, n, int(bool(canon)), pc))
 
     def export(self):
         n = C.c_size_t()

@@ -30,6 +30,7 @@ struct JellyfishException : KatException { using KatException::KatException; };
 struct HistogramException : KatException { using KatException::KatException; };
 struct CompException : KatException { using KatException::KatException; };
 struct FileSystemException : KatException { using KatException::KatException; };
+struct SectException : KatException { using KatException::KatException; };
 
 // One process-wide engine context (katgpu_init / katgpu_shutdown).
 class Engine {
@@ -224,6 +225,72 @@ private:
     bool densityPlot = false, outputHists = false, verbose = false;
     Matrix64 main_matrix, ends_matrix, middle_matrix, mixed_matrix;
     CompCounters comp_counters;
+};
+
+// FASTA / FASTQ (optionally gzip) records as seqan::SeqFileIn + readRecords(names, seqs, ...) deliver them to Sect
+// (deps/seqan-library-2.0.0/include/seqan/seq_io/fasta_fastq.h:306-380): the name is the whole header line, only
+// newlines are dropped from the sequence, and a sequence ends at the next '>' ('+' for FASTQ).
+class SeqRecordReader {
+public:
+    explicit SeqRecordReader(const std::string& path);
+    ~SeqRecordReader();
+    bool atEnd();
+    void readRecord(std::string& name, std::string& seq);
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl;
+    bool fastq = false;
+    int peek();
+    void line(std::string* into);
+};
+
+// src/sect.hpp
+class Sect {
+public:
+    Sect(const std::vector<std::string>& counts_files, const std::string& seq_file);
+    void setOutputPrefix(const std::string& p) { outputPrefix = p; }
+    void setGcBins(uint16_t b) { gcBins = b; }
+    void setCvgBins(uint16_t b) { cvgBins = b; }
+    void setCvgLogscale(bool l) { cvgLogscale = l; }
+    void setThreads(uint16_t t) { threads = t; }
+    void setTrim(const std::vector<uint16_t>& t) { input.set5pTrim(t); }
+    void setCanonical(bool c) { input.canonical = c; }
+    void setMerLen(uint16_t m) { input.merLen = m; }
+    uint16_t getMerLen() const { return input.merLen; }
+    void setHashSize(uint64_t h) { input.hashSize = h; }
+    void setDumpHash(bool d) { input.dumpHash = d; }
+    void setNoCountStats(bool n) { noCountStats = n; }
+    void setOutputGCStats(bool g) { outputGCStats = g; }
+    void setExtractNR(bool e) { extractNR = e; }
+    void setExtractR(bool e) { extractR = e; }
+    void setMinRepeat(uint32_t m) { minRepeat = m; }
+    void setMaxRepeat(uint32_t m) { maxRepeat = m; }
+    void setVerbose(bool v) { verbose = v; }
+    void execute();
+    void save();
+    void printContaminationMatrix(std::ostream& out, const std::string& seq_file);
+    static int main(int argc, char* argv[]);
+private:
+    struct Record {                         // the per-record slots of createBatchVars (src/sect.cc:310-322) + the text it prints
+        const std::string* name = nullptr; const std::string* seq = nullptr;
+        uint32_t median = 0, length = 0, invalid = 0, nonZero = 0;
+        double mean = 0.0, gc = 0.0, percentInvalid = 0.0, percentNonZero = 0.0, percentNonZeroCorrected = 0.0;
+        uint16_t mx_x = 0, mx_y = 0;
+        std::string cvg_txt, gc_txt, nr_txt, r_txt;
+    };
+    void processSeqFile();
+    void processSeq(Record& r, const uint64_t* counts);
+    void regions(std::string& out, const Record& r, const uint64_t* counts, size_t nb, uint32_t min_count, uint32_t max_count);
+    void merge();
+    InputHandler input;
+    std::string seqFile, outputPrefix;
+    uint16_t gcBins = 1001, cvgBins = 1001;
+    bool cvgLogscale = false;
+    uint16_t threads = 1;
+    bool noCountStats = false, outputGCStats = false, extractNR = false, extractR = false;
+    uint32_t minRepeat = 2, maxRepeat = 0;
+    bool verbose = false;
+    Matrix64 contamination_mx;
 };
 
 // ---- command-line helper shared by the three tools (stands in for boost::program_options) ----

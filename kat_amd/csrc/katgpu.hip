@@ -822,6 +822,62 @@ extern "C" int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n,
     return KATGPU_OK;
 }
 
+static int launch_profile(katgpu_table* t, const uint8_t* dev_bases, size_t n, int canonicalise, uint64_t* dev_counts) {
+    katgpu_ctx* c = t->ctx;
+    const uint64_t n_out = n - t->d.k + 1;
+    const uint64_t n_chunks = (n_out + CHUNK_STARTS - 1) / CHUNK_STARTS;
+    const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * 8);
+    ScopedTimer tm(c, KATGPU_K_PROFILE, n_out);
+    if ((reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0 && (reinterpret_cast<uintptr_t>(dev_counts) & 15) == 0)
+        hipLaunchKernelGGL(k_profile<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
+    else
+        hipLaunchKernelGGL(k_profile<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
+    HIPCHK(c, hipGetLastError());
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_bases, size_t n, int canonicalise, uint64_t* dev_counts) {
+    if (!t || (n && (!dev_bases || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
+    if (n < t->d.k) return KATGPU_OK;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    return launch_profile(t, dev_bases, n, canonicalise, dev_counts);
+}
+
+// Host form: the sequence goes through the device in batches of PROFILE_BATCH window starts (each batch re-sends the
+// k-1 bases it shares with the next one), so any length fits next to the table.
+extern "C" int katgpu_table_profile_host(katgpu_table* t, const char* bases, size_t n, int canonicalise, uint64_t* counts) {
+    if (!t || (n && (!bases || !counts))) return KATGPU_ERR_INVALID_ARG;
+    const uint32_t k = t->d.k;
+    if (n < k) return KATGPU_OK;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    const size_t n_out = n - k + 1;
+    const size_t PROFILE_BATCH = (size_t)32 << 20;
+    const size_t batch = std::min(n_out, PROFILE_BATCH);
+    uint8_t* db = nullptr; uint64_t* dc = nullptr;
+    HIPCHK(c, pool_alloc(c, (void**)&db, batch + 64));
+    if (pool_alloc(c, (void**)&dc, batch * 8) != hipSuccess) { pool_release(c, db); return fail(c, KATGPU_ERR_NOMEM, "profile buffers"); }
+    hipError_t e = hipSuccess;
+    for (size_t pos = 0; pos < n_out && rc == KATGPU_OK && e == hipSuccess; pos += batch) {
+        const size_t starts = std::min(batch, n_out - pos);
+        const size_t nb = starts + k - 1;
+        e = hipMemcpyAsync(db, bases + pos, nb, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) break;
+        rc = launch_profile(t, db, nb, canonicalise, dc);
+        if (rc) break;
+        e = hipMemcpyAsync(counts + pos, dc, starts * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    hipStreamSynchronize(c->stream);
+    pool_release(c, db); pool_release(c, dc);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
 // ------------------------------------------------------------------ partition / export / merge -------
 
 extern "C" int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, uint64_t* sizes) {

@@ -514,6 +514,78 @@ k_get(DevTable t, uint32_t n_ovf, const uint64_t* __restrict__ keys, uint64_t n,
     if (i < n) out[i] = table_get(t, canonicalise ? kmer_canonical(keys[i], t.k) : keys[i], n_ovf);
 }
 
+// K8.  Per-position coverage of a sequence (kat sect / kat cold; src/sect.cc:516-535): out[i] = count of the k-window
+// starting at base i, 0 when the window holds anything but ACGTacgt.  Same front end as k_count (16-byte loads, packed
+// codes through LDS, a 96-bit register window slid 16 times); the back end is a read-only probe, so the table's
+// cache lines are shared between waves and nothing is atomic.  Each lane produces 16 consecutive counts = one 128-byte
+// line of `out`, written as 8 dwordx4 stores.
+template <bool ALIGNED>
+__global__ void __launch_bounds__(COUNT_BLOCK)
+k_profile(DevTable t, uint32_t n_ovf, int canonicalise, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_chunks,
+          uint64_t* __restrict__ out) {
+    __shared__ uint32_t s_code[COUNT_BLOCK + 2];
+    __shared__ uint32_t s_bad[COUNT_BLOCK + 2];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = t.k;
+    const uint64_t n_out = n - k + 1;
+    if (tid < 2) { s_code[COUNT_BLOCK + tid] = 0; s_bad[COUNT_BLOCK + tid] = 0xFFFF; }
+
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint64_t off = chunk * CHUNK_STARTS + (uint64_t)tid * BASES_PER_LANE;
+        uint32_t w[4];
+        if (ALIGNED && off + BASES_PER_LANE <= n) {
+            const uint4 v = *reinterpret_cast<const uint4*>(bases + off);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    uint64_t i = off + q * 4 + b;
+                    uint32_t c = i < n ? bases[i] : (uint32_t)'N';
+                    x |= c << (8 * b);
+                }
+                w[q] = x;
+            }
+        }
+        uint32_t code, bad;
+        encode16(w, code, bad);
+        s_code[tid] = code;
+        s_bad[tid] = bad;
+        __syncthreads();
+
+        if (tid < LANES_WITH_STARTS && off < n_out) {
+            uint64_t hi = ((uint64_t)s_code[tid] << 32) | s_code[tid + 1];
+            uint64_t lo = (uint64_t)s_code[tid + 2] << 32;
+            uint64_t m = ((uint64_t)s_bad[tid] << 48) | ((uint64_t)s_bad[tid + 1] << 32) | ((uint64_t)s_bad[tid + 2] << 16);
+            const uint32_t kshift = 64 - 2 * k, mshift = 64 - k;
+            uint64_t c[BASES_PER_LANE];
+#pragma unroll
+            for (int j = 0; j < BASES_PER_LANE; ++j) {
+                c[j] = 0;
+                if ((m >> mshift) == 0) {
+                    uint64_t key = hi >> kshift;
+                    if (canonicalise) key = kmer_canonical(key, k);
+                    c[j] = table_get(t, key, n_ovf);
+                }
+                hi = (hi << 2) | (lo >> 62);
+                lo <<= 2;
+                m <<= 1;
+            }
+            if (off + BASES_PER_LANE <= n_out) {
+                ulonglong2* o = reinterpret_cast<ulonglong2*>(out + off);           // off is a multiple of 16: 128-byte aligned
+#pragma unroll
+                for (int j = 0; j < BASES_PER_LANE / 2; ++j) o[j] = make_ulonglong2(c[2 * j], c[2 * j + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < BASES_PER_LANE; ++j) if (off + j < n_out) out[off + j] = c[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- export / owner partition ----
 // mode 0: count records per part into sizes[]; mode 1: scatter records to cursors[part]++.
 template <int MODE>

@@ -111,6 +111,13 @@ int ko_write_comp_hist(const char* out_path, unsigned k, const char* const* path
 /* distance metrics (lib/include/kat/distance_metrics.hpp:39-127): 0 Manhattan 1 Euclidean 2 Cosine 3 Canberra 4 Jaccard */
 double ko_distance(int which, const uint64_t* s1, const uint64_t* s2, size_t n);
 
+/* ---- `kat sect` (koracle_sect.c; src/sect.cc) ---- */
+/* per-position coverage of one sequence: counts[i] (and gcs[i], may be NULL; -1 = invalid window) for i in [0, n-k] */
+void ko_profile(const ko_table* t, int canonical, const char* seq, size_t n, uint64_t* counts, int16_t* gcs);
+/* the whole tool; flags: 1 no_count_stats, 2 output_gc_stats, 4 extract_nr, 8 extract_r, 16 cvg_logscale, 32 save() */
+int ko_sect(const ko_table* t, int canonical, const char* seq_path, const char* prefix, uint32_t gc_bins, uint32_t cvg_bins,
+            unsigned flags, uint32_t min_repeat, uint32_t max_repeat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,8 @@ def lib():
     if _LIB is not None:
         return _LIB
     so = os.path.join(_HERE, "libkoracle.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "koracle.c")):
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, f))
+                                     for f in ("koracle.c", "koracle_sect.c", "koracle.h")):
         build()
     L = C.CDLL(so)
     L.ko_table_new.restype = C.c_void_p
@@ -70,6 +71,8 @@ def lib():
     L.ko_write_comp_main.argtypes = [C.c_char_p, C.c_uint, cpp, C.c_size_t, cpp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p]
     L.ko_write_comp_stats.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.ko_write_comp_hist.argtypes = [C.c_char_p, C.c_uint, cpp, C.c_size_t, C.c_void_p, C.c_uint32]
+    L.ko_profile.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ko_sect.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint, C.c_uint32, C.c_uint32]
     _LIB = L
     return L
 
@@ -280,3 +283,27 @@ def write_comp3(prefix, k, paths1, paths2, paths3, d1_bins, d2_bins, mxs, cc, sp
         m = np.ascontiguousarray(mxs[which + 1], np.uint64)
         L.ko_write_comp_extra(os.fsencode(prefix + name), which, os.fsencode(paths1[0]), os.fsencode(paths2[0]), os.fsencode(paths3[0]),
                               d1_bins, d2_bins, m.ctypes.data)
+
+
+def profile(table, seq, canonical=None):
+    """Per-position coverage of one sequence (src/sect.cc:516-535): (counts u64[n-k+1], gc i16[n-k+1], -1 = invalid)."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    n = max(0, len(seq) - table.k + 1)
+    counts = np.zeros(n, dtype=np.uint64)
+    gcs = np.zeros(n, dtype=np.int16)
+    if n:
+        lib().ko_profile(table.h, int(table.canonical if canonical is None else canonical), seq, len(seq),
+                         counts.ctypes.data, gcs.ctypes.data)
+    return counts, gcs
+
+
+def sect(table, seq_path, prefix, canonical=None, gc_bins=1001, cvg_bins=1001, no_count_stats=False, output_gc_stats=False,
+         extract_nr=False, extract_r=False, cvg_logscale=False, min_repeat=2, max_repeat=0, save=False):
+    """`kat sect` end to end: writes <prefix>-counts.cvg, -stats.tsv (+ optional files; save=True adds -contamination.mx)."""
+    flags = (1 if no_count_stats else 0) | (2 if output_gc_stats else 0) | (4 if extract_nr else 0) | (8 if extract_r else 0) | \
+        (16 if cvg_logscale else 0) | (32 if save else 0)
+    rc = lib().ko_sect(table.h, int(table.canonical if canonical is None else canonical), os.fsencode(seq_path), os.fsencode(prefix),
+                       gc_bins, cvg_bins, flags, min_repeat, max_repeat)
+    if rc:
+        raise OracleError(rc)

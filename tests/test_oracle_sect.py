@@ -1,0 +1,109 @@
+"""`kat sect` in the C oracle (oracle/koracle_sect.c) against the independent pure-Python statement in tests/naive.py, on
+the reference's own sect inputs (tests/data/sect_test.fa, sect_length_test.fa, used by tests/test_sect.sh) and on generated
+edge cases.  The reference holds no golden sect outputs, so this cross-check is what pins the restatement."""
+import gzip
+import os
+import random
+
+import pytest
+
+from tests import naive
+
+
+def oracle_files(ko, table, seq_path, tmp_path, tag, **kw):
+    prefix = str(tmp_path / tag)
+    ko.sect(table, seq_path, prefix, **kw)
+    out = {}
+    for suffix in ("-counts.cvg", "-counts.gc", "-non_repetitive.fa", "-repetitive.fa", "-stats.tsv", "-contamination.mx"):
+        if os.path.exists(prefix + suffix):
+            out[suffix] = open(prefix + suffix, "rb").read()
+    return out
+
+
+def counts_of(ko, table):
+    keys, cnts = table.dump_sorted()
+    return {ko.decode(int(k), table.k): int(c) for k, c in zip(keys, cnts)}
+
+
+def test_reference_cli_case(ko, refdata, tmp_path):
+    """tests/test_sect.sh: sect_length_test.fa against ecoli.header.jf27 (k = 27, canonical)."""
+    t = ko.Table.from_jf(os.path.join(refdata, "ecoli.header.jf27"))
+    counts = counts_of(ko, t)
+    for name in ("sect_length_test.fa", "sect_test.fa"):
+        p = os.path.join(refdata, name)
+        want = naive.sect(counts, 27, True, p, output_gc_stats=True, extract_nr=True, extract_r=True, save=True)
+        got = oracle_files(ko, t, p, tmp_path, name, output_gc_stats=True, extract_nr=True, extract_r=True, save=True)
+        assert got == want
+    # every sect_test.fa record is shorter than k = 27 or barely longer: the short-record branch and the uint32 wrap of kmers_in_seq
+    stats = want["-stats.tsv"].decode().splitlines()
+    assert stats[2].split("\t")[4:6] == ["13", str(2**32 + 13 - 27 + 1)]
+
+
+@pytest.mark.parametrize("k,canonical", [(5, True), (5, False), (11, True), (31, True)])
+def test_self_coverage(ko, refdata, tmp_path, k, canonical):
+    """Hash counted from the sequence file itself: non-trivial counts, repeats, N runs."""
+    p = os.path.join(refdata, "sect_test.fa")
+    t = ko.Table(k, canonical).count_files([p])
+    counts = counts_of(ko, t)
+    for kw in (dict(), dict(output_gc_stats=True, extract_nr=True, extract_r=True), dict(no_count_stats=True, extract_r=True, min_repeat=1, max_repeat=2),
+               dict(extract_nr=True, min_repeat=3, gc_bins=10, cvg_bins=4, save=True)):
+        want = naive.sect(counts, k, canonical, p, **kw)
+        got = oracle_files(ko, t, p, tmp_path, "s%d%d%d" % (k, canonical, len(kw)), **kw)
+        assert got == want
+
+
+def make_cases(tmp_path):
+    rng = random.Random(7)
+    unit = "".join(rng.choice("ACGT") for _ in range(40))
+    recs = [("r0 plain description", unit * 3), ("lower", unit.lower() + "acgtnnnnACGT" + unit), ("allN", "N" * 30), ("empty", ""),
+            ("short", "ACG"), ("odd chars", unit[:20] + "RYK-*" + unit[20:] + " " + unit), ("gc", "GC" * 25), ("at>", "AT" * 25)]
+    fa = tmp_path / "cases.fa"
+    with open(fa, "w") as f:
+        for name, seq in recs:
+            f.write(">" + name + "\n")
+            for i in range(0, len(seq), 17):
+                f.write(seq[i:i + 17] + "\n")
+        f.write("\n\n")
+    crlf = tmp_path / "crlf.fasta"
+    crlf.write_bytes(b"junk before the first record\r\n" + fa.read_bytes().replace(b"\n", b"\r\n"))
+    fq = tmp_path / "reads.fq"
+    with open(fq, "w") as f:
+        for i in range(6):
+            s = unit[i:i + 30] + ("N" if i % 2 else "") + unit[:10]
+            f.write("@read%d/1\n%s\n+read%d/1\n%s\n" % (i, s, i, "@" * len(s)))      # '@' qualities must not start a record
+    gz = tmp_path / "cases.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(fa.read_bytes())
+    sniffed = tmp_path / "noext.seq"
+    sniffed.write_bytes(fa.read_bytes())
+    return [str(fa), str(crlf), str(fq), str(gz), str(sniffed)], str(fa)
+
+
+def test_generated_edge_cases(ko, tmp_path):
+    paths, fa = make_cases(tmp_path)
+    for k, canonical in ((7, True), (21, False)):
+        t = ko.Table(k, canonical).count_files([fa])
+        counts = counts_of(ko, t)
+        for i, p in enumerate(paths):
+            kw = dict(output_gc_stats=True, extract_nr=True, extract_r=True, min_repeat=2, max_repeat=5, save=True)
+            want = naive.sect(counts, k, canonical, p, **kw)
+            got = oracle_files(ko, t, p, tmp_path, "g%d%d" % (k, i), **kw)
+            assert got == want, p
+    # '>' inside a sequence line ends the record there (SeqAn reads to the next '>' wherever it stands)
+    assert [n for n, _ in naive.seqan_records(fa)][-1] == b"at>"
+    assert b"-nan" in want["-stats.tsv"]          # the all-N and empty records: 0/0 GC%
+
+
+def test_reader_errors(ko, tmp_path):
+    t = ko.Table(5, True)
+    bad = tmp_path / "x.fa"
+    bad.write_bytes(b"no record marker here\n")
+    with pytest.raises(ko.OracleError):
+        ko.sect(t, str(bad), str(tmp_path / "o"))
+    with pytest.raises(ValueError):
+        naive.seqan_records(str(bad))
+    empty = tmp_path / "e.fa"
+    empty.write_bytes(b"")
+    ko.sect(t, str(empty), str(tmp_path / "e"))
+    assert (tmp_path / "e-stats.tsv").read_bytes().count(b"\n") == 1
+    assert (tmp_path / "e-counts.cvg").read_bytes() == b""
