@@ -48,6 +48,7 @@ struct katgpu_ctx {
     uint8_t* arena = nullptr;
     size_t arena_bytes = 0;
     bool part_attr_set = false;
+    bool arena_busy = false;              // a partition round is using it: pool_alloc must not free it to satisfy a table growth
     bool arena_borrowed = false;          // katgpu_scratch_acquire handed the arena out: it must not be freed behind the caller's back
     int count_blocks_per_cu = 6;
 };
@@ -246,10 +247,11 @@ static hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes) {
         return hipSuccess;
     }
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && (!c->pool.empty() || (c->arena && !c->arena_borrowed))) {    // give cached scratch back and retry once
+    const bool arena_free = c->arena && !c->arena_borrowed && !c->arena_busy;
+    if (e != hipSuccess && (!c->pool.empty() || arena_free)) {    // give cached scratch back and retry once
         (void)hipGetLastError();
         pool_trim(c);
-        if (c->arena && !c->arena_borrowed) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+        if (arena_free) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
         e = hipMalloc(p, bytes);
     }
     *got_bytes = bytes;
@@ -468,6 +470,61 @@ static bool part_geometry(const DevTable& d, PartGeom* g) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+static const bool g_test_grow_nomem = getenv("KATGPU_TEST_GROW_NOMEM") != nullptr;   // tests: table growth "fails" while the arena is busy
+
+static void release_arena(katgpu_ctx* c) {
+    if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+    c->arena_busy = false;
+}
+
+// Growth while a partition call holds the arena.  First with the arena protected; when the device cannot hold the old
+// table, the new one and the arena at once, `stash` (spilled keys that live in the arena, may be null) is parked in host
+// memory, the arena is given up, the growth retried and the keys re-inserted from the host.  *arena_lost tells the
+// caller that its carve of the arena is gone.
+static int grow_beside_arena(katgpu_table* t, uint64_t incoming, uint64_t min_cap, const uint64_t* stash, uint64_t n_stash, bool* arena_lost) {
+    katgpu_ctx* c = t->ctx;
+    auto grow = [&]() -> int {
+        if (min_cap > t->d.cap) {
+            if (t->disable_grow) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
+            uint64_t nc = t->d.cap; while (nc < min_cap) nc *= 2;
+            return regrow(t, nc);
+        }
+        return ensure_room(t, incoming);
+    };
+    *arena_lost = false;
+    int rc = g_test_grow_nomem ? KATGPU_ERR_NOMEM : grow();
+    if (rc != KATGPU_ERR_NOMEM) return rc;
+    (void)hipGetLastError();
+    std::vector<uint64_t> host;
+    if (n_stash) {
+        try { host.resize(n_stash); } catch (...) { return fail(c, KATGPU_ERR_NOMEM, "no host memory to park %llu spilled k-mers", (unsigned long long)n_stash); }
+        HIPCHK(c, hipMemcpy(host.data(), stash, n_stash * 8, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    release_arena(c);
+    *arena_lost = true;
+    if (g_trace) fprintf(stderr, "[katgpu] growth beside the partition arena failed: arena released, %llu keys parked on the host\n", (unsigned long long)n_stash);
+    rc = grow();
+    if (rc) return rc;
+    if (n_stash) {
+        const size_t chunk = std::min<size_t>(n_stash, (size_t)32 << 20);
+        uint64_t* d = nullptr;
+        HIPCHK(c, pool_alloc(c, (void**)&d, chunk * 8));
+        for (size_t i = 0; i < n_stash && rc == KATGPU_OK; i += chunk) {
+            const size_t m = std::min(chunk, (size_t)n_stash - i);
+            rc = maybe_sweep(t, m);
+            if (rc) break;
+            t->unchecked_adds += m;
+            if (hipMemcpyAsync(d, host.data() + i, m * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(c, KATGPU_ERR_DEVICE, "spill upload"); break; }
+            ScopedTimer tm(c, KATGPU_K_COUNT, m);
+            hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, m, 256, 6)), dim3(256), 0, c->stream, t->d, (const uint64_t*)d, (uint64_t)m);
+            if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, KATGPU_ERR_DEVICE, "spill insert");
+        }
+        pool_release(c, d);
+    }
+    return rc;
+}
+
 // Count a resident, 16-byte aligned base stream through partition rounds.  *done = number of window starts consumed
 // (all of them unless the geometry stops fitting, in which case the caller finishes with the direct kernel).
 static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n, size_t* done) {
@@ -476,6 +533,13 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const size_t n_starts = n - k + 1;
     *done = 0;
     c->arena_borrowed = false;                    // a borrowed arena is only promised until the next count call
+    // A table hopelessly small for this input (KAT's default -H against a whole run) would spill nearly every k-mer of the
+    // first round: give it room for 1/16 of the starts first -- cheap while it is still small, and before the arena exists.
+    if (!g_test_round_items && !t->disable_grow && t->d.cap < n_starts / 16) {
+        uint64_t nc = t->d.cap; while (nc < n_starts / 16) nc *= 2;
+        int grc = regrow(t, nc);
+        if (grc) return grc;
+    }
     const bool p1v2 = g_p1_wgs > 0;
     const uint32_t W = (uint32_t)c->n_cu * (p1v2 ? std::min<uint32_t>(g_p1_wgs, 4) : 1);      // level-1 workgroups (rows of hist1 / offs)
     const uint32_t W2 = (uint32_t)c->n_cu;                                                      // level-2 / apply: one per CU
@@ -510,6 +574,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             c->arena_bytes = bytes;
         }
     }
+    struct Busy { katgpu_ctx* c; explicit Busy(katgpu_ctx* c_) : c(c_) { c->arena_busy = true; } ~Busy() { c->arena_busy = false; } } busy(c);
     uint8_t* a = c->arena;
     uint32_t* hist1 = (uint32_t*)a;               a += align_up((size_t)W * MAX_PARTS * 4, 256);
     uint64_t* offs = (uint64_t*)a;                a += align_up((size_t)W * MAX_PARTS * 8, 256);
@@ -530,9 +595,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         int rc = refresh_counters(t);
         if (rc) return rc;
         if ((double)t->distinct > 0.6 * (double)t->d.cap) {
-            if (t->disable_grow) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
-            rc = regrow(t, t->d.cap * 2);
+            bool lost = false;
+            rc = grow_beside_arena(t, 0, t->d.cap * 2, nullptr, 0, &lost);
             if (rc) return rc;
+            if (lost) break;                                                      // the caller re-enters with a fresh arena
         }
         PartGeom g;
         if (!part_geometry(t->d, &g)) break;                                      // table too large for two levels: direct path
@@ -607,8 +673,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (spilled) {                         // regions that ran out of slots: make room, then the direct path
-                rc = ensure_room(t, spilled);
+                bool lost = false;
+                rc = grow_beside_arena(t, spilled, 0, l1_buf, spilled, &lost);
                 if (rc) return rc;
+                if (lost) { pos += m; break; }     // the spill went in from the host; the caller re-enters for the rest
                 rc = maybe_sweep(t, spilled);
                 if (rc) return rc;
                 t->unchecked_adds += spilled;
@@ -634,11 +702,12 @@ extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bas
     const size_t n_starts = n - k + 1;
     // Large, aligned inputs go through the partitioned counter (no global atomic per k-mer); whatever it leaves (nothing,
     // normally) and everything small goes through the direct kernel below.
-    if (n_starts >= g_part_min_starts && (reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0) {
-        size_t done = 0;
-        int prc = count_partitioned(t, dev_bases, n, &done);
+    while (n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
+        size_t done = 0;                        // returns early (done < remaining) when a table growth cost it the arena
+        int prc = count_partitioned(t, dev_bases + pos, n - pos, &done);
         if (prc) return prc;
-        pos = done;
+        if (!done) break;
+        pos += done;
     }
     while (pos < n_starts) {
         int rc = refresh_counters(t);
