@@ -293,6 +293,37 @@ private:
     Matrix64 contamination_mx;
 };
 
+// src/cold.hpp
+class Cold {
+public:
+    Cold(const std::vector<std::string>& reads_files, const std::string& asm_file);
+    void setOutputPrefix(const std::string& p) { outputPrefix = p; }
+    void setReadsTrim(const std::vector<uint16_t>& t) { reads.set5pTrim(t); }
+    void setCvgBins(uint16_t b) { cvgBins = b; }
+    void setGcBins(uint16_t b) { gcBins = b; }
+    void setThreads(uint16_t t) { threads = t; }
+    void setHashSize(uint64_t h) { reads.hashSize = h; assembly.hashSize = h / 2; }         // src/cold.hpp:151-154
+    void setMerLen(uint8_t m) { reads.merLen = m; assembly.merLen = m; }                    // uint8_t, src/cold.hpp:160-163
+    uint8_t getMerLen() const { return (uint8_t)reads.merLen; }
+    bool dumpHashes() const { return reads.dumpHash; }
+    void setDumpHashes(bool d) { reads.dumpHash = d; assembly.dumpHash = d; }
+    void setDisableHashGrow(bool d) { reads.disableHashGrow = d; }                          // src/cold.hpp:178-180
+    void setVerbose(bool v) { verbose = v; }
+    void execute();
+    static int main(int argc, char* argv[]);
+private:
+    struct Row {
+        uint32_t median = 0, asmCn = 0, length = 0, invalid = 0, nonZero = 0;
+        double mean = 0.0, gc = 0.0, percentInvalid = 0.0, percentNonZero = 0.0, percentNonZeroCorrected = 0.0;
+    };
+    void processSeqFile();
+    void processSeq(Row& r, const std::string& seq, const uint64_t* readsCounts, const uint64_t* asmCounts);
+    InputHandler reads, assembly;
+    std::string outputPrefix;
+    uint16_t gcBins = 1001, cvgBins = 1001, threads = 1;
+    bool verbose = false;
+};
+
 // ---- command-line helper shared by the three tools (stands in for boost::program_options) ----
 struct OptSpec { const char* lng; char sht; bool takes_value; };
 struct ParsedArgs {

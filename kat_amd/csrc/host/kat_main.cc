@@ -1,4 +1,4 @@
-// kat_main.cc -- `katgpu hist|gcp|comp|sect ...`: the dispatcher for the KAT modes on the path, with KAT's exit codes
+// kat_main.cc -- `katgpu hist|gcp|comp|sect|cold ...`: the dispatcher for the KAT modes on the path, with KAT's exit codes
 // (src/kat.cc:178-305: option errors 1, KAT/boost exceptions 4, std::exception 5, const char* 6, anything else 7).
 #include "kat_host.hpp"
 
@@ -6,7 +6,7 @@
 #include <iostream>
 
 static void usage() {
-    std::cout << "The K-mer Analysis Toolkit, MI355X engine (katgpu): hist | gcp | comp | sect\n"
+    std::cout << "The K-mer Analysis Toolkit, MI355X engine (katgpu): hist | gcp | comp | sect | cold\n"
                  "Usage: katgpu <mode> [options] <inputs>   (same options as `kat <mode>`; see INTEGRATION.md)\n";
 }
 
@@ -19,7 +19,8 @@ int main(int argc, char* argv[]) {
         else if (mode == "gcp") rc = kat::Gcp::main(argc - 1, argv + 1);
         else if (mode == "comp") rc = kat::Comp::main(argc - 1, argv + 1);
         else if (mode == "sect") rc = kat::Sect::main(argc - 1, argv + 1);
-        else throw kat::OptionError("Could not recognise mode string: " + mode + " (this build carries hist, gcp, comp and sect)");
+        else if (mode == "cold") rc = kat::Cold::main(argc - 1, argv + 1);
+        else throw kat::OptionError("Could not recognise mode string: " + mode + " (this build carries hist, gcp, comp, sect and cold)");
     } catch (kat::OptionError& e) {
         std::cerr << "Error: Parsing Command Line: " << e.what() << std::endl;
         rc = 1;

@@ -406,4 +406,162 @@ int Sect::main(int argc, char* argv[]) {                                        
     return 0;
 }
 
+// ================================================================ Cold (src/cold.cc) ==============================
+// Every record of the assembly profiled against the reads hash and against the assembly's own hash: two
+// katgpu_table_profile_host calls per batch, one -stats.tsv row per record.
+
+Cold::Cold(const vector<string>& reads_files, const string& asm_file) {                          // src/cold.cc:67-77
+    reads.setMultipleInputs(reads_files);
+    reads.index = 1;
+    assembly.setSingleInput(asm_file);
+    assembly.index = 1;                                                                         // sic: both inputs are "Input 1"
+    outputPrefix = "kat-cold";
+}
+
+void Cold::execute() {                                                                           // src/cold.cc:80-122
+    reads.validateInput();
+    assembly.validateInput();
+    ensureDirectoryExists(parentOfAbsolute(outputPrefix));
+    // Cold never sets InputHandler::canonical (lib/include/kat/input_handler.hpp:48 defaults it to false): counted hashes
+    // are non-canonical and probed as such; a loaded .jf brings its own flag.
+    if (reads.mode == InputHandler::COUNT) reads.count(threads);
+    else { reads.loadHeader(); reads.loadHash(); }
+    if (assembly.mode == InputHandler::COUNT) assembly.count(threads);
+    else { assembly.loadHeader(); assembly.loadHash(); }
+    processSeqFile();
+    if (dumpHashes()) {
+        reads.dump(outputPrefix + "-reads_hash.jf" + std::to_string(reads.merLen), threads);
+        assembly.dump(outputPrefix + "-asm_hash.jf" + std::to_string(assembly.merLen), threads);
+    }
+}
+
+void Cold::processSeq(Row& r, const string& seq, const uint64_t* readsCounts, const uint64_t* asmCounts) {   // src/cold.cc:303-408
+    const uint16_t k = reads.merLen;
+    const uint64_t seqLength = seq.size();
+    const int64_t nbCounts = (int64_t)seqLength - k + 1;
+    const size_t nb = nbCounts > 0 ? (size_t)nbCounts : 0;
+    uint64_t nbNonZero = 0, nbInvalid = 0;
+    r.median = 0; r.mean = 0.0; r.asmCn = 0;
+    if (nb) {
+        uint32_t bad = 0;
+        uint64_t sum = 0;
+        for (size_t i = 0; i < seqLength; i++) {                     // rolling validKmer: invalid windows count for neither sum nor nonZero
+            bad += !isBase(seq[i]);
+            if (i >= k) bad -= !isBase(seq[i - k]);
+            if (i + 1 >= k) {
+                const size_t w = i + 1 - k;
+                if (bad) nbInvalid++;
+                else { sum += readsCounts[w]; if (readsCounts[w]) nbNonZero++; }
+            }
+        }
+        vector<uint64_t> sorted(readsCounts, readsCounts + nb);
+        std::nth_element(sorted.begin(), sorted.begin() + nb / 2, sorted.end());
+        r.median = (uint32_t)(double)sorted[nb / 2];
+        r.mean = (double)sum / (double)nbCounts;
+        sorted.assign(asmCounts, asmCounts + nb);
+        std::nth_element(sorted.begin(), sorted.begin() + nb / 2, sorted.end());
+        r.asmCn = (uint32_t)(double)sorted[nb / 2];
+    }
+    r.length = (uint32_t)seqLength;
+    r.nonZero = (uint32_t)nbNonZero;
+    r.percentNonZero = nbNonZero == 0 || nbCounts <= 0 ? 0.0 : ((double)nbNonZero / (double)nbCounts) * 100.0;
+    r.invalid = (uint32_t)nbInvalid;
+    r.percentInvalid = nbInvalid == 0 || nbCounts <= 0 ? 0.0 : ((double)nbInvalid / (double)nbCounts) * 100.0;
+    const uint64_t notInvalid = (uint64_t)nbCounts - nbInvalid;
+    r.percentNonZeroCorrected = nbNonZero == 0 || notInvalid <= 0 ? 0.0 : ((double)nbNonZero / (double)notInvalid) * 100.0;
+    uint64_t gs = 0, cs = 0, ns = 0;
+    for (char c : seq) {
+        if (c == 'G' || c == 'g') gs++;
+        else if (c == 'C' || c == 'c') cs++;
+        else if (c == 'N' || c == 'n') ns++;
+    }
+    volatile double num = (double)(gs + cs), den = (double)(seqLength - ns);
+    r.gc = num / den;
+}
+
+void Cold::processSeqFile() {                                                                    // src/cold.cc:126-200
+    PhaseTimer timer;
+    cout << "Calculating kmer coverage across sequences ...";
+    cout.flush();
+    SeqRecordReader reader(assembly.pathString());
+    if (verbose) std::cerr << endl;
+    std::ofstream cvg_gc_stream((outputPrefix + "-stats.tsv").c_str());
+    cvg_gc_stream << "seq_name\tread_median_cvg\tread_mean_cvg\tasm_cn\tgc%\tseq_length\tkmers_in_seq\tinvalid_kmers\t%_invalid\tnon_zero_kmers\t%_non_zero\t%_non_zero_corrected" << endl;
+
+    const size_t BATCH_BASES = (size_t)64 << 20;
+    vector<string> names, seqs;
+    vector<Row> rows;
+    string joined;
+    vector<uint64_t> rcounts, acounts;
+    vector<size_t> offs;
+    while (!reader.atEnd()) {
+        if (verbose) std::cerr << "Loading Batch of sequences... ";
+        names.clear(); seqs.clear();
+        size_t bases = 0;
+        while (!reader.atEnd() && bases < BATCH_BASES) {
+            names.emplace_back(); seqs.emplace_back();
+            reader.readRecord(names.back(), seqs.back());
+            bases += seqs.back().size() + 1;
+        }
+        const size_t n = names.size();
+        if (verbose) std::cerr << "Loaded " << n << " records.  Processing batch... ";
+        joined.clear(); joined.reserve(bases);
+        offs.assign(n, 0);
+        for (size_t i = 0; i < n; i++) { offs[i] = joined.size(); joined += seqs[i]; joined += '\n'; }
+        if (rcounts.size() < joined.size()) { rcounts.resize(joined.size()); acounts.resize(joined.size()); }
+        Engine::check(katgpu_table_profile_host(reads.hash, joined.data(), joined.size(), reads.canonical ? 1 : 0, rcounts.data()));
+        Engine::check(katgpu_table_profile_host(assembly.hash, joined.data(), joined.size(), assembly.canonical ? 1 : 0, acounts.data()));
+
+        rows.assign(n, Row());
+        const unsigned workers = std::max<unsigned>(1, std::min<unsigned>(threads, (unsigned)n));
+        auto work = [&](unsigned th) { for (size_t i = th; i < n; i += workers) processSeq(rows[i], seqs[i], rcounts.data() + offs[i], acounts.data() + offs[i]); };
+        if (workers == 1) work(0);
+        else {
+            vector<std::thread> team;
+            for (unsigned th = 0; th < workers; th++) team.emplace_back(work, th);
+            for (auto& t : team) t.join();
+        }
+        char line[512];
+        for (size_t i = 0; i < n; i++) {                                                        // printStatTable, src/cold.cc:254-271
+            const Row& r = rows[i];
+            snprintf(line, sizeof line, "\t%u\t%.5f\t%u\t%.5f\t%u\t%u\t%u\t%.5f\t%u\t%.5f\t%.5f\n", r.median, r.mean, r.asmCn, r.gc, r.length,
+                     (uint32_t)(r.length - assembly.merLen + 1), r.invalid, r.percentInvalid, r.nonZero, r.percentNonZero, r.percentNonZeroCorrected);
+            cvg_gc_stream << names[i] << line;
+        }
+        if (verbose) std::cerr << "done" << endl;
+    }
+    cout << " done.";
+    cout.flush();
+}
+
+int Cold::main(int argc, char* argv[]) {                                                         // src/cold.cc:436-546
+    static const vector<OptSpec> spec = {
+        {"output_prefix", 'o', true}, {"gc_bins", 'x', true}, {"cvg_bins", 'y', true}, {"threads", 't', true}, {"5ptrim", 0, true},
+        {"mer_len", 'm', true}, {"hash_size", 'H', true}, {"dump_hashes", 'd', false}, {"disable_hash_grow", 'g', false},
+        {"output_type", 'p', true}, {"verbose", 'v', false}, {"help", 0, false}};
+    ParsedArgs pa = parseArgs(argc, argv, spec);
+    if (pa.has("help") || argc <= 1) {
+        cout << "Usage: kat cold [options] <assembly> (<reads>)+\n\nCalculates median read k-mer coverage, assembly k-mer coverage and GC% across each sequence in the provided assembly.\n" << endl;
+        return 1;
+    }
+    vector<uint16_t> trim = parseTrimList(pa.get("5ptrim", "0"));
+    PhaseTimer total("KAT CoLD completed.\nTotal runtime: %.1fs\n\n");
+    cout << "Running KAT in Cold mode" << endl << "------------------------" << endl << endl;
+    string asm_file = pa.positional.empty() ? string() : pa.positional[0];                      // p.add("asm_file", 1); p.add("reads_files", -1)
+    vector<string> reads_files(pa.positional.begin() + (pa.positional.empty() ? 0 : 1), pa.positional.end());
+    Cold cold(reads_files, asm_file);
+    cold.setOutputPrefix(pa.get("output_prefix", "kat-cold"));
+    cold.setGcBins((uint16_t)std::stoul(pa.get("gc_bins", "1001")));
+    cold.setCvgBins((uint16_t)std::stoul(pa.get("cvg_bins", "1001")));
+    cold.setThreads((uint16_t)std::stoul(pa.get("threads", "1")));
+    cold.setReadsTrim(trim);
+    cold.setMerLen((uint8_t)std::stoul(pa.get("mer_len", std::to_string(DEFAULT_MER_LEN))));   // uint8_t setter, src/cold.hpp:160
+    cold.setHashSize(std::stoull(pa.get("hash_size", std::to_string(DEFAULT_HASH_SIZE))));
+    cold.setDumpHashes(pa.has("dump_hashes"));
+    cold.setVerbose(pa.has("verbose"));
+    // --disable_hash_grow is parsed and never applied in the reference's main (src/cold.cc:525-535)
+    cold.execute();         // cold.plot() needs the Python plotting package: out of scope
+    return 0;
+}
+
 }  // namespace kat

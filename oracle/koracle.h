@@ -115,6 +115,8 @@ double ko_distance(int which, const uint64_t* s1, const uint64_t* s2, size_t n);
 /* per-position coverage of one sequence: counts[i] (and gcs[i], may be NULL; -1 = invalid window) for i in [0, n-k] */
 void ko_profile(const ko_table* t, int canonical, const char* seq, size_t n, uint64_t* counts, int16_t* gcs);
 /* the whole tool; flags: 1 no_count_stats, 2 output_gc_stats, 4 extract_nr, 8 extract_r, 16 cvg_logscale, 32 save() */
+/* `kat cold` (src/cold.cc): <prefix>-stats.tsv for every record of the assembly file */
+int ko_cold(const ko_table* reads, int canon_reads, const ko_table* assembly, int canon_asm, const char* asm_path, const char* prefix);
 int ko_sect(const ko_table* t, int canonical, const char* seq_path, const char* prefix, uint32_t gc_bins, uint32_t cvg_bins,
             unsigned flags, uint32_t min_repeat, uint32_t max_repeat);
 

@@ -73,6 +73,7 @@ def lib():
     L.ko_write_comp_hist.argtypes = [C.c_char_p, C.c_uint, cpp, C.c_size_t, C.c_void_p, C.c_uint32]
     L.ko_profile.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ko_sect.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint, C.c_uint32, C.c_uint32]
+    L.ko_cold.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p]
     _LIB = L
     return L
 
@@ -305,5 +306,13 @@ def sect(table, seq_path, prefix, canonical=None, gc_bins=1001, cvg_bins=1001, n
         (16 if cvg_logscale else 0) | (32 if save else 0)
     rc = lib().ko_sect(table.h, int(table.canonical if canonical is None else canonical), os.fsencode(seq_path), os.fsencode(prefix),
                        gc_bins, cvg_bins, flags, min_repeat, max_repeat)
+    if rc:
+        raise OracleError(rc)
+
+
+def cold(reads, assembly, asm_path, prefix, canon_reads=None, canon_asm=None):
+    """`kat cold`: writes <prefix>-stats.tsv (Cold never sets InputHandler::canonical, so counted hashes are non-canonical)."""
+    rc = lib().ko_cold(reads.h, int(reads.canonical if canon_reads is None else canon_reads),
+                       assembly.h, int(assembly.canonical if canon_asm is None else canon_asm), os.fsencode(asm_path), os.fsencode(prefix))
     if rc:
         raise OracleError(rc)

@@ -169,6 +169,63 @@ static void print_regions(FILE* out, const record_t* r, const uint64_t* counts, 
     free(ss.p);
 }
 
+/* `kat cold` (Cold::processSeqFile + processSeq + printStatTable, src/cold.cc:126-408, 254-271): every record of the
+ * assembly file profiled against the reads hash and the assembly's own hash; one -stats.tsv row per record. */
+int ko_cold(const ko_table* reads, int canon_reads, const ko_table* assembly, int canon_asm, const char* asm_path, const char* prefix) {
+    const unsigned k = ko_table_k(reads);
+    char* data; size_t n;
+    int rc = slurp_gz(asm_path, &data, &n);
+    if (rc) return rc;
+    int fmt = guess_format(asm_path, data, n);
+    if (fmt < 0) { free(data); return KO_ERR_FORMAT; }
+    char path[4096];
+    snprintf(path, sizeof path, "%s-stats.tsv", prefix);
+    FILE* f = fopen(path, "w");
+    if (!f) { free(data); return KO_ERR_IO; }
+    fprintf(f, "seq_name\tread_median_cvg\tread_mean_cvg\tasm_cn\tgc%%\tseq_length\tkmers_in_seq\tinvalid_kmers\t%%_invalid\tnon_zero_kmers\t%%_non_zero\t%%_non_zero_corrected\n");
+    record_t r; memset(&r, 0, sizeof r);
+    uint64_t *rc_counts = NULL, *as_counts = NULL; int16_t* gcs = NULL; size_t cap = 0;
+    size_t pos = 0;
+    while (pos < n) {
+        pos = read_record(data, n, pos, fmt, &r);
+        if (pos == (size_t)-1) { rc = KO_ERR_FORMAT; break; }
+        const uint64_t seq_len = r.seq.n;
+        const int64_t nb_counts = (int64_t)seq_len - (int64_t)k + 1;
+        const size_t nb = nb_counts > 0 ? (size_t)nb_counts : 0;
+        uint64_t nb_nonzero = 0, nb_invalid = 0;
+        uint32_t median = 0, asm_cn = 0; double mean = 0.0;
+        if (nb) {
+            if (nb > cap) { cap = nb; rc_counts = realloc(rc_counts, cap * 8); as_counts = realloc(as_counts, cap * 8); gcs = realloc(gcs, cap * 2); }
+            ko_profile(reads, canon_reads, r.seq.p, r.seq.n, rc_counts, gcs);
+            ko_profile(assembly, canon_asm, r.seq.p, r.seq.n, as_counts, NULL);
+            uint64_t sum = 0;
+            for (size_t i = 0; i < nb; i++) { if (gcs[i] < 0) nb_invalid++; else { sum += rc_counts[i]; if (rc_counts[i]) nb_nonzero++; } }
+            qsort(rc_counts, nb, 8, cmp_u64);
+            qsort(as_counts, nb, 8, cmp_u64);
+            median = (uint32_t)(double)rc_counts[nb / 2];
+            asm_cn = (uint32_t)(double)as_counts[nb / 2];
+            mean = (double)sum / (double)nb_counts;
+        }
+        const double pct_nonzero = nb_nonzero == 0 || nb_counts <= 0 ? 0.0 : ((double)nb_nonzero / (double)nb_counts) * 100.0;
+        const double pct_invalid = nb_invalid == 0 || nb_counts <= 0 ? 0.0 : ((double)nb_invalid / (double)nb_counts) * 100.0;
+        const uint64_t not_invalid = (uint64_t)nb_counts - nb_invalid;
+        const double pct_nz_corr = nb_nonzero == 0 || not_invalid == 0 ? 0.0 : ((double)nb_nonzero / (double)not_invalid) * 100.0;
+        uint64_t gs = 0, cs = 0, ns = 0;
+        for (uint64_t i = 0; i < seq_len; i++) {
+            char c = r.seq.p[i];
+            if (c == 'G' || c == 'g') gs++; else if (c == 'C' || c == 'c') cs++; else if (c == 'N' || c == 'n') ns++;
+        }
+        volatile double num = (double)(gs + cs), den = (double)(seq_len - ns);
+        const double gc_perc = num / den;
+        put_name(f, &r.name);
+        fprintf(f, "\t%u\t%.5f\t%u\t%.5f\t%u\t%u\t%u\t%.5f\t%u\t%.5f\t%.5f\n", median, mean, asm_cn, gc_perc, (uint32_t)seq_len,
+                (uint32_t)((uint32_t)seq_len - k + 1), (uint32_t)nb_invalid, pct_invalid, (uint32_t)nb_nonzero, pct_nonzero, pct_nz_corr);
+    }
+    fclose(f);
+    free(rc_counts); free(as_counts); free(gcs); free(r.name.p); free(r.seq.p); free(data);
+    return rc;
+}
+
 /* `kat sect` end to end (Sect::execute + save, src/sect.cc:86-143).  flags: bit0 no_count_stats, bit1 output_gc_stats,
  * bit2 extract_nr, bit3 extract_r, bit4 cvg_logscale, bit5 also Sect::save() (the contamination matrix). */
 int ko_sect(const ko_table* t, int canonical, const char* seq_path, const char* prefix, uint32_t gc_bins, uint32_t cvg_bins,

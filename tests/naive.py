@@ -235,3 +235,37 @@ def sect(counts, k, canonical, seq_path, gc_bins=1001, cvg_bins=1001, output_gc_
         head += "# Columns:%d\n# Rows:%d\n# MaxVal:%d\n# Transpose:0\n###\n" % (gc_bins, cvg_bins, max(max(r) for r in mx))
         files["-contamination.mx"] = (head + "".join(" ".join(map(str, r)) + "\n" for r in mx)).encode()
     return files
+
+
+def cold(reads, canon_reads, asm, canon_asm, k, asm_path):
+    """`kat cold` (src/cold.cc): the bytes of <prefix>-stats.tsv.  reads / asm map upper-case k-mers to counts."""
+    out = [b"seq_name\tread_median_cvg\tread_mean_cvg\tasm_cn\tgc%\tseq_length\tkmers_in_seq\tinvalid_kmers\t%_invalid\tnon_zero_kmers\t%_non_zero\t%_non_zero_corrected\n"]
+    for name, seq in seqan_records(asm_path):
+        s = seq.decode("latin-1")
+        L = len(s)
+        nb = L - k + 1
+        rs, as_, invalid = [], [], 0
+        for i in range(max(nb, 0)):
+            w = s[i:i + k]
+            if any(ch not in "ACGTacgt" for ch in w):
+                rs.append(0)
+                as_.append(0)
+                invalid += 1
+                continue
+            u = w.upper()
+            rs.append(reads.get(min(u, revcomp(u)) if canon_reads else u, 0))
+            as_.append(asm.get(min(u, revcomp(u)) if canon_asm else u, 0))
+        nonzero = sum(1 for c in rs if c)
+        median = _u32(sorted(rs)[len(rs) // 2]) if rs else 0
+        asm_cn = _u32(sorted(as_)[len(as_) // 2]) if as_ else 0
+        mean = sum(rs) / nb if rs else 0.0
+        p_nz = 0.0 if nonzero == 0 or nb <= 0 else nonzero / nb * 100.0
+        p_inv = 0.0 if invalid == 0 or nb <= 0 else invalid / nb * 100.0
+        not_invalid = (nb - invalid) & 0xFFFFFFFFFFFFFFFF
+        p_nzc = 0.0 if nonzero == 0 or not_invalid == 0 else nonzero / not_invalid * 100.0
+        g_ = sum(ch in "GgCc" for ch in s)
+        n_ = sum(ch in "Nn" for ch in s)
+        gc = g_ / (L - n_) if L - n_ else float("nan")
+        out.append(name + ("\t%d\t%s\t%d\t%s\t%d\t%d\t%d\t%s\t%d\t%s\t%s\n" % (median, _f5(mean), asm_cn, _f5(gc), _u32(L), _u32(_u32(L) - k + 1),
+                                                                                 _u32(invalid), _f5(p_inv), _u32(nonzero), _f5(p_nz), _f5(p_nzc))).encode())
+    return b"".join(out)

@@ -144,4 +144,4 @@ def test_cli_exit_codes(refdata, tmp_path):
     assert r.returncode == 5 and "Unsupported format" in r.stderr
     r = run(["comp", "-m", "27", "-g", "-H", "1000", os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "sect_test.fa")], tmp_path)
     assert r.returncode == 5 and "Hash full" in r.stderr
-    assert run(["cold", "x"], tmp_path).returncode == 1                          # a mode this build does not carry
+    assert run(["filter", "x"], tmp_path).returncode == 1                        # a mode this build does not carry

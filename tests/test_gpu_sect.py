@@ -140,3 +140,23 @@ def test_sect_cli_errors(refdata, tmp_path):
     r = run(["sect", "-o", "x", str(bad), jf], tmp_path)
     assert r.returncode == 5 and "Unexpected end of input." in r.stderr
     assert run(["sect"], tmp_path).returncode == 1
+
+
+def test_cold_cli(ko, refdata, tmp_path):
+    """`katgpu cold <assembly> <reads>+`: -stats.tsv byte for byte; counted hashes are non-canonical (Cold never sets the flag)."""
+    paths, fa = make_cases(tmp_path)
+    r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
+    for k, asm_path, reads in ((7, fa, [r1, paths[2]]), (27, paths[3], [r1, r2]), (21, os.path.join(refdata, "sect_length_test.fa"), [fa])):
+        r = run(["cold", "-m", str(k), "-H", "100000", "-t", "2", "-o", "c%d" % k, asm_path] + reads, tmp_path)
+        assert r.returncode == 0, r.stderr
+        assert "Running KAT in Cold mode" in r.stdout and "KAT CoLD completed." in r.stdout
+        ko.cold(ko.Table(k, False).count_files(reads), ko.Table(k, False).count_files([asm_path]), asm_path, str(tmp_path / ("w%d" % k)))
+        assert (tmp_path / ("c%d-stats.tsv" % k)).read_bytes() == (tmp_path / ("w%d-stats.tsv" % k)).read_bytes()
+    # a loaded .jf brings its own canonical flag (reads side), and -d dumps both hashes
+    jf = os.path.join(refdata, "ecoli.header.jf27")
+    asm_path = os.path.join(refdata, "sect_length_test.fa")
+    r = run(["cold", "-o", "cj", "-d", asm_path, jf], tmp_path)
+    assert r.returncode == 0, r.stderr
+    ko.cold(ko.Table.from_jf(jf), ko.Table(27, False).count_files([asm_path]), asm_path, str(tmp_path / "wj"))
+    assert (tmp_path / "cj-stats.tsv").read_bytes() == (tmp_path / "wj-stats.tsv").read_bytes()
+    assert os.path.islink(tmp_path / "cj-reads_hash.jf27") and os.path.getsize(tmp_path / "cj-asm_hash.jf27") > 0

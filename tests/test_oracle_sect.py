@@ -107,3 +107,16 @@ def test_reader_errors(ko, tmp_path):
     ko.sect(t, str(empty), str(tmp_path / "e"))
     assert (tmp_path / "e-stats.tsv").read_bytes().count(b"\n") == 1
     assert (tmp_path / "e-counts.cvg").read_bytes() == b""
+
+
+def test_cold_oracle_vs_naive(ko, refdata, tmp_path):
+    """`kat cold`: reads hash + assembly hash, both non-canonical when counted (Cold never sets InputHandler::canonical)."""
+    paths, fa = make_cases(tmp_path)
+    r1 = os.path.join(refdata, "ecoli_r1.1K.fastq")
+    for k, cr, ca in ((7, False, False), (15, True, False), (27, False, True)):
+        reads = ko.Table(k, cr).count_files([r1, paths[2]])
+        asm = ko.Table(k, ca).count_files([fa, os.path.join(refdata, "sect_test.fa")])
+        for p in (paths[0], paths[1], paths[3], os.path.join(refdata, "sect_test.fa")):
+            ko.cold(reads, asm, p, str(tmp_path / "c"))
+            want = naive.cold(counts_of(ko, reads), cr, counts_of(ko, asm), ca, k, p)
+            assert (tmp_path / "c-stats.tsv").read_bytes() == want
