@@ -60,8 +60,9 @@ def main():
         a.gpus = world
 
     if world > 1:
-        # leave room next to the partition arena for the owner tables of the exchange (must be set before the library loads)
-        os.environ.setdefault("KATGPU_ARENA_FRACTION", "0.5")
+        # the exchange keeps its send list and receive buffers inside the arena and allocates nothing else; leave room for the
+        # second table, RCCL's channel buffers and the small per-region count matrices (must be set before the library loads)
+        os.environ.setdefault("KATGPU_ARENA_FRACTION", "0.75")
     import torch
     import kat_amd
     from kat_amd import dist as kdist
@@ -124,12 +125,10 @@ def main():
         t2.count_bases_device(asm_ptr, asm_bytes)
         tp = mark("alloc2+count_asm", tp)
         if world > 1:
-            s1, s2 = kdist.HipShard(t1), kdist.HipShard(t2)
-            o1 = kdist.exchange_merge(s1)
-            t1.free()
-            o2 = kdist.exchange_merge(s2, grid_of=o1)
-            t2.free()
-            t1, t2 = o1.table, o2.table
+            # in place: each table is extracted into a region-ordered send list, emptied, and refilled with the k-mers this
+            # rank owns (kat_amd/dist.py); t2 keeps t1's region grid, so comp still joins region against region
+            kdist.exchange_merge(kdist.HipShard(t1))
+            kdist.exchange_merge(kdist.HipShard(t2))
             tp = mark("exchange", tp)
         mx, cc, sp = kat_amd.comp(t1, t2)
         tp = mark("comp", tp)

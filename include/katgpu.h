@@ -164,6 +164,31 @@ int katgpu_table_partition(katgpu_table* t, uint32_t n_parts, const uint64_t* of
 int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_keys, const uint64_t* dev_counts, size_t n);
 int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, const uint64_t* counts, size_t n);
 
+/* ---- region-ordered exchange (multi-GPU; no counterpart in KAT, which merges per-thread results in one address space:
+ *      ThreadedSparseMatrix::mergeThreadedMatricies lib/include/kat/sparse_matrix.hpp:325-335, Histogram::merge
+ *      src/histogram.cc:146-160) ----
+ * Ranks that count into tables of the same region grid (p1, p2) hold a k-mer in the same region index.  The sender extracts
+ * its records grouped by owner and, within an owner, ordered by region; the owner applies the runs of each region in LDS. */
+typedef struct { uint32_t k, canonical, n_regions, region_slots, p1, p2; uint64_t capacity; } katgpu_geometry;
+int katgpu_table_geometry(const katgpu_table* t, katgpu_geometry* g);
+/* pass 1: dev_region_counts[p * n_regions + g] (device, u32) = records of region g owned by part p (owner = hash of the canonical
+ * k-mer, the rule of katgpu_table_partition); part_sizes[p] (host) = records owned by part p.  n_parts <= 256. */
+int katgpu_table_extract_sizes(katgpu_table* t, uint32_t n_parts, uint32_t* dev_region_counts, uint64_t* part_sizes);
+/* pass 2: the records.  Part p starts at sum(part_sizes[0..p)); inside a part records are ordered by region.  Counts are 32 bit:
+ * a k-mer whose count does not fit (and the all-ones k-mer, which has no slot) is returned in the host arrays big_keys /
+ * big_counts (*n_big entries, at most big_cap; 4200 always suffices) and its record, if any, carries count 0. */
+int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint64_t* dev_keys, uint32_t* dev_counts,
+                         uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big);
+/* empty the table, keeping its storage and its region grid (the extracted table becomes the owner table) */
+int katgpu_table_clear(katgpu_table* t);
+/* add records with 32-bit counts (count 0 = skip) through the direct path */
+int katgpu_table_merge_device32(katgpu_table* t, const uint64_t* dev_keys, const uint32_t* dev_counts, size_t n);
+/* Owner side.  Source i holds n_records records of the sender's regions [g_lo, g_hi) in region order (dev_region_counts: u32 per
+ * region, NULL if unknown); p1 / p2 name the grid the sender ordered them by.  Sources of this table's grid are applied region
+ * by region in LDS, the others through the direct path.  Exact either way. */
+typedef struct { const uint64_t* dev_keys; const uint32_t* dev_counts; const uint32_t* dev_region_counts; uint64_t n_records; uint32_t p1, p2; } katgpu_merge_source;
+int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source* src);
+
 /* ---- measurement ------------------------------------------------------------------------------------- */
 /* HIP-event timing of the kernels this ctx launched, per kernel class, accumulated since the last reset. */
 typedef enum katgpu_kernel {

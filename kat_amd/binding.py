@@ -26,11 +26,25 @@ EXPORTS = (
     "katgpu_table_canonical", "katgpu_table_get", "katgpu_table_profile_host", "katgpu_table_profile_device",
     "katgpu_table_export", "katgpu_hist", "katgpu_gcp",
     "katgpu_comp", "katgpu_comp3", "katgpu_table_partition_sizes", "katgpu_table_partition", "katgpu_table_merge_device",
-    "katgpu_table_merge_host", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
+    "katgpu_table_merge_host", "katgpu_table_geometry", "katgpu_table_extract_sizes", "katgpu_table_extract", "katgpu_table_clear",
+    "katgpu_table_merge_device32", "katgpu_table_merge_regions", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
     "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_free_host",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
 )
+
+
+class Geometry(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("canonical", C.c_uint32), ("n_regions", C.c_uint32), ("region_slots", C.c_uint32),
+                ("p1", C.c_uint32), ("p2", C.c_uint32), ("capacity", C.c_uint64)]
+
+
+class MergeSource(C.Structure):
+    _fields_ = [("dev_keys", C.c_void_p), ("dev_counts", C.c_void_p), ("dev_region_counts", C.c_void_p), ("n_records", C.c_uint64),
+                ("p1", C.c_uint32), ("p2", C.c_uint32)]
+
+
+BIG_CAP = 4200          # side-table entries + the all-ones key: what katgpu_table_extract can return out of band
 
 
 class KatGpuError(RuntimeError):
@@ -90,6 +104,12 @@ def load_library():
     L.katgpu_table_partition.argtypes = [vp, u32, vp, vp, vp]
     L.katgpu_table_merge_device.argtypes = [vp, vp, vp, sz]
     L.katgpu_table_merge_host.argtypes = [vp, vp, vp, sz]
+    L.katgpu_table_geometry.argtypes = [vp, vp]
+    L.katgpu_table_extract_sizes.argtypes = [vp, u32, vp, vp]
+    L.katgpu_table_extract.argtypes = [vp, u32, vp, vp, vp, vp, vp, u32, C.POINTER(u32)]
+    L.katgpu_table_clear.argtypes = [vp]
+    L.katgpu_table_merge_device32.argtypes = [vp, vp, vp, sz]
+    L.katgpu_table_merge_regions.argtypes = [vp, u32, u32, u32, vp]
     L.katgpu_profile_reset.argtypes = [vp]
     L.katgpu_profile_get.argtypes = [vp, C.c_int, pu64, C.POINTER(C.c_double), pu64]
     L.katgpu_dev_alloc.argtypes = [vp, sz, pp]
@@ -240,7 +260,9 @@ class Engine:
         (`torch.as_tensor(obj, device="cuda")` through __cuda_array_interface__)."""
         p, got = C.c_void_p(), C.c_size_t()
         self._chk(self.L.katgpu_scratch_acquire(self.h, int(nbytes), C.byref(p), C.byref(got)))
-        return ScratchView(p.value, int(nbytes))
+        v = ScratchView(p.value, int(nbytes))
+        v.capacity = int(got.value)             # what the arena holds (>= nbytes): the caller may size itself to it
+        return v
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
@@ -420,6 +442,37 @@ class Table:
 
     def merge_device(self, dev_keys_ptr, dev_counts_ptr, n):
         self.engine._chk(self.engine.L.katgpu_table_merge_device(self.h, dev_keys_ptr, dev_counts_ptr, n))
+
+    # region-ordered exchange (dist.py)
+    def geometry(self):
+        g = Geometry()
+        self.engine._chk(self.engine.L.katgpu_table_geometry(self.h, C.byref(g)))
+        return g
+
+    def extract_sizes(self, n_parts, dev_region_counts_ptr):
+        sizes = np.zeros(n_parts, np.uint64)
+        self.engine._chk(self.engine.L.katgpu_table_extract_sizes(self.h, n_parts, dev_region_counts_ptr, sizes.ctypes.data))
+        return sizes
+
+    def extract(self, n_parts, dev_region_counts_ptr, dev_keys_ptr, dev_counts_ptr):
+        """Returns the out-of-band records (counts above 32 bits, the all-ones k-mer) as (keys, counts) uint64 arrays."""
+        bk, bc, nb = np.zeros(BIG_CAP, np.uint64), np.zeros(BIG_CAP, np.uint64), C.c_uint32()
+        self.engine._chk(self.engine.L.katgpu_table_extract(self.h, n_parts, dev_region_counts_ptr, dev_keys_ptr, dev_counts_ptr,
+                                                            bk.ctypes.data, bc.ctypes.data, BIG_CAP, C.byref(nb)))
+        return bk[:nb.value].copy(), bc[:nb.value].copy()
+
+    def clear(self):
+        self.engine._chk(self.engine.L.katgpu_table_clear(self.h))
+
+    def merge_device32(self, dev_keys_ptr, dev_counts_ptr, n):
+        self.engine._chk(self.engine.L.katgpu_table_merge_device32(self.h, dev_keys_ptr, dev_counts_ptr, n))
+
+    def merge_regions(self, g_lo, g_hi, sources):
+        """sources: (dev_keys_ptr, dev_counts_ptr, dev_region_counts_ptr or None, n_records, p1, p2) per sender."""
+        arr = (MergeSource * len(sources))()
+        for i, (k, c, r, n, p1, p2) in enumerate(sources):
+            arr[i] = MergeSource(k, c, r, n, p1, p2)
+        self.engine._chk(self.engine.L.katgpu_table_merge_regions(self.h, g_lo, g_hi, len(sources), C.cast(arr, C.c_void_p)))
 
     def merge_host(self, keys, counts):
         k = np.ascontiguousarray(keys, np.uint64)

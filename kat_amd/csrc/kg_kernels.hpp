@@ -603,6 +603,171 @@ k_partition(DevTable t, uint32_t n_ovf, uint32_t n_parts, unsigned long long* __
     }
 }
 
+// ---- region-ordered extraction and merge: the multi-GPU exchange (kat_amd/dist.py) ----
+// Every rank counts into a table of the same region grid, so the records of one region of one rank belong to the same
+// region of the owner's table.  Extraction walks the table region by region and writes each owner's records in region
+// order; the owner then applies, per region, the runs it received from every rank to that region in LDS -- no
+// global atomic per record and no re-partitioning on the receiving side.
+constexpr int EXTRACT_BLOCK = 256;
+constexpr uint32_t MAX_EXCHANGE_PARTS = 256;
+constexpr int MAX_MERGE_SRC = 16;
+
+// pass 1: rcnt[p * R + g] = number of records of region g owned by part p.  One workgroup per region.
+__global__ void __launch_bounds__(EXTRACT_BLOCK)
+k_extract_count(DevTable t, uint32_t n_parts, uint32_t* __restrict__ rcnt) {
+    __shared__ uint32_t s_cnt[MAX_EXCHANGE_PARTS];
+    const uint32_t tid = threadIdx.x, S = t.region_slots;
+    for (uint32_t g = blockIdx.x; g < t.n_regions; g += gridDim.x) {
+        for (uint32_t p = tid; p < n_parts; p += EXTRACT_BLOCK) s_cnt[p] = 0;
+        __syncthreads();
+        const uint64_t base = (uint64_t)g * S;
+        for (uint32_t i = tid; i < S; i += EXTRACT_BLOCK) {
+            const uint64_t key = t.keys[base + i];
+            if (key != EMPTY) atomicAdd(&s_cnt[n_parts > 1 ? owner_of(key, t.k, n_parts) : 0], 1u);
+        }
+        __syncthreads();
+        for (uint32_t p = tid; p < n_parts; p += EXTRACT_BLOCK) rcnt[(uint64_t)p * t.n_regions + g] = s_cnt[p];
+        __syncthreads();
+    }
+}
+
+// Exclusive scan of each row of a u32 matrix into u64 (row_base[r] added when given); one workgroup per row.
+// off may be null (totals only); off rows have n_cols + 1 entries when `closed` (the last one is the row total).
+__global__ void __launch_bounds__(1024)
+k_rows_scan(const uint32_t* __restrict__ m, uint32_t n_cols, uint64_t row_stride, const uint64_t* __restrict__ row_base,
+            uint64_t* __restrict__ off, uint64_t off_stride, int closed, unsigned long long* __restrict__ totals) {
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_run;
+    const uint32_t r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t* row = m + (uint64_t)r * row_stride;
+    if (tid == 0) s_run = row_base ? row_base[r] : 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_cols; c0 += 1024) {
+        const uint32_t c = c0 + tid;
+        const uint64_t v = c < n_cols ? row[c] : 0;
+        uint64_t x = v;                                            // inclusive scan within the wave
+        for (int d = 1; d < 64; d <<= 1) { uint64_t y = __shfl_up(x, d, 64); if ((int)lane >= d) x += y; }
+        if (lane == 63) s_wave[w] = x;
+        __syncthreads();
+        uint64_t before = s_run;
+        for (uint32_t q = 0; q < w; ++q) before += s_wave[q];
+        if (off && c < n_cols) off[(uint64_t)r * off_stride + c] = before + x - v;
+        __syncthreads();
+        if (tid == 1023) s_run = before + x;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (off && closed) off[(uint64_t)r * off_stride + n_cols] = s_run;
+        if (totals) totals[r] = s_run - (row_base ? row_base[r] : 0);
+    }
+}
+
+// pass 2: write the records.  off[p * R + g] = global index of the first record of (part p, region g).  Counts that do
+// not fit 32 bits travel in the `big` list (their record carries count 0, which a merge skips).
+__global__ void __launch_bounds__(EXTRACT_BLOCK)
+k_extract_write(DevTable t, uint32_t n_ovf, uint32_t n_parts, const uint64_t* __restrict__ off, uint64_t* __restrict__ out_keys,
+                uint32_t* __restrict__ out_counts, uint64_t* __restrict__ big_keys, uint64_t* __restrict__ big_counts,
+                unsigned long long* __restrict__ big_n, uint32_t big_cap) {
+    __shared__ uint32_t s_cur[MAX_EXCHANGE_PARTS];
+    const uint32_t tid = threadIdx.x, S = t.region_slots;
+    for (uint32_t g = blockIdx.x; g < t.n_regions; g += gridDim.x) {
+        for (uint32_t p = tid; p < n_parts; p += EXTRACT_BLOCK) s_cur[p] = 0;
+        __syncthreads();
+        const uint64_t base = (uint64_t)g * S;
+        for (uint32_t i = tid; i < S; i += EXTRACT_BLOCK) {
+            const uint64_t key = t.keys[base + i];
+            if (key == EMPTY) continue;
+            const uint32_t p = n_parts > 1 ? owner_of(key, t.k, n_parts) : 0;
+            const uint64_t at = off[(uint64_t)p * t.n_regions + g] + atomicAdd(&s_cur[p], 1u);
+            uint64_t c = slot_count(t, base + i, key, n_ovf);
+            if (c > 0xFFFFFFFFULL) {
+                const unsigned long long b = atomicAdd(big_n, 1ULL);
+                if (b < big_cap) { big_keys[b] = key; big_counts[b] = c; }
+                c = 0;
+            }
+            out_keys[at] = key;
+            out_counts[at] = (uint32_t)c;
+        }
+        __syncthreads();
+    }
+}
+
+struct MergeSrc { const uint64_t* keys; const uint32_t* counts; const uint64_t* off; };   // off: u64[regions + 1], relative to keys / counts
+struct MergeSrcs { MergeSrc s[MAX_MERGE_SRC]; uint32_t n; };
+
+// Owner side: regions [g_lo, g_hi).  LDS: keys[S] (u64) | counts[S] (u32), the protocol of k_p3_apply with arbitrary
+// 32-bit amounts.  A region that could overflow (occupied + incoming > S) is not touched: its index goes to `deferred`
+// and the host sends its runs through the direct path after making room.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t* __restrict__ deferred, unsigned long long* __restrict__ n_deferred) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ uint32_t s_occ;
+    unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
+    uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)t.region_slots * 8);
+    const uint32_t tid = threadIdx.x, S = t.region_slots;
+    uint32_t new_distinct = 0;
+    for (uint32_t g = g_lo + blockIdx.x; g < g_hi; g += gridDim.x) {
+        const uint32_t j = g - g_lo;
+        uint64_t incoming = 0;
+        for (uint32_t s = 0; s < srcs.n; ++s) incoming += srcs.s[s].off[j + 1] - srcs.s[s].off[j];
+        if (incoming == 0) continue;                                             // uniform over the workgroup
+        if (tid == 0) s_occ = 0;
+        __syncthreads();
+        const uint64_t base = (uint64_t)g * S;
+        uint32_t occ = 0;
+        for (uint32_t i = tid; i < S; i += BLOCK) {
+            const uint64_t key = t.keys[base + i];
+            rk[i] = key; rc[i] = t.counts[base + i];
+            occ += key != EMPTY;
+        }
+        for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
+        if ((tid & 63) == 0 && occ) atomicAdd(&s_occ, occ);
+        __syncthreads();
+        if ((uint64_t)s_occ + incoming > S) {                                    // uniform
+            if (tid == 0) deferred[atomicAdd(n_deferred, 1ULL)] = g;
+            __syncthreads();
+            continue;
+        }
+        for (uint32_t s = 0; s < srcs.n; ++s) {
+            const uint64_t beg = srcs.s[s].off[j], end = srcs.s[s].off[j + 1];
+            for (uint64_t i = beg + tid; i < end; i += BLOCK) {
+                const uint32_t c = srcs.s[s].counts[i];
+                if (!c) continue;
+                const unsigned long long key = srcs.s[s].keys[i];
+                uint32_t slot = offset_of_hash(mix64(key), S);
+                for (uint32_t probe = 0; probe < S; ++probe) {                   // cannot fail: occupied + incoming <= S
+                    unsigned long long cur = rk[slot];
+                    if (cur == EMPTY) {
+                        cur = atomicCAS(&rk[slot], (unsigned long long)EMPTY, key);
+                        if (cur == EMPTY) { ++new_distinct; cur = key; }
+                    }
+                    if (cur == key) {
+                        const uint32_t old = atomicAdd(&rc[slot], c);
+                        if ((uint32_t)(old + c) < old) ovf_add(t, key, 1ULL << 32);
+                        break;
+                    }
+                    slot = slot + 1 == S ? 0 : slot + 1;
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
+        __syncthreads();
+    }
+    flush_distinct(t, new_distinct);
+}
+
+// records with 32-bit counts through the direct path (sources of another grid, deferred regions)
+__global__ void __launch_bounds__(256)
+k_merge32(DevTable dst, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, uint64_t n) {
+    uint32_t new_distinct = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (counts[i]) table_add(dst, keys[i], (uint64_t)counts[i], new_distinct);
+    flush_distinct(dst, new_distinct);
+}
+
 // ---- synthetic workload (bench / tests), bit-identical to kat_amd/synth.py ----
 __device__ __forceinline__ uint32_t genome_code(uint64_t seed, uint64_t i) {
     return (uint32_t)(rng2(seed, i >> 5) >> (2 * (i & 31))) & 3;

@@ -17,37 +17,67 @@ from kat_amd import synth
 
 
 class OracleShard:
-    """Same duck type as kat_amd.dist.HipShard, backed by the CPU oracle table."""
+    """Same duck type as kat_amd.dist.HipShard, backed by the CPU oracle table.  Its "region grid" is R buckets of a hash
+    of the k-mer, so the region-ordered protocol (per-region counts, chunks of consecutive regions, runs per region) is
+    exercised and CHECKED here: merge_chunk asserts that every aligned source really is ordered the way it claims."""
 
-    def __init__(self, table):
+    def __init__(self, table, n_regions=8):
         self.table = table
         self.device = torch.device("cpu")
+        self.R = n_regions
+        self.chunks_seen = 0
 
-    def new_like(self, size_hint, grid_of=None):
-        from oracle import koracle as ko
-        return OracleShard(ko.Table(self.table.k, self.table.canonical))
+    def _region(self, keys):
+        return (kdist._mix64(keys) % np.uint64(self.R)).astype(np.int64)
 
-    def _records_by_part(self, n_parts):
+    def geometry(self):
+        return np.array([self.table.k, int(self.table.canonical), self.R, 1 << 20, self.R, 1], dtype=np.int64)
+
+    def begin_exchange(self, n_parts):
         keys, counts = self.table.dump_sorted()
         part = kdist.owner_of(keys, self.table.k, n_parts)
-        order = np.argsort(part, kind="stable")
-        return keys[order], counts[order], np.bincount(part, minlength=n_parts).astype(np.int64)
+        reg = self._region(keys)
+        order = np.lexsort((keys, reg, part))                    # by owner, then region
+        self._rec = (keys[order], counts[order])
+        cnt = np.zeros((n_parts, self.R), np.int32)
+        np.add.at(cnt, (part, reg), 1)
+        return cnt.sum(1).astype(np.int64), torch.from_numpy(cnt)
 
-    def partition_sizes(self, n_parts):
-        return self._records_by_part(n_parts)[2]
+    def exchange_buffers(self, total_send, set_records):
+        mk = lambda n, dt: torch.empty(max(int(n), 1), dtype=dt)
+        return {"send_keys": mk(total_send, torch.int64), "send_counts": mk(total_send, torch.int32),
+                "recv": [(mk(set_records, torch.int64), mk(set_records, torch.int32)) for _ in range(2)]}
 
-    def partition_into(self, n_parts, sizes):
-        keys, counts, s = self._records_by_part(n_parts)
-        assert np.array_equal(s, sizes)
-        return torch.from_numpy(keys.view(np.int64).copy()), torch.from_numpy(counts.view(np.int64).copy())
+    def extract(self, n_parts, bufs):
+        keys, counts = self._rec
+        big = counts > np.uint64(0xFFFFFFFF)
+        c32 = np.where(big, 0, counts).astype(np.uint32)
+        bufs["send_keys"][:keys.size] = torch.from_numpy(keys.view(np.int64).copy())
+        bufs["send_counts"][:keys.size] = torch.from_numpy(c32.view(np.int32).copy())
+        return keys[big], counts[big]
 
-    def merge_from(self, keys, counts, n):
-        kk, cc = keys.numpy().view(np.uint64), counts.numpy().view(np.uint64)
-        for i in range(int(n)):
-            self.table.add(int(kk[i]), int(cc[i]))
+    def clear(self):
+        from oracle import koracle as ko
+        self.table = ko.Table(self.table.k, self.table.canonical)
 
-    def empty_like(self, n):
-        return torch.empty(max(n, 1), dtype=torch.int64), torch.empty(max(n, 1), dtype=torch.int64)
+    def merge_chunk(self, g_lo, g_hi, sources, set_index):
+        self.chunks_seen += 1
+        for s in sources:
+            n = int(s["n"])
+            kk = s["keys"][:n].numpy().view(np.uint64)
+            cc = s["counts"][:n].numpy().view(np.uint32)
+            if s["rcnt"] is not None:                             # an aligned source: runs per region, in region order
+                assert (int(s["p1"]), int(s["p2"])) == (self.R, 1)
+                r = s["rcnt"].numpy().astype(np.int64)
+                assert r.size == g_hi - g_lo and int(r.sum()) == n
+                assert np.array_equal(self._region(kk), np.repeat(np.arange(g_lo, g_hi), r))
+            for i in range(n):
+                if cc[i]:
+                    self.table.add(int(kk[i]), int(cc[i]))
+
+    def merge_big(self, keys, counts):
+        for k_, c_ in zip(keys, counts):
+            self.table.add(int(k_), int(c_))
 
 
 def _free_port():
@@ -61,7 +91,7 @@ def _free_port():
 K, G, N_READS, CONTIG = 21, 40000, 3000, 5000
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mixed_grids):
     from oracle import koracle as ko
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -74,8 +104,12 @@ def _worker(rank, world, port, out_dir):
     asm = synth.stream_of_contigs(g[c_lo * CONTIG:c_hi * CONTIG], CONTIG)
     t1 = ko.Table(K, True).count_bases(reads)
     t2 = ko.Table(K, True).count_bases(asm)
-    o1 = kdist.exchange_merge(OracleShard(t1)).table
-    o2 = kdist.exchange_merge(OracleShard(t2)).table
+    t1.add(ko.encode("ACGT" * 5 + "A"), (1 << 33) + rank)                 # a count above 32 bits travels out of band
+    regions = 8 if not (mixed_grids and rank == 1) else 5                  # mixed: rank 1's table has another grid
+    s1 = kdist.exchange_merge(OracleShard(t1, regions), min_chunks=3)
+    s2 = kdist.exchange_merge(OracleShard(t2, regions), min_chunks=1)
+    assert s1.chunks_seen == 3 and s2.chunks_seen == 1
+    o1, o2 = s1.table, s2.table
     # every key this rank now owns really is its own
     keys, _ = o1.dump_sorted()
     assert (kdist.owner_of(keys, K, world) == rank).all()
@@ -89,12 +123,14 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_exchange_matches_single_process(ko, tmp_path):
+@pytest.mark.parametrize("mixed_grids", [False, True])
+def test_two_rank_exchange_matches_single_process(ko, tmp_path, mixed_grids):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mixed_grids), nprocs=world, join=True)
     got = np.load(tmp_path / "sharded.npz")
     g = synth.genome(G, seed=11)
     t1 = ko.Table(K, True).count_bases(synth.reads(g, 0, N_READS, seed=1))
+    t1.add(ko.encode("ACGT" * 5 + "A"), (1 << 34) + 1)                     # both ranks' out-of-band amounts
     t2 = ko.Table(K, True).count_bases(synth.stream_of_contigs(g, CONTIG))
     mx, cc, sp = ko.comp(t1, t2, 1.0, 1.0, 101, 101)
     assert np.array_equal(got["mx"], mx) and np.array_equal(got["cc"], cc) and np.array_equal(got["sp"], sp)
