@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="sync + print per-phase wall time (diagnostic; perturbs the timing)")
     ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: diagnostic only -- ranks may share one GPU, records are staged through host memory")
     return ap.parse_args()
 
 
@@ -67,12 +69,18 @@ def main():
     import kat_amd
     from kat_amd import dist as kdist
 
+    staged = a.dist_backend == "gloo"
+    if staged:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if staged:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = kat_amd.Engine(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if staged else torch.device("cuda", local_rank)      # where collective tensors live
 
     def barrier():
         eng.sync()
@@ -127,8 +135,9 @@ def main():
         if world > 1:
             # in place: each table is extracted into a region-ordered send list, emptied, and refilled with the k-mers this
             # rank owns (kat_amd/dist.py); t2 keeps t1's region grid, so comp still joins region against region
-            kdist.exchange_merge(kdist.HipShard(t1))
-            kdist.exchange_merge(kdist.HipShard(t2))
+            results["distinct1_local"] = t1.stats(want_total=False)["distinct"]
+            kdist.exchange_merge(kdist.HipShard(t1, staged=staged))
+            kdist.exchange_merge(kdist.HipShard(t2, staged=staged))
             tp = mark("exchange", tp)
         mx, cc, sp = kat_amd.comp(t1, t2)
         tp = mark("comp", tp)
@@ -173,7 +182,7 @@ def main():
         # algorithmic bytes: per instance L/(L-k+1) B of ASCII + 8 B key read + 4 B count read + 4 B count
         # write, plus 8 B key write per distinct k-mer; summed over this rank's count work of the timed steps.
         per_inst = L / (L - k + 1) + 16.0
-        d1_local = results["distinct1"] / world
+        d1_local = results.get("distinct1_local", results["distinct1"])          # what THIS rank's count stage wrote
         alg_bytes_step = per_inst * (inst_reads + inst_asm) + 8.0 * (d1_local + max(inst_asm, 0))
         stage = ["part_l1_count", "part_l1_scatter", "part_l2", "part_apply"]
         part_ms = sum(prof[n]["ms"] for n in stage)
