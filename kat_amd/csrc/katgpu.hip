@@ -460,6 +460,7 @@ static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? s
 // share of the free HBM the partition arena may take (multi-GPU runs leave room for the owner tables: bench.py sets 0.5)
 static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::min(0.95, std::max(0.05, atof(getenv("KATGPU_ARENA_FRACTION")))) : 0.85;
 static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10) : 3;   // 0 = first edition (1024-thread, 1 per CU)
+static const uint32_t g_apply_batch = getenv("KATGPU_APPLY_BATCH") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BATCH"), nullptr, 10) : 4;
 static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 1024;
 static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 
@@ -551,6 +552,9 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -662,10 +666,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 const uint32_t blk = g_apply_block;
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
-#define KG_APPLY(B, N) hipLaunchKernelGGL((k_p3_apply<B, N>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod)
+#define KG_APPLY(B, ...) hipLaunchKernelGGL((k_p3_apply<B, __VA_ARGS__>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod)
                 const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
                 if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
-                else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) KG_APPLY(1024, 8); else KG_APPLY(1024, 12); }
+                else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) { if (g_apply_batch == 8) KG_APPLY(1024, 8, 8); else if (g_apply_batch == 12) KG_APPLY(1024, 8, 12); else if (g_apply_batch == 16) KG_APPLY(1024, 8, 16); else KG_APPLY(1024, 8); }
+                       else KG_APPLY(1024, 12); }
 #undef KG_APPLY
             }
             HIPCHK(c, hipGetLastError());

@@ -497,7 +497,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 // SPT = slots per lane held in registers while a region is prefetched (region_slots <= SPT * BLOCK).
 // Software pipeline: while region r's run is applied in LDS, region r' (the workgroup's next one) is already on its way
 // from HBM into registers, and r's write-back drains behind it -- the CU's memory pipe stays busy through the LDS phase.
-template <int BLOCK, int SPT>
+template <int BLOCK, int SPT, int BATCH = 4>
 __global__ void __launch_bounds__(BLOCK)
 k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
            uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod) {
@@ -507,7 +507,6 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
     const uint32_t tid = threadIdx.x, S = g.S;
     uint32_t new_distinct = 0;
     uint64_t kk[SPT]; uint32_t cc[SPT];
-    constexpr int BATCH = 4;                                      // k-mers of the run in flight per lane (registers are the limit)
 
     auto next_region = [&](uint32_t from) {                       // first region >= from (stride gridDim) that received k-mers
         uint32_t r = from;
@@ -530,36 +529,60 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
         lds_barrier();
         const uint32_t rn = next_region(r + gridDim.x);
         bool prefetched = false;
+        // Each lane walks ITS k-mers of the batch on its own: a lane that has placed one k-mer starts probing for its next
+        // while its neighbours are still on longer probe chains.  (With a per-k-mer loop the wave waits for the longest of
+        // 64 chains for every k-mer -- about 10 probes at load 0.6 -- and this LDS-latency-bound loop ran at a fifth of the
+        // speed; the lane-independent walk waits once, for the largest SUM of BATCH chains.)  The next batch is already on
+        // its way from HBM.
+        unsigned long long cur[BATCH], nxt[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) { const uint64_t i = beg + (uint64_t)u * BLOCK + tid; cur[u] = i < end ? l2_buf[i] : EMPTY; }
         for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)BATCH * BLOCK) {
-          unsigned long long batch[BATCH];
+          const uint64_t i1 = i0 + (uint64_t)BATCH * BLOCK;
 #pragma unroll
-          for (int u = 0; u < BATCH; ++u) { const uint64_t i = i0 + (uint64_t)u * BLOCK + tid; batch[u] = i < end ? l2_buf[i] : EMPTY; }
-          if (!prefetched) { if (rn < g.R) prefetch(rn); prefetched = true; }     // issued AFTER the first batch: its wait does not cover these
+          for (int u = 0; u < BATCH; ++u) { const uint64_t i = i1 + (uint64_t)u * BLOCK + tid; nxt[u] = i < end ? l2_buf[i] : EMPTY; }
+          if (!prefetched) { if (rn < g.R) prefetch(rn); prefetched = true; }     // issued AFTER the first batches: their wait does not cover these
+          uint32_t nv = 0;                                                          // this lane's k-mers in the batch (EMPTY only pads the tail)
 #pragma unroll
-          for (int u = 0; u < BATCH; ++u) {
-            const uint64_t i = i0 + (uint64_t)u * BLOCK + tid;
-            const unsigned long long key = batch[u];
-            if (key == EMPTY) continue;
-            uint32_t s = offset_of_hash(mix64(key), S);
-            bool done = false;
-            const bool force_spill = spill_mod && (i % spill_mod) == 0;                        // test hook: exercise the spill path
-            for (uint32_t probe = 0; probe < S && !force_spill; ++probe) {
-                unsigned long long cur = rk[s];
-                if (cur == EMPTY) {
-                    cur = atomicCAS(&rk[s], (unsigned long long)EMPTY, key);
-                    if (cur == EMPTY) { ++new_distinct; cur = key; }
-                }
-                if (cur == key) {
-                    // LDS returning add: a 32-bit wrap is seen right here and chained into the side table, so a round may
-                    // carry any number of copies of one k-mer and needs no host-side overflow guard
-                    if (atomicAdd(&rc[s], 1u) == 0xFFFFFFFFu) ovf_add(t, key, 1ULL << 32);
-                    done = true;
-                    break;
-                }
-                s = s + 1 == S ? 0 : s + 1;
-            }
-            if (!done) spill[atomicAdd(spill_n, 1ULL)] = key;                                   // region full: direct path later
+          for (int u = 0; u < BATCH; ++u) nv += cur[u] != EMPTY;
+          uint32_t u = 0, slot = 0, probes = 0;
+          unsigned long long key = EMPTY;
+          auto start = [&]() {                                                      // load k-mer u into the walk state
+              while (u < nv) {
+                  key = cur[0];
+#pragma unroll
+                  for (int q = 1; q < BATCH; ++q) key = u == (uint32_t)q ? cur[q] : key;
+                  const uint64_t h = mix64(key);
+                  slot = offset_of_hash(h, S);
+                  probes = 0;
+                  if (!(spill_mod && __umulhi((uint32_t)(h >> 32), spill_mod) == 0)) break;   // test hook: 1 k-mer in spill_mod takes the spill path
+                  spill[atomicAdd(spill_n, 1ULL)] = key;
+                  ++u;
+              }
+          };
+          start();
+          while (__any(u < nv)) {
+              if (u < nv) {
+                  unsigned long long c0 = rk[slot];
+                  if (c0 == EMPTY) {
+                      c0 = atomicCAS(&rk[slot], (unsigned long long)EMPTY, key);
+                      if (c0 == EMPTY) { ++new_distinct; c0 = key; }
+                  }
+                  bool fin = false;
+                  if (c0 == key) {
+                      // LDS returning add: a 32-bit wrap is seen right here and chained into the side table, so a round may
+                      // carry any number of copies of one k-mer and needs no host-side overflow guard
+                      if (atomicAdd(&rc[slot], 1u) == 0xFFFFFFFFu) ovf_add(t, key, 1ULL << 32);
+                      fin = true;
+                  } else {
+                      slot = slot + 1 == S ? 0 : slot + 1;
+                      if (++probes == S) { spill[atomicAdd(spill_n, 1ULL)] = key; fin = true; }      // region full: direct path later
+                  }
+                  if (fin) { ++u; start(); }
+              }
           }
+#pragma unroll
+          for (int q = 0; q < BATCH; ++q) cur[q] = nxt[q];
         }
         lds_barrier();
         for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
