@@ -462,6 +462,11 @@ static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::mi
 static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10) : 3;   // 0 = first edition (1024-thread, 1 per CU)
 static const uint32_t g_apply_batch = getenv("KATGPU_APPLY_BATCH") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BATCH"), nullptr, 10) : 4;
 static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 1024;
+// level 2 without its histogram pass (kg_partition.hpp: k_p2_fast): 0 = never, 1 = when the mean run is long enough for the
+// capacity slack to cover the noise, 2 = always (tests).  KATGPU_TEST_P2_OVF_CAP shrinks the overflow list (tests: forces the
+// fall back to the exact kernel).
+static const uint32_t g_p2_fast = getenv("KATGPU_P2_FAST") ? (uint32_t)strtoul(getenv("KATGPU_P2_FAST"), nullptr, 10) : 1;
+static const uint64_t g_test_p2_ovf_cap = getenv("KATGPU_TEST_P2_OVF_CAP") ? strtoull(getenv("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
 static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 
 static bool part_geometry(const DevTable& d, PartGeom* g) {
@@ -513,9 +518,6 @@ static int grow_beside_arena(katgpu_table* t, uint64_t incoming, uint64_t min_ca
         HIPCHK(c, pool_alloc(c, (void**)&d, chunk * 8));
         for (size_t i = 0; i < n_stash && rc == KATGPU_OK; i += chunk) {
             const size_t m = std::min(chunk, (size_t)n_stash - i);
-            rc = maybe_sweep(t, m);
-            if (rc) break;
-            t->unchecked_adds += m;
             if (hipMemcpyAsync(d, host.data() + i, m * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(c, KATGPU_ERR_DEVICE, "spill upload"); break; }
             ScopedTimer tm(c, KATGPU_K_COUNT, m);
             hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, m, 256, 6)), dim3(256), 0, c->stream, t->d, (const uint64_t*)d, (uint64_t)m);
@@ -549,6 +551,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -560,20 +563,23 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         c->part_attr_set = true;
     }
-    // ---- arena: [hist1 | offs | l1_off | off2 | spill_n | L1 buffer | L2 buffer] ----
+    // ---- arena: [hist1 | offs | l1_off | off2 | cnt2 | spill_n, ovf_n | L1 buffer | L2 buffer (+1/16 + 16 per region) | overflow list] ----
+    // 16.75 bytes per k-mer of a round: 8 (level 1) + 8.5 (level 2 with the capacity slack of k_p2_fast) + 0.25 (overflow list)
     const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +   /* W <= 4 * CUs */
-                               align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) + 256;
+                               align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) +
+                               align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256) + 256 +
+                               ((size_t)MAX_PARTS * MAX_PARTS * 16 + 2048) * 8;                  /* the 16 spare slots of every region's run */
     size_t want_items = n_starts;
     if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
-    if (c->arena_bytes < small_bytes + 16 * want_items) {                        // the arena could be more useful than it is
+    if (c->arena_bytes < small_bytes + 17 * want_items) {                        // the arena could be more useful than it is
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         free_b += c->arena_bytes;
-        size_t bytes = std::min<size_t>(small_bytes + 16 * want_items, (size_t)(g_arena_fraction * (double)free_b));
+        size_t bytes = std::min<size_t>(small_bytes + 17 * want_items, (size_t)(g_arena_fraction * (double)free_b));
         // re-allocate only for a substantially larger arena (fewer rounds): a fresh hipMalloc of this size is not free
-        if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 16 * std::min<size_t>(want_items, (size_t)64 << 20)) {
+        if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 17 * std::min<size_t>(want_items, (size_t)64 << 20)) {
             if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
-            if (!g_test_round_items && bytes < small_bytes + 16 * ((size_t)1 << 20)) return KATGPU_OK;   // no room for a useful round: direct path
+            if (!g_test_round_items && bytes < small_bytes + 17 * ((size_t)1 << 20)) return KATGPU_OK;   // no room for a useful round: direct path
             if (hipMalloc((void**)&c->arena, bytes) != hipSuccess) { (void)hipGetLastError(); c->arena = nullptr; return KATGPU_OK; }   // direct path
             c->arena_bytes = bytes;
         }
@@ -584,10 +590,16 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     uint64_t* offs = (uint64_t*)a;                a += align_up((size_t)W * MAX_PARTS * 8, 256);
     uint64_t* l1_off = (uint64_t*)a;              a += align_up((MAX_PARTS + 1) * 8, 256);
     uint64_t* off2 = (uint64_t*)a;                a += align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256);
-    unsigned long long* spill_n = (unsigned long long*)a; a += 256;
-    const size_t round_items = std::min<size_t>(want_items, (c->arena_bytes - small_bytes) / 16);
+    uint32_t* cnt2 = (uint32_t*)a;                a += align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256);
+    unsigned long long* spill_n = (unsigned long long*)a;
+    unsigned long long* ovf_n = spill_n + 1;      a += 256;
+    const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / 16.75));
     uint64_t* l1_buf = (uint64_t*)a;
     uint64_t* l2_buf = l1_buf + round_items;
+    const size_t l2_items = round_items + round_items / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024;
+    uint64_t* ovf_buf = l2_buf + l2_items;
+    const uint64_t ovf_cap = g_test_p2_ovf_cap ? g_test_p2_ovf_cap : round_items / 32 + 1024;
+    bool p2_fast_ok = g_p2_fast != 0;
     if (!g_test_round_items && round_items < ((size_t)1 << 20) && round_items < n_starts) return KATGPU_OK;
 
     // Rounds are sized in ITEMS (valid k-mers), not window starts: a cheap pre-count of a prefix measures items/starts
@@ -655,7 +667,26 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 if (p1v2) hipLaunchKernelGGL(k_p1v2_scatter, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
                 else hipLaunchKernelGGL(k_p1_scatter, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
             }
-            {
+            // level 2: one pass when the runs are predictable (k_p2_fast), else -- or when its overflow list did not hold --
+            // the exact two-pass kernel
+            const uint32_t* run_len = nullptr;
+            unsigned long long overflowed = 0;
+            if (p2_fast_ok && (g_p2_fast == 2 || items / g.R >= 1024)) {
+                HIPCHK(c, hipMemsetAsync(ovf_n, 0, sizeof(unsigned long long), c->stream));
+                {
+                    ScopedTimer tm(c, KATGPU_K_PART_L2, items);
+                    hipLaunchKernelGGL(k_p2_fast, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2,
+                                       ovf_buf, ovf_n, ovf_cap);
+                }
+                HIPCHK(c, hipMemcpyAsync(&overflowed, ovf_n, sizeof overflowed, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (overflowed > ovf_cap) {
+                    if (g_trace) fprintf(stderr, "[katgpu] k_p2_fast: %llu k-mers beyond their runs (list holds %llu): exact level 2 from here on\n", overflowed, (unsigned long long)ovf_cap);
+                    p2_fast_ok = false;
+                    overflowed = 0;
+                } else run_len = cnt2;
+            }
+            if (!run_len) {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
                 hipLaunchKernelGGL(k_p2, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2);
             }
@@ -666,7 +697,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 const uint32_t blk = g_apply_block;
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
-#define KG_APPLY(B, ...) hipLaunchKernelGGL((k_p3_apply<B, __VA_ARGS__>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod)
+#define KG_APPLY(B, ...) hipLaunchKernelGGL((k_p3_apply<B, __VA_ARGS__>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len)
                 const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
                 if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
                 else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) { if (g_apply_batch == 8) KG_APPLY(1024, 8, 8); else if (g_apply_batch == 12) KG_APPLY(1024, 8, 12); else if (g_apply_batch == 16) KG_APPLY(1024, 8, 16); else KG_APPLY(1024, 8); }
@@ -677,14 +708,15 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             unsigned long long spilled = 0;
             HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (overflowed) {                      // k_p2_fast's overflow list joins the spill list (both level buffers are dead by now)
+                HIPCHK(c, hipMemcpyAsync(l1_buf + spilled, ovf_buf, overflowed * 8, hipMemcpyDeviceToDevice, c->stream));
+                spilled += overflowed;
+            }
             if (spilled) {                         // regions that ran out of slots: make room, then the direct path
                 bool lost = false;
                 rc = grow_beside_arena(t, spilled, 0, l1_buf, spilled, &lost);
                 if (rc) return rc;
                 if (lost) { pos += m; break; }     // the spill went in from the host; the caller re-enters for the rest
-                rc = maybe_sweep(t, spilled);
-                if (rc) return rc;
-                t->unchecked_adds += spilled;
                 ScopedTimer tm(c, KATGPU_K_COUNT, spilled);
                 hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, spilled, 256, 6)), dim3(256), 0, c->stream, t->d, (const uint64_t*)l1_buf, (uint64_t)spilled);
             }

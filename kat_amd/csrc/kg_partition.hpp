@@ -492,6 +492,97 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
     }
 }
 
+// ---- level 2 without the histogram pass ----
+// The exact k_p2 reads every bucket twice: once to size the P2 sub-runs, once to scatter.  With a uniform hash the sizes
+// are known in advance up to noise (n_b / P2 k-mers per region, sigma = sqrt of that), so the fast edition gives every
+// region the same capacity -- mean + 1/16 + 16 -- scatters in ONE pass and reports what it really wrote (cnt2).  K-mers
+// beyond a region's capacity (heavy hitters, or a very unlucky region) go to a small overflow list that the host
+// inserts through the direct path; if even that list overflows, the host redoes the round with the exact kernel
+// (the level-1 buffer is only read here) and stays exact for the rest of the call.
+__device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t b1, uint32_t P2) { return beg + (beg >> 4) + (uint64_t)b1 * P2 * 16; }
+__device__ __host__ __forceinline__ uint64_t p2_region_cap(uint64_t n_b, uint32_t P2) { return (n_b + (n_b >> 4)) / P2 + 16; }
+
+__device__ __forceinline__ void scatter_tile2_bounded(PartLds& L, const PartGeom g, const uint64_t (&key)[PART_ITEMS], uint32_t valid,
+                                                      uint64_t* __restrict__ out, const uint64_t* lim, uint64_t* __restrict__ ovf_buf,
+                                                      unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t P = g.P2;
+    if (tid < MAX_PARTS) L.hist[tid] = 0;
+    lds_barrier();
+    uint32_t br[PART_ITEMS];
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        br[j] = 0;
+        if (valid >> j & 1) {
+            const uint32_t b = digit2_of_hash(mix64(key[j]), g.P2);
+            br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+        }
+    }
+    lds_barrier();
+    uint32_t total;
+    const uint32_t mine = tid < P ? L.hist[tid] : 0;
+    const uint32_t excl = block_exclusive_scan(mine, L.wave_tot, &total);
+    if (tid < MAX_PARTS) L.off[tid] = excl;
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j)
+        if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = key[j];
+    lds_barrier();
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    for (uint32_t b = wave; b < P; b += PART_BLOCK / 64) {
+        const uint32_t cnt = L.hist[b], src = L.off[b];
+        const uint64_t dst = L.cursor[b];
+        const uint64_t room = lim[b] - dst;
+        const uint32_t fit = (uint64_t)cnt <= room ? cnt : (uint32_t)room;
+        for (uint32_t i = lane; i < fit; i += 64) out[dst + i] = L.staging[src + i];
+        if (fit < cnt) {                                                   // uniform over the wave
+            const uint32_t excess = cnt - fit;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(ovf_n, (unsigned long long)excess);
+            base = __shfl(base, 0, 64);
+            for (uint32_t i = lane; i < excess; i += 64) if (base + i < ovf_cap) ovf_buf[base + i] = L.staging[src + fit + i];
+            if (lane == 0) L.hist[b] = fit;                                // what the cursor advances by
+        }
+    }
+    lds_barrier();
+    if (tid < P) L.cursor[tid] += L.hist[tid];
+}
+
+__global__ void __launch_bounds__(PART_BLOCK)
+k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
+          uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
+          uint64_t ovf_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
+    uint64_t* lim = reinterpret_cast<uint64_t*>(L.code);                   // code / bad are level-1 only: 8 KB for the run limits
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
+        const uint64_t beg = l1_off[b1], end = l1_off[b1 + 1];
+        const uint64_t cap = p2_region_cap(end - beg, g.P2), obase = p2_out_base(beg, b1, g.P2);
+        lds_barrier();
+        if (tid < g.P2) {
+            const uint64_t start = obase + (uint64_t)tid * cap;
+            L.cursor[tid] = start;
+            lim[tid] = start + cap;
+            off2[(uint64_t)b1 * g.P2 + tid] = start;
+        }
+        for (uint64_t tbeg = beg; tbeg < end; tbeg += TILE_ITEMS) {
+            uint64_t key[PART_ITEMS];
+            uint32_t valid = 0;
+#pragma unroll
+            for (int j = 0; j < PART_ITEMS; ++j) {
+                const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + tid;
+                key[j] = 0;
+                if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
+            }
+            lds_barrier();
+            scatter_tile2_bounded(L, g, key, valid, l2_buf, lim, ovf_buf, ovf_n, ovf_cap);
+        }
+        lds_barrier();
+        if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = (uint32_t)(L.cursor[tid] - (obase + (uint64_t)tid * cap));
+    }
+}
+
 // ---- level 3: apply a region's run to the region, in LDS ----
 // LDS: keys[S] (u64) | counts[S] (u32).  Insert = LDS CAS claim + LDS add (same protocol as table_inc, minus the HBM).
 // SPT = slots per lane held in registers while a region is prefetched (region_slots <= SPT * BLOCK).
@@ -500,7 +591,8 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 template <int BLOCK, int SPT, int BATCH = 4>
 __global__ void __launch_bounds__(BLOCK)
 k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
-           uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod) {
+           uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod,
+           const uint32_t* __restrict__ cnt2 /* run lengths when k_p2_fast laid the runs out; null: off2[r + 1] ends run r */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
     uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)g.S * 8);
@@ -510,7 +602,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
 
     auto next_region = [&](uint32_t from) {                       // first region >= from (stride gridDim) that received k-mers
         uint32_t r = from;
-        while (r < g.R && off2[r] == off2[r + 1]) r += gridDim.x;
+        while (r < g.R && (cnt2 ? cnt2[r] == 0 : off2[r] == off2[r + 1])) r += gridDim.x;
         return r;
     };
     auto prefetch = [&](uint32_t r) {
@@ -522,7 +614,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
     uint32_t r = next_region(blockIdx.x);
     if (r < g.R) prefetch(r);
     while (r < g.R) {
-        const uint64_t beg = off2[r], end = off2[r + 1];
+        const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : off2[r + 1];
         const uint64_t base = (uint64_t)r * S;
 #pragma unroll
         for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
@@ -592,12 +684,13 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
     flush_distinct(t, new_distinct);
 }
 
-// spilled k-mers (count 1 each) through the direct path
+// spilled k-mers (count 1 each) through the direct path.  Checked adds (table_add sees a 32-bit wrap itself): these lists
+// are short, and the unchecked table_inc would oblige the host to sweep the whole table first (katgpu.hip: maybe_sweep).
 __global__ void __launch_bounds__(256)
 k_insert_keys(DevTable t, const uint64_t* __restrict__ keys, uint64_t n) {
     uint32_t new_distinct = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) table_inc(t, keys[i], new_distinct);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) table_add(t, keys[i], 1ULL, new_distinct);
     flush_distinct(t, new_distinct);
 }
 

@@ -14,14 +14,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 # grow_nomem: every table growth during a partition call "fails" beside the arena, so the spilled keys are parked on the
-# host, the arena is given up and the call re-enters (the path a too-small size hint takes at production sizes)
-@pytest.mark.parametrize("region_slots,round_items,spill_mod,grow_nomem", [(512, 100000, 0, 0), (1024, 3000000, 7, 0), (8192, 400000, 0, 0),
-                                                                           (512, 100000, 5, 1), (2048, 250000, 0, 1)])
-def test_partitioned_counter_matches_oracle(region_slots, round_items, spill_mod, grow_nomem):
+# host, the arena is given up and the call re-enters (the path a too-small size hint takes at production sizes).
+# p2_fast=2: level 2 without its histogram pass (k_p2_fast) even on these tiny rounds, where runs overflow their capacity
+# all the time (overflow list -> direct path); ovf_cap=3 makes that list overflow too (fall back to the exact kernel).
+@pytest.mark.parametrize("region_slots,round_items,spill_mod,extra", [
+    (512, 100000, 0, {}), (1024, 3000000, 7, {}), (8192, 400000, 0, {}),
+    (512, 100000, 5, {"KATGPU_TEST_GROW_NOMEM": "1"}), (2048, 250000, 0, {"KATGPU_TEST_GROW_NOMEM": "1"}),
+    (512, 100000, 0, {"KATGPU_P2_FAST": "2"}), (1024, 3000000, 7, {"KATGPU_P2_FAST": "2"}),
+    (2048, 250000, 3, {"KATGPU_P2_FAST": "2", "KATGPU_TEST_P2_OVF_CAP": "3"}),
+    (512, 150000, 0, {"KATGPU_P2_FAST": "2", "KATGPU_TEST_GROW_NOMEM": "1"}), (8192, 400000, 0, {"KATGPU_P2_FAST": "0"})])
+def test_partitioned_counter_matches_oracle(region_slots, round_items, spill_mod, extra):
     env = dict(os.environ, KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
                KATGPU_TEST_ROUND_ITEMS=str(round_items), KATGPU_TEST_SPILL_MOD=str(spill_mod))
-    if grow_nomem:
-        env["KATGPU_TEST_GROW_NOMEM"] = "1"
+    env.update(extra)
     r = subprocess.run([sys.executable, os.path.join(HERE, "partition_cases.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "partition cases ok" in r.stdout
