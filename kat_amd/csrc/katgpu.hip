@@ -465,6 +465,10 @@ static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)s
 // level 2 without its histogram pass (kg_partition.hpp: k_p2_fast): 0 = never, 1 = when the mean run is long enough for the
 // capacity slack to cover the noise, 2 = always (tests).  KATGPU_TEST_P2_OVF_CAP shrinks the overflow list (tests: forces the
 // fall back to the exact kernel).
+// level 1 without its counting pass (kg_partition.hpp: k_p1v2_scatter_chunked): 0 = never (the default: measured slower on
+// MI355X, see the kernel's comment), 1 = for rounds of at least 64 M k-mers, 2 = always (tests)
+static const uint32_t g_test_l1_cpb = getenv("KATGPU_TEST_L1_CPB") ? (uint32_t)strtoul(getenv("KATGPU_TEST_L1_CPB"), nullptr, 10) : 0;   // tests: chunks per bucket (forces overflow)
+static const uint32_t g_l1_fast = getenv("KATGPU_L1_FAST") ? (uint32_t)strtoul(getenv("KATGPU_L1_FAST"), nullptr, 10) : 0;
 static const uint32_t g_p2_fast = getenv("KATGPU_P2_FAST") ? (uint32_t)strtoul(getenv("KATGPU_P2_FAST"), nullptr, 10) : 1;
 static const uint64_t g_test_p2_ovf_cap = getenv("KATGPU_TEST_P2_OVF_CAP") ? strtoull(getenv("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
 static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
@@ -563,23 +567,26 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         c->part_attr_set = true;
     }
-    // ---- arena: [hist1 | offs | l1_off | off2 | cnt2 | spill_n, ovf_n | L1 buffer | L2 buffer (+1/16 + 16 per region) | overflow list] ----
-    // 16.75 bytes per k-mer of a round: 8 (level 1) + 8.5 (level 2 with the capacity slack of k_p2_fast) + 0.25 (overflow list)
+    // ---- arena: [hist1 | offs | l1_off | off2 | cnt2 | bend | chunk_cur | spill_n, ovf_n | L1 buffer | L2 buffer | overflow list] ----
+    // L1 buffer: a round's k-mers + 1/32 (chunk slack of k_p1v2_scatter_chunked) + one chunk per workgroup and bucket;
+    // L2 buffer: that + 1/16 + 16 per region (capacity slack of k_p2_fast); overflow list: 1/32.  17.27 bytes per k-mer of a round.
+    const size_t fixed_l1 = (size_t)W * MAX_PARTS * L1_CHUNK;
+    const size_t fixed_l2 = fixed_l1 + fixed_l1 / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024;
     const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +   /* W <= 4 * CUs */
                                align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) +
-                               align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256) + 256 +
-                               ((size_t)MAX_PARTS * MAX_PARTS * 16 + 2048) * 8;                  /* the 16 spare slots of every region's run */
+                               align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256) + align_up((size_t)MAX_PARTS * 8, 256) + align_up((size_t)MAX_PARTS * 4, 256) + 256 +
+                               (fixed_l1 + fixed_l2 + 4096) * 8;
     size_t want_items = n_starts;
     if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
-    if (c->arena_bytes < small_bytes + 17 * want_items) {                        // the arena could be more useful than it is
+    if (c->arena_bytes < small_bytes + 18 * want_items) {                        // the arena could be more useful than it is
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         free_b += c->arena_bytes;
-        size_t bytes = std::min<size_t>(small_bytes + 17 * want_items, (size_t)(g_arena_fraction * (double)free_b));
+        size_t bytes = std::min<size_t>(small_bytes + 18 * want_items, (size_t)(g_arena_fraction * (double)free_b));
         // re-allocate only for a substantially larger arena (fewer rounds): a fresh hipMalloc of this size is not free
-        if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 17 * std::min<size_t>(want_items, (size_t)64 << 20)) {
+        if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 18 * std::min<size_t>(want_items, (size_t)64 << 20)) {
             if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
-            if (!g_test_round_items && bytes < small_bytes + 17 * ((size_t)1 << 20)) return KATGPU_OK;   // no room for a useful round: direct path
+            if (!g_test_round_items && bytes < small_bytes + 18 * ((size_t)1 << 20)) return KATGPU_OK;   // no room for a useful round: direct path
             if (hipMalloc((void**)&c->arena, bytes) != hipSuccess) { (void)hipGetLastError(); c->arena = nullptr; return KATGPU_OK; }   // direct path
             c->arena_bytes = bytes;
         }
@@ -591,15 +598,18 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     uint64_t* l1_off = (uint64_t*)a;              a += align_up((MAX_PARTS + 1) * 8, 256);
     uint64_t* off2 = (uint64_t*)a;                a += align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256);
     uint32_t* cnt2 = (uint32_t*)a;                a += align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256);
+    uint64_t* bend = (uint64_t*)a;                a += align_up((size_t)MAX_PARTS * 8, 256);
+    uint32_t* chunk_cur = (uint32_t*)a;           a += align_up((size_t)MAX_PARTS * 4, 256);
     unsigned long long* spill_n = (unsigned long long*)a;
     unsigned long long* ovf_n = spill_n + 1;      a += 256;
-    const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / 16.75));
+    const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / 17.27));
+    const size_t l1_items = round_items + round_items / 32 + fixed_l1;
+    const size_t l2_items = l1_items + l1_items / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024;
     uint64_t* l1_buf = (uint64_t*)a;
-    uint64_t* l2_buf = l1_buf + round_items;
-    const size_t l2_items = round_items + round_items / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024;
+    uint64_t* l2_buf = l1_buf + l1_items;
     uint64_t* ovf_buf = l2_buf + l2_items;
     const uint64_t ovf_cap = g_test_p2_ovf_cap ? g_test_p2_ovf_cap : round_items / 32 + 1024;
-    bool p2_fast_ok = g_p2_fast != 0;
+    bool p2_fast_ok = g_p2_fast != 0, l1_fast_ok = g_l1_fast != 0 && p1v2;
     if (!g_test_round_items && round_items < ((size_t)1 << 20) && round_items < n_starts) return KATGPU_OK;
 
     // Rounds are sized in ITEMS (valid k-mers), not window starts: a cheap pre-count of a prefix measures items/starts
@@ -645,51 +655,89 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         t->count_bound = 0xFFFFFFFFULL;          // the apply kernel chains its own carries; a later direct launch sweeps first
         const uint64_t n_tiles = (m + tile_starts - 1) / tile_starts;
         const uint64_t tiles_per_wg = (n_tiles + W - 1) / W;
-        {
-            ScopedTimer tm(c, KATGPU_K_PART_L1, m);
-            if (p1v2) hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
-            else hipLaunchKernelGGL(k_p1_count, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
-            hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
-        }
+        // Level 1.  Chunked edition (one pass, no exact sizes) when the round is big enough for its fixed costs; the exact
+        // edition (count + scan + scatter) otherwise, and for the rest of the call once a chunked round overflowed.
+        const uint64_t est_items = (uint64_t)((double)m * items_per_start);
+        uint32_t cpb = (uint32_t)std::min<uint64_t>(l1_items / ((uint64_t)g.P1 * L1_CHUNK), 0x7FFFFFFFu);             // chunks per bucket
+        if (g_test_l1_cpb) cpb = std::min(cpb, g_test_l1_cpb);
+        const bool chunked = l1_fast_ok && (cpb > W || g_test_l1_cpb) && (g_l1_fast == 2 || est_items >= ((uint64_t)64 << 20));
         uint64_t items = 0;
-        HIPCHK(c, hipMemcpyAsync(&items, &l1_off[g.P1], sizeof items, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (g_trace) fprintf(stderr, "[katgpu] partition round: %zu starts -> %llu items (buffer %zu items, arena %.1f GB, ratio %.3f)\n", m, (unsigned long long)items, round_items, c->arena_bytes / 1e9, items_per_start);
-        if (items > round_items) {                      // denser than the prefix suggested: redo this round smaller
-            if (t->d.k == 32 && !t->d.canonical) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-            items_per_start = std::min(1.0, (double)items / (double)m * 1.02);
-            continue;
-        }
-        if (items) {
-            HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
+        unsigned long long ovf_l1 = 0;
+        HIPCHK(c, hipMemsetAsync(spill_n, 0, 2 * sizeof(unsigned long long), c->stream));          // spill_n, ovf_n
+        if (chunked) {
+            items = est_items;                                                    // the exact number is not needed (and not known)
+            HIPCHK(c, hipMemsetAsync(chunk_cur, 0, (size_t)g.P1 * 4, c->stream));
             {
+                ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
+                hipLaunchKernelGGL(k_p1v2_scatter_chunked, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, chunk_cur, cpb, l1_buf,
+                                   ovf_buf, ovf_n, ovf_cap);
+            }
+            HIPCHK(c, hipMemcpyAsync(&ovf_l1, ovf_n, sizeof ovf_l1, hipMemcpyDeviceToHost, c->stream));      // read at the next synchronisation
+            if (g_trace) fprintf(stderr, "[katgpu] partition round (chunked level 1): %zu starts, ~%llu items, %u chunks per bucket (arena %.1f GB)\n", m, (unsigned long long)items, cpb, c->arena_bytes / 1e9);
+        } else {
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_L1, m);
+                if (p1v2) hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
+                else hipLaunchKernelGGL(k_p1_count, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
+                hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
+            }
+            HIPCHK(c, hipMemcpyAsync(&items, &l1_off[g.P1], sizeof items, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (g_trace) fprintf(stderr, "[katgpu] partition round: %zu starts -> %llu items (buffer %zu items, arena %.1f GB, ratio %.3f)\n", m, (unsigned long long)items, round_items, c->arena_bytes / 1e9, items_per_start);
+            if (items > round_items) {                      // denser than the prefix suggested: redo this round smaller
+                if (t->d.k == 32 && !t->d.canonical) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+                items_per_start = std::min(1.0, (double)items / (double)m * 1.02);
+                continue;
+            }
+            if (items) {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
                 if (p1v2) hipLaunchKernelGGL(k_p1v2_scatter, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
                 else hipLaunchKernelGGL(k_p1_scatter, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
             }
+        }
+        if (items) {
+            const uint32_t* cc = chunked ? chunk_cur : nullptr;
             // level 2: one pass when the runs are predictable (k_p2_fast), else -- or when its overflow list did not hold --
             // the exact two-pass kernel
             const uint32_t* run_len = nullptr;
             unsigned long long overflowed = 0;
-            if (p2_fast_ok && (g_p2_fast == 2 || items / g.R >= 1024)) {
-                HIPCHK(c, hipMemsetAsync(ovf_n, 0, sizeof(unsigned long long), c->stream));
-                {
-                    ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-                    hipLaunchKernelGGL(k_p2_fast, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2,
-                                       ovf_buf, ovf_n, ovf_cap);
-                }
+            const bool try_fast = p2_fast_ok && (g_p2_fast == 2 || items / g.R >= 1024);
+            if (try_fast) {
+                ScopedTimer tm(c, KATGPU_K_PART_L2, items);
+                hipLaunchKernelGGL(k_p2_fast, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2,
+                                   ovf_buf, ovf_n, ovf_cap, cc, cpb);
+            }
+            if (try_fast || chunked) {
                 HIPCHK(c, hipMemcpyAsync(&overflowed, ovf_n, sizeof overflowed, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
-                if (overflowed > ovf_cap) {
+                if (chunked && g_trace) {
+                    std::vector<uint32_t> cur(g.P1);
+                    hipMemcpy(cur.data(), chunk_cur, (size_t)g.P1 * 4, hipMemcpyDeviceToHost);
+                    uint64_t used = 0; uint32_t mx = 0, mn = ~0u;
+                    for (uint32_t v : cur) { used += std::min(v, cpb); mx = std::max(mx, v); mn = std::min(mn, v); }
+                    fprintf(stderr, "[katgpu]   chunks used %llu (= %llu slots for ~%llu items), per bucket %u..%u of %u; level-1 overflow %llu\n", (unsigned long long)used,
+                            (unsigned long long)used * L1_CHUNK, (unsigned long long)items, mn, mx, cpb, ovf_l1);
+                }
+                if (chunked && ovf_l1 > ovf_cap) {           // the level-1 buffer itself is incomplete: this round again, exactly
+                    if (g_trace) fprintf(stderr, "[katgpu] chunked level 1: %llu k-mers found no chunk (list holds %llu): exact level 1 from here on\n", ovf_l1, (unsigned long long)ovf_cap);
+                    l1_fast_ok = false;
+                    HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));   // the scatter tallied the all-ones key
+                    continue;
+                }
+                if (try_fast && overflowed <= ovf_cap) run_len = cnt2;
+                else if (try_fast) {
                     if (g_trace) fprintf(stderr, "[katgpu] k_p2_fast: %llu k-mers beyond their runs (list holds %llu): exact level 2 from here on\n", overflowed, (unsigned long long)ovf_cap);
                     p2_fast_ok = false;
-                    overflowed = 0;
-                } else run_len = cnt2;
+                    overflowed = ovf_l1;                     // what level 1 put on the list is still there and still valid
+                    HIPCHK(c, hipMemcpyAsync(ovf_n, &ovf_l1, sizeof ovf_l1, hipMemcpyHostToDevice, c->stream));
+                }
             }
             if (!run_len) {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-                hipLaunchKernelGGL(k_p2, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2);
+                hipLaunchKernelGGL(k_p2, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cc, cpb,
+                                   chunked ? bend : (uint64_t*)nullptr);
             }
+            const uint64_t* bucket_end = (!run_len && chunked) ? bend : nullptr;
             {
                 ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
                 // as many workgroups per CU as the regions' LDS footprint (and the 2048-thread limit) admits
@@ -697,7 +745,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 const uint32_t blk = g_apply_block;
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
-#define KG_APPLY(B, ...) hipLaunchKernelGGL((k_p3_apply<B, __VA_ARGS__>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len)
+#define KG_APPLY(B, ...) hipLaunchKernelGGL((k_p3_apply<B, __VA_ARGS__>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
                 const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
                 if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
                 else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) { if (g_apply_batch == 8) KG_APPLY(1024, 8, 8); else if (g_apply_batch == 12) KG_APPLY(1024, 8, 12); else if (g_apply_batch == 16) KG_APPLY(1024, 8, 16); else KG_APPLY(1024, 8); }

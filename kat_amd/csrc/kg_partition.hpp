@@ -274,6 +274,7 @@ struct P1Lds {
     uint32_t code[P1_BLOCK + 2];
     uint32_t bad[P1_BLOCK + 2];
     uint16_t pos[P1_TILE_BYTES];
+    uint32_t next[MAX_PARTS];           // chunked edition: the chunk this workgroup has reserved ahead in each bucket
 };
 
 struct LaneWindow {                       // the 96-bit sliding window of kg_kernels.hpp's K1, as an object
@@ -447,15 +448,154 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
     }
 }
 
+// ---- level 1 without the counting pass ----
+// The exact edition needs every workgroup's bucket sizes before it can write (k_p1v2_count: a second decode + hash of the
+// whole input).  The chunked edition writes in ONE pass: a bucket's share of the level-1 buffer is cut into chunks of
+// L1_CHUNK k-mers; a workgroup appends to its current chunk of bucket b and takes the next free one (one global atomic per
+// 256 k-mers) when that is full.  What a workgroup leaves unfilled in its last chunk of each bucket is padded with EMPTY,
+// which level 2 skips (the all-ones k-mer never is an item).  A bucket that runs out of chunks (heavy hitters) sends its
+// k-mers to the overflow list; when that list cannot hold them the host redoes the round with the exact kernels.
+// MEASURED (bench config, 300 M reads, 4 rounds of 9.3 G k-mers): NOT a win on MI355X as it stands.  The counting pass
+// (70 ms per step) goes away and level 2 pays 15 ms for the padding, but this scatter takes 320-330 ms where the exact one
+// takes 211: step 944 ms against 898.  Reserving the next chunk ahead (so that no wave waits on a returning atomic at a
+// chunk boundary) changed nothing, so the loss is in the copy-out loop itself, not in the atomics.  Off by default
+// (KATGPU_L1_FAST=1 enables it, =2 forces it for small rounds); kept, and covered by tests/test_gpu_partition.py, as the
+// starting point for a copy-out that handles the chunk boundary outside the per-bucket loop.
+constexpr uint32_t L1_CHUNK = 256;
+
+__device__ __forceinline__ uint64_t l1_bucket_base(uint32_t b, uint32_t cpb) { return (uint64_t)b * cpb * L1_CHUNK; }
+
+__global__ void __launch_bounds__(P1_BLOCK)
+k_p1v2_scatter_chunked(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
+                       uint32_t* __restrict__ chunk_cur, uint32_t cpb, uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ ovf_buf,
+                       unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
+    __shared__ __attribute__((aligned(16))) P1Lds L;
+    const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;
+    const bool canonical = t.canonical != 0;
+    // cursor[b]: next write position of this workgroup in bucket b; a multiple of L1_CHUNK means "no chunk in hand".
+    // next[b]: a chunk reserved AHEAD, so that crossing a chunk boundary never waits for a global atomic: the crossing takes
+    // next[b] and issues the reservation of the one after; that atomic's result is parked in a register (two slots per
+    // 16-lane group) and stored to next[b] at the top of the next tile's copy-out, long after it has arrived.
+    for (uint32_t b = tid; b < P; b += P1_BLOCK) { L.cursor[b] = 0; L.next[b] = atomicAdd(&chunk_cur[b], 1u); }
+    uint32_t ones = 0;
+    const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
+    uint32_t w[4], wn[4];
+    if (t0 < t1) p1_tile_load(bases, n, t0 * P1_TILE_STARTS, w);
+    const uint32_t grp = tid >> 4, l16 = tid & 15;
+    uint32_t np = 0, pb0 = 0, pb1 = 0, pv0 = 0, pv1 = 0;              // lane 0 of each group: reservations in flight
+    auto flush = [&]() {
+        if (l16 == 0) {
+            if (np > 0) L.next[pb0] = pv0;
+            if (np > 1) L.next[pb1] = pv1;
+        }
+        np = 0;
+    };
+    for (uint64_t tile = t0; tile < t1; ++tile) {
+        if (tile + 1 < t1) p1_tile_load(bases, n, (tile + 1) * P1_TILE_STARTS, wn);
+        lds_barrier();
+        for (uint32_t b = tid; b < MAX_PARTS; b += P1_BLOCK) L.hist[b] = 0;
+        p1_tile_stage(L, w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = wn[q];
+        uint32_t br[PART_ITEMS];
+        uint32_t valid = 0;
+        if (tid < P1_LANES_WITH_STARTS) {
+            LaneWindow lw;
+            lw.init(L.code, L.bad, tid, k);
+#pragma unroll
+            for (int j = 0; j < PART_ITEMS; ++j, lw.step()) {
+                br[j] = 0;
+                if (!lw.valid()) continue;
+                const uint64_t key = canon_if(lw.fwd(), k, canonical);
+                if (key == EMPTY) { ++ones; continue; }
+                const uint32_t b = digit1_of_hash(mix64(key), P);
+                br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+                valid |= 1u << j;
+            }
+        }
+        lds_barrier();
+        uint32_t e0, e1;
+        p1_scan_pair(tid < P ? L.hist[tid] : 0, tid + P1_BLOCK < P ? L.hist[tid + P1_BLOCK] : 0, L.wave_tot, e0, e1);
+        L.off[tid] = e0;
+        L.off[tid + P1_BLOCK] = e1;
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < PART_ITEMS; ++j)
+            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = (uint16_t)(tid * PART_ITEMS + j);
+        flush();                                                              // last tile's reservations have long arrived
+        lds_barrier();
+        // copy-out: a 16-lane group per bucket appends the run to the workgroup's current chunk of that bucket
+        for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
+            uint32_t left = L.hist[b], src = L.off[b];
+            uint64_t dst = L.cursor[b];
+            while (left) {                                                    // uniform over the group
+                uint32_t room = (L1_CHUNK - (uint32_t)(dst & (L1_CHUNK - 1))) & (L1_CHUNK - 1);
+                if (room == 0) {                                              // move on to the chunk reserved ahead, reserve the one after
+                    if (np == 2 || (np > 0 && pb0 == b) || (np > 1 && pb1 == b)) flush();      // (a run longer than a chunk, or many crossings)
+                    uint32_t c = 0;
+                    if (l16 == 0) {
+                        c = L.next[b];
+                        const uint32_t v = atomicAdd(&chunk_cur[b], 1u);
+                        if (np == 0) { pb0 = b; pv0 = v; } else { pb1 = b; pv1 = v; }
+                    }
+                    ++np;
+                    c = __shfl(c, 0, 16);
+                    if (c >= cpb) {                                           // the bucket is out of chunks: the rest of the run overflows
+                        unsigned long long at = 0;
+                        if (l16 == 0) at = atomicAdd(ovf_n, (unsigned long long)left);
+                        at = __shfl(at, 0, 16);
+                        for (uint32_t i = l16; i < left; i += 16)
+                            if (at + i < ovf_cap) ovf_buf[at + i] = kmer_at(L.code, L.pos[src + i], k, canonical);
+                        dst = 0;
+                        break;
+                    }
+                    dst = l1_bucket_base(b, cpb) + (uint64_t)c * L1_CHUNK;
+                    room = L1_CHUNK;
+                }
+                const uint32_t part = left < room ? left : room;
+                for (uint32_t i = l16; i < part; i += 16) l1_buf[dst + i] = kmer_at(L.code, L.pos[src + i], k, canonical);
+                dst += part; src += part; left -= part;
+            }
+            if (l16 == 0) L.cursor[b] = dst;
+        }
+    }
+    flush();
+    lds_barrier();
+    // pad what is left of the chunk in hand and the whole chunk reserved ahead: level 2 reads every chunk that was handed out
+    for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
+        const uint64_t dst = L.cursor[b];
+        const uint32_t room = (L1_CHUNK - (uint32_t)(dst & (L1_CHUNK - 1))) & (L1_CHUNK - 1);
+        for (uint32_t i = l16; i < room; i += 16) l1_buf[dst + i] = EMPTY;
+        const uint32_t c = L.next[b];
+        if (c < cpb) {
+            const uint64_t base = l1_bucket_base(b, cpb) + (uint64_t)c * L1_CHUNK;
+            for (uint32_t i = l16; i < L1_CHUNK; i += 16) l1_buf[base + i] = EMPTY;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
+    if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
+}
+
+// where bucket b1 of the level-1 buffer lies: exact layout (l1_off) or chunked (whole chunks, EMPTY-padded)
+__device__ __forceinline__ void l1_bucket_range(const uint64_t* __restrict__ l1_off, const uint32_t* __restrict__ chunk_cur, uint32_t cpb, uint32_t b1,
+                                                uint64_t& beg, uint64_t& end) {
+    if (chunk_cur) {
+        const uint32_t used = chunk_cur[b1];
+        beg = l1_bucket_base(b1, cpb);
+        end = beg + (uint64_t)(used < cpb ? used : cpb) * L1_CHUNK;
+    } else { beg = l1_off[b1]; end = l1_off[b1 + 1]; }
+}
+
 // ---- level 2: one workgroup per level-1 bucket: histogram by sub-bucket, scan, scatter.  off2[r] = start of region r's run. ----
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
-     uint64_t* __restrict__ off2) {
+     uint64_t* __restrict__ off2, const uint32_t* __restrict__ chunk_cur, uint32_t cpb, uint64_t* __restrict__ bend /* end of bucket b1's last run (chunked layout) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
     const uint32_t tid = threadIdx.x;
     for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
-        const uint64_t beg = l1_off[b1], end = l1_off[b1 + 1];
+        uint64_t beg, end;
+        l1_bucket_range(l1_off, chunk_cur, cpb, b1, beg, end);
         lds_barrier();
         // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
         // the cursor array is free until the scan, so it doubles as the histogram
@@ -477,6 +617,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
             off2[(uint64_t)b1 * g.P2 + tid] = beg + excl;
         }
         if (b1 == g.P1 - 1 && tid == 0) off2[(uint64_t)g.P1 * g.P2] = end;
+        if (bend && tid == g.P2 - 1) bend[b1] = beg + excl + mine;                             // the runs of a bucket stop short of the next bucket (padding)
         for (uint64_t tbeg = beg; tbeg < end; tbeg += TILE_ITEMS) {                            // pass B
             uint64_t key[PART_ITEMS];
             uint32_t valid = 0;
@@ -485,6 +626,10 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
                 const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + tid;
                 key[j] = 0;
                 if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
+            }
+            if (chunk_cur) {                                     // chunk padding (looked at only after all 16 loads are in flight)
+#pragma unroll
+                for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);
             }
             lds_barrier();
             scatter_tile<2>(L, g, key, valid, l2_buf);
@@ -551,13 +696,14 @@ __device__ __forceinline__ void scatter_tile2_bounded(PartLds& L, const PartGeom
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
           uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
-          uint64_t ovf_cap) {
+          uint64_t ovf_cap, const uint32_t* __restrict__ chunk_cur, uint32_t cpb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
     uint64_t* lim = reinterpret_cast<uint64_t*>(L.code);                   // code / bad are level-1 only: 8 KB for the run limits
     const uint32_t tid = threadIdx.x;
     for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
-        const uint64_t beg = l1_off[b1], end = l1_off[b1 + 1];
+        uint64_t beg, end;
+        l1_bucket_range(l1_off, chunk_cur, cpb, b1, beg, end);
         const uint64_t cap = p2_region_cap(end - beg, g.P2), obase = p2_out_base(beg, b1, g.P2);
         lds_barrier();
         if (tid < g.P2) {
@@ -574,6 +720,10 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
                 const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + tid;
                 key[j] = 0;
                 if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
+            }
+            if (chunk_cur) {                                     // chunk padding (looked at only after all 16 loads are in flight)
+#pragma unroll
+                for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);
             }
             lds_barrier();
             scatter_tile2_bounded(L, g, key, valid, l2_buf, lim, ovf_buf, ovf_n, ovf_cap);
@@ -592,7 +742,8 @@ template <int BLOCK, int SPT, int BATCH = 4>
 __global__ void __launch_bounds__(BLOCK)
 k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
            uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod,
-           const uint32_t* __restrict__ cnt2 /* run lengths when k_p2_fast laid the runs out; null: off2[r + 1] ends run r */) {
+           const uint32_t* __restrict__ cnt2 /* run lengths when k_p2_fast laid the runs out; null: off2[r + 1] ends run r */,
+           const uint64_t* __restrict__ bend /* exact level 2 over a chunked level 1: where the last run of each bucket ends */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
     uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)g.S * 8);
@@ -600,9 +751,13 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
     uint32_t new_distinct = 0;
     uint64_t kk[SPT]; uint32_t cc[SPT];
 
+    auto run_end = [&](uint32_t r) -> uint64_t {                  // exact layouts: run r ends where the next one starts
+        if (bend && (r + 1) % g.P2 == 0) return bend[r / g.P2];
+        return off2[r + 1];
+    };
     auto next_region = [&](uint32_t from) {                       // first region >= from (stride gridDim) that received k-mers
         uint32_t r = from;
-        while (r < g.R && (cnt2 ? cnt2[r] == 0 : off2[r] == off2[r + 1])) r += gridDim.x;
+        while (r < g.R && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
         return r;
     };
     auto prefetch = [&](uint32_t r) {
@@ -614,7 +769,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
     uint32_t r = next_region(blockIdx.x);
     if (r < g.R) prefetch(r);
     while (r < g.R) {
-        const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : off2[r + 1];
+        const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : run_end(r);
         const uint64_t base = (uint64_t)r * S;
 #pragma unroll
         for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }

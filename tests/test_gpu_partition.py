@@ -22,7 +22,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     (512, 100000, 5, {"KATGPU_TEST_GROW_NOMEM": "1"}), (2048, 250000, 0, {"KATGPU_TEST_GROW_NOMEM": "1"}),
     (512, 100000, 0, {"KATGPU_P2_FAST": "2"}), (1024, 3000000, 7, {"KATGPU_P2_FAST": "2"}),
     (2048, 250000, 3, {"KATGPU_P2_FAST": "2", "KATGPU_TEST_P2_OVF_CAP": "3"}),
-    (512, 150000, 0, {"KATGPU_P2_FAST": "2", "KATGPU_TEST_GROW_NOMEM": "1"}), (8192, 400000, 0, {"KATGPU_P2_FAST": "0"})])
+    (512, 150000, 0, {"KATGPU_P2_FAST": "2", "KATGPU_TEST_GROW_NOMEM": "1"}), (8192, 400000, 0, {"KATGPU_P2_FAST": "0"}),
+    # l1_fast=2: level 1 without its counting pass (chunked scatter); L1_CPB caps the chunks of a bucket so that runs overflow
+    # (list -> direct path) and, with a tiny list, the round is redone exactly
+    (512, 100000, 0, {"KATGPU_L1_FAST": "2"}), (1024, 3000000, 7, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2"}),
+    (8192, 400000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "0"}),
+    (2048, 250000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2", "KATGPU_TEST_L1_CPB": "3", "KATGPU_P1_WGS": "1"}),
+    (512, 150000, 3, {"KATGPU_L1_FAST": "2", "KATGPU_TEST_L1_CPB": "2", "KATGPU_TEST_P2_OVF_CAP": "50", "KATGPU_P1_WGS": "1"}),
+    (1024, 200000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2", "KATGPU_TEST_GROW_NOMEM": "1"})])
 def test_partitioned_counter_matches_oracle(region_slots, round_items, spill_mod, extra):
     env = dict(os.environ, KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
                KATGPU_TEST_ROUND_ITEMS=str(round_items), KATGPU_TEST_SPILL_MOD=str(spill_mod))
