@@ -51,6 +51,31 @@ def expected_distinct(instances, genome, k, err_ppm):
     return int(min(instances, genome + instances * p_err * 1.05))
 
 
+def pmc_traffic(a, world):
+    """HBM bytes per launch (= per partition round) of the count stage, from the committed rocprofv3 PMC passes of THIS command
+    (tools/profile_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs with --kernel-trace; units KB; FETCH_SIZE doubled, as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  The workload is seeded, so the traffic of a round is
+    reproducible; counters cannot be collected from inside the timed run.  None when the workload is not the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_fetch_write.json")
+    if world != 1 or (a.reads, a.genome, a.contig, a.k, a.read_len, a.err_ppm) != (300_000_000, 1_000_000_000, 1_000_000, 27, 150, 2000):
+        return None, None
+    try:
+        prof = json.load(open(path))
+    except Exception:
+        return None, None
+    stage = ("k_p1v2_count", "k_p1_scan", "k_p1v2_scatter", "k_p1v2_scatter_chunked", "k_p2", "k_p2_fast", "k_p3_apply", "k_insert_keys")
+    kb, rounds = 0.0, 0
+    for name, e in prof.items():
+        base = name.replace("kg::", "").split("<")[0]
+        if base in stage:
+            kb += 2.0 * e.get("FETCH_SIZE_KB_total", 0.0) + e.get("WRITE_SIZE_KB_total", 0.0)
+            if base == "k_p3_apply":
+                rounds += e.get("launches", 0)
+    if not rounds:
+        return None, None
+    return int(kb * 1024 / rounds), "profiles/r01_final_pmc_fetch_write.json: (2 x FETCH_SIZE + WRITE_SIZE) of the count-stage kernels / %d rounds" % rounds
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -199,8 +224,9 @@ def main():
             name = "k_count"
             per_kernel = {"count": {"launches": prof["count"]["launches"], "avg_ms": round(direct_ms / rounds, 3)}}
         achieved = alg_bytes_step * a.steps / (stage_ms / 1e3) / 1e9 if stage_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(a, world)
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": rounds, "avg_launch_ms": round(stage_ms / rounds, 3),
                 "alg_bytes_per_launch": int(alg_bytes_step * a.steps / rounds), "per_kernel": per_kernel}
         kernels_ms = {n: round(v["ms"] / a.steps, 3) for n, v in prof.items() if v["launches"]}
