@@ -412,22 +412,34 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
         const uint64_t bbase = (uint64_t)r * Sb, abase = (uint64_t)r * Sa;
         for (uint32_t i = threadIdx.x; i < Sb; i += blockDim.x) { rk[i] = tb.keys[bbase + i]; rc[i] = tb.counts[bbase + i]; }
         __syncthreads();
-        for (uint32_t i0 = 0; i0 < Sa; i0 += blockDim.x) {                  // uniform trip count: ballots inside comp_account
-            const uint32_t i = i0 + threadIdx.x;
-            uint64_t key = EMPTY, ca = 0, cb = 0;
-            bool occ = false;
-            if (i < Sa) { key = ta.keys[abase + i]; occ = key != EMPTY; }
-            if (occ) {
-                ca = slot_count(ta, abase + i, key, na_ovf);
-                uint32_t s = offset_of_hash(mix64(key), Sb);
-                for (uint32_t probe = 0; probe < Sb; ++probe) {
-                    const unsigned long long cur = rk[s];
-                    if (cur == key) { cb = rc[s]; if (nb_ovf) cb += ovf_get(tb, key); break; }
-                    if (cur == EMPTY) break;
-                    s = s + 1 == Sb ? 0 : s + 1;
-                }
+        constexpr int JB = 4;                                               // slots per lane in flight: keys and counts are loaded together
+        for (uint32_t i0 = 0; i0 < Sa; i0 += JB * blockDim.x) {             // uniform trip count: ballots inside comp_account
+            uint64_t keys[JB]; uint32_t cnts[JB];
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const uint32_t i = i0 + u * blockDim.x + threadIdx.x;
+                const uint32_t ic = i < Sa ? i : Sa - 1;                    // clamped: the loads stay in one basic block
+                keys[u] = ta.keys[abase + ic]; cnts[u] = ta.counts[abase + ic];
+                if (i >= Sa) keys[u] = EMPTY;
             }
-            comp_account<PASS>(occ, ca, cb, a, s_tile, s_spec, acc);
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const uint64_t key = keys[u];
+                const bool occ = key != EMPTY;
+                uint64_t ca = 0, cb = 0;
+                if (occ) {
+                    ca = cnts[u];
+                    if (na_ovf) ca += ovf_get(ta, key);
+                    uint32_t s = offset_of_hash(mix64(key), Sb);
+                    for (uint32_t probe = 0; probe < Sb; ++probe) {
+                        const unsigned long long cur = rk[s];
+                        if (cur == key) { cb = rc[s]; if (nb_ovf) cb += ovf_get(tb, key); break; }
+                        if (cur == EMPTY) break;
+                        s = s + 1 == Sb ? 0 : s + 1;
+                    }
+                }
+                comp_account<PASS>(occ, ca, cb, a, s_tile, s_spec, acc);
+            }
         }
     }
     {   // the all-ones key lives outside the slots: one lane of block 0 takes it through the HBM path
