@@ -8,10 +8,12 @@
 //   P1  radix-partitions the round's k-mers by the high part of their region index into P1 buckets  (8 B out / k-mer)
 //   P2  splits every bucket by the low part of the region index -> one contiguous run per region     (8 B in, 8 B out)
 //   P3  loads a region (96 KB) into LDS, applies its run with LDS atomics, writes the region back     (8 B in + 24 B/slot)
-// so HBM sees only streaming traffic.  Both partition levels are exact two-pass (histogram, scan, scatter) with
-// per-workgroup running cursors held in LDS: no global atomics, deterministic placement, no bucket can overflow.
-// A region that fills up in P3 (more distinct k-mers than slots) spills the k-mer to a list (held in the then-free
-// P1 buffer, so it can never overflow) that is inserted with the direct kernel's path after a regrow.
+// so HBM sees only streaming traffic.  Level 1 is exact two-pass (histogram, scan, scatter) with per-workgroup running
+// cursors held in LDS: no global atomic per k-mer, deterministic placement.  Level 2 normally runs in ONE pass
+// (k_p2_fast: equal-capacity runs sized from the uniform hash, an overflow list for what does not fit, the exact
+// histogram/scan/scatter kernel k_p2 as the fall back).  A region that fills up in P3 (more distinct k-mers than slots)
+// spills the k-mer to a list (held in the then-free P1 buffer, so it can never overflow) that is inserted through the
+// direct path after a regrow.
 #pragma once
 #include "kg_kernels.hpp"
 
