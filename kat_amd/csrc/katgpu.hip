@@ -460,7 +460,6 @@ static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? s
 // share of the free HBM the partition arena may take (multi-GPU runs leave room for the owner tables: bench.py sets 0.5)
 static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::min(0.95, std::max(0.05, atof(getenv("KATGPU_ARENA_FRACTION")))) : 0.85;
 static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10) : 3;   // 0 = first edition (1024-thread, 1 per CU)
-static const uint32_t g_apply_batch = getenv("KATGPU_APPLY_BATCH") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BATCH"), nullptr, 10) : 4;
 static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 1024;
 // level 2 without its histogram pass (kg_partition.hpp: k_p2_fast): 0 = never, 1 = when the mean run is long enough for the
 // capacity slack to cover the noise, 2 = always (tests).  KATGPU_TEST_P2_OVF_CAP shrinks the overflow list (tests: forces the
@@ -559,9 +558,6 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -748,8 +744,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
 #define KG_APPLY(B, ...) hipLaunchKernelGGL((k_p3_apply<B, __VA_ARGS__>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
                 const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
                 if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
-                else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) { if (g_apply_batch == 8) KG_APPLY(1024, 8, 8); else if (g_apply_batch == 12) KG_APPLY(1024, 8, 12); else if (g_apply_batch == 16) KG_APPLY(1024, 8, 16); else KG_APPLY(1024, 8); }
-                       else KG_APPLY(1024, 12); }
+                else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) KG_APPLY(1024, 8); else KG_APPLY(1024, 12); }
 #undef KG_APPLY
             }
             HIPCHK(c, hipGetLastError());
@@ -905,9 +900,14 @@ extern "C" int katgpu_count_files(katgpu_table* t, const char* const* paths, siz
     HostFeeder f(t);
     int rc = f.begin(); if (rc) return rc;
     for (size_t i = 0; i < n_paths; ++i) {
-        kg::SeqFileParser parser;
         std::string err;
-        int prc = parser.open(paths[i], trim5p ? trim5p[i] : 0, &err);
+        // large plain files are parsed by a thread team (kg_ingest.hpp: parse_file_parallel, byte-identical output) ...
+        int prc = kg::parse_file_parallel(paths[i], trim5p ? trim5p[i] : 0, [&](const uint8_t* p, size_t n) { return f.push(p, n); }, &err);
+        if (prc == 0) { rc = f.end_of_file(); if (rc) return rc; continue; }
+        if (prc > 0) return err.empty() ? prc : fail(c, prc, "%s", err.c_str());
+        // ... gzip, pipes, small files and 5' trimming stream through the single-threaded parser
+        kg::SeqFileParser parser;
+        prc = parser.open(paths[i], trim5p ? trim5p[i] : 0, &err);
         if (prc) return fail(c, prc, "%s", err.c_str());
         for (;;) {
             const uint8_t* p; size_t n;

@@ -3,12 +3,18 @@
 
 #include "../../include/katgpu.h"
 
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
+#include <thread>
 
 namespace kg {
 
@@ -24,7 +30,7 @@ SeqFileParser::~SeqFileParser() {
 
 int SeqFileParser::open(const char* path, uint32_t trim5p, std::string* err) {
     path_ = path;
-    trim5p_ = trim5p;
+    ps_.trim5p = trim5p;
     // the reference opens every input through a gzip-aware stream (stream_manager.hpp:133-145); zlib passes plain files through
     gz_ = gzopen(path, "rb");
     if (!gz_) {
@@ -37,81 +43,98 @@ int SeqFileParser::open(const char* path, uint32_t trim5p, std::string* err) {
     return KATGPU_OK;
 }
 
-void SeqFileParser::after_header() {
-    if (trim5p_ > 0) st_ = TRIM_SKIPNL;          // read_sequence: skip_newlines(); is.ignore(trim5p)   (parser.hpp:250-253)
-    else st_ = LOOP_CHECK;
+void ParseState::after_header() {
+    if (trim5p > 0) st = TRIM_SKIPNL;            // read_sequence: skip_newlines(); is.ignore(trim5p)   (parser.hpp:250-253)
+    else st = LOOP_CHECK;
 }
 
-// Feed one raw block through the record state machine, appending base-stream bytes to out_.
-void SeqFileParser::consume(const uint8_t* d, size_t n, bool* bad_fastq) {
-    const uint8_t stop = type_ == FASTA ? '>' : '+';
+bool ParseState::begin(uint8_t first_byte) {       // open_next_file: dispatch on the first byte (parser.hpp:171-185)
+    if (first_byte == '>') type = FASTA;
+    else if (first_byte == '@') type = FASTQ;
+    else return false;
+    st = HEADER; seq_len = 0;
+    return true;
+}
+
+// Truncated record?  (Deviation, documented in DESIGN.md: a last quality line of exactly the right length but without '\n'
+// is accepted; the reference throws there and its pool swallows the exception.)
+bool ParseState::end_ok() const {
+    if (type != FASTQ) return true;
+    if (st == QUAL_IGNORE) return quals + got == read_len;
+    if (st == QUAL_SKIPNL) return false;
+    if (st == PLUS_LINE) return seq_len + trim5p == 0;
+    return true;
+}
+
+void ParseState::consume(const uint8_t* d, size_t n, std::vector<uint8_t>& out, bool* bad_fastq) {
+    const uint8_t stop = type == FASTA ? '>' : '+';
     size_t i = 0;
     while (i < n) {
-        switch (st_) {
+        switch (st) {
         case HEADER:
         case PLUS_LINE: {                                   // ignore_line (parser.hpp:264-266)
             const uint8_t* nl = (const uint8_t*)memchr(d + i, '\n', n - i);
             if (!nl) { i = n; break; }
             i = (size_t)(nl - d) + 1;
-            if (st_ == HEADER) after_header();
+            if (st == HEADER) after_header();
             else {                                           // skip_quals(seq_len + trim5p)   (parser.hpp:237,274-289)
-                read_len_ = seq_len_ + trim5p_; quals_ = 0;
-                st_ = read_len_ ? QUAL_SKIPNL : QUAL_DONE_SKIPNL;
+                read_len = seq_len + trim5p; quals = 0;
+                st = read_len ? QUAL_SKIPNL : QUAL_DONE_SKIPNL;
             }
             break;
         }
         case TRIM_SKIPNL:
             if (d[i] == '\n') { ++i; break; }
-            trim_left_ = trim5p_; st_ = TRIM_IGNORE;
+            trim_left = trim5p; st = TRIM_IGNORE;
             break;
         case TRIM_IGNORE: {
-            size_t take = (size_t)std::min<uint64_t>(trim_left_, n - i);
-            i += take; trim_left_ -= take;
-            if (!trim_left_) st_ = LOOP_CHECK;
+            size_t take = (size_t)std::min<uint64_t>(trim_left, n - i);
+            i += take; trim_left -= take;
+            if (!trim_left) st = LOOP_CHECK;
             break;
         }
         case LOOP_CHECK:                                     // "while(... && is.peek() != stop)"   (parser.hpp:254)
             if (d[i] == stop) {
-                if (type_ == FASTA) { out_.push_back('N'); st_ = HEADER; }     // 'N' between records (parser.hpp:202)
-                else st_ = PLUS_LINE;
-            } else if (d[i] == '\n') st_ = FORCED_SKIPNL;    // blank line right after a header: the next line is read unconditionally
-            else st_ = SEQ_LINE;
+                if (type == FASTA) { out.push_back('N'); st = HEADER; }        // 'N' between records (parser.hpp:202)
+                else st = PLUS_LINE;
+            } else if (d[i] == '\n') st = FORCED_SKIPNL;     // blank line right after a header: the next line is read unconditionally
+            else st = SEQ_LINE;
             break;
         case FORCED_SKIPNL:
             if (d[i] == '\n') { ++i; break; }
-            st_ = SEQ_LINE;
+            st = SEQ_LINE;
             break;
         case SEQ_LINE: {                                     // is.get(): the rest of the line, verbatim   (parser.hpp:257)
             const uint8_t* nl = (const uint8_t*)memchr(d + i, '\n', n - i);
             size_t e = nl ? (size_t)(nl - d) : n;
-            out_.insert(out_.end(), d + i, d + e);
-            seq_len_ += e - i;
+            out.insert(out.end(), d + i, d + e);
+            seq_len += e - i;
             i = e;
-            if (nl) st_ = SEQ_SKIPNL;
+            if (nl) st = SEQ_SKIPNL;
             break;
         }
         case SEQ_SKIPNL:
             if (d[i] == '\n') { ++i; break; }
-            st_ = LOOP_CHECK;
+            st = LOOP_CHECK;
             break;
         case QUAL_SKIPNL:
             if (d[i] == '\n') { ++i; break; }
-            want_ = read_len_ - quals_ + 1; got_ = 0; st_ = QUAL_IGNORE;
+            want = read_len - quals + 1; got = 0; st = QUAL_IGNORE;
             break;
         case QUAL_IGNORE: {                                  // is.ignore(read_len - quals + 1, '\n')   (parser.hpp:280)
-            size_t lim = (size_t)std::min<uint64_t>(want_ - got_, n - i);
+            size_t lim = (size_t)std::min<uint64_t>(want - got, n - i);
             const uint8_t* nl = (const uint8_t*)memchr(d + i, '\n', lim);
             size_t take = nl ? (size_t)(nl - (d + i)) + 1 : lim;
-            i += take; got_ += take;
-            if (nl || got_ == want_) {
-                quals_ += got_; ++read_len_;                 // "if(is) ++read_len"
-                st_ = quals_ < read_len_ ? QUAL_SKIPNL : QUAL_DONE_SKIPNL;
+            i += take; got += take;
+            if (nl || got == want) {
+                quals += got; ++read_len;                    // "if(is) ++read_len"
+                st = quals < read_len ? QUAL_SKIPNL : QUAL_DONE_SKIPNL;
             }
             break;
         }
         case QUAL_DONE_SKIPNL:
             if (d[i] == '\n') { ++i; break; }
-            if (d[i] == '@') { out_.push_back('N'); seq_len_ = 0; st_ = HEADER; }   // parser.hpp:285-286,238-242
+            if (d[i] == '@') { out.push_back('N'); seq_len = 0; st = HEADER; }      // parser.hpp:285-286,238-242
             else { *bad_fastq = true; return; }
             break;
         }
@@ -126,29 +149,178 @@ int SeqFileParser::next(const uint8_t** p, size_t* n, std::string* err) {
         if (r < 0) { *err = "read error on " + path_; return KATGPU_ERR_IO; }
         if (r == 0) {
             eof_ = true;
-            if (type_ == FASTQ) {
-                // Truncated record.  (Deviation, documented in DESIGN.md: a last quality line of exactly the right length
-                // but without '\n' is accepted; the reference throws there and its pool swallows the exception.)
-                bool ok = true;
-                if (st_ == QUAL_IGNORE) ok = quals_ + got_ == read_len_;
-                else if (st_ == QUAL_SKIPNL) ok = false;
-                else if (st_ == PLUS_LINE) ok = seq_len_ + trim5p_ == 0;
-                if (!ok) { *err = "Invalid fastq sequence"; return KATGPU_ERR_FASTQ; }
-            }
+            if (!ps_.end_ok()) { *err = "Invalid fastq sequence"; return KATGPU_ERR_FASTQ; }
             break;
         }
-        size_t off = 0;
-        if (type_ == NONE) {                                  // open_next_file: dispatch on the first byte (parser.hpp:171-185)
-            if (raw_[0] == '>') type_ = FASTA;
-            else if (raw_[0] == '@') type_ = FASTQ;
-            else { *err = "Unsupported format"; return KATGPU_ERR_FORMAT; }
-            st_ = HEADER; seq_len_ = 0;
-        }
+        if (ps_.type == ParseState::NONE && !ps_.begin(raw_[0])) { *err = "Unsupported format"; return KATGPU_ERR_FORMAT; }
         bool bad = false;
-        consume(raw_.data() + off, (size_t)r - off, &bad);
+        ps_.consume(raw_.data(), (size_t)r, out_, &bad);
         if (bad) { *err = "Invalid fastq sequence"; return KATGPU_ERR_FASTQ; }
     }
     *p = out_.data(); *n = out_.size();
+    return KATGPU_OK;
+}
+
+// ------------------------------------------------------------------ parallel front end ------------------------------
+
+namespace {
+
+uint64_t env_u64(const char* name, uint64_t def) {
+    const char* v = getenv(name);
+    return v && *v ? strtoull(v, nullptr, 10) : def;
+}
+
+// First guessed record start at file offset >= from, looking only at buf (which holds file bytes [buf_off, buf_off + len)).
+// Returns the file offset, or -1 when none is certain inside the buffer.
+int64_t find_cut(ParseState::Type type, const uint8_t* buf, int64_t buf_off, int64_t len, int64_t from) {
+    int64_t p = from - buf_off;
+    if (p < 1) p = 1;                                        // a cut needs the '\n' before it
+    const uint8_t mark = type == ParseState::FASTA ? '>' : '@';
+    while (p < len) {
+        const uint8_t* nl = (const uint8_t*)memchr(buf + p - 1, '\n', (size_t)(len - (p - 1)));
+        if (!nl) return -1;
+        p = (nl - buf) + 1;                                  // first byte of the next line
+        if (p >= len) return -1;
+        if (buf[p] != mark) { ++p; continue; }
+        if (type == ParseState::FASTA) return buf_off + p;
+        const uint8_t* l1 = (const uint8_t*)memchr(buf + p, '\n', (size_t)(len - p));                 // end of the header line
+        if (!l1) return -1;
+        const uint8_t* l2 = (const uint8_t*)memchr(l1 + 1, '\n', (size_t)(len - (l1 + 1 - buf)));      // end of the sequence line
+        if (!l2 || l2 + 1 >= buf + len) return -1;
+        if (l2[1] == '+') return buf_off + p;
+        ++p;
+    }
+    return -1;
+}
+
+struct Segment {
+    int64_t s = -1, e = -1;          // accepted range [s, e) in file offsets; -1: no certain cut
+    std::vector<uint8_t> out;
+    ParseState end;
+    bool bad = false, io_error = false;
+};
+
+}  // namespace
+
+int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err) {
+    if (trim5p) return -1;                                   // is.ignore(trim5p) swallows line starts: keep that case on the streaming path
+    struct stat st;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return -1;
+    const int64_t size = (int64_t)st.st_size;
+    if ((uint64_t)size < env_u64("KATGPU_INGEST_MIN_BYTES", (uint64_t)256 << 20)) return -1;
+    const int64_t seg = (int64_t)std::max<uint64_t>(16, env_u64("KATGPU_INGEST_SEGMENT", (uint64_t)16 << 20));
+    const int64_t margin = (int64_t)std::max<uint64_t>(16, env_u64("KATGPU_INGEST_MARGIN", (uint64_t)4 << 20));
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(env_u64("KATGPU_INGEST_THREADS", std::min(hw, 64u)), 256));
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    uint8_t head[2] = {0, 0};
+    if (pread(fd, head, 2, 0) != 2) return -1;
+    if (head[0] == 0x1f && head[1] == 0x8b) return -1;       // gzip: one serial stream
+    ParseState state;                                        // the machine's TRUE state at file offset `pos`
+    if (!state.begin(head[0])) return -1;                    // the streaming path words the error
+    const ParseState::Type type = state.type;
+    int64_t pos = 0;
+
+    // one wave = T consecutive nominal segments starting at `from`; every thread reads its own bytes (parallel I/O too).
+    // Raw and output buffers live in two sets that successive waves alternate between (a wave is parsed while the previous
+    // one is handed over): fresh 64 MB vectors per piece would spend more time in page faults than in parsing.
+    std::vector<std::vector<uint8_t>> raws(2 * (size_t)T);
+    std::vector<std::shared_ptr<std::vector<Segment>>> sets = {std::make_shared<std::vector<Segment>>(T), std::make_shared<std::vector<Segment>>(T)};
+    unsigned parity = 0;
+    auto parse_wave = [&](int64_t from, const ParseState& first_state, unsigned set) {
+        auto segs = sets[set];
+        std::vector<std::thread> team;
+        for (unsigned i = 0; i < T; ++i) {
+            team.emplace_back([&, i, from, first_state]() {
+                Segment& g = (*segs)[i];
+                g.s = g.e = -1; g.bad = g.io_error = false; g.out.clear();
+                const int64_t ns = from + (int64_t)i * seg, ne = std::min(size, ns + seg);
+                if (ns >= size) { g.s = g.e = size; g.end = first_state; return; }
+                const int64_t b0 = i == 0 ? ns : ns - 1, b1 = std::min(size, ne + margin);
+                std::vector<uint8_t>& raw = raws[(size_t)set * T + i];
+                if (raw.size() < (size_t)(b1 - b0)) raw.resize((size_t)(b1 - b0));
+                int64_t got = 0;
+                while (got < b1 - b0) {
+                    ssize_t r = pread(fd, raw.data() + got, (size_t)(b1 - b0 - got), b0 + got);
+                    if (r <= 0) { g.io_error = true; return; }
+                    got += r;
+                }
+                g.s = i == 0 ? ns : find_cut(type, raw.data(), b0, b1 - b0, ns);
+                if (g.s < 0 && b1 == size) g.s = size;       // no record starts in the rest of the file
+                g.e = ne >= size ? size : find_cut(type, raw.data(), b0, b1 - b0, ne);
+                if (g.e < 0 && b1 == size) g.e = size;
+                if (g.s < 0 || g.e < 0 || g.e < g.s) { g.s = g.e = -1; return; }
+                ParseState ps = first_state;
+                if (i > 0) {                                 // assumed: a record starts here, i.e. the piece before ended at a boundary
+                    ps = ParseState(); ps.type = type;
+                    ps.st = type == ParseState::FASTA ? ParseState::LOOP_CHECK : ParseState::QUAL_DONE_SKIPNL;
+                }
+                g.out.reserve((size_t)(g.e - g.s));
+                ps.consume(raw.data() + (g.s - b0), (size_t)(g.e - g.s), g.out, &g.bad);
+                g.end = ps;
+            });
+        }
+        for (auto& th : team) th.join();
+        return segs;
+    };
+
+    auto serial_rest = [&]() -> int {                        // from `pos`, in `state`, to the end of the file
+        std::vector<uint8_t> raw((size_t)16 << 20), out;
+        while (pos < size) {
+            ssize_t r = pread(fd, raw.data(), (size_t)std::min<int64_t>((int64_t)raw.size(), size - pos), pos);
+            if (r <= 0) { *err = std::string("read error on ") + path; return KATGPU_ERR_IO; }
+            out.clear();
+            bool bad = false;
+            state.consume(raw.data(), (size_t)r, out, &bad);
+            if (bad) { *err = "Invalid fastq sequence"; return KATGPU_ERR_FASTQ; }
+            pos += r;
+            if (!out.empty()) { int rc = sink(out.data(), out.size()); if (rc) return rc; }
+        }
+        return KATGPU_OK;
+    };
+
+    const bool trace = getenv("KATGPU_TRACE") != nullptr;
+    size_t pieces = 0;
+    auto wave = parse_wave(0, state, parity);
+    while (pos < size) {
+        // accept the longest prefix of the wave whose assumptions hold
+        size_t ok = 0;
+        ParseState st_after = state;
+        int64_t p_after = pos;
+        for (; ok < wave->size(); ++ok) {
+            const Segment& g = (*wave)[ok];
+            if (g.io_error) { *err = std::string("read error on ") + path; return KATGPU_ERR_IO; }
+            if (g.s != p_after || g.e < 0) break;
+            if (ok > 0 && g.s < size && !st_after.at_record_boundary()) break;      // the guess at g.s was wrong
+            if (g.bad) {
+                if (ok == 0 || st_after.at_record_boundary()) { *err = "Invalid fastq sequence"; return KATGPU_ERR_FASTQ; }
+                break;
+            }
+            st_after = g.s < size ? g.end : st_after;
+            p_after = g.e;
+        }
+        // the next wave is parsed while this one is handed over
+        std::future<std::shared_ptr<std::vector<Segment>>> next;
+        const bool whole = ok == wave->size();
+        if (whole && p_after < size) { parity ^= 1; next = std::async(std::launch::async, parse_wave, p_after, st_after, parity); }
+        for (size_t i = 0; i < ok; ++i) {
+            const Segment& g = (*wave)[i];
+            if (!g.out.empty()) { int rc = sink(g.out.data(), g.out.size()); if (rc) { if (next.valid()) next.wait(); return rc; } }
+        }
+        pos = p_after; state = st_after;
+        pieces += ok;
+        if (!whole) {
+            if (trace) fprintf(stderr, "[katgpu] ingest %s: %zu pieces by the team, streaming from offset %lld of %lld\n", path, pieces, (long long)pos, (long long)size);
+            int rc = serial_rest(); if (rc) return rc;
+            pieces = 0;
+            break;
+        }
+        if (pos < size) wave = next.get();
+    }
+    if (trace && pieces) fprintf(stderr, "[katgpu] ingest %s: %zu pieces by the team (%u threads), all accepted\n", path, pieces, T);
+    if (!state.end_ok()) { *err = "Invalid fastq sequence"; return KATGPU_ERR_FASTQ; }
     return KATGPU_OK;
 }
 
@@ -158,14 +330,19 @@ extern "C" int katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** ba
     static thread_local std::string last;
     if (!path || !bases || !n) return KATGPU_ERR_INVALID_ARG;
     *bases = nullptr; *n = 0;
-    kg::SeqFileParser parser;
     std::vector<uint8_t> all;
-    int rc = parser.open(path, trim5p, &last);
-    while (!rc) {
-        const uint8_t* p; size_t got;
-        rc = parser.next(&p, &got, &last);
-        if (rc || !got) break;
-        all.insert(all.end(), p, p + got);
+    // large plain files: the thread team (same bytes out); everything else, and whatever the team declines: the streaming parser
+    int rc = kg::parse_file_parallel(path, trim5p, [&](const uint8_t* p, size_t got) { all.insert(all.end(), p, p + got); return 0; }, &last);
+    if (rc < 0) {
+        all.clear();
+        kg::SeqFileParser parser;
+        rc = parser.open(path, trim5p, &last);
+        while (!rc) {
+            const uint8_t* p; size_t got;
+            rc = parser.next(&p, &got, &last);
+            if (rc || !got) break;
+            all.insert(all.end(), p, p + got);
+        }
     }
     if (rc) { if (err_msg) *err_msg = last.c_str(); return rc; }
     *bases = (uint8_t*)malloc(all.size() ? all.size() : 1);

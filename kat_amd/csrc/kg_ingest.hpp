@@ -10,12 +10,38 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
 namespace kg {
 
 uint64_t file_size_or_zero(const char* path);
+
+// The record state machine, separated from the file it reads so that ranges of a file can be parsed independently
+// (parse_file_parallel) with the same code as the streaming parser.
+struct ParseState {
+    enum Type { NONE, FASTA, FASTQ };
+    enum State { HEADER, TRIM_SKIPNL, TRIM_IGNORE, LOOP_CHECK, FORCED_SKIPNL, SEQ_LINE, SEQ_SKIPNL, PLUS_LINE,
+                 QUAL_SKIPNL, QUAL_IGNORE, QUAL_DONE_SKIPNL };
+    Type type = NONE;
+    State st = HEADER;
+    uint32_t trim5p = 0;
+    uint64_t trim_left = 0;
+    uint64_t seq_len = 0;                  // sequence bytes of the current FASTQ record
+    uint64_t read_len = 0, quals = 0;      // skip_quals bookkeeping
+    uint64_t want = 0, got = 0;
+
+    // Feed one raw block through the machine, appending base-stream bytes to out.  *bad_fastq: "Invalid fastq sequence".
+    void consume(const uint8_t* d, size_t n, std::vector<uint8_t>& out, bool* bad_fastq);
+    bool begin(uint8_t first_byte);        // dispatch on the first byte of the file; false: "Unsupported format"
+    bool end_ok() const;                   // end of file: is the last record complete?
+    // Will a '>' ('@' for FASTQ) as the next byte start a record?  (After a sequence line the machine sits in SEQ_SKIPNL until
+    // it sees a byte that is not a newline, and then looks at it exactly as LOOP_CHECK does.)
+    bool at_record_boundary() const { return type == FASTA ? (st == LOOP_CHECK || st == SEQ_SKIPNL) : st == QUAL_DONE_SKIPNL; }
+private:
+    void after_header();
+};
 
 class SeqFileParser {
 public:
@@ -30,23 +56,19 @@ public:
     int next(const uint8_t** p, size_t* n, std::string* err);
 
 private:
-    enum Type { NONE, FASTA, FASTQ };
-    enum State { HEADER, TRIM_SKIPNL, TRIM_IGNORE, LOOP_CHECK, FORCED_SKIPNL, SEQ_LINE, SEQ_SKIPNL, PLUS_LINE,
-                 QUAL_SKIPNL, QUAL_IGNORE, QUAL_DONE_SKIPNL };
-    void consume(const uint8_t* d, size_t n, bool* bad_fastq);
-    void after_header();
-
     void* gz_ = nullptr;
     std::string path_;
-    Type type_ = NONE;
-    State st_ = HEADER;
+    ParseState ps_;
     bool eof_ = false;
-    uint32_t trim5p_ = 0;
-    uint64_t trim_left_ = 0;
-    uint64_t seq_len_ = 0;                 // sequence bytes of the current FASTQ record
-    uint64_t read_len_ = 0, quals_ = 0;    // skip_quals bookkeeping
-    uint64_t want_ = 0, got_ = 0;
     std::vector<uint8_t> raw_, out_;
 };
+
+// Multi-threaded front end for large plain (not gzip) regular files: the file is cut at record starts, the pieces are parsed
+// by a thread team with the state machine above and handed to `sink` in file order.  A cut is only a guess ("\n>" for
+// FASTA; "\n@", a line, then "\n+" for FASTQ): a piece is accepted only if the piece before it -- parsed from a state known to
+// be right -- ends in the record-boundary state exactly where the piece begins; otherwise the rest of the file goes through
+// the machine serially from that known state.  The output is therefore byte-identical to the streaming parser's whatever the
+// file looks like.  Returns a katgpu_status, or -1 when the file does not qualify (the caller then streams it).
+int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err);
 
 }  // namespace kg

@@ -11,6 +11,23 @@ from tests import naive
 from tests.test_oracle_vs_naive import write_messy_fasta, write_messy_fastq
 
 
+# Every test runs four times: through the streaming parser, and through the thread team (kg_ingest.hpp:
+# parse_file_parallel) with segment sizes that cut these small files into many pieces -- guessed record starts that are
+# wrong (blank line after a header, '@' qualities, multi-line FASTQ) must be caught and the output must not change.
+@pytest.fixture(autouse=True, params=["stream", "seg37", "seg1000_margin64", "seg200k"])
+def ingest_mode(request, monkeypatch):
+    mode = request.param
+    if mode == "stream":
+        monkeypatch.setenv("KATGPU_INGEST_MIN_BYTES", str(1 << 60))
+    else:
+        seg, margin = {"seg37": (37, 4096), "seg1000_margin64": (1000, 64), "seg200k": (200_000, 1 << 20)}[mode]
+        monkeypatch.setenv("KATGPU_INGEST_MIN_BYTES", "0")
+        monkeypatch.setenv("KATGPU_INGEST_SEGMENT", str(seg))
+        monkeypatch.setenv("KATGPU_INGEST_MARGIN", str(margin))
+        monkeypatch.setenv("KATGPU_INGEST_THREADS", "5")
+    return mode
+
+
 def stream_of(path):
     return kat_amd.parse_file(str(path)).tobytes()
 
@@ -95,3 +112,27 @@ def test_errors(ko, tmp_path):
         with pytest.raises(ko.OracleError) as oi:
             ko.parse_file(str(p))
         assert oi.value.code == 3, name
+
+
+def test_team_accepts_clean_files_and_falls_back_on_wrong_guesses(ko, tmp_path, ingest_mode, monkeypatch, capfd):
+    """What the thread team reports (KATGPU_TRACE): clean files are parsed piece by piece; a file whose guessed record starts
+    are wrong is handed to the streaming machine from the last state known to be right."""
+    if ingest_mode != "seg1000_margin64":
+        pytest.skip("one parallel geometry is enough here")
+    monkeypatch.setenv("KATGPU_TRACE", "1")
+    monkeypatch.setenv("KATGPU_INGEST_MARGIN", "4096")
+    rng = np.random.default_rng(5)
+    recs = ["".join(rng.choice(list("ACGTN"), int(rng.integers(30, 200)))) for _ in range(400)]
+    fa, fq = tmp_path / "clean.fa", tmp_path / "clean.fq"
+    fa.write_text("".join(">r%d\n%s\n" % (i, r) for i, r in enumerate(recs)))
+    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (i, r, "@" * len(r)) for i, r in enumerate(recs)))      # qualities made of '@'
+    for p in (fa, fq):
+        capfd.readouterr()
+        assert stream_of(p) == "N".join(recs).encode()
+        err = capfd.readouterr().err
+        assert "all accepted" in err and "streaming from offset" not in err, err
+    trap = tmp_path / "trap.fa"                      # every record: header, blank line, then a SEQUENCE line that starts with '>'
+    trap.write_text("".join(">h%d\n\n>%s\n" % (i, r) for i, r in enumerate(recs)))
+    capfd.readouterr()
+    assert stream_of(trap) == ko.parse_file(str(trap)).tobytes() == "N".join(">" + r for r in recs).encode()
+    assert "streaming from offset" in capfd.readouterr().err
