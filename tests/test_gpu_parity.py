@@ -325,3 +325,29 @@ def test_comp_join_form(engine, ko):
         t2.merge_host([key], [c + (1 << 33)]); o2.add(key, c + (1 << 33))
     got, want = kat_amd.comp(t1, t2), ko.comp(o1, o2)
     assert all(np.array_equal(x, y) for x, y in zip(got, want))
+
+
+@pytest.mark.parametrize("seg", [300, 5000])
+def test_count_files_through_the_ingest_thread_team(engine, ko, refdata, tmp_path, monkeypatch, seg):
+    """katgpu_count_files with the multi-threaded front end (kg_ingest.hpp: parse_file_parallel) feeding the staged host path:
+    same table as the oracle, for the reference's FASTQ pair and for a FASTA with k-mers across line and piece cuts."""
+    monkeypatch.setenv("KATGPU_INGEST_MIN_BYTES", "0")
+    monkeypatch.setenv("KATGPU_INGEST_SEGMENT", str(seg))
+    monkeypatch.setenv("KATGPU_INGEST_MARGIN", "4096")
+    monkeypatch.setenv("KATGPU_INGEST_THREADS", "7")
+    g = synth.genome(30000, seed=4)
+    fa = tmp_path / "contigs.fa"
+    with open(fa, "wb") as f:
+        for i in range(0, g.size, 2500):
+            f.write(b">c%d\n" % i)
+            c = g[i:i + 2500].tobytes()
+            for j in range(0, len(c), 61):
+                f.write(c[j:j + 61] + b"\n")
+    paths = [os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq"), str(fa)]
+    for k, canonical in ((27, True), (17, False)):
+        t = engine.count(paths, k, canonical)
+        o = ko.Table(k, canonical).count_files(paths)
+        gk, gc = t.dump_sorted()
+        ok_, oc = o.dump_sorted()
+        assert np.array_equal(gk, ok_) and np.array_equal(gc, oc)
+        t.free()
