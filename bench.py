@@ -231,7 +231,7 @@ def main():
                 "alg_bytes_per_launch": int(alg_bytes_step * a.steps / rounds), "per_kernel": per_kernel}
         kernels_ms = {n: round(v["ms"] / a.steps, 3) for n, v in prof.items() if v["launches"]}
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:                  # the host-core baseline is an N = 1 figure
             cpu = cpu_baseline(eng, a, k, L)
         line = {
             "metric": "k-mers/sec (whole node) for kat comp k=%d, reads vs assembly" % k,
