@@ -7,20 +7,28 @@
  * product (kat_amd/, include/) may include, link, import or execute anything in oracle/.
  *
  * PINNING STATUS (see DESIGN.md "Oracle"):
- *   - The reference itself is UNBUILDABLE in this image: every translation unit on the path
- *     includes the autoconf-generated <config.h> (e.g. lib/src/input_handler.cc:19,
- *     deps/jellyfish-2.2.0/include/jellyfish/mer_dna.hpp:21) and autotools are absent, so no
- *     oracle/_ref binary exists and no reference output could be generated here.
- *   - Pinned against the known answers the reference's own tests hold for this path:
+ *   - The reference's TOOL DRIVERS are unbuildable in this image: src/*.cc, lib/src/input_handler.cc and jellyfish_helper.cc
+ *     include the autoconf-generated <config.h> unconditionally (e.g. lib/src/input_handler.cc:19), as do Jellyfish's
+ *     lib/allocators_mmap.cc, misc.cc and storage.cc (so its hash_counter / large_hash_array cannot be driven either), and
+ *     autotools are absent.  No `kat` binary exists here.
+ *   - The HEART of the semantics does build, from the sources where they lie and with nothing stubbed (oracle/Makefile `ref`,
+ *     drivers in oracle/ref/): Jellyfish 2.2.0's parser + mer_iterator + mer_dna + file_header / binary_reader
+ *     (oracle/_ref/jf_ref) and KAT's CompCounters, distance metrics, SparseMatrix, str_utils (oracle/_ref/kat_ref_parts).
+ *     tests/test_oracle_vs_reference.py checks this oracle against that real code: the k-mer multiset of every input (the
+ *     reference's test data, generated messy FASTA/FASTQ/gzip, edge files), k-mer arithmetic for k = 1..32, the .jf fixture
+ *     and .jf files written by the product as the reference's reader sees them, CompCounters::printCounts with its five
+ *     distance metrics byte for byte, the counter arithmetic of Comp::compareSlice, SparseMatrix's bounds behaviour, and
+ *     validKmer / gcCount.  tests/golden/reference_vectors.json keeps the digests for the fixed inputs.
+ *   - Also pinned against the known answers the reference's own tests hold for this path:
  *       tests/check_jellyfish.cc:38-116  (.jf header fields, 1889 records, k-mer lookups 3/1/1/1 and
  *                                         canonical lookups 3/1/0/0 on tests/data/ecoli.header.jf27)
  *       tests/check_compcounters.cc:30-62 (CompCounters arithmetic: distinct 4, total 60)
  *       tests/data/kat.hist, scripts/test/resources/{hist1.hist,gcp1.mx,spectracn1.mx} (file formats)
- *   - The reference holds NO golden hist/.mx/.stats outputs (its CLI tests only check exit codes,
- *     tests/test_hist.sh, test_gcp.sh, test_comp.sh).  End-to-end numbers quoted in SURVEY.md 8(c)
- *     (recorded by the survey stage from a hand-built reference binary) are used as additional
- *     known answers in tests/test_oracle_known_answers.py, with that provenance stated there.
- *     Beyond those, end-to-end parity of the text outputs is UNPINNED.
+ *   - What remains a restatement only (the reference holds NO golden hist/.mx/.stats outputs; its CLI tests check exit codes):
+ *     the bodies of Histogram::bin, Gcp::analyse, Comp::compare (binning, scaling, which matrix a k-mer lands in), the text
+ *     headers of the .hist / .mx files, and `kat sect` / `kat cold` end to end.  End-to-end numbers quoted in SURVEY.md 8(c)
+ *     (recorded by the survey stage from a hand-built reference binary) serve as additional known answers in
+ *     tests/test_oracle_known_answers.py, with that provenance stated there.
  */
 #ifndef KORACLE_H
 #define KORACLE_H
