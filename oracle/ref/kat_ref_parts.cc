@@ -10,6 +10,8 @@
 //   kat_ref_parts distance            stdin: N, spectrum a, spectrum b  ->  the five metrics, default stream precision
 //   kat_ref_parts matrix R C          stdin: "i j v" triples (inc)  ->  getMaxVal, then printMatrix
 //   kat_ref_parts strutils            stdin: one string per line  ->  "validKmer gcCount"
+//   kat_ref_parts mxread <file.mx>    the reference's own readers on a matrix file: matrix_metadata_extractor (every key) and
+//                                     SparseMatrix(path): rows, columns, getMaxVal, sum of all cells
 #include <iostream>
 #include <memory>
 #include <string>
@@ -22,6 +24,7 @@
 #include <kat/sparse_matrix.hpp>
 #include <kat/comp_counters.hpp>
 #include <kat/distance_metrics.hpp>
+#include <kat/matrix_metadata_extractor.hpp>
 
 using std::cin;
 using std::cout;
@@ -81,6 +84,18 @@ int main(int argc, char* argv[]) {
         while (cin >> i >> j >> v) m.inc(i, j, v);
         cout << m.getMaxVal() << endl;
         m.printMatrix(cout);
+        return 0;
+    }
+    if (mode == "mxread" && argc >= 3) {
+        const path p(argv[2]);
+        cout << mme::getNumeric(p, mme::KEY_NB_COLUMNS) << ' ' << mme::getNumeric(p, mme::KEY_NB_ROWS) << ' ' << mme::getNumeric(p, mme::KEY_MAX_VAL) << ' '
+             << mme::getNumeric(p, mme::KEY_TRANSPOSE) << ' ' << mme::getNumeric(p, mme::KEY_KMER) << endl;
+        cout << mme::getString(p, mme::KEY_TITLE) << endl << mme::getString(p, mme::KEY_X_LABEL) << endl << mme::getString(p, mme::KEY_Y_LABEL) << endl
+             << mme::getString(p, mme::KEY_Z_LABEL) << endl << mme::getString(p, mme::KEY_INPUT_1) << endl << mme::getString(p, mme::KEY_INPUT_2) << endl;
+        kat::SM64 m(p);
+        unsigned long long sum = 0;
+        for (uint32_t i = 0; i < m.height(); ++i) for (uint32_t j = 0; j < m.width(); ++j) sum += m.get(j, i);
+        cout << m.width() << ' ' << m.height() << ' ' << m.getMaxVal() << ' ' << sum << endl;
         return 0;
     }
     if (mode == "strutils") {

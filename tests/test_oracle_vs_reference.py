@@ -230,3 +230,27 @@ def test_sparse_matrix_and_str_utils(ko):
     t.add(ko.encode("ACGT"), 3)
     counts, gcs = ko.profile(t, "ACGTNACGTacgt", False)
     assert gcs.tolist() == [2, -1, -1, -1, -1, 2, 2, 2, 2, 2] and counts.tolist()[0] == 3 and counts.tolist()[5] == 3
+
+
+@have_ref
+def test_matrix_files_as_the_reference_reads_them(ko, refdata, tmp_path):
+    """The .mx files of `kat gcp` and `kat comp` (oracle writers == the product's CLI bytes, tests/test_gpu_cli.py) go through the
+    reference's own readers: matrix_metadata_extractor finds every key, SparseMatrix(path) loads the body with the right shape,
+    MaxVal and cell sum."""
+    r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
+    t1, t2 = ko.Table(17, True).count_files([r1]), ko.Table(17, True).count_files([r2])
+    g = t1.gcp(1.0, 200)
+    p = str(tmp_path / "g.mx")
+    ko.write_gcp(p, 17, [r1], 200, g)
+    rc, out = ref(KAT_REF, ["mxread", p])
+    lines = out.decode().split("\n")
+    assert rc == 0 and lines[0].split() == ["201", "17", str(int(g.max())), "0", "17"]
+    assert lines[1:5] == ["K-mer coverage vs GC count plot for: ecoli_r1.1K.fastq", "17-mer frequency", "GC count", "# distinct 17-mers"] and lines[5] == r1
+    assert lines[7].split() == ["17", "201", str(int(g.max())), str(int(g.sum()))]
+    mx, cc, sp = ko.comp(t1, t2, 1.0, 1.0, 60, 40)
+    ko.write_comp(str(tmp_path / "c"), 17, [r1], [r2], 60, 40, mx, cc, sp)
+    rc, out = ref(KAT_REF, ["mxread", str(tmp_path / "c-main.mx")])
+    lines = out.decode().split("\n")
+    assert rc == 0 and lines[0].split() == ["40", "60", str(int(mx.max())), "1", "17"]
+    assert lines[1] == "K-mer comparison plot" and lines[5] == r1 and lines[6] == r2
+    assert lines[7].split() == ["60", "40", str(int(mx.max())), str(int(mx.sum()))]
