@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="sync + print per-phase wall time (diagnostic; perturbs the timing)")
     ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
+    ap.add_argument("--hint-scale", type=float, default=1.0, help="diagnostic: scale the tables' size hints (e.g. 0.02: grown on the way)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: diagnostic only -- ranks may share one GPU, records are staged through host memory")
     return ap.parse_args()
@@ -135,6 +136,8 @@ def main():
     inst_asm_total = max(0, a.genome - n_contigs * (k - 1))
     hint1 = int(expected_distinct(inst_reads, a.genome, k, a.err_ppm) / 0.62) + (1 << 20)
     hint2 = int(asm_bases_local / 0.62) + (1 << 20)
+    if a.hint_scale != 1.0:
+        hint1, hint2 = max(1024, int(hint1 * a.hint_scale)), max(1024, int(hint2 * a.hint_scale))
 
     results = {}
 
