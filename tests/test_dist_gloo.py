@@ -123,14 +123,13 @@ def _worker(rank, world, port, out_dir, mixed_grids):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mixed_grids", [False, True])
-def test_two_rank_exchange_matches_single_process(ko, tmp_path, mixed_grids):
-    world = 2
+@pytest.mark.parametrize("world,mixed_grids", [(2, False), (2, True), (3, False), (4, True)])
+def test_sharded_exchange_matches_single_process(ko, tmp_path, world, mixed_grids):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mixed_grids), nprocs=world, join=True)
     got = np.load(tmp_path / "sharded.npz")
     g = synth.genome(G, seed=11)
     t1 = ko.Table(K, True).count_bases(synth.reads(g, 0, N_READS, seed=1))
-    t1.add(ko.encode("ACGT" * 5 + "A"), (1 << 34) + 1)                     # both ranks' out-of-band amounts
+    t1.add(ko.encode("ACGT" * 5 + "A"), world * (1 << 33) + world * (world - 1) // 2)      # every rank's out-of-band amount
     t2 = ko.Table(K, True).count_bases(synth.stream_of_contigs(g, CONTIG))
     mx, cc, sp = ko.comp(t1, t2, 1.0, 1.0, 101, 101)
     assert np.array_equal(got["mx"], mx) and np.array_equal(got["cc"], cc) and np.array_equal(got["sp"], sp)
