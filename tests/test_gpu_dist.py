@@ -66,15 +66,14 @@ def _worker(rank, world, port, out_dir, mode):
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["same", "mixed"])
-def test_two_ranks_one_gpu_match_single_process(engine, ko, tmp_path, mode):
+@pytest.mark.parametrize("world,mode", [(2, "same"), (2, "mixed"), (3, "same")])
+def test_ranks_sharing_one_gpu_match_single_process(engine, ko, tmp_path, world, mode):
     from kat_amd import synth
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     got = np.load(tmp_path / "sharded.npz")
     g = synth.genome(G, seed=11)
     o1 = ko.Table(K, True).count_bases(synth.reads(g, 0, N_READS, seed=1))
-    o1.add(12345, (1 << 34) + 1)
+    o1.add(12345, world * (1 << 33) + world * (world - 1) // 2)
     o2 = ko.Table(K, True).count_bases(synth.stream_of_contigs(g, CONTIG))
     mx, cc, sp = ko.comp(o1, o2, 1.0, 1.0, 201, 101)
     assert np.array_equal(got["cc"], cc) and np.array_equal(got["mx"], mx) and np.array_equal(got["sp"], sp)
