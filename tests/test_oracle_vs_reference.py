@@ -254,3 +254,23 @@ def test_matrix_files_as_the_reference_reads_them(ko, refdata, tmp_path):
     assert rc == 0 and lines[0].split() == ["40", "60", str(int(mx.max())), "1", "17"]
     assert lines[1] == "K-mer comparison plot" and lines[5] == r1 and lines[6] == r2
     assert lines[7].split() == ["60", "40", str(int(mx.max())), str(int(mx.sum()))]
+
+
+@have_ref
+def test_product_ingest_against_the_reference_parser(tmp_path):
+    """The PRODUCT's host ingest (kat_amd.parse_file: what katgpu_count ships to the GPU), counted window by window in Python,
+    is the k-mer multiset of the reference's parser + iterator -- no oracle in between."""
+    from tests import naive
+    rng = np.random.default_rng(21)
+    fa, fq, fqm = tmp_path / "m.fa", tmp_path / "m.fq", tmp_path / "mm.fq"
+    write_messy_fasta(str(fa), rng, n_rec=12)
+    write_messy_fastq(str(fq), rng, n_rec=80)
+    write_messy_fastq(str(fqm), rng, n_rec=80, multiline=True)
+    trap = tmp_path / "trap.fa"
+    trap.write_bytes(b">a\n\n>ACGTACGTTG\nGGAACCTT\n>c\r\nTTGGCCAAGT\r\n")
+    for p in (fa, fq, fqm, trap):
+        stream = kat_amd.parse_file(str(p)).tobytes().decode("latin-1")
+        for k, canonical in ((6, True), (13, False)):
+            got = naive.count_string(stream, k, canonical)
+            text = "".join("%s %d\n" % (w, c) for w, c in sorted(got.items())).encode()
+            assert text == ref_kmers([str(p)], k, canonical), (p, k, canonical)
