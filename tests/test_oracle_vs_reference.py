@@ -274,3 +274,18 @@ def test_product_ingest_against_the_reference_parser(tmp_path):
             got = naive.count_string(stream, k, canonical)
             text = "".join("%s %d\n" % (w, c) for w, c in sorted(got.items())).encode()
             assert text == ref_kmers([str(p)], k, canonical), (p, k, canonical)
+
+
+@have_ref
+def test_documented_deviations_on_truncated_fastq(ko, tmp_path):
+    """DESIGN.md 4, "Known deviations": what the reference really does there.  Its producer thread throws "Invalid fastq sequence"
+    and the pool swallows it together with the buffer being filled (here the whole 4 KB file): no k-mers, exit status 0.  The
+    product counts the complete records of a file that merely lacks its final newline, and REPORTS a truncated record."""
+    nf, tr = tmp_path / "nf.fq", tmp_path / "tr.fq"
+    nf.write_bytes(b"@r\nACGTA\n+\nIIIII\n@s\nGGACC\n+\nIIIII")            # complete, no final newline
+    tr.write_bytes(b"@r\nACGTA\n+\nIIIII\n@s\nGGACC\n+\nIII")              # quality line cut short
+    assert ref_kmers([str(nf)], 3, False) == b"" and ref_kmers([str(tr)], 3, False) == b""
+    assert kat_amd.parse_file(str(nf)).tobytes() == b"ACGTANGGACC" == ko.parse_file(str(nf)).tobytes()
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        kat_amd.parse_file(str(tr))
+    assert ei.value.code == 4
