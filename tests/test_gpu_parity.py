@@ -351,3 +351,29 @@ def test_count_files_through_the_ingest_thread_team(engine, ko, refdata, tmp_pat
         ok_, oc = o.dump_sorted()
         assert np.array_equal(gk, ok_) and np.array_equal(gc, oc)
         t.free()
+
+
+JF_REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "jf_ref")
+
+
+@pytest.mark.skipif(not os.access(JF_REF, os.X_OK), reason="oracle/_ref not built (no /root/reference at build time)")
+def test_hip_table_against_the_reference_parser_directly(engine, ko, refdata, tmp_path):
+    """No oracle in between: the HIP table's (k-mer, count) dump equals what the REAL Jellyfish 2.2.0 parser + mer_iterator of the
+    reference deliver (oracle/_ref/jf_ref, compiled from /root/reference's sources) for the same files."""
+    import subprocess
+    from tests.test_oracle_vs_naive import write_messy_fasta, write_messy_fastq
+    rng = np.random.default_rng(33)
+    fa, fq = tmp_path / "m.fa", tmp_path / "mm.fq"
+    write_messy_fasta(str(fa), rng)
+    write_messy_fastq(str(fq), rng, multiline=True)
+    groups = [[os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")], [os.path.join(refdata, "sect_length_test.fa")],
+              [str(fa), str(fq)]]
+    for paths in groups:
+        for k, canonical in ((27, True), (31, False), (11, True)):
+            out = subprocess.run([JF_REF, "kmers", str(k), str(int(canonical))] + paths, capture_output=True, timeout=300)
+            assert out.returncode == 0
+            t = engine.count(paths, k, canonical)
+            keys, counts = t.dump_sorted()
+            got = "".join("%s %d\n" % (ko.decode(int(a), k), int(b)) for a, b in zip(keys, counts)).encode()
+            assert got == out.stdout, (paths, k, canonical)
+            t.free()
