@@ -145,3 +145,28 @@ def test_cli_exit_codes(refdata, tmp_path):
     r = run(["comp", "-m", "27", "-g", "-H", "1000", os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "sect_test.fa")], tmp_path)
     assert r.returncode == 5 and "Hash full" in r.stderr
     assert run(["filter", "x"], tmp_path).returncode == 1                        # a mode this build does not carry
+
+
+KAT_REF = os.path.join(ROOT, "oracle", "_ref", "kat_ref_parts")
+
+
+@pytest.mark.skipif(not os.access(KAT_REF, os.X_OK), reason="oracle/_ref not built (no /root/reference at build time)")
+def test_comp_stats_and_matrix_through_the_reference_code(engine, refdata, tmp_path):
+    """`katgpu comp`'s files against the reference's OWN code (oracle/_ref/kat_ref_parts, no oracle in between): the .stats file is
+    what KAT's CompCounters::printCounts prints for the device's counters and spectra, and the -main.mx file loads in KAT's
+    SparseMatrix / matrix_metadata_extractor with the device matrix's shape, MaxVal and cell sum."""
+    import kat_amd
+    r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
+    r = run(["comp", "-m15", "-i", "120", "-j", "90", "-o", "refcmp", r1, r2], tmp_path)
+    assert r.returncode == 0, r.stderr
+    t1, t2 = engine.count([r1], 15, True), engine.count([r2], 15, True)
+    mx, cc, sp = kat_amd.comp(t1, t2, 1.0, 1.0, 120, 90)
+    n = sp.shape[1]
+    stdin = "%s\n%s\n\n%d\n%s\n%s\n" % (r1, r2, n, " ".join(map(str, cc.tolist())), "\n".join(" ".join(map(str, row.tolist())) for row in sp))
+    out = subprocess.run([KAT_REF, "compstats"], input=stdin.encode(), capture_output=True, timeout=120)
+    assert out.returncode == 0 and out.stdout == (tmp_path / "refcmp.stats").read_bytes()
+    out = subprocess.run([KAT_REF, "mxread", str(tmp_path / "refcmp-main.mx")], capture_output=True, timeout=120)
+    lines = out.stdout.decode().split("\n")
+    assert lines[0].split() == ["90", "120", str(int(mx.max())), "1", "15"]
+    assert lines[7].split() == ["120", "90", str(int(mx.max())), str(int(mx.sum()))]
+    t1.free(); t2.free()
