@@ -229,7 +229,8 @@ private:
 
 // FASTA / FASTQ (optionally gzip) records as seqan::SeqFileIn + readRecords(names, seqs, ...) deliver them to Sect
 // (deps/seqan-library-2.0.0/include/seqan/seq_io/fasta_fastq.h:306-380): the name is the whole header line, only
-// newlines are dropped from the sequence, and a sequence ends at the next '>' ('+' for FASTQ).
+// newlines are dropped from the sequence, and a sequence ends at the next '>' ('+' for FASTQ).  The format follows from the file
+// name alone (.fa/.fasta, .fq/.fastq, .txt = one nameless record per line; optionally .gz); other names throw, as SeqAn does.
 class SeqRecordReader {
 public:
     explicit SeqRecordReader(const std::string& path);
@@ -239,7 +240,7 @@ public:
 private:
     struct Impl;
     std::unique_ptr<Impl> impl;
-    bool fastq = false;
+    enum { FASTA, FASTQ, RAW } format = FASTA;
     int peek();
     void line(std::string* into);
 };

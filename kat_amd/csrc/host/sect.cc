@@ -77,14 +77,11 @@ SeqRecordReader::SeqRecordReader(const string& path) : impl(new Impl) {
     if (!impl->f) throw std::runtime_error("Could not open sequence file: " + path);
     string base = path;
     if (endsWithNoCase(base, ".gz")) base.resize(base.size() - 3);
-    if (endsWithNoCase(base, ".fa") || endsWithNoCase(base, ".fasta")) fastq = false;           // fasta_fastq.h:104-131
-    else if (endsWithNoCase(base, ".fq") || endsWithNoCase(base, ".fastq")) fastq = true;
-    else {
-        const int c = peek();
-        if (c == '>') fastq = false;
-        else if (c == '@') fastq = true;
-        else throw std::runtime_error("Could not determine the format of sequence file: " + path);
-    }
+    // SeqAn decides on the file name alone (fasta_fastq.h:104-143), case-insensitively; anything else is UnknownExtensionError
+    if (endsWithNoCase(base, ".fa") || endsWithNoCase(base, ".fasta")) format = FASTA;
+    else if (endsWithNoCase(base, ".fq") || endsWithNoCase(base, ".fastq")) format = FASTQ;
+    else if (endsWithNoCase(base, ".txt")) format = RAW;
+    else throw std::runtime_error("Unknown file extension of " + path + ": iostream error");
 }
 
 SeqRecordReader::~SeqRecordReader() { if (impl->f) gzclose(impl->f); }
@@ -101,6 +98,8 @@ void SeqRecordReader::line(string* into) {      // readLine / skipLine (seqan/st
 
 void SeqRecordReader::readRecord(string& name, string& seq) {
     name.clear(); seq.clear();
+    if (format == RAW) { line(&seq); return; }                                                  // every line a nameless record
+    const bool fastq = format == FASTQ;
     const int begin = fastq ? '@' : '>', stop = fastq ? '+' : '>';
     int c;
     while ((c = peek()) >= 0 && c != begin) impl->pos++;

@@ -7,7 +7,7 @@
  * product (kat_amd/, include/) may include, link, import or execute anything in oracle/.
  *
  * PINNING STATUS (see DESIGN.md "Oracle"):
- *   - The reference's TOOL DRIVERS are unbuildable in this image: src/*.cc, lib/src/input_handler.cc and jellyfish_helper.cc
+ *   - The reference's TOOL DRIVERS are unbuildable in this image: the .cc files under src/, lib/src/input_handler.cc and jellyfish_helper.cc
  *     include the autoconf-generated <config.h> unconditionally (e.g. lib/src/input_handler.cc:19), as do Jellyfish's
  *     lib/allocators_mmap.cc, misc.cc and storage.cc (so its hash_counter / large_hash_array cannot be driven either), and
  *     autotools are absent.  No `kat` binary exists here.

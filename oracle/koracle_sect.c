@@ -64,16 +64,17 @@ static int ends_with_ci(const char* s, const char* suffix) {
     return 1;
 }
 
-/* 0 = FASTA, 1 = FASTQ, -1 = unknown.  SeqAn decides on the file name (fasta_fastq.h:104-131), after stripping a
- * compression extension; for other names it falls back to the first character of the stream. */
+/* 0 = FASTA, 1 = FASTQ, 2 = Raw (.txt: every line a nameless record), -1 = unknown.  SeqAn decides on the file name alone
+ * (fasta_fastq.h:104-143), case-insensitively, after stripping a compression extension; any other name is
+ * seqan::UnknownExtensionError (checked against the real library: oracle/_ref/seqan_ref). */
 static int guess_format(const char* path, const char* d, size_t n) {
     char base[4096];
+    (void)d; (void)n;
     snprintf(base, sizeof base, "%s", path);
     if (ends_with_ci(base, ".gz")) base[strlen(base) - 3] = 0;
     if (ends_with_ci(base, ".fa") || ends_with_ci(base, ".fasta")) return 0;
     if (ends_with_ci(base, ".fq") || ends_with_ci(base, ".fastq")) return 1;
-    if (n && d[0] == '>') return 0;
-    if (n && d[0] == '@') return 1;
+    if (ends_with_ci(base, ".txt")) return 2;
     return -1;
 }
 
@@ -83,6 +84,7 @@ typedef struct { buf_t name, seq; } record_t;
  * sequence ends at the next '>' / '+' wherever it stands).  Returns the new position. */
 static size_t read_record(const char* d, size_t n, size_t i, int fastq, record_t* r) {
     r->name.n = 0; r->seq.n = 0;
+    if (fastq == 2) return read_line(d, n, i, &r->seq);      /* Raw: readUntil(seq, IsNewline); skipLine (fasta_fastq.h:283-292) */
     const char begin = fastq ? '@' : '>';
     while (i < n && d[i] != begin) i++;          /* skipUntil(begin) */
     if (i >= n) return (size_t)-1;               /* skipOne at the end: seqan::UnexpectedEnd */

@@ -97,8 +97,21 @@ def seqan_records(path):
         fastq = False
     elif low.endswith((".fq", ".fastq")):
         fastq = True
-    else:
-        fastq = {b">": False, b"@": True}[raw[:1]]
+    elif low.endswith(".txt"):                     # SeqAn's "Raw" format: every line is a record without a name
+        out, i, n = [], 0, len(raw)
+        while i < n:
+            j = i
+            while j < n and raw[j:j + 1] not in (b"\n", b"\r"):
+                j += 1
+            out.append((b"", raw[i:j]))
+            if raw[j:j + 1] == b"\r":
+                j += 1
+            if raw[j:j + 1] == b"\n":
+                j += 1
+            i = j
+        return out
+    else:                                          # SeqAn decides on the file name alone
+        raise ValueError("Unknown file extension of %s: iostream error" % path)
     begin, stop = (b"@", b"+") if fastq else (b">", b">")
     out = []
     i, n = 0, len(raw)

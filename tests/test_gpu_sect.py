@@ -139,6 +139,10 @@ def test_sect_cli_errors(refdata, tmp_path):
     bad.write_text("no marker\n")
     r = run(["sect", "-o", "x", str(bad), jf], tmp_path)
     assert r.returncode == 5 and "Unexpected end of input." in r.stderr
+    fna = tmp_path / "contigs.fna"                                       # SeqAn goes by the file name: seqan::UnknownExtensionError
+    fna.write_text(">x\nACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    r = run(["sect", "-o", "x", str(fna), jf], tmp_path)
+    assert r.returncode == 5 and "Unknown file extension of " + str(fna) in r.stderr
     assert run(["sect"], tmp_path).returncode == 1
 
 

@@ -74,9 +74,11 @@ def make_cases(tmp_path):
     gz = tmp_path / "cases.fa.gz"
     with gzip.open(gz, "wb") as f:
         f.write(fa.read_bytes())
-    sniffed = tmp_path / "noext.seq"
-    sniffed.write_bytes(fa.read_bytes())
-    return [str(fa), str(crlf), str(fq), str(gz), str(sniffed)], str(fa)
+    raw = tmp_path / "lines.txt"                      # SeqAn's Raw format: one nameless record per line
+    raw.write_bytes(b"\n".join((unit * 2)[i:i + 45].encode() for i in range(0, 60, 7)) + b"\n\nACGTNNACGT" + unit.encode() + b"\r\n")
+    upper = tmp_path / "CASES.FA"                     # extensions are matched case-insensitively
+    upper.write_bytes(fa.read_bytes())
+    return [str(fa), str(crlf), str(fq), str(gz), str(raw), str(upper)], str(fa)
 
 
 def test_generated_edge_cases(ko, tmp_path):
@@ -102,6 +104,12 @@ def test_reader_errors(ko, tmp_path):
         ko.sect(t, str(bad), str(tmp_path / "o"))
     with pytest.raises(ValueError):
         naive.seqan_records(str(bad))
+    other = tmp_path / "contigs.fna"                  # SeqAn decides on the name alone: UnknownExtensionError (KAT exits with 5)
+    other.write_bytes(b">x\nACGTACGT\n")
+    with pytest.raises(ko.OracleError):
+        ko.sect(t, str(other), str(tmp_path / "o"))
+    with pytest.raises(ValueError, match="Unknown file extension"):
+        naive.seqan_records(str(other))
     empty = tmp_path / "e.fa"
     empty.write_bytes(b"")
     ko.sect(t, str(empty), str(tmp_path / "e"))
@@ -120,3 +128,27 @@ def test_cold_oracle_vs_naive(ko, refdata, tmp_path):
             ko.cold(reads, asm, p, str(tmp_path / "c"))
             want = naive.cold(counts_of(ko, reads), cr, counts_of(ko, asm), ca, k, p)
             assert (tmp_path / "c-stats.tsv").read_bytes() == want
+
+
+SEQAN_REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "seqan_ref")
+
+
+@pytest.mark.skipif(not os.access(SEQAN_REF, os.X_OK), reason="oracle/_ref not built (no /root/reference at build time)")
+def test_record_reader_against_the_real_seqan(tmp_path):
+    """The records `kat sect` / `kat cold` see: tests/naive.py's statement of the SeqAn 2.0.0 reader against the library itself
+    (oracle/_ref/seqan_ref, compiled from the reference's vendored headers), on every edge case used above."""
+    import subprocess
+    paths, fa = make_cases(tmp_path)
+    extra = {"mid.fasta": b"leading junk\r\n>r0 desc\r\nACGT\r\nAC GT\r\n>r1\r\nTT>GG\r\n\r\n", "two.fq": b"@a\nACGT\n+\n@III\n@b\nGG\nTT\n+b\n@@\n@@\n",
+             "empty.fa": b"", "x.fna": b">x\nACGT\n", "nomarker.fa": b"no marker\n", "noplus.fq": b"@a\nACGT\n"}
+    for name, data in extra.items():
+        (tmp_path / name).write_bytes(data)
+        paths.append(str(tmp_path / name))
+    for p in paths:
+        r = subprocess.run([SEQAN_REF, p], capture_output=True, timeout=60)
+        try:
+            want = b"".join(b"%d %s\n%d %s\n" % (len(n), n, len(s), s) for n, s in naive.seqan_records(p))
+        except ValueError as e:
+            assert r.returncode == 5 and r.stdout.startswith(b"EXCEPTION " + str(e).encode()[:20]), (p, r.stdout[:200])
+            continue
+        assert r.returncode == 0 and r.stdout == want, p
