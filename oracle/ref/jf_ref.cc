@@ -9,6 +9,8 @@
 //   jf_ref kmers <k> <canonical 0|1> <file>...     every k-mer the reference's parser + mer_iterator deliver, counted in a
 //                                                  std::map: "<kmer> <count>" lines in key order -- the reference's count
 //                                                  semantics (mer_overlap_sequence_parser.hpp + mer_iterator.hpp)
+//   jf_ref kmerst <k> <canonical> <t1,t2,..> <file>...   the same with KAT's 5' trim list (one value per file), through the
+//                                                  trim5p_list constructor KAT added to the vendored parser
 //   jf_ref merops <k> <kmer>...                    mer_dna: 2-bit word, reverse complement, canonical form of each k-mer
 //   jf_ref jfread <file.jf>                        file_header + binary_reader: header fields, then "<kmer> <count> <pos>"
 #include <cstdlib>
@@ -42,6 +44,21 @@ int main(int argc, char* argv[]) {
         file_vector files(argv + 4, argv + argc);
         stream_manager_t streams(files.begin(), files.end(), 1);            // one file at a time, as JellyfishHelper::countSeqFile does
         parser_t parser(k, streams.nb_streams(), 3, 4096, streams);         // 4096-byte buffers: jellyfish_helper.cc / count_main.cc
+        std::map<std::string, unsigned long> counts;
+        for (iterator_t it(parser, canonical); it; ++it) counts[it->to_str()]++;
+        for (std::map<std::string, unsigned long>::const_iterator kv = counts.begin(); kv != counts.end(); ++kv)
+            std::cout << kv->first << ' ' << kv->second << '\n';
+        return 0;
+    }
+    if (mode == "kmerst" && argc >= 6) {
+        const unsigned k = atoi(argv[2]);
+        const bool canonical = atoi(argv[3]) != 0;
+        jellyfish::mer_dna::k(k);
+        std::vector<uint16_t> trims;
+        for (char* tok = strtok(argv[4], ","); tok; tok = strtok(NULL, ",")) trims.push_back((uint16_t)atoi(tok));
+        file_vector files(argv + 5, argv + argc);
+        stream_manager_t streams(files.begin(), files.end(), 1);
+        parser_t parser(k, streams.nb_streams(), 3, 4096, streams, trims);
         std::map<std::string, unsigned long> counts;
         for (iterator_t it(parser, canonical); it; ++it) counts[it->to_str()]++;
         for (std::map<std::string, unsigned long>::const_iterator kv = counts.begin(); kv != counts.end(); ++kv)

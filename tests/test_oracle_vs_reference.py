@@ -289,3 +289,38 @@ def test_documented_deviations_on_truncated_fastq(ko, tmp_path):
     with pytest.raises(kat_amd.KatGpuError) as ei:
         kat_amd.parse_file(str(tr))
     assert ei.value.code == 4
+
+
+def ref_kmers_trim(paths, k, canonical, trims):
+    rc, out = ref(JF_REF, ["kmerst", k, int(canonical), ",".join(map(str, trims))] + list(paths))
+    assert rc == 0
+    return out
+
+
+@have_ref
+def test_five_prime_trim_against_the_reference_parser(ko, tmp_path):
+    """--5ptrim through the trim5p_list constructor KAT added to the vendored parser.  FASTQ: identical.  FASTA: identical while
+    the file fits one of the parser's 4096-byte buffers; beyond that the reference re-applies the trim at EVERY buffer fill, in the
+    middle of records (read_fasta sets newread = true on entry, mer_overlap_sequence_parser.hpp:198), and joins the seam to what
+    follows the dropped bases -- quirk B7, the one place where the oracle and the product deliberately trim once per record."""
+    rng = np.random.default_rng(2)
+    rnd = lambda n: "".join(rng.choice(list("ACGT"), n))
+    fq = tmp_path / "t.fq"
+    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in enumerate(rnd(int(rng.integers(12, 90))) for _ in range(400))))
+    small = tmp_path / "small.fa"
+    small.write_text("".join(">c%d\n%s\n" % (i, "\n".join(rnd(60) for _ in range(4))) for i in range(12)))       # 2.9 KB of sequence
+    big = tmp_path / "big.fa"
+    big.write_text(">a\n" + rnd(9000) + "\n>b\n" + "\n".join(rnd(70) for _ in range(200)) + "\n")
+    def oracle(paths, k, c, trims):
+        keys, counts = ko.Table(k, c).count_files(paths, trims).dump_sorted()
+        return "".join("%s %d\n" % (ko.decode(int(a), k), int(b)) for a, b in zip(keys, counts)).encode()
+    for trim in (1, 3, 10):
+        for k, c in ((7, True), (21, False)):
+            assert oracle([str(fq)], k, c, [trim]) == ref_kmers_trim([str(fq)], k, c, [trim])
+            assert oracle([str(small)], k, c, [trim]) == ref_kmers_trim([str(small)], k, c, [trim])
+            assert oracle([str(fq), str(small)], k, c, [trim, 0]) == ref_kmers_trim([str(fq), str(small)], k, c, [trim, 0])
+    mine, theirs = oracle([str(big)], 7, True, [3]), ref_kmers_trim([str(big)], 7, True, [3])
+    assert mine != theirs                                               # the documented deviation, as the real parser shows it
+    total = lambda b: sum(int(l.split()[1]) for l in b.splitlines())
+    assert total(mine) == (9000 - 3 - 6) + (14000 - 3 - 6) and total(theirs) < total(mine)
+    assert kat_amd.parse_file(str(big), 3).size == 9000 - 3 + 1 + 14000 - 3
