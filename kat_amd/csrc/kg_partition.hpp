@@ -275,8 +275,7 @@ struct P1Lds {
     uint32_t wave_tot[16];
     uint32_t code[P1_BLOCK + 2];
     uint32_t bad[P1_BLOCK + 2];
-    uint16_t pos[P1_TILE_BYTES];
-    uint32_t next[MAX_PARTS];           // chunked edition: the chunk this workgroup has reserved ahead in each bucket
+    uint32_t pos[P1_TILE_BYTES];        // per staged k-mer: bucket << 16 | tile position  (52 KB in all: three workgroups per CU)
 };
 
 struct LaneWindow {                       // the 96-bit sliding window of kg_kernels.hpp's K1, as an object
@@ -436,14 +435,16 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         // sweep 2: park the tile position of every k-mer in its bucket's run
 #pragma unroll
         for (int j = 0; j < PART_ITEMS; ++j)
-            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = (uint16_t)(tid * PART_ITEMS + j);
+            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = (br[j] & 0xFFFF0000u) | (tid * PART_ITEMS + j);
         lds_barrier();
-        // copy-out: a 16-lane group per bucket; the k-mer is recomputed from the codes, the run leaves as <= 128-byte pieces
-        const uint32_t grp = tid >> 4, l16 = tid & 15;
-        for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
-            const uint32_t cnt = L.hist[b], src = L.off[b];
-            const uint64_t dst = L.cursor[b];
-            for (uint32_t i = l16; i < cnt; i += 16) l1_buf[dst + i] = kmer_at(L.code, L.pos[src + i], k, canonical);
+        // copy-out, one staged k-mer per lane and step: its bucket travels with its position, so no lane idles on a short run
+        // and the steps are independent of each other (a loop over buckets serialised ~24 LDS round trips per lane group and
+        // was 57 % of this kernel: cycle stamps; same-box A/B 228 -> 216 ms).  Neighbouring lanes still write neighbouring addresses
+        // inside a run.
+        const uint32_t total = L.off[P - 1] + L.hist[P - 1];
+        for (uint32_t idx = tid; idx < total; idx += P1_BLOCK) {
+            const uint32_t v = L.pos[idx], b = v >> 16;
+            l1_buf[L.cursor[b] + (idx - L.off[b])] = kmer_at(L.code, v & 0xFFFF, k, canonical);
         }
         lds_barrier();
         for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] += L.hist[b];
@@ -472,13 +473,14 @@ k_p1v2_scatter_chunked(DevTable t, PartGeom g, const uint8_t* __restrict__ bases
                        uint32_t* __restrict__ chunk_cur, uint32_t cpb, uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ ovf_buf,
                        unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
     __shared__ __attribute__((aligned(16))) P1Lds L;
+    __shared__ uint32_t s_next[MAX_PARTS];                // the chunk this workgroup has reserved ahead in each bucket
     const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;
     const bool canonical = t.canonical != 0;
     // cursor[b]: next write position of this workgroup in bucket b; a multiple of L1_CHUNK means "no chunk in hand".
     // next[b]: a chunk reserved AHEAD, so that crossing a chunk boundary never waits for a global atomic: the crossing takes
     // next[b] and issues the reservation of the one after; that atomic's result is parked in a register (two slots per
     // 16-lane group) and stored to next[b] at the top of the next tile's copy-out, long after it has arrived.
-    for (uint32_t b = tid; b < P; b += P1_BLOCK) { L.cursor[b] = 0; L.next[b] = atomicAdd(&chunk_cur[b], 1u); }
+    for (uint32_t b = tid; b < P; b += P1_BLOCK) { L.cursor[b] = 0; s_next[b] = atomicAdd(&chunk_cur[b], 1u); }
     uint32_t ones = 0;
     const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
     uint32_t w[4], wn[4];
@@ -487,8 +489,8 @@ k_p1v2_scatter_chunked(DevTable t, PartGeom g, const uint8_t* __restrict__ bases
     uint32_t np = 0, pb0 = 0, pb1 = 0, pv0 = 0, pv1 = 0;              // lane 0 of each group: reservations in flight
     auto flush = [&]() {
         if (l16 == 0) {
-            if (np > 0) L.next[pb0] = pv0;
-            if (np > 1) L.next[pb1] = pv1;
+            if (np > 0) s_next[pb0] = pv0;
+            if (np > 1) s_next[pb1] = pv1;
         }
         np = 0;
     };
@@ -523,7 +525,7 @@ k_p1v2_scatter_chunked(DevTable t, PartGeom g, const uint8_t* __restrict__ bases
         lds_barrier();
 #pragma unroll
         for (int j = 0; j < PART_ITEMS; ++j)
-            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = (uint16_t)(tid * PART_ITEMS + j);
+            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = tid * PART_ITEMS + j;
         flush();                                                              // last tile's reservations have long arrived
         lds_barrier();
         // copy-out: a 16-lane group per bucket appends the run to the workgroup's current chunk of that bucket
@@ -536,7 +538,7 @@ k_p1v2_scatter_chunked(DevTable t, PartGeom g, const uint8_t* __restrict__ bases
                     if (np == 2 || (np > 0 && pb0 == b) || (np > 1 && pb1 == b)) flush();      // (a run longer than a chunk, or many crossings)
                     uint32_t c = 0;
                     if (l16 == 0) {
-                        c = L.next[b];
+                        c = s_next[b];
                         const uint32_t v = atomicAdd(&chunk_cur[b], 1u);
                         if (np == 0) { pb0 = b; pv0 = v; } else { pb1 = b; pv1 = v; }
                     }
@@ -568,7 +570,7 @@ k_p1v2_scatter_chunked(DevTable t, PartGeom g, const uint8_t* __restrict__ bases
         const uint64_t dst = L.cursor[b];
         const uint32_t room = (L1_CHUNK - (uint32_t)(dst & (L1_CHUNK - 1))) & (L1_CHUNK - 1);
         for (uint32_t i = l16; i < room; i += 16) l1_buf[dst + i] = EMPTY;
-        const uint32_t c = L.next[b];
+        const uint32_t c = s_next[b];
         if (c < cpb) {
             const uint64_t base = l1_bucket_base(b, cpb) + (uint64_t)c * L1_CHUNK;
             for (uint32_t i = l16; i < L1_CHUNK; i += 16) l1_buf[base + i] = EMPTY;
