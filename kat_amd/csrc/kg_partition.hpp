@@ -677,24 +677,23 @@ __device__ __forceinline__ void scatter_tile2_bounded(PartLds& L, const PartGeom
     for (int j = 0; j < PART_ITEMS; ++j)
         if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = key[j];
     lds_barrier();
-    const uint32_t lane = tid & 63, wave = tid >> 6;
-    for (uint32_t b = wave; b < P; b += PART_BLOCK / 64) {
-        const uint32_t cnt = L.hist[b], src = L.off[b];
-        const uint64_t dst = L.cursor[b];
-        const uint64_t room = lim[b] - dst;
-        const uint32_t fit = (uint64_t)cnt <= room ? cnt : (uint32_t)room;
-        for (uint32_t i = lane; i < fit; i += 64) out[dst + i] = L.staging[src + i];
-        if (fit < cnt) {                                                   // uniform over the wave
-            const uint32_t excess = cnt - fit;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(ovf_n, (unsigned long long)excess);
-            base = __shfl(base, 0, 64);
-            for (uint32_t i = lane; i < excess; i += 64) if (base + i < ovf_cap) ovf_buf[base + i] = L.staging[src + fit + i];
-            if (lane == 0) L.hist[b] = fit;                                // what the cursor advances by
+    // copy-out, one staged k-mer per lane and step (as in k_p1v2_scatter): the bucket is recomputed from the key -- cheaper than
+    // a third LDS array -- and the steps are independent, where a loop over buckets kept a third of the lanes busy
+    for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
+        const uint64_t key1 = L.staging[idx];
+        const uint32_t b = digit2_of_hash(mix64(key1), g.P2);
+        const uint64_t dst = L.cursor[b] + (idx - L.off[b]);
+        if (dst < lim[b]) out[dst] = key1;
+        else {                                                             // beyond the run's capacity: the overflow list
+            const unsigned long long at = atomicAdd(ovf_n, 1ULL);
+            if (at < ovf_cap) ovf_buf[at] = key1;
         }
     }
     lds_barrier();
-    if (tid < P) L.cursor[tid] += L.hist[tid];
+    if (tid < P) {
+        const uint64_t room = lim[tid] - L.cursor[tid];
+        L.cursor[tid] += (uint64_t)L.hist[tid] <= room ? L.hist[tid] : room;
+    }
 }
 
 __global__ void __launch_bounds__(PART_BLOCK)
