@@ -163,12 +163,13 @@ __device__ __forceinline__ void scatter_tile(PartLds& L, const PartGeom g, const
     for (int j = 0; j < PART_ITEMS; ++j)
         if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = key[j];
     lds_barrier();
-    // bucket-parallel copy-out: each wave walks its share of the buckets, lanes copy that bucket's run contiguously
-    const uint32_t lane = tid & 63, wave = tid >> 6;
-    for (uint32_t b = wave; b < P; b += PART_BLOCK / 64) {
-        const uint32_t cnt = L.hist[b], src = L.off[b];
-        const uint64_t dst = L.cursor[b];
-        for (uint32_t i = lane; i < cnt; i += 64) out[dst + i] = L.staging[src + i];
+    // copy-out, one staged k-mer per lane and step: the bucket is recomputed from the key (cheaper than a third LDS array) and the
+    // steps are independent of each other; a loop over buckets kept a third of the lanes busy on runs of ~20 k-mers
+    for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
+        const uint64_t key1 = L.staging[idx];
+        const uint64_t h = mix64(key1);
+        const uint32_t b = LEVEL == 1 ? digit1_of_hash(h, g.P1) : digit2_of_hash(h, g.P2);
+        out[L.cursor[b] + (idx - L.off[b])] = key1;
     }
     lds_barrier();
     if (tid < P) L.cursor[tid] += L.hist[tid];
