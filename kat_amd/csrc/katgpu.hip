@@ -460,7 +460,7 @@ static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? s
 // share of the free HBM the partition arena may take (multi-GPU runs leave room for the owner tables: bench.py sets 0.5)
 static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::min(0.95, std::max(0.05, atof(getenv("KATGPU_ARENA_FRACTION")))) : 0.85;
 static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10) : 3;   // 0 = first edition (1024-thread, 1 per CU)
-static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 1024;
+static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 0;   // 0: by region size
 // level 2 without its histogram pass (kg_partition.hpp: k_p2_fast): 0 = never, 1 = when the mean run is long enough for the
 // capacity slack to cover the noise, 2 = always (tests).  KATGPU_TEST_P2_OVF_CAP shrinks the overflow list (tests: forces the
 // fall back to the exact kernel).
@@ -738,7 +738,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
                 // as many workgroups per CU as the regions' LDS footprint (and the 2048-thread limit) admits
                 const size_t lds = (size_t)g.S * 12;
-                const uint32_t blk = g_apply_block;
+                // small regions (a table created "like" a bigger one): 512-thread workgroups, four per CU instead of two
+                const uint32_t blk = g_apply_block ? g_apply_block : (g.S <= 4096 ? 512 : 1024);
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
 #define KG_APPLY(B, ...) hipLaunchKernelGGL((k_p3_apply<B, __VA_ARGS__>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
