@@ -174,10 +174,10 @@ def _exchange_rows(rows_out, rows_in, rank, world, group):
         r.wait()
 
 
-def exchange_merge(shard, group=None, min_chunks=4, grid_of=None, load=None):
+def exchange_merge(shard, group=None, min_chunks=4):
     """Route every record of `shard` to its owner rank, IN PLACE: on return the same shard holds exactly the k-mers this
-    rank owns, with their counts summed over all ranks.  (grid_of / load: accepted for compatibility, unused -- the table
-    keeps its storage and its region grid.)
+    rank owns, with their counts summed over all ranks.  The table keeps its storage and its region grid (a second table created
+    "like" the first still joins with it region by region).
 
     world_size == 1: the local table already is the owner table.
     """
