@@ -1330,12 +1330,13 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
                 if (t->disable_grow) rc = fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
                 else rc = regrow(t, (uint64_t)t->d.n_regions * need_s);
             }
-            for (uint32_t g : regs)
-                for (uint32_t q = 0; q < na && rc == KATGPU_OK; ++q) {
-                    const uint64_t* o = off.data() + (size_t)q * (n_reg + 1);
-                    const uint64_t b = o[g - g_lo], e2 = o[g - g_lo + 1];
-                    if (e2 > b) rc = merge_direct32(t, ms.s[q].keys + b, ms.s[q].counts + b, (size_t)(e2 - b));
-                }
+            if (rc == KATGPU_OK) {                    // one launch for all deferred regions: every region now has the room
+                ScopedTimer tm(c, KATGPU_K_MERGE, max_in * ndef);
+                hipLaunchKernelGGL(k_merge_deferred, dim3((unsigned)std::min<unsigned long long>(ndef, (unsigned long long)c->n_cu * 8)), dim3(256), 0, c->stream,
+                                   t->d, g_lo, ms, (const uint32_t*)d_def, (uint32_t)ndef);
+                if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, KATGPU_ERR_DEVICE, "deferred merge");
+                else rc = refresh_counters(t);
+            }
         }
         hipFree(tmp);
         if (rc) return rc;

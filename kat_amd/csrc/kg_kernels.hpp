@@ -770,6 +770,24 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
     flush_distinct(t, new_distinct);
 }
 
+// The runs of the regions k_merge_apply deferred, through the direct path: one workgroup per deferred region, every source's
+// run of that region.  (One launch for all of them: when a whole table is too small, every region is on the list.)
+__global__ void __launch_bounds__(256)
+k_merge_deferred(DevTable t, uint32_t g_lo, MergeSrcs srcs, const uint32_t* __restrict__ deferred, uint32_t n_deferred) {
+    uint32_t new_distinct = 0;
+    for (uint32_t d = blockIdx.x; d < n_deferred; d += gridDim.x) {
+        const uint32_t j = deferred[d] - g_lo;
+        for (uint32_t s = 0; s < srcs.n; ++s) {
+            const uint64_t beg = srcs.s[s].off[j], end = srcs.s[s].off[j + 1];
+            for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+                const uint32_t c = srcs.s[s].counts[i];
+                if (c) table_add(t, srcs.s[s].keys[i], (uint64_t)c, new_distinct);
+            }
+        }
+    }
+    flush_distinct(t, new_distinct);
+}
+
 // records with 32-bit counts through the direct path (sources of another grid, deferred regions)
 __global__ void __launch_bounds__(256)
 k_merge32(DevTable dst, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, uint64_t n) {
