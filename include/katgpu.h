@@ -88,6 +88,13 @@ void katgpu_table_free(katgpu_table* t);
  * katgpu_free_host).  Needs no device; *err_msg (optional, static storage, valid until the next call on this thread)
  * receives the message on failure.  This is what katgpu_count_files streams to the GPU. */
 int  katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** bases, size_t* n, const char** err_msg);
+/* The same for one input group (InputHandler::count's file list, lib/src/input_handler.cc:180-202): the stream
+ * katgpu_count_files feeds to the counter for these paths.  Files that stream (gzip, 5' trim, small) are read
+ * concurrently, so the stream interleaves their blocks -- with 'N' + the file's previous k-1 bytes at every switch
+ * of source, which keeps the k-mer multiset equal to that of the files read one after the other.  The byte ORDER
+ * may differ from call to call; KATGPU_INGEST_FILES=1 reads the files in sequence. */
+int  katgpu_parse_files(const char* const* paths, size_t n_paths, const uint16_t* trim5p, uint32_t k,
+                        uint8_t** bases, size_t* n, const char** err_msg);
 void katgpu_free_host(void* p);
 
 /* distinct k-mers, sum of counts, slots allocated */

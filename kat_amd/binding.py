@@ -29,7 +29,7 @@ EXPORTS = (
     "katgpu_table_merge_host", "katgpu_table_geometry", "katgpu_table_extract_sizes", "katgpu_table_extract", "katgpu_table_clear",
     "katgpu_table_merge_device32", "katgpu_table_merge_regions", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
-    "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_free_host",
+    "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_parse_files", "katgpu_free_host",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
 )
 
@@ -120,6 +120,7 @@ def load_library():
     L.katgpu_synth_genome_device.argtypes = [vp, vp, u64, u64, u64]
     L.katgpu_synth_reads_device.argtypes = [vp, vp, u64, vp, u64, u64, u32, u32, u32, u64]
     L.katgpu_parse_file.argtypes = [C.c_char_p, u32, pp, C.POINTER(sz), cpp]
+    L.katgpu_parse_files.argtypes = [vp, sz, vp, u32, pp, C.POINTER(sz), cpp]
     L.katgpu_free_host.argtypes = [vp]
     L.katgpu_free_host.restype = None
     L.katgpu_jf_load.argtypes = [vp, C.c_char_p, pp]
@@ -136,6 +137,21 @@ def parse_file(path, trim5p=0):
     L = load_library()
     p, n, msg = C.c_void_p(), C.c_size_t(), C.c_char_p()
     rc = L.katgpu_parse_file(os.fsencode(path), trim5p, C.byref(p), C.byref(n), C.byref(msg))
+    if rc:
+        raise KatGpuError(rc, (msg.value or b"").decode(errors="replace"))
+    out = np.frombuffer(C.string_at(p, n.value), dtype=np.uint8).copy() if n.value else np.zeros(0, np.uint8)
+    L.katgpu_free_host(p)
+    return out
+
+
+def parse_files(paths, k, trim5p=None):
+    """Host-only ingest of one input group: the base stream katgpu_count_files feeds to the counter (files that stream are
+    read concurrently and interleaved; see include/katgpu.h).  Needs no GPU."""
+    L = load_library()
+    arr, n_paths = _cpaths(paths)
+    tr = (C.c_uint16 * n_paths)(*trim5p) if trim5p else None
+    p, n, msg = C.c_void_p(), C.c_size_t(), C.c_char_p()
+    rc = L.katgpu_parse_files(arr, n_paths, tr, k, C.byref(p), C.byref(n), C.byref(msg))
     if rc:
         raise KatGpuError(rc, (msg.value or b"").decode(errors="replace"))
     out = np.frombuffer(C.string_at(p, n.value), dtype=np.uint8).copy() if n.value else np.zeros(0, np.uint8)

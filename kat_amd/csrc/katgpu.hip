@@ -900,25 +900,10 @@ extern "C" int katgpu_count_files(katgpu_table* t, const char* const* paths, siz
     t->carry_n = 0;
     HostFeeder f(t);
     int rc = f.begin(); if (rc) return rc;
-    for (size_t i = 0; i < n_paths; ++i) {
-        std::string err;
-        // large plain files are parsed by a thread team (kg_ingest.hpp: parse_file_parallel, byte-identical output) ...
-        int prc = kg::parse_file_parallel(paths[i], trim5p ? trim5p[i] : 0, [&](const uint8_t* p, size_t n) { return f.push(p, n); }, &err);
-        if (prc == 0) { rc = f.end_of_file(); if (rc) return rc; continue; }
-        if (prc > 0) return err.empty() ? prc : fail(c, prc, "%s", err.c_str());
-        // ... gzip, pipes, small files and 5' trimming stream through the single-threaded parser
-        kg::SeqFileParser parser;
-        prc = parser.open(paths[i], trim5p ? trim5p[i] : 0, &err);
-        if (prc) return fail(c, prc, "%s", err.c_str());
-        for (;;) {
-            const uint8_t* p; size_t n;
-            prc = parser.next(&p, &n, &err);
-            if (prc) return fail(c, prc, "%s", err.c_str());
-            if (!n) break;
-            rc = f.push(p, n); if (rc) return rc;
-        }
-        rc = f.end_of_file(); if (rc) return rc;
-    }
+    // the group's files -> one base stream (kg_ingest.hpp: thread team for large plain files, concurrent readers for gzip & co.)
+    std::string err;
+    rc = kg::stream_group(paths, n_paths, trim5p, t->d.k, [&](const uint8_t* p, size_t n) { return f.push(p, n); }, &err);
+    if (rc) return err.empty() ? rc : fail(c, rc, "%s", err.c_str());
     return f.finish();
 }
 

@@ -12,8 +12,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <future>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 namespace kg {
@@ -28,7 +32,7 @@ SeqFileParser::~SeqFileParser() {
     if (gz_) gzclose((gzFile)gz_);
 }
 
-int SeqFileParser::open(const char* path, uint32_t trim5p, std::string* err) {
+int SeqFileParser::open(const char* path, uint32_t trim5p, std::string* err, size_t raw_bytes) {
     path_ = path;
     ps_.trim5p = trim5p;
     // the reference opens every input through a gzip-aware stream (stream_manager.hpp:133-145); zlib passes plain files through
@@ -38,7 +42,7 @@ int SeqFileParser::open(const char* path, uint32_t trim5p, std::string* err) {
         return KATGPU_ERR_IO;
     }
     gzbuffer((gzFile)gz_, 1 << 20);
-    raw_.resize((size_t)16 << 20);
+    raw_.resize(std::max<size_t>(raw_bytes, 1));
     out_.reserve(raw_.size() + 16);
     return KATGPU_OK;
 }
@@ -202,12 +206,31 @@ struct Segment {
 
 }  // namespace
 
-int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err) {
-    if (trim5p) return -1;                                   // is.ignore(trim5p) swallows line starts: keep that case on the streaming path
+// The conditions under which the team takes a file; *size_out / *first_byte for the caller that goes on.
+static bool team_applies_impl(const char* path, uint32_t trim5p, int64_t* size_out, uint8_t* first_byte) {
+    if (trim5p) return false;                                // is.ignore(trim5p) swallows line starts: keep that case on the streaming path
     struct stat st;
-    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return -1;
-    const int64_t size = (int64_t)st.st_size;
-    if ((uint64_t)size < env_u64("KATGPU_INGEST_MIN_BYTES", (uint64_t)256 << 20)) return -1;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    if ((uint64_t)st.st_size < env_u64("KATGPU_INGEST_MIN_BYTES", (uint64_t)256 << 20)) return false;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    uint8_t head[2] = {0, 0};
+    const bool got = pread(fd, head, 2, 0) == 2;
+    ::close(fd);
+    if (!got) return false;
+    if (head[0] == 0x1f && head[1] == 0x8b) return false;    // gzip: one serial stream
+    if (head[0] != '>' && head[0] != '@') return false;      // the streaming path words the error
+    if (size_out) *size_out = (int64_t)st.st_size;
+    if (first_byte) *first_byte = head[0];
+    return true;
+}
+
+bool team_applies(const char* path, uint32_t trim5p) { return team_applies_impl(path, trim5p, nullptr, nullptr); }
+
+int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err) {
+    int64_t size = 0;
+    uint8_t first = 0;
+    if (!team_applies_impl(path, trim5p, &size, &first)) return -1;
     const int64_t seg = (int64_t)std::max<uint64_t>(16, env_u64("KATGPU_INGEST_SEGMENT", (uint64_t)16 << 20));
     const int64_t margin = (int64_t)std::max<uint64_t>(16, env_u64("KATGPU_INGEST_MARGIN", (uint64_t)4 << 20));
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -215,11 +238,8 @@ int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<i
     const int fd = ::open(path, O_RDONLY);
     if (fd < 0) return -1;
     struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
-    uint8_t head[2] = {0, 0};
-    if (pread(fd, head, 2, 0) != 2) return -1;
-    if (head[0] == 0x1f && head[1] == 0x8b) return -1;       // gzip: one serial stream
     ParseState state;                                        // the machine's TRUE state at file offset `pos`
-    if (!state.begin(head[0])) return -1;                    // the streaming path words the error
+    state.begin(first);
     const ParseState::Type type = state.type;
     int64_t pos = 0;
 
@@ -324,6 +344,160 @@ int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<i
     return KATGPU_OK;
 }
 
+// ------------------------------------------------------------------ the input group ---------------------------------
+
+namespace {
+
+// Files [lo, hi) of the group, all of the streaming kind, read by `readers` threads at once (see stream_group in the header).
+int stream_run_concurrent(const char* const* paths, const uint16_t* trim5p, size_t lo, size_t hi, uint32_t k, unsigned readers,
+                          const std::function<int(const uint8_t*, size_t)>& sink, std::string* err) {
+    struct Block { size_t file = 0; unsigned reader = 0; std::vector<uint8_t> data; };
+    const size_t raw_bytes = (size_t)std::max<uint64_t>(1, env_u64("KATGPU_INGEST_BLOCK", (uint64_t)4 << 20));
+    const size_t depth = 3;                                  // blocks one reader may have waiting
+
+    std::mutex mu;
+    std::condition_variable cv_data, cv_room;
+    std::deque<Block> ready;                                 // every reader's blocks, in arrival order
+    std::vector<size_t> waiting(readers, 0);                 // per reader: how many of them are its own
+    std::vector<std::vector<uint8_t>> spare;                 // emptied buffers go back to the readers
+    unsigned live = readers;
+    size_t bad_file = SIZE_MAX; int bad_rc = 0; std::string bad_msg;      // the lowest-numbered failing file so far
+    bool abort_all = false;                                  // the sink failed: nothing more is wanted
+    size_t next_file = lo;
+
+    auto reader = [&](unsigned me) {
+        for (;;) {
+            size_t f;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                // files are handed out in order, so when file f fails every lower-numbered file is already open or done
+                if (abort_all || next_file >= hi || next_file > bad_file) break;
+                f = next_file++;
+            }
+            SeqFileParser parser;
+            std::string msg;
+            int rc = parser.open(paths[f], trim5p ? trim5p[f] : 0, &msg, raw_bytes);
+            bool stopped = false;
+            while (!rc && !stopped) {
+                const uint8_t* p; size_t n;
+                rc = parser.next(&p, &n, &msg);
+                if (rc || !n) break;
+                Block b; b.file = f; b.reader = me;
+                std::unique_lock<std::mutex> g(mu);
+                cv_room.wait(g, [&] { return waiting[me] < depth || abort_all || f > bad_file; });
+                if (abort_all || f > bad_file) { stopped = true; break; }
+                if (!spare.empty()) { b.data = std::move(spare.back()); spare.pop_back(); }
+                g.unlock();
+                b.data.assign(p, p + n);
+                g.lock();
+                ready.push_back(std::move(b)); ++waiting[me];
+                cv_data.notify_one();
+            }
+            if (rc) {
+                std::lock_guard<std::mutex> g(mu);
+                if (f < bad_file) { bad_file = f; bad_rc = rc; bad_msg = msg; }
+                cv_room.notify_all();                        // higher-numbered files stop; lower ones run on (they may fail too)
+            }
+        }
+        std::lock_guard<std::mutex> g(mu);
+        --live;
+        cv_data.notify_one();
+    };
+    std::vector<std::thread> team;
+    for (unsigned i = 0; i < readers; ++i) team.emplace_back(reader, i);
+
+    // the consumer: whatever arrives first goes out; 'N' + the file's last k-1 bytes wherever the source changes
+    std::vector<std::vector<uint8_t>> tails(hi - lo);
+    const size_t keep = k > 0 ? k - 1 : 0;
+    const uint8_t sep = 'N';
+    size_t last_file = SIZE_MAX;
+    int sink_rc = 0;
+    for (;;) {
+        Block b;
+        bool drop;
+        {
+            std::unique_lock<std::mutex> g(mu);
+            cv_data.wait(g, [&] { return !ready.empty() || live == 0; });
+            if (ready.empty()) break;
+            b = std::move(ready.front()); ready.pop_front();
+            drop = abort_all || bad_file != SIZE_MAX;        // after an error the result is discarded anyway
+        }
+        if (!drop) {
+            std::vector<uint8_t>& tail = tails[b.file - lo];
+            if (b.file != last_file) {
+                if (last_file != SIZE_MAX) sink_rc = sink(&sep, 1);
+                if (!sink_rc && !tail.empty()) sink_rc = sink(tail.data(), tail.size());
+                last_file = b.file;
+            }
+            if (!sink_rc) sink_rc = sink(b.data.data(), b.data.size());
+            if (b.data.size() >= keep) tail.assign(b.data.end() - keep, b.data.end());
+            else {
+                tail.insert(tail.end(), b.data.begin(), b.data.end());
+                if (tail.size() > keep) tail.erase(tail.begin(), tail.end() - keep);
+            }
+        }
+        std::lock_guard<std::mutex> g(mu);
+        if (sink_rc) abort_all = true;
+        --waiting[b.reader];
+        spare.push_back(std::move(b.data));
+        cv_room.notify_all();
+    }
+    for (auto& th : team) th.join();
+    if (sink_rc) { err->clear(); return sink_rc; }
+    if (bad_file != SIZE_MAX) { *err = bad_msg; return bad_rc; }
+    return last_file != SIZE_MAX ? sink(&sep, 1) : KATGPU_OK;            // the run ends as a file does
+}
+
+int stream_one(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err) {
+    SeqFileParser parser;
+    int rc = parser.open(path, trim5p, err);
+    while (!rc) {
+        const uint8_t* p; size_t n;
+        rc = parser.next(&p, &n, err);
+        if (rc || !n) break;
+        rc = sink(p, n);
+        if (rc) { err->clear(); return rc; }
+    }
+    return rc;
+}
+
+}  // namespace
+
+int stream_group(const char* const* paths, size_t n_paths, const uint16_t* trim5p, uint32_t k,
+                 const std::function<int(const uint8_t*, size_t)>& sink, std::string* err) {
+    static const uint8_t sep = 'N';
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned max_readers = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(env_u64("KATGPU_INGEST_FILES", std::min(hw, 8u)), 64));
+    size_t i = 0;
+    while (i < n_paths) {
+        const uint32_t trim = trim5p ? trim5p[i] : 0;
+        if (team_applies(paths[i], trim)) {
+            // a large plain file: the thread team (same bytes out as the streaming parser)
+            int rc = parse_file_parallel(paths[i], trim, sink, err);
+            if (rc > 0) return rc;
+            if (rc < 0) { rc = stream_one(paths[i], trim, sink, err); if (rc) return rc; }    // it changed under us: stream it
+            rc = sink(&sep, 1);
+            if (rc) { err->clear(); return rc; }
+            ++i;
+            continue;
+        }
+        size_t j = i + 1;                                    // the run of streaming files that starts here
+        while (j < n_paths && !team_applies(paths[j], trim5p ? trim5p[j] : 0)) ++j;
+        const unsigned readers = (unsigned)std::min<size_t>(max_readers, j - i);
+        int rc;
+        if (readers <= 1) {
+            rc = KATGPU_OK;
+            for (size_t f = i; f < j && !rc; ++f) {
+                rc = stream_one(paths[f], trim5p ? trim5p[f] : 0, sink, err);
+                if (!rc) { rc = sink(&sep, 1); if (rc) err->clear(); }
+            }
+        } else rc = stream_run_concurrent(paths, trim5p, i, j, k, readers, sink, err);
+        if (rc) return rc;
+        i = j;
+    }
+    return KATGPU_OK;
+}
+
 }  // namespace kg
 
 extern "C" int katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** bases, size_t* n, const char** err_msg) {
@@ -344,6 +518,22 @@ extern "C" int katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** ba
             all.insert(all.end(), p, p + got);
         }
     }
+    if (rc) { if (err_msg) *err_msg = last.c_str(); return rc; }
+    *bases = (uint8_t*)malloc(all.size() ? all.size() : 1);
+    if (!*bases) return KATGPU_ERR_NOMEM;
+    memcpy(*bases, all.data(), all.size());
+    *n = all.size();
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_parse_files(const char* const* paths, size_t n_paths, const uint16_t* trim5p, uint32_t k,
+                                  uint8_t** bases, size_t* n, const char** err_msg) {
+    static thread_local std::string last;
+    if (!paths || !bases || !n) return KATGPU_ERR_INVALID_ARG;
+    *bases = nullptr; *n = 0;
+    std::vector<uint8_t> all;
+    last.clear();
+    int rc = kg::stream_group(paths, n_paths, trim5p, k, [&](const uint8_t* p, size_t got) { all.insert(all.end(), p, p + got); return 0; }, &last);
     if (rc) { if (err_msg) *err_msg = last.c_str(); return rc; }
     *bases = (uint8_t*)malloc(all.size() ? all.size() : 1);
     if (!*bases) return KATGPU_ERR_NOMEM;

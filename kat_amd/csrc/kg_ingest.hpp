@@ -50,8 +50,8 @@ public:
     SeqFileParser(const SeqFileParser&) = delete;
     SeqFileParser& operator=(const SeqFileParser&) = delete;
 
-    // returns a katgpu_status (0 ok); *err gets the message
-    int open(const char* path, uint32_t trim5p, std::string* err);
+    // returns a katgpu_status (0 ok); *err gets the message.  raw_bytes: how much of the (inflated) file one next() call reads
+    int open(const char* path, uint32_t trim5p, std::string* err, size_t raw_bytes = (size_t)16 << 20);
     // next piece of the base stream; *n == 0 means end of file
     int next(const uint8_t** p, size_t* n, std::string* err);
 
@@ -70,5 +70,19 @@ private:
 // the machine serially from that known state.  The output is therefore byte-identical to the streaming parser's whatever the
 // file looks like.  Returns a katgpu_status, or -1 when the file does not qualify (the caller then streams it).
 int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err);
+bool team_applies(const char* path, uint32_t trim5p);      // would parse_file_parallel take this file?
+
+// One input group (InputHandler::count's file list) -> the base stream the counter consumes, handed to `sink` piece by piece.
+// Files never join (mer_overlap_sequence_parser.hpp:151-155), so the stream is a sequence of file pieces with an 'N' wherever
+// the source changes.  Large plain files go through the thread team above, one after the other.  Runs of files that have to
+// stream (gzip, 5' trim, small) are read CONCURRENTLY, one reader thread per file (inflate is ~0.3 GB/s per stream, and paired
+// libraries come as two or more .gz files): the sink then sees the files' blocks interleaved, and every time the source
+// switches back to a file the stream carries 'N' followed by that file's previous k-1 bytes, so that each k-mer window of each
+// file appears in the stream exactly once.  The k-mer MULTISET of the stream is therefore that of the files read one by one
+// (tests/test_ingest_parser.py checks exactly this); the order is not, and no consumer here depends on it.
+// Errors: the one from the lowest-numbered bad file, as reading the files in order would report.
+// Returns a katgpu_status; a nonzero value returned by `sink` is passed through with *err left empty.
+int stream_group(const char* const* paths, size_t n_paths, const uint16_t* trim5p, uint32_t k,
+                 const std::function<int(const uint8_t*, size_t)>& sink, std::string* err);
 
 }  // namespace kg

@@ -353,6 +353,34 @@ def test_count_files_through_the_ingest_thread_team(engine, ko, refdata, tmp_pat
         t.free()
 
 
+@pytest.mark.parametrize("files_at_once,block", [(8, 97), (2, 5000), (1, 4 << 20)])
+def test_count_files_group_read_concurrently(engine, ko, refdata, tmp_path, monkeypatch, files_at_once, block):
+    """katgpu_count_files on a group of files that must stream (gzip; small; 5' trim): kg_ingest.hpp's stream_group reads them
+    concurrently and interleaves their blocks -- the table is the oracle's for the same files read one by one."""
+    import gzip
+    monkeypatch.setenv("KATGPU_INGEST_FILES", str(files_at_once))
+    monkeypatch.setenv("KATGPU_INGEST_BLOCK", str(block))
+    r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
+    z1, z2 = tmp_path / "r1.fq.gz", tmp_path / "r2.fq.gz"
+    for src, dst in ((r1, z1), (r2, z2)):
+        with open(src, "rb") as f, gzip.open(dst, "wb") as g:
+            g.write(f.read())
+    g = synth.genome(20000, seed=9)
+    fa = tmp_path / "asm.fa.gz"
+    with gzip.open(fa, "wb") as f:
+        for i in range(0, g.size, 4000):
+            f.write(b">c%d\n" % i + g[i:i + 4000].tobytes() + b"\n")
+    paths = [str(z1), str(z2), str(fa), r1, str(z2)]
+    for k, canonical, trims in ((27, True, None), (21, False, [0, 3, 0, 5, 1])):
+        t = engine.count(paths, k, canonical, trim5p=trims)
+        o = ko.Table(k, canonical).count_files(paths, trims)
+        gk, gc = t.dump_sorted()
+        ok_, oc = o.dump_sorted()
+        assert np.array_equal(gk, ok_) and np.array_equal(gc, oc)
+        assert t.stats()["total"] == int(oc.sum())
+        t.free()
+
+
 JF_REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "jf_ref")
 
 

@@ -136,3 +136,70 @@ def test_team_accepts_clean_files_and_falls_back_on_wrong_guesses(ko, tmp_path, 
     capfd.readouterr()
     assert stream_of(trap) == ko.parse_file(str(trap)).tobytes() == "N".join(">" + r for r in recs).encode()
     assert "streaming from offset" in capfd.readouterr().err
+
+
+# ---------------------------------------------------------------- one input group (kg_ingest.hpp: stream_group) ---------
+
+def _group(tmp_path, rng):
+    fa, fq, fqm = tmp_path / "g.fa", tmp_path / "g.fq", tmp_path / "gm.fq"
+    write_messy_fasta(str(fa), rng)
+    write_messy_fastq(str(fq), rng)
+    write_messy_fastq(str(fqm), rng, multiline=True)
+    z1, z2 = tmp_path / "z1.fq.gz", tmp_path / "z2.fa.gz"
+    write_messy_fastq(str(z1), rng)
+    with gzip.open(z2, "wb") as f:
+        f.write(fa.read_bytes())
+    tiny = tmp_path / "tiny.fa"
+    tiny.write_bytes(b">t\nACGTACGTACGTTTGACCA\n")
+    clean = tmp_path / "c.fq.gz"                                       # reads long enough for a 5' trim (the messy ones are not)
+    with gzip.open(clean, "wb") as f:
+        for i in range(300):
+            r = "".join(rng.choice(list("ACGTN"), int(rng.integers(30, 120)), p=[.24, .24, .24, .24, .04]))
+            f.write(("@c%d\n%s\n+\n%s\n" % (i, r, "I" * len(r))).encode())
+    return [str(p) for p in (z1, fa, z2, tiny, clean, fqm, z1)]       # a file may be named twice in a group
+
+
+def _kmer_table(ko, k, stream):
+    return ko.Table(k, True).count_bases(stream).dump_sorted()
+
+
+@pytest.mark.parametrize("files_at_once,block", [(1, 4 << 20), (2, 61), (8, 7), (8, 1000), (3, 4 << 20)])
+def test_group_stream_keeps_the_kmer_multiset(ko, tmp_path, monkeypatch, files_at_once, block):
+    """Files of a group that have to stream are read concurrently and their blocks interleave (with 'N' + the file's last k-1
+    bytes at each switch): the stream's k-mers, counted by the oracle, are those of the files counted one after the other."""
+    monkeypatch.setenv("KATGPU_INGEST_FILES", str(files_at_once))
+    monkeypatch.setenv("KATGPU_INGEST_BLOCK", str(block))
+    paths = _group(tmp_path, np.random.default_rng(11))
+    trims = [0, 1, 2, 0, 3, 0, 0]
+    for k in (5, 21, 31):
+        for tr in (None, trims):
+            stream = kat_amd.parse_files(paths, k, tr)
+            if tr is None:
+                want = ko.Table(k, True).count_files(paths).dump_sorted()
+            else:      # the oracle's FASTA 5' trim is the documented per-record one, as the product's: count the product's own per-file streams
+                want = _kmer_table(ko, k, b"N".join(kat_amd.parse_file(p, t).tobytes() for p, t in zip(paths, tr)))
+            got = _kmer_table(ko, k, stream)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (k, tr)
+            if files_at_once == 1:
+                assert stream.tobytes() == b"".join(kat_amd.parse_file(p, t).tobytes() + b"N" for p, t in zip(paths, tr or [0] * len(paths)))
+
+
+def test_group_errors_name_the_first_bad_file(tmp_path, monkeypatch):
+    monkeypatch.setenv("KATGPU_INGEST_BLOCK", "50")
+    good = tmp_path / "good.fa"
+    good.write_bytes(b"".join(b">r%d\n%s\n" % (i, b"ACGT" * 40) for i in range(200)))
+    badq = tmp_path / "bad.fq"
+    badq.write_bytes(b"".join(b"@r%d\nACGTACGT\n+\nIIIIIIII\n" % i for i in range(100)) + b"@x\nACGT\n+\nII")
+    junk = tmp_path / "junk.dat"
+    junk.write_bytes(b"hello\n")
+    missing = tmp_path / "missing.fq"
+    for n in (1, 8):
+        monkeypatch.setenv("KATGPU_INGEST_FILES", str(n))
+        for order, code, text in (([good, badq, junk, missing], 4, "Invalid fastq sequence"),
+                                  ([good, junk, badq, good], 3, "Unsupported format"),
+                                  ([missing, badq, junk], 2, "Could not find input file at"),
+                                  ([good, good, good, missing], 2, "Could not find input file at")):
+            with pytest.raises(kat_amd.KatGpuError) as ei:
+                kat_amd.parse_files([str(p) for p in order], 21)
+            assert ei.value.code == code and text in ei.value.message, (n, order)
+    assert kat_amd.parse_files([], 21).size == 0
