@@ -234,7 +234,10 @@ int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<i
     const int64_t seg = (int64_t)std::max<uint64_t>(16, env_u64("KATGPU_INGEST_SEGMENT", (uint64_t)16 << 20));
     const int64_t margin = (int64_t)std::max<uint64_t>(16, env_u64("KATGPU_INGEST_MARGIN", (uint64_t)4 << 20));
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(env_u64("KATGPU_INGEST_THREADS", std::min(hw, 64u)), 256));
+    // 16: measured on the MI355X host (2 x EPYC 9575F, tools/bench_ingest_host.sh): 35 GB/s of FASTQ into a null sink with 16
+    // threads, 23 with 32, 11 with 64 -- every wave's fresh buffers are first touched by all threads at once, and page faults of
+    // one process serialise on its address-space lock.  The feeder behind it takes ~22 GB/s.
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(env_u64("KATGPU_INGEST_THREADS", std::min(hw, 16u)), 256));
     const int fd = ::open(path, O_RDONLY);
     if (fd < 0) return -1;
     struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};

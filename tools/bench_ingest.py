@@ -16,7 +16,7 @@ import kat_amd  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gb", type=float, default=4.0)
-    ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--k", type=int, default=27)
     a = ap.parse_args()
     path = "/tmp/katgpu_ingest_bench.fq"
