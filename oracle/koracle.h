@@ -98,6 +98,28 @@ void ko_comp3(const ko_table* t1, const ko_table* t2, const ko_table* t3, int ca
               uint64_t* main_mx, uint64_t* ends_mx, uint64_t* middle_mx, uint64_t* mixed_mx,
               uint64_t counters[13], uint64_t* spectra);
 
+/* --- k > 32 (koracle_wide.c): the same semantics for k-mers of 1..64 bases, one k-mer = (hi, lo) = the 2k-bit word's upper and
+ * lower 64 bits.  Checked against koracle.c for k <= 32 and against oracle/_ref/jf_ref (the reference's parser + mer_dna)
+ * and tests/naive.py for k > 32 (tests/test_oracle_wide.py). --- */
+typedef struct ko_wtable ko_wtable;
+ko_wtable* ko_wtable_new(unsigned k, int canonical);
+void      ko_wtable_free(ko_wtable*);
+unsigned  ko_wtable_k(const ko_wtable*);
+uint64_t  ko_wtable_distinct(const ko_wtable*);
+uint64_t  ko_wtable_total(const ko_wtable*);
+void      ko_wtable_add(ko_wtable*, uint64_t hi, uint64_t lo, uint64_t amount);
+uint64_t  ko_wtable_get(const ko_wtable*, uint64_t hi, uint64_t lo);
+void      ko_wtable_dump_sorted(const ko_wtable*, uint64_t* hi, uint64_t* lo, uint64_t* counts);   /* ko_wtable_distinct entries, by key */
+void      ko_wcount_bases(ko_wtable*, const uint8_t* bases, size_t n);
+int       ko_wcount_files(ko_wtable*, const char* const* paths, size_t n_paths, const uint16_t* trim5p);
+void      ko_whist(const ko_wtable*, uint64_t base, uint64_t ceil_, uint64_t inc, uint64_t* out, size_t nb);
+void      ko_wgcp(const ko_wtable*, double cvg_scale, uint32_t cvg_bins, uint64_t* out);
+void      ko_wcomp(const ko_wtable* t1, const ko_wtable* t2, int canon1, int canon2, double d1_scale, double d2_scale,
+                   uint32_t d1_bins, uint32_t d2_bins, uint64_t* main_mx, uint64_t counters[13], uint64_t* spectra);
+void      ko_wcomp3(const ko_wtable* t1, const ko_wtable* t2, const ko_wtable* t3, int canon1, int canon2, int canon3,
+                    double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins,
+                    uint64_t* main_mx, uint64_t* ends_mx, uint64_t* middle_mx, uint64_t* mixed_mx, uint64_t counters[13], uint64_t* spectra);
+
 /* --- writers (byte-exact text) --- */
 int ko_write_hist(const char* out_path, unsigned k, const char* const* paths, size_t n_paths,
                   uint64_t base, uint64_t inc, const uint64_t* data, size_t nb);

@@ -26,7 +26,7 @@ def lib():
         return _LIB
     so = os.path.join(_HERE, "libkoracle.so")
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, f))
-                                     for f in ("koracle.c", "koracle_sect.c", "koracle.h")):
+                                     for f in ("koracle.c", "koracle_sect.c", "koracle_wide.c", "koracle.h")):
         build()
     L = C.CDLL(so)
     L.ko_table_new.restype = C.c_void_p
@@ -57,6 +57,22 @@ def lib():
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ko_write_comp_stats3.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.ko_write_comp_extra.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.ko_wtable_new.restype = C.c_void_p
+    L.ko_wtable_new.argtypes = [C.c_uint, C.c_int]
+    L.ko_wtable_free.argtypes = [C.c_void_p]
+    for f in ("ko_wtable_distinct", "ko_wtable_total"):
+        getattr(L, f).restype = C.c_uint64
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.ko_wtable_add.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.ko_wtable_get.restype = C.c_uint64
+    L.ko_wtable_get.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.ko_wtable_dump_sorted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ko_wcount_bases.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.ko_wcount_files.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_uint16)]
+    L.ko_whist.argtypes = L.ko_hist.argtypes
+    L.ko_wgcp.argtypes = L.ko_gcp.argtypes
+    L.ko_wcomp.argtypes = L.ko_comp.argtypes
+    L.ko_wcomp3.argtypes = L.ko_comp3.argtypes
     L.ko_encode.argtypes = [C.c_char_p, C.c_uint, u64p]
     L.ko_decode.argtypes = [C.c_uint64, C.c_uint, C.c_char_p]
     L.ko_revcomp.restype = C.c_uint64
@@ -205,6 +221,69 @@ class Table:
         return out
 
 
+M64 = (1 << 64) - 1
+
+
+class WideTable:
+    """The same multiset for k-mers of up to 64 bases (koracle_wide.c); keys are Python ints of 2k bits, dumps are (hi, lo, counts)."""
+
+    def __init__(self, k, canonical=True):
+        self.h = lib().ko_wtable_new(k, int(bool(canonical)))
+        if not self.h:
+            raise OracleError(4)
+        self.k = k
+        self.canonical = bool(canonical)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ko_wtable_free(self.h)
+            self.h = None
+
+    def count_bases(self, bases):
+        b = np.ascontiguousarray(np.frombuffer(bases, dtype=np.uint8) if isinstance(bases, (bytes, bytearray)) else bases, dtype=np.uint8)
+        lib().ko_wcount_bases(self.h, b.ctypes.data, b.size)
+        return self
+
+    def count_files(self, paths, trim5p=None):
+        arr, n = _paths(paths)
+        tr = (C.c_uint16 * n)(*trim5p) if trim5p else None
+        rc = lib().ko_wcount_files(self.h, arr, n, tr)
+        if rc:
+            raise OracleError(rc)
+        return self
+
+    def add(self, key, amount=1):
+        lib().ko_wtable_add(self.h, int(key) >> 64, int(key) & M64, int(amount))
+
+    def get(self, key):
+        return lib().ko_wtable_get(self.h, int(key) >> 64, int(key) & M64)
+
+    @property
+    def distinct(self):
+        return lib().ko_wtable_distinct(self.h)
+
+    @property
+    def total(self):
+        return lib().ko_wtable_total(self.h)
+
+    def dump_sorted(self):
+        n = self.distinct
+        hi, lo, counts = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        lib().ko_wtable_dump_sorted(self.h, hi.ctypes.data, lo.ctypes.data, counts.ctypes.data)
+        return hi, lo, counts
+
+    def hist(self, low=1, high=10000, inc=1):
+        base, ceil_, nb = hist_geometry(low, high)
+        out = np.zeros(nb, np.uint64)
+        lib().ko_whist(self.h, base, ceil_, inc, out.ctypes.data, nb)
+        return out
+
+    def gcp(self, cvg_scale=1.0, cvg_bins=1000):
+        out = np.zeros((self.k, cvg_bins + 1), np.uint64)
+        lib().ko_wgcp(self.h, cvg_scale, cvg_bins, out.ctypes.data)
+        return out
+
+
 def hist_geometry(low, high):
     """Histogram::calcBase / calcCeil / nb_buckets (src/histogram.hpp:172-178, src/histogram.cc:68-70)."""
     base = low - 1 if low > 1 else 1
@@ -217,7 +296,10 @@ def comp(t1, t2, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001, threads
     mx = np.zeros((d1_bins, d2_bins), np.uint64)
     cc = np.zeros(13, np.uint64)
     sp = np.zeros((4, ss), np.uint64)
-    if threads > 1:
+    if isinstance(t1, WideTable):
+        lib().ko_wcomp(t1.h, t2.h, int(t1.canonical), int(t2.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
+                       mx.ctypes.data, cc.ctypes.data, sp.ctypes.data)
+    elif threads > 1:
         lib().ko_comp_mt(t1.h, t2.h, int(t1.canonical), int(t2.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
                          mx.ctypes.data, cc.ctypes.data, sp.ctypes.data, threads)
     else:
@@ -267,7 +349,8 @@ def comp3(t1, t2, t3, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001):
     mxs = [np.zeros((d1_bins, d2_bins), np.uint64) for _ in range(4)]
     cc = np.zeros(13, np.uint64)
     sp = np.zeros((4, ss), np.uint64)
-    lib().ko_comp3(t1.h, t2.h, t3.h, int(t1.canonical), int(t2.canonical), int(t3.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
+    fn = lib().ko_wcomp3 if isinstance(t1, WideTable) else lib().ko_comp3
+    fn(t1.h, t2.h, t3.h, int(t1.canonical), int(t2.canonical), int(t3.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
                    mxs[0].ctypes.data, mxs[1].ctypes.data, mxs[2].ctypes.data, mxs[3].ctypes.data, cc.ctypes.data, sp.ctypes.data)
     return mxs[0], mxs[1], mxs[2], mxs[3], cc, sp
 
