@@ -29,6 +29,13 @@ extern "C" {
 typedef struct katgpu_ctx katgpu_ctx;
 typedef struct katgpu_table katgpu_table;
 
+/* k-mer lengths.  1..32: one 64-bit word per k-mer (all entry points).  33..KATGPU_MAX_K: "wide" tables, the k-mer's 2k bits
+ * in two words -- counted and reduced (count*, stats, hist, gcp, comp, comp3) exactly like the narrow ones; records move
+ * through the *_wide entry points as (hi, lo) = the upper and lower 64 bits of the 2k-bit word (first base most significant,
+ * A=0 C=1 G=2 T=3, as mer_dna: JF/include/jellyfish/mer_dna.hpp:235-258).  Entry points that take 64-bit keys, .jf files,
+ * the multi-GPU exchange and the sect/cold profile return KATGPU_ERR_K for a wide table. */
+#define KATGPU_MAX_K 63
+
 typedef enum katgpu_status {
     KATGPU_OK = 0,
     KATGPU_ERR_INVALID_ARG = 1,
@@ -36,7 +43,8 @@ typedef enum katgpu_status {
     KATGPU_ERR_FORMAT = 3,      /* "Unsupported format"                  JF/include/jellyfish/mer_overlap_sequence_parser.hpp:184 */
     KATGPU_ERR_FASTQ = 4,       /* "Invalid fastq sequence"              mer_overlap_sequence_parser.hpp:288 */
     KATGPU_ERR_NOMEM = 5,       /* device allocation failed */
-    KATGPU_ERR_K = 6,           /* k outside 1..32 (reference: any k, JF/include/jellyfish/mer_dna.hpp:725) */
+    KATGPU_ERR_K = 6,           /* k outside 1..KATGPU_MAX_K (reference: any k, JF/include/jellyfish/mer_dna.hpp:725), or an
+                                 * entry point that handles one-word k-mers only called on a k > 32 table */
     KATGPU_ERR_TABLE_FULL = 7,  /* "Hash full"                           JF/include/jellyfish/hash_counter.hpp:198-199 */
     KATGPU_ERR_DEVICE = 8,      /* HIP runtime error / no gfx950 device */
     KATGPU_ERR_MISMATCH = 9     /* tables with different k   lib/src/input_handler.cc:145-158 (validateMerLen) */
@@ -115,6 +123,11 @@ int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_bases, size_
 /* All (key,count) pairs in unspecified order (the eager_iterator walk, JF/.../large_hash_iterator.hpp:28-65).
  * Pass cap = 0 to query *n_out only. */
 int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* counts, size_t cap, size_t* n_out);
+/* The same three for wide tables (33 <= k <= KATGPU_MAX_K). */
+int katgpu_table_get_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, size_t n, int canonicalise, uint64_t* counts);
+int katgpu_table_export_wide(katgpu_table* t, uint64_t* keys_hi, uint64_t* keys_lo, uint64_t* counts, size_t cap, size_t* n_out);
+/* hash_counter::add for a batch of (k-mer, amount) records (what katgpu_table_merge_host is for narrow tables) */
+int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, const uint64_t* counts, size_t n);
 
 /* ---- Jellyfish hash files (.jf, "binary/sorted"): replaces HashLoader::loadHash / JellyfishHelper::dumpHash
  *      (lib/src/jellyfish_helper.cc:97-187,248-256) and InputHandler::dump (lib/src/input_handler.cc:221-243).

@@ -30,6 +30,7 @@ EXPORTS = (
     "katgpu_table_merge_device32", "katgpu_table_merge_regions", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
     "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_parse_files", "katgpu_free_host",
+    "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
 )
 
@@ -120,6 +121,9 @@ def load_library():
     L.katgpu_synth_genome_device.argtypes = [vp, vp, u64, u64, u64]
     L.katgpu_synth_reads_device.argtypes = [vp, vp, u64, vp, u64, u64, u32, u32, u32, u64]
     L.katgpu_parse_file.argtypes = [C.c_char_p, u32, pp, C.POINTER(sz), cpp]
+    L.katgpu_table_get_wide.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+    L.katgpu_table_export_wide.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
+    L.katgpu_table_merge_host_wide.argtypes = [vp, vp, vp, vp, sz]
     L.katgpu_parse_files.argtypes = [vp, sz, vp, u32, pp, C.POINTER(sz), cpp]
     L.katgpu_free_host.argtypes = [vp]
     L.katgpu_free_host.restype = None
@@ -424,9 +428,36 @@ class Table:
         return keys, counts
 
     def dump_sorted(self):
+        if self.k > 32:
+            return self.dump_sorted_wide()
         keys, counts = self.export()
         order = np.argsort(keys, kind="stable")
         return keys[order], counts[order]
+
+    # ---- wide tables (33 <= k <= 63): a k-mer is (hi, lo), the upper and lower 64 bits of its 2k-bit word ----
+    def export_wide(self):
+        n = C.c_size_t()
+        self.engine._chk(self.engine.L.katgpu_table_export_wide(self.h, None, None, None, 0, C.byref(n)))
+        hi, lo, counts = np.zeros(n.value, np.uint64), np.zeros(n.value, np.uint64), np.zeros(n.value, np.uint64)
+        if n.value:
+            self.engine._chk(self.engine.L.katgpu_table_export_wide(self.h, hi.ctypes.data, lo.ctypes.data, counts.ctypes.data, n.value, C.byref(n)))
+        return hi, lo, counts
+
+    def dump_sorted_wide(self):
+        hi, lo, counts = self.export_wide()
+        order = np.lexsort((lo, hi))
+        return hi[order], lo[order], counts[order]
+
+    def merge_host_wide(self, hi, lo, counts):
+        h, l, c = (np.ascontiguousarray(x, np.uint64) for x in (hi, lo, counts))
+        assert h.size == l.size == c.size
+        self.engine._chk(self.engine.L.katgpu_table_merge_host_wide(self.h, h.ctypes.data, l.ctypes.data, c.ctypes.data, h.size))
+
+    def get_wide(self, hi, lo, canonicalise=False):
+        h, l = np.ascontiguousarray(hi, np.uint64), np.ascontiguousarray(lo, np.uint64)
+        out = np.zeros(h.size, np.uint64)
+        self.engine._chk(self.engine.L.katgpu_table_get_wide(self.h, h.ctypes.data, l.ctypes.data, h.size, int(bool(canonicalise)), out.ctypes.data))
+        return out
 
     def dump_jf(self, path):
         """InputHandler::dump: write the table as a Jellyfish binary/sorted hash."""

@@ -4,6 +4,7 @@
 #include "kg_ingest.hpp"
 #include "kg_kernels.hpp"
 #include "kg_partition.hpp"
+#include "kg_wide.hpp"
 
 #include <algorithm>
 #include <cstdarg>
@@ -73,6 +74,12 @@ static int fail(katgpu_ctx* c, int code, const char* fmt, ...) {
     if (c) c->err = buf;
     return code;
 }
+
+// entry points that handle one-word k-mers only (lookups by 64-bit key, .jf, the multi-GPU exchange, sect/cold profiles)
+#define NARROW_ONLY(t, what)                                                                             \
+    do {                                                                                                 \
+        if ((t)->d.keys_b) return fail((t)->ctx, KATGPU_ERR_K, "%s is not available for k > 32 (k = %u)", what, (t)->d.k); \
+    } while (0)
 
 #define HIPCHK(c, expr)                                                                                  \
     do {                                                                                                 \
@@ -294,7 +301,10 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
     cap = (uint64_t)d.n_regions * d.region_slots;
     d.cap = cap; d.k = k; d.canonical = canonical ? 1 : 0;
     const double t0 = now_ms();
-    HIPCHK(c, pool_alloc(c, (void**)&d.keys, cap * sizeof(uint64_t)));
+    const bool wide = k > 32;                                  // two key words per slot (kg_device.hpp "wide keys"), one block
+    const size_t key_bytes = cap * sizeof(uint64_t) * (wide ? 2 : 1);
+    HIPCHK(c, pool_alloc(c, (void**)&d.keys, key_bytes));
+    if (wide) d.keys_b = d.keys + cap;
     if (g_trace) fprintf(stderr, "[katgpu] alloc keys %.1f GB: %.1f ms\n", cap * 8 / 1e9, now_ms() - t0);
     hipError_t e = pool_alloc(c, (void**)&d.counts, cap * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&d.ovf_keys, OVF_CAP * sizeof(uint64_t));
@@ -304,7 +314,7 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
         pool_release(c, d.keys); pool_release(c, d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
         return fail(c, KATGPU_ERR_NOMEM, "device allocation of a %llu-slot table failed: %s", (unsigned long long)cap, hipGetErrorString(e));
     }
-    HIPCHK(c, hipMemsetAsync(d.keys, 0xFF, cap * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(d.keys, 0xFF, key_bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(d.counts, 0, cap * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_hi, 0, OVF_CAP * sizeof(uint64_t), c->stream));
@@ -323,7 +333,7 @@ static void free_dev_table(katgpu_ctx* c, DevTable& d) {
 extern "C" int katgpu_table_create(katgpu_ctx* c, uint32_t k, int canonical, uint64_t size_hint, int disable_grow, katgpu_table** out) {
     if (!c || !out) return KATGPU_ERR_INVALID_ARG;
     *out = nullptr;
-    if (k < 1 || k > 32) return fail(c, KATGPU_ERR_K, "k = %u unsupported: this build packs a k-mer into one 64-bit word (1 <= k <= 32)", k);
+    if (k < 1 || k > KATGPU_MAX_K) return fail(c, KATGPU_ERR_K, "k = %u unsupported: this build keeps a k-mer in at most two 63-bit words (1 <= k <= %d)", k, KATGPU_MAX_K);
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t cap = std::max<uint64_t>(size_hint ? size_hint : (1u << 20), 1024);
     katgpu_table* t = new katgpu_table();
@@ -338,12 +348,13 @@ extern "C" int katgpu_table_create_like(katgpu_ctx* c, const katgpu_table* like,
                                         int disable_grow, katgpu_table** out) {
     if (!c || !out || !like) return KATGPU_ERR_INVALID_ARG;
     *out = nullptr;
-    if (k < 1 || k > 32) return fail(c, KATGPU_ERR_K, "k = %u unsupported: this build packs a k-mer into one 64-bit word (1 <= k <= 32)", k);
+    if (k < 1 || k > KATGPU_MAX_K) return fail(c, KATGPU_ERR_K, "k = %u unsupported: this build keeps a k-mer in at most two 63-bit words (1 <= k <= %d)", k, KATGPU_MAX_K);
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t cap = std::max<uint64_t>(size_hint ? size_hint : (1u << 20), 1024);
     katgpu_table* t = new katgpu_table();
     t->ctx = c; t->disable_grow = disable_grow;
-    int rc = alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2);
+    int rc = (k > 32) != (like->d.k > 32) ? alloc_dev_table(c, k, canonical, cap, &t->d)     // no common grid across key widths
+                                          : alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2);
     if (rc) { delete t; return rc; }
     *out = t;
     return KATGPU_OK;
@@ -384,7 +395,8 @@ static int regrow(katgpu_table* t, uint64_t new_cap) {
     if (rc) return rc;
     {
         ScopedTimer tm(c, KATGPU_K_REGROW, t->d.cap);
-        hipLaunchKernelGGL(k_regrow, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, nd, t->d, t->n_ovf);
+        if (t->d.keys_b) hipLaunchKernelGGL(k_regrow_w, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, nd, t->d, t->n_ovf);
+        else hipLaunchKernelGGL(k_regrow, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, nd, t->d, t->n_ovf);
     }
     HIPCHK(c, hipMemcpyAsync(&nd.ctrs[CTR_ONES], &t->d.ctrs[CTR_ONES], sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -436,6 +448,17 @@ static int maybe_sweep(katgpu_table* t, uint64_t next_starts) {
 static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
     katgpu_ctx* c = t->ctx;
     if (n < t->d.k) return KATGPU_OK;
+    if (t->d.keys_b) {                                         // wide k-mers: checked adds, nothing to sweep
+        const uint64_t n_chunks = (n + WIDE_CHUNK_STARTS - 1) / WIDE_CHUNK_STARTS;
+        const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * 4);
+        ScopedTimer tm(c, KATGPU_K_COUNT, n);
+        if ((reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0)
+            hipLaunchKernelGGL(k_count_w<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
+        else
+            hipLaunchKernelGGL(k_count_w<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
+        HIPCHK(c, hipGetLastError());
+        return KATGPU_OK;
+    }
     int src = maybe_sweep(t, n);
     if (src) return src;
     t->unchecked_adds += n;
@@ -783,7 +806,7 @@ extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bas
     const size_t n_starts = n - k + 1;
     // Large, aligned inputs go through the partitioned counter (no global atomic per k-mer); whatever it leaves (nothing,
     // normally) and everything small goes through the direct kernel below.
-    while (n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
+    while (!t->d.keys_b && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
         size_t done = 0;                        // returns early (done < remaining) when a table growth cost it the arena
         int prc = count_partitioned(t, dev_bases + pos, n - pos, &done);
         if (prc) return prc;
@@ -830,7 +853,7 @@ static int ensure_staging(katgpu_ctx* c) {
 // Each staged batch starts with the previous batch's last k-1 bytes so windows across the cut are counted once.
 struct HostFeeder {
     katgpu_table* t; katgpu_ctx* c; int cur = 0; size_t fill = 0; bool used[2] = {false, false};
-    static constexpr size_t HEAD = 32;        // carry area: keeps the payload 16-byte aligned
+    static constexpr size_t HEAD = 64;        // carry area (k - 1 <= 62 bytes): keeps the payload 16-byte aligned
     explicit HostFeeder(katgpu_table* t_) : t(t_), c(t_->ctx) {}
     int begin() {
         int rc = ensure_staging(c); if (rc) return rc;
@@ -946,6 +969,7 @@ extern "C" int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t*
 
 extern "C" int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n, int canonicalise, uint64_t* counts) {
     if (!t || (n && (!keys || !counts))) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "katgpu_table_get: use katgpu_table_get_wide;");
     if (!n) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -978,6 +1002,7 @@ static int launch_profile(katgpu_table* t, const uint8_t* dev_bases, size_t n, i
 
 extern "C" int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_bases, size_t n, int canonicalise, uint64_t* dev_counts) {
     if (!t || (n && (!dev_bases || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "katgpu_table_profile (kat sect / kat cold)");
     if (n < t->d.k) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -989,6 +1014,7 @@ extern "C" int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_b
 // k-1 bases it shares with the next one), so any length fits next to the table.
 extern "C" int katgpu_table_profile_host(katgpu_table* t, const char* bases, size_t n, int canonicalise, uint64_t* counts) {
     if (!t || (n && (!bases || !counts))) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "katgpu_table_profile (kat sect / kat cold)");
     const uint32_t k = t->d.k;
     if (n < k) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;
@@ -1022,6 +1048,7 @@ extern "C" int katgpu_table_profile_host(katgpu_table* t, const char* bases, siz
 
 extern "C" int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, uint64_t* sizes) {
     if (!t || !sizes || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "katgpu_table_partition");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
@@ -1041,6 +1068,7 @@ extern "C" int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, u
 
 extern "C" int katgpu_table_partition(katgpu_table* t, uint32_t n_parts, const uint64_t* offsets, uint64_t* dev_keys, uint64_t* dev_counts) {
     if (!t || !offsets || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "katgpu_table_partition");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
@@ -1059,6 +1087,7 @@ extern "C" int katgpu_table_partition(katgpu_table* t, uint32_t n_parts, const u
 
 extern "C" int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* counts, size_t cap, size_t* n_out) {
     if (!t || !n_out) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "katgpu_table_export: use katgpu_table_export_wide;");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
@@ -1081,6 +1110,7 @@ extern "C" int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* co
 
 extern "C" int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_keys, const uint64_t* dev_counts, size_t n) {
     if (!t || (n && (!dev_keys || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "katgpu_table_merge_device");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     size_t pos = 0;
@@ -1106,6 +1136,7 @@ extern "C" int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_ke
 
 extern "C" int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, const uint64_t* counts, size_t n) {
     if (!t || (n && (!keys || !counts))) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "katgpu_table_merge_host: use katgpu_table_merge_host_wide;");
     if (!n) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1119,10 +1150,93 @@ extern "C" int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, co
     return rc;
 }
 
+// ------------------------------------------------------------------ wide tables (33 <= k <= 63): records in and out ----
+
+extern "C" int katgpu_table_export_wide(katgpu_table* t, uint64_t* keys_hi, uint64_t* keys_lo, uint64_t* counts, size_t cap, size_t* n_out) {
+    if (!t || !n_out) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_export_wide is for k > 32 tables (k = %u): use katgpu_table_export", t->d.k);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    *n_out = (size_t)t->distinct;
+    if (cap == 0) return KATGPU_OK;
+    if (cap < t->distinct || !keys_hi || !keys_lo || !counts) return fail(c, KATGPU_ERR_INVALID_ARG, "export buffer too small: %zu < %llu", cap, (unsigned long long)t->distinct);
+    if (!t->distinct) return KATGPU_OK;
+    const size_t n = (size_t)t->distinct;
+    uint64_t* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, (3 * n + 1) * 8));
+    unsigned long long* cursor = (unsigned long long*)(d + 3 * n);
+    hipMemsetAsync(cursor, 0, 8, c->stream);
+    hipLaunchKernelGGL(k_export_w, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, d, d + n, d + 2 * n, cursor);
+    hipMemcpyAsync(keys_hi, d, n * 8, hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(keys_lo, d + n, n * 8, hipMemcpyDeviceToHost, c->stream);
+    hipMemcpyAsync(counts, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, const uint64_t* counts, size_t n) {
+    if (!t || (n && (!keys_hi || !keys_lo || !counts))) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_merge_host_wide is for k > 32 tables (k = %u): use katgpu_table_merge_host", t->d.k);
+    if (!n) return KATGPU_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t k = t->d.k;
+    const uint64_t hi_mask = (1ULL << (2 * k - 64)) - 1;           // 2 <= 2k - 64 <= 62
+    for (size_t i = 0; i < n; ++i)
+        if (keys_hi[i] & ~hi_mask) return fail(c, KATGPU_ERR_INVALID_ARG, "record %zu: key wider than 2k = %u bits", i, 2 * k);
+    uint64_t* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 3 * n * 8));
+    hipMemcpy(d, keys_hi, n * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d + n, keys_lo, n * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d + 2 * n, counts, n * 8, hipMemcpyHostToDevice);
+    int rc = KATGPU_OK;
+    size_t pos = 0;
+    while (pos < n && !rc) {
+        rc = refresh_counters(t); if (rc) break;
+        const uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
+        const uint64_t want = n - pos;
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
+            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
+            continue;
+        }
+        const uint64_t take = std::min(want, room);
+        ScopedTimer tm(c, KATGPU_K_MERGE, take);
+        hipLaunchKernelGGL(k_merge_w, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->d, d + pos, d + n + pos, d + 2 * n + pos, (uint64_t)take);
+        pos += take;
+    }
+    if (!rc) rc = refresh_counters(t);
+    hipStreamSynchronize(c->stream);
+    hipFree(d);
+    return rc;
+}
+
+extern "C" int katgpu_table_get_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, size_t n, int canonicalise, uint64_t* counts) {
+    if (!t || (n && (!keys_hi || !keys_lo || !counts))) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_get_wide is for k > 32 tables (k = %u): use katgpu_table_get", t->d.k);
+    if (!n) return KATGPU_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    uint64_t* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 3 * n * 8));
+    hipMemcpyAsync(d, keys_hi, n * 8, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(d + n, keys_lo, n * 8, hipMemcpyHostToDevice, c->stream);
+    hipLaunchKernelGGL(k_get_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, t->d, t->n_ovf, d, d + n, (uint64_t)n, canonicalise, d + 2 * n);
+    hipMemcpyAsync(counts, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
 // ------------------------------------------------------------------ region-ordered exchange -----------
 
 extern "C" int katgpu_table_geometry(const katgpu_table* t, katgpu_geometry* g) {
     if (!t || !g) return KATGPU_ERR_INVALID_ARG;
+    if (t->d.keys_b) return fail(t->ctx, KATGPU_ERR_K, "the multi-GPU exchange is not available for k > 32 (k = %u)", t->d.k);
     g->k = t->d.k; g->canonical = t->d.canonical; g->n_regions = t->d.n_regions; g->region_slots = t->d.region_slots;
     g->p1 = t->d.p1; g->p2 = t->d.p2; g->capacity = t->d.cap;
     return KATGPU_OK;
@@ -1130,6 +1244,7 @@ extern "C" int katgpu_table_geometry(const katgpu_table* t, katgpu_geometry* g) 
 
 extern "C" int katgpu_table_extract_sizes(katgpu_table* t, uint32_t n_parts, uint32_t* dev_region_counts, uint64_t* part_sizes) {
     if (!t || !dev_region_counts || !part_sizes || n_parts == 0 || n_parts > MAX_EXCHANGE_PARTS) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
@@ -1151,6 +1266,7 @@ extern "C" int katgpu_table_extract_sizes(katgpu_table* t, uint32_t n_parts, uin
 extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint64_t* dev_keys, uint32_t* dev_counts,
                                     uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big) {
     if (!t || !dev_region_counts || !dev_keys || !dev_counts || !n_big || n_parts == 0 || n_parts > MAX_EXCHANGE_PARTS || (big_cap && (!big_keys || !big_counts)))
+    NARROW_ONLY(t, "the multi-GPU exchange");
         return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1205,6 +1321,7 @@ extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uin
 
 extern "C" int katgpu_table_clear(katgpu_table* t) {
     if (!t) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     DevTable& d = t->d;
@@ -1240,6 +1357,7 @@ static int merge_direct32(katgpu_table* t, const uint64_t* dev_keys, const uint3
 
 extern "C" int katgpu_table_merge_device32(katgpu_table* t, const uint64_t* dev_keys, const uint32_t* dev_counts, size_t n) {
     if (!t || (n && (!dev_keys || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
     HIPCHK(t->ctx, hipSetDevice(t->ctx->device));
     return merge_direct32(t, dev_keys, dev_counts, n);
 }
@@ -1248,6 +1366,7 @@ static const bool g_no_merge_apply = getenv("KATGPU_NO_MERGE_APPLY") != nullptr;
 
 extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source* src) {
     if (!t || !src || n_src == 0 || g_lo > g_hi) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
@@ -1374,11 +1493,15 @@ extern "C" int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, 
     const size_t lds = cells * sizeof(uint32_t);
     const uint32_t use_lds = lds <= 150 * 1024 ? 1 : 0;                         // 160 KB LDS per CU
     if (use_lds && lds > 64 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_gcp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(t->d.keys_b ? k_gcp<true> : k_gcp<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         ScopedTimer tm(c, KATGPU_K_GCP, t->d.cap);
-        hipLaunchKernelGGL(k_gcp, dim3(reducer_grid(c, t->d.cap, use_lds ? 1 : 8)), dim3(256), use_lds ? lds : 0, c->stream,
-                           t->d, t->n_ovf, cvg_scale, cvg_bins, d, use_lds);
+        if (t->d.keys_b)
+            hipLaunchKernelGGL(k_gcp<true>, dim3(reducer_grid(c, t->d.cap, use_lds ? 1 : 8)), dim3(256), use_lds ? lds : 0, c->stream,
+                               t->d, t->n_ovf, cvg_scale, cvg_bins, d, use_lds);
+        else
+            hipLaunchKernelGGL(k_gcp<false>, dim3(reducer_grid(c, t->d.cap, use_lds ? 1 : 8)), dim3(256), use_lds ? lds : 0, c->stream,
+                               t->d, t->n_ovf, cvg_scale, cvg_bins, d, use_lds);
     }
     HIPCHK(c, hipGetLastError());
     hipMemcpyAsync(out, d, cells * 8, hipMemcpyDeviceToHost, c->stream);
@@ -1399,6 +1522,7 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t1); if (rc) return rc;
     rc = refresh_counters(t2); if (rc) return rc;
+    const bool wide = t1->d.keys_b != nullptr;               // same k => same key width in both tables
     const uint32_t ss = std::min(d1_bins, d2_bins);
     const size_t mx_cells = (size_t)d1_bins * d2_bins, total = mx_cells + 13 + 4 * (size_t)ss;
     unsigned long long* d = nullptr;
@@ -1411,12 +1535,12 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     const size_t lds1 = 16 * 8 + COMP_TILE * COMP_TILE * 4 + 3 * (size_t)ss * 4, lds2 = 16 * 8 + COMP_TILE * COMP_TILE * 4 + (size_t)ss * 4;
     if (lds1 > 150 * 1024) { hipFree(d); return fail(c, KATGPU_ERR_INVALID_ARG, "min(d1_bins,d2_bins) = %u too large for the LDS-privatised spectra", ss); }
     if (lds1 > 64 * 1024) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(wide ? k_comp<1, true> : k_comp<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(wide ? k_comp<2, true> : k_comp<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     }
     // Join form (region r of one table against region r of the other, in LDS) whenever the two tables share the region grid
     // and the probe key equals the stored key; probe form (random HBM probes) otherwise.
-    const bool same_grid = t1->d.p1 == t2->d.p1 && t1->d.p2 == t2->d.p2 && t1->d.n_regions > 1 && !g_no_join;
+    const bool same_grid = !wide && t1->d.p1 == t2->d.p1 && t1->d.p2 == t2->d.p2 && t1->d.n_regions > 1 && !g_no_join;   // the join holds 12-byte slots
     const bool ident1 = t1->d.canonical || !canon2;          // pass 1 probes canonical(key) iff input 2 is canonical
     const bool ident2 = t2->d.canonical != 0;                // pass 2 always probes canonical(key)
     const size_t join1 = ((lds1 + 15) & ~(size_t)15) + (size_t)t2->d.region_slots * 12, join2 = ((lds2 + 15) & ~(size_t)15) + (size_t)t1->d.region_slots * 12;
@@ -1432,16 +1556,20 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
         if (same_grid && ident1 && join1 <= 150 * 1024 && (g_force_join || join_pays(t1, t2))) {
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             hipLaunchKernelGGL(k_comp_join<1>, dim3(join_grid(join1, t1->d.n_regions)), dim3(512), join1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
-        } else
-            hipLaunchKernelGGL(k_comp<1>, dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
+        } else if (wide)
+            hipLaunchKernelGGL((k_comp<1, true>), dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
+        else
+            hipLaunchKernelGGL((k_comp<1, false>), dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
     }
     {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS2, t2->d.cap);
         if (same_grid && ident2 && join2 <= 150 * 1024 && (g_force_join || join_pays(t2, t1))) {
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             hipLaunchKernelGGL(k_comp_join<2>, dim3(join_grid(join2, t2->d.n_regions)), dim3(512), join2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
-        } else
-            hipLaunchKernelGGL(k_comp<2>, dim3(reducer_grid(c, t2->d.cap + 1, 4)), dim3(256), lds2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
+        } else if (wide)
+            hipLaunchKernelGGL((k_comp<2, true>), dim3(reducer_grid(c, t2->d.cap + 1, 4)), dim3(256), lds2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
+        else
+            hipLaunchKernelGGL((k_comp<2, false>), dim3(reducer_grid(c, t2->d.cap + 1, 4)), dim3(256), lds2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
     }
     HIPCHK(c, hipGetLastError());
     hipMemcpyAsync(main_mx, d, mx_cells * 8, hipMemcpyDeviceToHost, c->stream);
@@ -1474,8 +1602,12 @@ extern "C" int katgpu_comp3(katgpu_table* t1, katgpu_table* t2, katgpu_table* t3
     a.mx[0] = d; a.mx[1] = d + cells; a.mx[2] = d + 2 * cells;
     {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap);
-        hipLaunchKernelGGL(k_comp3_pass1, dim3(reducer_grid(c, t1->d.cap + 1, 3)), dim3(256), 3 * COMP_TILE * COMP_TILE * sizeof(uint32_t), c->stream,
-                           t1->d, t1->n_ovf, t2->d, t2->n_ovf, t3->d, t3->n_ovf, a);
+        if (t1->d.keys_b)
+            hipLaunchKernelGGL(k_comp3_pass1<true>, dim3(reducer_grid(c, t1->d.cap + 1, 3)), dim3(256), 3 * COMP_TILE * COMP_TILE * sizeof(uint32_t), c->stream,
+                               t1->d, t1->n_ovf, t2->d, t2->n_ovf, t3->d, t3->n_ovf, a);
+        else
+            hipLaunchKernelGGL(k_comp3_pass1<false>, dim3(reducer_grid(c, t1->d.cap + 1, 3)), dim3(256), 3 * COMP_TILE * COMP_TILE * sizeof(uint32_t), c->stream,
+                               t1->d, t1->n_ovf, t2->d, t2->n_ovf, t3->d, t3->n_ovf, a);
         hipLaunchKernelGGL(k_comp3_pass3, dim3(reducer_grid(c, t3->d.cap + 1, 8)), dim3(256), 0, c->stream, t3->d, t3->n_ovf, d + 3 * cells);
     }
     HIPCHK(c, hipGetLastError());

@@ -30,6 +30,7 @@ constexpr int CTR_WORDS = 80;
 
 struct DevTable {
     uint64_t* keys;
+    uint64_t* keys_b;      // wide tables only (k > 32, see "wide keys" below): the second key word per slot; nullptr otherwise
     uint32_t* counts;
     uint64_t cap;          // == n_regions * region_slots
     uint32_t n_regions;    // a k-mer hashes to one region and probes (linearly, wrapping) only inside it, so a region
@@ -120,10 +121,11 @@ __device__ inline uint64_t ovf_get(const DevTable& t, uint64_t key) {
     return 0;
 }
 
-// full 64-bit count of an occupied slot
+// full 64-bit count of an occupied slot (the side table is keyed by the k-mer; for wide tables, whose k-mer is two words, by
+// the slot -- slots never move within a table's life, and a regrow re-adds full counts)
 __device__ __forceinline__ uint64_t slot_count(const DevTable& t, uint64_t pos, uint64_t key, uint32_t n_ovf) {
     uint64_t c = t.counts[pos];
-    if (n_ovf) c += ovf_get(t, key);
+    if (n_ovf) c += ovf_get(t, t.keys_b ? pos : key);
     return c;
 }
 
@@ -187,6 +189,88 @@ __device__ __forceinline__ uint64_t table_get(const DevTable& t, uint64_t key, u
         uint64_t cur = t.keys[pos];
         if (cur == key) return slot_count(t, pos, key, n_ovf);
         if (cur == EMPTY) return 0;
+    }
+    return 0;
+}
+
+// ---- wide keys: 33 <= k <= 63 --------------------------------------------------------------------------------------
+// The reference keeps a k-mer in uint64_t[ceil(k/32)] (mer_dna.hpp:235-258) and its table stores arbitrary key widths bit-packed;
+// here a k-mer of up to 63 bases is a 2k <= 126-bit word cut into TWO 63-BIT halves, a = bits 125..63, b = bits 62..0, held in two
+// parallel arrays keys[] / keys_b[].  Neither half can equal the all-ones EMPTY marker, so a slot is claimed without a 128-bit
+// atomic and without anyone waiting for anyone: CAS a into keys[], then CAS b into keys_b[] -- whoever finds its own `a` in a
+// slot tries to install its own `b`, and either wins, finds its `b` already there, or finds another k-mer's (same a, other b)
+// and moves on.  A slot whose `a` is set always gets a `b` from one of the lanes that saw it, so tables are complete when the
+// kernel ends; "distinct" is counted where `b` is installed.  (k = 64 would need the 128th bit and is not supported.)
+struct KeyW { uint64_t a, b; };
+constexpr uint64_t M63 = 0x7FFFFFFFFFFFFFFFULL;
+__device__ __host__ __forceinline__ KeyW keyw_from_words(uint64_t hi, uint64_t lo) { return KeyW{(hi << 1) | (lo >> 63), lo & M63}; }
+__device__ __host__ __forceinline__ uint64_t keyw_hi(KeyW x) { return x.a >> 1; }
+__device__ __host__ __forceinline__ uint64_t keyw_lo(KeyW x) { return x.b | (x.a << 63); }
+
+__device__ __forceinline__ uint64_t revcomp_word(uint64_t x) {       // all 32 bases of a word
+    uint64_t r = __brevll(x);
+    r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+    return ~r;
+}
+// reverse complement of the 2k-bit word (hi, lo), 33 <= k <= 63: reverse all 64 bases, then drop the 64 - k complemented pad bases
+__device__ __forceinline__ void revcomp_words(uint64_t hi, uint64_t lo, uint32_t k, uint64_t& rhi, uint64_t& rlo) {
+    const uint64_t H = revcomp_word(lo), L = revcomp_word(hi);
+    const uint32_t s = 128 - 2 * k;                                   // 2 .. 62
+    rlo = (L >> s) | (H << (64 - s));
+    rhi = H >> s;
+}
+__device__ __forceinline__ KeyW keyw_canonical(KeyW x, uint32_t k) {
+    const uint64_t hi = keyw_hi(x), lo = keyw_lo(x);
+    uint64_t rhi, rlo;
+    revcomp_words(hi, lo, k, rhi, rlo);
+    const bool rc_less = rhi < hi || (rhi == hi && rlo < lo);
+    return rc_less ? keyw_from_words(rhi, rlo) : x;
+}
+__device__ __forceinline__ uint32_t keyw_gc(KeyW x, uint32_t k) { return kmer_gc(keyw_lo(x), 32) + kmer_gc(keyw_hi(x), k - 32); }
+__device__ __forceinline__ uint64_t keyw_hash(KeyW x) { return mix64(x.b ^ (x.a * 0x9E3779B97F4A7C15ULL)); }
+__device__ __forceinline__ Probe probe_start_w(KeyW key, const DevTable& t) {
+    const uint64_t h = keyw_hash(key);
+    Probe p;
+    p.base = (uint64_t)region_of_hash(h, t.p1, t.p2) * t.region_slots;
+    p.s = offset_of_hash(h, t.region_slots);
+    p.S = t.region_slots;
+    return p;
+}
+
+__device__ __forceinline__ bool table_add_w(const DevTable& t, KeyW key, uint64_t amount, uint32_t& new_distinct) {
+    Probe pr = probe_start_w(key, t);
+    for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
+        const uint64_t pos = pr.pos();
+        uint64_t a = t.keys[pos];                                   // write-once words: a stale EMPTY only costs the CAS
+        if (a == EMPTY) {
+            a = atomicCAS((unsigned long long*)&t.keys[pos], (unsigned long long)EMPTY, (unsigned long long)key.a);
+            if (a == EMPTY) a = key.a;
+        }
+        if (a != key.a) continue;
+        uint64_t b = t.keys_b[pos];
+        if (b == EMPTY) {
+            b = atomicCAS((unsigned long long*)&t.keys_b[pos], (unsigned long long)EMPTY, (unsigned long long)key.b);
+            if (b == EMPTY) { ++new_distinct; b = key.b; }
+        }
+        if (b != key.b) continue;
+        const uint32_t low = (uint32_t)amount;
+        uint64_t hi = amount >> 32;
+        const uint32_t old = atomicAdd(&t.counts[pos], low);
+        if ((uint64_t)old + low > 0xFFFFFFFFULL) ++hi;
+        if (hi) ovf_add(t, pos, hi << 32);
+        return true;
+    }
+    atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 1ULL);
+    return false;
+}
+
+__device__ __forceinline__ uint64_t table_get_w(const DevTable& t, KeyW key, uint32_t n_ovf) {
+    Probe pr = probe_start_w(key, t);
+    for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
+        const uint64_t pos = pr.pos();
+        const uint64_t a = t.keys[pos];
+        if (a == EMPTY) return 0;
+        if (a == key.a && t.keys_b[pos] == key.b) return slot_count(t, pos, pos, n_ovf);
     }
     return 0;
 }

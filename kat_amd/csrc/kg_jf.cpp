@@ -185,7 +185,7 @@ extern "C" int katgpu_jf_read_records(const char* path, uint32_t* k, int* canoni
         g_jf_err = std::string("Failed to parse header of file: ") + path;
         return KATGPU_ERR_FORMAT;
     }
-    if (key_len > 64) { fclose(f); g_jf_err = "k = " + std::to_string(key_len / 2) + " unsupported: this build packs a k-mer into one 64-bit word (1 <= k <= 32)"; return KATGPU_ERR_K; }
+    if (key_len > 64) { fclose(f); g_jf_err = "k = " + std::to_string(key_len / 2) + " unsupported: .jf files are read and written for k <= 32 only in this build"; return KATGPU_ERR_K; }
     const size_t key_bytes = (key_len + 7) / 8, rec = key_bytes + counter_len, offset = 9 + hlen;
     fseek(f, 0, SEEK_END);
     const size_t data_bytes = (size_t)ftell(f) - offset;

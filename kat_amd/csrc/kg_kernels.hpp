@@ -214,6 +214,7 @@ __device__ __forceinline__ uint64_t scale_count(uint64_t c, double scale) {
 
 // K4.  Gcp::analyseSlice (src/gcp.cc:179-197): row = popcount-based GC count, column = min(ceil(count*scale), bins).
 // The whole k x (bins+1) matrix is privatised in LDS as u32 when it fits (27 x 1001 x 4 B = 108 KB of the 160 KB).
+template <bool W>                                         // W: wide table (k > 32, kg_device.hpp "wide keys")
 __global__ void __launch_bounds__(256)
 k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long long* __restrict__ out, uint32_t use_lds) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
@@ -228,7 +229,8 @@ k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long lon
         bool occ = key != EMPTY;
         uint32_t cell = 0;
         if (occ) {
-            uint32_t g = kmer_gc(key, k);
+            uint32_t g;
+            if constexpr (W) g = keyw_gc(KeyW{key, t.keys_b[i]}, k); else g = kmer_gc(key, k);
             uint64_t pos = scale_count(slot_count(t, i, key, n_ovf), scale);
             if (pos > bins) pos = bins;
             occ = g < k;                                   // the reference's matrix has k rows: GC == k never printed
@@ -352,7 +354,7 @@ __device__ __forceinline__ void comp_lds_init(const CompArgs& a, int pass, unsig
 
 // K5 (probe form): scan one table, probe the other in HBM.  Used when the two tables' region grids differ or when the
 // probe key is not the stored key (mixed canonical flags).
-template <int PASS>
+template <int PASS, bool W>
 __global__ void __launch_bounds__(256)
 k_comp(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -381,8 +383,14 @@ k_comp(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
         if (occ) {
             // pass 1: hash-1 key probed in hash 2, canonicalised iff input 2 is canonical (src/comp.cc:401)
             // pass 2: hash-2 key probed in hash 1, ALWAYS canonicalised (src/comp.cc:447 passes a pointer as the bool)
-            uint64_t probe = (PASS == 2 || a.canon_probe) ? kmer_canonical(key, k) : key;
-            cb = table_get(tb, probe, nb_ovf);
+            if constexpr (W) {
+                KeyW kw{key, ta.keys_b[i]};
+                if (PASS == 2 || a.canon_probe) kw = keyw_canonical(kw, k);
+                cb = table_get_w(tb, kw, nb_ovf);
+            } else {
+                uint64_t probe = (PASS == 2 || a.canon_probe) ? kmer_canonical(key, k) : key;
+                cb = table_get(tb, probe, nb_ovf);
+            }
         }
         comp_account<PASS>(occ, ca, cb, a, s_tile, s_spec, acc);
     }
@@ -465,6 +473,7 @@ struct Comp3Args {
     unsigned long long* mx[3];       // 0 ends, 1 middle, 2 mixed: each d1_bins x d2_bins
 };
 
+template <bool W>
 __global__ void __launch_bounds__(256)
 k_comp3_pass1(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, DevTable t3, uint32_t n3_ovf, Comp3Args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_tiles[];      // 3 x 64 x 64
@@ -483,9 +492,16 @@ k_comp3_pass1(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, DevTab
         uint32_t which = 0, cell = 0;
         bool in_tile = false;
         if (occ) {
-            const uint64_t can = kmer_canonical(key, k);
-            const uint64_t c2 = table_get(t2, a.canon2 ? can : key, n2_ovf);
-            const uint64_t c3 = table_get(t3, a.canon3 ? can : key, n3_ovf);
+            uint64_t c2, c3;
+            if constexpr (W) {
+                const KeyW kw{key, t1.keys_b[i]}, can = keyw_canonical(kw, k);
+                c2 = table_get_w(t2, a.canon2 ? can : kw, n2_ovf);
+                c3 = table_get_w(t3, a.canon3 ? can : kw, n3_ovf);
+            } else {
+                const uint64_t can = kmer_canonical(key, k);
+                c2 = table_get(t2, a.canon2 ? can : key, n2_ovf);
+                c3 = table_get(t3, a.canon3 ? can : key, n3_ovf);
+            }
             uint64_t s1 = scale_count(c1, a.d1_scale), s2 = scale_count(c2, a.d2_scale), s3 = scale_count(c3, a.d2_scale);
             if (s1 >= a.d1_bins) s1 = a.d1_bins - 1;
             if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;

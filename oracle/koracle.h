@@ -19,6 +19,8 @@
  *     and .jf files written by the product as the reference's reader sees them, CompCounters::printCounts with its five
  *     distance metrics byte for byte, the counter arithmetic of Comp::compareSlice, SparseMatrix's bounds behaviour, and
  *     validKmer / gcCount.  tests/golden/reference_vectors.json keeps the digests for the fixed inputs.
+ *     koracle_wide.c (k up to 64) is checked the same way against jf_ref's multi-word mer_dna for k = 33..64, and against
+ *     koracle.c for k <= 32 (tests/test_oracle_wide.py).
  *   - Also pinned against the known answers the reference's own tests hold for this path:
  *       tests/check_jellyfish.cc:38-116  (.jf header fields, 1889 records, k-mer lookups 3/1/1/1 and
  *                                         canonical lookups 3/1/0/0 on tests/data/ecoli.header.jf27)
