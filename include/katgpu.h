@@ -32,8 +32,8 @@ typedef struct katgpu_table katgpu_table;
 /* k-mer lengths.  1..32: one 64-bit word per k-mer (all entry points).  33..KATGPU_MAX_K: "wide" tables, the k-mer's 2k bits
  * in two words -- counted and reduced (count*, stats, hist, gcp, comp, comp3) exactly like the narrow ones; records move
  * through the *_wide entry points as (hi, lo) = the upper and lower 64 bits of the 2k-bit word (first base most significant,
- * A=0 C=1 G=2 T=3, as mer_dna: JF/include/jellyfish/mer_dna.hpp:235-258).  Entry points that take 64-bit keys, .jf files,
- * the multi-GPU exchange and the sect/cold profile return KATGPU_ERR_K for a wide table. */
+ * A=0 C=1 G=2 T=3, as mer_dna: JF/include/jellyfish/mer_dna.hpp:235-258); .jf files are loaded and dumped for both.  Entry
+ * points that take 64-bit keys, the multi-GPU exchange and the sect/cold profile return KATGPU_ERR_K for a wide table. */
 #define KATGPU_MAX_K 63
 
 typedef enum katgpu_status {
@@ -139,6 +139,10 @@ int katgpu_jf_dump(katgpu_table* t, const char* path);
 /* host only, no device needed */
 int katgpu_jf_write_records(const char* path, uint32_t k, int canonical, const uint64_t* keys, const uint64_t* counts, size_t n);
 int katgpu_jf_read_records(const char* path, uint32_t* k, int* canonical, uint64_t** keys, uint64_t** counts, size_t* n);  /* free with katgpu_free_host */
+/* the two host-only calls for any k <= KATGPU_MAX_K: a k-mer is (hi, lo), hi = 0 for k <= 32 */
+int katgpu_jf_write_records_wide(const char* path, uint32_t k, int canonical, const uint64_t* keys_hi, const uint64_t* keys_lo,
+                                 const uint64_t* counts, size_t n);
+int katgpu_jf_read_records_wide(const char* path, uint32_t* k, int* canonical, uint64_t** keys_hi, uint64_t** keys_lo, uint64_t** counts, size_t* n);
 const char* katgpu_jf_last_error(void);
 
 /* ---- reducers ---------------------------------------------------------------------------------------- */

@@ -6,4 +6,4 @@ binding.py ctypes binding of the C ABI
 synth.py   seeded synthetic genome / read generator (host edition of the device generator)
 dist.py    one-process-per-GPU sharding + owner-partitioned merge over torch.distributed (RCCL)
 """
-from .binding import Engine, Table, DeviceBuffer, KatGpuError, comp, comp3, hist_geometry, load_library, parse_file, parse_files, jf_read_records, jf_write_records, LIB_PATH, EXPORTS  # noqa: F401
+from .binding import Engine, Table, DeviceBuffer, KatGpuError, comp, comp3, hist_geometry, load_library, parse_file, parse_files, jf_read_records, jf_write_records, jf_read_records_wide, jf_write_records_wide, LIB_PATH, EXPORTS  # noqa: F401

@@ -32,6 +32,7 @@ EXPORTS = (
     "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_parse_files", "katgpu_free_host",
     "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
+    "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide",
 )
 
 
@@ -131,6 +132,8 @@ def load_library():
     L.katgpu_jf_dump.argtypes = [vp, C.c_char_p]
     L.katgpu_jf_write_records.argtypes = [C.c_char_p, u32, C.c_int, vp, vp, sz]
     L.katgpu_jf_read_records.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(C.c_int), pp, pp, C.POINTER(sz)]
+    L.katgpu_jf_write_records_wide.argtypes = [C.c_char_p, u32, C.c_int, vp, vp, vp, sz]
+    L.katgpu_jf_read_records_wide.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(C.c_int), pp, pp, pp, C.POINTER(sz)]
     L.katgpu_jf_last_error.restype = C.c_char_p
     _lib = L
     return L
@@ -195,6 +198,29 @@ def jf_write_records(path, k, canonical, keys, counts):
     kk = np.ascontiguousarray(keys, np.uint64)
     cc = np.ascontiguousarray(counts, np.uint64)
     rc = L.katgpu_jf_write_records(os.fsencode(path), k, int(bool(canonical)), kk.ctypes.data, cc.ctypes.data, kk.size)
+    if rc:
+        raise KatGpuError(rc, L.katgpu_jf_last_error().decode(errors="replace"))
+
+
+def jf_read_records_wide(path):
+    """Host-only .jf reader for any k <= 63: (k, canonical, keys_hi, keys_lo, counts)."""
+    L = load_library()
+    k, can, n = C.c_uint32(), C.c_int(), C.c_size_t()
+    ph, pk, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    rc = L.katgpu_jf_read_records_wide(os.fsencode(path), C.byref(k), C.byref(can), C.byref(ph), C.byref(pk), C.byref(pc), C.byref(n))
+    if rc:
+        raise KatGpuError(rc, L.katgpu_jf_last_error().decode(errors="replace"))
+    out = [np.frombuffer(C.string_at(p, n.value * 8), dtype=np.uint64).copy() if n.value else np.zeros(0, np.uint64) for p in (ph, pk, pc)]
+    for p in (ph, pk, pc):
+        L.katgpu_free_host(p)
+    return k.value, bool(can.value), out[0], out[1], out[2]
+
+
+def jf_write_records_wide(path, k, canonical, keys_hi, keys_lo, counts):
+    """Host-only .jf writer for any k <= 63 (binary/sorted, 4-byte saturated counters)."""
+    L = load_library()
+    hh, kk, cc = (np.ascontiguousarray(x, np.uint64) for x in (keys_hi, keys_lo, counts))
+    rc = L.katgpu_jf_write_records_wide(os.fsencode(path), k, int(bool(canonical)), hh.ctypes.data, kk.ctypes.data, cc.ctypes.data, kk.size)
     if rc:
         raise KatGpuError(rc, L.katgpu_jf_last_error().decode(errors="replace"))
 

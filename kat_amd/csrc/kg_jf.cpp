@@ -90,21 +90,23 @@ std::vector<uint64_t> random_matrix(unsigned r, unsigned c, uint64_t seed) {
     }
 }
 
-inline uint64_t matrix_times(const std::vector<uint64_t>& cols, uint64_t key) {
+typedef unsigned __int128 u128;                               // a k-mer of up to 64 bases (k > 32: "wide", include/katgpu.h)
+
+inline uint64_t matrix_times(const std::vector<uint64_t>& cols, u128 key) {
     const unsigned c = (unsigned)cols.size();
     uint64_t res = 0;
     for (unsigned i = 0; i < c && key; ++i, key >>= 1) if (key & 1) res ^= cols[c - 1 - i];
     return res;
 }
 
-struct Rec { uint64_t pos, key, count; };
+struct Rec { uint64_t pos; u128 key; uint64_t count; };
 
 }  // namespace
 
 extern "C" const char* katgpu_jf_last_error(void) { return g_jf_err.c_str(); }
 
-extern "C" int katgpu_jf_write_records(const char* path, uint32_t k, int canonical, const uint64_t* keys, const uint64_t* counts, size_t n) {
-    if (!path || k < 1 || k > 32 || (n && (!keys || !counts))) return KATGPU_ERR_INVALID_ARG;
+// keys_hi == nullptr: one-word k-mers
+static int write_records(const char* path, uint32_t k, int canonical, const uint64_t* keys_hi, const uint64_t* keys, const uint64_t* counts, size_t n) {
     const unsigned key_len = 2 * k, key_bytes = (key_len + 7) / 8, counter_len = 4;
     // size: the power of two Jellyfish would have needed for n entries (HashLoader sizes 2n rounded up, jellyfish_helper.cc:144-145)
     unsigned r = 1;
@@ -113,7 +115,10 @@ extern "C" int katgpu_jf_write_records(const char* path, uint32_t k, int canonic
     const uint64_t size = (uint64_t)1 << r;
     const std::vector<uint64_t> cols = random_matrix(r, key_len, 0x6B61746770750000ULL ^ ((uint64_t)k << 8) ^ (uint64_t)n);
     std::vector<Rec> recs(n);
-    for (size_t i = 0; i < n; ++i) recs[i] = {matrix_times(cols, keys[i]) & (size - 1), keys[i], counts[i]};
+    for (size_t i = 0; i < n; ++i) {
+        const u128 key = ((u128)(keys_hi ? keys_hi[i] : 0) << 64) | keys[i];
+        recs[i] = {matrix_times(cols, key) & (size - 1), key, counts[i]};
+    }
     std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.pos != b.pos ? a.pos < b.pos : a.key < b.key; });
 
     // ---- header (alphabetical keys, terse, like jsoncpp's FastWriter) ----
@@ -153,9 +158,21 @@ extern "C" int katgpu_jf_write_records(const char* path, uint32_t k, int canonic
     return KATGPU_OK;
 }
 
-extern "C" int katgpu_jf_read_records(const char* path, uint32_t* k, int* canonical, uint64_t** keys, uint64_t** counts, size_t* n) {
-    if (!path || !k || !keys || !counts || !n) return KATGPU_ERR_INVALID_ARG;
+extern "C" int katgpu_jf_write_records(const char* path, uint32_t k, int canonical, const uint64_t* keys, const uint64_t* counts, size_t n) {
+    if (!path || k < 1 || k > 32 || (n && (!keys || !counts))) return KATGPU_ERR_INVALID_ARG;
+    return write_records(path, k, canonical, nullptr, keys, counts, n);
+}
+
+extern "C" int katgpu_jf_write_records_wide(const char* path, uint32_t k, int canonical, const uint64_t* keys_hi, const uint64_t* keys_lo,
+                                            const uint64_t* counts, size_t n) {
+    if (!path || k < 1 || k > KATGPU_MAX_K || (n && (!keys_hi || !keys_lo || !counts))) return KATGPU_ERR_INVALID_ARG;
+    return write_records(path, k, canonical, keys_hi, keys_lo, counts, n);
+}
+
+// max_key_len: 64 for the one-word form (keys_hi == nullptr), 2 * KATGPU_MAX_K for the wide one
+static int read_records(const char* path, unsigned max_key_len, uint32_t* k, int* canonical, uint64_t** keys_hi, uint64_t** keys, uint64_t** counts, size_t* n) {
     *keys = *counts = nullptr; *n = 0;
+    if (keys_hi) *keys_hi = nullptr;
     FILE* f = fopen(path, "rb");
     if (!f) { g_jf_err = std::string("Could not find input file at: ") + path + "; please check the path and try again."; return KATGPU_ERR_IO; }
     char digits[10] = {0};
@@ -185,7 +202,11 @@ extern "C" int katgpu_jf_read_records(const char* path, uint32_t* k, int* canoni
         g_jf_err = std::string("Failed to parse header of file: ") + path;
         return KATGPU_ERR_FORMAT;
     }
-    if (key_len > 64) { fclose(f); g_jf_err = "k = " + std::to_string(key_len / 2) + " unsupported: .jf files are read and written for k <= 32 only in this build"; return KATGPU_ERR_K; }
+    if (key_len > max_key_len) {
+        fclose(f);
+        g_jf_err = "k = " + std::to_string(key_len / 2) + " unsupported: " + (max_key_len == 64 ? "this entry point reads one-word k-mers (k <= 32)" : "this build keeps a k-mer in at most two 63-bit words (k <= " + std::to_string(KATGPU_MAX_K) + ")");
+        return KATGPU_ERR_K;
+    }
     const size_t key_bytes = (key_len + 7) / 8, rec = key_bytes + counter_len, offset = 9 + hlen;
     fseek(f, 0, SEEK_END);
     const size_t data_bytes = (size_t)ftell(f) - offset;
@@ -197,19 +218,21 @@ extern "C" int katgpu_jf_read_records(const char* path, uint32_t* k, int* canoni
     const size_t nrec = data_bytes / rec;
     uint64_t* kk = (uint64_t*)malloc(std::max<size_t>(nrec, 1) * 8);
     uint64_t* cc = (uint64_t*)malloc(std::max<size_t>(nrec, 1) * 8);
-    if (!kk || !cc) { fclose(f); free(kk); free(cc); return KATGPU_ERR_NOMEM; }
+    uint64_t* kh = keys_hi ? (uint64_t*)malloc(std::max<size_t>(nrec, 1) * 8) : nullptr;
+    if (!kk || !cc || (keys_hi && !kh)) { fclose(f); free(kk); free(cc); free(kh); return KATGPU_ERR_NOMEM; }
     fseek(f, (long)offset, SEEK_SET);
     std::vector<uint8_t> buf(rec * (1 << 16));
     size_t i = 0;
     while (i < nrec) {
         const size_t take = std::min<size_t>(nrec - i, 1 << 16);
-        if (fread(buf.data(), rec, take, f) != take) { fclose(f); free(kk); free(cc); g_jf_err = std::string("read error on ") + path; return KATGPU_ERR_IO; }
+        if (fread(buf.data(), rec, take, f) != take) { fclose(f); free(kk); free(cc); free(kh); g_jf_err = std::string("read error on ") + path; return KATGPU_ERR_IO; }
         for (size_t j = 0; j < take; ++j) {
             const uint8_t* p = buf.data() + j * rec;
-            uint64_t key = 0, cnt = 0;
-            for (size_t b = 0; b < key_bytes; ++b) key |= (uint64_t)p[b] << (8 * b);
+            u128 key = 0; uint64_t cnt = 0;
+            for (size_t b = 0; b < key_bytes; ++b) key |= (u128)p[b] << (8 * b);
             for (size_t b = 0; b < counter_len; ++b) cnt |= (uint64_t)p[key_bytes + b] << (8 * b);
-            kk[i + j] = key; cc[i + j] = cnt;
+            kk[i + j] = (uint64_t)key; cc[i + j] = cnt;
+            if (kh) kh[i + j] = (uint64_t)(key >> 64);
         }
         i += take;
     }
@@ -217,7 +240,18 @@ extern "C" int katgpu_jf_read_records(const char* path, uint32_t* k, int* canoni
     *k = (uint32_t)(key_len / 2);
     if (canonical) *canonical = json_bool(js, "canonical", false) ? 1 : 0;
     *keys = kk; *counts = cc; *n = nrec;
+    if (keys_hi) *keys_hi = kh;
     return KATGPU_OK;
+}
+
+extern "C" int katgpu_jf_read_records(const char* path, uint32_t* k, int* canonical, uint64_t** keys, uint64_t** counts, size_t* n) {
+    if (!path || !k || !keys || !counts || !n) return KATGPU_ERR_INVALID_ARG;
+    return read_records(path, 64, k, canonical, nullptr, keys, counts, n);
+}
+
+extern "C" int katgpu_jf_read_records_wide(const char* path, uint32_t* k, int* canonical, uint64_t** keys_hi, uint64_t** keys_lo, uint64_t** counts, size_t* n) {
+    if (!path || !k || !keys_hi || !keys_lo || !counts || !n) return KATGPU_ERR_INVALID_ARG;
+    return read_records(path, 2 * KATGPU_MAX_K, k, canonical, keys_hi, keys_lo, counts, n);
 }
 
 // ---- device-level wrappers: InputHandler::loadHash / dump ----
@@ -225,13 +259,14 @@ extern "C" int katgpu_jf_read_records(const char* path, uint32_t* k, int* canoni
 extern "C" int katgpu_jf_load(katgpu_ctx* ctx, const char* path, katgpu_table** out) {
     if (!ctx || !out) return KATGPU_ERR_INVALID_ARG;
     *out = nullptr;
-    uint32_t k = 0; int canonical = 0; uint64_t *keys = nullptr, *counts = nullptr; size_t n = 0;
-    int rc = katgpu_jf_read_records(path, &k, &canonical, &keys, &counts, &n);
+    uint32_t k = 0; int canonical = 0; uint64_t *keys_hi = nullptr, *keys = nullptr, *counts = nullptr; size_t n = 0;
+    int rc = katgpu_jf_read_records_wide(path, &k, &canonical, &keys_hi, &keys, &counts, &n);
     if (rc) return rc;
     katgpu_table* t = nullptr;
     rc = katgpu_table_create(ctx, k, canonical, std::max<uint64_t>((uint64_t)(n / 0.6) + 1024, 1 << 16), 0, &t);
-    if (!rc) rc = katgpu_table_merge_host(t, keys, counts, n);       // hash->add(reader.key(), reader.val()) per record (:172-174)
-    free(keys); free(counts);
+    if (!rc) rc = k > 32 ? katgpu_table_merge_host_wide(t, keys_hi, keys, counts, n)
+                         : katgpu_table_merge_host(t, keys, counts, n);       // hash->add(reader.key(), reader.val()) per record (:172-174)
+    free(keys_hi); free(keys); free(counts);
     if (rc) { if (t) katgpu_table_free(t); g_jf_err = katgpu_last_error(ctx); return rc; }
     *out = t;
     return KATGPU_OK;
@@ -240,6 +275,13 @@ extern "C" int katgpu_jf_load(katgpu_ctx* ctx, const char* path, katgpu_table** 
 extern "C" int katgpu_jf_dump(katgpu_table* t, const char* path) {
     if (!t || !path) return KATGPU_ERR_INVALID_ARG;
     size_t n = 0;
+    if (katgpu_table_k(t) > 32) {
+        int rc = katgpu_table_export_wide(t, nullptr, nullptr, nullptr, 0, &n);
+        if (rc) return rc;
+        std::vector<uint64_t> hi(std::max<size_t>(n, 1)), lo(std::max<size_t>(n, 1)), counts(std::max<size_t>(n, 1));
+        if (n) { rc = katgpu_table_export_wide(t, hi.data(), lo.data(), counts.data(), n, &n); if (rc) return rc; }
+        return katgpu_jf_write_records_wide(path, katgpu_table_k(t), katgpu_table_canonical(t), hi.data(), lo.data(), counts.data(), n);
+    }
     int rc = katgpu_table_export(t, nullptr, nullptr, 0, &n);
     if (rc) return rc;
     std::vector<uint64_t> keys(std::max<size_t>(n, 1)), counts(std::max<size_t>(n, 1));

@@ -134,7 +134,7 @@ def test_comp_and_comp3_wide(engine, ko, k, c1, c2):
 def test_narrow_only_entry_points_say_so(engine, tmp_path):
     t = engine.table(40, True).count_bases(b"ACGT" * 30)
     for call in (lambda: t.get(np.array([1], np.uint64)), lambda: t.export(), lambda: t.profile(b"ACGT" * 20),
-                 lambda: t.dump_jf(str(tmp_path / "x.jf")), lambda: t.geometry(), lambda: t.merge_host([1], [1])):
+                 lambda: t.geometry(), lambda: t.merge_host([1], [1])):
         with pytest.raises(kat_amd.KatGpuError) as ei:
             call()
         assert ei.value.code == 6, ei.value
@@ -171,3 +171,75 @@ def test_cli_hist_gcp_comp_wide(ko, refdata, tmp_path):
     assert (tmp_path / "c.stats").read_bytes() == (tmp_path / "want.stats").read_bytes()
     r = run(["sect", "-m", "41", "-o", "s", os.path.join(refdata, "sect_test.fa"), r1])
     assert r.returncode != 0 and "k > 32" in (r.stderr + r.stdout)
+
+
+def test_jf_dump_and_load_wide(engine, ko, refdata, tmp_path):
+    """-d dumps and .jf inputs at k > 32: dump -> (the reference's reader, when oracle/_ref is there) -> load gives the table back;
+    the CLI counts from the .jf what it counts from the reads."""
+    import subprocess
+    from tests.test_oracle_vs_reference import JF_REF, ref, parse_jfread
+    r1 = os.path.join(refdata, "ecoli_r1.1K.fastq")
+    for k, canonical in ((45, True), (63, False)):
+        gt = engine.count([r1], k, canonical)
+        p = str(tmp_path / ("d%d.jf" % k))
+        gt.dump_jf(p)
+        back = engine.load_jf(p)
+        assert (back.k, back.canonical) == (k, canonical)
+        ot = ko.WideTable(k, canonical).count_files([r1])
+        assert_same_wide(back, ot)
+        if os.access(JF_REF, os.X_OK):
+            rc, out = ref(JF_REF, ["jfread", p])
+            assert rc == 0
+            hdr, recs = parse_jfread(out)
+            assert hdr["key_len"] == str(2 * k) and len(recs) == ot.distinct
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kat_amd", "bin", "katgpu")
+    run = lambda args: subprocess.run([exe] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    r = run(["hist", "-m", "41", "-d", "-o", "a", r1])
+    assert r.returncode == 0, r.stderr
+    r = run(["hist", "-o", "b", "a-hash.jf41"])
+    assert r.returncode == 0, r.stderr
+    body = lambda f: [ln for ln in (tmp_path / f).read_text().splitlines() if not ln.startswith("#")]
+    assert body("a") == body("b") and len(body("a")) == 10001
+
+
+def test_wide_checksums_at_scale(engine):
+    """4 M reads at k = 51 (400 M k-mer instances) counted on the device: sum of counts == number of windows, the reducers'
+    marginals agree, and the table does not depend on batching or order."""
+    import time
+    G, n_reads, k, L = 20_000_000, 4_000_000, 51, 150
+    g = engine.synth_genome(G, seed=20260927)
+    reads = engine.synth_reads(g, G, 0, n_reads, seed=1)
+    asm = engine.synth_genome(G, seed=20260927, contig_len=1_000_000)
+    engine.sync()
+    t0 = time.perf_counter()
+    t1 = engine.table(k, True, size_hint=200_000_000).count_bases(reads)
+    engine.sync()
+    dt = time.perf_counter() - t0
+    t2 = engine.table(k, True, size_hint=40_000_000).count_bases(asm)
+    s1, s2 = t1.stats(), t2.stats()
+    print("wide count k=51: %.2f G k-mers/s" % (s1["total"] / dt / 1e9))
+    assert s1["total"] == n_reads * (L - k + 1)
+    assert s2["total"] == G - (G // 1_000_000) * (k - 1)
+    assert 0.999 * s2["total"] < s2["distinct"] <= s2["total"]
+    h = t1.hist()
+    assert int(h.sum()) == s1["distinct"]
+    gm = t1.gcp()
+    assert int(gm.sum()) == s1["distinct"]                                # an all-G/C 51-mer is not going to happen
+    mx, cc, sp = kat_amd.comp(t1, t2)
+    assert int(cc[0]) == s1["total"] and int(cc[1]) == s2["total"] and int(cc[3]) == s1["distinct"] and int(cc[4]) == s2["distinct"]
+    assert int(cc[8]) + int(cc[12]) == int(cc[3]) and int(cc[9]) + int(cc[12]) == int(cc[4])
+    assert int(mx.sum()) == int(cc[3]) + int(cc[9])
+    assert np.array_equal(mx.sum(axis=1)[1:], sp[0][1:])
+    # error k-mers: ~ (1 - 0.998^51) = 9.7 % of the instances are singletons absent from the assembly
+    assert 0.07 < int(mx[1, 0]) / s1["total"] < 0.12
+    # 100 K of the reads, in four unequal calls, in reverse order, into a table that starts tiny: same as one call
+    rec = L + 1
+    n_q = 100_000
+    whole = engine.table(k, True, size_hint=20_000_000)
+    whole.count_bases_device(reads.ptr, n_q * rec)
+    parts = engine.table(k, True, size_hint=1 << 12)
+    cuts = [0, 10_000, 35_001, 77_777, n_q]
+    for a, b in reversed(list(zip(cuts[:-1], cuts[1:]))):
+        parts.count_bases_device(reads.ptr + a * rec, (b - a) * rec)
+    for x, y in zip(whole.dump_sorted(), parts.dump_sorted()):
+        assert np.array_equal(x, y)

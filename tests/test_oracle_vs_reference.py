@@ -169,6 +169,28 @@ def test_jf_files_as_the_reference_reads_them(ko, refdata, tmp_path):
         assert {ko.encode(a): b for a, b, _ in recs} == want
         pos = [c for _, _, c in recs]
         assert pos == sorted(pos)                                       # binary/sorted: by hash position, as the reference's readers expect
+    # k > 32 (two-word k-mers): the same writer through its (hi, lo) entry point, read by the reference's multi-word mer_dna
+    M = (1 << 64) - 1
+    pack = lambda s_: sum("ACGT".index(ch) << (2 * (len(s_) - 1 - i)) for i, ch in enumerate(s_))
+    for k, canonical, n in ((33, True, 3000), (48, False, 1), (63, True, 40000), (40, False, 500)):
+        kk = sorted({int.from_bytes(rng.bytes(16), "big") & ((1 << (2 * k)) - 1) for _ in range(n)})
+        cc = rng.integers(1, 1 << 20, len(kk)).astype(np.uint64)
+        cc[0] = (1 << 40)
+        p = str(tmp_path / ("w%d.jf" % k))
+        kat_amd.jf_write_records_wide(p, k, canonical, [x >> 64 for x in kk], [x & M for x in kk], cc)
+        rc, out = ref(JF_REF, ["jfread", p])
+        assert rc == 0, (k, rc)
+        hdr, recs = parse_jfread(out)
+        assert (hdr["key_len"], hdr["counter_len"], hdr["canonical"], hdr["format"]) == (str(2 * k), "4", str(int(canonical)), "binary/sorted")
+        assert {pack(a): b for a, b, _ in recs} == {x: min(int(b), 0xFFFFFFFF) for x, b in zip(kk, cc)}
+        pos = [c for _, _, c in recs]
+        assert pos == sorted(pos)
+        k2, can2, hi, lo, cnt = kat_amd.jf_read_records_wide(p)
+        assert (k2, can2) == (k, canonical)
+        assert sorted(((int(a) << 64) | int(b), int(c)) for a, b, c in zip(hi, lo, cnt)) == [(x, min(int(b), 0xFFFFFFFF)) for x, b in zip(kk, cc)]
+        with pytest.raises(kat_amd.KatGpuError) as ei:
+            kat_amd.jf_read_records(p)                                   # the one-word reader says what it is
+        assert ei.value.code == 6
 
 
 @have_ref
