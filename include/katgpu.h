@@ -32,8 +32,8 @@ typedef struct katgpu_table katgpu_table;
 /* k-mer lengths.  1..32: one 64-bit word per k-mer (all entry points).  33..KATGPU_MAX_K: "wide" tables, the k-mer's 2k bits
  * in two words -- counted and reduced (count*, stats, hist, gcp, comp, comp3) exactly like the narrow ones; records move
  * through the *_wide entry points as (hi, lo) = the upper and lower 64 bits of the 2k-bit word (first base most significant,
- * A=0 C=1 G=2 T=3, as mer_dna: JF/include/jellyfish/mer_dna.hpp:235-258); .jf files are loaded and dumped for both.  Entry
- * points that take 64-bit keys, the multi-GPU exchange and the sect/cold profile return KATGPU_ERR_K for a wide table. */
+ * A=0 C=1 G=2 T=3, as mer_dna: JF/include/jellyfish/mer_dna.hpp:235-258); .jf files and the sect/cold profile work for both.
+ * Entry points that take 64-bit keys and the multi-GPU exchange return KATGPU_ERR_K for a wide table. */
 #define KATGPU_MAX_K 63
 
 typedef enum katgpu_status {

@@ -988,11 +988,18 @@ extern "C" int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n,
 
 static int launch_profile(katgpu_table* t, const uint8_t* dev_bases, size_t n, int canonicalise, uint64_t* dev_counts) {
     katgpu_ctx* c = t->ctx;
+    const bool wide = t->d.keys_b != nullptr;
     const uint64_t n_out = n - t->d.k + 1;
-    const uint64_t n_chunks = (n_out + CHUNK_STARTS - 1) / CHUNK_STARTS;
+    const uint64_t per_chunk = wide ? WIDE_CHUNK_STARTS : CHUNK_STARTS;
+    const uint64_t n_chunks = (n_out + per_chunk - 1) / per_chunk;
     const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * 8);
+    const bool aligned = (reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0 && (reinterpret_cast<uintptr_t>(dev_counts) & 15) == 0;
     ScopedTimer tm(c, KATGPU_K_PROFILE, n_out);
-    if ((reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0 && (reinterpret_cast<uintptr_t>(dev_counts) & 15) == 0)
+    if (wide && aligned)
+        hipLaunchKernelGGL(k_profile_w<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
+    else if (wide)
+        hipLaunchKernelGGL(k_profile_w<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
+    else if (aligned)
         hipLaunchKernelGGL(k_profile<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
     else
         hipLaunchKernelGGL(k_profile<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
@@ -1002,7 +1009,6 @@ static int launch_profile(katgpu_table* t, const uint8_t* dev_bases, size_t n, i
 
 extern "C" int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_bases, size_t n, int canonicalise, uint64_t* dev_counts) {
     if (!t || (n && (!dev_bases || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
-    NARROW_ONLY(t, "katgpu_table_profile (kat sect / kat cold)");
     if (n < t->d.k) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1014,7 +1020,6 @@ extern "C" int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_b
 // k-1 bases it shares with the next one), so any length fits next to the table.
 extern "C" int katgpu_table_profile_host(katgpu_table* t, const char* bases, size_t n, int canonicalise, uint64_t* counts) {
     if (!t || (n && (!bases || !counts))) return KATGPU_ERR_INVALID_ARG;
-    NARROW_ONLY(t, "katgpu_table_profile (kat sect / kat cold)");
     const uint32_t k = t->d.k;
     if (n < k) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;

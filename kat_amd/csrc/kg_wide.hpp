@@ -1,5 +1,5 @@
 // kg_wide.hpp -- the kernels that exist only for wide tables (33 <= k <= 63; kg_device.hpp "wide keys"): counting, regrow, record
-// merge, export, lookup.  The reducers (k_hist, k_total, k_gcp<true>, k_comp<PASS, true>, k_comp3_pass1<true>, k_comp3_pass3)
+// merge, export, lookup, per-position profile.  The reducers (k_hist, k_total, k_gcp<true>, k_comp<PASS, true>, k_comp3_pass1<true>, k_comp3_pass3)
 // are the narrow ones with the second key word read where the k-mer itself matters.
 //
 // Replaces the same reference code as the narrow kernels -- mer_iterator + multi-word mer_dna (mer_iterator.hpp:59-89,
@@ -139,6 +139,79 @@ k_get_w(DevTable t, uint32_t n_ovf, const uint64_t* __restrict__ hi, const uint6
     KeyW kw = keyw_from_words(hi[i], lo[i]);
     if (canonicalise) kw = keyw_canonical(kw, t.k);
     out[i] = table_get_w(t, kw, n_ovf);
+}
+
+// K8 for wide tables: per-position coverage (kat sect / kat cold; src/sect.cc:516-535).  k_profile's shape with k_count_w's
+// 160-bit window: 16 counts per lane = one 128-byte line of `out`.
+template <bool ALIGNED>
+__global__ void __launch_bounds__(COUNT_BLOCK)
+k_profile_w(DevTable t, uint32_t n_ovf, int canonicalise, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_chunks,
+            uint64_t* __restrict__ out) {
+    __shared__ uint32_t s_code[COUNT_BLOCK + 4];
+    __shared__ uint32_t s_bad[COUNT_BLOCK + 4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = t.k;
+    const uint64_t n_out = n - k + 1;
+    if (tid < 4) { s_code[COUNT_BLOCK + tid] = 0; s_bad[COUNT_BLOCK + tid] = 0xFFFF; }
+
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint64_t off = chunk * WIDE_CHUNK_STARTS + (uint64_t)tid * BASES_PER_LANE;
+        uint32_t w[4];
+        if (ALIGNED && off + BASES_PER_LANE <= n) {
+            const uint4 v = *reinterpret_cast<const uint4*>(bases + off);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint64_t i = off + q * 4 + b;
+                    const uint32_t c = i < n ? bases[i] : (uint32_t)'N';
+                    x |= c << (8 * b);
+                }
+                w[q] = x;
+            }
+        }
+        uint32_t code, bad;
+        encode16(w, code, bad);
+        s_code[tid] = code;
+        s_bad[tid] = bad;
+        __syncthreads();
+
+        if (tid < WIDE_LANES_WITH_STARTS && off < n_out) {
+            uint64_t hi = ((uint64_t)s_code[tid] << 32) | s_code[tid + 1];
+            uint64_t lo = ((uint64_t)s_code[tid + 2] << 32) | s_code[tid + 3];
+            uint64_t nx = (uint64_t)s_code[tid + 4] << 32;
+            uint64_t m = ((uint64_t)s_bad[tid] << 48) | ((uint64_t)s_bad[tid + 1] << 32) | ((uint64_t)s_bad[tid + 2] << 16) | s_bad[tid + 3];
+            uint64_t mn = (uint64_t)s_bad[tid + 4] << 48;
+            const uint32_t s = 128 - 2 * k, mshift = 64 - k;
+            uint64_t c[BASES_PER_LANE];
+#pragma unroll
+            for (int j = 0; j < BASES_PER_LANE; ++j) {
+                c[j] = 0;
+                if ((m >> mshift) == 0) {
+                    KeyW key = keyw_from_words(hi >> s, (lo >> s) | (hi << (64 - s)));
+                    if (canonicalise) key = keyw_canonical(key, k);
+                    c[j] = table_get_w(t, key, n_ovf);
+                }
+                hi = (hi << 2) | (lo >> 62);
+                lo = (lo << 2) | (nx >> 62);
+                nx <<= 2;
+                m = (m << 1) | (mn >> 63);
+                mn <<= 1;
+            }
+            if (off + BASES_PER_LANE <= n_out) {
+                ulonglong2* o = reinterpret_cast<ulonglong2*>(out + off);           // off is a multiple of 16: 128-byte aligned
+#pragma unroll
+                for (int j = 0; j < BASES_PER_LANE / 2; ++j) o[j] = make_ulonglong2(c[2 * j], c[2 * j + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < BASES_PER_LANE; ++j) if (off + j < n_out) out[off + j] = c[j];
+            }
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace kg

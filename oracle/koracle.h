@@ -111,6 +111,7 @@ uint64_t  ko_wtable_distinct(const ko_wtable*);
 uint64_t  ko_wtable_total(const ko_wtable*);
 void      ko_wtable_add(ko_wtable*, uint64_t hi, uint64_t lo, uint64_t amount);
 uint64_t  ko_wtable_get(const ko_wtable*, uint64_t hi, uint64_t lo);
+uint64_t  ko_wtable_get_mer(const ko_wtable*, const char* mer /* k valid bases */, int canonical);
 void      ko_wtable_dump_sorted(const ko_wtable*, uint64_t* hi, uint64_t* lo, uint64_t* counts);   /* ko_wtable_distinct entries, by key */
 void      ko_wcount_bases(ko_wtable*, const uint8_t* bases, size_t n);
 int       ko_wcount_files(ko_wtable*, const char* const* paths, size_t n_paths, const uint16_t* trim5p);
@@ -151,6 +152,11 @@ void ko_profile(const ko_table* t, int canonical, const char* seq, size_t n, uin
 int ko_cold(const ko_table* reads, int canon_reads, const ko_table* assembly, int canon_asm, const char* asm_path, const char* prefix);
 int ko_sect(const ko_table* t, int canonical, const char* seq_path, const char* prefix, uint32_t gc_bins, uint32_t cvg_bins,
             unsigned flags, uint32_t min_repeat, uint32_t max_repeat);
+/* the same three on a wide table (k > 32, koracle_wide.c) */
+void ko_wprofile(const ko_wtable* t, int canonical, const char* seq, size_t n, uint64_t* counts, int16_t* gcs);
+int ko_wcold(const ko_wtable* reads, int canon_reads, const ko_wtable* assembly, int canon_asm, const char* asm_path, const char* prefix);
+int ko_wsect(const ko_wtable* t, int canonical, const char* seq_path, const char* prefix, uint32_t gc_bins, uint32_t cvg_bins,
+             unsigned flags, uint32_t min_repeat, uint32_t max_repeat);
 
 #ifdef __cplusplus
 }

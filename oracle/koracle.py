@@ -88,8 +88,11 @@ def lib():
     L.ko_write_comp_stats.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.ko_write_comp_hist.argtypes = [C.c_char_p, C.c_uint, cpp, C.c_size_t, C.c_void_p, C.c_uint32]
     L.ko_profile.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ko_wprofile.argtypes = L.ko_profile.argtypes
     L.ko_sect.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint, C.c_uint32, C.c_uint32]
     L.ko_cold.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p]
+    L.ko_wsect.argtypes = L.ko_sect.argtypes
+    L.ko_wcold.argtypes = L.ko_cold.argtypes
     _LIB = L
     return L
 
@@ -377,7 +380,7 @@ def profile(table, seq, canonical=None):
     counts = np.zeros(n, dtype=np.uint64)
     gcs = np.zeros(n, dtype=np.int16)
     if n:
-        lib().ko_profile(table.h, int(table.canonical if canonical is None else canonical), seq, len(seq),
+        (lib().ko_wprofile if isinstance(table, WideTable) else lib().ko_profile)(table.h, int(table.canonical if canonical is None else canonical), seq, len(seq),
                          counts.ctypes.data, gcs.ctypes.data)
     return counts, gcs
 
@@ -387,7 +390,7 @@ def sect(table, seq_path, prefix, canonical=None, gc_bins=1001, cvg_bins=1001, n
     """`kat sect` end to end: writes <prefix>-counts.cvg, -stats.tsv (+ optional files; save=True adds -contamination.mx)."""
     flags = (1 if no_count_stats else 0) | (2 if output_gc_stats else 0) | (4 if extract_nr else 0) | (8 if extract_r else 0) | \
         (16 if cvg_logscale else 0) | (32 if save else 0)
-    rc = lib().ko_sect(table.h, int(table.canonical if canonical is None else canonical), os.fsencode(seq_path), os.fsencode(prefix),
+    rc = (lib().ko_wsect if isinstance(table, WideTable) else lib().ko_sect)(table.h, int(table.canonical if canonical is None else canonical), os.fsencode(seq_path), os.fsencode(prefix),
                        gc_bins, cvg_bins, flags, min_repeat, max_repeat)
     if rc:
         raise OracleError(rc)
@@ -395,7 +398,7 @@ def sect(table, seq_path, prefix, canonical=None, gc_bins=1001, cvg_bins=1001, n
 
 def cold(reads, assembly, asm_path, prefix, canon_reads=None, canon_asm=None):
     """`kat cold`: writes <prefix>-stats.tsv (Cold never sets InputHandler::canonical, so counted hashes are non-canonical)."""
-    rc = lib().ko_cold(reads.h, int(reads.canonical if canon_reads is None else canon_reads),
+    rc = (lib().ko_wcold if isinstance(reads, WideTable) else lib().ko_cold)(reads.h, int(reads.canonical if canon_reads is None else canon_reads),
                        assembly.h, int(assembly.canonical if canon_asm is None else canon_asm), os.fsencode(asm_path), os.fsencode(prefix))
     if rc:
         raise OracleError(rc)

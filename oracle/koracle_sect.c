@@ -107,11 +107,14 @@ static int valid_base(char c) {                  /* lib/include/kat/str_utils.hp
     switch (c) { case 'A': case 'a': case 'C': case 'c': case 'G': case 'g': case 'T': case 't': return 1; default: return 0; }
 }
 
+/* The hash behind a profile: the one-word table (koracle.c) or, for k > 32, the wide one (koracle_wide.c). */
+typedef struct { unsigned k; const ko_table* n; const ko_wtable* w; } lookup_t;
+
 /* Per-position coverage of one sequence: src/sect.cc:516-535.  counts / gcs hold n-k+1 entries. */
-void ko_profile(const ko_table* t, int canonical, const char* seq, size_t n, uint64_t* counts, int16_t* gcs) {
-    const unsigned k = ko_table_k(t);
+static void profile_l(const lookup_t* L, int canonical, const char* seq, size_t n, uint64_t* counts, int16_t* gcs) {
+    const unsigned k = L->k;
     if (n < k) return;
-    char mer[40];
+    char mer[72];
     for (size_t i = 0; i + k <= n; i++) {
         int ok = 1, gc = 0;
         for (unsigned j = 0; j < k; j++) {
@@ -122,11 +125,23 @@ void ko_profile(const ko_table* t, int canonical, const char* seq, size_t n, uin
         }
         if (!ok) { counts[i] = 0; if (gcs) gcs[i] = -1; continue; }
         mer[k] = 0;
-        uint64_t key;
-        ko_encode(mer, k, &key);
-        counts[i] = ko_table_get(t, canonical ? ko_canonical(key, k) : key);    /* lib/src/jellyfish_helper.cc getCount */
+        if (L->w) counts[i] = ko_wtable_get_mer(L->w, mer, canonical);
+        else {
+            uint64_t key;
+            ko_encode(mer, k, &key);
+            counts[i] = ko_table_get(L->n, canonical ? ko_canonical(key, k) : key);    /* lib/src/jellyfish_helper.cc getCount */
+        }
         if (gcs) gcs[i] = (int16_t)gc;
     }
+}
+
+void ko_profile(const ko_table* t, int canonical, const char* seq, size_t n, uint64_t* counts, int16_t* gcs) {
+    const lookup_t L = {ko_table_k(t), t, NULL};
+    profile_l(&L, canonical, seq, n, counts, gcs);
+}
+void ko_wprofile(const ko_wtable* t, int canonical, const char* seq, size_t n, uint64_t* counts, int16_t* gcs) {
+    const lookup_t L = {ko_wtable_k(t), NULL, t};
+    profile_l(&L, canonical, seq, n, counts, gcs);
 }
 
 static int cmp_u64(const void* a, const void* b) {
@@ -173,8 +188,8 @@ static void print_regions(FILE* out, const record_t* r, const uint64_t* counts, 
 
 /* `kat cold` (Cold::processSeqFile + processSeq + printStatTable, src/cold.cc:126-408, 254-271): every record of the
  * assembly file profiled against the reads hash and the assembly's own hash; one -stats.tsv row per record. */
-int ko_cold(const ko_table* reads, int canon_reads, const ko_table* assembly, int canon_asm, const char* asm_path, const char* prefix) {
-    const unsigned k = ko_table_k(reads);
+static int cold_l(const lookup_t* reads, int canon_reads, const lookup_t* assembly, int canon_asm, const char* asm_path, const char* prefix) {
+    const unsigned k = reads->k;
     char* data; size_t n;
     int rc = slurp_gz(asm_path, &data, &n);
     if (rc) return rc;
@@ -198,8 +213,8 @@ int ko_cold(const ko_table* reads, int canon_reads, const ko_table* assembly, in
         uint32_t median = 0, asm_cn = 0; double mean = 0.0;
         if (nb) {
             if (nb > cap) { cap = nb; rc_counts = realloc(rc_counts, cap * 8); as_counts = realloc(as_counts, cap * 8); gcs = realloc(gcs, cap * 2); }
-            ko_profile(reads, canon_reads, r.seq.p, r.seq.n, rc_counts, gcs);
-            ko_profile(assembly, canon_asm, r.seq.p, r.seq.n, as_counts, NULL);
+            profile_l(reads, canon_reads, r.seq.p, r.seq.n, rc_counts, gcs);
+            profile_l(assembly, canon_asm, r.seq.p, r.seq.n, as_counts, NULL);
             uint64_t sum = 0;
             for (size_t i = 0; i < nb; i++) { if (gcs[i] < 0) nb_invalid++; else { sum += rc_counts[i]; if (rc_counts[i]) nb_nonzero++; } }
             qsort(rc_counts, nb, 8, cmp_u64);
@@ -228,11 +243,20 @@ int ko_cold(const ko_table* reads, int canon_reads, const ko_table* assembly, in
     return rc;
 }
 
+int ko_cold(const ko_table* reads, int canon_reads, const ko_table* assembly, int canon_asm, const char* asm_path, const char* prefix) {
+    const lookup_t a = {ko_table_k(reads), reads, NULL}, b = {ko_table_k(assembly), assembly, NULL};
+    return cold_l(&a, canon_reads, &b, canon_asm, asm_path, prefix);
+}
+int ko_wcold(const ko_wtable* reads, int canon_reads, const ko_wtable* assembly, int canon_asm, const char* asm_path, const char* prefix) {
+    const lookup_t a = {ko_wtable_k(reads), NULL, reads}, b = {ko_wtable_k(assembly), NULL, assembly};
+    return cold_l(&a, canon_reads, &b, canon_asm, asm_path, prefix);
+}
+
 /* `kat sect` end to end (Sect::execute + save, src/sect.cc:86-143).  flags: bit0 no_count_stats, bit1 output_gc_stats,
  * bit2 extract_nr, bit3 extract_r, bit4 cvg_logscale, bit5 also Sect::save() (the contamination matrix). */
-int ko_sect(const ko_table* t, int canonical, const char* seq_path, const char* prefix, uint32_t gc_bins, uint32_t cvg_bins,
-            unsigned flags, uint32_t min_repeat, uint32_t max_repeat) {
-    const unsigned k = ko_table_k(t);
+static int sect_l(const lookup_t* t, int canonical, const char* seq_path, const char* prefix, uint32_t gc_bins, uint32_t cvg_bins,
+                  unsigned flags, uint32_t min_repeat, uint32_t max_repeat) {
+    const unsigned k = t->k;
     char* data; size_t n;
     int rc = slurp_gz(seq_path, &data, &n);
     if (rc) return rc;
@@ -264,7 +288,7 @@ int ko_sect(const ko_table* t, int canonical, const char* seq_path, const char* 
         const size_t nb = nb_counts > 0 ? (size_t)nb_counts : 0;
         if (nb) {                                                        /* Sect::processSeq, src/sect.cc:486-546 */
             if (nb > cap) { cap = nb; counts = realloc(counts, cap * 8); sorted = realloc(sorted, cap * 8); gcs = realloc(gcs, cap * 2); }
-            ko_profile(t, canonical, r.seq.p, r.seq.n, counts, gcs);
+            profile_l(t, canonical, r.seq.p, r.seq.n, counts, gcs);
             uint64_t sum = 0;
             for (size_t i = 0; i < nb; i++) { if (gcs[i] < 0) nb_invalid++; else { sum += counts[i]; if (counts[i]) nb_nonzero++; } }
             memcpy(sorted, counts, nb * 8);
@@ -339,4 +363,15 @@ done:
 #undef OPEN
     free(mx); free(counts); free(sorted); free(gcs); free(r.name.p); free(r.seq.p); free(data);
     return rc;
+}
+
+int ko_sect(const ko_table* t, int canonical, const char* seq_path, const char* prefix, uint32_t gc_bins, uint32_t cvg_bins,
+            unsigned flags, uint32_t min_repeat, uint32_t max_repeat) {
+    const lookup_t L = {ko_table_k(t), t, NULL};
+    return sect_l(&L, canonical, seq_path, prefix, gc_bins, cvg_bins, flags, min_repeat, max_repeat);
+}
+int ko_wsect(const ko_wtable* t, int canonical, const char* seq_path, const char* prefix, uint32_t gc_bins, uint32_t cvg_bins,
+             unsigned flags, uint32_t min_repeat, uint32_t max_repeat) {
+    const lookup_t L = {ko_wtable_k(t), NULL, t};
+    return sect_l(&L, canonical, seq_path, prefix, gc_bins, cvg_bins, flags, min_repeat, max_repeat);
 }

@@ -117,6 +117,13 @@ static uint64_t wget(const ko_wtable* t, u128 key) {              /* get_val_for
 void ko_wtable_add(ko_wtable* t, uint64_t hi, uint64_t lo, uint64_t amount) { wadd(t, mk128(hi, lo) & wmask(t->k), amount); }
 uint64_t ko_wtable_get(const ko_wtable* t, uint64_t hi, uint64_t lo) { return wget(t, mk128(hi, lo)); }
 
+/* JellyfishHelper::getCount for a k-mer given as text (lib/src/jellyfish_helper.cc:189-194): mer_dna(string), canonicalised on demand */
+uint64_t ko_wtable_get_mer(const ko_wtable* t, const char* mer, int canonical) {
+    u128 x = 0;
+    for (unsigned i = 0; i < t->k; i++) x = (x << 2) | (u128)(unsigned)wbase_code((uint8_t)mer[i]);
+    return wget(t, canonical ? wcanonical(x, t->k) : x);
+}
+
 typedef struct { u128 k; uint64_t c; } wkc_t;
 static int wkc_cmp(const void* a, const void* b) {
     const wkc_t *x = (const wkc_t*)a, *y = (const wkc_t*)b;

@@ -133,7 +133,7 @@ def test_comp_and_comp3_wide(engine, ko, k, c1, c2):
 
 def test_narrow_only_entry_points_say_so(engine, tmp_path):
     t = engine.table(40, True).count_bases(b"ACGT" * 30)
-    for call in (lambda: t.get(np.array([1], np.uint64)), lambda: t.export(), lambda: t.profile(b"ACGT" * 20),
+    for call in (lambda: t.get(np.array([1], np.uint64)), lambda: t.export(),
                  lambda: t.geometry(), lambda: t.merge_host([1], [1])):
         with pytest.raises(kat_amd.KatGpuError) as ei:
             call()
@@ -169,8 +169,62 @@ def test_cli_hist_gcp_comp_wide(ko, refdata, tmp_path):
     ko.write_comp(str(tmp_path / "want"), 41, [r1], [r2], 1001, 1001, mx, cc, sp)
     assert (tmp_path / "c-main.mx").read_bytes() == (tmp_path / "want-main.mx").read_bytes()
     assert (tmp_path / "c.stats").read_bytes() == (tmp_path / "want.stats").read_bytes()
-    r = run(["sect", "-m", "41", "-o", "s", os.path.join(refdata, "sect_test.fa"), r1])
-    assert r.returncode != 0 and "k > 32" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("k,canonical", [(33, True), (50, False), (63, True)])
+def test_profile_wide(ko, engine, k, canonical):
+    """katgpu_table_profile_* (k_profile_w) against the oracle's per-position lookups: shared, shuffled and ragged probes, both
+    canonicalisation choices, the device form at odd alignments, a count above 32 bits."""
+    from tests.test_gpu_sect import random_seq
+    rng = np.random.default_rng(k)
+    genome = random_seq(rng, 200_000)
+    t = engine.table(k, canonical).count_bases(genome)
+    o = ko.WideTable(k, canonical).count_bases(genome)
+    for probe in (genome[1000:150_000], random_seq(rng, 50_000, 0.0), genome[:k], genome[:k - 1], genome[:0], genome[5:5 + 4032 + k],
+                  genome[3:3 + 4031 + k], np.frombuffer(b"N" * 100, np.uint8)):
+        for canon in (canonical, True, False):
+            want, _ = ko.profile(o, probe.tobytes(), canon)
+            assert np.array_equal(t.profile(probe, canon), want)
+    probe = genome[777:90_000]
+    want, _ = ko.profile(o, probe.tobytes(), True)
+    for shift in (0, 1, 7):
+        db, dc = engine.alloc(probe.size + 64), engine.alloc(want.size * 8 + 64)
+        db.upload(probe, offset=shift)
+        t.profile_device(db.ptr + shift, probe.size, dc.ptr + (8 if shift & 1 else 0), True)
+        engine.sync()
+        assert np.array_equal(dc.download(np.uint64, want.size, offset=8 if shift & 1 else 0), want)
+        db.free(); dc.free()
+    big = engine.table(k, False)
+    i = next(j for j in range(1000, 5000) if all(c in b"ACGTacgt" for c in genome[j:j + k].tobytes()))
+    word = 0
+    for c in genome[i:i + k].tobytes().upper():
+        word = (word << 2) | b"ACGT".index(c)
+    big.merge_host_wide([word >> 64], [word & ((1 << 64) - 1)], [(1 << 33) + 5])
+    got = big.profile(genome[i - 2:i + k + 2], False)
+    assert got.tolist() == [0, 0, (1 << 33) + 5, 0, 0]
+
+
+def test_sect_and_cold_cli_wide(ko, refdata, tmp_path):
+    """`katgpu sect` / `katgpu cold` at k = 41: the files koracle_sect.c writes from the wide oracle table, byte for byte."""
+    from tests.test_gpu_sect import run, files, SUFFIXES
+    from tests.test_oracle_sect import make_cases
+    paths, fa = make_cases(tmp_path)
+    length = os.path.join(refdata, "sect_length_test.fa")
+    r1 = os.path.join(refdata, "ecoli_r1.1K.fastq")
+    k = 41
+    t = ko.WideTable(k, True).count_files([fa, length])
+    for i, p in enumerate([paths[0], paths[2], paths[3], length]):
+        r = run(["sect", "-m", str(k), "-H", "100000", "-o", "o%d" % i, "-g", "-E", "-F", "-M", "2", "-G", "5", "-x", "50", "-y", "7", p, fa, length],
+                tmp_path, env={"KATGPU_SECT_SAVE": "1"})
+        assert r.returncode == 0, r.stderr
+        ko.sect(t, p, str(tmp_path / ("w%d" % i)), output_gc_stats=True, extract_nr=True, extract_r=True, min_repeat=2, max_repeat=5,
+                gc_bins=50, cvg_bins=7, save=True)
+        got, want = files(str(tmp_path / ("o%d" % i))), files(str(tmp_path / ("w%d" % i)))
+        assert set(got) == set(SUFFIXES) and got == want, p
+    r = run(["cold", "-m", str(k), "-H", "100000", "-o", "c", length, r1, fa], tmp_path)
+    assert r.returncode == 0, r.stderr
+    ko.cold(ko.WideTable(k, False).count_files([r1, fa]), ko.WideTable(k, False).count_files([length]), length, str(tmp_path / "wc"))
+    assert (tmp_path / "c-stats.tsv").read_bytes() == (tmp_path / "wc-stats.tsv").read_bytes()
 
 
 def test_jf_dump_and_load_wide(engine, ko, refdata, tmp_path):

@@ -21,6 +21,11 @@ def oracle_files(ko, table, seq_path, tmp_path, tag, **kw):
 
 
 def counts_of(ko, table):
+    if isinstance(table, ko.WideTable):
+        hi, lo, cnts = table.dump_sorted()
+        k = table.k
+        dec = lambda x: "".join("ACGT"[(x >> (2 * (k - 1 - i))) & 3] for i in range(k))
+        return {dec((int(a) << 64) | int(b)): int(c) for a, b, c in zip(hi, lo, cnts)}
     keys, cnts = table.dump_sorted()
     return {ko.decode(int(k), table.k): int(c) for k, c in zip(keys, cnts)}
 
@@ -128,6 +133,22 @@ def test_cold_oracle_vs_naive(ko, refdata, tmp_path):
             ko.cold(reads, asm, p, str(tmp_path / "c"))
             want = naive.cold(counts_of(ko, reads), cr, counts_of(ko, asm), ca, k, p)
             assert (tmp_path / "c-stats.tsv").read_bytes() == want
+
+
+@pytest.mark.parametrize("k,canonical", [(33, True), (40, False), (63, True)])
+def test_wide_sect_and_cold_vs_naive(ko, refdata, tmp_path, k, canonical):
+    """k > 32 (koracle_wide.c behind the same sect / cold code) against the naive statement, which works on strings."""
+    paths, fa = make_cases(tmp_path)
+    length = os.path.join(refdata, "sect_length_test.fa")
+    t = ko.WideTable(k, canonical).count_files([fa, length, os.path.join(refdata, "ecoli_r1.1K.fastq")])
+    counts = counts_of(ko, t)
+    for i, p in enumerate(paths[:4] + [length]):
+        kw = dict(output_gc_stats=True, extract_nr=True, extract_r=True, min_repeat=2, max_repeat=5, save=True)
+        assert oracle_files(ko, t, p, tmp_path, "w%d" % i, **kw) == naive.sect(counts, k, canonical, p, **kw), p
+    asm = ko.WideTable(k, not canonical).count_files([fa, length])
+    for p in (paths[0], paths[3], length):
+        ko.cold(t, asm, p, str(tmp_path / "wc"))
+        assert (tmp_path / "wc-stats.tsv").read_bytes() == naive.cold(counts, canonical, counts_of(ko, asm), not canonical, k, p)
 
 
 SEQAN_REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "seqan_ref")
