@@ -1106,8 +1106,9 @@ extern "C" int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* co
     uint64_t zero = 0;
     rc = katgpu_table_partition(t, 1, &zero, dk, dc);
     if (!rc) {
-        hipMemcpy(keys, dk, t->distinct * 8, hipMemcpyDeviceToHost);
-        hipMemcpy(counts, dc, t->distinct * 8, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(keys, dk, t->distinct * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(counts, dc, t->distinct * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, KATGPU_ERR_DEVICE, "export: %s", hipGetErrorString(e));
     }
     hipFree(dk); hipFree(dc);
     return rc;
@@ -1148,9 +1149,9 @@ extern "C" int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, co
     uint64_t *dk = nullptr, *dc = nullptr;
     HIPCHK(c, hipMalloc(&dk, n * 8));
     if (hipMalloc(&dc, n * 8) != hipSuccess) { hipFree(dk); return fail(c, KATGPU_ERR_NOMEM, "merge buffers"); }
-    hipMemcpy(dk, keys, n * 8, hipMemcpyHostToDevice);
-    hipMemcpy(dc, counts, n * 8, hipMemcpyHostToDevice);
-    int rc = katgpu_table_merge_device(t, dk, dc, n);
+    hipError_t e = hipMemcpy(dk, keys, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dc, counts, n * 8, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? katgpu_table_merge_device(t, dk, dc, n) : fail(c, KATGPU_ERR_DEVICE, "merge: %s", hipGetErrorString(e));
     hipFree(dk); hipFree(dc);
     return rc;
 }
@@ -1194,10 +1195,10 @@ extern "C" int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* key
         if (keys_hi[i] & ~hi_mask) return fail(c, KATGPU_ERR_INVALID_ARG, "record %zu: key wider than 2k = %u bits", i, 2 * k);
     uint64_t* d = nullptr;
     HIPCHK(c, hipMalloc(&d, 3 * n * 8));
-    hipMemcpy(d, keys_hi, n * 8, hipMemcpyHostToDevice);
-    hipMemcpy(d + n, keys_lo, n * 8, hipMemcpyHostToDevice);
-    hipMemcpy(d + 2 * n, counts, n * 8, hipMemcpyHostToDevice);
-    int rc = KATGPU_OK;
+    hipError_t e = hipMemcpy(d, keys_hi, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, keys_lo, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 2 * n, counts, n * 8, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? KATGPU_OK : fail(c, KATGPU_ERR_DEVICE, "merge: %s", hipGetErrorString(e));
     size_t pos = 0;
     while (pos < n && !rc) {
         rc = refresh_counters(t); if (rc) break;
@@ -1312,7 +1313,7 @@ extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uin
         if (nb > dev_big_cap) rc = fail(c, KATGPU_ERR_DEVICE, "extract: %llu counts above 32 bits", nb);
         else {
             std::vector<uint64_t> hk(nb), hc(nb);
-            if (nb) { hipMemcpy(hk.data(), d_bk, nb * 8, hipMemcpyDeviceToHost); hipMemcpy(hc.data(), d_bc, nb * 8, hipMemcpyDeviceToHost); }
+            if (nb) { e = hipMemcpy(hk.data(), d_bk, nb * 8, hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemcpy(hc.data(), d_bc, nb * 8, hipMemcpyDeviceToHost); }
             if (t->ones) { hk.push_back(~0ULL); hc.push_back(t->ones); }          // the all-ones key has no slot (kg_device.hpp)
             if (hk.size() > big_cap) rc = fail(c, KATGPU_ERR_INVALID_ARG, "extract: big list needs %zu entries", hk.size());
             else { for (size_t i = 0; i < hk.size(); ++i) { big_keys[i] = hk[i]; big_counts[i] = hc[i]; } out = (uint32_t)hk.size(); }
@@ -1423,8 +1424,9 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
         if (ndef) {                                   // regions that could have overflowed: their runs go in directly (with growth)
             std::vector<uint32_t> regs(ndef);
             std::vector<uint64_t> off((size_t)na * (n_reg + 1));
-            hipMemcpy(regs.data(), d_def, ndef * 4, hipMemcpyDeviceToHost);
-            hipMemcpy(off.data(), d_off, off.size() * 8, hipMemcpyDeviceToHost);
+            e = hipMemcpy(regs.data(), d_def, ndef * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(off.data(), d_off, off.size() * 8, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { hipFree(tmp); return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e)); }
             if (g_trace) fprintf(stderr, "[katgpu] merge: %llu region(s) deferred to the direct path\n", ndef);
             // Room first, per REGION: the runs of one region all land in that region, so the global load says nothing here.
             // After growing every region to hold what it has plus what arrives (at load 0.7) no insert below can fail.
