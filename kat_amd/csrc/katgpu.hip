@@ -1272,8 +1272,8 @@ extern "C" int katgpu_table_extract_sizes(katgpu_table* t, uint32_t n_parts, uin
 extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint64_t* dev_keys, uint32_t* dev_counts,
                                     uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big) {
     if (!t || !dev_region_counts || !dev_keys || !dev_counts || !n_big || n_parts == 0 || n_parts > MAX_EXCHANGE_PARTS || (big_cap && (!big_keys || !big_counts)))
-    NARROW_ONLY(t, "the multi-GPU exchange");
         return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
