@@ -164,8 +164,12 @@ def main():
             # in place: each table is extracted into a region-ordered send list, emptied, and refilled with the k-mers this
             # rank owns (kat_amd/dist.py); t2 keeps t1's region grid, so comp still joins region against region
             results["distinct1_local"] = t1.stats(want_total=False)["distinct"]
-            kdist.exchange_merge(kdist.HipShard(t1, staged=staged))
-            kdist.exchange_merge(kdist.HipShard(t2, staged=staged))
+            if k > 32:                                      # wide tables: owner partition -> all-to-all -> rebuild (not in place)
+                t1 = kdist.exchange_merge_wide(kdist.HipWideShard(t1, staged=staged)).table
+                t2 = kdist.exchange_merge_wide(kdist.HipWideShard(t2, staged=staged)).table
+            else:
+                kdist.exchange_merge(kdist.HipShard(t1, staged=staged))
+                kdist.exchange_merge(kdist.HipShard(t2, staged=staged))
             tp = mark("exchange", tp)
         mx, cc, sp = kat_amd.comp(t1, t2)
         tp = mark("comp", tp)

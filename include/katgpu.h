@@ -33,7 +33,8 @@ typedef struct katgpu_table katgpu_table;
  * in two words -- counted and reduced (count*, stats, hist, gcp, comp, comp3) exactly like the narrow ones; records move
  * through the *_wide entry points as (hi, lo) = the upper and lower 64 bits of the 2k-bit word (first base most significant,
  * A=0 C=1 G=2 T=3, as mer_dna: JF/include/jellyfish/mer_dna.hpp:235-258); .jf files and the sect/cold profile work for both.
- * Entry points that take 64-bit keys and the multi-GPU exchange return KATGPU_ERR_K for a wide table. */
+ * Entry points that take 64-bit keys and the region-ordered exchange return KATGPU_ERR_K for a wide table (its exchange is
+ * katgpu_table_partition_sizes + katgpu_table_partition_wide + katgpu_table_merge_device_wide). */
 #define KATGPU_MAX_K 63
 
 typedef enum katgpu_status {
@@ -128,6 +129,11 @@ int katgpu_table_get_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64
 int katgpu_table_export_wide(katgpu_table* t, uint64_t* keys_hi, uint64_t* keys_lo, uint64_t* counts, size_t cap, size_t* n_out);
 /* hash_counter::add for a batch of (k-mer, amount) records (what katgpu_table_merge_host is for narrow tables) */
 int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, const uint64_t* counts, size_t n);
+/* Owner-partitioned export / record merge of a wide table for the multi-GPU exchange (katgpu_table_partition_sizes serves both
+ * table kinds; these two are katgpu_table_partition / katgpu_table_merge_device with (hi, lo) keys; device pointers). */
+int katgpu_table_partition_wide(katgpu_table* t, uint32_t n_parts, const uint64_t* offsets, uint64_t* dev_keys_hi, uint64_t* dev_keys_lo,
+                                uint64_t* dev_counts);
+int katgpu_table_merge_device_wide(katgpu_table* t, const uint64_t* dev_keys_hi, const uint64_t* dev_keys_lo, const uint64_t* dev_counts, size_t n);
 
 /* ---- Jellyfish hash files (.jf, "binary/sorted"): replaces HashLoader::loadHash / JellyfishHelper::dumpHash
  *      (lib/src/jellyfish_helper.cc:97-187,248-256) and InputHandler::dump (lib/src/input_handler.cc:221-243).

@@ -31,6 +31,7 @@ EXPORTS = (
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
     "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_parse_files", "katgpu_free_host",
     "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
+    "katgpu_table_partition_wide", "katgpu_table_merge_device_wide",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
     "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide",
 )
@@ -125,6 +126,8 @@ def load_library():
     L.katgpu_table_get_wide.argtypes = [vp, vp, vp, sz, C.c_int, vp]
     L.katgpu_table_export_wide.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
     L.katgpu_table_merge_host_wide.argtypes = [vp, vp, vp, vp, sz]
+    L.katgpu_table_partition_wide.argtypes = [vp, u32, vp, vp, vp, vp]
+    L.katgpu_table_merge_device_wide.argtypes = [vp, vp, vp, vp, sz]
     L.katgpu_parse_files.argtypes = [vp, sz, vp, u32, pp, C.POINTER(sz), cpp]
     L.katgpu_free_host.argtypes = [vp]
     L.katgpu_free_host.restype = None
@@ -478,6 +481,13 @@ class Table:
         h, l, c = (np.ascontiguousarray(x, np.uint64) for x in (hi, lo, counts))
         assert h.size == l.size == c.size
         self.engine._chk(self.engine.L.katgpu_table_merge_host_wide(self.h, h.ctypes.data, l.ctypes.data, c.ctypes.data, h.size))
+
+    def partition_wide(self, n_parts, offsets, dev_hi_ptr, dev_lo_ptr, dev_counts_ptr):
+        off = np.ascontiguousarray(offsets, np.uint64)
+        self.engine._chk(self.engine.L.katgpu_table_partition_wide(self.h, n_parts, off.ctypes.data, dev_hi_ptr, dev_lo_ptr, dev_counts_ptr))
+
+    def merge_device_wide(self, dev_hi_ptr, dev_lo_ptr, dev_counts_ptr, n):
+        self.engine._chk(self.engine.L.katgpu_table_merge_device_wide(self.h, dev_hi_ptr, dev_lo_ptr, dev_counts_ptr, n))
 
     def get_wide(self, hi, lo, canonicalise=False):
         h, l = np.ascontiguousarray(hi, np.uint64), np.ascontiguousarray(lo, np.uint64)

@@ -1053,7 +1053,6 @@ extern "C" int katgpu_table_profile_host(katgpu_table* t, const char* bases, siz
 
 extern "C" int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, uint64_t* sizes) {
     if (!t || !sizes || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
-    NARROW_ONLY(t, "katgpu_table_partition");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
@@ -1062,7 +1061,10 @@ extern "C" int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, u
     hipMemsetAsync(d, 0, n_parts * 8, c->stream);
     {
         ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
-        hipLaunchKernelGGL(k_partition<0>, dim3(grid_for(c, t->d.cap + 1, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, (uint64_t*)nullptr, (uint64_t*)nullptr);
+        if (t->d.keys_b)
+            hipLaunchKernelGGL(k_partition_w<0>, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr);
+        else
+            hipLaunchKernelGGL(k_partition<0>, dim3(grid_for(c, t->d.cap + 1, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, (uint64_t*)nullptr, (uint64_t*)nullptr);
     }
     hipMemcpyAsync(sizes, d, n_parts * 8, hipMemcpyDeviceToHost, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -1183,6 +1185,49 @@ extern "C" int katgpu_table_export_wide(katgpu_table* t, uint64_t* keys_hi, uint
     return KATGPU_OK;
 }
 
+extern "C" int katgpu_table_partition_wide(katgpu_table* t, uint32_t n_parts, const uint64_t* offsets, uint64_t* dev_hi, uint64_t* dev_lo, uint64_t* dev_counts) {
+    if (!t || !offsets || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_partition_wide is for k > 32 tables (k = %u): use katgpu_table_partition", t->d.k);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    if (t->distinct && (!dev_hi || !dev_lo || !dev_counts)) return KATGPU_ERR_INVALID_ARG;
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n_parts * 8));
+    hipMemcpyAsync(d, offsets, n_parts * 8, hipMemcpyHostToDevice, c->stream);
+    {
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
+        hipLaunchKernelGGL(k_partition_w<1>, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, dev_hi, dev_lo, dev_counts);
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_merge_device_wide(katgpu_table* t, const uint64_t* dev_hi, const uint64_t* dev_lo, const uint64_t* dev_counts, size_t n) {
+    if (!t || (n && (!dev_hi || !dev_lo || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = t->ctx;
+    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_merge_device_wide is for k > 32 tables (k = %u): use katgpu_table_merge_device", t->d.k);
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t pos = 0;
+    while (pos < n) {
+        int rc = refresh_counters(t); if (rc) return rc;
+        const uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
+        const uint64_t want = n - pos;
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
+            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
+            if (rc) return rc;
+            continue;
+        }
+        const uint64_t take = std::min(want, room);
+        ScopedTimer tm(c, KATGPU_K_MERGE, take);
+        hipLaunchKernelGGL(k_merge_w, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->d, dev_hi + pos, dev_lo + pos, dev_counts + pos, (uint64_t)take);
+        pos += take;
+    }
+    return refresh_counters(t);
+}
+
 extern "C" int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, const uint64_t* counts, size_t n) {
     if (!t || (n && (!keys_hi || !keys_lo || !counts))) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
@@ -1198,22 +1243,7 @@ extern "C" int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* key
     hipError_t e = hipMemcpy(d, keys_hi, n * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + n, keys_lo, n * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + 2 * n, counts, n * 8, hipMemcpyHostToDevice);
-    int rc = e == hipSuccess ? KATGPU_OK : fail(c, KATGPU_ERR_DEVICE, "merge: %s", hipGetErrorString(e));
-    size_t pos = 0;
-    while (pos < n && !rc) {
-        rc = refresh_counters(t); if (rc) break;
-        const uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
-        const uint64_t want = n - pos;
-        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
-            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
-            continue;
-        }
-        const uint64_t take = std::min(want, room);
-        ScopedTimer tm(c, KATGPU_K_MERGE, take);
-        hipLaunchKernelGGL(k_merge_w, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->d, d + pos, d + n + pos, d + 2 * n + pos, (uint64_t)take);
-        pos += take;
-    }
-    if (!rc) rc = refresh_counters(t);
+    int rc = e == hipSuccess ? katgpu_table_merge_device_wide(t, d, d + n, d + 2 * n, n) : fail(c, KATGPU_ERR_DEVICE, "merge: %s", hipGetErrorString(e));
     hipStreamSynchronize(c->stream);
     hipFree(d);
     return rc;

@@ -228,6 +228,11 @@ __device__ __forceinline__ KeyW keyw_canonical(KeyW x, uint32_t k) {
 }
 __device__ __forceinline__ uint32_t keyw_gc(KeyW x, uint32_t k) { return kmer_gc(keyw_lo(x), 32) + kmer_gc(keyw_hi(x), k - 32); }
 __device__ __forceinline__ uint64_t keyw_hash(KeyW x) { return mix64(x.b ^ (x.a * 0x9E3779B97F4A7C15ULL)); }
+// owner part of a wide k-mer for the multi-GPU merge: a second mix of the CANONICAL form, as owner_of does for one-word k-mers
+__device__ __forceinline__ uint32_t owner_of_w(KeyW key, uint32_t k, uint32_t n_parts) {
+    const KeyW c = keyw_canonical(key, k);
+    return (uint32_t)__umul64hi(mix64(keyw_hash(c) ^ 0x9E3779B97F4A7C15ULL), (uint64_t)n_parts);
+}
 __device__ __forceinline__ Probe probe_start_w(KeyW key, const DevTable& t) {
     const uint64_t h = keyw_hash(key);
     Probe p;

@@ -131,6 +131,23 @@ k_export_w(DevTable t, uint32_t n_ovf, uint64_t* __restrict__ hi, uint64_t* __re
     }
 }
 
+// owner-partitioned export for the multi-GPU merge (k_partition for wide tables).  MODE 0: records per part; MODE 1: scatter
+// (hi, lo, count) records to cursors[part]++.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_partition_w(DevTable t, uint32_t n_ovf, uint32_t n_parts, unsigned long long* __restrict__ sizes_or_cursors,
+              uint64_t* __restrict__ out_hi, uint64_t* __restrict__ out_lo, uint64_t* __restrict__ out_counts) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.cap; i += stride) {
+        const uint64_t a = t.keys[i];
+        if (a == EMPTY) continue;
+        const KeyW kw{a, t.keys_b[i]};
+        const uint32_t part = n_parts > 1 ? owner_of_w(kw, t.k, n_parts) : 0;
+        const unsigned long long at = atomicAdd(&sizes_or_cursors[part], 1ULL);
+        if (MODE == 1) { out_hi[at] = keyw_hi(kw); out_lo[at] = keyw_lo(kw); out_counts[at] = slot_count(t, i, i, n_ovf); }
+    }
+}
+
 // batch lookup (JellyfishHelper::getCount, lib/src/jellyfish_helper.cc:189-194)
 __global__ void __launch_bounds__(256)
 k_get_w(DevTable t, uint32_t n_ovf, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint64_t n, int canonicalise, uint64_t* __restrict__ out) {

@@ -346,3 +346,119 @@ def owner_of(keys, k, n_parts):
     x = np.asarray(keys, dtype=np.uint64)
     c = np.minimum(x, _revcomp(x, k))
     return mulhi64(_mix64(c ^ np.uint64(0x9E3779B97F4A7C15)), np.uint64(n_parts)).astype(np.int64)
+
+
+# ---- k > 32 ("wide" tables): the k-mer is (hi, lo), the upper / lower 64 bits of its 2k-bit word -----------------------
+
+def _revcomp_wide(hi, lo, k):
+    """Reverse complement of 2k-bit words given as (hi, lo) uint64 arrays, 33 <= k <= 64 (base-by-base, vectorised over records)."""
+    hi = np.asarray(hi, dtype=np.uint64)
+    lo = np.asarray(lo, dtype=np.uint64)
+    rhi, rlo = np.zeros_like(hi), np.zeros_like(lo)
+    for i in range(k):                                   # base i (from the LSB) -> complemented, to position k-1-i
+        b = ((lo >> np.uint64(2 * i)) if i < 32 else (hi >> np.uint64(2 * (i - 32)))) & np.uint64(3)
+        j = k - 1 - i
+        c = np.uint64(3) - b
+        if j < 32:
+            rlo |= c << np.uint64(2 * j)
+        else:
+            rhi |= c << np.uint64(2 * (j - 32))
+    return rhi, rlo
+
+
+def owner_of_wide(hi, lo, k, n_parts):
+    """Host mirror of kg_device.hpp: owner_of_w -- a second mix of the canonical form's table hash."""
+    from .synth import mulhi64
+    hi = np.asarray(hi, dtype=np.uint64)
+    lo = np.asarray(lo, dtype=np.uint64)
+    rhi, rlo = _revcomp_wide(hi, lo, k)
+    rc_less = (rhi < hi) | ((rhi == hi) & (rlo < lo))
+    chi, clo = np.where(rc_less, rhi, hi), np.where(rc_less, rlo, lo)
+    a = (chi << np.uint64(1)) | (clo >> np.uint64(63))                     # the two 63-bit halves the table stores
+    b = clo & np.uint64(0x7FFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        h = _mix64(b ^ (a * np.uint64(0x9E3779B97F4A7C15)))
+    return mulhi64(_mix64(h ^ np.uint64(0x9E3779B97F4A7C15)), np.uint64(n_parts)).astype(np.int64)
+
+
+class HipWideShard:
+    """Adapter over a wide kat_amd.Table (k > 32) for exchange_merge_wide.  Record buffers are plain torch tensors (device, or host
+    with staged=True for the gloo tests): this exchange is the simple one -- partition by owner, all-to-all, rebuild -- not the
+    region-ordered in-place protocol of the one-word tables, whose LDS merge is built around 12-byte slots."""
+
+    def __init__(self, table, staged=False):
+        assert table.k > 32
+        self.table = table
+        self.k = table.k
+        self.canonical = table.canonical
+        self.staged = staged
+        self.cuda = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device("cpu") if staged else self.cuda
+
+    def part_sizes(self, n_parts):
+        return self.table.partition_sizes(n_parts).astype(np.int64)
+
+    def partition(self, n_parts, offsets, total):
+        """(hi, lo, counts) int64 tensors of `total` records on self.device, part p starting at offsets[p]."""
+        dev = [torch.empty(max(total, 1), dtype=torch.int64, device=self.cuda) for _ in range(3)]
+        self.table.partition_wide(n_parts, offsets, dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr())
+        return [t.cpu() for t in dev] if self.staged else dev
+
+    def rebuild(self, hi, lo, counts, n):
+        """Replace the table by one holding exactly these n records (equal k-mers summed)."""
+        eng = self.table.engine
+        old = self.table
+        new = eng.table(self.k, self.canonical, size_hint=max(int(n / 0.6) + 1024, 1 << 16))
+        old.free()
+        if n:
+            dev = [t[:n].to(self.cuda).contiguous() for t in (hi, lo, counts)]
+            new.merge_device_wide(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), n)
+            eng.sync()
+        self.table = new
+
+    def free(self):
+        self.table.free()
+
+
+def exchange_merge_wide(shard, group=None):
+    """exchange_merge for wide tables: every (k-mer, count) record goes to owner_of_w(k-mer); on return shard.table holds exactly
+    the k-mers this rank owns, counts summed over ranks (exact integer sums: bit-identical to one process).  The shard is
+    duck-typed (part_sizes / partition / rebuild) like the one-word exchange's."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return shard
+    rank = dist.get_rank(group)
+    dev = shard.device
+    meta = torch.tensor([shard.k, int(shard.canonical)], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    if any(int(m[0]) != shard.k or int(m[1]) != int(shard.canonical) for m in metas):
+        raise ValueError("exchange_merge_wide: ranks disagree on k / canonical")
+    sizes = shard.part_sizes(world)                                          # records I hold for each owner
+    s_all = [torch.empty(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(s_all, torch.from_numpy(sizes).to(dev), group=group)
+    recv_from = np.array([int(s[rank]) for s in s_all], dtype=np.int64)      # what each peer holds for me
+    send_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    recv_off = np.concatenate([[0], np.cumsum(recv_from)]).astype(np.int64)
+    send = shard.partition(world, send_off[:-1].astype(np.uint64), int(send_off[-1]))
+    recv = [torch.empty(max(int(recv_off[-1]), 1), dtype=torch.int64, device=dev) for _ in range(3)]
+    ops = []
+    for p in range(world):
+        a, n_out = int(send_off[p]), int(sizes[p])
+        b, n_in = int(recv_off[p]), int(recv_from[p])
+        if p == rank:
+            for r, s in zip(recv, send):
+                r[b:b + n_in].copy_(s[a:a + n_out])
+            continue
+        for r, s in zip(recv, send):
+            if n_out:
+                ops.append(dist.P2POp(dist.isend, s[a:a + n_out], p, group))
+            if n_in:
+                ops.append(dist.P2POp(dist.irecv, r[b:b + n_in], p, group))
+    for r in (dist.batch_isend_irecv(ops) if ops else []):
+        r.wait()
+    if dev.type == "cuda":
+        torch.cuda.current_stream().synchronize()
+    del send
+    shard.rebuild(recv[0], recv[1], recv[2], int(recv_off[-1]))
+    return shard

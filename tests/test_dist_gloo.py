@@ -154,3 +154,78 @@ def test_shard_range_covers_everything():
         spans = [kdist.shard_range(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+# ---------------------------------------------------------------- k > 32: exchange_merge_wide --------------------------------
+
+class OracleWideShard:
+    """Same duck type as kat_amd.dist.HipWideShard (part_sizes / partition / rebuild), backed by the wide CPU oracle table."""
+
+    def __init__(self, table):
+        self.table = table
+        self.k, self.canonical = table.k, table.canonical
+        self.device = torch.device("cpu")
+
+    def _records(self):
+        hi, lo, c = self.table.dump_sorted()
+        return hi, lo, c
+
+    def part_sizes(self, n_parts):
+        hi, lo, _ = self._records()
+        return np.bincount(kdist.owner_of_wide(hi, lo, self.k, n_parts), minlength=n_parts).astype(np.int64)
+
+    def partition(self, n_parts, offsets, total):
+        hi, lo, c = self._records()
+        order = np.argsort(kdist.owner_of_wide(hi, lo, self.k, n_parts), kind="stable")
+        assert total == hi.size and list(offsets) == list(np.concatenate([[0], np.cumsum(self.part_sizes(n_parts))])[:-1])
+        return [torch.from_numpy(x[order].view(np.int64).copy()) for x in (hi, lo, c)]
+
+    def rebuild(self, hi, lo, counts, n):
+        from oracle import koracle as ko
+        t = ko.WideTable(self.k, self.canonical)
+        h, l, c = (x[:n].numpy().view(np.uint64) for x in (hi, lo, counts))
+        for a, b, v in zip(h, l, c):
+            t.add((int(a) << 64) | int(b), int(v))
+        self.table = t
+
+
+KW = 45
+
+
+def _wide_worker(rank, world, port, out_dir):
+    from oracle import koracle as ko
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = synth.genome(G, seed=11)
+    lo, hi = kdist.shard_range(N_READS // 2, rank, world)
+    reads = synth.reads(g, 2 * lo, 2 * (hi - lo), seed=1)
+    c_lo, c_hi = kdist.shard_range(G // CONTIG, rank, world)
+    asm = synth.stream_of_contigs(g[c_lo * CONTIG:c_hi * CONTIG], CONTIG)
+    t1 = ko.WideTable(KW, True).count_bases(reads)
+    t2 = ko.WideTable(KW, False).count_bases(asm)
+    t1.add((1 << 85) + 12345, (1 << 33) + rank)                                # a count above 32 bits travels like any other
+    o1 = kdist.exchange_merge_wide(OracleWideShard(t1)).table
+    o2 = kdist.exchange_merge_wide(OracleWideShard(t2)).table
+    hi_, lo_, _ = o1.dump_sorted()
+    assert (kdist.owner_of_wide(hi_, lo_, KW, world) == rank).all()
+    mx, cc, sp = ko.comp(o1, o2, 1.0, 1.0, 101, 101)
+    h, gm = o1.hist(1, 200, 1), o1.gcp(1.0, 100)
+    mx, cc, sp, h, gm = kdist.allreduce_u64([mx, cc, sp, h, gm], torch.device("cpu"))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "wide.npz"), mx=mx, cc=cc, sp=sp, h=h, gm=gm)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_wide_sharded_exchange_matches_single_process(ko, tmp_path, world):
+    mp.spawn(_wide_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "wide.npz")
+    g = synth.genome(G, seed=11)
+    t1 = ko.WideTable(KW, True).count_bases(synth.reads(g, 0, N_READS, seed=1))
+    t1.add((1 << 85) + 12345, world * (1 << 33) + world * (world - 1) // 2)
+    t2 = ko.WideTable(KW, False).count_bases(synth.stream_of_contigs(g, CONTIG))
+    mx, cc, sp = ko.comp(t1, t2, 1.0, 1.0, 101, 101)
+    assert np.array_equal(got["mx"], mx) and np.array_equal(got["cc"], cc) and np.array_equal(got["sp"], sp)
+    assert np.array_equal(got["h"], t1.hist(1, 200, 1)) and np.array_equal(got["gm"], t1.gcp(1.0, 100))
