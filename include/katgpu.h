@@ -110,6 +110,10 @@ void katgpu_free_host(void* p);
 int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t* total, uint64_t* capacity);
 uint32_t katgpu_table_k(const katgpu_table* t);
 int      katgpu_table_canonical(const katgpu_table* t);
+/* How many times the table has grown so far (hash_counter::double_size, JF/include/jellyfish/hash_counter.hpp:204-244, which
+ * prints "Warning: Specified hash size insufficent - attempting to double hash size... success!" each time): the size hint
+ * (KAT's -H) was too small.  A growth step here may more than double. */
+uint32_t katgpu_table_regrows(const katgpu_table* t);
 
 /* JellyfishHelper::getCount (lib/src/jellyfish_helper.cc:189-194) for a batch of packed k-mers. */
 int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n, int canonicalise, uint64_t* counts);

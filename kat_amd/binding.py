@@ -31,7 +31,7 @@ EXPORTS = (
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
     "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_parse_files", "katgpu_free_host",
     "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
-    "katgpu_table_partition_wide", "katgpu_table_merge_device_wide",
+    "katgpu_table_partition_wide", "katgpu_table_merge_device_wide", "katgpu_table_regrows",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
     "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide",
 )
@@ -126,6 +126,8 @@ def load_library():
     L.katgpu_table_get_wide.argtypes = [vp, vp, vp, sz, C.c_int, vp]
     L.katgpu_table_export_wide.argtypes = [vp, vp, vp, vp, sz, C.POINTER(sz)]
     L.katgpu_table_merge_host_wide.argtypes = [vp, vp, vp, vp, sz]
+    L.katgpu_table_regrows.argtypes = [vp]
+    L.katgpu_table_regrows.restype = u32
     L.katgpu_table_partition_wide.argtypes = [vp, u32, vp, vp, vp, vp]
     L.katgpu_table_merge_device_wide.argtypes = [vp, vp, vp, vp, sz]
     L.katgpu_parse_files.argtypes = [vp, sz, vp, u32, pp, C.POINTER(sz), cpp]
@@ -419,6 +421,11 @@ class Table:
         return self
 
     # ---- inspection ----
+    @property
+    def regrows(self):
+        """How often the table had to grow: the size hint (-H) was too small."""
+        return int(self.engine.L.katgpu_table_regrows(self.h))
+
     def stats(self, want_total=True):
         d, t, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self.engine._chk(self.engine.L.katgpu_table_stats(self.h, C.byref(d), C.byref(t) if want_total else None, C.byref(c)))

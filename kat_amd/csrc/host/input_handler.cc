@@ -126,6 +126,10 @@ void InputHandler::count(uint16_t threads, const katgpu_table* like) {      // l
     } else
         Engine::check(katgpu_count(Engine::ctx(), paths.data(), paths.size(), merLen, canonical ? 1 : 0, trim5p.data(), hashSize,
                                    disableHashGrow ? 1 : 0, &hash));
+    // hash_counter::double_size (JF/include/jellyfish/hash_counter.hpp:204-244) says this on stdout at every doubling, once per
+    // counting thread; here once per growth step of the device table (which may more than double)
+    for (uint32_t i = katgpu_table_regrows(hash); i > 0; --i)
+        std::cout << "\nWarning: Specified hash size insufficent - attempting to double hash size... success!\n";
     std::cout << " done.";
     std::cout.flush();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -64,6 +64,7 @@ struct katgpu_table {
     // overflow guard of the unchecked (no-return) +1 adds: no 32-bit counter exceeds count_bound + unchecked_adds
     uint64_t count_bound = 0;    // largest counter value possible at the last sweep (0 for a fresh table)
     uint64_t unchecked_adds = 0; // window starts launched through k_count since then
+    uint32_t n_regrows = 0;      // how often the table had to grow (the host mirror words the reference's warning from it)
     uint8_t carry[64];           // last k-1 bytes of the previous host batch of the current file
     uint32_t carry_n = 0;
 };
@@ -369,6 +370,7 @@ extern "C" void katgpu_table_free(katgpu_table* t) {
 }
 
 extern "C" uint32_t katgpu_table_k(const katgpu_table* t) { return t ? t->d.k : 0; }
+extern "C" uint32_t katgpu_table_regrows(const katgpu_table* t) { return t ? t->n_regrows : 0; }
 extern "C" int katgpu_table_canonical(const katgpu_table* t) { return t ? (int)t->d.canonical : 0; }
 
 // read the counter block back (one small D2H; synchronises the compute stream)
@@ -402,6 +404,7 @@ static int regrow(katgpu_table* t, uint64_t new_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_dev_table(c, t->d);
     t->d = nd;
+    ++t->n_regrows;
     return refresh_counters(t);
 }
 

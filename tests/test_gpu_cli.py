@@ -25,12 +25,14 @@ def test_hist_cli(ko, refdata, tmp_path):
     r = run(["hist", "-m17", "-o", "temp/hist_test", r1, r2], tmp_path)            # tests/test_hist.sh
     assert r.returncode == 0, r.stderr
     assert "Running KAT in HIST mode" in r.stdout and "KAT HIST completed." in r.stdout
+    assert "Warning: Specified hash size" not in r.stdout                   # the default -H is plenty for 2 x 1000 reads
     t = ko.Table(17, True).count_files([r1, r2])
     ko.write_hist(str(tmp_path / "want"), 17, [r1, r2], 1, 10000, 1, t.hist())
     assert (tmp_path / "temp" / "hist_test").read_bytes() == (tmp_path / "want").read_bytes()
     # non-default geometry + non-canonical + default output name
     r = run(["hist", "-m", "21", "-l", "3", "--high=50", "-i", "4", "-N", "-H", "5000", r1], tmp_path)
     assert r.returncode == 0, r.stderr
+    assert "Warning: Specified hash size insufficent - attempting to double hash size... success!" in r.stdout     # -H 5000 is too small
     t = ko.Table(21, False).count_files([r1])
     ko.write_hist(str(tmp_path / "want2"), 21, [r1], 3, 50, 4, t.hist(3, 50, 4))
     assert (tmp_path / "kat.hist").read_bytes() == (tmp_path / "want2").read_bytes()
