@@ -213,9 +213,9 @@ def main():
         # ---- roofline of the count stage, from HIP events recorded on katgpu's own stream ----
         # algorithmic bytes: per instance L/(L-k+1) B of ASCII + 8 B key read + 4 B count read + 4 B count
         # write, plus 8 B key write per distinct k-mer; summed over this rank's count work of the timed steps.
-        per_inst = L / (L - k + 1) + 16.0
+        per_inst = L / (L - k + 1) + 16.0 + (8.0 if k > 32 else 0.0)               # k > 32: a second key word per slot
         d1_local = results.get("distinct1_local", results["distinct1"])          # what THIS rank's count stage wrote
-        alg_bytes_step = per_inst * (inst_reads + inst_asm) + 8.0 * (d1_local + max(inst_asm, 0))
+        alg_bytes_step = per_inst * (inst_reads + inst_asm) + (16.0 if k > 32 else 8.0) * (d1_local + max(inst_asm, 0))
         stage = ["part_l1_count", "part_l1_scatter", "part_l2", "part_apply"]
         part_ms = sum(prof[n]["ms"] for n in stage)
         direct_ms = prof["count"]["ms"]
@@ -238,7 +238,7 @@ def main():
                 "alg_bytes_per_launch": int(alg_bytes_step * a.steps / rounds), "per_kernel": per_kernel}
         kernels_ms = {n: round(v["ms"] / a.steps, 3) for n, v in prof.items() if v["launches"]}
         cpu = None
-        if not a.no_cpu_baseline and world == 1:                  # the host-core baseline is an N = 1 figure
+        if not a.no_cpu_baseline and world == 1 and k <= 32:      # the host-core baseline is an N = 1 figure (the multi-threaded oracle port is one-word)
             cpu = cpu_baseline(eng, a, k, L)
         line = {
             "metric": "k-mers/sec (whole node) for kat comp k=%d, reads vs assembly" % k,
