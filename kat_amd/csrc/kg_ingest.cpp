@@ -347,6 +347,199 @@ int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<i
     return KATGPU_OK;
 }
 
+// ------------------------------------------------------------------ BGZF ---------------------------------------------
+
+namespace {
+
+// Whole size of the BGZF member whose header starts at p (RFC 1952 header with FLG == FEXTRA and a 'B','C' subfield of two
+// bytes holding size - 1; SAM specification section 4.1); 0 when the bytes are not such a header, 1 when `avail` bytes are too
+// few to tell.  *hdr: bytes before the deflate data.
+uint32_t bgzf_member_size(const uint8_t* p, size_t avail, uint32_t* hdr) {
+    static const uint8_t lead[4] = {0x1f, 0x8b, 8, 4};
+    for (size_t i = 0; i < 4 && i < avail; ++i) if (p[i] != lead[i]) return 0;
+    if (avail < 12) return 1;
+    const uint32_t xlen = p[10] | ((uint32_t)p[11] << 8);
+    if (avail < 12 + (size_t)xlen) return 1;
+    for (uint32_t o = 0; o + 4 <= xlen;) {
+        const uint8_t* f = p + 12 + o;
+        const uint32_t slen = f[2] | ((uint32_t)f[3] << 8);
+        if (f[0] == 'B' && f[1] == 'C' && slen == 2 && o + 6 <= xlen) {
+            const uint32_t size = (f[4] | ((uint32_t)f[5] << 8)) + 1;
+            *hdr = 12 + xlen;
+            return size >= *hdr + 8 ? size : 0;
+        }
+        o += 4 + slen;
+    }
+    return 0;
+}
+
+struct BgzfMember { uint32_t in_off, size, hdr, isize; uint64_t out_off; };
+struct BgzfWindow {
+    std::vector<uint8_t> comp, raw;
+    std::vector<BgzfMember> members;
+    int64_t next = 0;              // file offset after the last member taken
+    bool foreign = false;          // the bytes at `next` are not a BGZF member (and `next` < file size)
+    bool io_error = false, bad_data = false;
+};
+
+}  // namespace
+
+bool bgzf_applies(const char* path) {
+    if (env_u64("KATGPU_BGZF", 1) == 0) return false;
+    struct stat st;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    if ((uint64_t)st.st_size < env_u64("KATGPU_BGZF_MIN_BYTES", (uint64_t)1 << 20)) return false;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    uint8_t head[64];
+    const ssize_t got = pread(fd, head, sizeof head, 0);
+    ::close(fd);
+    uint32_t hdr;
+    return got >= 18 && bgzf_member_size(head, (size_t)got, &hdr) >= 2;
+}
+
+int parse_bgzf_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err) {
+    if (!bgzf_applies(path)) return -1;
+    struct stat st;
+    if (stat(path, &st) != 0) return -1;
+    const int64_t size = (int64_t)st.st_size;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(env_u64("KATGPU_BGZF_THREADS", std::min(hw, 16u)), 256));
+    const int64_t window = (int64_t)std::max<uint64_t>((uint64_t)1 << 17, env_u64("KATGPU_BGZF_WINDOW", (uint64_t)16 << 20));   // compressed bytes per round
+
+    // one round: read up to `window` compressed bytes at `from`, find the members, inflate them in parallel
+    BgzfWindow sets[2];
+    auto inflate_window = [&](int64_t from, BgzfWindow* w) {
+        w->members.clear(); w->foreign = w->io_error = w->bad_data = false; w->next = from;
+        const int64_t want = std::min(window, size - from);
+        if (want <= 0) return;
+        if (w->comp.size() < (size_t)want) w->comp.resize((size_t)want);
+        int64_t got = 0;
+        while (got < want) {
+            const ssize_t r = pread(fd, w->comp.data() + got, (size_t)(want - got), from + got);
+            if (r <= 0) { w->io_error = true; return; }
+            got += r;
+        }
+        uint64_t out = 0;
+        int64_t p = 0;
+        while (p < want) {
+            uint32_t hdr = 0;
+            const uint32_t msize = bgzf_member_size(w->comp.data() + p, (size_t)(want - p), &hdr);
+            if (msize == 1 && from + want < size && !w->members.empty()) break;   // a header cut by the window's end: next round
+            if (msize < 2) { w->foreign = true; break; }                         // not a BGZF member (or a truncated header at the end)
+            if (p + msize > want) {                                        // the member's tail lies beyond the window
+                if (from + p + msize > size) w->bad_data = true;           // ... or beyond the file: truncated
+                break;
+            }
+            const uint8_t* tail = w->comp.data() + p + msize - 8;
+            const uint32_t isize = tail[4] | ((uint32_t)tail[5] << 8) | ((uint32_t)tail[6] << 16) | ((uint32_t)tail[7] << 24);
+            if (isize > 65536) { w->bad_data = true; break; }
+            w->members.push_back({(uint32_t)p, msize, hdr, isize, out});
+            out += isize;
+            p += msize;
+        }
+        w->next = from + p;
+        if (w->bad_data) return;
+        if (w->raw.size() < out + 1) w->raw.resize(out + 1);
+        std::atomic<size_t> cursor{0};
+        std::atomic<bool> bad{false};
+        auto work = [&]() {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+            for (;;) {
+                const size_t i = cursor.fetch_add(1);
+                if (i >= w->members.size() || bad) break;
+                const BgzfMember& m = w->members[i];
+                if (m.isize == 0) continue;                                // the end-of-file marker (and any other empty member)
+                inflateReset(&zs);
+                zs.next_in = w->comp.data() + m.in_off + m.hdr;
+                zs.avail_in = m.size - m.hdr - 8;
+                zs.next_out = w->raw.data() + m.out_off;
+                zs.avail_out = m.isize;
+                const int zr = inflate(&zs, Z_FINISH);
+                const uint8_t* tail = w->comp.data() + m.in_off + m.size - 8;
+                const uint32_t crc = tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+                if (zr != Z_STREAM_END || zs.total_out != m.isize ||
+                    (uint32_t)crc32(crc32(0L, Z_NULL, 0), w->raw.data() + m.out_off, m.isize) != crc) bad = true;
+            }
+            inflateEnd(&zs);
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(T, std::max<size_t>(1, w->members.size() / 4));
+        std::vector<std::thread> team;
+        for (unsigned i = 1; i < nt; ++i) team.emplace_back(work);
+        work();
+        for (auto& th : team) th.join();
+        if (bad) w->bad_data = true;
+    };
+
+    ParseState ps;
+    ps.trim5p = trim5p;
+    std::vector<uint8_t> out;
+    auto feed = [&](const uint8_t* d, size_t n) -> int {       // inflated bytes -> state machine -> sink
+        if (!n) return KATGPU_OK;
+        if (ps.type == ParseState::NONE && !ps.begin(d[0])) { *err = "Unsupported format"; return KATGPU_ERR_FORMAT; }
+        out.clear();
+        bool bad = false;
+        ps.consume(d, n, out, &bad);
+        if (bad) { *err = "Invalid fastq sequence"; return KATGPU_ERR_FASTQ; }
+        if (!out.empty()) { const int rc = sink(out.data(), out.size()); if (rc) { err->clear(); return rc; } }
+        return KATGPU_OK;
+    };
+
+    int64_t pos = 0;
+    unsigned parity = 0;
+    size_t n_members = 0;
+    inflate_window(0, &sets[0]);
+    for (;;) {
+        BgzfWindow* w = &sets[parity];
+        if (w->io_error || w->bad_data) { *err = std::string("read error on ") + path; return KATGPU_ERR_IO; }
+        std::future<void> next;
+        const bool more = !w->foreign && w->next < size && !w->members.empty();
+        if (more) { parity ^= 1; next = std::async(std::launch::async, inflate_window, w->next, &sets[parity]); }   // inflate ahead
+        const uint64_t raw_bytes = w->members.empty() ? 0 : w->members.back().out_off + w->members.back().isize;
+        const int rc = feed(w->raw.data(), (size_t)raw_bytes);
+        n_members += w->members.size();
+        pos = w->next;
+        if (rc) { if (next.valid()) next.wait(); return rc; }
+        if (!more) {
+            if (!w->foreign && w->next < size && w->members.empty()) { *err = std::string("read error on ") + path; return KATGPU_ERR_IO; }   // no progress
+            break;
+        }
+        next.get();
+    }
+    if (getenv("KATGPU_TRACE")) fprintf(stderr, "[katgpu] ingest %s: %zu BGZF members by the team (%u threads)%s\n", path, n_members, T,
+                                        pos < size ? ", the rest through zlib" : "");
+    if (pos < size) {
+        // not a BGZF member here.  gzip magic: the rest goes through zlib from this offset (members are self-contained);
+        // anything else is trailing garbage, which zlib ignores after a complete member
+        uint8_t magic[2] = {0, 0};
+        if (pread(fd, magic, 2, pos) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            const int fd2 = ::open(path, O_RDONLY);
+            if (fd2 < 0 || lseek(fd2, (off_t)pos, SEEK_SET) < 0) { if (fd2 >= 0) ::close(fd2); *err = std::string("read error on ") + path; return KATGPU_ERR_IO; }
+            gzFile gz = gzdopen(fd2, "rb");
+            if (!gz) { ::close(fd2); *err = std::string("read error on ") + path; return KATGPU_ERR_IO; }
+            gzbuffer(gz, 1 << 20);
+            std::vector<uint8_t> raw((size_t)4 << 20);
+            int rc = KATGPU_OK;
+            for (;;) {
+                const int r = gzread(gz, raw.data(), (unsigned)raw.size());
+                if (r < 0) { *err = std::string("read error on ") + path; rc = KATGPU_ERR_IO; break; }
+                if (r == 0) break;
+                rc = feed(raw.data(), (size_t)r);
+                if (rc) break;
+            }
+            gzclose(gz);
+            if (rc) return rc;
+        }
+    }
+    if (!ps.end_ok()) { *err = "Invalid fastq sequence"; return KATGPU_ERR_FASTQ; }
+    return KATGPU_OK;
+}
+
 // ------------------------------------------------------------------ the input group ---------------------------------
 
 namespace {
@@ -474,9 +667,10 @@ int stream_group(const char* const* paths, size_t n_paths, const uint16_t* trim5
     size_t i = 0;
     while (i < n_paths) {
         const uint32_t trim = trim5p ? trim5p[i] : 0;
-        if (team_applies(paths[i], trim)) {
-            // a large plain file: the thread team (same bytes out as the streaming parser)
+        if (team_applies(paths[i], trim) || bgzf_applies(paths[i])) {
+            // a large plain file or a BGZF file: its thread team (same bytes out as the streaming parser)
             int rc = parse_file_parallel(paths[i], trim, sink, err);
+            if (rc < 0) rc = parse_bgzf_parallel(paths[i], trim, sink, err);
             if (rc > 0) return rc;
             if (rc < 0) { rc = stream_one(paths[i], trim, sink, err); if (rc) return rc; }    // it changed under us: stream it
             rc = sink(&sep, 1);
@@ -485,7 +679,7 @@ int stream_group(const char* const* paths, size_t n_paths, const uint16_t* trim5
             continue;
         }
         size_t j = i + 1;                                    // the run of streaming files that starts here
-        while (j < n_paths && !team_applies(paths[j], trim5p ? trim5p[j] : 0)) ++j;
+        while (j < n_paths && !team_applies(paths[j], trim5p ? trim5p[j] : 0) && !bgzf_applies(paths[j])) ++j;
         const unsigned readers = (unsigned)std::min<size_t>(max_readers, j - i);
         int rc;
         if (readers <= 1) {
@@ -509,7 +703,9 @@ extern "C" int katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** ba
     *bases = nullptr; *n = 0;
     std::vector<uint8_t> all;
     // large plain files: the thread team (same bytes out); everything else, and whatever the team declines: the streaming parser
-    int rc = kg::parse_file_parallel(path, trim5p, [&](const uint8_t* p, size_t got) { all.insert(all.end(), p, p + got); return 0; }, &last);
+    auto collect = [&](const uint8_t* p, size_t got) { all.insert(all.end(), p, p + got); return 0; };
+    int rc = kg::parse_file_parallel(path, trim5p, collect, &last);
+    if (rc < 0) rc = kg::parse_bgzf_parallel(path, trim5p, collect, &last);
     if (rc < 0) {
         all.clear();
         kg::SeqFileParser parser;

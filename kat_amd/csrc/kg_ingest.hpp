@@ -72,9 +72,18 @@ private:
 int parse_file_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err);
 bool team_applies(const char* path, uint32_t trim5p);      // would parse_file_parallel take this file?
 
+// BGZF files (bgzip: a gzip file made of independent members of <= 64 KB each, their compressed size in a 'BC' extra field):
+// the members are inflated by a thread team, a window of them at a time, straight into one buffer at offsets known from their
+// ISIZE trailers, and the inflated bytes go through the same state machine as the streaming parser -- so the output is
+// byte-identical to it, 5' trim included.  A member that is not BGZF (a plain gzip file appended, say) hands the rest of the
+// file to zlib from that offset; bytes that are not gzip at all end the input, as they do for zlib.  One ordinary gzip stream
+// cannot be cut this way and stays on the streaming path.  Returns a katgpu_status, or -1 when the file is not BGZF.
+int parse_bgzf_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err);
+bool bgzf_applies(const char* path);
+
 // One input group (InputHandler::count's file list) -> the base stream the counter consumes, handed to `sink` piece by piece.
 // Files never join (mer_overlap_sequence_parser.hpp:151-155), so the stream is a sequence of file pieces with an 'N' wherever
-// the source changes.  Large plain files go through the thread team above, one after the other.  Runs of files that have to
+// the source changes.  Large plain files and BGZF files go through their thread teams, one file after the other.  Runs of files that have to
 // stream (gzip, 5' trim, small) are read CONCURRENTLY, one reader thread per file (inflate is ~0.3 GB/s per stream, and paired
 // libraries come as two or more .gz files): the sink then sees the files' blocks interleaved, and every time the source
 // switches back to a file the stream carries 'N' followed by that file's previous k-1 bytes, so that each k-mer window of each

@@ -203,3 +203,116 @@ def test_group_errors_name_the_first_bad_file(tmp_path, monkeypatch):
                 kat_amd.parse_files([str(p) for p in order], 21)
             assert ei.value.code == code and text in ei.value.message, (n, order)
     assert kat_amd.parse_files([], 21).size == 0
+
+
+# ---------------------------------------------------------------- BGZF (kg_ingest.hpp: parse_bgzf_parallel) -------------
+
+def bgzf_bytes(data, rng, lo=1, hi=3000, eof=True):
+    """`data` as a BGZF file: independent gzip members of random sizes, each with the 'BC' extra field, then the empty EOF member."""
+    import struct
+    import zlib
+    out, i = [], 0
+    sizes = []
+    while i < len(data):
+        n = int(rng.integers(lo, hi + 1))
+        sizes.append(n)
+        chunk = data[i:i + n]
+        i += n
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+                   + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    if eof:
+        out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)
+
+
+@pytest.fixture
+def bgzf_env(monkeypatch):
+    monkeypatch.setenv("KATGPU_BGZF_MIN_BYTES", "0")
+    monkeypatch.setenv("KATGPU_BGZF_THREADS", "6")
+    monkeypatch.setenv("KATGPU_BGZF_WINDOW", str(1 << 17))            # the smallest window: many rounds even for these small files
+    monkeypatch.setenv("KATGPU_TRACE", "1")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_bgzf_files_match_the_streaming_parser(ko, tmp_path, bgzf_env, capfd, monkeypatch, seed):
+    """bgzip-style files go through the inflate team; the stream is the one zlib + the streaming parser produce (checked against
+    the oracle's parser on the same file, which reads it through zlib)."""
+    rng = np.random.default_rng(seed)
+    fa, fq, fqm = tmp_path / "a.fa", tmp_path / "a.fq", tmp_path / "am.fq"
+    write_messy_fasta(str(fa), rng, n_rec=200)
+    write_messy_fastq(str(fq), rng, n_rec=3000)
+    write_messy_fastq(str(fqm), rng, n_rec=1500, multiline=True)
+    for src in (fa, fq, fqm):
+        data = src.read_bytes()
+        for tag, lo, hi in (("small", 1, 300), ("big", 20000, 65280)):
+            z = tmp_path / (src.name + "." + tag + ".gz")
+            z.write_bytes(bgzf_bytes(data, rng, lo, hi))
+            assert gzip.decompress(z.read_bytes()) == data
+            capfd.readouterr()
+            got = stream_of(z)
+            assert "BGZF members by the team" in capfd.readouterr().err
+            assert got == ko.parse_file(str(z)).tobytes() == stream_of(src), (src, tag)
+    clean = tmp_path / "c.fa"
+    clean.write_bytes(b"".join(b">r%d\n%s\n" % (i, rng.choice(np.frombuffer(b"ACGT", np.uint8), 90).tobytes()) for i in range(3000)))
+    z = tmp_path / "c.fa.gz"
+    z.write_bytes(bgzf_bytes(clean.read_bytes(), rng, 100, 5000))
+    for trim in (0, 1, 7):
+        assert kat_amd.parse_file(str(z), trim).tobytes() == kat_amd.parse_file(str(clean), trim).tobytes()
+    monkeypatch.setenv("KATGPU_BGZF", "0")                          # switched off: same bytes through zlib
+    capfd.readouterr()
+    assert stream_of(z) == stream_of(clean)
+    assert "BGZF" not in capfd.readouterr().err
+
+
+def test_bgzf_edges_and_fallbacks(ko, tmp_path, bgzf_env, capfd):
+    rng = np.random.default_rng(9)
+    recs = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, rng.choice(np.frombuffer(b"ACGTN", np.uint8), 70).tobytes(), b"I" * 70) for i in range(2000))
+    plain = tmp_path / "p.fq"
+    plain.write_bytes(recs)
+    want = stream_of(plain)
+    # no EOF marker; only the EOF marker; EOF marker in the middle (two bgzip files concatenated)
+    z = tmp_path / "noeof.fq.gz"
+    z.write_bytes(bgzf_bytes(recs, rng, 50, 2000, eof=False))
+    assert stream_of(z) == want
+    z = tmp_path / "empty.fq.gz"
+    z.write_bytes(bgzf_bytes(b"", rng))
+    assert stream_of(z) == b"" == ko.parse_file(str(z)).tobytes()
+    half = recs.index(b"@r1000\n")
+    z = tmp_path / "cat.fq.gz"
+    z.write_bytes(bgzf_bytes(recs[:half], rng, 50, 2000) + bgzf_bytes(recs[half:], rng, 50, 2000))
+    assert stream_of(z) == want
+    # a plain gzip member appended: the rest goes through zlib from that offset; then garbage, which zlib ignores
+    z = tmp_path / "mixed.fq.gz"
+    z.write_bytes(bgzf_bytes(recs[:half], rng, 50, 2000, eof=False) + gzip.compress(recs[half:]) + b"trailing garbage")
+    capfd.readouterr()
+    assert stream_of(z) == want == ko.parse_file(str(z)).tobytes()
+    assert "the rest through zlib" in capfd.readouterr().err
+    z = tmp_path / "garbage.fq.gz"
+    z.write_bytes(bgzf_bytes(recs, rng, 50, 2000) + b"\x00\x01 not gzip at all")
+    assert stream_of(z) == want == ko.parse_file(str(z)).tobytes()
+    # damage: a flipped payload byte (CRC), a truncated last member
+    good = bgzf_bytes(recs, rng, 500, 2000)
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x55
+    z = tmp_path / "crc.fq.gz"
+    z.write_bytes(bytes(bad))
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        stream_of(z)
+    assert ei.value.code in (2, 4)                                   # read error (or, if the flip landed in a header, what zlib makes of the rest)
+    z = tmp_path / "trunc.fq.gz"
+    z.write_bytes(good[:len(good) - 40])
+    with pytest.raises(kat_amd.KatGpuError):
+        stream_of(z)
+    # a BGZF file that holds something else
+    z = tmp_path / "junk.gz"
+    z.write_bytes(bgzf_bytes(b"hello world\n" * 100, rng, 10, 100))
+    with pytest.raises(kat_amd.KatGpuError) as ei:
+        stream_of(z)
+    assert ei.value.code == 3 and ei.value.message == "Unsupported format"
+    # in a group with other files
+    paths = [str(plain), str(tmp_path / "cat.fq.gz"), str(tmp_path / "noeof.fq.gz")]
+    got = kat_amd.parse_files(paths, 21)
+    assert np.array_equal(ko.Table(21, True).count_bases(got).dump_sorted()[1], ko.Table(21, True).count_files(paths).dump_sorted()[1])
