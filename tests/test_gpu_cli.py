@@ -38,6 +38,15 @@ def test_hist_cli(ko, refdata, tmp_path):
     assert (tmp_path / "kat.hist").read_bytes() == (tmp_path / "want2").read_bytes()
 
 
+def test_hist_cli_survey_md5(refdata, tmp_path):
+    """The product's own `hist -m27` files for the reference's FASTA fixtures carry the body the reference binary wrote."""
+    from tests.test_oracle_known_answers import HIST_BODY_MD5, hist_body_md5
+    for name, want in HIST_BODY_MD5.items():
+        r = run(["hist", "-m27", "-o", name + ".hist", os.path.join(refdata, name)], tmp_path)
+        assert r.returncode == 0, r.stderr
+        assert hist_body_md5(str(tmp_path / (name + ".hist"))) == want, name
+
+
 def test_gcp_cli(ko, refdata, tmp_path):
     r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
     r = run(["gcp", "-m17", "-o", "temp/gcp_test", r1, r2], tmp_path)              # tests/test_gcp.sh

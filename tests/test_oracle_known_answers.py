@@ -67,6 +67,24 @@ def test_survey_known_answers_hist(ko, refdata):
     assert _rows(ko.Table(27, True).count_files([os.path.join(refdata, "sect_test.fa")]).hist()) == {1: 26}
 
 
+HIST_BODY_MD5 = {"sect_length_test.fa": "a915d3c7e7d24ef6de8e049b2f63fe46", "sect_test.fa": "411651418f41c1fb2b7e6f1955900ff4"}
+
+
+def hist_body_md5(path):
+    import hashlib
+    return hashlib.md5(b"".join(ln for ln in open(path, "rb").read().splitlines(True) if not ln.startswith(b"#"))).hexdigest()
+
+
+def test_survey_hist_file_bodies(ko, refdata, tmp_path):
+    """md5 of the non-'#' lines of the file `kat hist -m27` wrote for the reference's two FASTA fixtures (recorded by
+    the survey stage from a hand-built reference binary): pins count + Histogram::bin + the body Histogram::print writes."""
+    for name, want in HIST_BODY_MD5.items():
+        p = os.path.join(refdata, name)
+        out = str(tmp_path / (name + ".hist"))
+        ko.write_hist(out, 27, [p], 1, 10000, 1, ko.Table(27, True).count_files([p]).hist())
+        assert hist_body_md5(out) == want, name
+
+
 def test_survey_known_answers_gcp_comp(ko, refdata, tmp_path):
     r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
     g = ko.Table(17, True).count_files([r1, r2]).gcp()
