@@ -381,6 +381,25 @@ def test_count_files_group_read_concurrently(engine, ko, refdata, tmp_path, monk
         t.free()
 
 
+def test_count_files_bgzf(engine, ko, refdata, tmp_path, monkeypatch):
+    """A bgzip-style input goes through the inflate team (kg_ingest.hpp: parse_bgzf_parallel) on its way to the device table."""
+    from tests.test_ingest_parser import bgzf_bytes
+    monkeypatch.setenv("KATGPU_BGZF_MIN_BYTES", "0")
+    monkeypatch.setenv("KATGPU_BGZF_WINDOW", str(1 << 17))
+    rng = np.random.default_rng(3)
+    r1, r2 = os.path.join(refdata, "ecoli_r1.1K.fastq"), os.path.join(refdata, "ecoli_r2.1K.fastq")
+    z1, z2 = tmp_path / "r1.fq.gz", tmp_path / "r2.fq.gz"
+    z1.write_bytes(bgzf_bytes(open(r1, "rb").read(), rng, 100, 4000))
+    z2.write_bytes(bgzf_bytes(open(r2, "rb").read(), rng, 30000, 65280))
+    for k, canonical, trims in ((27, True, None), (40, False, [2, 0, 5])):
+        paths = [str(z1), r2, str(z2)]
+        t = engine.count(paths, k, canonical, trim5p=trims)
+        o = (ko.WideTable if k > 32 else ko.Table)(k, canonical).count_files([r1, r2, r2], trims)
+        for a, b in zip(t.dump_sorted(), o.dump_sorted()):
+            assert np.array_equal(a, b)
+        t.free()
+
+
 JF_REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "jf_ref")
 
 
