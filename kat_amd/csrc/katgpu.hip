@@ -483,7 +483,7 @@ static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
 
 static const uint64_t g_part_min_starts = getenv("KATGPU_PART_MIN_STARTS") ? strtoull(getenv("KATGPU_PART_MIN_STARTS"), nullptr, 10) : (32ULL << 20);
 static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? strtoull(getenv("KATGPU_TEST_ROUND_ITEMS"), nullptr, 10) : 0;
-// share of the free HBM the partition arena may take (multi-GPU runs leave room for the owner tables: bench.py sets 0.5)
+// share of the free HBM the partition arena may take (multi-GPU runs may lower it; bench.py sets 0.75 there)
 static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::min(0.95, std::max(0.05, atof(getenv("KATGPU_ARENA_FRACTION")))) : 0.85;
 static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10) : 3;   // 0 = first edition (1024-thread, 1 per CU)
 static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 0;   // 0: by region size
