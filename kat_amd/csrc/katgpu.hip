@@ -287,10 +287,10 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
     DevTable d{};
     const uint64_t like_r = (uint64_t)like_p1 * like_p2;
     // capacity is a whole number of regions (kg_device.hpp: Probe); a table smaller than one region is a single short region
-    if (like_r > 1 && (cap + like_r - 1) / like_r <= MAX_REGION_SLOTS) {
+    if (like_r > 1 && (cap + like_r - 1) / like_r <= MAX_REGION_SLOTS - 4) {
         d.p1 = like_p1; d.p2 = like_p2; d.n_regions = (uint32_t)like_r;
-        d.region_slots = (uint32_t)std::max<uint64_t>((cap + like_r - 1) / like_r, 16);
-    } else if (cap <= g_region_slots) { d.n_regions = d.p1 = d.p2 = 1; d.region_slots = (uint32_t)cap; }
+        d.region_slots = (uint32_t)((std::max<uint64_t>((cap + like_r - 1) / like_r, 16) + 3) & ~3ULL);   // whole 16-byte lines of keys and counts per region
+    } else if (cap <= g_region_slots) { d.n_regions = d.p1 = d.p2 = 1; d.region_slots = (uint32_t)((cap + 3) & ~3ULL); }
     else {
         const uint64_t nr = (cap + g_region_slots - 1) / g_region_slots;
         if (nr > 0x3FFFFFFFULL) return fail(c, KATGPU_ERR_NOMEM, "table of %llu slots exceeds the region index", (unsigned long long)cap);
@@ -486,6 +486,8 @@ static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? s
 // share of the free HBM the partition arena may take (multi-GPU runs may lower it; bench.py sets 0.75 there)
 static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::min(0.95, std::max(0.05, atof(getenv("KATGPU_ARENA_FRACTION")))) : 0.85;
 static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10) : 3;   // 0 = first edition (1024-thread, 1 per CU)
+static const uint32_t g_apply_v = getenv("KATGPU_APPLY_V") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_V"), nullptr, 10) : 2;   // 1: first-edition walk (A/B)
+static const uint32_t g_apply_unr = getenv("KATGPU_APPLY_UNR") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_UNR"), nullptr, 10) : 43;   // A/B: k-mers per lane x probe rounds
 static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 0;   // 0: by region size
 // level 2 without its histogram pass (kg_partition.hpp: k_p2_fast): 0 = never, 1 = when the mean run is long enough for the
 // capacity slack to cover the noise, 2 = always (tests).  KATGPU_TEST_P2_OVF_CAP shrinks the overflow list (tests: forces the
@@ -587,6 +589,14 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         c->part_attr_set = true;
     }
     // ---- arena: [hist1 | offs | l1_off | off2 | cnt2 | bend | chunk_cur | spill_n, ovf_n | L1 buffer | L2 buffer | overflow list] ----
@@ -763,9 +773,37 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             {
                 ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
                 // as many workgroups per CU as the regions' LDS footprint (and the 2048-thread limit) admits
+                const uint32_t blk = g_apply_block ? g_apply_block : (g.S <= 4096 ? 512 : 1024);
+                // second edition (batched walk, per-wave straggler queues behind the region in LDS) unless a test hook needs the first
+                const bool v2 = g_apply_v != 1 && !g_test_spill_mod && g.S % 4 == 0 && g.S >= 64 && g.S <= 8192 && (blk == 512 ? g.S <= 4096 : true);
+                if (v2) {
+                    const size_t lds2 = (size_t)g.S * 12 + (size_t)(blk / 64) * AP2_QCAP * 12;
+                    const uint32_t per_cu2 = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds2 + 512), 2048 / blk));
+                    const uint32_t grid2 = std::min<uint32_t>(g.R, W2 * per_cu2);
+#define KG_APPLY2(B, KP, U, NR) hipLaunchKernelGGL((k_p3_apply2<B, KP, U, NR>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end)
+                    if (blk == 512) { if (g.S <= 2048) KG_APPLY2(512, 2, 4, 3); else KG_APPLY2(512, 4, 4, 3); }
+                    else if (g_apply_unr == 82) KG_APPLY2(1024, 4, 8, 2);
+                    else if (g_apply_unr == 84) KG_APPLY2(1024, 4, 8, 4);
+                    else if (g_apply_unr == 83) KG_APPLY2(1024, 4, 8, 3);
+                    else if (g_apply_unr == 1043 || g_apply_unr == 1083) {      // cycle stamps of wave 0 (diagnostic; KATGPU_TRACE prints them)
+                        unsigned long long* d_st = nullptr;
+                        HIPCHK(c, hipMalloc((void**)&d_st, 64));
+                        HIPCHK(c, hipMemsetAsync(d_st, 0, 64, c->stream));
+                        if (g_apply_unr == 1043) hipLaunchKernelGGL((k_p3_apply2<1024, 4, 4, 3, true>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, d_st);
+                        else hipLaunchKernelGGL((k_p3_apply2<1024, 4, 8, 3, true>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, d_st);
+                        unsigned long long h[8];
+                        HIPCHK(c, hipMemcpyAsync(h, d_st, 56, hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        hipFree(d_st);
+                        const double n = (double)std::max<unsigned long long>(1, h[6]);
+                        fprintf(stderr, "[katgpu] apply2 stamps per region (cycles, wave 0): fill+sweep %.0f, loads+hash %.0f, rounds %.0f, queue %.0f, wait %.0f, write-back %.0f; %llu region visits, %llu items\n",
+                                h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6], (unsigned long long)items);
+                    }
+                    else KG_APPLY2(1024, 4, 4, 3);
+#undef KG_APPLY2
+                } else {
                 const size_t lds = (size_t)g.S * 12;
                 // small regions (a table created "like" a bigger one): 512-thread workgroups, four per CU instead of two
-                const uint32_t blk = g_apply_block ? g_apply_block : (g.S <= 4096 ? 512 : 1024);
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
 #define KG_APPLY(B, ...) hipLaunchKernelGGL((k_p3_apply<B, __VA_ARGS__>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
@@ -773,6 +811,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
                 else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) KG_APPLY(1024, 8); else KG_APPLY(1024, 12); }
 #undef KG_APPLY
+                }
             }
             HIPCHK(c, hipGetLastError());
             unsigned long long spilled = 0;

@@ -843,6 +843,256 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
     flush_distinct(t, new_distinct);
 }
 
+// ---- level 3, second edition: the walk as straight-line batches ----
+// k_p3_apply's walk is bound by dependent LDS round trips, not by LDS or VALU throughput (profiles/r01_partitioned_sq_counters.txt:
+// waves parked 67 % of their cycles, LDS array 15 % busy): every lane runs one probe chain at a time inside a divergent loop.
+// Here a wave takes U k-mers per lane and runs NR probe rounds over all of them in straight-line code: U independent
+// ds_read_b64 in flight per wave and one wait per round; a k-mer whose slot holds its key gets a NO-RETURN ds_add and is done.
+// What is left after NR rounds -- k-mers that met an EMPTY slot (a new key: needs the CAS claim) or a chain longer than NR --
+// goes to a small per-wave queue in LDS (key + slot + remaining probe budget), which the wave drains 64 entries at a time with
+// the dependent claim/add loop: dense, and only for the minority that needs it.  Waves never meet at a barrier inside a run.
+// No-return adds cannot report a 32-bit wrap, so none may happen: before a walk, counters >= 2^31 give 2^31 to the side table,
+// and a walk covers fewer than 2^31 k-mers (a longer run -- one region, one round, exact level 2 only -- is walked in segments).
+// Region fill and write-back move 16 bytes per lane and instruction (8- and 4-byte stores were store-issue-bound).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a native vector: stays in registers where HIP's uint4 struct went to scratch
+constexpr int AP2_QCAP = 256;                                 // straggler queue entries per wave (12 bytes each)
+constexpr int AP2_LANE_PROBES = 12;                           // probes a queue entry gets from its own lane before the wave takes it over
+constexpr uint64_t AP2_SEGMENT = 0x7FF00000ULL;               // k-mers per walk: < 2^31
+
+template <int BLOCK, int KP /* 16-byte key loads per lane that cover a region */, int U, int NR, bool STAMP = false>
+__global__ void __launch_bounds__(BLOCK)
+k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
+            uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n,
+            const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend, unsigned long long* __restrict__ stamps = nullptr) {
+    // STAMP: cycle stamps of wave 0 (tools/ab_apply.sh): [0] fill + sweep, [1] chunk loads + hash, [2] probe rounds, [3] queue push + drains,
+    // [4] wait for the other waves, [5] write-back, [6] regions
+    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return STAMP ? (unsigned long long)clock64() : 0ULL; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int NW = BLOCK / 64, CP = (KP + 1) / 2;
+    constexpr uint32_t CH = 64 * U;
+    const uint32_t S = g.S;                                   // S % 4 == 0 (host-checked): every region is 16-byte aligned in both arrays
+    unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
+    uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)S * 8);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long* wqk = reinterpret_cast<unsigned long long*>(lds_raw + (size_t)S * 12) + (size_t)wave * AP2_QCAP;
+    uint32_t* wqs = reinterpret_cast<uint32_t*>(lds_raw + (size_t)S * 12 + (size_t)NW * AP2_QCAP * 8) + (size_t)wave * AP2_QCAP;
+    uint32_t new_distinct = 0;
+    u32x4 kq[KP], cq[CP];
+
+    auto run_end = [&](uint32_t r) -> uint64_t {
+        if (bend && (r + 1) % g.P2 == 0) return bend[r / g.P2];
+        return off2[r + 1];
+    };
+    auto next_region = [&](uint32_t from) {
+        uint32_t r = from;
+        while (r < g.R && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
+        return r;
+    };
+    auto prefetch = [&](uint32_t r) {
+        const uint64_t base = (uint64_t)r * S;
+#pragma unroll
+        for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; kq[u] = *reinterpret_cast<const u32x4*>(t.keys + base + (i < S ? i : 0)); }    // clamped, unconditional: stays in registers
+#pragma unroll
+        for (int u = 0; u < CP; ++u) { const uint32_t i = (u * BLOCK + tid) * 4; cq[u] = *reinterpret_cast<const u32x4*>(t.counts + base + (i < S ? i : 0)); }
+    };
+
+    uint32_t r = next_region(blockIdx.x);
+    if (r < g.R) prefetch(r);
+    while (r < g.R) {
+        const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : run_end(r);
+        const uint64_t base = (uint64_t)r * S;
+        const unsigned long long t_top = now();
+        // ---- fill: registers -> LDS ----
+#pragma unroll
+        for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(rk + i) = kq[u]; }
+#pragma unroll
+        for (int u = 0; u < CP; ++u) { const uint32_t i = (u * BLOCK + tid) * 4; if (i < S) *reinterpret_cast<u32x4*>(rc + i) = cq[u]; }
+        const uint32_t rn = next_region(r + gridDim.x);
+
+        for (uint64_t sbeg = beg; sbeg < end; sbeg += AP2_SEGMENT) {        // one segment, normally
+            const uint64_t n_run = (end - sbeg < AP2_SEGMENT ? end - sbeg : AP2_SEGMENT);
+            lds_barrier();
+            // counters that could wrap during this walk hand 2^31 to the side table (each lane looks at the quads it filled)
+#pragma unroll 1
+            for (int u = 0; u < CP; ++u) {
+                const uint32_t i = (u * BLOCK + tid) * 4;
+                if (i >= S) break;
+                const u32x4 c = *reinterpret_cast<const u32x4*>(rc + i);
+                if (!((c.x | c.y | c.z | c.w) & 0x80000000u)) continue;
+#pragma unroll 1
+                for (uint32_t j = 0; j < 4; ++j)
+                    if (rc[i + j] & 0x80000000u) { rc[i + j] -= 0x80000000u; ovf_add(t, rk[i + j], 0x80000000ULL); }
+            }
+            lds_barrier();
+            st[0] += now() - t_top;
+
+            // ---- the walk ----
+            uint32_t q_n = 0;                                     // entries in this wave's queue (wave-uniform)
+            auto add1 = [&](uint32_t slot) { (void)__hip_atomic_fetch_add(&rc[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+            // One pass over up to 64 queue entries (taken from the tail).  Phase 1, one entry per lane: dependent probes with the
+            // claim, while at least 8 lanes are busy and for at most AP2_LANE_PROBES probes.  Phase 2: what is left is on a long
+            // chain (the longest of a region at load 0.6 runs to ~80 slots, and a lane walks it one LDS round trip per slot -- that
+            // lane made the whole workgroup wait at the barrier): the WAVE finishes such a k-mer, 64 consecutive slots per read.
+            auto drain_pass = [&](bool fin /* nothing will follow: leave no entry behind */) {
+                const uint32_t take = q_n < 64 ? q_n : 64;
+                q_n -= take;
+                bool live = lane < take;
+                unsigned long long key = EMPTY; uint32_t slot = 0, budget = 0;
+                if (live) { key = wqk[q_n + lane]; const uint32_t s = wqs[q_n + lane]; slot = s & 0xFFFF; budget = s >> 16; }
+#pragma unroll 1
+                for (int rr = 0; rr < AP2_LANE_PROBES; ++rr) {
+                    const int busy = __popcll(__ballot(live));
+                    if (busy == 0 || (busy < 8 && (fin || rr >= 4))) break;
+                    if (live) {
+                        unsigned long long c0 = rk[slot];
+                        if (c0 == EMPTY) {
+                            c0 = atomicCAS(&rk[slot], (unsigned long long)EMPTY, key);
+                            if (c0 == EMPTY) { ++new_distinct; c0 = key; }
+                        }
+                        if (c0 == key) { add1(slot); live = false; }
+                        else {
+                            slot = slot + 1 == S ? 0 : slot + 1;
+                            if (--budget == 0) { spill[atomicAdd(spill_n, 1ULL)] = key; live = false; }     // region full: direct path later
+                        }
+                    }
+                }
+                // the wave takes over what has had its AP2_LANE_PROBES (all that is left, when nothing follows); the rest goes back
+                const bool lng = live && (fin || S - budget >= (uint32_t)(AP2_LANE_PROBES + NR));
+                {
+                    const bool back = live && !lng;
+                    const unsigned long long m = __ballot(back);
+                    if (m) {
+                        const uint32_t at = q_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                        if (back) { wqk[at] = key; wqs[at] = slot | (budget << 16); }
+                        q_n += (uint32_t)__popcll(m);
+                    }
+                }
+                unsigned long long todo = __ballot(lng);
+#pragma unroll 1
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const unsigned long long ck = __shfl(key, src, 64);                      // wave-uniform from here on
+                    uint32_t cs = __shfl(slot, src, 64);
+                    int cb = (int)__shfl(budget, src, 64);
+#pragma unroll 1
+                    for (;;) {
+                        uint32_t idx = cs + lane; if (idx >= S) idx -= S;                      // S >= 64 on this path (host-checked)
+                        const unsigned long long c0 = rk[idx];
+                        const unsigned long long mk = __ballot(c0 == ck), me = __ballot(c0 == EMPTY);
+                        if (!(mk | me)) {                                                      // 64 foreign keys
+                            cb -= 64; cs = cs + 64 >= S ? cs + 64 - S : cs + 64;
+                            if (cb <= 0) { if (lane == 0) spill[atomicAdd(spill_n, 1ULL)] = ck; break; }
+                            continue;
+                        }
+                        const int first = __ffsll((long long)(mk | me)) - 1;
+                        if (first >= cb) { if (lane == 0) spill[atomicAdd(spill_n, 1ULL)] = ck; break; }   // beyond the region's last unprobed slot
+                        unsigned long long got = ck;                                           // what the slot holds after this step
+                        if (!((mk >> first) & 1)) {                                            // EMPTY comes first: claim it
+                            unsigned long long old = EMPTY;
+                            if ((int)lane == first) old = atomicCAS(&rk[idx], (unsigned long long)EMPTY, ck);
+                            old = __shfl(old, first, 64);
+                            if (old == EMPTY) { if ((int)lane == first) ++new_distinct; }
+                            else got = old;
+                        }
+                        if (got == ck) { if ((int)lane == first) add1(idx); break; }
+                        cb -= first; cs = cs + first >= S ? cs + first - S : cs + first;       // someone else's key landed there: go on from that slot
+                    }
+                }
+            };
+
+            const uint64_t n_chunks = (n_run + CH - 1) / CH;
+            unsigned long long cur[U], nxt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const uint64_t i = (uint64_t)wave * CH + (uint64_t)u * 64 + lane; cur[u] = i < n_run ? l2_buf[sbeg + i] : EMPTY; }
+            for (uint64_t c = wave; c < n_chunks; c += NW) {
+                const unsigned long long t_a = now();
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const uint64_t i = (c + NW) * CH + (uint64_t)u * 64 + lane; nxt[u] = i < n_run ? l2_buf[sbeg + i] : EMPTY; }   // next chunk: in flight behind this one
+                uint32_t slot[U];
+                bool pend[U];                                     // k-mer u still to be placed (lane masks in SGPRs)
+#pragma unroll
+                for (int u = 0; u < U; ++u) { slot[u] = offset_of_hash(mix64(cur[u]), S); pend[u] = cur[u] != EMPTY; }
+                const unsigned long long t_b = now();
+                // Probe rounds: U reads in flight, one wait; a match adds 1 and is done, a foreign key moves on, an EMPTY slot stays
+                // where it is -- the next round sees whoever claimed it, and what still faces EMPTY after the last round is a new
+                // key: its claim is the queue's business.  Lanes that are done take no part in the LDS operations.
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) {
+                    unsigned long long seen[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { seen[u] = EMPTY; if (pend[u]) seen[u] = rk[slot[u]]; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const bool hit = pend[u] && seen[u] == cur[u];
+                        if (hit) add1(slot[u]);
+                        pend[u] = pend[u] && !hit;
+                        const uint32_t nx = slot[u] + 1 == S ? 0 : slot[u] + 1;
+                        slot[u] = (pend[u] && seen[u] != EMPTY) ? nx : slot[u];
+                    }
+                }
+                if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
+                const unsigned long long t_c = now();
+                // survivors -> queue (q_n <= 64 here).  Normal case: one wave-wide prefix sum; a chunk with more survivors than the
+                // queue holds (a nearly empty table: every k-mer is new) goes in one k-mer column at a time.
+                uint32_t mine = 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) mine += pend[u] ? 1u : 0u;
+                uint32_t tot = mine;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(tot, d, 64); if (lane >= (uint32_t)d) tot += o; }
+                const uint32_t total = __shfl(tot, 63, 64);
+                if (total <= AP2_QCAP - 64) {
+                    uint32_t at = q_n + tot - mine;
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (pend[u]) { wqk[at] = cur[u]; wqs[at] = slot[u] | ((S - NR) << 16); ++at; }
+                    q_n += total;
+                } else {
+                    uint32_t pm = 0;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) pm |= pend[u] ? 1u << u : 0u;
+#pragma unroll 1
+                    for (int it = 0; it < U; ++it) {
+                        const bool p = pm & 1;
+                        const unsigned long long m = __ballot(p);
+                        if (m) {
+                            while (q_n > AP2_QCAP - 64) drain_pass(false);
+                            const uint32_t at = q_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                            if (p) { wqk[at] = cur[0]; wqs[at] = slot[0] | ((S - NR) << 16); }
+                            q_n += (uint32_t)__popcll(m);
+                        }
+                        pm >>= 1;
+#pragma unroll
+                        for (int u = 0; u + 1 < U; ++u) { cur[u] = cur[u + 1]; slot[u] = slot[u + 1]; }
+                    }
+                }
+                const bool last = c + NW >= n_chunks;                     // the wave's last chunk empties the queue
+                while (q_n > (last ? 0u : 64u)) drain_pass(last);
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+                if (STAMP) { const unsigned long long t_d = now(); st[1] += t_b - t_a; st[2] += t_c - t_b; st[3] += t_d - t_c; }
+            }
+        }
+        if (rn < g.R) prefetch(rn);                           // in flight behind the write-back
+        const unsigned long long t_w = now();
+
+        // ---- write-back: LDS -> HBM, 16 bytes per lane and store ----
+        lds_barrier();
+        const unsigned long long t_x = now();
+#pragma unroll
+        for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(t.keys + base + i) = *reinterpret_cast<const u32x4*>(rk + i); }
+#pragma unroll
+        for (int u = 0; u < CP; ++u) { const uint32_t i = (u * BLOCK + tid) * 4; if (i < S) *reinterpret_cast<u32x4*>(t.counts + base + i) = *reinterpret_cast<const u32x4*>(rc + i); }
+        lds_barrier();
+        if (STAMP) { st[4] += t_x - t_w; st[5] += now() - t_x; st[6] += 1; }
+        r = rn;
+    }
+    if (STAMP && tid == 0 && stamps) for (int i = 0; i < 7; ++i) atomicAdd(&stamps[i], st[i]);
+    flush_distinct(t, new_distinct);
+}
+
 // spilled k-mers (count 1 each) through the direct path.  Checked adds (table_add sees a 32-bit wrap itself): these lists
 // are short, and the unchecked table_inc would oblige the host to sweep the whole table first (katgpu.hip: maybe_sweep).
 __global__ void __launch_bounds__(256)
