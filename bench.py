@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's headline: k-mers/s for `kat comp` reads-vs-assembly, k=27 (configs[3]) on MI355X.
+"""bench.py -- BASELINE.json's headline: k-mers/s of the kat hist / gcp / comp hot path on MI355X.
 
 A step = one pass of the hot path over one synthetic batch already resident in HBM:
-    allocate tables -> count reads (K1) -> count assembly (K1) -> [N>1: owner-partitioned exchange + merge] ->
-    comp join/reduce (K5) -> D2H of the 8 MB matrix + counters.
-value = (valid k-mer instances of all inputs on all ranks) / (max-over-ranks wall time).  Host file parsing and
-PCIe are outside the timed region by contract (inputs resident); DESIGN.md quotes the PCIe-inclusive figure.
+    allocate tables -> count (partition rounds) -> [N>1: owner-partitioned exchange + merge] -> reduce on the device
+    (hist / gcp / comp) -> D2H of the result (80 KB / 216 KB / 8 MB + counters).
+value = (valid k-mer instances of all inputs on all ranks) / (max-over-ranks wall time).  Host file parsing and PCIe are
+outside the timed region by contract (inputs resident); the `end_to_end` object of the line times files -> output files
+through the C++ host binary on a bounded slice of the same workload (never `value`).
 
-  python bench.py                                  # N=1, full config: 300 M x 150 bp PE reads vs 1 Gbp assembly
-  python bench.py --reads 20000000 --genome 100000000          # scaled-down look
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N     # weak scaling: reads per GPU fixed
+Workloads (BASELINE.json configs[1..4]; --config N is an alias, N counted from 1 as SURVEY.md 8(d) does):
+  --workload comp      config 4 (default): kat comp, 300 M x 150 bp PE reads vs the 1 Gbp assembly, k = 27
+  --workload hist      config 2: kat hist, 50 M reads from a 100 Mbp genome, k = 27
+  --workload gcp       config 3: kat gcp, 100 M reads from a 200 Mbp genome, k = 27
+  --workload comp-rr   config 5: kat comp, reads library 1 vs reads library 2 (75 M + 75 M reads per GPU), k = 31
+
+  python bench.py                                   # N = 1, config 4 at full size
+  python bench.py --gpus 8                          # launches its own 8 ranks (torch.distributed.run, one per GPU, RCCL)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N      # the driver's form: the same thing
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -23,6 +33,17 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+REF_KMERS_PER_CORE = 3.0e6    # the reference's count phase per host core, measured by the survey (23-25 M k-mers/s on 8 cores)
+
+WORKLOADS = {
+    #           reads/GPU     genome         k   what
+    "comp":    (300_000_000, 1_000_000_000, 27, "kat comp reads-vs-assembly"),
+    "hist":    (50_000_000,  100_000_000,   27, "kat hist"),
+    "gcp":     (100_000_000, 200_000_000,   27, "kat gcp"),
+    "comp-rr": (150_000_000, 1_000_000_000, 31, "kat comp reads-vs-reads"),
+}
+CONFIG_ALIAS = {2: "hist", 3: "gcp", 4: "comp", 5: "comp-rr"}
+PROFILE_JSON = "profiles/r02_final_pmc_fetch_write.json"
 
 
 def parse_args():
@@ -30,19 +51,48 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=300_000_000, help="150 bp reads PER GPU (PE: reads/2 pairs)")
-    ap.add_argument("--genome", type=int, default=1_000_000_000, help="genome / assembly length in bp (shared by all ranks)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIG_ALIAS), help="BASELINE.json config number (1-based)")
+    ap.add_argument("--reads", type=int, default=None, help="150 bp reads PER GPU (PE: reads/2 pairs); default: the workload's")
+    ap.add_argument("--genome", type=int, default=None, help="genome / assembly length in bp (shared by all ranks)")
     ap.add_argument("--contig", type=int, default=1_000_000)
-    ap.add_argument("--k", type=int, default=27)
+    ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--err-ppm", type=int, default=2000, help="substitution errors per million bases (0.2 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the files -> output files leg")
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end slice (written as FASTQ to a temp dir)")
     ap.add_argument("--phases", action="store_true", help="sync + print per-phase wall time (diagnostic; perturbs the timing)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
+    ap.add_argument("--load", type=float, default=0.62, help="load factor the tables are pre-sized for (expected distinct k-mers / slots)")
     ap.add_argument("--hint-scale", type=float, default=1.0, help="diagnostic: scale the tables' size hints (e.g. 0.02: grown on the way)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: diagnostic only -- ranks may share one GPU, records are staged through host memory")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config is not None:
+        if a.workload is not None and a.workload != CONFIG_ALIAS[a.config]:
+            ap.error("--config %d is --workload %s" % (a.config, CONFIG_ALIAS[a.config]))
+        a.workload = CONFIG_ALIAS[a.config]
+    if a.workload is None:
+        a.workload = "comp"
+    reads, genome, k, _ = WORKLOADS[a.workload]
+    a.default_size = a.reads is None and a.genome is None and a.k is None
+    a.reads = reads if a.reads is None else a.reads
+    a.genome = genome if a.genome is None else a.genome
+    a.k = k if a.k is None else a.k
+    return a
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run --nproc-per-node N` of this script."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def expected_distinct(instances, genome, k, err_ppm):
@@ -57,35 +107,33 @@ def pmc_traffic(a, world):
     (tools/profile_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs with --kernel-trace; units KB; FETCH_SIZE doubled, as
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  The workload is seeded, so the traffic of a round is
     reproducible; counters cannot be collected from inside the timed run.  None when the workload is not the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_fetch_write.json")
-    if world != 1 or (a.reads, a.genome, a.contig, a.k, a.read_len, a.err_ppm) != (300_000_000, 1_000_000_000, 1_000_000, 27, 150, 2000):
+    path = os.path.join(ROOT, PROFILE_JSON)
+    if world != 1 or a.workload != "comp" or not a.default_size or (a.contig, a.read_len, a.err_ppm) != (1_000_000, 150, 2000):
         return None, None
     try:
         prof = json.load(open(path))
     except Exception:
         return None, None
-    stage = ("k_p1v2_count", "k_p1_scan", "k_p1v2_scatter", "k_p1v2_scatter_chunked", "k_p2", "k_p2_fast", "k_p3_apply", "k_insert_keys")
     kb, rounds = 0.0, 0
     for name, e in prof.items():
-        base = name.replace("kg::", "").split("<")[0]
-        if base in stage:
+        base = name.replace("kg::", "").replace("void ", "").split("<")[0].split("(")[0]
+        if base.startswith(("k_p1", "k_p2", "k_p3", "k_s1", "k_s2", "k_s3", "k_insert_keys")):
             kb += 2.0 * e.get("FETCH_SIZE_KB_total", 0.0) + e.get("WRITE_SIZE_KB_total", 0.0)
-            if base == "k_p3_apply":
+            if base.startswith(("k_p3_apply", "k_s3_apply")):
                 rounds += e.get("launches", 0)
     if not rounds:
         return None, None
-    return int(kb * 1024 / rounds), "profiles/r01_final_pmc_fetch_write.json: (2 x FETCH_SIZE + WRITE_SIZE) of the count-stage kernels / %d rounds" % rounds
+    return int(kb * 1024 / rounds), "%s: (2 x FETCH_SIZE + WRITE_SIZE) of the count-stage kernels / %d rounds" % (PROFILE_JSON, rounds)
 
 
 def main():
     a = parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-        a.gpus = world
+    a.gpus = world
 
     if world > 1:
         # the exchange keeps its send list and receive buffers inside the arena and allocates nothing else; leave room for the
@@ -115,32 +163,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    wl = a.workload
     k, L = a.k, a.read_len
-    n_reads = a.reads - (a.reads % 2)
+    two_tables = wl in ("comp", "comp-rr")
+    # ---- the files -> output files leg goes first: a child process that allocates right after this one has freed a hundred GB
+    # of HBM would spend seconds in the driver's scrubbing of that memory -- an artefact of benchmarking, not of the tool ----
+    e2e = None
+    if rank == 0 and world == 1 and not a.no_e2e:
+        try:
+            e2e = end_to_end(eng, a, k, L)
+        except Exception as ex:                            # the engine number stands on its own; say why the leg is missing
+            e2e = {"error": "%s: %s" % (type(ex).__name__, ex)}
     # ---- synthetic inputs, generated in HBM (not timed) ----
     g = eng.synth_genome(a.genome, seed=20260927)                               # genome the reads are sampled from
-    reads = eng.synth_reads(g, a.genome, first_read=rank * n_reads, n_reads=n_reads, read_len=L, frag_len=350,
-                            err_ppm=a.err_ppm, seed=1)
-    # assembly = that genome cut into contigs; contigs are sharded over ranks
-    n_contigs = (a.genome + a.contig - 1) // a.contig
-    c_lo, c_hi = kdist.shard_range(n_contigs, rank, world)
-    asm_full = eng.synth_genome(a.genome, seed=20260927, contig_len=a.contig)
-    asm_ptr = asm_full.ptr + c_lo * (a.contig + 1)
-    asm_bytes = min(asm_full.nbytes, c_hi * (a.contig + 1)) - c_lo * (a.contig + 1)
+    if wl == "comp-rr":                                                         # two read libraries, half of --reads each
+        n_reads = (a.reads // 2) & ~1
+        reads = eng.synth_reads(g, a.genome, first_read=rank * n_reads, n_reads=n_reads, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=1)
+        reads2 = eng.synth_reads(g, a.genome, first_read=rank * n_reads, n_reads=n_reads, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=2)
+        in2_ptr, in2_bytes = reads2.ptr, reads2.nbytes
+        inst_reads = n_reads * (L - k + 1)
+        inst2_local, inst2_total = inst_reads, world * inst_reads
+    else:
+        n_reads = a.reads & ~1
+        reads = eng.synth_reads(g, a.genome, first_read=rank * n_reads, n_reads=n_reads, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=1)
+        inst_reads = n_reads * (L - k + 1)
+        inst2_local = inst2_total = 0
+        in2_ptr = in2_bytes = 0
+    if wl == "comp":                                                            # assembly = that genome cut into contigs, sharded over ranks
+        n_contigs = (a.genome + a.contig - 1) // a.contig
+        c_lo, c_hi = kdist.shard_range(n_contigs, rank, world)
+        asm_full = eng.synth_genome(a.genome, seed=20260927, contig_len=a.contig)
+        in2_ptr = asm_full.ptr + c_lo * (a.contig + 1)
+        in2_bytes = min(asm_full.nbytes, c_hi * (a.contig + 1)) - c_lo * (a.contig + 1)
+        asm_bases_local = min(a.genome, c_hi * a.contig) - c_lo * a.contig
+        inst2_local = max(0, asm_bases_local - (c_hi - c_lo) * (k - 1))
+        inst2_total = max(0, a.genome - n_contigs * (k - 1))
     g.free()
     eng.sync()
 
-    inst_reads = n_reads * (L - k + 1)
-    asm_bases_local = min(a.genome, c_hi * a.contig) - c_lo * a.contig
-    inst_asm = max(0, asm_bases_local - (c_hi - c_lo) * (k - 1))
-    inst_asm_total = max(0, a.genome - n_contigs * (k - 1))
-    hint1 = int(expected_distinct(inst_reads, a.genome, k, a.err_ppm) / 0.62) + (1 << 20)
-    hint2 = int(asm_bases_local / 0.62) + (1 << 20)
+    hint1 = int(expected_distinct(inst_reads, a.genome, k, a.err_ppm) / a.load) + (1 << 20)
+    hint2 = 0
+    if wl == "comp":
+        hint2 = int(asm_bases_local / a.load) + (1 << 20)
+    elif wl == "comp-rr":
+        hint2 = hint1
     if a.hint_scale != 1.0:
         hint1, hint2 = max(1024, int(hint1 * a.hint_scale)), max(1024, int(hint2 * a.hint_scale))
 
     results = {}
-
     phases = {}
 
     def mark(name, t_prev):
@@ -151,34 +221,48 @@ def main():
             return now
         return t_prev
 
-    def step():
+    def exchange(t):
+        if k > 32:                                          # wide tables: owner partition -> all-to-all -> rebuild (not in place)
+            return kdist.exchange_merge_wide(kdist.HipWideShard(t, staged=staged)).table
+        kdist.exchange_merge(kdist.HipShard(t, staged=staged))  # in place: the table keeps its storage and its region grid
+        return t
+
+    def step(verify=False):
         tp = time.perf_counter()
         t1 = eng.table(k, True, size_hint=hint1)
         tp = mark("alloc1", tp)
         t1.count_bases_device(reads.ptr, reads.nbytes)
         tp = mark("count_reads", tp)
-        t2 = eng.table(k, True, size_hint=hint2, like=t1)
-        t2.count_bases_device(asm_ptr, asm_bytes)
-        tp = mark("alloc2+count_asm", tp)
+        t2 = None
+        if two_tables:
+            t2 = eng.table(k, True, size_hint=hint2, like=t1)
+            t2.count_bases_device(in2_ptr, in2_bytes)
+            tp = mark("alloc2+count_2", tp)
+        results["distinct1_local"] = t1.stats(want_total=False)["distinct"]
         if world > 1:
-            # in place: each table is extracted into a region-ordered send list, emptied, and refilled with the k-mers this
-            # rank owns (kat_amd/dist.py); t2 keeps t1's region grid, so comp still joins region against region
-            results["distinct1_local"] = t1.stats(want_total=False)["distinct"]
-            if k > 32:                                      # wide tables: owner partition -> all-to-all -> rebuild (not in place)
-                t1 = kdist.exchange_merge_wide(kdist.HipWideShard(t1, staged=staged)).table
-                t2 = kdist.exchange_merge_wide(kdist.HipWideShard(t2, staged=staged)).table
-            else:
-                kdist.exchange_merge(kdist.HipShard(t1, staged=staged))
-                kdist.exchange_merge(kdist.HipShard(t2, staged=staged))
+            t1 = exchange(t1)
+            if t2 is not None:
+                t2 = exchange(t2)
             tp = mark("exchange", tp)
-        mx, cc, sp = kat_amd.comp(t1, t2)
-        tp = mark("comp", tp)
+        if wl == "hist":
+            out = [t1.hist()]
+        elif wl == "gcp":
+            out = [t1.gcp()]
+        else:
+            out = list(kat_amd.comp(t1, t2))
+        tp = mark("reduce", tp)
         if world > 1:
-            mx, cc, sp = kdist.allreduce_u64([mx, cc, sp], dev)
-        results["mx"], results["cc"], results["sp"] = mx, cc, sp
-        results["distinct1"] = t1.stats(want_total=False)["distinct"]
+            out = kdist.allreduce_u64(out, dev)
+        results["out"] = out
+        st = t1.stats(want_total=verify)
+        results["distinct1"], results["cap1"] = st["distinct"], st["capacity"]
+        if verify:
+            results["total1"] = st["total"]
+        if t2 is not None:
+            st2 = t2.stats(want_total=False)
+            results["distinct2"], results["cap2"] = st2["distinct"], st2["capacity"]
+            t2.free()
         t1.free()
-        t2.free()
         tp = mark("free", tp)
 
     for _ in range(a.warmup):
@@ -192,20 +276,37 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile()
 
+    def allsum(v):
+        if world == 1:
+            return int(v)
+        t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        return int(t.item())
+
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        d1 = torch.tensor([results["distinct1"]], dtype=torch.int64, device=dev)
-        dist.all_reduce(d1)
-        results["distinct1"] = int(d1.item())
+    d1_local, cap1, cap2 = results["distinct1_local"], results["cap1"], results.get("cap2", 0)
+    distinct1, distinct2 = allsum(results["distinct1"]), allsum(results.get("distinct2", 0))
 
-    total_instances = world * inst_reads + inst_asm_total
+    total_instances = world * inst_reads + inst2_total
     value = total_instances * a.steps / dt
 
-    # ---- sanity: the counters must account for every instance (cheap size-independent parity property) ----
-    cc = results["cc"]
-    ok = int(cc[0]) == world * inst_reads and int(cc[1]) == inst_asm_total
+    # ---- sanity: the result must account for every instance / every distinct k-mer (size-independent parity properties) ----
+    out = results["out"]
+    if two_tables:
+        cc = out[1]
+        ok = int(cc[0]) == world * inst_reads and int(cc[1]) == inst2_total
+        what = "comp counters: hash1 total %d (expected %d), hash2 total %d (expected %d)" % (int(cc[0]), world * inst_reads, int(cc[1]), inst2_total)
+    else:
+        step(verify=True)                                   # once more, untimed, with the table's sum of counts
+        barrier()
+        tot = allsum(results["total1"])
+        cells = int(results["out"][0].sum())
+        # hist: every distinct k-mer lands in one bucket; gcp: in one cell, except the handful whose GC count is k -- the row the reference drops
+        ok = tot == world * inst_reads and (cells == distinct1 if wl == "hist" else cells <= distinct1 and cells >= distinct1 - 64)
+        what = "sum of counts %d (expected %d), result cells %d vs %d distinct" % (tot, world * inst_reads, cells, distinct1)
 
     if a.phases and rank == 0:
         print("phases (s, summed over steps):", {n: round(v, 3) for n, v in phases.items()}, file=sys.stderr)
@@ -214,16 +315,16 @@ def main():
         # algorithmic bytes: per instance L/(L-k+1) B of ASCII + 8 B key read + 4 B count read + 4 B count
         # write, plus 8 B key write per distinct k-mer; summed over this rank's count work of the timed steps.
         per_inst = L / (L - k + 1) + 16.0 + (8.0 if k > 32 else 0.0)               # k > 32: a second key word per slot
-        d1_local = results.get("distinct1_local", results["distinct1"])          # what THIS rank's count stage wrote
-        alg_bytes_step = per_inst * (inst_reads + inst_asm) + (16.0 if k > 32 else 8.0) * (d1_local + max(inst_asm, 0))
+        d2_local = results.get("distinct2", 0) if world == 1 else inst2_local      # upper bound on what the second count wrote
+        alg_bytes_step = per_inst * (inst_reads + inst2_local) + (16.0 if k > 32 else 8.0) * (d1_local + d2_local)
         stage = ["part_l1_count", "part_l1_scatter", "part_l2", "part_apply"]
         part_ms = sum(prof[n]["ms"] for n in stage)
         direct_ms = prof["count"]["ms"]
         if part_ms >= direct_ms:
-            # partitioned counter: one "launch" = one round = the four stage kernels over the round's k-mers
+            # partitioned counter: one "launch" = one round = the stage kernels over the round's k-mers
             rounds = max(1, prof["part_apply"]["launches"])
             stage_ms = part_ms + direct_ms
-            name = "count stage (partitioned): k_p1_count+k_p1_scan, k_p1_scatter, k_p2, k_p3_apply per round"
+            name = "count stage (partitioned): level-1 count+scan, level-1 scatter, level 2, apply per round"
             per_kernel = {n: {"launches": prof[n]["launches"], "avg_ms": round(prof[n]["ms"] / max(1, prof[n]["launches"]), 3)} for n in stage}
         else:
             rounds = max(1, prof["count"]["launches"])
@@ -236,23 +337,40 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": rounds, "avg_launch_ms": round(stage_ms / rounds, 3),
                 "alg_bytes_per_launch": int(alg_bytes_step * a.steps / rounds), "per_kernel": per_kernel}
+        # the reducers' own roofline (hist / gcp 12 B x C; comp 12 B x (C1 + C2) scan + 12 B x (D1 + D2) probes)
+        slot = 20.0 if k > 32 else 12.0
+        red = {}
+        if wl in ("hist", "gcp"):
+            ms = prof[wl]["ms"] / max(1, prof[wl]["launches"])
+            red["k_" + wl] = {"avg_ms": round(ms, 3), "alg_bytes": int(slot * cap1), "achieved_GBps": round(slot * cap1 / (ms / 1e3) / 1e9, 1) if ms else None}
+        else:
+            ms = (prof["comp_pass1"]["ms"] + prof["comp_pass2"]["ms"]) / max(1, prof["comp_pass1"]["launches"])
+            b = slot * (cap1 + cap2) + slot * (results["distinct1"] + results.get("distinct2", 0))
+            red["k_comp pass 1 + pass 2"] = {"avg_ms": round(ms, 3), "alg_bytes": int(b), "achieved_GBps": round(b / (ms / 1e3) / 1e9, 1) if ms else None}
+        for v in red.values():
+            v["frac"] = round(v["achieved_GBps"] / HBM_PEAK_GBPS, 4) if v["achieved_GBps"] else None
         kernels_ms = {n: round(v["ms"] / a.steps, 3) for n, v in prof.items() if v["launches"]}
         cpu = None
         if not a.no_cpu_baseline and world == 1 and k <= 32:      # the host-core baseline is an N = 1 figure (the multi-threaded oracle port is one-word)
             cpu = cpu_baseline(eng, a, k, L)
+        _, _, _, wl_name = WORKLOADS[wl]
+        if wl == "comp":
+            desc = "%s: %d x %d bp PE reads per GPU (0.2%% subst. errors) vs %d bp assembly in %d bp contigs, k=%d, canonical" % (wl_name, n_reads, L, a.genome, a.contig, k)
+        elif wl == "comp-rr":
+            desc = "%s: library 1 (%d reads per GPU) vs library 2 (%d reads per GPU), %d bp PE, 0.2%% subst. errors, %d bp genome, k=%d, canonical" % (wl_name, n_reads, n_reads, L, a.genome, k)
+        else:
+            desc = "%s: %d x %d bp PE reads per GPU (0.2%% subst. errors) from a %d bp genome, k=%d, canonical" % (wl_name, n_reads, L, a.genome, k)
         line = {
-            "metric": "k-mers/sec (whole node) for kat comp k=%d, reads vs assembly" % k,
+            "metric": "k-mers/sec (whole node) for %s k=%d" % (wl_name, k),
             "value": round(value, 1), "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "kat comp reads-vs-assembly: %d x %d bp PE reads per GPU (0.2%% subst. errors) vs %d bp assembly in %d bp contigs, k=%d, canonical"
-                                   % (n_reads, L, a.genome, a.contig, k),
-                       "reads_per_gpu": n_reads, "genome_bp": a.genome, "k": k,
-                       "parallelism": "reads sharded x%d, owner-partitioned merge" % world if world > 1 else "single GPU"},
-            "kmer_instances": total_instances, "distinct_reads_table": results["distinct1"],
-            "counters_account_for_all_instances": bool(ok),
+            "config": {"workload": desc, "reads_per_gpu": n_reads * (2 if wl == "comp-rr" else 1), "genome_bp": a.genome, "k": k,
+                       "parallelism": "reads sharded x%d, owner-partitioned merge over %s" % (world, "RCCL" if not staged else "gloo (staged, diagnostic)") if world > 1 else "single GPU"},
+            "kmer_instances": total_instances, "distinct_table1": distinct1, "distinct_table2": distinct2 if two_tables else None,
+            "result_accounts_for_every_kmer": bool(ok), "result_check": what,
             "kernel_ms_per_step": kernels_ms,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "reducers": red, "cpu_baseline": cpu, "end_to_end": e2e,
         }
         print(json.dumps(line))
     if world > 1:
@@ -260,31 +378,165 @@ def main():
         dist.destroy_process_group()
     eng.close()
     if not ok:
-        sys.exit("bench: comp counters do not account for every k-mer instance: %s" % list(map(int, cc)))
+        sys.exit("bench: the result does not account for every k-mer: %s" % what)
 
 
 def cpu_baseline(eng, a, k, L):
-    """The oracle (a C port of the reference algorithm, oracle/koracle.c) timed on this box's host cores over a BOUNDED
-    sample of the same workload: count sample reads + count a slice of the assembly (thread team over a shared CAS table,
-    like Jellyfish) + comp (T x compareSlice with private accumulators, merged under a lock, like KAT)."""
+    """The oracle (a C port of the reference algorithm, oracle/koracle.c) timed on this box's host cores over a BOUNDED sample of
+    the same workload: count sample reads (+ a slice of the second input) with a thread team over a shared CAS table, like
+    Jellyfish, then the workload's reducer (comp: T x compareSlice with private accumulators, merged under a lock, like KAT).
+    The thread count is swept (a shared CAS table stops scaling long before 256 threads) and the best is reported; next to it
+    `reference_scaled` = the reference's own measured per-core count rate x this box's cores."""
     from oracle import koracle as ko
-    threads = os.cpu_count() or 1
+    cores = os.cpu_count() or 1
+    wl = a.workload
     n = min(a.cpu_sample_reads, a.reads) & ~1
     gs = min(a.genome, 20_000_000)
     g = eng.synth_genome(gs, seed=77)
     r = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=3)
-    asm = eng.synth_genome(gs, seed=77, contig_len=100_000)
-    rh, ah = r.download(), asm.download()
-    for b in (g, r, asm):
+    rh = r.download()
+    second = None
+    inst = n * (L - k + 1)
+    if wl == "comp":
+        asm = eng.synth_genome(gs, seed=77, contig_len=100_000)
+        second = asm.download()
+        asm.free()
+        inst += max(0, gs - (gs // 100_000) * (k - 1))
+    elif wl == "comp-rr":
+        r2 = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=4)
+        second = r2.download()
+        r2.free()
+        inst += n * (L - k + 1)
+    for b in (g, r):
         b.free()
-    t0 = time.perf_counter()
-    t1 = ko.Table(k, True).count_bases(rh, threads=threads)
-    t2 = ko.Table(k, True).count_bases(ah, threads=threads)
-    ko.comp(t1, t2, threads=threads)
-    dt = time.perf_counter() - t0
-    inst = n * (L - k + 1) + max(0, gs - (gs // 100_000) * (k - 1))
-    return {"value": round(inst / dt, 1), "unit": "k-mers/s", "cores": threads, "kind": "port",
-            "sample": "%d reads x %d bp from a %d bp genome + that genome as assembly, k=%d; %.1f s" % (n, L, gs, k, dt)}
+
+    def run(threads):
+        t0 = time.perf_counter()
+        t1 = ko.Table(k, True).count_bases(rh, threads=threads)
+        if second is not None:
+            t2 = ko.Table(k, True).count_bases(second, threads=threads)
+            ko.comp(t1, t2, threads=threads)
+        elif wl == "hist":
+            t1.hist()
+        else:
+            t1.gcp()
+        return time.perf_counter() - t0
+
+    sweep = {}
+    for th in sorted({t for t in (8, 16, 32, 64, 128, 256, cores) if t <= cores}):
+        sweep[th] = run(th)
+        if sum(sweep.values()) > 40.0:                      # bounded: the default run stays within minutes
+            break
+    best = min(sweep, key=sweep.get)
+    return {"value": round(inst / sweep[best], 1), "unit": "k-mers/s", "cores": best, "kind": "port",
+            "sample": "%d reads x %d bp from a %d bp genome%s, k=%d; best of a thread sweep: %.2f s at %d threads" % (
+                n, L, gs, {"comp": " + that genome as assembly", "comp-rr": " + a second library of the same size"}.get(wl, ""), k, sweep[best], best),
+            "thread_sweep_kmers_per_s": {str(t): round(inst / s, 1) for t, s in sweep.items()},
+            "host_cores": cores,
+            "reference_scaled": {"value": REF_KMERS_PER_CORE * cores, "unit": "k-mers/s",
+                                 "source": "SURVEY.md section 6: the reference's count phase ran at ~3 M k-mers/s/core (8-core Xeon, hand-built reference binary); x %d host cores, assuming it scales linearly (it does not: an upper bound)" % cores}}
+
+
+def write_fastq(path, bases, first_read, mate, read_len):
+    """bases: uint8 [n, read_len].  4-line FASTQ with fixed-width headers (@r<9-digit pair>/<mate>), quality 'I'."""
+    n = bases.shape[0]
+    rec = np.empty((n, 2 * read_len + 18), np.uint8)
+    ids = np.arange(first_read, first_read + n, dtype=np.int64)
+    rec[:, 0] = ord("@")
+    rec[:, 1] = ord("r")
+    for d in range(9):
+        rec[:, 2 + d] = (ids // 10 ** (8 - d)) % 10 + ord("0")
+    rec[:, 11] = ord("/")
+    rec[:, 12] = ord("1") + mate
+    rec[:, 13] = ord("\n")
+    rec[:, 14:14 + read_len] = bases
+    p = 14 + read_len
+    rec[:, p] = ord("\n")
+    rec[:, p + 1] = ord("+")
+    rec[:, p + 2] = ord("\n")
+    rec[:, p + 3:p + 3 + read_len] = ord("I")
+    rec[:, p + 3 + read_len] = ord("\n")
+    with open(path, "wb") as f:
+        f.write(rec.tobytes())
+
+
+def end_to_end(eng, a, k, L):
+    """Files -> output files through the C++ host binary (kat_amd/bin/katgpu, the mirror of KAT's drivers over the C ABI) on a
+    bounded slice of the workload: the span of the reference's "Total runtime" (src/comp.cc:750; process start -> outputs
+    closed, no plots).  Inputs are written to a temp dir outside the timed span; the page cache is warm,
+    so this is parse + PCIe + count + reduce + write, not storage."""
+    exe = os.path.join(ROOT, "kat_amd", "bin", "katgpu")
+    if not os.path.exists(exe):
+        raise FileNotFoundError(exe)
+    wl = a.workload
+    n = min(a.e2e_reads, a.reads) & ~1
+    gs = min(a.genome, max(10_000_000, n * 5))                               # ~30x coverage of the slice's genome
+    tmp = tempfile.mkdtemp(prefix="katgpu_e2e_")
+    try:
+        g = eng.synth_genome(gs, seed=99)
+        files, inst, nbytes = [], 0, 0
+
+        def library(seed, tag):
+            r = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=seed)
+            h = r.download().reshape(n, L + 1)[:, :L]
+            r.free()
+            paths = []
+            for mate in (0, 1):
+                p = os.path.join(tmp, "%s_R%d.fastq" % (tag, mate + 1))
+                write_fastq(p, h[mate::2], 0, mate, L)
+                paths.append(p)
+            return paths
+        lib1 = library(5, "lib1")
+        inst += n * (L - k + 1)
+        second = None
+        if wl == "comp":
+            asm = eng.synth_genome(gs, seed=99).download()
+            second = os.path.join(tmp, "asm.fa")
+            with open(second, "wb") as f:
+                clen = 1_000_000
+                for c in range((gs + clen - 1) // clen):
+                    seq = asm[c * clen:(c + 1) * clen]
+                    f.write(b">contig%d\n" % c)
+                    pad = (-seq.size) % 80
+                    lines = np.concatenate([seq, np.full(pad, ord("\n"), np.uint8)]).reshape(-1, 80)
+                    body = np.concatenate([lines, np.full((lines.shape[0], 1), ord("\n"), np.uint8)], axis=1).tobytes()
+                    f.write(body.rstrip(b"\n") + b"\n")
+                    inst += max(0, seq.size - k + 1)
+        elif wl == "comp-rr":
+            second = " ".join(library(6, "lib2"))
+            inst += n * (L - k + 1)
+        g.free()
+        eng.sync()
+        eng.release_scratch()                               # the child process needs the device memory this one has parked
+        for root, _, fs in os.walk(tmp):
+            nbytes += sum(os.path.getsize(os.path.join(root, f)) for f in fs)
+        hint = int(expected_distinct(n * (L - k + 1), gs, k, a.err_ppm) / 0.62) + (1 << 20)
+        outp = os.path.join(tmp, "out")
+        tool = {"hist": "hist", "gcp": "gcp"}.get(wl, "comp")
+        cmd = [exe, tool, "-t", "16", "-m", str(k), "-H", str(hint), "-o", outp]
+        if second is not None:                              # comp: -I sizes the second hash (KAT's -H / -I)
+            cmd += ["-I", str(hint if wl == "comp-rr" else int(gs / 0.62) + (1 << 20))]
+        if second is not None:                              # comp takes one (quoted) argument per input group, hist / gcp a list of files
+            cmd += [" ".join(lib1), second]
+        else:
+            cmd += lib1
+        t0 = time.perf_counter()
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        dt = time.perf_counter() - t0
+        if pr.returncode != 0:
+            raise RuntimeError("katgpu %s exited %d: %s" % (tool, pr.returncode, (pr.stderr or pr.stdout)[-400:]))
+        outs = [f for f in os.listdir(tmp) if f.startswith("out")]
+        return {"value": round(inst / dt, 1), "unit": "k-mers/s", "seconds": round(dt, 3), "input_bytes": nbytes,
+                "input_GB_per_s": round(nbytes / dt / 1e9, 2), "kmer_instances": inst,
+                "span": "process start -> output files closed (src/comp.cc:750 'Total runtime'), inputs in the page cache",
+                "command": "katgpu %s -t 16 -m %d -H %d on %d reads x %d bp (2 FASTQ files%s)" % (
+                    tool, k, hint, n, L, {"comp": " + a %d bp FASTA assembly" % gs, "comp-rr": " + a second library"}.get(wl, "")),
+                "outputs": sorted(outs), "phases": [l.strip() for l in pr.stdout.splitlines() if "Time taken" in l or "Total runtime" in l][:8]}
+    finally:
+        for root, _, fs in os.walk(tmp, topdown=False):
+            for f in fs:
+                os.unlink(os.path.join(root, f))
+            os.rmdir(root)
 
 
 if __name__ == "__main__":

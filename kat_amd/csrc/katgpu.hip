@@ -7,12 +7,17 @@
 #include "kg_wide.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -34,11 +39,12 @@ struct katgpu_ctx {
     struct Pending { hipEvent_t a, b; int cls; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
-    // staging for file ingest: 2 pinned + 2 device buffers, allocated on first use
+    // staging for host / file ingest: 2 pinned buffers feed 2 device rings (allocated on first use, kept)
     uint8_t* pinned[2] = {nullptr, nullptr};
-    uint8_t* dev_stage[2] = {nullptr, nullptr};
-    hipEvent_t stage_free[2] = {nullptr, nullptr};   // kernel that read dev_stage[i] has finished
+    hipEvent_t pin_free[2] = {nullptr, nullptr};     // the H2D copy out of pinned[i] has finished
     size_t stage_bytes = 0;
+    uint8_t* ring[2] = {nullptr, nullptr};           // resident stretches of the base stream, counted like any device-resident input
+    size_t ring_bytes = 0;
     // Freed table arrays are parked here and handed out again to the next table of (nearly) the same size: on this
     // driver a hipMalloc of tens of GB right after a hipFree of that much stalls for seconds (VRAM scrubbing), which
     // would dominate a run that builds tables repeatedly.  Emptied by katgpu_shutdown or when an allocation fails.
@@ -139,8 +145,8 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
     for (auto e : c->event_pool) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (c->pinned[i]) hipHostFree(c->pinned[i]);
-        if (c->dev_stage[i]) hipFree(c->dev_stage[i]);
-        if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
+        if (c->ring[i]) hipFree(c->ring[i]);
+        if (c->pin_free[i]) hipEventDestroy(c->pin_free[i]);
     }
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream); hipStreamDestroy(c->copy_stream);
@@ -156,6 +162,8 @@ extern "C" int katgpu_release_scratch(katgpu_ctx* c) {
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
     if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+    for (int i = 0; i < 2; ++i) if (c->ring[i]) { hipFree(c->ring[i]); c->ring[i] = nullptr; }
+    c->ring_bytes = 0;
     c->arena_borrowed = false;
     return KATGPU_OK;
 }
@@ -168,11 +176,28 @@ extern "C" int katgpu_scratch_acquire(katgpu_ctx* c, size_t bytes, void** dev_pt
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->arena_bytes < bytes) {
-        if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
+        // the larger arena is tried BESIDE the old one first: the old one (sized to most of the free HBM) must survive a failure,
+        // or a caller that could have made do with it -- the exchange simply takes more chunks -- is left with nothing
         for (auto& b : c->pool) hipFree(b.p);
         c->pool.clear();
-        HIPCHK(c, hipMalloc((void**)&c->arena, bytes));
-        c->arena_bytes = bytes;
+        uint8_t* bigger = nullptr;
+        hipError_t e = hipMalloc((void**)&bigger, bytes);
+        if (e != hipSuccess && c->arena) {                       // no room for both: the old one goes, and comes back if that was not enough either
+            (void)hipGetLastError();
+            const size_t old_bytes = c->arena_bytes;
+            hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0;
+            e = hipMalloc((void**)&bigger, bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                if (hipMalloc((void**)&c->arena, old_bytes) == hipSuccess) c->arena_bytes = old_bytes; else (void)hipGetLastError();
+                return fail(c, KATGPU_ERR_NOMEM, "scratch of %zu bytes: %s (the arena keeps its %zu bytes)", bytes, hipGetErrorString(e), c->arena_bytes);
+            }
+        } else if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, KATGPU_ERR_NOMEM, "scratch of %zu bytes: %s", bytes, hipGetErrorString(e));
+        }
+        if (c->arena) hipFree(c->arena);
+        c->arena = bigger; c->arena_bytes = bytes;
     }
     c->arena_borrowed = true;
     *dev_ptr = c->arena;
@@ -287,7 +312,8 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
     DevTable d{};
     const uint64_t like_r = (uint64_t)like_p1 * like_p2;
     // capacity is a whole number of regions (kg_device.hpp: Probe); a table smaller than one region is a single short region
-    if (like_r > 1 && (cap + like_r - 1) / like_r <= MAX_REGION_SLOTS - 4) {
+    // (regions of fewer than 256 slots are not worth a common grid: the spread of the region loads would eat the table's fill limit)
+    if (like_r > 1 && (cap + like_r - 1) / like_r <= MAX_REGION_SLOTS - 4 && (cap + like_r - 1) / like_r >= 256) {
         d.p1 = like_p1; d.p2 = like_p2; d.n_regions = (uint32_t)like_r;
         d.region_slots = (uint32_t)((std::max<uint64_t>((cap + like_r - 1) / like_r, 16) + 3) & ~3ULL);   // whole 16-byte lines of keys and counts per region
     } else if (cap <= g_region_slots) { d.n_regions = d.p1 = d.p2 = 1; d.region_slots = (uint32_t)((cap + 3) & ~3ULL); }
@@ -405,15 +431,25 @@ static int regrow(katgpu_table* t, uint64_t new_cap) {
     free_dev_table(c, t->d);
     t->d = nd;
     ++t->n_regrows;
+    t->count_bound = 0xFFFFFFFFULL;           // full counts were folded back into the slots: the next unchecked launch sweeps first
+    t->unchecked_adds = 0;
     return refresh_counters(t);
 }
 
-// Make room for up to `incoming` new distinct k-mers (an upper bound: one per window start) at load <= 0.7.
+// The fill limit of the direct path.  A k-mer probes inside its region only, so it is the fullest REGION that must not run out
+// of slots: regions get Binomial(n, 1/R) k-mers, and small regions (a table created "like" a much bigger one) need more slack
+// than the 0.7 that suits regions of thousands of slots.
+static double load_limit(const DevTable& d) {
+    if (d.region_slots >= 1024 || d.n_regions == 1) return 0.7;
+    return std::max(0.25, 0.7 - 3.0 / std::sqrt((double)d.region_slots));
+}
+
+// Make room for up to `incoming` new distinct k-mers (an upper bound: one per window start) at load <= the fill limit.
 static int ensure_room(katgpu_table* t, uint64_t incoming) {
     int rc = refresh_counters(t);
     if (rc) return rc;
     const uint64_t need = t->distinct + incoming;
-    if ((double)need <= 0.7 * (double)t->d.cap) return KATGPU_OK;
+    if ((double)need <= load_limit(t->d) * (double)t->d.cap) return KATGPU_OK;
     if (t->disable_grow) return fail(t->ctx, KATGPU_ERR_TABLE_FULL, "Hash full");
     uint64_t new_cap = t->d.cap;
     while ((double)need > 0.5 * (double)new_cap) new_cap *= 2;
@@ -838,10 +874,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
 
 // Count a resident base stream.  The stream is cut into sub-batches so that "distinct + sub-batch starts" stays under
 // the load limit (the table can then never fill in the middle of a launch); consecutive sub-batches overlap by k-1.
-extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
-    if (!t || (!dev_bases && n)) return KATGPU_ERR_INVALID_ARG;
+static int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
     katgpu_ctx* c = t->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
     const uint32_t k = t->d.k;
     if (n < k) return KATGPU_OK;
     size_t pos = 0;
@@ -859,7 +893,7 @@ extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bas
         int rc = refresh_counters(t);
         if (rc) return rc;
         // largest batch that provably fits; if even a minimal one does not, grow first
-        uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
+        uint64_t room = (uint64_t)(load_limit(t->d) * (double)t->d.cap) > t->distinct ? (uint64_t)(load_limit(t->d) * (double)t->d.cap) - t->distinct : 0;
         uint64_t want = std::min<uint64_t>(n_starts - pos, (uint64_t)CHUNK_STARTS * 65536);   // <= 266 M starts per launch
         if (g_test_max_starts) want = std::min<uint64_t>(want, g_test_max_starts);
         // As the table fills, launches shrink to the remaining room (each adds far fewer distinct k-mers than window
@@ -879,70 +913,162 @@ extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bas
     return refresh_counters(t);
 }
 
+extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
+    if (!t || (!dev_bases && n)) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(t->ctx, hipSetDevice(t->ctx->device));
+    return count_resident(t, dev_bases, n);
+}
+
+// KATGPU_RING_MB: size of each of the two device rings the host feeder fills (default 1024)
+static const size_t g_ring_bytes = (getenv("KATGPU_RING_MB") ? std::max<size_t>(1, strtoull(getenv("KATGPU_RING_MB"), nullptr, 10)) : 1024) << 20;
+
 static int ensure_staging(katgpu_ctx* c) {
-    if (c->stage_bytes) return KATGPU_OK;
-    const size_t bytes = (size_t)64 << 20;
-    for (int i = 0; i < 2; ++i) {
-        HIPCHK(c, hipHostMalloc((void**)&c->pinned[i], bytes, hipHostMallocDefault));
-        HIPCHK(c, hipMalloc((void**)&c->dev_stage[i], bytes));
-        HIPCHK(c, hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming));
+    if (!c->stage_bytes) {
+        const size_t bytes = (size_t)64 << 20;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(c, hipHostMalloc((void**)&c->pinned[i], bytes, hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&c->pin_free[i], hipEventDisableTiming));
+        }
+        c->stage_bytes = bytes;
     }
-    c->stage_bytes = bytes;
+    if (!c->ring_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipMalloc((void**)&c->ring[i], g_ring_bytes);
+            if (e != hipSuccess && c->arena && !c->arena_borrowed && !c->arena_busy) {       // the cached arena holds most of the free HBM: give it back
+                (void)hipGetLastError();
+                hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0;
+                e = hipMalloc((void**)&c->ring[i], g_ring_bytes);
+            }
+            if (e != hipSuccess) { for (int j = 0; j < i; ++j) { hipFree(c->ring[j]); c->ring[j] = nullptr; } HIPCHK(c, e); }
+        }
+        c->ring_bytes = g_ring_bytes;
+    }
     return KATGPU_OK;
 }
 
-// Host base stream -> device, double buffered: while the kernel of batch i runs, batch i+1 is copied.
-// Each staged batch starts with the previous batch's last k-1 bytes so windows across the cut are counted once.
+// Host base stream -> table.  The stream is copied through two pinned buffers (64 MiB each) into one of two DEVICE RINGS; a full
+// ring is a resident stretch of the stream and goes to count_resident -- the partitioned counter for anything of size, exactly
+// what a caller with device-resident input gets -- on a worker thread, while the feeder (and the parser team behind it) fills
+// the other ring.  A ring starts with the previous ring's last k-1 bytes, so windows across the cut are counted once.
 struct HostFeeder {
-    katgpu_table* t; katgpu_ctx* c; int cur = 0; size_t fill = 0; bool used[2] = {false, false};
-    static constexpr size_t HEAD = 64;        // carry area (k - 1 <= 62 bytes): keeps the payload 16-byte aligned
+    katgpu_table* t; katgpu_ctx* c;
+    int cur = 0; size_t fill = 0; bool pin_used[2] = {false, false};
+    int ring_cur = 0; size_t ring_fill = 0;
+    uint8_t tail[64]; uint32_t tail_n = 0;          // last k-1 bytes of the stream so far
+    static constexpr size_t HEAD = 64;               // carry area (k - 1 <= 62 bytes) in front of a ring's payload: keeps it 16-byte aligned
+    // worker
+    std::thread worker;
+    std::mutex mu; std::condition_variable cv;
+    struct Job { int ring; size_t n; };
+    std::deque<Job> jobs;
+    bool ring_busy[2] = {false, false};
+    bool stop = false;
+    int worker_rc = KATGPU_OK; std::string worker_err;
+
     explicit HostFeeder(katgpu_table* t_) : t(t_), c(t_->ctx) {}
+    ~HostFeeder() { shutdown(); }
+
+    void run() {
+        hipSetDevice(c->device);
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;
+                j = jobs.front(); jobs.pop_front();
+            }
+            int rc = worker_rc ? worker_rc : count_resident(t, c->ring[j.ring], j.n);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc && !worker_rc) { worker_rc = rc; worker_err = c->err; }
+                ring_busy[j.ring] = false;
+            }
+            cv.notify_all();
+        }
+    }
+    void shutdown() {
+        if (!worker.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        worker.join();
+    }
     int begin() {
         int rc = ensure_staging(c); if (rc) return rc;
-        return open_buffer();
+        tail_n = 0;
+        worker = std::thread([this] { run(); });
+        return open_ring();
     }
-    int open_buffer() {
-        if (used[cur]) { hipError_t e = hipEventSynchronize(c->stage_free[cur]); if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e)); }
-        memset(c->pinned[cur], 'N', HEAD);
-        memcpy(c->pinned[cur] + HEAD - t->carry_n, t->carry, t->carry_n);
-        fill = HEAD;
+    int open_ring() {                                 // ring_cur is free: seed its head with the carry
+        uint8_t head[HEAD];
+        memset(head, 'N', HEAD);
+        memcpy(head + HEAD - tail_n, tail, tail_n);
+        HIPCHK(c, hipMemcpyAsync(c->ring[ring_cur], head, HEAD, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));          // `head` is on this stack
+        ring_fill = HEAD;
         return KATGPU_OK;
+    }
+    int submit_ring() {                               // hand the current ring to the worker, move on to the other one
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));          // every copy into it has landed
+        const int other = ring_cur ^ 1;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (ring_fill > HEAD) { ring_busy[ring_cur] = true; jobs.push_back({ring_cur, ring_fill}); }
+            cv.notify_all();
+            cv.wait(lk, [&] { return !ring_busy[other]; });
+            if (worker_rc) return fail(c, worker_rc, "%s", worker_err.c_str());
+        }
+        if (ring_fill > HEAD) ring_cur = other;
+        return open_ring();
     }
     int push(const uint8_t* p, size_t n) {
         while (n) {
-            size_t room = c->stage_bytes - fill, take = std::min(room, n);
+            if (fill == 0 && pin_used[cur]) { hipError_t e = hipEventSynchronize(c->pin_free[cur]); if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e)); }
+            const size_t room = c->stage_bytes - fill, take = std::min(room, n);
             memcpy(c->pinned[cur] + fill, p, take);
             fill += take; p += take; n -= take;
             if (fill == c->stage_bytes) { int rc = flush(); if (rc) return rc; }
         }
         return KATGPU_OK;
     }
-    int flush() {
-        if (fill <= HEAD) return KATGPU_OK;
-        const uint32_t k = t->d.k;
-        const size_t payload = fill - HEAD;
-        // remember the tail for the next batch
-        uint8_t tail[64]; uint32_t tn = (uint32_t)std::min<size_t>(k - 1, payload + t->carry_n);
-        memcpy(tail, c->pinned[cur] + fill - tn, tn);
-        int rc = ensure_room(t, fill);
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->dev_stage[cur], c->pinned[cur], fill, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(c, hipEventRecord(c->ev0, c->copy_stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev0, 0));
-        rc = launch_count(t, c->dev_stage[cur], fill);
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->stage_free[cur], c->stream));
-        used[cur] = true;
-        memcpy(t->carry, tail, tn); t->carry_n = tn;
-        cur ^= 1;
-        return open_buffer();
+    int flush() {                                     // pinned[cur][0, fill) -> the current ring (asynchronously)
+        if (!fill) return KATGPU_OK;
+        const uint32_t want = t->d.k - 1;
+        size_t off = 0;
+        while (off < fill) {
+            if (ring_fill == c->ring_bytes) { int rc = submit_ring(); if (rc) return rc; }      // its head = `tail`, the k-1 bytes before `off`
+            const size_t take = std::min(fill - off, c->ring_bytes - ring_fill);
+            const uint8_t* src = c->pinned[cur] + off;
+            HIPCHK(c, hipMemcpyAsync(c->ring[ring_cur] + ring_fill, src, take, hipMemcpyHostToDevice, c->copy_stream));
+            ring_fill += take; off += take;
+            // the last k-1 bytes of the stream that is in the rings so far
+            if (take >= want) { memcpy(tail, src + take - want, want); tail_n = want; }
+            else {
+                uint8_t tmp[128]; const uint32_t keep = (uint32_t)std::min<size_t>(tail_n, want - take);
+                memcpy(tmp, tail + tail_n - keep, keep); memcpy(tmp + keep, src, take);
+                tail_n = keep + (uint32_t)take; memcpy(tail, tmp, tail_n);
+            }
+        }
+        HIPCHK(c, hipEventRecord(c->pin_free[cur], c->copy_stream));
+        pin_used[cur] = true;
+        cur ^= 1; fill = 0;
+        return KATGPU_OK;
     }
     int end_of_file() {             // files of a group never join (mer_overlap_sequence_parser.hpp:151-155: have_seam = false)
         static const uint8_t sep = 'N';
         return push(&sep, 1);
     }
     int finish() {
-        int rc = flush(); if (rc) return rc;
+        int rc = flush(); if (rc) { shutdown(); return rc; }
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (ring_fill > HEAD) { ring_busy[ring_cur] = true; jobs.push_back({ring_cur, ring_fill}); }
+            cv.notify_all();
+            cv.wait(lk, [&] { return !ring_busy[0] && !ring_busy[1] && jobs.empty(); });
+        }
+        shutdown();
+        if (worker_rc) return fail(c, worker_rc, "%s", worker_err.c_str());
         t->carry_n = 0;
         return refresh_counters(t);
     }
@@ -1166,7 +1292,7 @@ extern "C" int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_ke
     size_t pos = 0;
     while (pos < n) {
         int rc = refresh_counters(t); if (rc) return rc;
-        uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
+        uint64_t room = (uint64_t)(load_limit(t->d) * (double)t->d.cap) > t->distinct ? (uint64_t)(load_limit(t->d) * (double)t->d.cap) - t->distinct : 0;
         uint64_t want = n - pos;
         if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
             rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
@@ -1255,7 +1381,7 @@ extern "C" int katgpu_table_merge_device_wide(katgpu_table* t, const uint64_t* d
     size_t pos = 0;
     while (pos < n) {
         int rc = refresh_counters(t); if (rc) return rc;
-        const uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
+        const uint64_t room = (uint64_t)(load_limit(t->d) * (double)t->d.cap) > t->distinct ? (uint64_t)(load_limit(t->d) * (double)t->d.cap) - t->distinct : 0;
         const uint64_t want = n - pos;
         if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
             rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
@@ -1417,7 +1543,7 @@ static int merge_direct32(katgpu_table* t, const uint64_t* dev_keys, const uint3
     size_t pos = 0;
     while (pos < n) {
         int rc = refresh_counters(t); if (rc) return rc;
-        uint64_t room = (uint64_t)(0.7 * (double)t->d.cap) > t->distinct ? (uint64_t)(0.7 * (double)t->d.cap) - t->distinct : 0;
+        uint64_t room = (uint64_t)(load_limit(t->d) * (double)t->d.cap) > t->distinct ? (uint64_t)(load_limit(t->d) * (double)t->d.cap) - t->distinct : 0;
         uint64_t want = n - pos;
         if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
             rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
@@ -1550,7 +1676,7 @@ extern "C" int katgpu_hist(katgpu_table* t, uint64_t base, uint64_t ceil_, uint6
     const uint32_t lds_bins = (uint32_t)std::min<uint64_t>(nb, 16384);          // 64 KB of u32 -> two blocks per CU
     {
         ScopedTimer tm(c, KATGPU_K_HIST, t->d.cap);
-        hipLaunchKernelGGL(k_hist, dim3(reducer_grid(c, t->d.cap, 2)), dim3(256), lds_bins * sizeof(uint32_t), c->stream,
+        hipLaunchKernelGGL(k_hist, dim3(grid_for(c, t->d.cap / 4, SCAN_BLOCK, 2)), dim3(SCAN_BLOCK), lds_bins * sizeof(uint32_t), c->stream,
                            t->d, t->n_ovf, base, ceil_, inc, (uint64_t)nb, d, lds_bins);
     }
     hipMemcpyAsync(out, d, nb * 8, hipMemcpyDeviceToHost, c->stream);
@@ -1576,10 +1702,10 @@ extern "C" int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, 
     {
         ScopedTimer tm(c, KATGPU_K_GCP, t->d.cap);
         if (t->d.keys_b)
-            hipLaunchKernelGGL(k_gcp<true>, dim3(reducer_grid(c, t->d.cap, use_lds ? 1 : 8)), dim3(256), use_lds ? lds : 0, c->stream,
+            hipLaunchKernelGGL(k_gcp<true>, dim3(grid_for(c, t->d.cap / 4, SCAN_BLOCK, use_lds && lds > 75 * 1024 ? 1 : 2)), dim3(SCAN_BLOCK), use_lds ? lds : 0, c->stream,
                                t->d, t->n_ovf, cvg_scale, cvg_bins, d, use_lds);
         else
-            hipLaunchKernelGGL(k_gcp<false>, dim3(reducer_grid(c, t->d.cap, use_lds ? 1 : 8)), dim3(256), use_lds ? lds : 0, c->stream,
+            hipLaunchKernelGGL(k_gcp<false>, dim3(grid_for(c, t->d.cap / 4, SCAN_BLOCK, use_lds && lds > 75 * 1024 ? 1 : 2)), dim3(SCAN_BLOCK), use_lds ? lds : 0, c->stream,
                                t->d, t->n_ovf, cvg_scale, cvg_bins, d, use_lds);
     }
     HIPCHK(c, hipGetLastError());

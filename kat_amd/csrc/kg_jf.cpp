@@ -49,10 +49,33 @@ bool json_string(const std::string& js, const char* key, std::string* out) {
     if (!json_find(js, key, &p)) return false;
     while (p < js.size() && isspace((unsigned char)js[p])) ++p;
     if (p >= js.size() || js[p] != '"') return false;
-    size_t e = js.find('"', p + 1);
-    if (e == std::string::npos) return false;
-    *out = js.substr(p + 1, e - p - 1);
-    return true;
+    std::string v;                                               // up to the closing quote; escapes (jsoncpp writes \" \\ \n ... \uXXXX) undone
+    for (size_t i = p + 1; i < js.size(); ++i) {
+        const char ch = js[i];
+        if (ch == '"') { *out = v; return true; }
+        if (ch != '\\' || i + 1 >= js.size()) { v += ch; continue; }
+        const char e = js[++i];
+        switch (e) {
+            case 'n': v += '\n'; break; case 't': v += '\t'; break; case 'r': v += '\r'; break;
+            case 'b': v += '\b'; break; case 'f': v += '\f'; break;
+            case 'u': if (i + 4 < js.size()) { v += (char)strtoul(js.substr(i + 1, 4).c_str(), nullptr, 16); i += 4; } break;
+            default: v += e;                                     // \" \\ \/
+        }
+    }
+    return false;
+}
+// a string value as Json::FastWriter emits it (the reference writes its header through jsoncpp, which escapes)
+std::string json_quote(const std::string& v) {
+    std::string o = "\"";
+    for (const unsigned char ch : v) {
+        switch (ch) {
+            case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\n': o += "\\n"; break; case '\t': o += "\\t"; break;
+            case '\r': o += "\\r"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break;
+            default:
+                if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04X", ch); o += b; } else o += (char)ch;
+        }
+    }
+    return o + "\"";
 }
 bool json_bool(const std::string& js, const char* key, bool def) {
     size_t p;
@@ -130,10 +153,10 @@ static int write_records(const char* path, uint32_t k, int canonical, const uint
     std::string js = "{\"alignment\":8,\"canonical\":";
     js += canonical ? "true" : "false";
     js += ",\"cmdline\":[\"katgpu\"],\"counter_len\":" + std::to_string(counter_len);
-    js += ",\"exe_path\":\"katgpu\",\"format\":\"binary/sorted\",\"hostname\":\"" + std::string(host) + "\"";
+    js += ",\"exe_path\":\"katgpu\",\"format\":\"binary/sorted\",\"hostname\":" + json_quote(host);
     js += ",\"key_len\":" + std::to_string(key_len) + ",\"matrix1\":{\"c\":" + std::to_string(key_len) + ",\"columns\":[";
     for (unsigned i = 0; i < key_len; ++i) { if (i) js += ','; js += std::to_string(cols[i]); }
-    js += "],\"r\":" + std::to_string(r) + "},\"max_reprobe\":126,\"pwd\":\"" + std::string(cwd) + "\",\"reprobes\":[1";
+    js += "],\"r\":" + std::to_string(r) + "},\"max_reprobe\":126,\"pwd\":" + json_quote(cwd) + ",\"reprobes\":[1";
     for (unsigned i = 1; i <= 126; ++i) js += "," + std::to_string((uint64_t)i * (i + 1) / 2);      // JF/lib/storage.cc:20-50
     js += "],\"size\":" + std::to_string(size) + ",\"time\":\"" + when + "\",\"val_len\":7}";
     size_t hlen = js.size();

@@ -175,27 +175,55 @@ __device__ __forceinline__ void lds_inc_aggregated(uint32_t* bins, uint32_t idx,
 
 // K3.  Histogram::binSlice (src/histogram.cc:183-199).  The first lds_bins buckets live in LDS (u32, flushed once
 // per block); anything above goes straight to the global u64 array.
-__global__ void __launch_bounds__(256)
+// Slot scan of the reducers: four consecutive slots per lane and step, as 16-byte loads (two for the keys, one for the counts;
+// cap is a multiple of 4 and both arrays are 256-byte aligned), 1024-thread workgroups so that the one or two workgroups a CU can
+// hold next to their LDS-privatised result still put 16-32 waves on it.  (The first edition read 8 + 4 bytes per lane from 256-thread
+// workgroups, one or two per CU: 0.8-1.5 TB/s.)
+constexpr int SCAN_BLOCK = 1024;
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+struct Slots4 { uint64_t key[4]; uint32_t cnt[4]; };
+// (the loads are unconditional, from a clamped address, and the lanes beyond the range are masked afterwards: loads issued inside
+// a branch make hipcc wait for them at the end of the branch, which turns every prefetch into a stall)
+__device__ __forceinline__ Slots4 load_slots4(const DevTable& t, uint64_t i4 /* first slot, multiple of 4 */, bool in_range) {
+    Slots4 r;
+    const uint64_t at = in_range ? i4 : 0;
+    const u64x2 a = *reinterpret_cast<const u64x2*>(t.keys + at), b = *reinterpret_cast<const u64x2*>(t.keys + at + 2);
+    const u32x4s c = *reinterpret_cast<const u32x4s*>(t.counts + at);
+    r.key[0] = in_range ? a.x : EMPTY; r.key[1] = in_range ? a.y : EMPTY; r.key[2] = in_range ? b.x : EMPTY; r.key[3] = in_range ? b.y : EMPTY;
+    r.cnt[0] = c.x; r.cnt[1] = c.y; r.cnt[2] = c.z; r.cnt[3] = c.w;
+    return r;
+}
+__device__ __forceinline__ uint64_t slot_count4(const DevTable& t, uint64_t pos, uint64_t key, uint32_t cnt, uint32_t n_ovf) {
+    uint64_t c = cnt;
+    if (n_ovf) c += ovf_get(t, t.keys_b ? pos : key);
+    return c;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
 k_hist(DevTable t, uint32_t n_ovf, uint64_t base, uint64_t ceil_, uint64_t inc, uint64_t nb,
        unsigned long long* __restrict__ out, uint32_t lds_bins) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
     for (uint32_t i = threadIdx.x; i < lds_bins; i += blockDim.x) s_bins[i] = 0;
     __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t quads = t.cap / 4, stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t rounds = (t.cap + stride - 1) / stride;
+    const uint64_t rounds = (quads + stride - 1) / stride;
     for (uint64_t r = 0; r < rounds; ++r) {              // uniform trip count: the aggregation uses whole-wave ballots
-        uint64_t i = first + r * stride;
-        uint64_t key = i < t.cap ? t.keys[i] : EMPTY;
-        bool occ = key != EMPTY;
-        uint64_t idx = 0;
-        if (occ) {
-            uint64_t v = slot_count(t, i, key, n_ovf);
-            idx = v < base ? 0 : (v > ceil_ ? nb - 1 : (inc == 1 ? v - base : (v - base) / inc));
+        const uint64_t q = first + r * stride;
+        const Slots4 s4 = load_slots4(t, q * 4, q < quads);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool occ = s4.key[j] != EMPTY;
+            uint64_t idx = 0;
+            if (occ) {
+                const uint64_t v = slot_count4(t, q * 4 + j, s4.key[j], s4.cnt[j], n_ovf);
+                idx = v < base ? 0 : (v > ceil_ ? nb - 1 : (inc == 1 ? v - base : (v - base) / inc));
+            }
+            const bool in_lds = occ && idx < lds_bins;
+            lds_inc_aggregated(s_bins, (uint32_t)idx, in_lds);
+            if (occ && !in_lds) atomicAdd(&out[idx], 1ULL);
         }
-        bool in_lds = occ && idx < lds_bins;
-        lds_inc_aggregated(s_bins, (uint32_t)idx, in_lds);
-        if (occ && !in_lds) atomicAdd(&out[idx], 1ULL);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {          // the all-ones key lives outside the slots
         uint64_t v = t.ctrs[CTR_ONES];
@@ -215,29 +243,39 @@ __device__ __forceinline__ uint64_t scale_count(uint64_t c, double scale) {
 // K4.  Gcp::analyseSlice (src/gcp.cc:179-197): row = popcount-based GC count, column = min(ceil(count*scale), bins).
 // The whole k x (bins+1) matrix is privatised in LDS as u32 when it fits (27 x 1001 x 4 B = 108 KB of the 160 KB).
 template <bool W>                                         // W: wide table (k > 32, kg_device.hpp "wide keys")
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SCAN_BLOCK)
 k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long long* __restrict__ out, uint32_t use_lds) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
     const uint32_t cols = bins + 1, k = t.k, cells = k * cols;
     if (use_lds) { for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) s_bins[i] = 0; __syncthreads(); }
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t quads = t.cap / 4, stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t rounds = (t.cap + stride - 1) / stride;
+    const uint64_t rounds = (quads + stride - 1) / stride;
     for (uint64_t r = 0; r < rounds; ++r) {
-        uint64_t i = first + r * stride;
-        uint64_t key = i < t.cap ? t.keys[i] : EMPTY;
-        bool occ = key != EMPTY;
-        uint32_t cell = 0;
-        if (occ) {
-            uint32_t g;
-            if constexpr (W) g = keyw_gc(KeyW{key, t.keys_b[i]}, k); else g = kmer_gc(key, k);
-            uint64_t pos = scale_count(slot_count(t, i, key, n_ovf), scale);
-            if (pos > bins) pos = bins;
-            occ = g < k;                                   // the reference's matrix has k rows: GC == k never printed
-            cell = g * cols + (uint32_t)pos;
+        const uint64_t q = first + r * stride;
+        const bool in_range = q < quads;
+        const Slots4 s4 = load_slots4(t, q * 4, in_range);
+        uint64_t kb[4] = {0, 0, 0, 0};
+        if constexpr (W) {
+            const uint64_t at = in_range ? q * 4 : 0;
+            const u64x2 a = *reinterpret_cast<const u64x2*>(t.keys_b + at), b = *reinterpret_cast<const u64x2*>(t.keys_b + at + 2);
+            kb[0] = a.x; kb[1] = a.y; kb[2] = b.x; kb[3] = b.y;
         }
-        if (use_lds) lds_inc_aggregated(s_bins, cell, occ);
-        else if (occ) atomicAdd(&out[cell], 1ULL);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool occ = s4.key[j] != EMPTY;
+            uint32_t cell = 0;
+            if (occ) {
+                uint32_t g;
+                if constexpr (W) g = keyw_gc(KeyW{s4.key[j], kb[j]}, k); else g = kmer_gc(s4.key[j], k);
+                uint64_t pos = scale_count(slot_count4(t, q * 4 + j, s4.key[j], s4.cnt[j], n_ovf), scale);
+                if (pos > bins) pos = bins;
+                occ = g < k;                                   // the reference's matrix has k rows: GC == k never printed
+                cell = g * cols + (uint32_t)pos;
+            }
+            if (use_lds) lds_inc_aggregated(s_bins, cell, occ);
+            else if (occ) atomicAdd(&out[cell], 1ULL);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t v = t.ctrs[CTR_ONES];                     // all-T 32-mer: GC count 0

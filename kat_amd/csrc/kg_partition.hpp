@@ -1005,11 +1005,15 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
             const uint64_t n_chunks = (n_run + CH - 1) / CH;
             unsigned long long cur[U], nxt[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const uint64_t i = (uint64_t)wave * CH + (uint64_t)u * 64 + lane; cur[u] = i < n_run ? l2_buf[sbeg + i] : EMPTY; }
+            for (int u = 0; u < U; ++u) { const uint64_t i = (uint64_t)wave * CH + (uint64_t)u * 64 + lane; const unsigned long long v = l2_buf[sbeg + (i < n_run ? i : 0)]; cur[u] = i < n_run ? v : EMPTY; }
             for (uint64_t c = wave; c < n_chunks; c += NW) {
                 const unsigned long long t_a = now();
 #pragma unroll
-                for (int u = 0; u < U; ++u) { const uint64_t i = (c + NW) * CH + (uint64_t)u * 64 + lane; nxt[u] = i < n_run ? l2_buf[sbeg + i] : EMPTY; }   // next chunk: in flight behind this one
+                for (int u = 0; u < U; ++u) {                 // next chunk: in flight behind this one (unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch)
+                    const uint64_t i = (c + NW) * CH + (uint64_t)u * 64 + lane;
+                    const unsigned long long v = l2_buf[sbeg + (i < n_run ? i : 0)];
+                    nxt[u] = i < n_run ? v : EMPTY;
+                }
                 uint32_t slot[U];
                 bool pend[U];                                     // k-mer u still to be placed (lane masks in SGPRs)
 #pragma unroll

@@ -65,7 +65,7 @@ class HipShard:
         cap = eng.scratch(0).capacity
         if cap < want_bytes:
             try:
-                cap = eng.scratch(want_bytes).capacity
+                cap = eng.scratch(want_bytes).capacity          # keeps the old arena when the larger one cannot be had
             except Exception:
                 cap = eng.scratch(0).capacity
         return cap
@@ -174,15 +174,16 @@ def _exchange_rows(rows_out, rows_in, rank, world, group):
         r.wait()
 
 
-def exchange_merge(shard, group=None, min_chunks=4):
+def exchange_merge(shard, group=None, min_chunks=4, force=False):
     """Route every record of `shard` to its owner rank, IN PLACE: on return the same shard holds exactly the k-mers this
     rank owns, with their counts summed over all ranks.  The table keeps its storage and its region grid (a second table created
     "like" the first still joins with it region by region).
 
-    world_size == 1: the local table already is the owner table.
+    world_size == 1: the local table already is the owner table (force=True runs the protocol all the same -- extraction,
+    clear, region-by-region merge of the rank's own send list, the collectives -- which is how a single-GPU box exercises it).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return shard
     rank = dist.get_rank(group)
     dev = shard.device
@@ -420,12 +421,12 @@ class HipWideShard:
         self.table.free()
 
 
-def exchange_merge_wide(shard, group=None):
+def exchange_merge_wide(shard, group=None, force=False):
     """exchange_merge for wide tables: every (k-mer, count) record goes to owner_of_w(k-mer); on return shard.table holds exactly
     the k-mers this rank owns, counts summed over ranks (exact integer sums: bit-identical to one process).  The shard is
     duck-typed (part_sizes / partition / rebuild) like the one-word exchange's."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return shard
     rank = dist.get_rank(group)
     dev = shard.device

@@ -37,6 +37,13 @@ def test_checksums_at_scale(engine):
     assert 0.03 < int(mx[1, 0]) / s1["total"] < 0.07
     # idempotence of the reducers on an immutable table
     assert np.array_equal(h, t1.hist())
+    # the three reducers against the documentation-derived restatement (tests/independent.py), from the exported multisets alone
+    from tests import independent as ind
+    k1, c1 = t1.export()
+    k2, c2 = t2.export()
+    assert np.array_equal(h, ind.hist(c1)) and np.array_equal(t2.hist(), ind.hist(c2))
+    assert np.array_equal(gm, ind.gcp(k1, c1, k))
+    assert np.array_equal(mx, ind.comp_matrix(k1, c1, k2, c2))
 
 
 def test_count_is_order_and_batch_independent(engine):

@@ -101,3 +101,19 @@ def test_reader_errors(tmp_path):
     with pytest.raises(kat_amd.KatGpuError) as ei:
         kat_amd.jf_read_records(str(big))
     assert ei.value.code == 6
+
+
+def test_header_strings_are_escaped(tmp_path, monkeypatch):
+    """The reference writes its header through jsoncpp, which escapes; a working directory with a quote or a backslash in its
+    name must still give a header every JSON reader (jsoncpp in jellyfish / KAT, json here, our own) accepts."""
+    d = tmp_path / 'odd "dir" \\ name'
+    d.mkdir()
+    monkeypatch.chdir(d)
+    keys = np.array([3, 9, 77], np.uint64)
+    counts = np.array([1, 2, 3], np.uint64)
+    kat_amd.jf_write_records("t.jf", 21, True, keys, counts)
+    hdr, _, _ = read_header("t.jf")                                   # json.loads: a strict parser
+    assert hdr["pwd"] == str(d) and hdr["format"] == "binary/sorted"
+    k, canonical, rk, rc = kat_amd.jf_read_records("t.jf")
+    o = np.argsort(rk)
+    assert (k, canonical) == (21, True) and np.array_equal(rk[o], keys) and np.array_equal(rc[o], counts)
