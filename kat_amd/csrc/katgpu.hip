@@ -521,17 +521,17 @@ static const uint64_t g_part_min_starts = getenv("KATGPU_PART_MIN_STARTS") ? str
 static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? strtoull(getenv("KATGPU_TEST_ROUND_ITEMS"), nullptr, 10) : 0;
 // share of the free HBM the partition arena may take (multi-GPU runs may lower it; bench.py sets 0.75 there)
 static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::min(0.95, std::max(0.05, atof(getenv("KATGPU_ARENA_FRACTION")))) : 0.85;
-static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10) : 3;   // 0 = first edition (1024-thread, 1 per CU)
+static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? std::max<uint32_t>(1, (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10)) : 3;   // level-1 workgroups per CU
 static const uint32_t g_apply_v = getenv("KATGPU_APPLY_V") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_V"), nullptr, 10) : 2;   // 1: first-edition walk (A/B)
 static const uint32_t g_apply_unr = getenv("KATGPU_APPLY_UNR") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_UNR"), nullptr, 10) : 43;   // A/B: k-mers per lane x probe rounds
 static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 0;   // 0: by region size
 // level 2 without its histogram pass (kg_partition.hpp: k_p2_fast): 0 = never, 1 = when the mean run is long enough for the
 // capacity slack to cover the noise, 2 = always (tests).  KATGPU_TEST_P2_OVF_CAP shrinks the overflow list (tests: forces the
 // fall back to the exact kernel).
-// level 1 without its counting pass (kg_partition.hpp: k_p1v2_scatter_chunked): 0 = never (the default: measured slower on
-// MI355X, see the kernel's comment), 1 = for rounds of at least 64 M k-mers, 2 = always (tests)
-static const uint32_t g_test_l1_cpb = getenv("KATGPU_TEST_L1_CPB") ? (uint32_t)strtoul(getenv("KATGPU_TEST_L1_CPB"), nullptr, 10) : 0;   // tests: chunks per bucket (forces overflow)
-static const uint32_t g_l1_fast = getenv("KATGPU_L1_FAST") ? (uint32_t)strtoul(getenv("KATGPU_L1_FAST"), nullptr, 10) : 0;
+// level 1 without its counting pass (kg_partition.hpp: k_p1v2_scatter<true>, one fixed-capacity segment per workgroup and bucket):
+// 0 = never, 1 = for rounds of at least 64 M k-mers (the default), 2 = always (tests)
+static const uint32_t g_test_l1_cpb = getenv("KATGPU_TEST_L1_CPB") ? (uint32_t)strtoul(getenv("KATGPU_TEST_L1_CPB"), nullptr, 10) : 0;   // tests: segment capacity (forces overflow)
+static const uint32_t g_l1_fast = getenv("KATGPU_L1_FAST") ? (uint32_t)strtoul(getenv("KATGPU_L1_FAST"), nullptr, 10) : 1;
 static const uint32_t g_p2_fast = getenv("KATGPU_P2_FAST") ? (uint32_t)strtoul(getenv("KATGPU_P2_FAST"), nullptr, 10) : 1;
 static const uint64_t g_test_p2_ovf_cap = getenv("KATGPU_TEST_P2_OVF_CAP") ? strtoull(getenv("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
 static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
@@ -610,13 +610,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         int grc = regrow(t, nc);
         if (grc) return grc;
     }
-    const bool p1v2 = g_p1_wgs > 0;
-    const uint32_t W = (uint32_t)c->n_cu * (p1v2 ? std::min<uint32_t>(g_p1_wgs, 4) : 1);      // level-1 workgroups (rows of hist1 / offs)
+    const uint32_t W = (uint32_t)c->n_cu * std::min<uint32_t>(g_p1_wgs, 4);                     // level-1 workgroups (rows of hist1 / offs)
     const uint32_t W2 = (uint32_t)c->n_cu;                                                      // level-2 / apply: one per CU
-    const size_t tile_starts = p1v2 ? P1_TILE_STARTS : L1_TILE_STARTS;
+    const size_t tile_starts = P1_TILE_STARTS;
     if (!c->part_attr_set) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -630,15 +627,19 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         c->part_attr_set = true;
     }
-    // ---- arena: [hist1 | offs | l1_off | off2 | cnt2 | bend | chunk_cur | spill_n, ovf_n | L1 buffer | L2 buffer | overflow list] ----
-    // L1 buffer: a round's k-mers + 1/32 (chunk slack of k_p1v2_scatter_chunked) + one chunk per workgroup and bucket;
-    // L2 buffer: that + 1/16 + 16 per region (capacity slack of k_p2_fast); overflow list: 1/32.  17.27 bytes per k-mer of a round.
-    const size_t fixed_l1 = (size_t)W * MAX_PARTS * L1_CHUNK;
+    // ---- arena: [hist1 | offs | l1_off | off2 | cnt2 | bend | spill_n, ovf_n | L1 buffer | L2 buffer | overflow list] ----
+    // L1 buffer: a round's k-mers + 1/24 + 64 per workgroup and bucket (segment slack of k_p1v2_scatter<true>);
+    // L2 buffer: that + 1/16 + 16 per region (capacity slack of k_p2_fast); overflow list: 1/32.  17.45 bytes per k-mer of a round.
+    constexpr size_t SEG_PAD = 64;
+    const size_t fixed_l1 = (size_t)W * MAX_PARTS * SEG_PAD;
     const size_t fixed_l2 = fixed_l1 + fixed_l1 / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024;
     const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +   /* W <= 4 * CUs */
                                align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) +
@@ -667,17 +668,17 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     uint64_t* off2 = (uint64_t*)a;                a += align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256);
     uint32_t* cnt2 = (uint32_t*)a;                a += align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256);
     uint64_t* bend = (uint64_t*)a;                a += align_up((size_t)MAX_PARTS * 8, 256);
-    uint32_t* chunk_cur = (uint32_t*)a;           a += align_up((size_t)MAX_PARTS * 4, 256);
+    a += align_up((size_t)MAX_PARTS * 4, 256);
     unsigned long long* spill_n = (unsigned long long*)a;
     unsigned long long* ovf_n = spill_n + 1;      a += 256;
-    const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / 17.27));
-    const size_t l1_items = round_items + round_items / 32 + fixed_l1;
+    const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / 17.45));
+    const size_t l1_items = round_items + round_items / 24 + fixed_l1;
     const size_t l2_items = l1_items + l1_items / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024;
     uint64_t* l1_buf = (uint64_t*)a;
     uint64_t* l2_buf = l1_buf + l1_items;
     uint64_t* ovf_buf = l2_buf + l2_items;
     const uint64_t ovf_cap = g_test_p2_ovf_cap ? g_test_p2_ovf_cap : round_items / 32 + 1024;
-    bool p2_fast_ok = g_p2_fast != 0, l1_fast_ok = g_l1_fast != 0 && p1v2;
+    bool p2_fast_ok = g_p2_fast != 0, l1_fast_ok = g_l1_fast != 0;
     if (!g_test_round_items && round_items < ((size_t)1 << 20) && round_items < n_starts) return KATGPU_OK;
 
     // Rounds are sized in ITEMS (valid k-mers), not window starts: a cheap pre-count of a prefix measures items/starts
@@ -696,11 +697,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         }
         PartGeom g;
         if (!part_geometry(t->d, &g)) break;                                      // table too large for two levels: direct path
-        if (!ratio_known && n_starts - pos > round_items && !g_test_round_items) {
+        // (the segmented level 1 sizes its segments from this ratio, so it wants it even when one round takes everything)
+        if (!ratio_known && !g_test_round_items && (n_starts - pos > round_items || (l1_fast_ok && n_starts - pos >= ((size_t)64 << 20)))) {
             const size_t probe_m = std::min<size_t>(n_starts - pos, (size_t)64 << 20) / tile_starts * tile_starts;
             const uint64_t pt = probe_m / tile_starts, ptw = (pt + W - 1) / W;
-            if (p1v2) hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, dev_bases + pos, (uint64_t)(probe_m + k - 1), pt, ptw, hist1);
-            else hipLaunchKernelGGL(k_p1_count, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, dev_bases + pos, (uint64_t)(probe_m + k - 1), pt, ptw, hist1);
+            hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, dev_bases + pos, (uint64_t)(probe_m + k - 1), pt, ptw, hist1);
             hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
             uint64_t probe_items = 0;
             HIPCHK(c, hipMemcpyAsync(&probe_items, &l1_off[g.P1], sizeof probe_items, hipMemcpyDeviceToHost, c->stream));
@@ -723,30 +724,30 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         t->count_bound = 0xFFFFFFFFULL;          // the apply kernel chains its own carries; a later direct launch sweeps first
         const uint64_t n_tiles = (m + tile_starts - 1) / tile_starts;
         const uint64_t tiles_per_wg = (n_tiles + W - 1) / W;
-        // Level 1.  Chunked edition (one pass, no exact sizes) when the round is big enough for its fixed costs; the exact
-        // edition (count + scan + scatter) otherwise, and for the rest of the call once a chunked round overflowed.
+        // Level 1.  Segmented edition (one pass, fixed-capacity segments) when the round is big enough for its fixed costs; the
+        // exact edition (count + scan + scatter) otherwise, and for the rest of the call once a segmented round overflowed.
         const uint64_t est_items = (uint64_t)((double)m * items_per_start);
-        uint32_t cpb = (uint32_t)std::min<uint64_t>(l1_items / ((uint64_t)g.P1 * L1_CHUNK), 0x7FFFFFFFu);             // chunks per bucket
-        if (g_test_l1_cpb) cpb = std::min(cpb, g_test_l1_cpb);
-        const bool chunked = l1_fast_ok && (cpb > W || g_test_l1_cpb) && (g_l1_fast == 2 || est_items >= ((uint64_t)64 << 20));
+        uint64_t seg_cap = est_items / ((uint64_t)W * g.P1);
+        seg_cap += seg_cap / 24 + SEG_PAD;
+        if (g_test_l1_cpb) seg_cap = std::min<uint64_t>(seg_cap, g_test_l1_cpb);
+        const bool seg = l1_fast_ok && (g_l1_fast == 2 || (ratio_known && est_items >= ((uint64_t)64 << 20))) && (uint64_t)W * g.P1 * seg_cap <= l1_items;
+        const uint64_t seg_slots = seg ? (uint64_t)W * seg_cap : 0;                // slots of one bucket
         uint64_t items = 0;
         unsigned long long ovf_l1 = 0;
         HIPCHK(c, hipMemsetAsync(spill_n, 0, 2 * sizeof(unsigned long long), c->stream));          // spill_n, ovf_n
-        if (chunked) {
+        if (seg) {
             items = est_items;                                                    // the exact number is not needed (and not known)
-            HIPCHK(c, hipMemsetAsync(chunk_cur, 0, (size_t)g.P1 * 4, c->stream));
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
-                hipLaunchKernelGGL(k_p1v2_scatter_chunked, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, chunk_cur, cpb, l1_buf,
-                                   ovf_buf, ovf_n, ovf_cap);
+                hipLaunchKernelGGL(k_p1v2_scatter<true>, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)nullptr, l1_buf,
+                                   seg_cap, ovf_buf, ovf_n, ovf_cap);
             }
             HIPCHK(c, hipMemcpyAsync(&ovf_l1, ovf_n, sizeof ovf_l1, hipMemcpyDeviceToHost, c->stream));      // read at the next synchronisation
-            if (g_trace) fprintf(stderr, "[katgpu] partition round (chunked level 1): %zu starts, ~%llu items, %u chunks per bucket (arena %.1f GB)\n", m, (unsigned long long)items, cpb, c->arena_bytes / 1e9);
+            if (g_trace) fprintf(stderr, "[katgpu] partition round (segmented level 1): %zu starts, ~%llu items, %llu k-mers per segment (arena %.1f GB)\n", m, (unsigned long long)items, (unsigned long long)seg_cap, c->arena_bytes / 1e9);
         } else {
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1, m);
-                if (p1v2) hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
-                else hipLaunchKernelGGL(k_p1_count, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
+                hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
                 hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
             }
             HIPCHK(c, hipMemcpyAsync(&items, &l1_off[g.P1], sizeof items, hipMemcpyDeviceToHost, c->stream));
@@ -759,12 +760,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             }
             if (items) {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
-                if (p1v2) hipLaunchKernelGGL(k_p1v2_scatter, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
-                else hipLaunchKernelGGL(k_p1_scatter, dim3(W), dim3(PART_BLOCK), sizeof(PartLds), c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, offs, l1_buf);
+                hipLaunchKernelGGL(k_p1v2_scatter<false>, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, l1_buf,
+                                   (uint64_t)0, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
             }
         }
         if (items) {
-            const uint32_t* cc = chunked ? chunk_cur : nullptr;
             // level 2: one pass when the runs are predictable (k_p2_fast), else -- or when its overflow list did not hold --
             // the exact two-pass kernel
             const uint32_t* run_len = nullptr;
@@ -773,21 +773,13 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             if (try_fast) {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
                 hipLaunchKernelGGL(k_p2_fast, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2,
-                                   ovf_buf, ovf_n, ovf_cap, cc, cpb);
+                                   ovf_buf, ovf_n, ovf_cap, seg_slots);
             }
-            if (try_fast || chunked) {
+            if (try_fast || seg) {
                 HIPCHK(c, hipMemcpyAsync(&overflowed, ovf_n, sizeof overflowed, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
-                if (chunked && g_trace) {
-                    std::vector<uint32_t> cur(g.P1);
-                    hipMemcpy(cur.data(), chunk_cur, (size_t)g.P1 * 4, hipMemcpyDeviceToHost);
-                    uint64_t used = 0; uint32_t mx = 0, mn = ~0u;
-                    for (uint32_t v : cur) { used += std::min(v, cpb); mx = std::max(mx, v); mn = std::min(mn, v); }
-                    fprintf(stderr, "[katgpu]   chunks used %llu (= %llu slots for ~%llu items), per bucket %u..%u of %u; level-1 overflow %llu\n", (unsigned long long)used,
-                            (unsigned long long)used * L1_CHUNK, (unsigned long long)items, mn, mx, cpb, ovf_l1);
-                }
-                if (chunked && ovf_l1 > ovf_cap) {           // the level-1 buffer itself is incomplete: this round again, exactly
-                    if (g_trace) fprintf(stderr, "[katgpu] chunked level 1: %llu k-mers found no chunk (list holds %llu): exact level 1 from here on\n", ovf_l1, (unsigned long long)ovf_cap);
+                if (seg && ovf_l1 > ovf_cap) {               // the level-1 buffer itself is incomplete: this round again, exactly
+                    if (g_trace) fprintf(stderr, "[katgpu] segmented level 1: %llu k-mers beyond their segments (list holds %llu): exact level 1 from here on\n", ovf_l1, (unsigned long long)ovf_cap);
                     l1_fast_ok = false;
                     HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));   // the scatter tallied the all-ones key
                     continue;
@@ -802,10 +794,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             }
             if (!run_len) {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-                hipLaunchKernelGGL(k_p2, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cc, cpb,
-                                   chunked ? bend : (uint64_t*)nullptr);
+                hipLaunchKernelGGL(k_p2, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, seg_slots,
+                                   seg ? bend : (uint64_t*)nullptr);
             }
-            const uint64_t* bucket_end = (!run_len && chunked) ? bend : nullptr;
+            const uint64_t* bucket_end = (!run_len && seg) ? bend : nullptr;
             {
                 ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
                 // as many workgroups per CU as the regions' LDS footprint (and the 2048-thread limit) admits
@@ -821,6 +813,9 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                     else if (g_apply_unr == 82) KG_APPLY2(1024, 4, 8, 2);
                     else if (g_apply_unr == 84) KG_APPLY2(1024, 4, 8, 4);
                     else if (g_apply_unr == 83) KG_APPLY2(1024, 4, 8, 3);
+                    else if (g_apply_unr == 430) hipLaunchKernelGGL((k_p3_apply2<1024, 4, 4, 3, false, false, false>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr);
+                    else if (g_apply_unr == 431) hipLaunchKernelGGL((k_p3_apply2<1024, 4, 4, 3, false, true, false>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr);
+                    else if (g_apply_unr == 432) hipLaunchKernelGGL((k_p3_apply2<1024, 4, 4, 3, false, false, true>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr);
                     else if (g_apply_unr == 1043 || g_apply_unr == 1083) {      // cycle stamps of wave 0 (diagnostic; KATGPU_TRACE prints them)
                         unsigned long long* d_st = nullptr;
                         HIPCHK(c, hipMalloc((void**)&d_st, 64));

@@ -176,41 +176,6 @@ __device__ __forceinline__ void scatter_tile(PartLds& L, const PartGeom g, const
     // (the next tile's first barrier orders this update before the next use)
 }
 
-// ---- level 1, pass A: per-workgroup bucket histogram of this round's k-mers.  hist1[w * P1 + b]. ----
-// Workgroup w owns tiles [w*tiles_per_wg, ...) in BOTH level-1 passes, which is what makes the precomputed per-workgroup
-// offsets valid.  The all-ones key (only k = 32, non-canonical poly-T) never enters a bucket: it is tallied here.
-__global__ void __launch_bounds__(PART_BLOCK)
-k_p1_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
-           uint32_t* __restrict__ hist1) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
-    const uint32_t tid = threadIdx.x;
-    if (tid < MAX_PARTS) L.hist[tid] = 0;
-    uint32_t ones = 0;
-    const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
-    uint32_t w[4], wn[4];
-    if (t0 < t1) tile_load(bases, n, t0 * L1_TILE_STARTS, w);
-    for (uint64_t tile = t0; tile < t1; ++tile) {
-        if (tile + 1 < t1) tile_load(bases, n, (tile + 1) * L1_TILE_STARTS, wn);
-        lds_barrier();
-        tile_stage(L, w);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = wn[q];
-        uint64_t key[PART_ITEMS];
-        const uint32_t valid = lane_kmers(L, t.k, t.canonical != 0, key);
-#pragma unroll
-        for (int j = 0; j < PART_ITEMS; ++j)
-            if (valid >> j & 1) {
-                if (key[j] == EMPTY) { ++ones; continue; }
-                atomicAdd(&L.hist[digit1_of_hash(mix64(key[j]), g.P1)], 1u);
-            }
-    }
-    lds_barrier();
-    if (tid < g.P1) hist1[(uint64_t)blockIdx.x * g.P1 + tid] = L.hist[tid];
-    for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
-    if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
-}
-
 // ---- level 1 scan: offs[w][b] = start of workgroup w's run inside bucket b; l1_off[b] = start of bucket b; l1_off[P1] = items ----
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p1_scan(PartGeom g, uint32_t n_wg, const uint32_t* __restrict__ hist1, uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_off) {
@@ -231,31 +196,6 @@ k_p1_scan(PartGeom g, uint32_t n_wg, const uint32_t* __restrict__ hist1, uint64_
     if (b < g.P1) {
         uint64_t run = s_base[b];
         for (uint32_t w = 0; w < n_wg; ++w) { offs[(uint64_t)w * g.P1 + b] = run; run += hist1[(uint64_t)w * g.P1 + b]; }
-    }
-}
-
-// ---- level 1, pass B: extract again (it is ~free) and scatter into the level-1 buckets ----
-__global__ void __launch_bounds__(PART_BLOCK)
-k_p1_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
-             const uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_buf) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
-    const uint32_t tid = threadIdx.x;
-    if (tid < g.P1) L.cursor[tid] = offs[(uint64_t)blockIdx.x * g.P1 + tid];
-    const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
-    uint32_t w[4], wn[4];
-    if (t0 < t1) tile_load(bases, n, t0 * L1_TILE_STARTS, w);
-    for (uint64_t tile = t0; tile < t1; ++tile) {
-        if (tile + 1 < t1) tile_load(bases, n, (tile + 1) * L1_TILE_STARTS, wn);
-        lds_barrier();
-        tile_stage(L, w);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = wn[q];
-        uint64_t key[PART_ITEMS];
-        uint32_t valid = lane_kmers(L, t.k, t.canonical != 0, key);
-#pragma unroll
-        for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);        // tallied in pass A
-        scatter_tile<1>(L, g, key, valid, l1_buf);
     }
 }
 
@@ -393,13 +333,24 @@ k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
     if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
 }
 
+// SEG = false: the exact edition -- every workgroup's share of every bucket was counted first (k_p1v2_count, k_p1_scan), `offs`
+// holds where it starts.  SEG = true: no counting pass -- bucket b is cut into one SEGMENT of seg_cap k-mers per workgroup
+// (segment (b, w) starts at (b * gridDim + w) * seg_cap); the hash spreads a workgroup's k-mers evenly, so a capacity of the
+// expected share + 1/24 + 64 holds them (5 sigma at the bench size); what a full segment cannot take goes to the overflow list
+// (-> direct path; if that overflows too the host redoes the round with the exact edition), what a segment has left at the
+// end is padded with EMPTY, which level 2 skips (the all-ones k-mer never is an item).  Saves the second decode + hash of the
+// whole input (k_p1v2_count: 70 ms of the bench step) for ~4 % more level-1 bytes.
+template <bool SEG>
 __global__ void __launch_bounds__(P1_BLOCK)
 k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
-               const uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_buf) {
+               const uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_buf, uint64_t seg_cap, uint64_t* __restrict__ ovf_buf,
+               unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
     __shared__ __attribute__((aligned(16))) P1Lds L;
     const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;
     const bool canonical = t.canonical != 0;
-    for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] = offs[(uint64_t)blockIdx.x * P + b];
+    uint32_t ones = 0;
+    auto seg_base = [&](uint32_t b) -> uint64_t { return ((uint64_t)b * gridDim.x + blockIdx.x) * seg_cap; };
+    for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] = SEG ? seg_base(b) : offs[(uint64_t)blockIdx.x * P + b];
     const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
     uint32_t w[4], wn[4];
     if (t0 < t1) p1_tile_load(bases, n, t0 * P1_TILE_STARTS, w);
@@ -421,7 +372,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                 br[j] = 0;
                 if (!lw.valid()) continue;
                 const uint64_t key = canon_if(lw.fwd(), k, canonical);
-                if (key == EMPTY) continue;                                     // tallied by the count pass
+                if (key == EMPTY) { if (SEG) ++ones; continue; }               // exact edition: tallied by the count pass
                 const uint32_t b = digit1_of_hash(mix64(key), P);
                 br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
                 valid |= 1u << j;
@@ -445,162 +396,51 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         const uint32_t total = L.off[P - 1] + L.hist[P - 1];
         for (uint32_t idx = tid; idx < total; idx += P1_BLOCK) {
             const uint32_t v = L.pos[idx], b = v >> 16;
-            l1_buf[L.cursor[b] + (idx - L.off[b])] = kmer_at(L.code, v & 0xFFFF, k, canonical);
-        }
-        lds_barrier();
-        for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] += L.hist[b];
-    }
-}
-
-// ---- level 1 without the counting pass ----
-// The exact edition needs every workgroup's bucket sizes before it can write (k_p1v2_count: a second decode + hash of the
-// whole input).  The chunked edition writes in ONE pass: a bucket's share of the level-1 buffer is cut into chunks of
-// L1_CHUNK k-mers; a workgroup appends to its current chunk of bucket b and takes the next free one (one global atomic per
-// 256 k-mers) when that is full.  What a workgroup leaves unfilled in its last chunk of each bucket is padded with EMPTY,
-// which level 2 skips (the all-ones k-mer never is an item).  A bucket that runs out of chunks (heavy hitters) sends its
-// k-mers to the overflow list; when that list cannot hold them the host redoes the round with the exact kernels.
-// MEASURED (bench config, 300 M reads, 4 rounds of 9.3 G k-mers): NOT a win on MI355X as it stands.  The counting pass
-// (70 ms per step) goes away and level 2 pays 15 ms for the padding, but this scatter takes 320-330 ms where the exact one
-// takes 211: step 944 ms against 898.  Reserving the next chunk ahead (so that no wave waits on a returning atomic at a
-// chunk boundary) changed nothing, so the loss is in the copy-out loop itself, not in the atomics.  Off by default
-// (KATGPU_L1_FAST=1 enables it, =2 forces it for small rounds); kept, and covered by tests/test_gpu_partition.py, as the
-// starting point for a copy-out that handles the chunk boundary outside the per-bucket loop.
-constexpr uint32_t L1_CHUNK = 256;
-
-__device__ __forceinline__ uint64_t l1_bucket_base(uint32_t b, uint32_t cpb) { return (uint64_t)b * cpb * L1_CHUNK; }
-
-__global__ void __launch_bounds__(P1_BLOCK)
-k_p1v2_scatter_chunked(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
-                       uint32_t* __restrict__ chunk_cur, uint32_t cpb, uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ ovf_buf,
-                       unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
-    __shared__ __attribute__((aligned(16))) P1Lds L;
-    __shared__ uint32_t s_next[MAX_PARTS];                // the chunk this workgroup has reserved ahead in each bucket
-    const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;
-    const bool canonical = t.canonical != 0;
-    // cursor[b]: next write position of this workgroup in bucket b; a multiple of L1_CHUNK means "no chunk in hand".
-    // next[b]: a chunk reserved AHEAD, so that crossing a chunk boundary never waits for a global atomic: the crossing takes
-    // next[b] and issues the reservation of the one after; that atomic's result is parked in a register (two slots per
-    // 16-lane group) and stored to next[b] at the top of the next tile's copy-out, long after it has arrived.
-    for (uint32_t b = tid; b < P; b += P1_BLOCK) { L.cursor[b] = 0; s_next[b] = atomicAdd(&chunk_cur[b], 1u); }
-    uint32_t ones = 0;
-    const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
-    uint32_t w[4], wn[4];
-    if (t0 < t1) p1_tile_load(bases, n, t0 * P1_TILE_STARTS, w);
-    const uint32_t grp = tid >> 4, l16 = tid & 15;
-    uint32_t np = 0, pb0 = 0, pb1 = 0, pv0 = 0, pv1 = 0;              // lane 0 of each group: reservations in flight
-    auto flush = [&]() {
-        if (l16 == 0) {
-            if (np > 0) s_next[pb0] = pv0;
-            if (np > 1) s_next[pb1] = pv1;
-        }
-        np = 0;
-    };
-    for (uint64_t tile = t0; tile < t1; ++tile) {
-        if (tile + 1 < t1) p1_tile_load(bases, n, (tile + 1) * P1_TILE_STARTS, wn);
-        lds_barrier();
-        for (uint32_t b = tid; b < MAX_PARTS; b += P1_BLOCK) L.hist[b] = 0;
-        p1_tile_stage(L, w);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = wn[q];
-        uint32_t br[PART_ITEMS];
-        uint32_t valid = 0;
-        if (tid < P1_LANES_WITH_STARTS) {
-            LaneWindow lw;
-            lw.init(L.code, L.bad, tid, k);
-#pragma unroll
-            for (int j = 0; j < PART_ITEMS; ++j, lw.step()) {
-                br[j] = 0;
-                if (!lw.valid()) continue;
-                const uint64_t key = canon_if(lw.fwd(), k, canonical);
-                if (key == EMPTY) { ++ones; continue; }
-                const uint32_t b = digit1_of_hash(mix64(key), P);
-                br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
-                valid |= 1u << j;
+            const uint64_t dst = L.cursor[b] + (idx - L.off[b]);
+            const uint64_t key1 = kmer_at(L.code, v & 0xFFFF, k, canonical);
+            if (!SEG || dst < seg_base(b) + seg_cap) l1_buf[dst] = key1;
+            else {                                                             // the segment is full: the overflow list
+                const unsigned long long at = atomicAdd(ovf_n, 1ULL);
+                if (at < ovf_cap) ovf_buf[at] = key1;
             }
         }
         lds_barrier();
-        uint32_t e0, e1;
-        p1_scan_pair(tid < P ? L.hist[tid] : 0, tid + P1_BLOCK < P ? L.hist[tid + P1_BLOCK] : 0, L.wave_tot, e0, e1);
-        L.off[tid] = e0;
-        L.off[tid + P1_BLOCK] = e1;
+        for (uint32_t b = tid; b < P; b += P1_BLOCK) {
+            uint64_t c = L.cursor[b] + L.hist[b];
+            if (SEG) { const uint64_t lim = seg_base(b) + seg_cap; c = c < lim ? c : lim; }
+            L.cursor[b] = c;
+        }
+    }
+    if (SEG) {
         lds_barrier();
-#pragma unroll
-        for (int j = 0; j < PART_ITEMS; ++j)
-            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = tid * PART_ITEMS + j;
-        flush();                                                              // last tile's reservations have long arrived
-        lds_barrier();
-        // copy-out: a 16-lane group per bucket appends the run to the workgroup's current chunk of that bucket
+        // what the segments have left is padded; a 16-lane group per bucket
+        const uint32_t grp = tid >> 4, l16 = tid & 15;
         for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
-            uint32_t left = L.hist[b], src = L.off[b];
-            uint64_t dst = L.cursor[b];
-            while (left) {                                                    // uniform over the group
-                uint32_t room = (L1_CHUNK - (uint32_t)(dst & (L1_CHUNK - 1))) & (L1_CHUNK - 1);
-                if (room == 0) {                                              // move on to the chunk reserved ahead, reserve the one after
-                    if (np == 2 || (np > 0 && pb0 == b) || (np > 1 && pb1 == b)) flush();      // (a run longer than a chunk, or many crossings)
-                    uint32_t c = 0;
-                    if (l16 == 0) {
-                        c = s_next[b];
-                        const uint32_t v = atomicAdd(&chunk_cur[b], 1u);
-                        if (np == 0) { pb0 = b; pv0 = v; } else { pb1 = b; pv1 = v; }
-                    }
-                    ++np;
-                    c = __shfl(c, 0, 16);
-                    if (c >= cpb) {                                           // the bucket is out of chunks: the rest of the run overflows
-                        unsigned long long at = 0;
-                        if (l16 == 0) at = atomicAdd(ovf_n, (unsigned long long)left);
-                        at = __shfl(at, 0, 16);
-                        for (uint32_t i = l16; i < left; i += 16)
-                            if (at + i < ovf_cap) ovf_buf[at + i] = kmer_at(L.code, L.pos[src + i], k, canonical);
-                        dst = 0;
-                        break;
-                    }
-                    dst = l1_bucket_base(b, cpb) + (uint64_t)c * L1_CHUNK;
-                    room = L1_CHUNK;
-                }
-                const uint32_t part = left < room ? left : room;
-                for (uint32_t i = l16; i < part; i += 16) l1_buf[dst + i] = kmer_at(L.code, L.pos[src + i], k, canonical);
-                dst += part; src += part; left -= part;
-            }
-            if (l16 == 0) L.cursor[b] = dst;
+            const uint64_t lim = seg_base(b) + seg_cap;
+            for (uint64_t i = L.cursor[b] + l16; i < lim; i += 16) l1_buf[i] = EMPTY;
         }
+        for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
+        if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
     }
-    flush();
-    lds_barrier();
-    // pad what is left of the chunk in hand and the whole chunk reserved ahead: level 2 reads every chunk that was handed out
-    for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
-        const uint64_t dst = L.cursor[b];
-        const uint32_t room = (L1_CHUNK - (uint32_t)(dst & (L1_CHUNK - 1))) & (L1_CHUNK - 1);
-        for (uint32_t i = l16; i < room; i += 16) l1_buf[dst + i] = EMPTY;
-        const uint32_t c = s_next[b];
-        if (c < cpb) {
-            const uint64_t base = l1_bucket_base(b, cpb) + (uint64_t)c * L1_CHUNK;
-            for (uint32_t i = l16; i < L1_CHUNK; i += 16) l1_buf[base + i] = EMPTY;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
-    if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
 }
 
-// where bucket b1 of the level-1 buffer lies: exact layout (l1_off) or chunked (whole chunks, EMPTY-padded)
-__device__ __forceinline__ void l1_bucket_range(const uint64_t* __restrict__ l1_off, const uint32_t* __restrict__ chunk_cur, uint32_t cpb, uint32_t b1,
-                                                uint64_t& beg, uint64_t& end) {
-    if (chunk_cur) {
-        const uint32_t used = chunk_cur[b1];
-        beg = l1_bucket_base(b1, cpb);
-        end = beg + (uint64_t)(used < cpb ? used : cpb) * L1_CHUNK;
-    } else { beg = l1_off[b1]; end = l1_off[b1 + 1]; }
+// where bucket b1 of the level-1 buffer lies: exact layout (l1_off) or segmented (seg_slots = workgroups x seg_cap slots per
+// bucket, EMPTY-padded)
+__device__ __forceinline__ void l1_bucket_range(const uint64_t* __restrict__ l1_off, uint64_t seg_slots, uint32_t b1, uint64_t& beg, uint64_t& end) {
+    if (seg_slots) { beg = (uint64_t)b1 * seg_slots; end = beg + seg_slots; }
+    else { beg = l1_off[b1]; end = l1_off[b1 + 1]; }
 }
 
 // ---- level 2: one workgroup per level-1 bucket: histogram by sub-bucket, scan, scatter.  off2[r] = start of region r's run. ----
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
-     uint64_t* __restrict__ off2, const uint32_t* __restrict__ chunk_cur, uint32_t cpb, uint64_t* __restrict__ bend /* end of bucket b1's last run (chunked layout) */) {
+     uint64_t* __restrict__ off2, uint64_t seg_slots, uint64_t* __restrict__ bend /* end of bucket b1's last run (segmented layout) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
     const uint32_t tid = threadIdx.x;
     for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
         uint64_t beg, end;
-        l1_bucket_range(l1_off, chunk_cur, cpb, b1, beg, end);
+        l1_bucket_range(l1_off, seg_slots, b1, beg, end);
         lds_barrier();
         // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
         // the cursor array is free until the scan, so it doubles as the histogram
@@ -632,7 +472,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
                 key[j] = 0;
                 if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
             }
-            if (chunk_cur) {                                     // chunk padding (looked at only after all 16 loads are in flight)
+            if (seg_slots) {                                     // segment padding (looked at only after all 16 loads are in flight)
 #pragma unroll
                 for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);
             }
@@ -700,14 +540,14 @@ __device__ __forceinline__ void scatter_tile2_bounded(PartLds& L, const PartGeom
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
           uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
-          uint64_t ovf_cap, const uint32_t* __restrict__ chunk_cur, uint32_t cpb) {
+          uint64_t ovf_cap, uint64_t seg_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
     uint64_t* lim = reinterpret_cast<uint64_t*>(L.code);                   // code / bad are level-1 only: 8 KB for the run limits
     const uint32_t tid = threadIdx.x;
     for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
         uint64_t beg, end;
-        l1_bucket_range(l1_off, chunk_cur, cpb, b1, beg, end);
+        l1_bucket_range(l1_off, seg_slots, b1, beg, end);
         const uint64_t cap = p2_region_cap(end - beg, g.P2), obase = p2_out_base(beg, b1, g.P2);
         lds_barrier();
         if (tid < g.P2) {
@@ -725,7 +565,7 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
                 key[j] = 0;
                 if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
             }
-            if (chunk_cur) {                                     // chunk padding (looked at only after all 16 loads are in flight)
+            if (seg_slots) {                                     // segment padding (looked at only after all 16 loads are in flight)
 #pragma unroll
                 for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);
             }
@@ -859,7 +699,7 @@ constexpr int AP2_QCAP = 256;                                 // straggler queue
 constexpr int AP2_LANE_PROBES = 12;                           // probes a queue entry gets from its own lane before the wave takes it over
 constexpr uint64_t AP2_SEGMENT = 0x7FF00000ULL;               // k-mers per walk: < 2^31
 
-template <int BLOCK, int KP /* 16-byte key loads per lane that cover a region */, int U, int NR, bool STAMP = false>
+template <int BLOCK, int KP /* 16-byte key loads per lane that cover a region */, int U, int NR, bool STAMP = false, bool INLINE_CLAIM = false, bool DYN = true>
 __global__ void __launch_bounds__(BLOCK)
 k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
             uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n,
@@ -879,6 +719,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
     uint32_t* wqs = reinterpret_cast<uint32_t*>(lds_raw + (size_t)S * 12 + (size_t)NW * AP2_QCAP * 8) + (size_t)wave * AP2_QCAP;
     uint32_t new_distinct = 0;
     u32x4 kq[KP], cq[CP];
+    __shared__ unsigned long long s_next_chunk;               // chunks of the run are handed out to the waves as they come free
 
     auto run_end = [&](uint32_t r) -> uint64_t {
         if (bend && (r + 1) % g.P2 == 0) return bend[r / g.P2];
@@ -912,6 +753,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
 
         for (uint64_t sbeg = beg; sbeg < end; sbeg += AP2_SEGMENT) {        // one segment, normally
             const uint64_t n_run = (end - sbeg < AP2_SEGMENT ? end - sbeg : AP2_SEGMENT);
+            if (tid == 0) s_next_chunk = NW;                  // chunks 0 .. NW-1 are the waves' first ones
             lds_barrier();
             // counters that could wrap during this walk hand 2^31 to the side table (each lane looks at the quads it filled)
 #pragma unroll 1
@@ -1006,11 +848,18 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
             unsigned long long cur[U], nxt[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { const uint64_t i = (uint64_t)wave * CH + (uint64_t)u * 64 + lane; const unsigned long long v = l2_buf[sbeg + (i < n_run ? i : 0)]; cur[u] = i < n_run ? v : EMPTY; }
-            for (uint64_t c = wave; c < n_chunks; c += NW) {
+            // (static round-robin left the workgroup waiting ~12 K cycles per region for its slowest wave: the drains vary)
+            auto grab = [&]() -> uint64_t {
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(&s_next_chunk, 1ULL);
+                return __shfl(v, 0, 64);
+            };
+            for (uint64_t c = wave; c < n_chunks;) {
                 const unsigned long long t_a = now();
+                const uint64_t c_next = DYN ? grab() : c + NW;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {                 // next chunk: in flight behind this one (unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch)
-                    const uint64_t i = (c + NW) * CH + (uint64_t)u * 64 + lane;
+                    const uint64_t i = c_next * CH + (uint64_t)u * 64 + lane;
                     const unsigned long long v = l2_buf[sbeg + (i < n_run ? i : 0)];
                     nxt[u] = i < n_run ? v : EMPTY;
                 }
@@ -1019,21 +868,43 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
 #pragma unroll
                 for (int u = 0; u < U; ++u) { slot[u] = offset_of_hash(mix64(cur[u]), S); pend[u] = cur[u] != EMPTY; }
                 const unsigned long long t_b = now();
-                // Probe rounds: U reads in flight, one wait; a match adds 1 and is done, a foreign key moves on, an EMPTY slot stays
-                // where it is -- the next round sees whoever claimed it, and what still faces EMPTY after the last round is a new
-                // key: its claim is the queue's business.  Lanes that are done take no part in the LDS operations.
+                // Probe rounds: U reads in flight, one wait; a match adds 1 and is done, a foreign key moves on, an EMPTY slot is
+                // claimed.  Lanes that are done take no part in the LDS operations.
 #pragma unroll
                 for (int rr = 0; rr < NR; ++rr) {
                     unsigned long long seen[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) { seen[u] = EMPTY; if (pend[u]) seen[u] = rk[slot[u]]; }
+                    bool claim[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const bool hit = pend[u] && seen[u] == cur[u];
                         if (hit) add1(slot[u]);
                         pend[u] = pend[u] && !hit;
+                        claim[u] = pend[u] && seen[u] == EMPTY;
                         const uint32_t nx = slot[u] + 1 == S ? 0 : slot[u] + 1;
-                        slot[u] = (pend[u] && seen[u] != EMPTY) ? nx : slot[u];
+                        slot[u] = (pend[u] && !claim[u]) ? nx : slot[u];
+                    }
+                    // INLINE_CLAIM: new keys claimed right here, U CAS in flight, instead of through the queue.  Measured (same box,
+                    // bench config): 217 ms against 196 without -- the extra dependent round trip per probe round costs more than
+                    // the queue traffic it saves (a first round on an empty table gains, every later round loses).  Off.
+                    bool any_claim = false;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) any_claim = any_claim || claim[u];
+                    if (INLINE_CLAIM && __any(any_claim)) {
+                        unsigned long long got[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) { got[u] = 0; if (claim[u]) got[u] = atomicCAS(&rk[slot[u]], (unsigned long long)EMPTY, cur[u]); }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (claim[u]) {
+                                if (got[u] == EMPTY) ++new_distinct;
+                                const bool mine = got[u] == EMPTY || got[u] == cur[u];
+                                if (mine) add1(slot[u]);
+                                pend[u] = !mine;
+                                if (!mine) slot[u] = slot[u] + 1 == S ? 0 : slot[u] + 1;    // someone else's key landed there
+                            }
+                        }
                     }
                 }
                 if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
@@ -1072,10 +943,11 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                         for (int u = 0; u + 1 < U; ++u) { cur[u] = cur[u + 1]; slot[u] = slot[u + 1]; }
                     }
                 }
-                const bool last = c + NW >= n_chunks;                     // the wave's last chunk empties the queue
+                const bool last = c_next >= n_chunks;                     // the wave's last chunk empties the queue
                 while (q_n > (last ? 0u : 64u)) drain_pass(last);
 #pragma unroll
                 for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+                c = c_next;
                 if (STAMP) { const unsigned long long t_d = now(); st[1] += t_b - t_a; st[2] += t_c - t_b; st[3] += t_d - t_c; }
             }
         }

@@ -9,12 +9,12 @@ IFS=';' read -ra VARS <<< "${1:-1 83;2 83}"
 for v in "${VARS[@]}"; do
   set -- $v
   echo "== KATGPU_APPLY_V=$1 KATGPU_APPLY_UNR=$2"
-  KATGPU_APPLY_V=$1 KATGPU_APPLY_UNR=$2 timeout 240 python bench.py --reads $R --genome $G --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | python -c "
+  KATGPU_APPLY_V=$1 KATGPU_APPLY_UNR=$2 timeout 240 python bench.py --reads $R --genome $G --steps 2 --warmup 1 --no-cpu-baseline --no-e2e 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()
     if l.startswith('{'):
-        d = json.loads(l); print('ms_per_step', d['ms_per_step'], 'ok', d['counters_account_for_all_instances'], d['kernel_ms_per_step'])
+        d = json.loads(l); print('ms_per_step', d['ms_per_step'], 'ok', d['result_accounts_for_every_kmer'], d['kernel_ms_per_step'])
     elif l: print(l[:300])
 "
 done
