@@ -401,7 +401,7 @@ int Sect::main(int argc, char* argv[]) {                                        
     sect.setDumpHash(pa.has("dump_hash"));
     sect.setVerbose(pa.has("verbose"));
     sect.execute();         // the reference's main stops here: Sect::save() (the contamination matrix) is never called
-    if (getenv("KATGPU_SECT_SAVE")) sect.save();     // test hook: exercises Sect::save() through the CLI
+    if (getenv("KATGPU_TESTING") && getenv("KATGPU_SECT_SAVE")) sect.save();     // test hook: exercises Sect::save() through the CLI
     return 0;
 }
 

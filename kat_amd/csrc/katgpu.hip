@@ -260,6 +260,11 @@ static double now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
 }
 static const bool g_trace = getenv("KATGPU_TRACE") != nullptr;
+// Test hooks (KATGPU_TEST_*) and A/B switches are read only when KATGPU_TESTING is set: a production process ignores them, and the
+// kernels that honour one (the spill hook of the first-edition apply) are separate instantiations it never launches.
+// What a deployment may tune stays plain: KATGPU_TRACE, KATGPU_ARENA_FRACTION, KATGPU_RING_MB, KATGPU_PART_MIN_STARTS, KATGPU_INGEST_*.
+static const bool g_testing = getenv("KATGPU_TESTING") != nullptr;
+static const char* hook(const char* name) { return g_testing ? getenv(name) : nullptr; }
 
 static void pool_trim(katgpu_ctx* c) {
     for (auto& b : c->pool) hipFree(b.p);
@@ -300,9 +305,9 @@ static void pool_release(katgpu_ctx* c, void* p) {
     c->pool.push_back({p, bytes});
 }
 
-static const bool g_force_join = getenv("KATGPU_FORCE_JOIN") != nullptr;  // tests: take the join form whenever it is legal
-static const bool g_no_join = getenv("KATGPU_NO_JOIN") != nullptr;       // A/B switch: force comp's probe form
-static const uint32_t g_region_slots = getenv("KATGPU_TEST_REGION_SLOTS") ? (uint32_t)strtoul(getenv("KATGPU_TEST_REGION_SLOTS"), nullptr, 10) : REGION_SLOTS;
+static const bool g_force_join = hook("KATGPU_FORCE_JOIN") != nullptr;  // tests: take the join form whenever it is legal
+static const bool g_no_join = hook("KATGPU_NO_JOIN") != nullptr;       // A/B switch: force comp's probe form
+static const uint32_t g_region_slots = hook("KATGPU_TEST_REGION_SLOTS") ? (uint32_t)strtoul(hook("KATGPU_TEST_REGION_SLOTS"), nullptr, 10) : REGION_SLOTS;
 
 constexpr uint32_t MAX_REGION_SLOTS = 12288;        // 144 KB of LDS in the apply / join kernels
 
@@ -459,8 +464,8 @@ static int ensure_room(katgpu_table* t, uint64_t incoming) {
 // ------------------------------------------------------------------ counting --------------------------
 
 // test hooks (tests/test_gpu_parity.py): shrink the sweep threshold / the launch size so small inputs exercise them
-static const uint64_t g_test_sweep_thr = getenv("KATGPU_TEST_SWEEP_THR") ? strtoull(getenv("KATGPU_TEST_SWEEP_THR"), nullptr, 10) : 0;
-static const uint64_t g_test_max_starts = getenv("KATGPU_TEST_MAX_STARTS") ? strtoull(getenv("KATGPU_TEST_MAX_STARTS"), nullptr, 10) : 0;
+static const uint64_t g_test_sweep_thr = hook("KATGPU_TEST_SWEEP_THR") ? strtoull(hook("KATGPU_TEST_SWEEP_THR"), nullptr, 10) : 0;
+static const uint64_t g_test_max_starts = hook("KATGPU_TEST_MAX_STARTS") ? strtoull(hook("KATGPU_TEST_MAX_STARTS"), nullptr, 10) : 0;
 
 // k_count adds with no-return atomics and cannot see a 32-bit wrap; make one impossible.  Invariant: every counter
 // <= count_bound + unchecked_adds.  When the next launch could break "<= 2^32-1", k_sweep moves multiples of thr out of
@@ -518,23 +523,23 @@ static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
 // ------------------------------------------------------------------ partitioned counter (kg_partition.hpp) ----
 
 static const uint64_t g_part_min_starts = getenv("KATGPU_PART_MIN_STARTS") ? strtoull(getenv("KATGPU_PART_MIN_STARTS"), nullptr, 10) : (32ULL << 20);
-static const uint64_t g_test_round_items = getenv("KATGPU_TEST_ROUND_ITEMS") ? strtoull(getenv("KATGPU_TEST_ROUND_ITEMS"), nullptr, 10) : 0;
+static const uint64_t g_test_round_items = hook("KATGPU_TEST_ROUND_ITEMS") ? strtoull(hook("KATGPU_TEST_ROUND_ITEMS"), nullptr, 10) : 0;
 // share of the free HBM the partition arena may take (multi-GPU runs may lower it; bench.py sets 0.75 there)
 static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::min(0.95, std::max(0.05, atof(getenv("KATGPU_ARENA_FRACTION")))) : 0.85;
-static const uint32_t g_p1_wgs = getenv("KATGPU_P1_WGS") ? std::max<uint32_t>(1, (uint32_t)strtoul(getenv("KATGPU_P1_WGS"), nullptr, 10)) : 3;   // level-1 workgroups per CU
-static const uint32_t g_apply_v = getenv("KATGPU_APPLY_V") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_V"), nullptr, 10) : 2;   // 1: first-edition walk (A/B)
-static const uint32_t g_apply_unr = getenv("KATGPU_APPLY_UNR") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_UNR"), nullptr, 10) : 43;   // A/B: k-mers per lane x probe rounds
-static const uint32_t g_apply_block = getenv("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(getenv("KATGPU_APPLY_BLOCK"), nullptr, 10) : 0;   // 0: by region size
+static const uint32_t g_p1_wgs = hook("KATGPU_P1_WGS") ? std::max<uint32_t>(1, (uint32_t)strtoul(hook("KATGPU_P1_WGS"), nullptr, 10)) : 3;   // level-1 workgroups per CU
+static const uint32_t g_apply_v = hook("KATGPU_APPLY_V") ? (uint32_t)strtoul(hook("KATGPU_APPLY_V"), nullptr, 10) : 2;   // 1: first-edition walk (A/B)
+static const uint32_t g_apply_unr = hook("KATGPU_APPLY_UNR") ? (uint32_t)strtoul(hook("KATGPU_APPLY_UNR"), nullptr, 10) : 43;   // A/B: k-mers per lane x probe rounds
+static const uint32_t g_apply_block = hook("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(hook("KATGPU_APPLY_BLOCK"), nullptr, 10) : 0;   // 0: by region size
 // level 2 without its histogram pass (kg_partition.hpp: k_p2_fast): 0 = never, 1 = when the mean run is long enough for the
 // capacity slack to cover the noise, 2 = always (tests).  KATGPU_TEST_P2_OVF_CAP shrinks the overflow list (tests: forces the
 // fall back to the exact kernel).
 // level 1 without its counting pass (kg_partition.hpp: k_p1v2_scatter<true>, one fixed-capacity segment per workgroup and bucket):
 // 0 = never, 1 = for rounds of at least 64 M k-mers (the default), 2 = always (tests)
-static const uint32_t g_test_l1_cpb = getenv("KATGPU_TEST_L1_CPB") ? (uint32_t)strtoul(getenv("KATGPU_TEST_L1_CPB"), nullptr, 10) : 0;   // tests: segment capacity (forces overflow)
-static const uint32_t g_l1_fast = getenv("KATGPU_L1_FAST") ? (uint32_t)strtoul(getenv("KATGPU_L1_FAST"), nullptr, 10) : 1;
-static const uint32_t g_p2_fast = getenv("KATGPU_P2_FAST") ? (uint32_t)strtoul(getenv("KATGPU_P2_FAST"), nullptr, 10) : 1;
-static const uint64_t g_test_p2_ovf_cap = getenv("KATGPU_TEST_P2_OVF_CAP") ? strtoull(getenv("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
-static const uint32_t g_test_spill_mod = getenv("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(getenv("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
+static const uint32_t g_test_l1_cpb = hook("KATGPU_TEST_L1_CPB") ? (uint32_t)strtoul(hook("KATGPU_TEST_L1_CPB"), nullptr, 10) : 0;   // tests: segment capacity (forces overflow)
+static const uint32_t g_l1_fast = hook("KATGPU_L1_FAST") ? (uint32_t)strtoul(hook("KATGPU_L1_FAST"), nullptr, 10) : 1;
+static const uint32_t g_p2_fast = hook("KATGPU_P2_FAST") ? (uint32_t)strtoul(hook("KATGPU_P2_FAST"), nullptr, 10) : 1;
+static const uint64_t g_test_p2_ovf_cap = hook("KATGPU_TEST_P2_OVF_CAP") ? strtoull(hook("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
+static const uint32_t g_test_spill_mod = hook("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(hook("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 
 static bool part_geometry(const DevTable& d, PartGeom* g) {
     g->R = d.n_regions; g->S = d.region_slots; g->P1 = d.p1; g->P2 = d.p2;
@@ -543,7 +548,7 @@ static bool part_geometry(const DevTable& d, PartGeom* g) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static const bool g_test_grow_nomem = getenv("KATGPU_TEST_GROW_NOMEM") != nullptr;   // tests: table growth "fails" while the arena is busy
+static const bool g_test_grow_nomem = hook("KATGPU_TEST_GROW_NOMEM") != nullptr;   // tests: table growth "fails" while the arena is busy
 
 static void release_arena(katgpu_ctx* c) {
     if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
@@ -616,12 +621,18 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     if (!c->part_attr_set) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 12, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 12, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 8, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 16, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 16, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -837,11 +848,13 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 // small regions (a table created "like" a bigger one): 512-thread workgroups, four per CU instead of two
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
-#define KG_APPLY(B, ...) hipLaunchKernelGGL((k_p3_apply<B, __VA_ARGS__>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
+#define KG_APPLY1(B, SPT, HOOKED) hipLaunchKernelGGL((k_p3_apply<B, SPT, 4, HOOKED>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
+#define KG_APPLY(B, SPT) do { if (g_test_spill_mod) KG_APPLY1(B, SPT, true); else KG_APPLY1(B, SPT, false); } while (0)
                 const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
                 if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
                 else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) KG_APPLY(1024, 8); else KG_APPLY(1024, 12); }
 #undef KG_APPLY
+#undef KG_APPLY1
                 }
             }
             HIPCHK(c, hipGetLastError());
@@ -1561,7 +1574,7 @@ extern "C" int katgpu_table_merge_device32(katgpu_table* t, const uint64_t* dev_
     return merge_direct32(t, dev_keys, dev_counts, n);
 }
 
-static const bool g_no_merge_apply = getenv("KATGPU_NO_MERGE_APPLY") != nullptr;    // A/B switch + tests: every source through the direct path
+static const bool g_no_merge_apply = hook("KATGPU_NO_MERGE_APPLY") != nullptr;    // A/B switch + tests: every source through the direct path
 
 extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source* src) {
     if (!t || !src || n_src == 0 || g_lo > g_hi) return KATGPU_ERR_INVALID_ARG;

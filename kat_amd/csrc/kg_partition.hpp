@@ -582,7 +582,7 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
 // SPT = slots per lane held in registers while a region is prefetched (region_slots <= SPT * BLOCK).
 // Software pipeline: while region r's run is applied in LDS, region r' (the workgroup's next one) is already on its way
 // from HBM into registers, and r's write-back drains behind it -- the CU's memory pipe stays busy through the LDS phase.
-template <int BLOCK, int SPT, int BATCH = 4>
+template <int BLOCK, int SPT, int BATCH = 4, bool TEST_SPILL = false /* honours spill_mod: instantiated for the test suite only */>
 __global__ void __launch_bounds__(BLOCK)
 k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
            uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod,
@@ -646,7 +646,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
                   const uint64_t h = mix64(key);
                   slot = offset_of_hash(h, S);
                   probes = 0;
-                  if (!(spill_mod && __umulhi((uint32_t)(h >> 32), spill_mod) == 0)) break;   // test hook: 1 k-mer in spill_mod takes the spill path
+                  if (!(TEST_SPILL && spill_mod && __umulhi((uint32_t)(h >> 32), spill_mod) == 0)) break;   // test hook: 1 k-mer in spill_mod takes the spill path
                   spill[atomicAdd(spill_n, 1ULL)] = key;
                   ++u;
               }

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the library reads its test hooks (KATGPU_TEST_*, the A/B switches) only when this is set; subprocesses inherit it
+os.environ.setdefault("KATGPU_TESTING", "1")
+
 REFDATA = os.path.join(ROOT, "tests", "golden", "refdata")   # data files the reference's own tests hold (tests/data/)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

@@ -4,6 +4,7 @@
 set -u
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
+export KATGPU_TESTING=1     # the A/B switches are test hooks
 R=${2:-300000000}; G=${3:-1000000000}
 IFS=';' read -ra VARS <<< "${1:-1 83;2 83}"
 for v in "${VARS[@]}"; do
