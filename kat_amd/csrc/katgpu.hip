@@ -537,6 +537,7 @@ static const uint32_t g_apply_block = hook("KATGPU_APPLY_BLOCK") ? (uint32_t)str
 // 0 = never, 1 = for rounds of at least 64 M k-mers (the default), 2 = always (tests)
 static const uint32_t g_test_l1_cpb = hook("KATGPU_TEST_L1_CPB") ? (uint32_t)strtoul(hook("KATGPU_TEST_L1_CPB"), nullptr, 10) : 0;   // tests: segment capacity (forces overflow)
 static const uint32_t g_l1_fast = hook("KATGPU_L1_FAST") ? (uint32_t)strtoul(hook("KATGPU_L1_FAST"), nullptr, 10) : 1;
+static const bool g_p2_nopack = hook("KATGPU_P2_NOPACK") != nullptr;       // A/B: level 2 re-hashes in its copy-out even when the bucket could ride along
 static const uint32_t g_p2_fast = hook("KATGPU_P2_FAST") ? (uint32_t)strtoul(hook("KATGPU_P2_FAST"), nullptr, 10) : 1;
 static const uint64_t g_test_p2_ovf_cap = hook("KATGPU_TEST_P2_OVF_CAP") ? strtoull(hook("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
 static const uint32_t g_test_spill_mod = hook("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(hook("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
@@ -620,7 +621,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const size_t tile_starts = P1_TILE_STARTS;
     if (!c->part_attr_set) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_fast<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_fast<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -783,8 +785,12 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             const bool try_fast = p2_fast_ok && (g_p2_fast == 2 || items / g.R >= 1024);
             if (try_fast) {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-                hipLaunchKernelGGL(k_p2_fast, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2,
-                                   ovf_buf, ovf_n, ovf_cap, seg_slots);
+                if (k <= 27 && !g_p2_nopack)                 // 2k <= 54: the bucket rides in the staged word's top bits
+                    hipLaunchKernelGGL(k_p2_fast<true>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2,
+                                       ovf_buf, ovf_n, ovf_cap, seg_slots);
+                else
+                    hipLaunchKernelGGL(k_p2_fast<false>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2,
+                                       ovf_buf, ovf_n, ovf_cap, seg_slots);
             }
             if (try_fast || seg) {
                 HIPCHK(c, hipMemcpyAsync(&overflowed, ovf_n, sizeof overflowed, hipMemcpyDeviceToHost, c->stream));

@@ -492,6 +492,8 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 __device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t b1, uint32_t P2) { return beg + (beg >> 4) + (uint64_t)b1 * P2 * 16; }
 __device__ __host__ __forceinline__ uint64_t p2_region_cap(uint64_t n_b, uint32_t P2) { return (n_b + (n_b >> 4)) / P2 + 16; }
 
+// PACK: 2k <= 54, so the top 10 bits of a staged k-mer are free and carry its bucket through LDS: the copy-out need not hash again
+template <bool PACK>
 __device__ __forceinline__ void scatter_tile2_bounded(PartLds& L, const PartGeom g, const uint64_t (&key)[PART_ITEMS], uint32_t valid,
                                                       uint64_t* __restrict__ out, const uint64_t* lim, uint64_t* __restrict__ ovf_buf,
                                                       unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
@@ -516,13 +518,14 @@ __device__ __forceinline__ void scatter_tile2_bounded(PartLds& L, const PartGeom
     lds_barrier();
 #pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j)
-        if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = key[j];
+        if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = PACK ? key[j] | ((uint64_t)(br[j] >> 16) << 54) : key[j];
     lds_barrier();
     // copy-out, one staged k-mer per lane and step (as in k_p1v2_scatter): the bucket is recomputed from the key -- cheaper than
     // a third LDS array -- and the steps are independent, where a loop over buckets kept a third of the lanes busy
     for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
-        const uint64_t key1 = L.staging[idx];
-        const uint32_t b = digit2_of_hash(mix64(key1), g.P2);
+        const uint64_t staged = L.staging[idx];
+        const uint64_t key1 = PACK ? staged & ((1ULL << 54) - 1) : staged;
+        const uint32_t b = PACK ? (uint32_t)(staged >> 54) : digit2_of_hash(mix64(key1), g.P2);
         const uint64_t dst = L.cursor[b] + (idx - L.off[b]);
         if (dst < lim[b]) out[dst] = key1;
         else {                                                             // beyond the run's capacity: the overflow list
@@ -537,6 +540,7 @@ __device__ __forceinline__ void scatter_tile2_bounded(PartLds& L, const PartGeom
     }
 }
 
+template <bool PACK>
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
           uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
@@ -570,7 +574,7 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
                 for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);
             }
             lds_barrier();
-            scatter_tile2_bounded(L, g, key, valid, l2_buf, lim, ovf_buf, ovf_n, ovf_cap);
+            scatter_tile2_bounded<PACK>(L, g, key, valid, l2_buf, lim, ovf_buf, ovf_n, ovf_cap);
         }
         lds_barrier();
         if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = (uint32_t)(L.cursor[tid] - (obase + (uint64_t)tid * cap));
