@@ -85,6 +85,9 @@ int katgpu_table_create(katgpu_ctx* ctx, uint32_t k, int canonical, uint64_t siz
  * joins the two region against region in LDS instead of probing HBM.  Falls back to an own grid if the sizes are too far apart. */
 int katgpu_table_create_like(katgpu_ctx* ctx, const katgpu_table* like, uint32_t k, int canonical, uint64_t size_hint,
                              int disable_grow, katgpu_table** out);
+/* Files and host buffers take the same counter as device-resident input: the parsed stream goes through pinned staging into
+ * two device rings (KATGPU_RING_MB, default 1024 each); a full ring is counted (partition rounds for anything of size) on a
+ * worker thread while the parser fills the other. */
 int katgpu_count_files(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p);
 /* A base stream is what the reference's parser hands to mer_iterator: sequence bytes, records separated by any
  * byte outside ACGTacgt (the reference inserts 'N', mer_overlap_sequence_parser.hpp:202,234).  Every k-window

@@ -529,6 +529,7 @@ static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::mi
 static const uint32_t g_p1_wgs = hook("KATGPU_P1_WGS") ? std::max<uint32_t>(1, (uint32_t)strtoul(hook("KATGPU_P1_WGS"), nullptr, 10)) : 3;   // level-1 workgroups per CU
 static const uint32_t g_apply_v = hook("KATGPU_APPLY_V") ? (uint32_t)strtoul(hook("KATGPU_APPLY_V"), nullptr, 10) : 2;   // 1: first-edition walk (A/B)
 static const uint32_t g_apply_unr = hook("KATGPU_APPLY_UNR") ? (uint32_t)strtoul(hook("KATGPU_APPLY_UNR"), nullptr, 10) : 43;   // A/B: k-mers per lane x probe rounds
+static const bool g_apply_noinline = hook("KATGPU_APPLY_NOINLINE") != nullptr;   // A/B: no inline claims in a table's first round
 static const uint32_t g_apply_block = hook("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(hook("KATGPU_APPLY_BLOCK"), nullptr, 10) : 0;   // 0: by region size
 // level 2 without its histogram pass (kg_partition.hpp: k_p2_fast): 0 = never, 1 = when the mean run is long enough for the
 // capacity slack to cover the noise, 2 = always (tests).  KATGPU_TEST_P2_OVF_CAP shrinks the overflow list (tests: forces the
@@ -641,10 +642,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 4, 4, 3, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 2, 4, 3, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         c->part_attr_set = true;
     }
@@ -826,13 +828,18 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                     const uint32_t per_cu2 = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds2 + 512), 2048 / blk));
                     const uint32_t grid2 = std::min<uint32_t>(g.R, W2 * per_cu2);
 #define KG_APPLY2(B, KP, U, NR) hipLaunchKernelGGL((k_p3_apply2<B, KP, U, NR>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end)
+                    // a table that is still empty sees nothing but new keys in this round: they are claimed inside the probe rounds
+                    // (INLINE_CLAIM) instead of all going through the queues; any later round loses by that (kg_partition.hpp)
+                    const bool fresh = t->distinct == 0 && !g_apply_noinline;
+#define KG_APPLY2F(B, KP) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, false, true, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr)
+                    if (fresh && g_apply_unr == 43) { if (blk == 512) { if (g.S <= 2048) KG_APPLY2F(512, 2); else KG_APPLY2F(512, 4); } else KG_APPLY2F(1024, 4); }
+                    else
+#undef KG_APPLY2F
                     if (blk == 512) { if (g.S <= 2048) KG_APPLY2(512, 2, 4, 3); else KG_APPLY2(512, 4, 4, 3); }
                     else if (g_apply_unr == 82) KG_APPLY2(1024, 4, 8, 2);
                     else if (g_apply_unr == 84) KG_APPLY2(1024, 4, 8, 4);
                     else if (g_apply_unr == 83) KG_APPLY2(1024, 4, 8, 3);
                     else if (g_apply_unr == 430) hipLaunchKernelGGL((k_p3_apply2<1024, 4, 4, 3, false, false, false>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr);
-                    else if (g_apply_unr == 431) hipLaunchKernelGGL((k_p3_apply2<1024, 4, 4, 3, false, true, false>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr);
-                    else if (g_apply_unr == 432) hipLaunchKernelGGL((k_p3_apply2<1024, 4, 4, 3, false, false, true>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr);
                     else if (g_apply_unr == 1043 || g_apply_unr == 1083) {      // cycle stamps of wave 0 (diagnostic; KATGPU_TRACE prints them)
                         unsigned long long* d_st = nullptr;
                         HIPCHK(c, hipMalloc((void**)&d_st, 64));

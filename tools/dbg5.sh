@@ -13,6 +13,6 @@ for l in sys.stdin:
     elif l: print(l[:300])"
 }
 for i in 1 2; do
-echo "== nopack"; KATGPU_P2_NOPACK=1 run
-echo "== pack"; run
+echo "== noinline"; KATGPU_APPLY_NOINLINE=1 run
+echo "== inline in the first round"; run
 done
