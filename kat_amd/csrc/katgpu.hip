@@ -70,6 +70,7 @@ struct katgpu_table {
     // overflow guard of the unchecked (no-return) +1 adds: no 32-bit counter exceeds count_bound + unchecked_adds
     uint64_t count_bound = 0;    // largest counter value possible at the last sweep (0 for a fresh table)
     uint64_t unchecked_adds = 0; // window starts launched through k_count since then
+    bool retrying = false;       // retry_failed is at work (refresh_counters must not re-enter it)
     uint32_t n_regrows = 0;      // how often the table had to grow (the host mirror words the reference's warning from it)
     uint8_t carry[64];           // last k-1 bytes of the previous host batch of the current file
     uint32_t carry_n = 0;
@@ -313,7 +314,13 @@ constexpr uint32_t MAX_REGION_SLOTS = 12288;        // 144 KB of LDS in the appl
 
 // like_p1/like_p2 != 0: adopt that region grid (so that comp can join region against region) and take up the capacity in the
 // region size, if a region of the resulting size still fits LDS.
-static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1 = 0, uint32_t like_p2 = 0) {
+// Minimizer regions (kg_device.hpp): tables of at least g_mz_min_regions regions key their regions by the k-mer's minimizer, which is
+// what lets the super-k-mer counter partition runs of k-mers instead of k-mers.  Below that the spread of the minimizers' weights
+// would not average out over a region.  like_mz: -1 = decide by size, else adopt (a table compared or merged with another must
+// share its region function as well as its grid).
+static const uint32_t g_mz_min_regions = hook("KATGPU_MZ_MIN_REGIONS") ? (uint32_t)strtoul(hook("KATGPU_MZ_MIN_REGIONS"), nullptr, 10) : 0xFFFFFFFFu;
+
+static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1 = 0, uint32_t like_p2 = 0, int like_mz = -1) {
     DevTable d{};
     const uint64_t like_r = (uint64_t)like_p1 * like_p2;
     // capacity is a whole number of regions (kg_device.hpp: Probe); a table smaller than one region is a single short region
@@ -332,6 +339,8 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
     }
     cap = (uint64_t)d.n_regions * d.region_slots;
     d.cap = cap; d.k = k; d.canonical = canonical ? 1 : 0;
+    const bool adopted = like_r > 1 && d.p1 == like_p1 && d.p2 == like_p2;
+    d.mz = k > 32 ? 0 : (adopted && like_mz >= 0 ? (uint32_t)like_mz : (d.n_regions > 1 && d.n_regions >= g_mz_min_regions ? 1u : 0u));
     const double t0 = now_ms();
     const bool wide = k > 32;                                  // two key words per slot (kg_device.hpp "wide keys"), one block
     const size_t key_bytes = cap * sizeof(uint64_t) * (wide ? 2 : 1);
@@ -342,8 +351,9 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
     if (e == hipSuccess) e = hipMalloc(&d.ovf_keys, OVF_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&d.ovf_hi, OVF_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&d.ctrs, CTR_WORDS * sizeof(uint64_t));
+    if (e == hipSuccess && d.mz) e = hipMalloc(&d.fail_buf, (size_t)2 * FAIL_CAP * sizeof(uint64_t));
     if (e != hipSuccess) {
-        pool_release(c, d.keys); pool_release(c, d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
+        pool_release(c, d.keys); pool_release(c, d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs); hipFree(d.fail_buf);
         return fail(c, KATGPU_ERR_NOMEM, "device allocation of a %llu-slot table failed: %s", (unsigned long long)cap, hipGetErrorString(e));
     }
     HIPCHK(c, hipMemsetAsync(d.keys, 0xFF, key_bytes, c->stream));
@@ -358,7 +368,7 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
 
 static void free_dev_table(katgpu_ctx* c, DevTable& d) {
     pool_release(c, d.keys); pool_release(c, d.counts);
-    hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
+    hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs); hipFree(d.fail_buf);
     d = DevTable{};
 }
 
@@ -386,7 +396,7 @@ extern "C" int katgpu_table_create_like(katgpu_ctx* c, const katgpu_table* like,
     katgpu_table* t = new katgpu_table();
     t->ctx = c; t->disable_grow = disable_grow;
     int rc = (k > 32) != (like->d.k > 32) ? alloc_dev_table(c, k, canonical, cap, &t->d)     // no common grid across key widths
-                                          : alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2);
+                                          : alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2, (int)like->d.mz);
     if (rc) { delete t; return rc; }
     *out = t;
     return KATGPU_OK;
@@ -404,6 +414,8 @@ extern "C" uint32_t katgpu_table_k(const katgpu_table* t) { return t ? t->d.k : 
 extern "C" uint32_t katgpu_table_regrows(const katgpu_table* t) { return t ? t->n_regrows : 0; }
 extern "C" int katgpu_table_canonical(const katgpu_table* t) { return t ? (int)t->d.canonical : 0; }
 
+static int retry_failed(katgpu_table* t, uint64_t n_failed);
+
 // read the counter block back (one small D2H; synchronises the compute stream)
 static int refresh_counters(katgpu_table* t) {
     katgpu_ctx* c = t->ctx;
@@ -416,6 +428,7 @@ static int refresh_counters(katgpu_table* t) {
     t->distinct = d + (t->ones ? 1 : 0);
     t->n_ovf = (uint32_t)h[CTR_OVF_USED];
     if (h[CTR_FULL]) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
+    if (h[CTR_FAIL_N] && !t->retrying) return retry_failed(t, h[CTR_FAIL_N]);
     return KATGPU_OK;
 }
 
@@ -424,7 +437,7 @@ static int refresh_counters(katgpu_table* t) {
 static int regrow(katgpu_table* t, uint64_t new_cap) {
     katgpu_ctx* c = t->ctx;
     DevTable nd{};
-    int rc = alloc_dev_table(c, t->d.k, t->d.canonical, new_cap, &nd, t->d.n_regions > 1 ? t->d.p1 : 0, t->d.n_regions > 1 ? t->d.p2 : 0);
+    int rc = alloc_dev_table(c, t->d.k, t->d.canonical, new_cap, &nd, t->d.n_regions > 1 ? t->d.p1 : 0, t->d.n_regions > 1 ? t->d.p2 : 0, (int)t->d.mz);
     if (rc) return rc;
     {
         ScopedTimer tm(c, KATGPU_K_REGROW, t->d.cap);
@@ -438,6 +451,39 @@ static int regrow(katgpu_table* t, uint64_t new_cap) {
     ++t->n_regrows;
     t->count_bound = 0xFFFFFFFFULL;           // full counts were folded back into the slots: the next unchecked launch sweeps first
     t->unchecked_adds = 0;
+    return refresh_counters(t);
+}
+
+// Minimizer-region tables: k-mers whose region was full were parked by the kernels (kg_device.hpp: table_park).  Grow and add them
+// again -- a growth re-places every k-mer, and may park some itself, hence the loop.  With growth disabled a full region is what a
+// full table is to the reference: "Hash full".
+static int retry_failed(katgpu_table* t, uint64_t n_failed) {
+    katgpu_ctx* c = t->ctx;
+    if (t->disable_grow) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
+    struct Guard { katgpu_table* t; explicit Guard(katgpu_table* t_) : t(t_) { t->retrying = true; } ~Guard() { t->retrying = false; } } guard(t);
+    for (int attempt = 0; attempt < 12 && n_failed; ++attempt) {
+        const uint64_t n = std::min<uint64_t>(n_failed, FAIL_CAP);
+        uint64_t* tmp = nullptr;
+        HIPCHK(c, hipMalloc((void**)&tmp, n * 16));
+        HIPCHK(c, hipMemcpyAsync(tmp, t->d.fail_buf, n * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tmp + n, t->d.fail_buf + FAIL_CAP, n * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(&t->d.ctrs[CTR_FAIL_N], 0, sizeof(uint64_t), c->stream));
+        if (g_trace) fprintf(stderr, "[katgpu] %llu k-mers found their (minimizer) region full: growing %llu -> %llu slots\n", (unsigned long long)n_failed,
+                             (unsigned long long)t->d.cap, (unsigned long long)t->d.cap * 2);
+        int rc = regrow(t, t->d.cap * 2);                         // (its refresh_counters does not recurse: `retrying`)
+        if (rc == KATGPU_OK) {
+            ScopedTimer tm(c, KATGPU_K_MERGE, n);
+            hipLaunchKernelGGL(k_merge, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, t->d, (const uint64_t*)tmp, (const uint64_t*)(tmp + n), n);
+        }
+        uint64_t h[CTR_WORDS];
+        if (rc == KATGPU_OK && (hipMemcpyAsync(h, t->d.ctrs, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
+            rc = fail(c, KATGPU_ERR_DEVICE, "retry of parked k-mers");
+        hipFree(tmp);
+        if (rc) return rc;
+        if (h[CTR_FULL]) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
+        n_failed = h[CTR_FAIL_N];
+    }
+    if (n_failed) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
     return refresh_counters(t);
 }
 
@@ -903,7 +949,7 @@ static int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
     const size_t n_starts = n - k + 1;
     // Large, aligned inputs go through the partitioned counter (no global atomic per k-mer); whatever it leaves (nothing,
     // normally) and everything small goes through the direct kernel below.
-    while (!t->d.keys_b && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
+    while (!t->d.keys_b && !t->d.mz && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
         size_t done = 0;                        // returns early (done < remaining) when a table growth cost it the arena
         int prc = count_partitioned(t, dev_bases + pos, n - pos, &done);
         if (prc) return prc;
@@ -1463,7 +1509,7 @@ extern "C" int katgpu_table_geometry(const katgpu_table* t, katgpu_geometry* g) 
     if (!t || !g) return KATGPU_ERR_INVALID_ARG;
     if (t->d.keys_b) return fail(t->ctx, KATGPU_ERR_K, "the multi-GPU exchange is not available for k > 32 (k = %u)", t->d.k);
     g->k = t->d.k; g->canonical = t->d.canonical; g->n_regions = t->d.n_regions; g->region_slots = t->d.region_slots;
-    g->p1 = t->d.p1; g->p2 = t->d.p2; g->capacity = t->d.cap;
+    g->p1 = t->d.p1 | (t->d.mz << 31); g->p2 = t->d.p2; g->capacity = t->d.cap;      // bit 31 of p1: minimizer regions -- "same grid" includes the region function
     return KATGPU_OK;
 }
 
@@ -1605,7 +1651,7 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
     for (uint32_t i = 0; i < n_src; ++i) {
         if (src[i].n_records == 0) continue;
         if (!src[i].dev_keys || !src[i].dev_counts) return KATGPU_ERR_INVALID_ARG;
-        const bool ok = !g_no_merge_apply && src[i].dev_region_counts && src[i].p1 == t->d.p1 && src[i].p2 == t->d.p2 && g_hi <= t->d.n_regions &&
+        const bool ok = !g_no_merge_apply && src[i].dev_region_counts && src[i].p1 == (t->d.p1 | (t->d.mz << 31)) && src[i].p2 == t->d.p2 && g_hi <= t->d.n_regions &&
                         (size_t)t->d.region_slots * 12 <= 150 * 1024;
         (ok ? aligned : direct).push_back(i);
     }
@@ -1670,7 +1716,7 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
         }
         hipFree(tmp);
         if (rc) return rc;
-        if (ndef && (src[aligned[a0]].p1 != t->d.p1 || src[aligned[a0]].p2 != t->d.p2)) {      // the growth changed the grid: the rest goes direct
+        if (ndef && (src[aligned[a0]].p1 != (t->d.p1 | (t->d.mz << 31)) || src[aligned[a0]].p2 != t->d.p2)) {      // the growth changed the grid: the rest goes direct
             for (size_t a = a0 + na; a < aligned.size(); ++a) direct.push_back(aligned[a]);
             break;
         }
@@ -1766,7 +1812,7 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     }
     // Join form (region r of one table against region r of the other, in LDS) whenever the two tables share the region grid
     // and the probe key equals the stored key; probe form (random HBM probes) otherwise.
-    const bool same_grid = !wide && t1->d.p1 == t2->d.p1 && t1->d.p2 == t2->d.p2 && t1->d.n_regions > 1 && !g_no_join;   // the join holds 12-byte slots
+    const bool same_grid = !wide && t1->d.p1 == t2->d.p1 && t1->d.p2 == t2->d.p2 && t1->d.mz == t2->d.mz && t1->d.n_regions > 1 && !g_no_join;   // the join holds 12-byte slots
     const bool ident1 = t1->d.canonical || !canon2;          // pass 1 probes canonical(key) iff input 2 is canonical
     const bool ident2 = t2->d.canonical != 0;                // pass 2 always probes canonical(key)
     const size_t join1 = ((lds1 + 15) & ~(size_t)15) + (size_t)t2->d.region_slots * 12, join2 = ((lds2 + 15) & ~(size_t)15) + (size_t)t1->d.region_slots * 12;

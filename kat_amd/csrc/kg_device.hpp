@@ -26,7 +26,9 @@ constexpr int CTR_ONES = 64;       // count of the all-ones key
 constexpr int CTR_OVF_USED = 65;   // entries in the carry table
 constexpr int CTR_FULL = 66;       // != 0: an insert ran out of probes / carry table full
 constexpr int CTR_SCRATCH = 67;    // cursors / scratch for export & partition (8 words)
+constexpr int CTR_FAIL_N = 76;     // k-mers parked in fail_buf: their region was full (minimizer-region tables, below)
 constexpr int CTR_WORDS = 80;
+constexpr uint32_t FAIL_CAP = 1u << 20;   // entries of a table's fail list
 
 struct DevTable {
     uint64_t* keys;
@@ -41,6 +43,8 @@ struct DevTable {
     uint64_t* ctrs;       // CTR_WORDS
     uint32_t k;
     uint32_t canonical;
+    uint32_t mz;          // region keyed by the k-mer's minimizer instead of its hash ("minimizer regions" below); one-word tables only
+    uint64_t* fail_buf;   // mz tables: [FAIL_CAP keys | FAIL_CAP amounts] of inserts that found their region full (the host grows and retries)
 };
 
 // ---- packed k-mer arithmetic (first base in the MSBs, A=0 C=1 G=2 T=3) ----
@@ -77,6 +81,47 @@ __device__ __forceinline__ uint32_t digit1_of_hash(uint64_t h, uint32_t p1) { re
 __device__ __forceinline__ uint32_t digit2_of_hash(uint64_t h, uint32_t p2) { return __umulhi((uint32_t)(h >> 12), p2); }
 __device__ __forceinline__ uint32_t region_of_hash(uint64_t h, uint32_t p1, uint32_t p2) { return digit1_of_hash(h, p1) * p2 + digit2_of_hash(h, p2); }
 __device__ __forceinline__ uint32_t offset_of_hash(uint64_t h, uint32_t region_slots) { return __umulhi((uint32_t)h, region_slots); }
+// ---- minimizer regions (DevTable::mz) ----
+// The super-k-mer counter (kg_superkmer.hpp) partitions RUNS of consecutive k-mers, not k-mers, so every k-mer of a run must land
+// in one region: the region is a function of the k-mer's MINIMIZER -- the m-mer (m = min(k, 16)) of the k-mer whose canonical
+// form hashes lowest.  Both strands of a k-mer see the same canonical m-mers, so a k-mer and its reverse complement share the
+// region whether or not the table is canonical.  Inside the region a k-mer sits where its own hash puts it, as in any table.
+constexpr uint32_t MZ_M = 16;
+__device__ __forceinline__ uint32_t mz_order(uint32_t x) {        // lowbias32: a bijection on 32 bits; the minimizer order
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t mz_mix(uint32_t x) {          // triple32: region digits come from this second mix of the winner
+    x ^= x >> 17; x *= 0xed5ad4bbU; x ^= x >> 11; x *= 0xac4c1b51U; x ^= x >> 15; x *= 0x31848babU; x ^= x >> 14;
+    return x;
+}
+// order value of the 2m-bit m-mer mm (first base in the MSBs of its 2m bits)
+__device__ __forceinline__ uint32_t mz_value(uint32_t mm, uint32_t m) {
+    uint32_t r = __brev(mm);
+    r = ((r >> 1) & 0x55555555U) | ((r & 0x55555555U) << 1);
+    r = ~r >> (32 - 2 * m);
+    return mz_order(r < mm ? r : mm);
+}
+__device__ __forceinline__ void mz_digits(uint32_t omin, uint32_t p1, uint32_t p2, uint32_t& b1, uint32_t& b2) {
+    const uint32_t h = mz_mix(omin);
+    b1 = __umulhi(h, p1);
+    b2 = __umulhi(mz_order(h ^ 0x5bd1e995U), p2);
+}
+// region of one packed k-mer: the slow form (w = k - m + 1 m-mers), for the direct path, lookups, regrow and merge
+__device__ __forceinline__ uint32_t region_mz(uint64_t key, uint32_t k, uint32_t p1, uint32_t p2) {
+    const uint32_t m = k < MZ_M ? k : MZ_M, w = k - m + 1;
+    const uint64_t top = key << (64 - 2 * k);                        // first base in bit 63
+    uint32_t omin = 0xFFFFFFFFU;
+    for (uint32_t i = 0; i < w; ++i) {
+        const uint32_t mm = (uint32_t)((top << (2 * i)) >> (64 - 2 * m));
+        const uint32_t o = mz_value(mm, m);
+        omin = o < omin ? o : omin;
+    }
+    uint32_t b1, b2;
+    mz_digits(omin, p1, p2, b1, b2);
+    return b1 * p2 + b2;
+}
+
 struct Probe {
     uint64_t base;   // first slot of the region
     uint32_t s;      // current offset inside the region
@@ -88,7 +133,7 @@ __device__ __forceinline__ Probe probe_start(const uint64_t key, const DevTable&
     const uint64_t h = mix64(key);
     Probe p;
     const uint32_t region_slots = t.region_slots;
-    p.base = (uint64_t)region_of_hash(h, t.p1, t.p2) * region_slots;
+    p.base = (uint64_t)(t.mz ? region_mz(key, t.k, t.p1, t.p2) : region_of_hash(h, t.p1, t.p2)) * region_slots;
     p.s = offset_of_hash(h, region_slots);
     p.S = region_slots;
     return p;
@@ -129,6 +174,18 @@ __device__ __forceinline__ uint64_t slot_count(const DevTable& t, uint64_t pos, 
     return c;
 }
 
+// An insert that walked its whole region without finding room.  Hash-placed regions never fill (the host keeps the table under
+// its fill limit and the hash spreads k-mers evenly); a minimizer-keyed region can, when one minimizer owns more distinct k-mers
+// than the average region holds.  Such k-mers are parked; the host grows the table and adds them again (katgpu.hip: retry_failed).
+__device__ inline bool table_park(const DevTable& t, uint64_t key, uint64_t amount) {
+    if (t.fail_buf) {
+        const unsigned long long at = atomicAdd((unsigned long long*)&t.ctrs[CTR_FAIL_N], 1ULL);
+        if (at < FAIL_CAP) { t.fail_buf[at] = key; t.fail_buf[FAIL_CAP + at] = amount; return false; }
+    }
+    atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 1ULL);
+    return false;
+}
+
 // ---- insert-or-add: the replacement for array_base::add (large_hash_array.hpp:298-302) ----
 // Claim = CAS on the key word; add = returning 32-bit atomic add whose carry is chained.  The first look at a
 // slot is a plain load: keys are write-once, so a stale "empty" only costs the CAS we would have issued anyway.
@@ -152,8 +209,7 @@ __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint6
             return true;
         }
     }
-    atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 1ULL);
-    return false;
+    return table_park(t, key, amount);
 }
 
 // +1 on the hot path of K1: same claim protocol, but the counter add is a NO-RETURN atomic, so a lane never waits for
@@ -176,8 +232,7 @@ __device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint3
             return true;
         }
     }
-    atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 1ULL);
-    return false;
+    return table_park(t, key, 1ULL);
 }
 
 // ---- lookup: get_val_for_key (large_hash_array.hpp:358-376) on an immutable table ----
