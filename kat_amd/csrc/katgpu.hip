@@ -4,6 +4,7 @@
 #include "kg_ingest.hpp"
 #include "kg_kernels.hpp"
 #include "kg_partition.hpp"
+#include "kg_superkmer.hpp"
 #include "kg_wide.hpp"
 
 #include <algorithm>
@@ -757,7 +758,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             if (lost) break;                                                      // the caller re-enters with a fresh arena
         }
         PartGeom g;
-        if (!part_geometry(t->d, &g)) break;                                      // table too large for two levels: direct path
+        if (!part_geometry(t->d, &g) || t->d.mz) break;                           // table too large for two levels: direct path; grown into minimizer regions: the other counter
         // (the segmented level 1 sizes its segments from this ratio, so it wants it even when one round takes everything)
         if (!ratio_known && !g_test_round_items && (n_starts - pos > round_items || (l1_fast_ok && n_starts - pos >= ((size_t)64 << 20)))) {
             const size_t probe_m = std::min<size_t>(n_starts - pos, (size_t)64 << 20) / tile_starts * tile_starts;
@@ -939,6 +940,209 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     return refresh_counters(t);
 }
 
+// ------------------------------------------------------------------ super-k-mer counter (kg_superkmer.hpp) ----
+// The partitioned counter for tables with minimizer regions: rounds of  S1 (items of up to 8 consecutive k-mers, sorted by the
+// level-1 digit into per-workgroup segments; exact count + scan + scatter when a segment list overflows or the round is small)
+// -> S2 (exact level 2) -> S3 (apply).  Same contract as count_partitioned.
+static int count_superkmer(katgpu_table* t, const uint8_t* dev_bases, size_t n, size_t* done) {
+    katgpu_ctx* c = t->ctx;
+    const uint32_t k = t->d.k;
+    const size_t n_starts = n - k + 1;
+    *done = 0;
+    c->arena_borrowed = false;
+    if (!g_test_round_items && !t->disable_grow && t->d.cap < n_starts / 16) {
+        uint64_t nc = t->d.cap; while (nc < n_starts / 16) nc *= 2;
+        int grc = regrow(t, nc);
+        if (grc) return grc;
+    }
+    const uint32_t W = (uint32_t)c->n_cu * 2;                                   // level-1 workgroups: two per CU (68 KB of LDS each)
+    const uint32_t W2 = (uint32_t)c->n_cu;
+    const size_t tile_starts = P1_TILE_STARTS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_s2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(S2Lds)));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_apply<1024, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_apply<1024, 4, 8, 3, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_apply<512, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_apply<512, 2, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    // ---- arena: [hist1 | offs | l1_off | off2 | cnt2 | kmers | spill_n, ovf_n | L1 items | L2 items | overflow items]; 16-byte items ----
+    constexpr size_t SEG_PAD = 16;
+    const size_t fixed_items = (size_t)W * MAX_PARTS * SEG_PAD;
+    const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) + align_up((MAX_PARTS + 1) * 8, 256) +
+                               align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) + align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256) + align_up((size_t)W * 8, 256) + 256 +
+                               (2 * fixed_items + fixed_items / 16 + 8192) * 16;
+    size_t want_starts = n_starts;
+    if (g_test_round_items) want_starts = std::min<size_t>(want_starts, g_test_round_items);
+    const size_t want_bytes = small_bytes + 8 * want_starts + ((size_t)1 << 20);                      // ~0.2 items per start x 16 B x (level 1 + level 2 + slack)
+    if (c->arena_bytes < want_bytes) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        free_b += c->arena_bytes;
+        const size_t bytes = std::min<size_t>(want_bytes, (size_t)(g_arena_fraction * (double)free_b));
+        if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 8 * std::min<size_t>(want_starts, (size_t)64 << 20)) {
+            if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
+            if (!g_test_round_items && bytes < small_bytes + 8 * ((size_t)1 << 20)) return KATGPU_OK;
+            if (hipMalloc((void**)&c->arena, bytes) != hipSuccess) { (void)hipGetLastError(); c->arena = nullptr; return KATGPU_OK; }
+            c->arena_bytes = bytes;
+        }
+    }
+    struct Busy { katgpu_ctx* c; explicit Busy(katgpu_ctx* c_) : c(c_) { c->arena_busy = true; } ~Busy() { c->arena_busy = false; } } busy(c);
+    uint8_t* a = c->arena;
+    uint32_t* hist1 = (uint32_t*)a;               a += align_up((size_t)W * MAX_PARTS * 4, 256);
+    uint64_t* offs = (uint64_t*)a;                a += align_up((size_t)W * MAX_PARTS * 8, 256);
+    uint64_t* l1_off = (uint64_t*)a;              a += align_up((MAX_PARTS + 1) * 8, 256);
+    uint64_t* off2 = (uint64_t*)a;                a += align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256);
+    uint32_t* cnt2 = (uint32_t*)a;                a += align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256);
+    unsigned long long* kmers = (unsigned long long*)a;   a += align_up((size_t)W * 8, 256);
+    unsigned long long* spill_n = (unsigned long long*)a;
+    unsigned long long* ovf_n = spill_n + 1;      a += 256;
+    // what is left: the level-1 buffer, the level-2 buffer (it mirrors the level-1 layout) and the overflow list (1/32 of a buffer)
+    const size_t item_room = (size_t)(c->arena + c->arena_bytes - a) / 16;
+    const size_t l1_cap = (size_t)((double)item_room * 32.0 / 65.0);
+    const size_t ovf_cap_items = g_test_p2_ovf_cap ? (size_t)g_test_p2_ovf_cap : l1_cap / 32;
+    if (l1_cap < fixed_items + 4096) return KATGPU_OK;
+    u32x4* l1_items = (u32x4*)a;
+    u32x4* l2_items = l1_items + l1_cap;
+    u32x4* ovf_items = l2_items + l1_cap;
+    uint64_t* spill_buf = (uint64_t*)l1_items;                                     // the apply's spilled k-mers: level 1 is dead by then
+    const uint64_t spill_cap = (uint64_t)l1_cap * 2;
+    bool seg_ok = g_l1_fast != 0;
+
+    double items_per_start = 0.0;                                                  // measured on a prefix before the first round
+    size_t pos = 0;
+    while (pos < n_starts) {
+        int rc = refresh_counters(t);
+        if (rc) return rc;
+        if ((double)t->distinct > 0.6 * (double)t->d.cap) {
+            bool lost = false;
+            rc = grow_beside_arena(t, 0, t->d.cap * 2, nullptr, 0, &lost);
+            if (rc) return rc;
+            if (lost) break;
+        }
+        PartGeom g;
+        if (!part_geometry(t->d, &g) || !t->d.mz || g.S % 4 || g.S < 64 || g.S > 8192) break;       // not a table for this counter: direct path
+        if (items_per_start == 0.0) {
+            const size_t probe_m = std::max<size_t>(tile_starts, std::min<size_t>(n_starts - pos, (size_t)64 << 20) / tile_starts * tile_starts);
+            const uint64_t pt = (std::min(probe_m, n_starts - pos) + tile_starts - 1) / tile_starts, ptw = (pt + W - 1) / W;
+            const size_t pm = std::min(probe_m, n_starts - pos);
+            HIPCHK(c, hipMemsetAsync(kmers, 0, (size_t)W * 8, c->stream));
+            hipLaunchKernelGGL(k_s1<0>, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, dev_bases + pos, (uint64_t)(pm + k - 1), pt, ptw, hist1, kmers, (const uint64_t*)nullptr,
+                               (u32x4*)nullptr, (uint64_t)0, (u32x4*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
+            hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
+            uint64_t probe_items = 0;
+            HIPCHK(c, hipMemcpyAsync(&probe_items, &l1_off[g.P1], sizeof probe_items, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (t->d.k == 32 && !t->d.canonical) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));   // the real pass tallies again
+            items_per_start = std::max(0.01, (double)probe_items / (double)pm) * 1.03;
+        }
+        const size_t round_starts = g_test_round_items ? (size_t)g_test_round_items
+                                                       : (size_t)std::max(1.0, ((double)l1_cap - (double)fixed_items) / (items_per_start * (1.0 + 1.0 / 24.0)));
+        size_t m = n_starts - pos;
+        if (m > round_starts) {
+            const size_t rounds_left = (m + round_starts - 1) / round_starts;          // balance the remaining rounds
+            m = (m + rounds_left - 1) / rounds_left;
+            m += tile_starts - m % tile_starts;                                        // whole tiles, keeps the next round 16-byte aligned
+            m = std::min(m, n_starts - pos);
+        }
+        const size_t nb = m + k - 1;
+        const uint8_t* p = dev_bases + pos;
+        t->count_bound = 0xFFFFFFFFULL;
+        const uint64_t n_tiles = (m + tile_starts - 1) / tile_starts;
+        const uint64_t tiles_per_wg = (n_tiles + W - 1) / W;
+        const uint64_t est_items = (uint64_t)((double)m * items_per_start) + 1;
+        uint64_t seg_cap = est_items / ((uint64_t)W * g.P1);
+        seg_cap += seg_cap / 24 + SEG_PAD;
+        if (g_test_l1_cpb) seg_cap = std::min<uint64_t>(seg_cap, g_test_l1_cpb);
+        const bool seg = seg_ok && (g_l1_fast == 2 || est_items >= ((uint64_t)16 << 20)) && (uint64_t)W * g.P1 * seg_cap <= l1_cap;
+        const uint64_t seg_slots = seg ? (uint64_t)W * seg_cap : 0;
+        uint64_t items = 0;
+        unsigned long long ovf_l1 = 0;
+        HIPCHK(c, hipMemsetAsync(spill_n, 0, 2 * sizeof(unsigned long long), c->stream));
+        if (seg) {
+            items = est_items;
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_L1S, m);
+                hipLaunchKernelGGL(k_s1<2>, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (uint32_t*)nullptr, (unsigned long long*)nullptr,
+                                   (const uint64_t*)nullptr, l1_items, seg_cap, ovf_items, ovf_n, (uint64_t)ovf_cap_items);
+            }
+            HIPCHK(c, hipMemcpyAsync(&ovf_l1, ovf_n, sizeof ovf_l1, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (g_trace) fprintf(stderr, "[katgpu] super-k-mer round (segmented level 1): %zu starts, ~%llu items (%.3f per start), %llu per segment, %llu overflowed (arena %.1f GB)\n", m,
+                                 (unsigned long long)items, items_per_start, (unsigned long long)seg_cap, ovf_l1, c->arena_bytes / 1e9);
+            if (ovf_l1 > ovf_cap_items) {                   // level 1 is incomplete: this round again, exactly
+                seg_ok = false;
+                HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));   // the scatter tallied the all-ones key
+                continue;
+            }
+        } else {
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_L1, m);
+                hipLaunchKernelGGL(k_s1<0>, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1, kmers, (const uint64_t*)nullptr,
+                                   (u32x4*)nullptr, (uint64_t)0, (u32x4*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
+                hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
+            }
+            HIPCHK(c, hipMemcpyAsync(&items, &l1_off[g.P1], sizeof items, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (g_trace) fprintf(stderr, "[katgpu] super-k-mer round (exact level 1): %zu starts -> %llu items (buffer %zu)\n", m, (unsigned long long)items, l1_cap);
+            if (items > l1_cap) {                           // denser than the prefix suggested: this round again, smaller
+                if (t->d.k == 32 && !t->d.canonical) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+                items_per_start = (double)items / (double)m * 1.05;
+                if (g_test_round_items) return fail(c, KATGPU_ERR_NOMEM, "super-k-mer round of %zu starts does not fit the arena", m);
+                continue;
+            }
+            if (items) {
+                ScopedTimer tm(c, KATGPU_K_PART_L1S, m);
+                hipLaunchKernelGGL(k_s1<1>, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (uint32_t*)nullptr, (unsigned long long*)nullptr,
+                                   (const uint64_t*)offs, l1_items, (uint64_t)0, (u32x4*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
+            }
+        }
+        if (items) {
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_L2, items);
+                hipLaunchKernelGGL(k_s2, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(S2Lds), c->stream, g, (const uint64_t*)l1_off, seg_slots, (const u32x4*)l1_items, l2_items, off2, cnt2);
+            }
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
+                const uint32_t blk = g.S <= 4096 ? 512 : 1024;
+                const size_t lds2 = (size_t)g.S * 12 + (size_t)(blk / 64) * AP2_QCAP * 12;
+                const uint32_t per_cu2 = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds2 + 512), 2048 / blk));
+                const uint32_t grid2 = std::min<uint32_t>(g.R, W2 * per_cu2);
+                const bool fresh = t->distinct == 0 && !g_apply_noinline;
+#define KG_S3(B, KP, ...) hipLaunchKernelGGL((k_s3_apply<B, KP, 8, 3, __VA_ARGS__>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, (const uint64_t*)off2, (const u32x4*)l2_items, spill_buf, spill_n, (const uint32_t*)cnt2, (const uint64_t*)nullptr, (unsigned long long*)nullptr)
+                if (blk == 512) { if (g.S <= 2048) KG_S3(512, 2, false, false, true); else KG_S3(512, 4, false, false, true); }
+                else if (fresh) KG_S3(1024, 4, false, true, true);
+                else KG_S3(1024, 4, false, false, true);
+#undef KG_S3
+            }
+            HIPCHK(c, hipGetLastError());
+            unsigned long long spilled = 0;
+            HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (spilled > spill_cap) return fail(c, KATGPU_ERR_NOMEM, "%llu k-mers found their regions full in one round (the list holds %llu): size the table (-H) for the input", spilled, (unsigned long long)spill_cap);
+            if (ovf_l1) {                               // level 1's overflow items through the direct path
+                rc = ensure_room(t, (uint64_t)ovf_l1 * SK_MAXN);
+                if (rc == KATGPU_ERR_NOMEM) rc = KATGPU_OK;              // (table_park takes care of a region that fills)
+                if (rc) return rc;
+                ScopedTimer tm(c, KATGPU_K_COUNT, ovf_l1);
+                hipLaunchKernelGGL(k_insert_items, dim3(grid_for(c, ovf_l1, 256, 6)), dim3(256), 0, c->stream, t->d, (const u32x4*)ovf_items, (uint64_t)ovf_l1);
+            }
+            if (spilled) {
+                bool lost = false;
+                rc = grow_beside_arena(t, spilled, 0, spill_buf, spilled, &lost);
+                if (rc) return rc;
+                if (lost) { pos += m; break; }
+                ScopedTimer tm(c, KATGPU_K_COUNT, spilled);
+                hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, spilled, 256, 6)), dim3(256), 0, c->stream, t->d, (const uint64_t*)spill_buf, (uint64_t)spilled);
+            }
+        }
+        pos += m;
+    }
+    *done = pos;
+    return refresh_counters(t);
+}
+
 // Count a resident base stream.  The stream is cut into sub-batches so that "distinct + sub-batch starts" stays under
 // the load limit (the table can then never fill in the middle of a launch); consecutive sub-batches overlap by k-1.
 static int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
@@ -949,9 +1153,9 @@ static int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
     const size_t n_starts = n - k + 1;
     // Large, aligned inputs go through the partitioned counter (no global atomic per k-mer); whatever it leaves (nothing,
     // normally) and everything small goes through the direct kernel below.
-    while (!t->d.keys_b && !t->d.mz && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
+    while (!t->d.keys_b && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
         size_t done = 0;                        // returns early (done < remaining) when a table growth cost it the arena
-        int prc = count_partitioned(t, dev_bases + pos, n - pos, &done);
+        int prc = t->d.mz ? count_superkmer(t, dev_bases + pos, n - pos, &done) : count_partitioned(t, dev_bases + pos, n - pos, &done);
         if (prc) return prc;
         if (!done) break;
         pos += done;
