@@ -37,3 +37,18 @@ def test_partitioned_counter_matches_oracle(region_slots, round_items, spill_mod
     r = subprocess.run([sys.executable, os.path.join(HERE, "partition_cases.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "partition cases ok" in r.stdout
+
+
+# The super-k-mer counter (kg_superkmer.hpp) on tables with minimizer regions -- off in production this round, forced on here
+# for every table of two regions or more: segmented level 1 with overflow (tiny rounds: every segment is nearly all slack), exact
+# level 1, regrows from a one-region (hash-placed) table into minimizer regions in the middle of a call, spills out of full regions.
+@pytest.mark.parametrize("region_slots,round_starts,extra", [
+    (8192, 400000, {}), (512, 100000, {}), (2048, 250000, {"KATGPU_L1_FAST": "2"}),
+    (1024, 150000, {"KATGPU_L1_FAST": "2", "KATGPU_TEST_L1_CPB": "3"}), (4096, 300000, {"KATGPU_L1_FAST": "0", "KATGPU_TEST_GROW_NOMEM": "1"})])
+def test_superkmer_counter_matches_oracle(region_slots, round_starts, extra):
+    env = dict(os.environ, KATGPU_MZ_MIN_REGIONS="2", KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
+               KATGPU_TEST_ROUND_ITEMS=str(round_starts), KATGPU_TEST_SPILL_MOD="0")
+    env.update(extra)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "partition_cases.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "partition cases ok" in r.stdout
