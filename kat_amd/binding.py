@@ -33,7 +33,7 @@ EXPORTS = (
     "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
     "katgpu_table_partition_wide", "katgpu_table_merge_device_wide", "katgpu_table_regrows",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
-    "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide",
+    "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_ingest_jf_5ptrim_compat",
 )
 
 
@@ -169,6 +169,13 @@ def parse_files(paths, k, trim5p=None):
     out = np.frombuffer(C.string_at(p, n.value), dtype=np.uint8).copy() if n.value else np.zeros(0, np.uint8)
     L.katgpu_free_host(p)
     return out
+
+
+def jf_5ptrim_compat(on):
+    """Process-wide switch: FASTA 5' trim the way the reference's parser really applies it (quirk B7).  Returns the old setting."""
+    L = load_library()
+    L.katgpu_ingest_jf_5ptrim_compat.argtypes = [C.c_int]
+    return bool(L.katgpu_ingest_jf_5ptrim_compat(int(bool(on))))
 
 
 def hist_geometry(low, high):

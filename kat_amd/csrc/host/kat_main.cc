@@ -15,6 +15,14 @@ int main(int argc, char* argv[]) {
     try {
         if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) { usage(); return 1; }
         const std::string mode = argv[1];
+        // a katgpu-only switch, valid in every mode: read FASTA inputs that carry a 5' trim exactly as the reference's parser does
+        // (the trim re-applied at each 4096-byte buffer fill) instead of once per record
+        int kept = 2;
+        for (int i = 2; i < argc; ++i) {
+            if (!strcmp(argv[i], "--jellyfish_5ptrim_compat")) katgpu_ingest_jf_5ptrim_compat(1);
+            else argv[kept++] = argv[i];
+        }
+        argc = kept;
         if (mode == "hist") rc = kat::Histogram::main(argc - 1, argv + 1);
         else if (mode == "gcp") rc = kat::Gcp::main(argc - 1, argv + 1);
         else if (mode == "comp") rc = kat::Comp::main(argc - 1, argv + 1);
