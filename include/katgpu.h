@@ -113,6 +113,13 @@ void katgpu_free_host(void* p);
  * (mer_overlap_sequence_parser.hpp:198, quirk B7 of SURVEY.md) -- instead of once per record.  FASTQ is identical either way. */
 int  katgpu_ingest_jf_5ptrim_compat(int on);
 
+/* The placement hash of one-word tables (kg_device.hpp "placement"; the counterpart of the invertible hash + remainder storage of
+ * JF/include/jellyfish/large_hash_array.hpp:169-171), on the host, for a table of p1 x 2^l2 regions: per key the two region digits,
+ * the remainder a partition item carries, and the key the inverse gives back.  *rem_bits = bits of a remainder.  No GPU needed;
+ * the parity tests use it to check that the hash is one to one and that its inverse is its inverse. */
+int katgpu_place_keys(uint32_t k, uint32_t p1, uint32_t l2, const uint64_t* keys, size_t n, uint32_t* d1, uint32_t* d2, uint64_t* rem,
+                      uint64_t* back, uint32_t* rem_bits);
+
 /* distinct k-mers, sum of counts, slots allocated */
 int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t* total, uint64_t* capacity);
 uint32_t katgpu_table_k(const katgpu_table* t);

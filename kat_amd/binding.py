@@ -33,7 +33,7 @@ EXPORTS = (
     "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
     "katgpu_table_partition_wide", "katgpu_table_merge_device_wide", "katgpu_table_regrows",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
-    "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_ingest_jf_5ptrim_compat",
+    "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_ingest_jf_5ptrim_compat", "katgpu_place_keys",
 )
 
 
@@ -176,6 +176,21 @@ def jf_5ptrim_compat(on):
     L = load_library()
     L.katgpu_ingest_jf_5ptrim_compat.argtypes = [C.c_int]
     return bool(L.katgpu_ingest_jf_5ptrim_compat(int(bool(on))))
+
+
+def place_keys(k, p1, l2, keys):
+    """Host edition of the one-word tables' placement hash: (d1, d2, remainder, inverse(key), remainder bits).  Needs no GPU."""
+    L = load_library()
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    n = keys.size
+    d1, d2 = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    rem, back = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    rb = C.c_uint32()
+    L.katgpu_place_keys.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.katgpu_place_keys(k, p1, l2, keys.ctypes.data, n, d1.ctypes.data, d2.ctypes.data, rem.ctypes.data, back.ctypes.data, C.addressof(rb))
+    if rc:
+        raise KatGpuError(rc, "katgpu_place_keys")
+    return d1, d2, rem, back, rb.value
 
 
 def hist_geometry(low, high):

@@ -335,11 +335,17 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
         if (nr > 0x3FFFFFFFULL) return fail(c, KATGPU_ERR_NOMEM, "table of %llu slots exceeds the region index", (unsigned long long)cap);
         uint32_t p2 = 1;
         while ((uint64_t)p2 * p2 < nr) ++p2;                   // two radix digits of about the same size
+        if (k <= 32) { uint32_t q = 1; while (q < p2) q <<= 1; p2 = q; }   // one-word tables: the level-2 digit is a bit field of the placement hash
         d.p2 = p2; d.p1 = (uint32_t)((nr + p2 - 1) / p2);
         d.n_regions = d.p1 * d.p2; d.region_slots = g_region_slots;
     }
     cap = (uint64_t)d.n_regions * d.region_slots;
     d.cap = cap; d.k = k; d.canonical = canonical ? 1 : 0;
+    if (k <= 32) {                                             // the placement hash's bit budget (kg_device.hpp "placement")
+        if (d.p2 & (d.p2 - 1)) return fail(c, KATGPU_ERR_INVALID_ARG, "a one-word table needs a power-of-two level-2 digit (got p2 = %u)", d.p2);
+        while ((1u << d.l2) < d.p2) ++d.l2;
+        d.n1 = place_n1(k, d.p1);
+    }
     const bool adopted = like_r > 1 && d.p1 == like_p1 && d.p2 == like_p2;
     d.mz = k > 32 ? 0 : (adopted && like_mz >= 0 ? (uint32_t)like_mz : (d.n_regions > 1 && d.n_regions >= g_mz_min_regions ? 1u : 0u));
     const double t0 = now_ms();
@@ -575,7 +581,6 @@ static const uint64_t g_test_round_items = hook("KATGPU_TEST_ROUND_ITEMS") ? str
 static const double g_arena_fraction = getenv("KATGPU_ARENA_FRACTION") ? std::min(0.95, std::max(0.05, atof(getenv("KATGPU_ARENA_FRACTION")))) : 0.85;
 static const uint32_t g_p1_wgs = hook("KATGPU_P1_WGS") ? std::max<uint32_t>(1, (uint32_t)strtoul(hook("KATGPU_P1_WGS"), nullptr, 10)) : 3;   // level-1 workgroups per CU
 static const uint32_t g_apply_v = hook("KATGPU_APPLY_V") ? (uint32_t)strtoul(hook("KATGPU_APPLY_V"), nullptr, 10) : 2;   // 1: first-edition walk (A/B)
-static const uint32_t g_apply_unr = hook("KATGPU_APPLY_UNR") ? (uint32_t)strtoul(hook("KATGPU_APPLY_UNR"), nullptr, 10) : 43;   // A/B: k-mers per lane x probe rounds
 static const bool g_apply_noinline = hook("KATGPU_APPLY_NOINLINE") != nullptr;   // A/B: no inline claims in a table's first round
 static const uint32_t g_apply_block = hook("KATGPU_APPLY_BLOCK") ? (uint32_t)strtoul(hook("KATGPU_APPLY_BLOCK"), nullptr, 10) : 0;   // 0: by region size
 // level 2 without its histogram pass (kg_partition.hpp: k_p2_fast): 0 = never, 1 = when the mean run is long enough for the
@@ -585,15 +590,19 @@ static const uint32_t g_apply_block = hook("KATGPU_APPLY_BLOCK") ? (uint32_t)str
 // 0 = never, 1 = for rounds of at least 64 M k-mers (the default), 2 = always (tests)
 static const uint32_t g_test_l1_cpb = hook("KATGPU_TEST_L1_CPB") ? (uint32_t)strtoul(hook("KATGPU_TEST_L1_CPB"), nullptr, 10) : 0;   // tests: segment capacity (forces overflow)
 static const uint32_t g_l1_fast = hook("KATGPU_L1_FAST") ? (uint32_t)strtoul(hook("KATGPU_L1_FAST"), nullptr, 10) : 1;
-static const bool g_p2_nopack = hook("KATGPU_P2_NOPACK") != nullptr;       // A/B: level 2 re-hashes in its copy-out even when the bucket could ride along
 static const uint32_t g_p2_fast = hook("KATGPU_P2_FAST") ? (uint32_t)strtoul(hook("KATGPU_P2_FAST"), nullptr, 10) : 1;
 static const uint64_t g_test_p2_ovf_cap = hook("KATGPU_TEST_P2_OVF_CAP") ? strtoull(hook("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
 static const uint32_t g_test_spill_mod = hook("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(hook("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 
 static bool part_geometry(const DevTable& d, PartGeom* g) {
-    g->R = d.n_regions; g->S = d.region_slots; g->P1 = d.p1; g->P2 = d.p2;
-    return g->P1 <= MAX_PARTS && g->P2 <= MAX_PARTS && (size_t)g->S * 12 <= 150 * 1024;
+    g->R = d.n_regions; g->S = d.region_slots; g->P1 = d.p1; g->P2 = d.p2; g->l2 = d.l2;
+    g->pl = place_make(d.k, d.p1, d.n1, d.l2);
+    g->hb = l2_hi_bytes(g->pl.rb);
+    return d.k <= 32 && g->P1 <= MAX_PARTS && g->P2 <= MAX_PARTS && (size_t)g->S * 12 <= 150 * 1024;
 }
+// bytes of partition arena per k-mer of a round: level-1 buffer (8 B + the segment slack 1/24), level-2 buffer (4 + hb B, that
+// slack again + the run slack 1/16), overflow list (8 B / 32)
+static double arena_bytes_per_item(uint32_t hb) { return 8.0 * (1 + 1.0 / 24) + (4.0 + hb) * (1 + 1.0 / 24) * (1 + 1.0 / 16) + 0.25 + 0.02; }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -668,52 +677,43 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const uint32_t W2 = (uint32_t)c->n_cu;                                                      // level-2 / apply: one per CU
     const size_t tile_starts = P1_TILE_STARTS;
     if (!c->part_attr_set) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_fast<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p2_fast<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartLds)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 12, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<1024, 12, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 8, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 16, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 16, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        if (g_testing) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply<512, 24, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 4, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 4, 4, 3, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 2, 4, 3, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<1024, 4, 4, 3, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_p3_apply2<512, 2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#define KG_LDS_ATTR(K, BYTES) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+#define KG_FOR_HB(M) M(0) M(1) M(2) M(4)
+#define KG_ATTR_HB(HB) \
+        KG_LDS_ATTR((k_p2<HB>), sizeof(PartLds)); KG_LDS_ATTR((k_p2_fast<HB>), sizeof(PartLds)); \
+        KG_LDS_ATTR((k_p3_apply2<1024, 4, 4, 3, HB>), 150 * 1024); KG_LDS_ATTR((k_p3_apply2<1024, 4, 4, 3, HB, false, true, true>), 150 * 1024); \
+        KG_LDS_ATTR((k_p3_apply2<512, 4, 4, 3, HB>), 150 * 1024); KG_LDS_ATTR((k_p3_apply2<512, 4, 4, 3, HB, false, true, true>), 150 * 1024); \
+        KG_LDS_ATTR((k_p3_apply2<512, 2, 4, 3, HB>), 150 * 1024); KG_LDS_ATTR((k_p3_apply2<512, 2, 4, 3, HB, false, true, true>), 150 * 1024);
+        KG_FOR_HB(KG_ATTR_HB)
+#undef KG_ATTR_HB
+#define KG_ATTR_AP1(B, SPT) KG_LDS_ATTR((k_p3_apply<B, SPT, 4, false>), 150 * 1024); if (g_testing) KG_LDS_ATTR((k_p3_apply<B, SPT, 4, true>), 150 * 1024);
+        KG_ATTR_AP1(1024, 4) KG_ATTR_AP1(1024, 8) KG_ATTR_AP1(1024, 12) KG_ATTR_AP1(512, 8) KG_ATTR_AP1(512, 16) KG_ATTR_AP1(512, 24)
+#undef KG_ATTR_AP1
         c->part_attr_set = true;
     }
     // ---- arena: [hist1 | offs | l1_off | off2 | cnt2 | bend | spill_n, ovf_n | L1 buffer | L2 buffer | overflow list] ----
     // L1 buffer: a round's k-mers + 1/24 + 64 per workgroup and bucket (segment slack of k_p1v2_scatter<true>);
-    // L2 buffer: that + 1/16 + 16 per region (capacity slack of k_p2_fast); overflow list: 1/32.  17.45 bytes per k-mer of a round.
+    // L2 buffer: that + 1/16 + 16 per region (capacity slack of k_p2_fast), 4 + hb bytes per item (low words, then the high parts);
+    // overflow list: 1/32.  14.1 bytes per k-mer of a round at hb = 1 (k = 27 at the bench size), 17.45 at hb = 4.
+    PartGeom g0;
+    if (!part_geometry(t->d, &g0)) return KATGPU_OK;                              // direct path
+    const uint32_t hb0 = g0.hb;                                                  // a table that grows has more regions: never more remainder bits
+    const double per_item = arena_bytes_per_item(hb0);
     constexpr size_t SEG_PAD = 64;
     const size_t fixed_l1 = (size_t)W * MAX_PARTS * SEG_PAD;
     const size_t fixed_l2 = fixed_l1 + fixed_l1 / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024;
     const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +   /* W <= 4 * CUs */
                                align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) +
                                align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256) + align_up((size_t)MAX_PARTS * 8, 256) + align_up((size_t)MAX_PARTS * 4, 256) + 256 +
-                               (fixed_l1 + fixed_l2 + 4096) * 8;
+                               (fixed_l1 + fixed_l2 + 4096) * 8 + 64;
     size_t want_items = n_starts;
     if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
-    if (c->arena_bytes < small_bytes + 18 * want_items) {                        // the arena could be more useful than it is
+    const size_t want_bytes = small_bytes + (size_t)((per_item + 0.5) * (double)want_items);
+    if (c->arena_bytes < want_bytes) {                                           // the arena could be more useful than it is
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         free_b += c->arena_bytes;
-        size_t bytes = std::min<size_t>(small_bytes + 18 * want_items, (size_t)(g_arena_fraction * (double)free_b));
+        size_t bytes = std::min<size_t>(want_bytes, (size_t)(g_arena_fraction * (double)free_b));
         // re-allocate only for a substantially larger arena (fewer rounds): a fresh hipMalloc of this size is not free
         if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 18 * std::min<size_t>(want_items, (size_t)64 << 20)) {
             if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
@@ -733,12 +733,13 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     a += align_up((size_t)MAX_PARTS * 4, 256);
     unsigned long long* spill_n = (unsigned long long*)a;
     unsigned long long* ovf_n = spill_n + 1;      a += 256;
-    const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / 17.45));
+    const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / per_item));
     const size_t l1_items = round_items + round_items / 24 + fixed_l1;
-    const size_t l2_items = l1_items + l1_items / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024;
+    const size_t l2_items = (l1_items + l1_items / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024 + 3) & ~(size_t)3;
     uint64_t* l1_buf = (uint64_t*)a;
-    uint64_t* l2_buf = l1_buf + l1_items;
-    uint64_t* ovf_buf = l2_buf + l2_items;
+    uint32_t* l2_lo = (uint32_t*)(l1_buf + l1_items);                              // level-2 items: low words ...
+    void* l2_hi = l2_lo + l2_items;                                              // ... and hb0 bytes each of high parts
+    uint64_t* ovf_buf = (uint64_t*)((uint8_t*)l2_hi + align_up(l2_items * hb0, 16));
     const uint64_t ovf_cap = g_test_p2_ovf_cap ? g_test_p2_ovf_cap : round_items / 32 + 1024;
     bool p2_fast_ok = g_p2_fast != 0, l1_fast_ok = g_l1_fast != 0;
     if (!g_test_round_items && round_items < ((size_t)1 << 20) && round_items < n_starts) return KATGPU_OK;
@@ -759,6 +760,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         }
         PartGeom g;
         if (!part_geometry(t->d, &g) || t->d.mz) break;                           // table too large for two levels: direct path; grown into minimizer regions: the other counter
+        if (g.hb > hb0) break;                                                    // (cannot happen: see hb0) the level-2 carve would not hold these items
         // (the segmented level 1 sizes its segments from this ratio, so it wants it even when one round takes everything)
         if (!ratio_known && !g_test_round_items && (n_starts - pos > round_items || (l1_fast_ok && n_starts - pos >= ((size_t)64 << 20)))) {
             const size_t probe_m = std::min<size_t>(n_starts - pos, (size_t)64 << 20) / tile_starts * tile_starts;
@@ -834,12 +836,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             const bool try_fast = p2_fast_ok && (g_p2_fast == 2 || items / g.R >= 1024);
             if (try_fast) {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-                if (k <= 27 && !g_p2_nopack)                 // 2k <= 54: the bucket rides in the staged word's top bits
-                    hipLaunchKernelGGL(k_p2_fast<true>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2,
-                                       ovf_buf, ovf_n, ovf_cap, seg_slots);
-                else
-                    hipLaunchKernelGGL(k_p2_fast<false>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2,
-                                       ovf_buf, ovf_n, ovf_cap, seg_slots);
+#define KG_P2F(HB) case HB: hipLaunchKernelGGL(k_p2_fast<HB>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_lo, l2_hi, \
+                                               off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots); break;
+                switch (g.hb) { KG_FOR_HB(KG_P2F) }
+#undef KG_P2F
             }
             if (try_fast || seg) {
                 HIPCHK(c, hipMemcpyAsync(&overflowed, ovf_n, sizeof overflowed, hipMemcpyDeviceToHost, c->stream));
@@ -860,8 +860,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             }
             if (!run_len) {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-                hipLaunchKernelGGL(k_p2, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, seg_slots,
-                                   seg ? bend : (uint64_t*)nullptr);
+#define KG_P2(HB) case HB: hipLaunchKernelGGL(k_p2<HB>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_lo, l2_hi, \
+                                              off2, seg_slots, seg ? bend : (uint64_t*)nullptr); break;
+                switch (g.hb) { KG_FOR_HB(KG_P2) }
+#undef KG_P2
             }
             const uint64_t* bucket_end = (!run_len && seg) ? bend : nullptr;
             {
@@ -874,41 +876,24 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                     const size_t lds2 = (size_t)g.S * 12 + (size_t)(blk / 64) * AP2_QCAP * 12;
                     const uint32_t per_cu2 = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds2 + 512), 2048 / blk));
                     const uint32_t grid2 = std::min<uint32_t>(g.R, W2 * per_cu2);
-#define KG_APPLY2(B, KP, U, NR) hipLaunchKernelGGL((k_p3_apply2<B, KP, U, NR>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end)
                     // a table that is still empty sees nothing but new keys in this round: they are claimed inside the probe rounds
                     // (INLINE_CLAIM) instead of all going through the queues; any later round loses by that (kg_partition.hpp)
                     const bool fresh = t->distinct == 0 && !g_apply_noinline;
-#define KG_APPLY2F(B, KP) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, false, true, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr)
-                    if (fresh && g_apply_unr == 43) { if (blk == 512) { if (g.S <= 2048) KG_APPLY2F(512, 2); else KG_APPLY2F(512, 4); } else KG_APPLY2F(1024, 4); }
-                    else
-#undef KG_APPLY2F
-                    if (blk == 512) { if (g.S <= 2048) KG_APPLY2(512, 2, 4, 3); else KG_APPLY2(512, 4, 4, 3); }
-                    else if (g_apply_unr == 82) KG_APPLY2(1024, 4, 8, 2);
-                    else if (g_apply_unr == 84) KG_APPLY2(1024, 4, 8, 4);
-                    else if (g_apply_unr == 83) KG_APPLY2(1024, 4, 8, 3);
-                    else if (g_apply_unr == 430) hipLaunchKernelGGL((k_p3_apply2<1024, 4, 4, 3, false, false, false>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr);
-                    else if (g_apply_unr == 1043 || g_apply_unr == 1083) {      // cycle stamps of wave 0 (diagnostic; KATGPU_TRACE prints them)
-                        unsigned long long* d_st = nullptr;
-                        HIPCHK(c, hipMalloc((void**)&d_st, 64));
-                        HIPCHK(c, hipMemsetAsync(d_st, 0, 64, c->stream));
-                        if (g_apply_unr == 1043) hipLaunchKernelGGL((k_p3_apply2<1024, 4, 4, 3, true>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, d_st);
-                        else hipLaunchKernelGGL((k_p3_apply2<1024, 4, 8, 3, true>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, run_len, bucket_end, d_st);
-                        unsigned long long h[8];
-                        HIPCHK(c, hipMemcpyAsync(h, d_st, 56, hipMemcpyDeviceToHost, c->stream));
-                        HIPCHK(c, hipStreamSynchronize(c->stream));
-                        hipFree(d_st);
-                        const double n = (double)std::max<unsigned long long>(1, h[6]);
-                        fprintf(stderr, "[katgpu] apply2 stamps per region (cycles, wave 0): fill+sweep %.0f, loads+hash %.0f, rounds %.0f, queue %.0f, wait %.0f, write-back %.0f; %llu region visits, %llu items\n",
-                                h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6], (unsigned long long)items);
-                    }
-                    else KG_APPLY2(1024, 4, 4, 3);
+#define KG_APPLY2(B, KP, HB) do { \
+                        if (fresh) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, true, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint32_t*)l2_lo, (const void*)l2_hi, \
+                                                      l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); \
+                        else hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint32_t*)l2_lo, (const void*)l2_hi, \
+                                                l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } while (0)
+#define KG_APPLY2_HB(HB) case HB: if (blk == 512) { if (g.S <= 2048) KG_APPLY2(512, 2, HB); else KG_APPLY2(512, 4, HB); } else KG_APPLY2(1024, 4, HB); break;
+                    switch (g.hb) { KG_FOR_HB(KG_APPLY2_HB) }
+#undef KG_APPLY2_HB
 #undef KG_APPLY2
                 } else {
                 const size_t lds = (size_t)g.S * 12;
                 // small regions (a table created "like" a bigger one): 512-thread workgroups, four per CU instead of two
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
-#define KG_APPLY1(B, SPT, HOOKED) hipLaunchKernelGGL((k_p3_apply<B, SPT, 4, HOOKED>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
+#define KG_APPLY1(B, SPT, HOOKED) hipLaunchKernelGGL((k_p3_apply<B, SPT, 4, HOOKED>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, (const uint32_t*)l2_lo, (const void*)l2_hi, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
 #define KG_APPLY(B, SPT) do { if (g_test_spill_mod) KG_APPLY1(B, SPT, true); else KG_APPLY1(B, SPT, false); } while (0)
                 const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
                 if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
@@ -1708,6 +1693,19 @@ extern "C" int katgpu_table_get_wide(katgpu_table* t, const uint64_t* keys_hi, c
 }
 
 // ------------------------------------------------------------------ region-ordered exchange -----------
+
+extern "C" int katgpu_place_keys(uint32_t k, uint32_t p1, uint32_t l2, const uint64_t* keys, size_t n, uint32_t* d1, uint32_t* d2, uint64_t* rem,
+                                 uint64_t* back, uint32_t* rem_bits) {
+    if (k < 1 || k > 32 || p1 < 1 || p1 > MAX_PARTS || l2 > 10 || (n && (!keys || !d1 || !d2 || !rem || !back))) return KATGPU_ERR_INVALID_ARG;
+    const Place pl = place_make(k, p1, place_n1(k, p1), l2);
+    if (rem_bits) *rem_bits = pl.rb;
+    for (size_t i = 0; i < n; ++i) {
+        const Placed h = place_hash(keys[i], pl);
+        d1[i] = h.d1; d2[i] = h.d2; rem[i] = h.rem;
+        back[i] = place_key(place_base1(h.d1, pl.n, pl.p1), (pl.rb < 64 ? (uint64_t)h.d2 << pl.rb : 0ULL) | h.rem, pl);
+    }
+    return KATGPU_OK;
+}
 
 extern "C" int katgpu_table_geometry(const katgpu_table* t, katgpu_geometry* g) {
     if (!t || !g) return KATGPU_ERR_INVALID_ARG;

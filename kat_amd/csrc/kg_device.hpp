@@ -44,6 +44,7 @@ struct DevTable {
     uint32_t k;
     uint32_t canonical;
     uint32_t mz;          // region keyed by the k-mer's minimizer instead of its hash ("minimizer regions" below); one-word tables only
+    uint32_t n1, l2;      // one-word tables ("placement" below): bits of the level-1 remainder (from k and p1); p2 == 1 << l2
     uint64_t* fail_buf;   // mz tables: [FAIL_CAP keys | FAIL_CAP amounts] of inserts that found their region full (the host grows and retries)
 };
 
@@ -81,6 +82,91 @@ __device__ __forceinline__ uint32_t digit1_of_hash(uint64_t h, uint32_t p1) { re
 __device__ __forceinline__ uint32_t digit2_of_hash(uint64_t h, uint32_t p2) { return __umulhi((uint32_t)(h >> 12), p2); }
 __device__ __forceinline__ uint32_t region_of_hash(uint64_t h, uint32_t p1, uint32_t p2) { return digit1_of_hash(h, p1) * p2 + digit2_of_hash(h, p2); }
 __device__ __forceinline__ uint32_t offset_of_hash(uint64_t h, uint32_t region_slots) { return __umulhi((uint32_t)h, region_slots); }
+// ---- placement of one-word k-mers (k <= 32): an invertible hash on 2k bits, cut into digits ----
+// Jellyfish stores only what the slot position does not already say about a key (its hash is an invertible matrix product and the
+// array keeps the remainder, JF/include/jellyfish/large_hash_array.hpp:169-171).  Same idea for the partitioned counter: the
+// placement hash is one to one on the n = 2k-bit k-mer space, built from two multiply / xor-shift stages so that each digit comes
+// off the top and what is below it is again a number to hash:
+//     a = key ^ (key >> ceil(n/2));    y1 = a * C1 mod 2^n;    d1 = floor(T(y1) * p1 / 2^32), T = the top 32 bits of y1 (level-1 digit);
+//                                      r1 = y1 - base1(d1)     (base1(d) = the smallest y1 whose digit is d):  n1 bits
+//     b = r1 ^ (r1 >> ceil(n1/2));     y2 = b * C2 mod 2^n1;   d2 = top l2 bits of y2 (level-2 digit, p2 = 2^l2);  rem = the rb = n1 - l2 bits below
+// region = d1 * p2 + d2, home offset = rem's top 32 bits scaled to the region's slots.  (key) -> (d1, d2, rem) is one to one, so an
+// item that sits in region r's run needs only `rem` -- 35 bits at k = 27 with ~2^19 regions, against 64 for the k-mer -- and the
+// apply kernel gets the k-mer back with the inverse (place_key).  A multiply by an odd constant is a bijection mod 2^n whose TOP bits
+// depend on every input bit; x ^ (x >> s) with 2s >= n is its own inverse.  p1 is any number <= 1024 (so that a table of any size
+// has full-size regions), which is why r1 is a difference and not a bit field.
+constexpr uint64_t PLACE_C1 = 0xff51afd7ed558ccdULL, PLACE_C2 = 0xc4ceb9fe1a85ec53ULL;
+constexpr uint64_t inv_mod_2_64(uint64_t a) { uint64_t x = a; for (int i = 0; i < 6; ++i) x *= 2 - a * x; return x; }   // Newton: doubles the correct low bits
+constexpr uint64_t PLACE_C1_INV = inv_mod_2_64(PLACE_C1), PLACE_C2_INV = inv_mod_2_64(PLACE_C2);
+static_assert(PLACE_C1 * PLACE_C1_INV == 1 && PLACE_C2 * PLACE_C2_INV == 1, "modular inverses");
+
+struct Place {             // the bit budget of one table: wave-uniform, a handful of SGPRs
+    uint32_t n, p1;        // 2k; level-1 digits
+    uint32_t n1, rb;       // bits of r1; bits below the level-2 digit (the remainder an item carries)
+    uint32_t s0, s1;       // xor-shift distances of the two stages
+    uint64_t m0, m1;       // masks of n and n1 bits
+};
+__device__ __host__ __forceinline__ uint64_t low_mask(uint32_t bits) { return bits >= 64 ? ~0ULL : (1ULL << bits) - 1; }
+__device__ __host__ __forceinline__ uint32_t place_top32(uint64_t y1, uint32_t n) { return n >= 32 ? (uint32_t)(y1 >> (n - 32)) : (uint32_t)(y1 << (32 - n)); }
+// the smallest n-bit y1 whose level-1 digit is d (d == p1: 2^n, one past the last); one 64-bit division: callers keep d uniform
+// where it matters (a bucket, a region)
+__device__ __host__ __forceinline__ uint64_t place_base1(uint32_t d, uint32_t n, uint32_t p1) {
+    if (d == 0) return 0;
+    const uint64_t tb = (((uint64_t)d << 32) + p1 - 1) / p1;                      // smallest T with floor(T * p1 / 2^32) >= d; <= 2^32
+    return n >= 32 ? tb << (n - 32) : (tb + (1ULL << (32 - n)) - 1) >> (32 - n);
+}
+// bits of the widest r1 (host: once per table)
+inline uint32_t place_n1(uint32_t k, uint32_t p1) {
+    const uint32_t n = 2 * k;
+    unsigned __int128 widest = 0, prev = 0;
+    for (uint32_t d = 1; d <= p1; ++d) {
+        const unsigned __int128 b = d == p1 ? (unsigned __int128)1 << n : (unsigned __int128)place_base1(d, n, p1);
+        if (b > prev && b - prev - 1 > widest) widest = b - prev - 1;          // (a digit without keys -- p1 > 4^k -- has no r1)
+        prev = b;
+    }
+    uint32_t bits = 0;
+    while (bits < 64 && (widest >> bits)) ++bits;
+    return bits;
+}
+__device__ __host__ __forceinline__ Place place_make(uint32_t k, uint32_t p1, uint32_t n1, uint32_t l2) {
+    Place p;
+    p.n = 2 * k; p.p1 = p1; p.n1 = n1;
+    p.rb = n1 - (l2 < n1 ? l2 : n1);                               // (a key space smaller than the grid: the digit just stays small)
+    p.s0 = (p.n + 1) / 2; p.s1 = (n1 + 1) / 2;
+    p.m0 = low_mask(p.n); p.m1 = low_mask(n1);
+    return p;
+}
+struct Placed { uint32_t d1, d2; uint64_t rem; };
+__device__ __host__ __forceinline__ uint64_t place_stage1(uint64_t key, const Place& p) { return ((key ^ (key >> p.s0)) * PLACE_C1) & p.m0; }   // y1
+__device__ __host__ __forceinline__ uint32_t place_digit1(uint64_t y1, const Place& p) { return (uint32_t)(((uint64_t)place_top32(y1, p.n) * p.p1) >> 32); }
+__device__ __host__ __forceinline__ uint64_t place_stage2(uint64_t r1, const Place& p) { return ((r1 ^ (r1 >> p.s1)) * PLACE_C2) & p.m1; }     // y2 = d2 : rem
+__device__ __host__ __forceinline__ uint32_t place_digit2(uint64_t y2, const Place& p) { return p.rb < 64 ? (uint32_t)(y2 >> p.rb) : 0u; }
+__device__ __host__ __forceinline__ uint64_t place_rem(uint64_t y2, const Place& p) { return y2 & low_mask(p.rb); }
+__device__ __host__ __forceinline__ Placed place_hash(uint64_t key, const Place& p) {
+    const uint64_t y1 = place_stage1(key, p);
+    const uint32_t T = place_top32(y1, p.n);
+    const uint64_t tp = (uint64_t)T * p.p1;                                       // d1 : fraction
+    Placed r;
+    r.d1 = (uint32_t)(tp >> 32);
+    // base1(d1) without the 64-bit division: T is (fraction / p1) steps above the first T of its digit
+    const uint32_t tb = T - (uint32_t)tp / p.p1;
+    const uint64_t base1 = p.n >= 32 ? (uint64_t)tb << (p.n - 32) : ((uint64_t)tb + (1ULL << (32 - p.n)) - 1) >> (32 - p.n);
+    const uint64_t y2 = place_stage2(y1 - base1, p);
+    r.d2 = place_digit2(y2, p); r.rem = place_rem(y2, p);
+    return r;
+}
+// the inverse; base1 = place_base1(d1, ...) (the caller's: uniform over a region)
+__device__ __host__ __forceinline__ uint64_t place_key(uint64_t base1, uint64_t y2, const Place& p) {
+    const uint64_t b = (y2 * PLACE_C2_INV) & p.m1, r1 = b ^ (b >> p.s1);
+    const uint64_t a = ((base1 + r1) * PLACE_C1_INV) & p.m0;
+    return a ^ (a >> p.s0);
+}
+// home offset inside a region of S slots from the remainder: its top 32 bits (the best mixed ones), scaled without a division
+__device__ __host__ __forceinline__ uint32_t place_offset(uint64_t rem, const Place& p, uint32_t S) {
+    const uint32_t top = p.rb >= 32 ? (uint32_t)(rem >> (p.rb - 32)) : (uint32_t)(rem << (32 - p.rb));
+    return (uint32_t)(((uint64_t)top * S) >> 32);
+}
+
 // ---- minimizer regions (DevTable::mz) ----
 // The super-k-mer counter (kg_superkmer.hpp) partitions RUNS of consecutive k-mers, not k-mers, so every k-mer of a run must land
 // in one region: the region is a function of the k-mer's MINIMIZER -- the m-mer (m = min(k, 16)) of the k-mer whose canonical
@@ -129,13 +215,38 @@ struct Probe {
     __device__ __forceinline__ uint64_t pos() const { return base + s; }
     __device__ __forceinline__ void next() { s = s + 1 == S ? 0 : s + 1; }
 };
+// home offset of a k-mer inside its region (kernels that are handed the region -- the applies, the merges -- need only this)
+__device__ __forceinline__ uint32_t home_offset(const uint64_t key, const DevTable& t) {
+    if (t.mz) return offset_of_hash(mix64(key), t.region_slots);
+    const Place pl = place_make(t.k, t.p1, t.n1, t.l2);
+    return place_offset(place_hash(key, pl).rem, pl, t.region_slots);
+}
+// the same for kernels that go through one region's k-mers: the level-1 digit is the region's, so its base is computed once
+struct RegionPlace { Place pl; uint64_t base1; uint32_t S, mz; };
+__device__ __forceinline__ RegionPlace region_place(const DevTable& t, uint32_t region) {
+    RegionPlace rp;
+    rp.pl = place_make(t.k, t.p1, t.n1, t.l2);
+    rp.base1 = t.mz ? 0 : place_base1(region >> t.l2, rp.pl.n, rp.pl.p1);
+    rp.S = t.region_slots; rp.mz = t.mz;
+    return rp;
+}
+__device__ __forceinline__ uint32_t home_offset_in(const uint64_t key, const RegionPlace& rp) {
+    if (rp.mz) return offset_of_hash(mix64(key), rp.S);
+    return place_offset(place_rem(place_stage2(place_stage1(key, rp.pl) - rp.base1, rp.pl), rp.pl), rp.pl, rp.S);
+}
 __device__ __forceinline__ Probe probe_start(const uint64_t key, const DevTable& t) {
-    const uint64_t h = mix64(key);
     Probe p;
     const uint32_t region_slots = t.region_slots;
-    p.base = (uint64_t)(t.mz ? region_mz(key, t.k, t.p1, t.p2) : region_of_hash(h, t.p1, t.p2)) * region_slots;
-    p.s = offset_of_hash(h, region_slots);
     p.S = region_slots;
+    if (t.mz) {
+        p.base = (uint64_t)region_mz(key, t.k, t.p1, t.p2) * region_slots;
+        p.s = offset_of_hash(mix64(key), region_slots);
+        return p;
+    }
+    const Place pl = place_make(t.k, t.p1, t.n1, t.l2);
+    const Placed h = place_hash(key, pl);
+    p.base = (uint64_t)((h.d1 << t.l2) | h.d2) * region_slots;
+    p.s = place_offset(h.rem, pl, region_slots);
     return p;
 }
 // owner part of a k-mer for the multi-GPU merge: a second, independent mix of the CANONICAL form

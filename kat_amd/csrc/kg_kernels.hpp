@@ -456,6 +456,7 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
     for (uint32_t r = blockIdx.x; r < R; r += gridDim.x) {
         __syncthreads();
         const uint64_t bbase = (uint64_t)r * Sb, abase = (uint64_t)r * Sa;
+        const RegionPlace rpb = region_place(tb, r);
         for (uint32_t i = threadIdx.x; i < Sb; i += blockDim.x) { rk[i] = tb.keys[bbase + i]; rc[i] = tb.counts[bbase + i]; }
         __syncthreads();
         constexpr int JB = 4;                                               // slots per lane in flight: keys and counts are loaded together
@@ -476,7 +477,7 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
                 if (occ) {
                     ca = cnts[u];
                     if (na_ovf) ca += ovf_get(ta, key);
-                    uint32_t s = offset_of_hash(mix64(key), Sb);
+                    uint32_t s = home_offset_in(key, rpb);
                     for (uint32_t probe = 0; probe < Sb; ++probe) {
                         const unsigned long long cur = rk[s];
                         if (cur == key) { cb = rc[s]; if (nb_ovf) cb += ovf_get(tb, key); break; }
@@ -781,6 +782,7 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
         if (tid == 0) s_occ = 0;
         __syncthreads();
         const uint64_t base = (uint64_t)g * S;
+        const RegionPlace rp = region_place(t, g);
         uint32_t occ = 0;
         for (uint32_t i = tid; i < S; i += BLOCK) {
             const uint64_t key = t.keys[base + i];
@@ -801,7 +803,7 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
                 const uint32_t c = srcs.s[s].counts[i];
                 if (!c) continue;
                 const unsigned long long key = srcs.s[s].keys[i];
-                uint32_t slot = offset_of_hash(mix64(key), S);
+                uint32_t slot = home_offset_in(key, rp);
                 for (uint32_t probe = 0; probe < S; ++probe) {                   // cannot fail: occupied + incoming <= S
                     unsigned long long cur = rk[slot];
                     if (cur == EMPTY) {

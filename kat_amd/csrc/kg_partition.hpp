@@ -6,8 +6,11 @@
 // This path removes the per-instance global atomic.  The table is made of regions of `region_slots` slots with
 // region-local probing (kg_device.hpp: Probe); a round of the partitioned counter
 //   P1  radix-partitions the round's k-mers by the high part of their region index into P1 buckets  (8 B out / k-mer)
-//   P2  splits every bucket by the low part of the region index -> one contiguous run per region     (8 B in, 8 B out)
-//   P3  loads a region (96 KB) into LDS, applies its run with LDS atomics, writes the region back     (8 B in + 24 B/slot)
+//   P2  splits every bucket by the low part of the region index -> one contiguous run per region     (8 B in, 4 + HB B out)
+//   P3  loads a region (96 KB) into LDS, applies its run with LDS atomics, writes the region back     (4 + HB B in + 24 B/slot)
+// What level 2 writes is not the k-mer but the REMAINDER of its placement hash (kg_device.hpp "placement": the hash is one to one
+// and the region already says its digits): rb = 2k - log2(regions) bits, kept as two streams -- the low 32 bits and HB = 0, 1, 2
+// or 4 bytes of high bits (35 bits at the bench size: 5 bytes per k-mer instead of 8).
 // so HBM sees only streaming traffic.  Level 1 is exact two-pass (histogram, scan, scatter) with per-workgroup running
 // cursors held in LDS: no global atomic per k-mer, deterministic placement.  Level 2 normally runs in ONE pass
 // (k_p2_fast: equal-capacity runs sized from the uniform hash, an overflow list for what does not fit, the exact
@@ -36,7 +39,32 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct PartGeom {
     uint32_t R, S;     // regions, slots per region (the table's)
     uint32_t P1, P2;   // region r = b1 * P2 + b2 (the table's p1, p2): level-1 bucket b1, level-2 bucket b2
+    uint32_t l2;       // P2 == 1 << l2
+    uint32_t hb;       // bytes of a level-2 item beyond its low 32 bits: 0, 1, 2 or 4 (from pl.rb)
+    Place pl;          // the placement hash's bit budget for this table (kg_device.hpp)
 };
+// the two streams of a level-2 buffer of `cap` items: low words first, high parts behind them
+__device__ __host__ __forceinline__ const void* l2_hi_of(const uint32_t* lo, uint64_t cap) { return lo + cap; }
+__device__ __host__ __forceinline__ void* l2_hi_of(uint32_t* lo, uint64_t cap) { return lo + cap; }
+__device__ __host__ __forceinline__ uint32_t l2_hi_bytes(uint32_t rb) { return rb <= 32 ? 0u : rb <= 40 ? 1u : rb <= 48 ? 2u : 4u; }
+template <int HB> struct HiWord { typedef uint32_t type; };
+template <> struct HiWord<1> { typedef uint8_t type; };
+template <> struct HiWord<2> { typedef uint16_t type; };
+template <int HB>
+__device__ __forceinline__ void l2_store(uint32_t* __restrict__ lo, void* __restrict__ hi, uint64_t at, uint64_t rem) {
+    lo[at] = (uint32_t)rem;
+    if (HB) reinterpret_cast<typename HiWord<HB>::type*>(hi)[at] = (typename HiWord<HB>::type)(rem >> 32);
+}
+template <int HB>
+__device__ __forceinline__ uint64_t l2_load(const uint32_t* __restrict__ lo, const void* __restrict__ hi, uint64_t at) {
+    const uint32_t l = lo[at];
+    const uint32_t h = HB ? (uint32_t)reinterpret_cast<const typename HiWord<HB>::type*>(hi)[at] : 0u;
+    return ((uint64_t)h << 32) | l;
+}
+// (slow paths: the width is a run-time number)
+__device__ __forceinline__ uint64_t l2_load_any(uint32_t hb, const uint32_t* __restrict__ lo, const void* __restrict__ hi, uint64_t at) {
+    return hb == 0 ? l2_load<0>(lo, hi, at) : hb == 1 ? l2_load<1>(lo, hi, at) : hb == 2 ? l2_load<2>(lo, hi, at) : l2_load<4>(lo, hi, at);
+}
 
 // LDS carve of the partition kernels (dynamic shared memory, 16-byte aligned base)
 struct PartLds {
@@ -132,48 +160,6 @@ __device__ __forceinline__ uint32_t lane_kmers(const PartLds& L, uint32_t k, boo
         m <<= 1;
     }
     return valid;
-}
-
-// Counting-sort one tile's k-mers by bucket through LDS and append every bucket's run at this workgroup's cursor.
-// LEVEL 1: bucket = region / P2; LEVEL 2: bucket = region % P2.  All 1024 lanes must call it (barriers inside).
-template <int LEVEL>
-__device__ __forceinline__ void scatter_tile(PartLds& L, const PartGeom g, const uint64_t (&key)[PART_ITEMS], uint32_t valid,
-                                             uint64_t* __restrict__ out) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t P = LEVEL == 1 ? g.P1 : g.P2;
-    if (tid < MAX_PARTS) L.hist[tid] = 0;
-    lds_barrier();
-    uint32_t br[PART_ITEMS];                                  // bucket << 16 | rank inside the tile's bucket run
-#pragma unroll
-    for (int j = 0; j < PART_ITEMS; ++j) {
-        br[j] = 0;
-        if (valid >> j & 1) {
-            const uint64_t h = mix64(key[j]);
-            const uint32_t b = LEVEL == 1 ? digit1_of_hash(h, g.P1) : digit2_of_hash(h, g.P2);
-            br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
-        }
-    }
-    lds_barrier();
-    uint32_t total;
-    const uint32_t mine = tid < P ? L.hist[tid] : 0;
-    const uint32_t excl = block_exclusive_scan(mine, L.wave_tot, &total);
-    if (tid < MAX_PARTS) L.off[tid] = excl;
-    lds_barrier();
-#pragma unroll
-    for (int j = 0; j < PART_ITEMS; ++j)
-        if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = key[j];
-    lds_barrier();
-    // copy-out, one staged k-mer per lane and step: the bucket is recomputed from the key (cheaper than a third LDS array) and the
-    // steps are independent of each other; a loop over buckets kept a third of the lanes busy on runs of ~20 k-mers
-    for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
-        const uint64_t key1 = L.staging[idx];
-        const uint64_t h = mix64(key1);
-        const uint32_t b = LEVEL == 1 ? digit1_of_hash(h, g.P1) : digit2_of_hash(h, g.P2);
-        out[L.cursor[b] + (idx - L.off[b])] = key1;
-    }
-    lds_barrier();
-    if (tid < P) L.cursor[tid] += L.hist[tid];
-    // (the next tile's first barrier orders this update before the next use)
 }
 
 // ---- level 1 scan: offs[w][b] = start of workgroup w's run inside bucket b; l1_off[b] = start of bucket b; l1_off[P1] = items ----
@@ -323,7 +309,7 @@ k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
                 if (!lw.valid()) continue;
                 const uint64_t key = canon_if(lw.fwd(), t.k, canonical);
                 if (key == EMPTY) { ++ones; continue; }
-                atomicAdd(&s_hist[digit1_of_hash(mix64(key), g.P1)], 1u);
+                atomicAdd(&s_hist[place_digit1(place_stage1(key, g.pl), g.pl)], 1u);
             }
         }
     }
@@ -341,7 +327,7 @@ k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
 // end is padded with EMPTY, which level 2 skips (the all-ones k-mer never is an item).  Saves the second decode + hash of the
 // whole input (k_p1v2_count: 70 ms of the bench step) for ~4 % more level-1 bytes.
 template <bool SEG>
-__global__ void __launch_bounds__(P1_BLOCK)
+__global__ void __launch_bounds__(P1_BLOCK, 6)                // six waves per SIMD = three workgroups per CU (g_p1_wgs): at most 80 VGPRs
 k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
                const uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_buf, uint64_t seg_cap, uint64_t* __restrict__ ovf_buf,
                unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
@@ -373,7 +359,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                 if (!lw.valid()) continue;
                 const uint64_t key = canon_if(lw.fwd(), k, canonical);
                 if (key == EMPTY) { if (SEG) ++ones; continue; }               // exact edition: tallied by the count pass
-                const uint32_t b = digit1_of_hash(mix64(key), P);
+                const uint32_t b = place_digit1(place_stage1(key, g.pl), g.pl);
                 br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
                 valid |= 1u << j;
             }
@@ -431,9 +417,82 @@ __device__ __forceinline__ void l1_bucket_range(const uint64_t* __restrict__ l1_
     else { beg = l1_off[b1]; end = l1_off[b1 + 1]; }
 }
 
-// ---- level 2: one workgroup per level-1 bucket: histogram by sub-bucket, scan, scatter.  off2[r] = start of region r's run. ----
+// ---- level 2 ----
+// Counting-sort one tile's k-mers of bucket b1 by their level-2 digit through LDS and append every digit's run at this workgroup's
+// cursor.  What is staged and written is the placement hash below the level-1 digit (y2 = digit : remainder, kg_device.hpp), so
+// the copy-out reads its digit off the staged word instead of hashing again, and what reaches HBM is the remainder alone.
+// BOUNDED: a run has a capacity (lim[]); what does not fit goes to the overflow list as a k-mer (through the inverse hash).
+// All 1024 lanes must call it (barriers inside).
+template <int HB, bool BOUNDED>
+__device__ __forceinline__ void scatter_tile2(PartLds& L, const PartGeom g, const uint64_t base1, const uint64_t (&key)[PART_ITEMS], uint32_t valid,
+                                              uint32_t* __restrict__ out_lo, void* __restrict__ out_hi, const uint64_t* lim, uint64_t* __restrict__ ovf_buf,
+                                              unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t P = g.P2;
+    if (tid < MAX_PARTS) L.hist[tid] = 0;
+    lds_barrier();
+    uint32_t br[PART_ITEMS];                                  // digit << 16 | rank inside the tile's run
+    uint64_t y2[PART_ITEMS];
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        br[j] = 0; y2[j] = 0;
+        if (valid >> j & 1) {
+            y2[j] = place_stage2(place_stage1(key[j], g.pl) - base1, g.pl);
+            const uint32_t b = place_digit2(y2[j], g.pl);
+            br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+        }
+    }
+    lds_barrier();
+    uint32_t total;
+    const uint32_t mine = tid < P ? L.hist[tid] : 0;
+    const uint32_t excl = block_exclusive_scan(mine, L.wave_tot, &total);
+    if (tid < MAX_PARTS) L.off[tid] = excl;
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j)
+        if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = y2[j];
+    lds_barrier();
+    // copy-out, one staged k-mer per lane and step (as in k_p1v2_scatter): the steps are independent, where a loop over the runs
+    // kept a third of the lanes busy
+    for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
+        const uint64_t staged = L.staging[idx];
+        const uint32_t b = place_digit2(staged, g.pl);
+        const uint64_t dst = L.cursor[b] + (idx - L.off[b]);
+        if (!BOUNDED || dst < lim[b]) l2_store<HB>(out_lo, out_hi, dst, place_rem(staged, g.pl));
+        else {                                                             // beyond the run's capacity: the overflow list
+            const unsigned long long at = atomicAdd(ovf_n, 1ULL);
+            if (at < ovf_cap) ovf_buf[at] = place_key(base1, staged, g.pl);
+        }
+    }
+    lds_barrier();
+    if (tid < P) {
+        if (BOUNDED) { const uint64_t room = lim[tid] - L.cursor[tid]; L.cursor[tid] += (uint64_t)L.hist[tid] <= room ? L.hist[tid] : room; }
+        else L.cursor[tid] += L.hist[tid];
+    }
+    // (the next tile's first barrier orders this update before the next use)
+}
+
+// the 16 k-mers of a lane for one tile of bucket [beg, end) of the level-1 buffer; bit j of `valid` = item j is a k-mer (not past
+// the end, not segment padding)
+__device__ __forceinline__ uint32_t p2_tile_load(const uint64_t* __restrict__ l1_buf, uint64_t tbeg, uint64_t end, bool padded, uint64_t (&key)[PART_ITEMS]) {
+    uint32_t valid = 0;
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + threadIdx.x;
+        key[j] = 0;
+        if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
+    }
+    if (padded) {                                        // segment padding (looked at only after all 16 loads are in flight)
+#pragma unroll
+        for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);
+    }
+    return valid;
+}
+
+// The exact edition: one workgroup per level-1 bucket: histogram by digit, scan, scatter.  off2[r] = start of region r's run.
+template <int HB>
 __global__ void __launch_bounds__(PART_BLOCK)
-k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
+k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint32_t* __restrict__ l2_lo, void* __restrict__ l2_hi,
      uint64_t* __restrict__ off2, uint64_t seg_slots, uint64_t* __restrict__ bend /* end of bucket b1's last run (segmented layout) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
@@ -441,6 +500,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
     for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
         uint64_t beg, end;
         l1_bucket_range(l1_off, seg_slots, b1, beg, end);
+        const uint64_t base1 = place_base1(b1, g.pl.n, g.pl.p1);
         lds_barrier();
         // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
         // the cursor array is free until the scan, so it doubles as the histogram
@@ -452,7 +512,8 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const uint64_t i = i0 + (uint64_t)u * PART_BLOCK + tid; v[u] = i < end ? l1_buf[i] : EMPTY; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (v[u] != EMPTY) atomicAdd(&h64[digit2_of_hash(mix64(v[u]), g.P2)], 1ULL);
+            for (int u = 0; u < 8; ++u)
+                if (v[u] != EMPTY) atomicAdd(&h64[place_digit2(place_stage2(place_stage1(v[u], g.pl) - base1, g.pl), g.pl)], 1ULL);
         }
         lds_barrier();
         const uint64_t mine = tid < g.P2 ? h64[tid] : 0;
@@ -465,19 +526,9 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
         if (bend && tid == g.P2 - 1) bend[b1] = beg + excl + mine;                             // the runs of a bucket stop short of the next bucket (padding)
         for (uint64_t tbeg = beg; tbeg < end; tbeg += TILE_ITEMS) {                            // pass B
             uint64_t key[PART_ITEMS];
-            uint32_t valid = 0;
-#pragma unroll
-            for (int j = 0; j < PART_ITEMS; ++j) {
-                const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + tid;
-                key[j] = 0;
-                if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
-            }
-            if (seg_slots) {                                     // segment padding (looked at only after all 16 loads are in flight)
-#pragma unroll
-                for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);
-            }
+            const uint32_t valid = p2_tile_load(l1_buf, tbeg, end, seg_slots != 0, key);
             lds_barrier();
-            scatter_tile<2>(L, g, key, valid, l2_buf);
+            scatter_tile2<HB, false>(L, g, base1, key, valid, l2_lo, l2_hi, nullptr, nullptr, nullptr, 0);
         }
     }
 }
@@ -492,57 +543,9 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 __device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t b1, uint32_t P2) { return beg + (beg >> 4) + (uint64_t)b1 * P2 * 16; }
 __device__ __host__ __forceinline__ uint64_t p2_region_cap(uint64_t n_b, uint32_t P2) { return (n_b + (n_b >> 4)) / P2 + 16; }
 
-// PACK: 2k <= 54, so the top 10 bits of a staged k-mer are free and carry its bucket through LDS: the copy-out need not hash again
-template <bool PACK>
-__device__ __forceinline__ void scatter_tile2_bounded(PartLds& L, const PartGeom g, const uint64_t (&key)[PART_ITEMS], uint32_t valid,
-                                                      uint64_t* __restrict__ out, const uint64_t* lim, uint64_t* __restrict__ ovf_buf,
-                                                      unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t P = g.P2;
-    if (tid < MAX_PARTS) L.hist[tid] = 0;
-    lds_barrier();
-    uint32_t br[PART_ITEMS];
-#pragma unroll
-    for (int j = 0; j < PART_ITEMS; ++j) {
-        br[j] = 0;
-        if (valid >> j & 1) {
-            const uint32_t b = digit2_of_hash(mix64(key[j]), g.P2);
-            br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
-        }
-    }
-    lds_barrier();
-    uint32_t total;
-    const uint32_t mine = tid < P ? L.hist[tid] : 0;
-    const uint32_t excl = block_exclusive_scan(mine, L.wave_tot, &total);
-    if (tid < MAX_PARTS) L.off[tid] = excl;
-    lds_barrier();
-#pragma unroll
-    for (int j = 0; j < PART_ITEMS; ++j)
-        if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = PACK ? key[j] | ((uint64_t)(br[j] >> 16) << 54) : key[j];
-    lds_barrier();
-    // copy-out, one staged k-mer per lane and step (as in k_p1v2_scatter): the bucket is recomputed from the key -- cheaper than
-    // a third LDS array -- and the steps are independent, where a loop over buckets kept a third of the lanes busy
-    for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
-        const uint64_t staged = L.staging[idx];
-        const uint64_t key1 = PACK ? staged & ((1ULL << 54) - 1) : staged;
-        const uint32_t b = PACK ? (uint32_t)(staged >> 54) : digit2_of_hash(mix64(key1), g.P2);
-        const uint64_t dst = L.cursor[b] + (idx - L.off[b]);
-        if (dst < lim[b]) out[dst] = key1;
-        else {                                                             // beyond the run's capacity: the overflow list
-            const unsigned long long at = atomicAdd(ovf_n, 1ULL);
-            if (at < ovf_cap) ovf_buf[at] = key1;
-        }
-    }
-    lds_barrier();
-    if (tid < P) {
-        const uint64_t room = lim[tid] - L.cursor[tid];
-        L.cursor[tid] += (uint64_t)L.hist[tid] <= room ? L.hist[tid] : room;
-    }
-}
-
-template <bool PACK>
+template <int HB>
 __global__ void __launch_bounds__(PART_BLOCK)
-k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint64_t* __restrict__ l2_buf,
+k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint32_t* __restrict__ l2_lo, void* __restrict__ l2_hi,
           uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
           uint64_t ovf_cap, uint64_t seg_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -553,6 +556,7 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
         uint64_t beg, end;
         l1_bucket_range(l1_off, seg_slots, b1, beg, end);
         const uint64_t cap = p2_region_cap(end - beg, g.P2), obase = p2_out_base(beg, b1, g.P2);
+        const uint64_t base1 = place_base1(b1, g.pl.n, g.pl.p1);
         lds_barrier();
         if (tid < g.P2) {
             const uint64_t start = obase + (uint64_t)tid * cap;
@@ -562,19 +566,9 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
         }
         for (uint64_t tbeg = beg; tbeg < end; tbeg += TILE_ITEMS) {
             uint64_t key[PART_ITEMS];
-            uint32_t valid = 0;
-#pragma unroll
-            for (int j = 0; j < PART_ITEMS; ++j) {
-                const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + tid;
-                key[j] = 0;
-                if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
-            }
-            if (seg_slots) {                                     // segment padding (looked at only after all 16 loads are in flight)
-#pragma unroll
-                for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);
-            }
+            const uint32_t valid = p2_tile_load(l1_buf, tbeg, end, seg_slots != 0, key);
             lds_barrier();
-            scatter_tile2_bounded<PACK>(L, g, key, valid, l2_buf, lim, ovf_buf, ovf_n, ovf_cap);
+            scatter_tile2<HB, true>(L, g, base1, key, valid, l2_lo, l2_hi, lim, ovf_buf, ovf_n, ovf_cap);
         }
         lds_barrier();
         if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = (uint32_t)(L.cursor[tid] - (obase + (uint64_t)tid * cap));
@@ -588,7 +582,7 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
 // from HBM into registers, and r's write-back drains behind it -- the CU's memory pipe stays busy through the LDS phase.
 template <int BLOCK, int SPT, int BATCH = 4, bool TEST_SPILL = false /* honours spill_mod: instantiated for the test suite only */>
 __global__ void __launch_bounds__(BLOCK)
-k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
+k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint32_t* __restrict__ l2_lo, const void* __restrict__ l2_hi,
            uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod,
            const uint32_t* __restrict__ cnt2 /* run lengths when k_p2_fast laid the runs out; null: off2[r + 1] ends run r */,
            const uint64_t* __restrict__ bend /* exact level 2 over a chunked level 1: where the last run of each bucket ends */) {
@@ -619,6 +613,9 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
     while (r < g.R) {
         const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : run_end(r);
         const uint64_t base = (uint64_t)r * S;
+        // an item is the remainder of its k-mer's placement hash; the region supplies the digits (kg_device.hpp "placement")
+        const uint64_t base1 = place_base1(r >> g.l2, g.pl.n, g.pl.p1), d2_hi = g.pl.rb < 64 ? (uint64_t)(r & (g.P2 - 1)) << g.pl.rb : 0ULL;
+        auto item = [&](uint64_t i) -> unsigned long long { return place_key(base1, d2_hi | l2_load_any(g.hb, l2_lo, l2_hi, i), g.pl); };
 #pragma unroll
         for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
         lds_barrier();
@@ -631,11 +628,11 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
         // its way from HBM.
         unsigned long long cur[BATCH], nxt[BATCH];
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u) { const uint64_t i = beg + (uint64_t)u * BLOCK + tid; cur[u] = i < end ? l2_buf[i] : EMPTY; }
+        for (int u = 0; u < BATCH; ++u) { const uint64_t i = beg + (uint64_t)u * BLOCK + tid; cur[u] = i < end ? item(i) : EMPTY; }
         for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)BATCH * BLOCK) {
           const uint64_t i1 = i0 + (uint64_t)BATCH * BLOCK;
 #pragma unroll
-          for (int u = 0; u < BATCH; ++u) { const uint64_t i = i1 + (uint64_t)u * BLOCK + tid; nxt[u] = i < end ? l2_buf[i] : EMPTY; }
+          for (int u = 0; u < BATCH; ++u) { const uint64_t i = i1 + (uint64_t)u * BLOCK + tid; nxt[u] = i < end ? item(i) : EMPTY; }
           if (!prefetched) { if (rn < g.R) prefetch(rn); prefetched = true; }     // issued AFTER the first batches: their wait does not cover these
           uint32_t nv = 0;                                                          // this lane's k-mers in the batch (EMPTY only pads the tail)
 #pragma unroll
@@ -647,10 +644,9 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
                   key = cur[0];
 #pragma unroll
                   for (int q = 1; q < BATCH; ++q) key = u == (uint32_t)q ? cur[q] : key;
-                  const uint64_t h = mix64(key);
-                  slot = offset_of_hash(h, S);
+                  slot = home_offset(key, t);
                   probes = 0;
-                  if (!(TEST_SPILL && spill_mod && __umulhi((uint32_t)(h >> 32), spill_mod) == 0)) break;   // test hook: 1 k-mer in spill_mod takes the spill path
+                  if (!(TEST_SPILL && spill_mod && __umulhi((uint32_t)(mix64(key) >> 32), spill_mod) == 0)) break;   // test hook: 1 k-mer in spill_mod takes the spill path
                   spill[atomicAdd(spill_n, 1ULL)] = key;
                   ++u;
               }
@@ -703,9 +699,9 @@ constexpr int AP2_QCAP = 256;                                 // straggler queue
 constexpr int AP2_LANE_PROBES = 12;                           // probes a queue entry gets from its own lane before the wave takes it over
 constexpr uint64_t AP2_SEGMENT = 0x7FF00000ULL;               // k-mers per walk: < 2^31
 
-template <int BLOCK, int KP /* 16-byte key loads per lane that cover a region */, int U, int NR, bool STAMP = false, bool INLINE_CLAIM = false, bool DYN = true>
+template <int BLOCK, int KP /* 16-byte key loads per lane that cover a region */, int U, int NR, int HB /* high bytes of an item */, bool STAMP = false, bool INLINE_CLAIM = false, bool DYN = true>
 __global__ void __launch_bounds__(BLOCK)
-k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ l2_buf,
+k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint32_t* __restrict__ l2_lo, const void* __restrict__ l2_hi,
             uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n,
             const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend, unsigned long long* __restrict__ stamps = nullptr) {
     // STAMP: cycle stamps of wave 0 (tools/ab_apply.sh): [0] fill + sweep, [1] chunk loads + hash, [2] probe rounds, [3] queue push + drains,
@@ -754,6 +750,9 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
 #pragma unroll
         for (int u = 0; u < CP; ++u) { const uint32_t i = (u * BLOCK + tid) * 4; if (i < S) *reinterpret_cast<u32x4*>(rc + i) = cq[u]; }
         const uint32_t rn = next_region(r + gridDim.x);
+        // an item is the remainder of its k-mer's placement hash; the region supplies the digits (kg_device.hpp "placement"):
+        // the home slot comes straight from the remainder, the k-mer (what the slots hold) through the inverse hash
+        const uint64_t base1 = place_base1(r >> g.l2, g.pl.n, g.pl.p1), d2_hi = g.pl.rb < 64 ? (uint64_t)(r & (g.P2 - 1)) << g.pl.rb : 0ULL;
 
         for (uint64_t sbeg = beg; sbeg < end; sbeg += AP2_SEGMENT) {        // one segment, normally
             const uint64_t n_run = (end - sbeg < AP2_SEGMENT ? end - sbeg : AP2_SEGMENT);
@@ -849,9 +848,10 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
             };
 
             const uint64_t n_chunks = (n_run + CH - 1) / CH;
-            unsigned long long cur[U], nxt[U];
+            unsigned long long cur[U], nxt[U];                    // remainders (then k-mers) of this chunk, remainders of the next
+            uint32_t cur_n = 0, nxt_n = 0;                        // bit u: item u exists
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const uint64_t i = (uint64_t)wave * CH + (uint64_t)u * 64 + lane; const unsigned long long v = l2_buf[sbeg + (i < n_run ? i : 0)]; cur[u] = i < n_run ? v : EMPTY; }
+            for (int u = 0; u < U; ++u) { const uint64_t i = (uint64_t)wave * CH + (uint64_t)u * 64 + lane; cur[u] = l2_load<HB>(l2_lo, l2_hi, sbeg + (i < n_run ? i : 0)); cur_n |= i < n_run ? 1u << u : 0u; }
             // (static round-robin left the workgroup waiting ~12 K cycles per region for its slowest wave: the drains vary)
             auto grab = [&]() -> uint64_t {
                 unsigned long long v = 0;
@@ -864,13 +864,17 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
 #pragma unroll
                 for (int u = 0; u < U; ++u) {                 // next chunk: in flight behind this one (unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch)
                     const uint64_t i = c_next * CH + (uint64_t)u * 64 + lane;
-                    const unsigned long long v = l2_buf[sbeg + (i < n_run ? i : 0)];
-                    nxt[u] = i < n_run ? v : EMPTY;
+                    nxt[u] = l2_load<HB>(l2_lo, l2_hi, sbeg + (i < n_run ? i : 0));
+                    nxt_n |= i < n_run ? 1u << u : 0u;
                 }
                 uint32_t slot[U];
                 bool pend[U];                                     // k-mer u still to be placed (lane masks in SGPRs)
 #pragma unroll
-                for (int u = 0; u < U; ++u) { slot[u] = offset_of_hash(mix64(cur[u]), S); pend[u] = cur[u] != EMPTY; }
+                for (int u = 0; u < U; ++u) {
+                    pend[u] = (cur_n >> u) & 1;
+                    slot[u] = place_offset(cur[u], g.pl, S);
+                    cur[u] = place_key(base1, d2_hi | cur[u], g.pl);
+                }
                 const unsigned long long t_b = now();
                 // Probe rounds: U reads in flight, one wait; a match adds 1 and is done, a foreign key moves on, an EMPTY slot is
                 // claimed.  Lanes that are done take no part in the LDS operations.
@@ -951,6 +955,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                 while (q_n > (last ? 0u : 64u)) drain_pass(last);
 #pragma unroll
                 for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+                cur_n = nxt_n; nxt_n = 0;
                 c = c_next;
                 if (STAMP) { const unsigned long long t_d = now(); st[1] += t_b - t_a; st[2] += t_c - t_b; st[3] += t_d - t_c; }
             }
