@@ -312,6 +312,8 @@ static const bool g_no_join = hook("KATGPU_NO_JOIN") != nullptr;       // A/B sw
 static const uint32_t g_region_slots = hook("KATGPU_TEST_REGION_SLOTS") ? (uint32_t)strtoul(hook("KATGPU_TEST_REGION_SLOTS"), nullptr, 10) : REGION_SLOTS;
 
 constexpr uint32_t MAX_REGION_SLOTS = 12288;        // 144 KB of LDS in the apply / join kernels
+constexpr uint32_t AP2_MAX_SLOTS = 10240;           // the second-edition apply: 120 KB of region + 36 KB of queues (k_p3_apply2<1024, 5, ...>)
+constexpr int AP2_QCAP_BIG = 192;                   // its queue entries per wave for regions beyond 8192 slots
 
 // like_p1/like_p2 != 0: adopt that region grid (so that comp can join region against region) and take up the capacity in the
 // region size, if a region of the resulting size still fits LDS.
@@ -337,7 +339,18 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
         while ((uint64_t)p2 * p2 < nr) ++p2;                   // two radix digits of about the same size
         if (k <= 32) { uint32_t q = 1; while (q < p2) q <<= 1; p2 = q; }   // one-word tables: the level-2 digit is a bit field of the placement hash
         d.p2 = p2; d.p1 = (uint32_t)((nr + p2 - 1) / p2);
-        d.n_regions = d.p1 * d.p2; d.region_slots = g_region_slots;
+        d.region_slots = g_region_slots;
+        // Level 2 of the partitioned counter works one bucket per workgroup and CU at a time: 584 buckets on 256 CUs are three
+        // passes of which the last keeps 72 CUs busy.  With more buckets than CUs, make them a whole number of passes -- fewer,
+        // larger regions if the apply kernel's LDS holds them (AP2_MAX_SLOTS), else more, smaller ones.
+        const uint32_t ncu = (uint32_t)c->n_cu;
+        if (k <= 32 && g_region_slots == REGION_SLOTS && ncu && d.p1 > ncu && d.p1 % ncu) {
+            auto slots_for = [&](uint32_t p1) { return (uint32_t)(((cap + (uint64_t)p1 * p2 - 1) / ((uint64_t)p1 * p2) + 3) & ~3ULL); };
+            const uint32_t lo = d.p1 / ncu * ncu, hi = lo + ncu;
+            if (slots_for(lo) <= AP2_MAX_SLOTS) { d.p1 = lo; d.region_slots = slots_for(lo); }
+            else if (hi <= MAX_PARTS) { d.p1 = hi; d.region_slots = slots_for(hi); }
+        }
+        d.n_regions = d.p1 * d.p2;
     }
     cap = (uint64_t)d.n_regions * d.region_slots;
     d.cap = cap; d.k = k; d.canonical = canonical ? 1 : 0;
@@ -594,15 +607,18 @@ static const uint32_t g_p2_fast = hook("KATGPU_P2_FAST") ? (uint32_t)strtoul(hoo
 static const uint64_t g_test_p2_ovf_cap = hook("KATGPU_TEST_P2_OVF_CAP") ? strtoull(hook("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
 static const uint32_t g_test_spill_mod = hook("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(hook("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 
+static const bool g_p2_stamp = hook("KATGPU_P2_STAMP") != nullptr;       // diagnostic: per-phase cycle stamps of k_p2_fast
+static const uint32_t g_test_hb = hook("KATGPU_TEST_HB") ? (uint32_t)strtoul(hook("KATGPU_TEST_HB"), nullptr, 10) : 0;   // A/B: wider level-2 items than needed (1, 2, 4)
 static bool part_geometry(const DevTable& d, PartGeom* g) {
     g->R = d.n_regions; g->S = d.region_slots; g->P1 = d.p1; g->P2 = d.p2; g->l2 = d.l2;
     g->pl = place_make(d.k, d.p1, d.n1, d.l2);
-    g->hb = l2_hi_bytes(g->pl.rb);
-    return d.k <= 32 && g->P1 <= MAX_PARTS && g->P2 <= MAX_PARTS && (size_t)g->S * 12 <= 150 * 1024;
+    g->hb = std::max(l2_hi_bytes(g->pl.rb), g_test_hb);
+    return d.k <= 32 && g->pl.rb <= 63 /* all-ones is "no item" */ && g->P1 <= MAX_PARTS && g->P2 <= MAX_PARTS && (size_t)g->S * 12 <= 150 * 1024;
 }
 // bytes of partition arena per k-mer of a round: level-1 buffer (8 B + the segment slack 1/24), level-2 buffer (4 + hb B, that
-// slack again + the run slack 1/16), overflow list (8 B / 32)
-static double arena_bytes_per_item(uint32_t hb) { return 8.0 * (1 + 1.0 / 24) + (4.0 + hb) * (1 + 1.0 / 24) * (1 + 1.0 / 16) + 0.25 + 0.02; }
+// slack again + the run slack 1/16 + the group padding's allowance 2 * 1024 / tile), overflow list (8 B / 32)
+static double l2_items_per_l1_item(uint32_t hb) { return 1 + 1.0 / 16 + 2.0 * MAX_PARTS / l2_tile_items(hb); }
+static double arena_bytes_per_item(uint32_t hb) { return 8.0 * (1 + 1.0 / 24) + (4.0 + hb) * (1 + 1.0 / 24) * l2_items_per_l1_item(hb) + 0.25 + 0.02; }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -680,8 +696,9 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
 #define KG_LDS_ATTR(K, BYTES) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
 #define KG_FOR_HB(M) M(0) M(1) M(2) M(4)
 #define KG_ATTR_HB(HB) \
-        KG_LDS_ATTR((k_p2<HB>), sizeof(PartLds)); KG_LDS_ATTR((k_p2_fast<HB>), sizeof(PartLds)); \
+        KG_LDS_ATTR((k_p2<HB>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB>), sizeof(P2Lds<HB>)); \
         KG_LDS_ATTR((k_p3_apply2<1024, 4, 4, 3, HB>), 150 * 1024); KG_LDS_ATTR((k_p3_apply2<1024, 4, 4, 3, HB, false, true, true>), 150 * 1024); \
+        KG_LDS_ATTR((k_p3_apply2<1024, 5, 4, 3, HB, false, false, true, AP2_QCAP_BIG>), 160 * 1024 - 256); KG_LDS_ATTR((k_p3_apply2<1024, 5, 4, 3, HB, false, true, true, AP2_QCAP_BIG>), 160 * 1024 - 256); \
         KG_LDS_ATTR((k_p3_apply2<512, 4, 4, 3, HB>), 150 * 1024); KG_LDS_ATTR((k_p3_apply2<512, 4, 4, 3, HB, false, true, true>), 150 * 1024); \
         KG_LDS_ATTR((k_p3_apply2<512, 2, 4, 3, HB>), 150 * 1024); KG_LDS_ATTR((k_p3_apply2<512, 2, 4, 3, HB, false, true, true>), 150 * 1024);
         KG_FOR_HB(KG_ATTR_HB)
@@ -693,19 +710,20 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     }
     // ---- arena: [hist1 | offs | l1_off | off2 | cnt2 | bend | spill_n, ovf_n | L1 buffer | L2 buffer | overflow list] ----
     // L1 buffer: a round's k-mers + 1/24 + 64 per workgroup and bucket (segment slack of k_p1v2_scatter<true>);
-    // L2 buffer: that + 1/16 + 16 per region (capacity slack of k_p2_fast), 4 + hb bytes per item (low words, then the high parts);
-    // overflow list: 1/32.  14.1 bytes per k-mer of a round at hb = 1 (k = 27 at the bench size), 17.45 at hb = 4.
+    // L2 buffer: items of 4 + hb bytes in groups of four (kg_partition.hpp "the level-2 buffer"): the L1 count + 1/16 + 16 per region
+    // (capacity slack of k_p2_fast) + two items per tile and region (group padding); overflow list: 1/32.
+    // 14.8 bytes per k-mer of a round at hb = 1 (k = 27 at the bench size), 18.5 at hb = 4.
     PartGeom g0;
     if (!part_geometry(t->d, &g0)) return KATGPU_OK;                              // direct path
     const uint32_t hb0 = g0.hb;                                                  // a table that grows has more regions: never more remainder bits
     const double per_item = arena_bytes_per_item(hb0);
     constexpr size_t SEG_PAD = 64;
     const size_t fixed_l1 = (size_t)W * MAX_PARTS * SEG_PAD;
-    const size_t fixed_l2 = fixed_l1 + fixed_l1 / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024;
+    const size_t fixed_l2 = (size_t)((double)fixed_l1 * l2_items_per_l1_item(hb0)) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 8192;
     const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +   /* W <= 4 * CUs */
                                align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) +
                                align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256) + align_up((size_t)MAX_PARTS * 8, 256) + align_up((size_t)MAX_PARTS * 4, 256) + 256 +
-                               (fixed_l1 + fixed_l2 + 4096) * 8 + 64;
+                               (fixed_l1 + fixed_l2 + 4096) * 8 + 4096;
     size_t want_items = n_starts;
     if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
     const size_t want_bytes = small_bytes + (size_t)((per_item + 0.5) * (double)want_items);
@@ -735,11 +753,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     unsigned long long* ovf_n = spill_n + 1;      a += 256;
     const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / per_item));
     const size_t l1_items = round_items + round_items / 24 + fixed_l1;
-    const size_t l2_items = (l1_items + l1_items / 16 + (size_t)MAX_PARTS * MAX_PARTS * 16 + 1024 + 3) & ~(size_t)3;
+    const size_t l2_items = ((size_t)((double)l1_items * l2_items_per_l1_item(hb0)) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 4096 + 3) & ~(size_t)3;
     uint64_t* l1_buf = (uint64_t*)a;
-    uint32_t* l2_lo = (uint32_t*)(l1_buf + l1_items);                              // level-2 items: low words ...
-    void* l2_hi = l2_lo + l2_items;                                              // ... and hb0 bytes each of high parts
-    uint64_t* ovf_buf = (uint64_t*)((uint8_t*)l2_hi + align_up(l2_items * hb0, 16));
+    uint8_t* l2_buf = (uint8_t*)(l1_buf + l1_items);                               // level-2 items, groups of 4
+    uint64_t* ovf_buf = (uint64_t*)(l2_buf + align_up(l2_items / 4 * l2_group_bytes(hb0), 16));
     const uint64_t ovf_cap = g_test_p2_ovf_cap ? g_test_p2_ovf_cap : round_items / 32 + 1024;
     bool p2_fast_ok = g_p2_fast != 0, l1_fast_ok = g_l1_fast != 0;
     if (!g_test_round_items && round_items < ((size_t)1 << 20) && round_items < n_starts) return KATGPU_OK;
@@ -834,9 +851,24 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             const uint32_t* run_len = nullptr;
             unsigned long long overflowed = 0;
             const bool try_fast = p2_fast_ok && (g_p2_fast == 2 || items / g.R >= 1024);
+            if (try_fast && g_p2_stamp && g.hb == 1) {         // diagnostic: cycle stamps of wave 0 of every workgroup
+                unsigned long long* d_st = nullptr;
+                HIPCHK(c, hipMalloc((void**)&d_st, 64));
+                HIPCHK(c, hipMemsetAsync(d_st, 0, 64, c->stream));
+                KG_LDS_ATTR((k_p2_fast<1, true>), sizeof(P2Lds<1>));
+                hipLaunchKernelGGL((k_p2_fast<1, true>), dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(P2Lds<1>), c->stream, g, l1_off, l1_buf, l2_buf,
+                                   off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, d_st);
+                unsigned long long h[8];
+                HIPCHK(c, hipMemcpyAsync(h, d_st, 48, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                hipFree(d_st);
+                const double n = (double)std::max<unsigned long long>(1, h[5]);
+                fprintf(stderr, "[katgpu] k_p2_fast stamps per tile (cycles, wave 0): loads %.0f, hash+rank %.0f, scan %.0f, staging %.0f, copy-out %.0f; %llu tiles\n",
+                        h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5]);
+            } else
             if (try_fast) {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-#define KG_P2F(HB) case HB: hipLaunchKernelGGL(k_p2_fast<HB>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_lo, l2_hi, \
+#define KG_P2F(HB) case HB: hipLaunchKernelGGL(k_p2_fast<HB>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots); break;
                 switch (g.hb) { KG_FOR_HB(KG_P2F) }
 #undef KG_P2F
@@ -860,40 +892,47 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             }
             if (!run_len) {
                 ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-#define KG_P2(HB) case HB: hipLaunchKernelGGL(k_p2<HB>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(PartLds), c->stream, g, l1_off, l1_buf, l2_lo, l2_hi, \
-                                              off2, seg_slots, seg ? bend : (uint64_t*)nullptr); break;
+#define KG_P2(HB) case HB: hipLaunchKernelGGL(k_p2<HB>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+                                              off2, seg_slots, bend); break;
                 switch (g.hb) { KG_FOR_HB(KG_P2) }
 #undef KG_P2
             }
-            const uint64_t* bucket_end = (!run_len && seg) ? bend : nullptr;
+            const uint64_t* bucket_end = !run_len ? bend : nullptr;             // exact level 2: a bucket's runs stop short of the next bucket's
             {
                 ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
                 // as many workgroups per CU as the regions' LDS footprint (and the 2048-thread limit) admits
                 const uint32_t blk = g_apply_block ? g_apply_block : (g.S <= 4096 ? 512 : 1024);
                 // second edition (batched walk, per-wave straggler queues behind the region in LDS) unless a test hook needs the first
-                const bool v2 = g_apply_v != 1 && !g_test_spill_mod && g.S % 4 == 0 && g.S >= 64 && g.S <= 8192 && (blk == 512 ? g.S <= 4096 : true);
+                const bool v2 = g_apply_v != 1 && !g_test_spill_mod && g.S % 4 == 0 && g.S >= 64 && g.S <= AP2_MAX_SLOTS && (blk == 512 ? g.S <= 4096 : true);
                 if (v2) {
-                    const size_t lds2 = (size_t)g.S * 12 + (size_t)(blk / 64) * AP2_QCAP * 12;
+                    const bool big = g.S > 8192;
+                    const size_t lds2 = (size_t)g.S * 12 + (size_t)(blk / 64) * (big ? AP2_QCAP_BIG : AP2_QCAP) * 12;
                     const uint32_t per_cu2 = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds2 + 512), 2048 / blk));
                     const uint32_t grid2 = std::min<uint32_t>(g.R, W2 * per_cu2);
                     // a table that is still empty sees nothing but new keys in this round: they are claimed inside the probe rounds
                     // (INLINE_CLAIM) instead of all going through the queues; any later round loses by that (kg_partition.hpp)
                     const bool fresh = t->distinct == 0 && !g_apply_noinline;
 #define KG_APPLY2(B, KP, HB) do { \
-                        if (fresh) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, true, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint32_t*)l2_lo, (const void*)l2_hi, \
+                        if (fresh) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, true, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
                                                       l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); \
-                        else hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint32_t*)l2_lo, (const void*)l2_hi, \
+                        else hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
                                                 l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } while (0)
-#define KG_APPLY2_HB(HB) case HB: if (blk == 512) { if (g.S <= 2048) KG_APPLY2(512, 2, HB); else KG_APPLY2(512, 4, HB); } else KG_APPLY2(1024, 4, HB); break;
+#define KG_APPLY2_BIG(HB) do { \
+                        if (fresh) hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, true, true, AP2_QCAP_BIG>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
+                                                      l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); \
+                        else hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, false, true, AP2_QCAP_BIG>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
+                                                l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } while (0)
+#define KG_APPLY2_HB(HB) case HB: if (blk == 512) { if (g.S <= 2048) KG_APPLY2(512, 2, HB); else KG_APPLY2(512, 4, HB); } else if (big) KG_APPLY2_BIG(HB); else KG_APPLY2(1024, 4, HB); break;
                     switch (g.hb) { KG_FOR_HB(KG_APPLY2_HB) }
 #undef KG_APPLY2_HB
+#undef KG_APPLY2_BIG
 #undef KG_APPLY2
                 } else {
                 const size_t lds = (size_t)g.S * 12;
                 // small regions (a table created "like" a bigger one): 512-thread workgroups, four per CU instead of two
                 const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
                 const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
-#define KG_APPLY1(B, SPT, HOOKED) hipLaunchKernelGGL((k_p3_apply<B, SPT, 4, HOOKED>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, (const uint32_t*)l2_lo, (const void*)l2_hi, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
+#define KG_APPLY1(B, SPT, HOOKED) hipLaunchKernelGGL((k_p3_apply<B, SPT, 4, HOOKED>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
 #define KG_APPLY(B, SPT) do { if (g_test_spill_mod) KG_APPLY1(B, SPT, true); else KG_APPLY1(B, SPT, false); } while (0)
                 const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
                 if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }

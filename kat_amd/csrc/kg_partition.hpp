@@ -40,42 +40,94 @@ struct PartGeom {
     uint32_t R, S;     // regions, slots per region (the table's)
     uint32_t P1, P2;   // region r = b1 * P2 + b2 (the table's p1, p2): level-1 bucket b1, level-2 bucket b2
     uint32_t l2;       // P2 == 1 << l2
-    uint32_t hb;       // bytes of a level-2 item beyond its low 32 bits: 0, 1, 2 or 4 (from pl.rb)
+    uint32_t hb;       // bytes of a level-2 item beyond its low 32 bits: 0, 1, 2 or 4 (from pl.rb; "the level-2 buffer" below)
     Place pl;          // the placement hash's bit budget for this table (kg_device.hpp)
 };
-// the two streams of a level-2 buffer of `cap` items: low words first, high parts behind them
-__device__ __host__ __forceinline__ const void* l2_hi_of(const uint32_t* lo, uint64_t cap) { return lo + cap; }
-__device__ __host__ __forceinline__ void* l2_hi_of(uint32_t* lo, uint64_t cap) { return lo + cap; }
-__device__ __host__ __forceinline__ uint32_t l2_hi_bytes(uint32_t rb) { return rb <= 32 ? 0u : rb <= 40 ? 1u : rb <= 48 ? 2u : 4u; }
+// ---- the level-2 buffer ----
+// Items of 4 + HB bytes (low word + HB = 0, 1, 2 or 4 bytes of high bits) in GROUPS of four: [4 low words | 4 high parts] =
+// 16 + 4 HB contiguous bytes (20 at the bench size).  Level 2 stores, and the apply loads, a group with two instructions, and what
+// a sub-bucket receives from one tile is ONE contiguous piece.  That is what the layout is for: the copy-out is bound by how many
+// pieces (cache-line visits) reach the memory system and how long their acknowledgements take -- waves parked 75 % of their cycles
+// (profiles/) -- not by bytes: plain per-item stores into a low-word stream and a high-part stream measured 301 ms for level 2 at
+// the bench size, groups with the two streams 128 bytes apart 285, against 205 for 8-byte k-mers.  Runs start on group
+// boundaries; the all-ones item is "no item" (padding), which is why HB leaves the remainder at least one spare code.  Groups are
+// only 4-byte aligned (gfx950 takes 16-byte accesses at any dword).
+__device__ __host__ __forceinline__ uint32_t l2_hi_bytes(uint32_t rb) { return rb <= 31 ? 0u : rb <= 39 ? 1u : rb <= 47 ? 2u : 4u; }   // rb = 64: no partition path (part_geometry)
+template <int HB> struct L2Fmt {
+    static constexpr int N = HB == 4 ? 12 : 16;              // k-mers per lane and tile (what the padded tile costs in LDS)
+    static constexpr int TILE = N * 1024;
+    static constexpr int NS = TILE + 3 * 1024;               // staged slots of a tile: every sub-bucket's run padded to whole groups
+    static constexpr uint32_t GS = 16 + 4 * HB;              // bytes of a group
+    static constexpr uint64_t NONE = HB == 4 ? ~0ULL : (1ULL << (32 + 8 * HB)) - 1;
+};
+__device__ __host__ __forceinline__ uint32_t l2_group_bytes(uint32_t hb) { return 16 + 4 * hb; }
+__device__ __host__ __forceinline__ uint32_t l2_tile_items(uint32_t hb) { return hb == 4 ? 12 * 1024 : 16 * 1024; }
 template <int HB> struct HiWord { typedef uint32_t type; };
 template <> struct HiWord<1> { typedef uint8_t type; };
 template <> struct HiWord<2> { typedef uint16_t type; };
+// one item (slow paths: the exact level 2, the first-edition apply)
 template <int HB>
-__device__ __forceinline__ void l2_store(uint32_t* __restrict__ lo, void* __restrict__ hi, uint64_t at, uint64_t rem) {
-    lo[at] = (uint32_t)rem;
-    if (HB) reinterpret_cast<typename HiWord<HB>::type*>(hi)[at] = (typename HiWord<HB>::type)(rem >> 32);
+__device__ __forceinline__ void l2_put(uint8_t* __restrict__ buf, uint64_t i, uint64_t rem) {
+    uint8_t* grp = buf + (i >> 2) * L2Fmt<HB>::GS;
+    reinterpret_cast<uint32_t*>(grp)[i & 3] = (uint32_t)rem;
+    if (HB) reinterpret_cast<typename HiWord<HB>::type*>(grp + 16)[i & 3] = (typename HiWord<HB>::type)(rem >> 32);
 }
 template <int HB>
-__device__ __forceinline__ uint64_t l2_load(const uint32_t* __restrict__ lo, const void* __restrict__ hi, uint64_t at) {
-    const uint32_t l = lo[at];
-    const uint32_t h = HB ? (uint32_t)reinterpret_cast<const typename HiWord<HB>::type*>(hi)[at] : 0u;
+__device__ __forceinline__ uint64_t l2_get(const uint8_t* __restrict__ buf, uint64_t i) {
+    const uint8_t* grp = buf + (i >> 2) * L2Fmt<HB>::GS;
+    const uint32_t l = reinterpret_cast<const uint32_t*>(grp)[i & 3];
+    const uint32_t h = HB ? (uint32_t)reinterpret_cast<const typename HiWord<HB>::type*>(grp + 16)[i & 3] : 0u;
     return ((uint64_t)h << 32) | l;
 }
-// (slow paths: the width is a run-time number)
-__device__ __forceinline__ uint64_t l2_load_any(uint32_t hb, const uint32_t* __restrict__ lo, const void* __restrict__ hi, uint64_t at) {
-    return hb == 0 ? l2_load<0>(lo, hi, at) : hb == 1 ? l2_load<1>(lo, hi, at) : hb == 2 ? l2_load<2>(lo, hi, at) : l2_load<4>(lo, hi, at);
+__device__ __forceinline__ uint64_t l2_get_any(uint32_t hb, const uint8_t* __restrict__ buf, uint64_t i, bool& none) {
+    uint64_t v;
+    if (hb == 0) { v = l2_get<0>(buf, i); none = v == L2Fmt<0>::NONE; }
+    else if (hb == 1) { v = l2_get<1>(buf, i); none = v == L2Fmt<1>::NONE; }
+    else if (hb == 2) { v = l2_get<2>(buf, i); none = v == L2Fmt<2>::NONE; }
+    else { v = l2_get<4>(buf, i); none = v == L2Fmt<4>::NONE; }
+    return v;
+}
+// one group: four low words + four high parts (HB = 4: the high parts are a second 16-byte piece)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a native vector: stays in registers where HIP's uint4 struct went to scratch
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));           // in the level-2 buffer: dword-aligned
+typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
+template <int HB> struct HiGroup { typedef uint32_t type; typedef uint32_t mem; };          // HB = 0: unused; HB = 1: four bytes
+template <> struct HiGroup<2> { typedef u32x2 type; typedef u32x2_a4 mem; };
+template <> struct HiGroup<4> { typedef u32x4 type; typedef u32x4_a4 mem; };
+template <int HB>
+__device__ __forceinline__ uint32_t hi_of_group(const typename HiGroup<HB>::type& h, int q);
+template <> __device__ __forceinline__ uint32_t hi_of_group<0>(const uint32_t&, int) { return 0; }
+template <> __device__ __forceinline__ uint32_t hi_of_group<1>(const uint32_t& h, int q) { return (h >> (8 * q)) & 0xFF; }
+template <> __device__ __forceinline__ uint32_t hi_of_group<2>(const u32x2& h, int q) { return ((q < 2 ? h.x : h.y) >> (16 * (q & 1))) & 0xFFFF; }
+template <> __device__ __forceinline__ uint32_t hi_of_group<4>(const u32x4& h, int q) { return q == 0 ? h.x : q == 1 ? h.y : q == 2 ? h.z : h.w; }
+template <int HB>
+__device__ __forceinline__ void l2_load_group(const uint8_t* __restrict__ buf, uint64_t grp, u32x4& lo, typename HiGroup<HB>::type& hi) {
+    const uint8_t* p = buf + grp * L2Fmt<HB>::GS;
+    lo = *reinterpret_cast<const u32x4_a4*>(p);
+    if (HB) hi = *reinterpret_cast<const typename HiGroup<HB>::mem*>(p + 16);
+}
+template <int HB>
+__device__ __forceinline__ void l2_store_group(uint8_t* __restrict__ buf, uint64_t grp, const u32x4& lo, const typename HiGroup<HB>::type& hi) {
+    uint8_t* p = buf + grp * L2Fmt<HB>::GS;
+    *reinterpret_cast<u32x4_a4*>(p) = lo;
+    if (HB) *reinterpret_cast<typename HiGroup<HB>::mem*>(p + 16) = hi;
 }
 
-// LDS carve of the partition kernels (dynamic shared memory, 16-byte aligned base)
-struct PartLds {
-    uint64_t staging[TILE_ITEMS];      // 128 KB: the tile's k-mers grouped by bucket
-    uint64_t cursor[MAX_PARTS];        // running output position of each bucket for THIS workgroup
-    uint32_t hist[MAX_PARTS];          // per-tile (scatter) or accumulated (count) bucket sizes
-    uint32_t off[MAX_PARTS];           // exclusive scan of hist
+// LDS carve of the level-2 kernels (dynamic shared memory, 16-byte aligned base)
+template <int HB>
+struct P2Lds {
+    uint64_t cursor[MAX_PARTS];        // next free group (fast edition) / item (exact edition) of each sub-bucket's run, THIS workgroup's
+    uint64_t lim[MAX_PARTS];           // fast edition: first group beyond the run
+    uint32_t hist[MAX_PARTS];          // k-mers of the tile per sub-bucket
+    uint32_t goff[MAX_PARTS];          // where the sub-bucket's k-mers of this tile are staged: first group (fast) / first slot (exact)
     uint32_t wave_tot[32];
-    uint32_t code[PART_BLOCK + 2];
-    uint32_t bad[PART_BLOCK + 2];
+    uint32_t pad_[28];                 // (st_lo starts on a 16-byte boundary)
+    uint32_t st_lo[L2Fmt<HB>::NS];     // staged remainders, grouped by sub-bucket: low words ...
+    typename HiWord<HB>::type st_hi[HB ? L2Fmt<HB>::NS : 4];   // ... high parts ...
+    uint16_t grp_b[L2Fmt<HB>::NS / 4]; // ... and the sub-bucket of every staged group
 };
+static_assert(sizeof(P2Lds<0>) <= 160 * 1024 && sizeof(P2Lds<1>) <= 160 * 1024 && sizeof(P2Lds<2>) <= 160 * 1024 && sizeof(P2Lds<4>) <= 160 * 1024, "LDS");
 
 // exclusive scan of v over the first MAX_PARTS lanes of a 1024-thread block (lane b holds bucket b); returns the
 // exclusive prefix, *total gets the grand total.  Two barriers inside.
@@ -108,58 +160,6 @@ __device__ __forceinline__ uint64_t block_exclusive_scan64(uint64_t v, uint64_t*
     for (int w = 0; w < PART_BLOCK / 64; ++w) { uint64_t x = wave_tot[w]; if ((uint32_t)w < wave) prefix += x; }
     lds_barrier();
     return prefix + inc - v;
-}
-
-// One tile of the base stream is 16 bytes per lane.  The load is split from the staging so that the NEXT tile's load can be
-// in flight while the current tile is processed (one workgroup per CU: nothing else hides the ~2 us HBM latency).
-__device__ __forceinline__ void tile_load(const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off, uint32_t (&w)[4]) {
-    const uint64_t off = tile_off + (uint64_t)threadIdx.x * PART_ITEMS;
-    if (off + PART_ITEMS <= n) {
-        const uint4 v = *reinterpret_cast<const uint4*>(bases + off);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { uint64_t i = off + q * 4 + b; x |= (i < n ? (uint32_t)bases[i] : (uint32_t)'N') << (8 * b); }
-            w[q] = x;
-        }
-    }
-}
-
-// 2-bit codes + validity flags of the loaded tile into LDS.  Ends with a barrier.
-__device__ __forceinline__ void tile_stage(PartLds& L, const uint32_t (&w)[4]) {
-    const uint32_t tid = threadIdx.x;
-    uint32_t code, bad;
-    encode16(w, code, bad);
-    L.code[tid] = code;
-    L.bad[tid] = bad;
-    if (tid < 2) { L.code[PART_BLOCK + tid] = 0; L.bad[PART_BLOCK + tid] = 0xFFFF; }
-    lds_barrier();
-}
-
-// The 16 k-mers whose windows start in this lane's 16 positions (canonical if asked); bit j of the result = window j valid.
-__device__ __forceinline__ uint32_t lane_kmers(const PartLds& L, uint32_t k, bool canonical, uint64_t (&key)[PART_ITEMS]) {
-    const uint32_t tid = threadIdx.x;
-    uint32_t valid = 0;
-    if (tid >= L1_LANES_WITH_STARTS) return 0;
-    uint64_t hi = ((uint64_t)L.code[tid] << 32) | L.code[tid + 1];
-    uint64_t lo = (uint64_t)L.code[tid + 2] << 32;
-    uint64_t m = ((uint64_t)L.bad[tid] << 48) | ((uint64_t)L.bad[tid + 1] << 32) | ((uint64_t)L.bad[tid + 2] << 16);
-    const uint32_t kshift = 64 - 2 * k, mshift = 64 - k;
-#pragma unroll
-    for (int j = 0; j < PART_ITEMS; ++j) {
-        uint64_t fwd = hi >> kshift;
-        uint64_t kk = fwd;
-        if (canonical) { uint64_t rc = kmer_revcomp(fwd, k); kk = rc < fwd ? rc : fwd; }
-        key[j] = kk;
-        if ((m >> mshift) == 0) valid |= 1u << j;
-        hi = (hi << 2) | (lo >> 62);
-        lo <<= 2;
-        m <<= 1;
-    }
-    return valid;
 }
 
 // ---- level 1 scan: offs[w][b] = start of workgroup w's run inside bucket b; l1_off[b] = start of bucket b; l1_off[P1] = items ----
@@ -418,23 +418,47 @@ __device__ __forceinline__ void l1_bucket_range(const uint64_t* __restrict__ l1_
 }
 
 // ---- level 2 ----
-// Counting-sort one tile's k-mers of bucket b1 by their level-2 digit through LDS and append every digit's run at this workgroup's
-// cursor.  What is staged and written is the placement hash below the level-1 digit (y2 = digit : remainder, kg_device.hpp), so
-// the copy-out reads its digit off the staged word instead of hashing again, and what reaches HBM is the remainder alone.
-// BOUNDED: a run has a capacity (lim[]); what does not fit goes to the overflow list as a k-mer (through the inverse hash).
-// All 1024 lanes must call it (barriers inside).
-template <int HB, bool BOUNDED>
-__device__ __forceinline__ void scatter_tile2(PartLds& L, const PartGeom g, const uint64_t base1, const uint64_t (&key)[PART_ITEMS], uint32_t valid,
-                                              uint32_t* __restrict__ out_lo, void* __restrict__ out_hi, const uint64_t* lim, uint64_t* __restrict__ ovf_buf,
-                                              unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
+// What level 2 writes is the placement hash below the level-1 digit (y2 = digit : remainder, kg_device.hpp): the digit sorts, the
+// remainder alone reaches HBM.
+// the N k-mers of a lane for one tile of bucket [beg, end) of the level-1 buffer; bit j of the result = item j is a k-mer (not past
+// the end, not segment padding)
+template <int N>
+__device__ __forceinline__ uint32_t p2_tile_load(const uint64_t* __restrict__ l1_buf, uint64_t tbeg, uint64_t end, bool padded, uint64_t (&key)[N]) {
+    // unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch (the compiler pulled
+    // the padding test into the branch of each load: sixteen serialised round trips to HBM, 29 K of a tile's 54 K cycles)
+    uint32_t valid = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + threadIdx.x;
+        key[j] = l1_buf[i < end ? i : end - 1];
+        valid |= i < end ? 1u << j : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) if (padded && key[j] == EMPTY) valid &= ~(1u << j);      // segment padding
+    return valid;
+}
+
+// Counting-sort one tile's k-mers of a bucket by their level-2 digit through LDS and append every digit's run at this workgroup's
+// cursor.  GROUPED (the fast edition): a digit's k-mers of the tile are padded to whole groups of four in LDS and leave as groups --
+// one 16-byte store of low words + one of high parts per four k-mers -- into a run with a capacity (lim[], in groups); what does not
+// fit goes to the overflow list as a k-mer (through the inverse hash).  Not GROUPED (the exact edition): item by item at exact
+// positions.  All 1024 lanes must call it (barriers inside).
+template <int HB, bool GROUPED, bool STAMP = false>
+__device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, const uint64_t base1, const uint64_t (&key)[L2Fmt<HB>::N], uint32_t valid,
+                                              uint8_t* __restrict__ out, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap,
+                                              unsigned long long* st = nullptr /* STAMP: cycles of [1] hash + rank, [2] scan, [3] staging, [4] copy-out */) {
+    constexpr int N = L2Fmt<HB>::N;
+    auto now = [&]() -> unsigned long long { return STAMP ? (unsigned long long)clock64() : 0ULL; };
+    const unsigned long long t0 = now();
+    typedef typename HiWord<HB>::type hi_t;
     const uint32_t tid = threadIdx.x;
     const uint32_t P = g.P2;
     if (tid < MAX_PARTS) L.hist[tid] = 0;
     lds_barrier();
-    uint32_t br[PART_ITEMS];                                  // digit << 16 | rank inside the tile's run
-    uint64_t y2[PART_ITEMS];
+    uint32_t br[N];                                           // digit << 16 | rank inside the tile's run
+    uint64_t y2[N];
 #pragma unroll
-    for (int j = 0; j < PART_ITEMS; ++j) {
+    for (int j = 0; j < N; ++j) {
         br[j] = 0; y2[j] = 0;
         if (valid >> j & 1) {
             y2[j] = place_stage2(place_stage1(key[j], g.pl) - base1, g.pl);
@@ -443,64 +467,82 @@ __device__ __forceinline__ void scatter_tile2(PartLds& L, const PartGeom g, cons
         }
     }
     lds_barrier();
-    uint32_t total;
+    const unsigned long long t1 = now();
+    uint32_t total;                                           // staged groups (GROUPED) / k-mers of the tile
     const uint32_t mine = tid < P ? L.hist[tid] : 0;
-    const uint32_t excl = block_exclusive_scan(mine, L.wave_tot, &total);
-    if (tid < MAX_PARTS) L.off[tid] = excl;
+    const uint32_t excl = block_exclusive_scan(GROUPED ? (mine + 3) >> 2 : mine, L.wave_tot, &total);
+    if (tid < MAX_PARTS) L.goff[tid] = excl;
+    if (GROUPED && tid < P) {                                 // the last group of the run: what the k-mers leave is "no item"
+        for (uint32_t q = mine; q & 3; ++q) { L.st_lo[excl * 4 + q] = 0xFFFFFFFFu; if (HB) L.st_hi[excl * 4 + q] = (hi_t)~(hi_t)0; }
+    }
     lds_barrier();
+    const unsigned long long t2 = now();
 #pragma unroll
-    for (int j = 0; j < PART_ITEMS; ++j)
-        if (valid >> j & 1) L.staging[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = y2[j];
-    lds_barrier();
-    // copy-out, one staged k-mer per lane and step (as in k_p1v2_scatter): the steps are independent, where a loop over the runs
-    // kept a third of the lanes busy
-    for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
-        const uint64_t staged = L.staging[idx];
-        const uint32_t b = place_digit2(staged, g.pl);
-        const uint64_t dst = L.cursor[b] + (idx - L.off[b]);
-        if (!BOUNDED || dst < lim[b]) l2_store<HB>(out_lo, out_hi, dst, place_rem(staged, g.pl));
-        else {                                                             // beyond the run's capacity: the overflow list
-            const unsigned long long at = atomicAdd(ovf_n, 1ULL);
-            if (at < ovf_cap) ovf_buf[at] = place_key(base1, staged, g.pl);
+    for (int j = 0; j < N; ++j)
+        if (valid >> j & 1) {
+            const uint32_t b = br[j] >> 16, slot = L.goff[b] * (GROUPED ? 4u : 1u) + (br[j] & 0xFFFF);
+            const uint64_t rem = place_rem(y2[j], g.pl);
+            L.st_lo[slot] = (uint32_t)rem;
+            if (HB) L.st_hi[slot] = (hi_t)(rem >> 32);
+            if (GROUPED) L.grp_b[slot >> 2] = (uint16_t)b;
         }
-    }
     lds_barrier();
-    if (tid < P) {
-        if (BOUNDED) { const uint64_t room = lim[tid] - L.cursor[tid]; L.cursor[tid] += (uint64_t)L.hist[tid] <= room ? L.hist[tid] : room; }
-        else L.cursor[tid] += L.hist[tid];
+    const unsigned long long t3 = now();
+    if (GROUPED) {
+        // copy-out, one staged group per lane and step: the steps are independent of each other
+        for (uint32_t gi = tid; gi < total; gi += PART_BLOCK) {
+            const uint32_t b = L.grp_b[gi];
+            const uint64_t dst = L.cursor[b] + (gi - L.goff[b]);
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(&L.st_lo[gi * 4]);
+            typename HiGroup<HB>::type hi;
+            if (HB) hi = *reinterpret_cast<const typename HiGroup<HB>::type*>(&L.st_hi[gi * 4]);
+            if (dst < L.lim[b]) l2_store_group<HB>(out, dst, lo, hi);
+            else {                                                             // beyond the run's capacity: the overflow list
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t rem = ((uint64_t)hi_of_group<HB>(hi, q) << 32) | (q == 0 ? lo.x : q == 1 ? lo.y : q == 2 ? lo.z : lo.w);
+                    if (rem == L2Fmt<HB>::NONE) continue;
+                    const unsigned long long at = atomicAdd(ovf_n, 1ULL);
+                    if (at < ovf_cap) ovf_buf[at] = place_key(base1, (g.pl.rb < 64 ? (uint64_t)b << g.pl.rb : 0ULL) | rem, g.pl);
+                }
+            }
+        }
+        lds_barrier();
+        if (STAMP && st) { const unsigned long long t4 = now(); st[1] += t1 - t0; st[2] += t2 - t1; st[3] += t3 - t2; st[4] += t4 - t3; }
+        if (tid < P) { const uint64_t room = L.lim[tid] - L.cursor[tid], want = (mine + 3) >> 2; L.cursor[tid] += want <= room ? want : room; }
+    } else {
+        // copy-out, one k-mer per lane and step; its sub-bucket: the last one whose staged run starts at or before it
+        for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
+            uint32_t lo_b = 0, hi_b = P - 1;
+            while (lo_b < hi_b) { const uint32_t mid = (lo_b + hi_b + 1) >> 1; if (L.goff[mid] <= idx) lo_b = mid; else hi_b = mid - 1; }
+            // (an empty sub-bucket shares its successor's start, so the last one found is never empty)
+            const uint64_t rem = ((uint64_t)(HB ? (uint32_t)L.st_hi[idx] : 0u) << 32) | L.st_lo[idx];
+            l2_put<HB>(out, L.cursor[lo_b] + (idx - L.goff[lo_b]), rem);
+        }
+        lds_barrier();
+        if (tid < P) L.cursor[tid] += mine;
     }
-    // (the next tile's first barrier orders this update before the next use)
+    // (the next tile's first barrier orders the cursor update before the next use)
 }
 
-// the 16 k-mers of a lane for one tile of bucket [beg, end) of the level-1 buffer; bit j of `valid` = item j is a k-mer (not past
-// the end, not segment padding)
-__device__ __forceinline__ uint32_t p2_tile_load(const uint64_t* __restrict__ l1_buf, uint64_t tbeg, uint64_t end, bool padded, uint64_t (&key)[PART_ITEMS]) {
-    uint32_t valid = 0;
-#pragma unroll
-    for (int j = 0; j < PART_ITEMS; ++j) {
-        const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + threadIdx.x;
-        key[j] = 0;
-        if (i < end) { key[j] = l1_buf[i]; valid |= 1u << j; }
-    }
-    if (padded) {                                        // segment padding (looked at only after all 16 loads are in flight)
-#pragma unroll
-        for (int j = 0; j < PART_ITEMS; ++j) if (key[j] == EMPTY) valid &= ~(1u << j);
-    }
-    return valid;
-}
+// first item of bucket b1's runs in the exact edition: every run may end on up to three padding items
+__device__ __host__ __forceinline__ uint64_t p2_exact_base(uint64_t beg, uint32_t b1, uint32_t P2) { return (beg + 4 * ((uint64_t)P2 + 1) * b1 + 3) & ~3ULL; }
 
-// The exact edition: one workgroup per level-1 bucket: histogram by digit, scan, scatter.  off2[r] = start of region r's run.
+// The exact edition: one workgroup per level-1 bucket: histogram by digit, scan, scatter.  off2[r] = start of region r's run (a
+// multiple of 4: runs begin on group boundaries; the up to three items between a run's last k-mer and the next run are "no item").
 template <int HB>
 __global__ void __launch_bounds__(PART_BLOCK)
-k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint32_t* __restrict__ l2_lo, void* __restrict__ l2_hi,
-     uint64_t* __restrict__ off2, uint64_t seg_slots, uint64_t* __restrict__ bend /* end of bucket b1's last run (segmented layout) */) {
+k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
+     uint64_t* __restrict__ off2, uint64_t seg_slots, uint64_t* __restrict__ bend /* end of bucket b1's last run: the next bucket's runs start later */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
+    P2Lds<HB>& L = *reinterpret_cast<P2Lds<HB>*>(lds_raw);
+    constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
     for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
         uint64_t beg, end;
         l1_bucket_range(l1_off, seg_slots, b1, beg, end);
         const uint64_t base1 = place_base1(b1, g.pl.n, g.pl.p1);
+        const uint64_t obeg = p2_exact_base(beg, b1, g.P2);
         lds_barrier();
         // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
         // the cursor array is free until the scan, so it doubles as the histogram
@@ -510,25 +552,27 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
         for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)8 * PART_BLOCK) {                   // 8 coalesced loads in flight per lane
             uint64_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const uint64_t i = i0 + (uint64_t)u * PART_BLOCK + tid; v[u] = i < end ? l1_buf[i] : EMPTY; }
+            for (int u = 0; u < 8; ++u) { const uint64_t i = i0 + (uint64_t)u * PART_BLOCK + tid; const uint64_t x = l1_buf[i < end ? i : end - 1]; v[u] = i < end ? x : EMPTY; }   // (clamped, unconditional: see p2_tile_load)
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (v[u] != EMPTY) atomicAdd(&h64[place_digit2(place_stage2(place_stage1(v[u], g.pl) - base1, g.pl), g.pl)], 1ULL);
         }
         lds_barrier();
         const uint64_t mine = tid < g.P2 ? h64[tid] : 0;
-        const uint64_t excl = block_exclusive_scan64(mine, reinterpret_cast<uint64_t*>(L.staging));
+        const uint64_t excl = block_exclusive_scan64((mine + 3) & ~3ULL, reinterpret_cast<uint64_t*>(L.st_lo));
         if (tid < g.P2) {
-            L.cursor[tid] = beg + excl;
-            off2[(uint64_t)b1 * g.P2 + tid] = beg + excl;
+            const uint64_t start = obeg + excl;
+            L.cursor[tid] = start;
+            off2[(uint64_t)b1 * g.P2 + tid] = start;
+            for (uint64_t q = mine; q & 3; ++q) l2_put<HB>(l2_buf, start + q, L2Fmt<HB>::NONE);
         }
-        if (b1 == g.P1 - 1 && tid == 0) off2[(uint64_t)g.P1 * g.P2] = end;
-        if (bend && tid == g.P2 - 1) bend[b1] = beg + excl + mine;                             // the runs of a bucket stop short of the next bucket (padding)
-        for (uint64_t tbeg = beg; tbeg < end; tbeg += TILE_ITEMS) {                            // pass B
-            uint64_t key[PART_ITEMS];
-            const uint32_t valid = p2_tile_load(l1_buf, tbeg, end, seg_slots != 0, key);
+        if (b1 == g.P1 - 1 && tid == g.P2 - 1) off2[(uint64_t)g.P1 * g.P2] = obeg + excl + ((mine + 3) & ~3ULL);
+        if (bend && tid == g.P2 - 1) bend[b1] = obeg + excl + ((mine + 3) & ~3ULL);             // the runs of a bucket stop short of the next bucket's
+        for (uint64_t tbeg = beg; tbeg < end; tbeg += L2Fmt<HB>::TILE) {                       // pass B
+            uint64_t key[N];
+            const uint32_t valid = p2_tile_load<N>(l1_buf, tbeg, end, seg_slots != 0, key);
             lds_barrier();
-            scatter_tile2<HB, false>(L, g, base1, key, valid, l2_lo, l2_hi, nullptr, nullptr, nullptr, 0);
+            scatter_tile2<HB, false>(L, g, base1, key, valid, l2_buf, nullptr, nullptr, 0);
         }
     }
 }
@@ -536,43 +580,53 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
 // ---- level 2 without the histogram pass ----
 // The exact k_p2 reads every bucket twice: once to size the P2 sub-runs, once to scatter.  With a uniform hash the sizes
 // are known in advance up to noise (n_b / P2 k-mers per region, sigma = sqrt of that), so the fast edition gives every
-// region the same capacity -- mean + 1/16 + 16 -- scatters in ONE pass and reports what it really wrote (cnt2).  K-mers
+// region the same capacity -- mean + 1/16 + what the group padding can add (two items per tile on average 1.5) + 16 --
+// scatters in ONE pass and reports what it really wrote (cnt2, padding included).  K-mers
 // beyond a region's capacity (heavy hitters, or a very unlucky region) go to a small overflow list that the host
 // inserts through the direct path; if even that list overflows, the host redoes the round with the exact kernel
 // (the level-1 buffer is only read here) and stays exact for the rest of the call.
-__device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t b1, uint32_t P2) { return beg + (beg >> 4) + (uint64_t)b1 * P2 * 16; }
-__device__ __host__ __forceinline__ uint64_t p2_region_cap(uint64_t n_b, uint32_t P2) { return (n_b + (n_b >> 4)) / P2 + 16; }
+// Both in ITEMS, both multiples of 4.  p2_out_base(beg + n) - p2_out_base(beg) >= P2 * p2_region_cap(n): buckets do not overlap.
+__device__ __host__ __forceinline__ uint64_t p2_region_cap(uint64_t n_b, uint32_t P2, uint32_t tile) { return ((n_b + (n_b >> 4)) / P2 + 2 * (n_b / tile + 1) + 16 + 3) & ~3ULL; }
+__device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t b1, uint32_t P2, uint32_t tile) {
+    return (beg + (beg >> 4) + 2 * (uint64_t)P2 * (beg / tile) + (uint64_t)b1 * P2 * 32 + 3) & ~3ULL;
+}
 
-template <int HB>
+template <int HB, bool STAMP = false>
 __global__ void __launch_bounds__(PART_BLOCK)
-k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint32_t* __restrict__ l2_lo, void* __restrict__ l2_hi,
+k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
           uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
-          uint64_t ovf_cap, uint64_t seg_slots) {
+          uint64_t ovf_cap, uint64_t seg_slots, unsigned long long* __restrict__ stamps = nullptr) {
+    // STAMP (diagnostic, KATGPU_P2_STAMP): cycles of wave 0: [0] tile loads, [1] hash + rank, [2] scan, [3] staging, [4] copy-out, [5] tiles
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    PartLds& L = *reinterpret_cast<PartLds*>(lds_raw);
-    uint64_t* lim = reinterpret_cast<uint64_t*>(L.code);                   // code / bad are level-1 only: 8 KB for the run limits
+    P2Lds<HB>& L = *reinterpret_cast<P2Lds<HB>*>(lds_raw);
+    constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
     for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
         uint64_t beg, end;
         l1_bucket_range(l1_off, seg_slots, b1, beg, end);
-        const uint64_t cap = p2_region_cap(end - beg, g.P2), obase = p2_out_base(beg, b1, g.P2);
+        const uint64_t cap = p2_region_cap(end - beg, g.P2, L2Fmt<HB>::TILE), obase = p2_out_base(beg, b1, g.P2, L2Fmt<HB>::TILE);
         const uint64_t base1 = place_base1(b1, g.pl.n, g.pl.p1);
         lds_barrier();
         if (tid < g.P2) {
-            const uint64_t start = obase + (uint64_t)tid * cap;
-            L.cursor[tid] = start;
-            lim[tid] = start + cap;
+            const uint64_t start = obase + (uint64_t)tid * cap;                // items; the cursor counts groups
+            L.cursor[tid] = start >> 2;
+            L.lim[tid] = (start + cap) >> 2;
             off2[(uint64_t)b1 * g.P2 + tid] = start;
         }
-        for (uint64_t tbeg = beg; tbeg < end; tbeg += TILE_ITEMS) {
-            uint64_t key[PART_ITEMS];
-            const uint32_t valid = p2_tile_load(l1_buf, tbeg, end, seg_slots != 0, key);
+        for (uint64_t tbeg = beg; tbeg < end; tbeg += L2Fmt<HB>::TILE) {
+            const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
+            uint64_t key[N];
+            const uint32_t valid = p2_tile_load<N>(l1_buf, tbeg, end, seg_slots != 0, key);
+            if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
             lds_barrier();
-            scatter_tile2<HB, true>(L, g, base1, key, valid, l2_lo, l2_hi, lim, ovf_buf, ovf_n, ovf_cap);
+            if (STAMP) { st[0] += (unsigned long long)clock64() - ta; st[5] += 1; }
+            scatter_tile2<HB, true, STAMP>(L, g, base1, key, valid, l2_buf, ovf_buf, ovf_n, ovf_cap, st);
         }
         lds_barrier();
-        if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = (uint32_t)(L.cursor[tid] - (obase + (uint64_t)tid * cap));
+        if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = (uint32_t)((L.cursor[tid] << 2) - (obase + (uint64_t)tid * cap));
     }
+    if (STAMP && tid == 0 && stamps) for (int i = 0; i < 6; ++i) atomicAdd(&stamps[i], st[i]);
 }
 
 // ---- level 3: apply a region's run to the region, in LDS ----
@@ -582,7 +636,7 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
 // from HBM into registers, and r's write-back drains behind it -- the CU's memory pipe stays busy through the LDS phase.
 template <int BLOCK, int SPT, int BATCH = 4, bool TEST_SPILL = false /* honours spill_mod: instantiated for the test suite only */>
 __global__ void __launch_bounds__(BLOCK)
-k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint32_t* __restrict__ l2_lo, const void* __restrict__ l2_hi,
+k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
            uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod,
            const uint32_t* __restrict__ cnt2 /* run lengths when k_p2_fast laid the runs out; null: off2[r + 1] ends run r */,
            const uint64_t* __restrict__ bend /* exact level 2 over a chunked level 1: where the last run of each bucket ends */) {
@@ -615,7 +669,11 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
         const uint64_t base = (uint64_t)r * S;
         // an item is the remainder of its k-mer's placement hash; the region supplies the digits (kg_device.hpp "placement")
         const uint64_t base1 = place_base1(r >> g.l2, g.pl.n, g.pl.p1), d2_hi = g.pl.rb < 64 ? (uint64_t)(r & (g.P2 - 1)) << g.pl.rb : 0ULL;
-        auto item = [&](uint64_t i) -> unsigned long long { return place_key(base1, d2_hi | l2_load_any(g.hb, l2_lo, l2_hi, i), g.pl); };
+        auto item = [&](uint64_t i) -> unsigned long long {            // EMPTY: padding
+            bool none;
+            const uint64_t rem = l2_get_any(g.hb, l2_buf, i, none);
+            return none ? EMPTY : place_key(base1, d2_hi | rem, g.pl);
+        };
 #pragma unroll
         for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
         lds_barrier();
@@ -634,9 +692,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
 #pragma unroll
           for (int u = 0; u < BATCH; ++u) { const uint64_t i = i1 + (uint64_t)u * BLOCK + tid; nxt[u] = i < end ? item(i) : EMPTY; }
           if (!prefetched) { if (rn < g.R) prefetch(rn); prefetched = true; }     // issued AFTER the first batches: their wait does not cover these
-          uint32_t nv = 0;                                                          // this lane's k-mers in the batch (EMPTY only pads the tail)
-#pragma unroll
-          for (int u = 0; u < BATCH; ++u) nv += cur[u] != EMPTY;
+          const uint32_t nv = BATCH;                                                // (EMPTY entries -- padding, the tail -- are stepped over)
           uint32_t u = 0, slot = 0, probes = 0;
           unsigned long long key = EMPTY;
           auto start = [&]() {                                                      // load k-mer u into the walk state
@@ -644,6 +700,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
                   key = cur[0];
 #pragma unroll
                   for (int q = 1; q < BATCH; ++q) key = u == (uint32_t)q ? cur[q] : key;
+                  if (key == EMPTY) { ++u; continue; }
                   slot = home_offset(key, t);
                   probes = 0;
                   if (!(TEST_SPILL && spill_mod && __umulhi((uint32_t)(mix64(key) >> 32), spill_mod) == 0)) break;   // test hook: 1 k-mer in spill_mod takes the spill path
@@ -694,14 +751,14 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
 // No-return adds cannot report a 32-bit wrap, so none may happen: before a walk, counters >= 2^31 give 2^31 to the side table,
 // and a walk covers fewer than 2^31 k-mers (a longer run -- one region, one round, exact level 2 only -- is walked in segments).
 // Region fill and write-back move 16 bytes per lane and instruction (8- and 4-byte stores were store-issue-bound).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a native vector: stays in registers where HIP's uint4 struct went to scratch
 constexpr int AP2_QCAP = 256;                                 // straggler queue entries per wave (12 bytes each)
 constexpr int AP2_LANE_PROBES = 12;                           // probes a queue entry gets from its own lane before the wave takes it over
 constexpr uint64_t AP2_SEGMENT = 0x7FF00000ULL;               // k-mers per walk: < 2^31
 
-template <int BLOCK, int KP /* 16-byte key loads per lane that cover a region */, int U, int NR, int HB /* high bytes of an item */, bool STAMP = false, bool INLINE_CLAIM = false, bool DYN = true>
+template <int BLOCK, int KP /* 16-byte key loads per lane that cover a region */, int U, int NR, int HB /* high bytes of an item */, bool STAMP = false, bool INLINE_CLAIM = false, bool DYN = true,
+          int QCAP = AP2_QCAP /* queue entries per wave: what the region leaves of the LDS */>
 __global__ void __launch_bounds__(BLOCK)
-k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint32_t* __restrict__ l2_lo, const void* __restrict__ l2_hi,
+k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
             uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n,
             const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend, unsigned long long* __restrict__ stamps = nullptr) {
     // STAMP: cycle stamps of wave 0 (tools/ab_apply.sh): [0] fill + sweep, [1] chunk loads + hash, [2] probe rounds, [3] queue push + drains,
@@ -711,12 +768,13 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int NW = BLOCK / 64, CP = (KP + 1) / 2;
     constexpr uint32_t CH = 64 * U;
+    static_assert(U == 4, "a lane takes one group of the level-2 buffer: four items");
     const uint32_t S = g.S;                                   // S % 4 == 0 (host-checked): every region is 16-byte aligned in both arrays
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
     uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)S * 8);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long* wqk = reinterpret_cast<unsigned long long*>(lds_raw + (size_t)S * 12) + (size_t)wave * AP2_QCAP;
-    uint32_t* wqs = reinterpret_cast<uint32_t*>(lds_raw + (size_t)S * 12 + (size_t)NW * AP2_QCAP * 8) + (size_t)wave * AP2_QCAP;
+    unsigned long long* wqk = reinterpret_cast<unsigned long long*>(lds_raw + (size_t)S * 12) + (size_t)wave * QCAP;
+    uint32_t* wqs = reinterpret_cast<uint32_t*>(lds_raw + (size_t)S * 12 + (size_t)NW * QCAP * 8) + (size_t)wave * QCAP;
     uint32_t new_distinct = 0;
     u32x4 kq[KP], cq[CP];
     __shared__ unsigned long long s_next_chunk;               // chunks of the run are handed out to the waves as they come free
@@ -847,11 +905,15 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                 }
             };
 
-            const uint64_t n_chunks = (n_run + CH - 1) / CH;
-            unsigned long long cur[U], nxt[U];                    // remainders (then k-mers) of this chunk, remainders of the next
-            uint32_t cur_n = 0, nxt_n = 0;                        // bit u: item u exists
-#pragma unroll
-            for (int u = 0; u < U; ++u) { const uint64_t i = (uint64_t)wave * CH + (uint64_t)u * 64 + lane; cur[u] = l2_load<HB>(l2_lo, l2_hi, sbeg + (i < n_run ? i : 0)); cur_n |= i < n_run ? 1u << u : 0u; }
+            const uint64_t n_chunks = (n_run + CH - 1) / CH;         // chunk c = groups [64 c, 64 c + 64) of the run
+            // a lane's share of a chunk is one GROUP of the buffer (four items: 16 bytes of low words + 4 HB of high parts);
+            // the next chunk's group is in flight while this one is worked on
+            const uint64_t n_grp = (n_run + 3) >> 2, g0 = sbeg >> 2;      // (runs start on group boundaries and end on "no item" padding)
+            unsigned long long cur[U];
+            u32x4 c_lo, n_lo;
+            typename HiGroup<HB>::type c_hi{}, n_hi{};
+            bool c_in, n_in;                                      // the lane's group lies inside the run
+            { const uint64_t gi = (uint64_t)wave * 64 + lane; c_in = gi < n_grp; l2_load_group<HB>(l2_buf, g0 + (c_in ? gi : 0), c_lo, c_hi); }
             // (static round-robin left the workgroup waiting ~12 K cycles per region for its slowest wave: the drains vary)
             auto grab = [&]() -> uint64_t {
                 unsigned long long v = 0;
@@ -861,19 +923,19 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
             for (uint64_t c = wave; c < n_chunks;) {
                 const unsigned long long t_a = now();
                 const uint64_t c_next = DYN ? grab() : c + NW;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {                 // next chunk: in flight behind this one (unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch)
-                    const uint64_t i = c_next * CH + (uint64_t)u * 64 + lane;
-                    nxt[u] = l2_load<HB>(l2_lo, l2_hi, sbeg + (i < n_run ? i : 0));
-                    nxt_n |= i < n_run ? 1u << u : 0u;
+                {                                             // next chunk: in flight behind this one (unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch)
+                    const uint64_t gi = c_next * 64 + lane;
+                    n_in = gi < n_grp;
+                    l2_load_group<HB>(l2_buf, g0 + (n_in ? gi : 0), n_lo, n_hi);
                 }
                 uint32_t slot[U];
                 bool pend[U];                                     // k-mer u still to be placed (lane masks in SGPRs)
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    pend[u] = (cur_n >> u) & 1;
-                    slot[u] = place_offset(cur[u], g.pl, S);
-                    cur[u] = place_key(base1, d2_hi | cur[u], g.pl);
+                    const uint64_t rem = ((uint64_t)hi_of_group<HB>(c_hi, u) << 32) | (u == 0 ? c_lo.x : u == 1 ? c_lo.y : u == 2 ? c_lo.z : c_lo.w);
+                    pend[u] = c_in && rem != L2Fmt<HB>::NONE;
+                    slot[u] = place_offset(rem, g.pl, S);
+                    cur[u] = place_key(base1, d2_hi | rem, g.pl);
                 }
                 const unsigned long long t_b = now();
                 // Probe rounds: U reads in flight, one wait; a match adds 1 and is done, a foreign key moves on, an EMPTY slot is
@@ -926,7 +988,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(tot, d, 64); if (lane >= (uint32_t)d) tot += o; }
                 const uint32_t total = __shfl(tot, 63, 64);
-                if (total <= AP2_QCAP - 64) {
+                if (total <= QCAP - 64) {
                     uint32_t at = q_n + tot - mine;
 #pragma unroll
                     for (int u = 0; u < U; ++u)
@@ -941,7 +1003,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                         const bool p = pm & 1;
                         const unsigned long long m = __ballot(p);
                         if (m) {
-                            while (q_n > AP2_QCAP - 64) drain_pass(false);
+                            while (q_n > QCAP - 64) drain_pass(false);
                             const uint32_t at = q_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
                             if (p) { wqk[at] = cur[0]; wqs[at] = slot[0] | ((S - NR) << 16); }
                             q_n += (uint32_t)__popcll(m);
@@ -953,9 +1015,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                 }
                 const bool last = c_next >= n_chunks;                     // the wave's last chunk empties the queue
                 while (q_n > (last ? 0u : 64u)) drain_pass(last);
-#pragma unroll
-                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-                cur_n = nxt_n; nxt_n = 0;
+                c_lo = n_lo; c_hi = n_hi; c_in = n_in;
                 c = c_next;
                 if (STAMP) { const unsigned long long t_d = now(); st[1] += t_b - t_a; st[2] += t_c - t_b; st[3] += t_d - t_c; }
             }
