@@ -611,6 +611,7 @@ static const bool g_p2_stamp = hook("KATGPU_P2_STAMP") != nullptr;       // diag
 static const uint32_t g_test_hb = hook("KATGPU_TEST_HB") ? (uint32_t)strtoul(hook("KATGPU_TEST_HB"), nullptr, 10) : 0;   // A/B: wider level-2 items than needed (1, 2, 4)
 static bool part_geometry(const DevTable& d, PartGeom* g) {
     g->R = d.n_regions; g->S = d.region_slots; g->P1 = d.p1; g->P2 = d.p2; g->l2 = d.l2;
+    g->b_lo = 0; g->b_hi = d.p1;
     g->pl = place_make(d.k, d.p1, d.n1, d.l2);
     g->hb = std::max(l2_hi_bytes(g->pl.rb), g_test_hb);
     return d.k <= 32 && g->pl.rb <= 63 /* all-ones is "no item" */ && g->P1 <= MAX_PARTS && g->P2 <= MAX_PARTS && (size_t)g->S * 12 <= 150 * 1024;
@@ -618,7 +619,10 @@ static bool part_geometry(const DevTable& d, PartGeom* g) {
 // bytes of partition arena per k-mer of a round: level-1 buffer (8 B + the segment slack 1/24), level-2 buffer (4 + hb B, that
 // slack again + the run slack 1/16 + the group padding's allowance 2 * 1024 / tile), overflow list (8 B / 32)
 static double l2_items_per_l1_item(uint32_t hb) { return 1 + 1.0 / 16 + 2.0 * MAX_PARTS / l2_tile_items(hb); }
-static double arena_bytes_per_item(uint32_t hb) { return 8.0 * (1 + 1.0 / 24) + (4.0 + hb) * (1 + 1.0 / 24) * l2_items_per_l1_item(hb) + 0.25 + 0.02; }
+// buckets per pass of level 2 + apply: a CU-full when the buckets are a whole number of those (alloc_dev_table sees to it), else all
+static uint32_t pass_buckets(uint32_t p1, uint32_t n_cu) { return n_cu && p1 > n_cu && p1 % n_cu == 0 ? n_cu : p1; }
+// ... of which the level-2 buffer holds one pass = 1 / passes of a round
+static double arena_bytes_per_item(uint32_t hb, uint32_t passes) { return 8.0 * (1 + 1.0 / 24) + (4.0 + hb) * (1 + 1.0 / 24) * l2_items_per_l1_item(hb) / passes + 0.25 + 0.02; }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -633,7 +637,10 @@ static void release_arena(katgpu_ctx* c) {
 // table, the new one and the arena at once, `stash` (spilled keys that live in the arena, may be null) is parked in host
 // memory, the arena is given up, the growth retried and the keys re-inserted from the host.  *arena_lost tells the
 // caller that its carve of the arena is gone.
-static int grow_beside_arena(katgpu_table* t, uint64_t incoming, uint64_t min_cap, const uint64_t* stash, uint64_t n_stash, bool* arena_lost) {
+typedef std::vector<std::pair<const uint64_t*, uint64_t>> KeyLists;
+static int grow_beside_arena(katgpu_table* t, uint64_t incoming, uint64_t min_cap, const KeyLists& stash, bool* arena_lost) {
+    uint64_t n_stash = 0;
+    for (auto& l : stash) n_stash += l.second;
     katgpu_ctx* c = t->ctx;
     auto grow = [&]() -> int {
         if (min_cap > t->d.cap) {
@@ -650,7 +657,8 @@ static int grow_beside_arena(katgpu_table* t, uint64_t incoming, uint64_t min_ca
     std::vector<uint64_t> host;
     if (n_stash) {
         try { host.resize(n_stash); } catch (...) { return fail(c, KATGPU_ERR_NOMEM, "no host memory to park %llu spilled k-mers", (unsigned long long)n_stash); }
-        HIPCHK(c, hipMemcpy(host.data(), stash, n_stash * 8, hipMemcpyDeviceToHost));
+        uint64_t at = 0;
+        for (auto& l : stash) { HIPCHK(c, hipMemcpy(host.data() + at, l.first, l.second * 8, hipMemcpyDeviceToHost)); at += l.second; }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     release_arena(c);
@@ -712,14 +720,16 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     // L1 buffer: a round's k-mers + 1/24 + 64 per workgroup and bucket (segment slack of k_p1v2_scatter<true>);
     // L2 buffer: items of 4 + hb bytes in groups of four (kg_partition.hpp "the level-2 buffer"): the L1 count + 1/16 + 16 per region
     // (capacity slack of k_p2_fast) + two items per tile and region (group padding); overflow list: 1/32.
-    // 14.8 bytes per k-mer of a round at hb = 1 (k = 27 at the bench size), 18.5 at hb = 4.
+    // 14.8 bytes per k-mer of a round at hb = 1 (k = 27 at the bench size), 18.5 at hb = 4 -- with one pass; the level-2 buffer
+    // holds one PASS of level 2 + apply (a CU-full of buckets, see the rounds below): 11.7 bytes with two passes.
     PartGeom g0;
     if (!part_geometry(t->d, &g0)) return KATGPU_OK;                              // direct path
     const uint32_t hb0 = g0.hb;                                                  // a table that grows has more regions: never more remainder bits
-    const double per_item = arena_bytes_per_item(hb0);
+    const uint32_t passes0 = g0.P1 / pass_buckets(g0.P1, (uint32_t)c->n_cu);
+    const double per_item = arena_bytes_per_item(hb0, passes0);
     constexpr size_t SEG_PAD = 64;
     const size_t fixed_l1 = (size_t)W * MAX_PARTS * SEG_PAD;
-    const size_t fixed_l2 = (size_t)((double)fixed_l1 * l2_items_per_l1_item(hb0)) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 8192;
+    const size_t fixed_l2 = (size_t)((double)fixed_l1 * l2_items_per_l1_item(hb0) / passes0) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 8192;
     const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +   /* W <= 4 * CUs */
                                align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) +
                                align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256) + align_up((size_t)MAX_PARTS * 8, 256) + align_up((size_t)MAX_PARTS * 4, 256) + 256 +
@@ -753,7 +763,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     unsigned long long* ovf_n = spill_n + 1;      a += 256;
     const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / per_item));
     const size_t l1_items = round_items + round_items / 24 + fixed_l1;
-    const size_t l2_items = ((size_t)((double)l1_items * l2_items_per_l1_item(hb0)) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 4096 + 3) & ~(size_t)3;
+    const size_t l2_items = ((size_t)((double)l1_items * l2_items_per_l1_item(hb0) / passes0) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 4096 + 3) & ~(size_t)3;
     uint64_t* l1_buf = (uint64_t*)a;
     uint8_t* l2_buf = (uint8_t*)(l1_buf + l1_items);                               // level-2 items, groups of 4
     uint64_t* ovf_buf = (uint64_t*)(l2_buf + align_up(l2_items / 4 * l2_group_bytes(hb0), 16));
@@ -771,7 +781,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         if (rc) return rc;
         if ((double)t->distinct > 0.6 * (double)t->d.cap) {
             bool lost = false;
-            rc = grow_beside_arena(t, 0, t->d.cap * 2, nullptr, 0, &lost);
+            rc = grow_beside_arena(t, 0, t->d.cap * 2, KeyLists(), &lost);
             if (rc) return rc;
             if (lost) break;                                                      // the caller re-enters with a fresh arena
         }
@@ -846,116 +856,155 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             }
         }
         if (items) {
-            // level 2: one pass when the runs are predictable (k_p2_fast), else -- or when its overflow list did not hold --
-            // the exact two-pass kernel
-            const uint32_t* run_len = nullptr;
-            unsigned long long overflowed = 0;
-            const bool try_fast = p2_fast_ok && (g_p2_fast == 2 || items / g.R >= 1024);
-            if (try_fast && g_p2_stamp && g.hb == 1) {         // diagnostic: cycle stamps of wave 0 of every workgroup
-                unsigned long long* d_st = nullptr;
-                HIPCHK(c, hipMalloc((void**)&d_st, 64));
-                HIPCHK(c, hipMemsetAsync(d_st, 0, 64, c->stream));
-                KG_LDS_ATTR((k_p2_fast<1, true>), sizeof(P2Lds<1>));
-                hipLaunchKernelGGL((k_p2_fast<1, true>), dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(P2Lds<1>), c->stream, g, l1_off, l1_buf, l2_buf,
-                                   off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, d_st);
-                unsigned long long h[8];
-                HIPCHK(c, hipMemcpyAsync(h, d_st, 48, hipMemcpyDeviceToHost, c->stream));
+            // Level 2 + apply, in passes over sets of buckets: the level-2 buffer holds one pass (arena sizing above), a pass is a whole
+            // number of CU-fulls of buckets where the geometry allows (alloc_dev_table).  Where bucket b starts in the level-1 buffer:
+            std::vector<uint64_t> h_l1_off;
+            if (!seg) {
+                h_l1_off.resize(g.P1 + 1);
+                HIPCHK(c, hipMemcpyAsync(h_l1_off.data(), l1_off, (g.P1 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
-                hipFree(d_st);
-                const double n = (double)std::max<unsigned long long>(1, h[5]);
-                fprintf(stderr, "[katgpu] k_p2_fast stamps per tile (cycles, wave 0): loads %.0f, hash+rank %.0f, scan %.0f, staging %.0f, copy-out %.0f; %llu tiles\n",
-                        h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5]);
-            } else
-            if (try_fast) {
-                ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-#define KG_P2F(HB) case HB: hipLaunchKernelGGL(k_p2_fast<HB>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
-                                               off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots); break;
-                switch (g.hb) { KG_FOR_HB(KG_P2F) }
+            }
+            auto lbeg = [&](uint32_t b) -> uint64_t { return seg ? (uint64_t)b * seg_slots : h_l1_off[b]; };
+            const uint32_t tile2 = l2_tile_items(g.hb);
+            auto pass_extent = [&](uint32_t b_lo, uint32_t b_hi) -> uint64_t {       // bound of what level 2 writes for these buckets, in items (either edition)
+                const uint64_t nn = lbeg(b_hi) - lbeg(b_lo);
+                return nn + nn / 16 + 2ULL * g.P2 * (nn / tile2 + 1) + (uint64_t)(b_hi - b_lo) * g.P2 * 32 + 64;
+            };
+            if (seg) HIPCHK(c, hipStreamSynchronize(c->stream));                   // ovf_l1 has arrived
+            uint32_t step = pass_buckets(g.P1, (uint32_t)c->n_cu);
+            auto fits = [&](uint32_t st) { for (uint32_t b = 0; b < g.P1; b += st) if (pass_extent(b, std::min(g.P1, b + st)) > l2_items) return false; return true; };
+            while (step > 1 && !fits(step)) step = (step + 1) / 2;
+            if (!fits(step)) {                                                      // (a single bucket beyond the buffer: direct path)
+                if (seg) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));   // the scatter tallied the all-ones key
+                break;
+            }
+            // level 2: one pass over the bucket when the runs are predictable (k_p2_fast), else -- or when its overflow list did not
+            // hold -- the exact two-pass kernel
+            const bool try_fast0 = p2_fast_ok && (g_p2_fast == 2 || items / g.R >= 1024);
+            std::vector<std::pair<const uint64_t*, uint64_t>> lists;              // spilled k-mers: in the parts of the level-1 buffer that are dead
+            unsigned long long ovf_total = ovf_l1;                                 // entries of the overflow list so far (level 1's, then every pass's)
+            bool redo_round = false;
+            if (g_trace && g.P1 > step) fprintf(stderr, "[katgpu]   level 2 + apply in %u passes of %u buckets (level-2 buffer: %zu items)\n", (g.P1 + step - 1) / step, step, l2_items);
+            for (uint32_t b_lo = 0; b_lo < g.P1 && !redo_round; b_lo += step) {
+                g.b_lo = b_lo; g.b_hi = std::min(g.P1, b_lo + step);
+                const uint64_t pass_items = std::max<uint64_t>(1, (uint64_t)((double)items * (g.b_hi - g.b_lo) / g.P1));
+                uint64_t* spill_buf = l1_buf + lbeg(b_lo);                         // this pass's part of the level-1 buffer: dead once its level 2 is through
+                const uint32_t* run_len = nullptr;
+                unsigned long long overflowed = ovf_total;
+                const bool try_fast = try_fast0 && p2_fast_ok;
+                const uint32_t grid_l2 = std::min<uint32_t>(g.b_hi - g.b_lo, W2);
+                HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
+                if (try_fast && g_p2_stamp && g.hb == 1) {         // diagnostic: cycle stamps of wave 0 of every workgroup
+                    unsigned long long* d_st = nullptr;
+                    HIPCHK(c, hipMalloc((void**)&d_st, 64));
+                    HIPCHK(c, hipMemsetAsync(d_st, 0, 64, c->stream));
+                    KG_LDS_ATTR((k_p2_fast<1, true>), sizeof(P2Lds<1>));
+                    hipLaunchKernelGGL((k_p2_fast<1, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<1>), c->stream, g, l1_off, l1_buf, l2_buf,
+                                       off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, d_st);
+                    unsigned long long h[8];
+                    HIPCHK(c, hipMemcpyAsync(h, d_st, 48, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    hipFree(d_st);
+                    const double n = (double)std::max<unsigned long long>(1, h[5]);
+                    fprintf(stderr, "[katgpu] k_p2_fast stamps per tile (cycles, wave 0): loads %.0f, hash+rank %.0f, scan %.0f, staging %.0f, copy-out %.0f; %llu tiles\n",
+                            h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5]);
+                } else
+                if (try_fast) {
+                    ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
+#define KG_P2F(HB) case HB: hipLaunchKernelGGL(k_p2_fast<HB>, dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+                                               off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); break;
+                    switch (g.hb) { KG_FOR_HB(KG_P2F) }
 #undef KG_P2F
-            }
-            if (try_fast || seg) {
-                HIPCHK(c, hipMemcpyAsync(&overflowed, ovf_n, sizeof overflowed, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                if (seg && ovf_l1 > ovf_cap) {               // the level-1 buffer itself is incomplete: this round again, exactly
-                    if (g_trace) fprintf(stderr, "[katgpu] segmented level 1: %llu k-mers beyond their segments (list holds %llu): exact level 1 from here on\n", ovf_l1, (unsigned long long)ovf_cap);
-                    l1_fast_ok = false;
-                    HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));   // the scatter tallied the all-ones key
-                    continue;
                 }
-                if (try_fast && overflowed <= ovf_cap) run_len = cnt2;
-                else if (try_fast) {
-                    if (g_trace) fprintf(stderr, "[katgpu] k_p2_fast: %llu k-mers beyond their runs (list holds %llu): exact level 2 from here on\n", overflowed, (unsigned long long)ovf_cap);
-                    p2_fast_ok = false;
-                    overflowed = ovf_l1;                     // what level 1 put on the list is still there and still valid
-                    HIPCHK(c, hipMemcpyAsync(ovf_n, &ovf_l1, sizeof ovf_l1, hipMemcpyHostToDevice, c->stream));
+                if (try_fast || (seg && b_lo == 0)) {
+                    HIPCHK(c, hipMemcpyAsync(&overflowed, ovf_n, sizeof overflowed, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    if (seg && ovf_l1 > ovf_cap) {               // the level-1 buffer itself is incomplete: this round again, exactly
+                        if (g_trace) fprintf(stderr, "[katgpu] segmented level 1: %llu k-mers beyond their segments (list holds %llu): exact level 1 from here on\n", ovf_l1, (unsigned long long)ovf_cap);
+                        l1_fast_ok = false;
+                        HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));   // the scatter tallied the all-ones key
+                        redo_round = true;                       // (only ever in the first pass: nothing has been applied yet)
+                        break;
+                    }
+                    if (try_fast && overflowed <= ovf_cap) run_len = cnt2;
+                    else if (try_fast) {
+                        if (g_trace) fprintf(stderr, "[katgpu] k_p2_fast: %llu k-mers beyond their runs (list holds %llu): exact level 2 from here on\n", overflowed, (unsigned long long)ovf_cap);
+                        p2_fast_ok = false;
+                        overflowed = ovf_total;                  // what was on the list before this pass is still there and still valid
+                        HIPCHK(c, hipMemcpyAsync(ovf_n, &ovf_total, sizeof ovf_total, hipMemcpyHostToDevice, c->stream));
+                    }
                 }
-            }
-            if (!run_len) {
-                ScopedTimer tm(c, KATGPU_K_PART_L2, items);
-#define KG_P2(HB) case HB: hipLaunchKernelGGL(k_p2<HB>, dim3(std::min<uint32_t>(g.P1, W2)), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+                if (!run_len) {
+                    ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
+#define KG_P2(HB) case HB: hipLaunchKernelGGL(k_p2<HB>, dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
                                               off2, seg_slots, bend); break;
-                switch (g.hb) { KG_FOR_HB(KG_P2) }
+                    switch (g.hb) { KG_FOR_HB(KG_P2) }
 #undef KG_P2
-            }
-            const uint64_t* bucket_end = !run_len ? bend : nullptr;             // exact level 2: a bucket's runs stop short of the next bucket's
-            {
-                ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
-                // as many workgroups per CU as the regions' LDS footprint (and the 2048-thread limit) admits
-                const uint32_t blk = g_apply_block ? g_apply_block : (g.S <= 4096 ? 512 : 1024);
-                // second edition (batched walk, per-wave straggler queues behind the region in LDS) unless a test hook needs the first
-                const bool v2 = g_apply_v != 1 && !g_test_spill_mod && g.S % 4 == 0 && g.S >= 64 && g.S <= AP2_MAX_SLOTS && (blk == 512 ? g.S <= 4096 : true);
-                if (v2) {
-                    const bool big = g.S > 8192;
-                    const size_t lds2 = (size_t)g.S * 12 + (size_t)(blk / 64) * (big ? AP2_QCAP_BIG : AP2_QCAP) * 12;
-                    const uint32_t per_cu2 = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds2 + 512), 2048 / blk));
-                    const uint32_t grid2 = std::min<uint32_t>(g.R, W2 * per_cu2);
-                    // a table that is still empty sees nothing but new keys in this round: they are claimed inside the probe rounds
-                    // (INLINE_CLAIM) instead of all going through the queues; any later round loses by that (kg_partition.hpp)
-                    const bool fresh = t->distinct == 0 && !g_apply_noinline;
-#define KG_APPLY2(B, KP, HB) do { \
-                        if (fresh) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, true, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
-                                                      l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); \
-                        else hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
-                                                l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } while (0)
-#define KG_APPLY2_BIG(HB) do { \
-                        if (fresh) hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, true, true, AP2_QCAP_BIG>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
-                                                      l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); \
-                        else hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, false, true, AP2_QCAP_BIG>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
-                                                l1_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } while (0)
-#define KG_APPLY2_HB(HB) case HB: if (blk == 512) { if (g.S <= 2048) KG_APPLY2(512, 2, HB); else KG_APPLY2(512, 4, HB); } else if (big) KG_APPLY2_BIG(HB); else KG_APPLY2(1024, 4, HB); break;
-                    switch (g.hb) { KG_FOR_HB(KG_APPLY2_HB) }
-#undef KG_APPLY2_HB
-#undef KG_APPLY2_BIG
-#undef KG_APPLY2
-                } else {
-                const size_t lds = (size_t)g.S * 12;
-                // small regions (a table created "like" a bigger one): 512-thread workgroups, four per CU instead of two
-                const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
-                const uint32_t grid = std::min<uint32_t>(g.R, W2 * per_cu);
-#define KG_APPLY1(B, SPT, HOOKED) hipLaunchKernelGGL((k_p3_apply<B, SPT, 4, HOOKED>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, l1_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
-#define KG_APPLY(B, SPT) do { if (g_test_spill_mod) KG_APPLY1(B, SPT, true); else KG_APPLY1(B, SPT, false); } while (0)
-                const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
-                if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
-                else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) KG_APPLY(1024, 8); else KG_APPLY(1024, 12); }
-#undef KG_APPLY
-#undef KG_APPLY1
                 }
+                ovf_total = overflowed;
+                const uint64_t* bucket_end = !run_len ? bend : nullptr;             // exact level 2: a bucket's runs stop short of the next bucket's
+                {
+                    ScopedTimer tm(c, KATGPU_K_PART_APPLY, pass_items);
+                    // as many workgroups per CU as the regions' LDS footprint (and the 2048-thread limit) admits
+                    const uint32_t blk = g_apply_block ? g_apply_block : (g.S <= 4096 ? 512 : 1024);
+                    // second edition (batched walk, per-wave straggler queues behind the region in LDS) unless a test hook needs the first
+                    const bool v2 = g_apply_v != 1 && !g_test_spill_mod && g.S % 4 == 0 && g.S >= 64 && g.S <= AP2_MAX_SLOTS && (blk == 512 ? g.S <= 4096 : true);
+                    if (v2) {
+                        const bool big = g.S > 8192;
+                        const size_t lds2 = (size_t)g.S * 12 + (size_t)(blk / 64) * (big ? AP2_QCAP_BIG : AP2_QCAP) * 12;
+                        const uint32_t per_cu2 = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds2 + 512), 2048 / blk));
+                        const uint32_t grid2 = std::min<uint32_t>((g.b_hi - g.b_lo) * g.P2, W2 * per_cu2);
+                        // a table that is still empty sees nothing but new keys in this round: they are claimed inside the probe rounds
+                        // (INLINE_CLAIM) instead of all going through the queues; any later round loses by that (kg_partition.hpp)
+                        const bool fresh = t->distinct == 0 && !g_apply_noinline;
+    #define KG_APPLY2(B, KP, HB) do { \
+                            if (fresh) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, true, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
+                                                          spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); \
+                            else hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
+                                                    spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } while (0)
+    #define KG_APPLY2_BIG(HB) do { \
+                            if (fresh) hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, true, true, AP2_QCAP_BIG>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
+                                                          spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); \
+                            else hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, false, true, AP2_QCAP_BIG>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
+                                                    spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } while (0)
+    #define KG_APPLY2_HB(HB) case HB: if (blk == 512) { if (g.S <= 2048) KG_APPLY2(512, 2, HB); else KG_APPLY2(512, 4, HB); } else if (big) KG_APPLY2_BIG(HB); else KG_APPLY2(1024, 4, HB); break;
+                        switch (g.hb) { KG_FOR_HB(KG_APPLY2_HB) }
+    #undef KG_APPLY2_HB
+    #undef KG_APPLY2_BIG
+    #undef KG_APPLY2
+                    } else {
+                    const size_t lds = (size_t)g.S * 12;
+                    // small regions (a table created "like" a bigger one): 512-thread workgroups, four per CU instead of two
+                    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2048 / blk));
+                    const uint32_t grid = std::min<uint32_t>((g.b_hi - g.b_lo) * g.P2, W2 * per_cu);
+    #define KG_APPLY1(B, SPT, HOOKED) hipLaunchKernelGGL((k_p3_apply<B, SPT, 4, HOOKED>), dim3(grid), dim3(B), lds, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, spill_buf, spill_n, g_test_spill_mod, run_len, bucket_end)
+    #define KG_APPLY(B, SPT) do { if (g_test_spill_mod) KG_APPLY1(B, SPT, true); else KG_APPLY1(B, SPT, false); } while (0)
+                    const uint32_t spt = (g.S + blk - 1) / blk;                      // region slots each lane carries while prefetching
+                    if (blk == 512) { if (spt <= 8) KG_APPLY(512, 8); else if (spt <= 16) KG_APPLY(512, 16); else KG_APPLY(512, 24); }
+                    else { if (spt <= 4) KG_APPLY(1024, 4); else if (spt <= 8) KG_APPLY(1024, 8); else KG_APPLY(1024, 12); }
+    #undef KG_APPLY
+    #undef KG_APPLY1
+                    }
+                }
+                HIPCHK(c, hipGetLastError());
+                unsigned long long spilled = 0;
+                HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (spilled) lists.push_back({spill_buf, spilled});
             }
-            HIPCHK(c, hipGetLastError());
-            unsigned long long spilled = 0;
-            HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (overflowed) {                      // k_p2_fast's overflow list joins the spill list (both level buffers are dead by now)
-                HIPCHK(c, hipMemcpyAsync(l1_buf + spilled, ovf_buf, overflowed * 8, hipMemcpyDeviceToDevice, c->stream));
-                spilled += overflowed;
-            }
-            if (spilled) {                         // regions that ran out of slots: make room, then the direct path
+            if (redo_round) continue;
+            if (ovf_total) lists.push_back({ovf_buf, ovf_total});                  // what level 1 / level 2 could not place
+            if (!lists.empty()) {                      // regions that ran out of slots, runs beyond their capacity: make room, then the direct path
+                uint64_t total = 0;
+                for (auto& l : lists) total += l.second;
                 bool lost = false;
-                rc = grow_beside_arena(t, spilled, 0, l1_buf, spilled, &lost);
+                rc = grow_beside_arena(t, total, 0, lists, &lost);
                 if (rc) return rc;
-                if (lost) { pos += m; break; }     // the spill went in from the host; the caller re-enters for the rest
-                ScopedTimer tm(c, KATGPU_K_COUNT, spilled);
-                hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, spilled, 256, 6)), dim3(256), 0, c->stream, t->d, (const uint64_t*)l1_buf, (uint64_t)spilled);
+                if (lost) { pos += m; break; }         // the lists went in from the host; the caller re-enters for the rest
+                for (auto& l : lists) {
+                    ScopedTimer tm(c, KATGPU_K_COUNT, l.second);
+                    hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, l.second, 256, 6)), dim3(256), 0, c->stream, t->d, l.first, (uint64_t)l.second);
+                }
             }
         }
         pos += m;
@@ -1041,7 +1090,7 @@ static int count_superkmer(katgpu_table* t, const uint8_t* dev_bases, size_t n, 
         if (rc) return rc;
         if ((double)t->distinct > 0.6 * (double)t->d.cap) {
             bool lost = false;
-            rc = grow_beside_arena(t, 0, t->d.cap * 2, nullptr, 0, &lost);
+            rc = grow_beside_arena(t, 0, t->d.cap * 2, KeyLists(), &lost);
             if (rc) return rc;
             if (lost) break;
         }
@@ -1154,7 +1203,7 @@ static int count_superkmer(katgpu_table* t, const uint8_t* dev_bases, size_t n, 
             }
             if (spilled) {
                 bool lost = false;
-                rc = grow_beside_arena(t, spilled, 0, spill_buf, spilled, &lost);
+                rc = grow_beside_arena(t, spilled, 0, KeyLists{{spill_buf, spilled}}, &lost);
                 if (rc) return rc;
                 if (lost) { pos += m; break; }
                 ScopedTimer tm(c, KATGPU_K_COUNT, spilled);

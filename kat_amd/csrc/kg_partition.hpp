@@ -39,6 +39,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct PartGeom {
     uint32_t R, S;     // regions, slots per region (the table's)
     uint32_t P1, P2;   // region r = b1 * P2 + b2 (the table's p1, p2): level-1 bucket b1, level-2 bucket b2
+    uint32_t b_lo, b_hi; // this launch's share of a round: level-1 buckets [b_lo, b_hi) = regions [b_lo * P2, b_hi * P2) (a round goes
+                       // through level 2 + apply in as many passes as there are whole sets of n_CU buckets: the level-2 buffer holds one pass)
     uint32_t l2;       // P2 == 1 << l2
     uint32_t hb;       // bytes of a level-2 item beyond its low 32 bits: 0, 1, 2 or 4 (from pl.rb; "the level-2 buffer" below)
     Place pl;          // the placement hash's bit budget for this table (kg_device.hpp)
@@ -426,6 +428,8 @@ template <int N>
 __device__ __forceinline__ uint32_t p2_tile_load(const uint64_t* __restrict__ l1_buf, uint64_t tbeg, uint64_t end, bool padded, uint64_t (&key)[N]) {
     // unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch (the compiler pulled
     // the padding test into the branch of each load: sixteen serialised round trips to HBM, 29 K of a tile's 54 K cycles)
+    // (Issuing the next tile's loads behind the staging, so that they fly during the copy-out, moved the wait instead of removing it:
+    // the loads queue behind the stores.  Level 2 now moves its 14 bytes per k-mer at 3.5 TB/s.)
     uint32_t valid = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -538,11 +542,13 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
     P2Lds<HB>& L = *reinterpret_cast<P2Lds<HB>*>(lds_raw);
     constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
+    uint64_t beg0, end0;
+    l1_bucket_range(l1_off, seg_slots, g.b_lo, beg0, end0);
+    for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
         uint64_t beg, end;
         l1_bucket_range(l1_off, seg_slots, b1, beg, end);
         const uint64_t base1 = place_base1(b1, g.pl.n, g.pl.p1);
-        const uint64_t obeg = p2_exact_base(beg, b1, g.P2);
+        const uint64_t obeg = p2_exact_base(beg, b1, g.P2) - p2_exact_base(beg0, g.b_lo, g.P2);   // the level-2 buffer holds this pass only
         lds_barrier();
         // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
         // the cursor array is free until the scan, so it doubles as the histogram
@@ -566,7 +572,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
             off2[(uint64_t)b1 * g.P2 + tid] = start;
             for (uint64_t q = mine; q & 3; ++q) l2_put<HB>(l2_buf, start + q, L2Fmt<HB>::NONE);
         }
-        if (b1 == g.P1 - 1 && tid == g.P2 - 1) off2[(uint64_t)g.P1 * g.P2] = obeg + excl + ((mine + 3) & ~3ULL);
+        if (b1 == g.b_hi - 1 && tid == g.P2 - 1) off2[(uint64_t)g.b_hi * g.P2] = obeg + excl + ((mine + 3) & ~3ULL);
         if (bend && tid == g.P2 - 1) bend[b1] = obeg + excl + ((mine + 3) & ~3ULL);             // the runs of a bucket stop short of the next bucket's
         for (uint64_t tbeg = beg; tbeg < end; tbeg += L2Fmt<HB>::TILE) {                       // pass B
             uint64_t key[N];
@@ -602,10 +608,13 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
     P2Lds<HB>& L = *reinterpret_cast<P2Lds<HB>*>(lds_raw);
     constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t b1 = blockIdx.x; b1 < g.P1; b1 += gridDim.x) {
+    uint64_t beg0, end0;
+    l1_bucket_range(l1_off, seg_slots, g.b_lo, beg0, end0);
+    for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
         uint64_t beg, end;
         l1_bucket_range(l1_off, seg_slots, b1, beg, end);
-        const uint64_t cap = p2_region_cap(end - beg, g.P2, L2Fmt<HB>::TILE), obase = p2_out_base(beg, b1, g.P2, L2Fmt<HB>::TILE);
+        const uint64_t cap = p2_region_cap(end - beg, g.P2, L2Fmt<HB>::TILE);
+        const uint64_t obase = p2_out_base(beg, b1, g.P2, L2Fmt<HB>::TILE) - p2_out_base(beg0, g.b_lo, g.P2, L2Fmt<HB>::TILE);   // the level-2 buffer holds this pass only
         const uint64_t base1 = place_base1(b1, g.pl.n, g.pl.p1);
         lds_barrier();
         if (tid < g.P2) {
@@ -647,13 +656,14 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
     uint32_t new_distinct = 0;
     uint64_t kk[SPT]; uint32_t cc[SPT];
 
+    const uint32_t r_hi = g.b_hi * g.P2;                       // regions [b_lo * P2, r_hi): this launch's
     auto run_end = [&](uint32_t r) -> uint64_t {                  // exact layouts: run r ends where the next one starts
         if (bend && (r + 1) % g.P2 == 0) return bend[r / g.P2];
         return off2[r + 1];
     };
     auto next_region = [&](uint32_t from) {                       // first region >= from (stride gridDim) that received k-mers
         uint32_t r = from;
-        while (r < g.R && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
+        while (r < r_hi && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
         return r;
     };
     auto prefetch = [&](uint32_t r) {
@@ -662,9 +672,9 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
         for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; kk[u] = i < S ? t.keys[base + i] : 0; cc[u] = i < S ? t.counts[base + i] : 0; }
     };
 
-    uint32_t r = next_region(blockIdx.x);
-    if (r < g.R) prefetch(r);
-    while (r < g.R) {
+    uint32_t r = next_region(g.b_lo * g.P2 + blockIdx.x);
+    if (r < r_hi) prefetch(r);
+    while (r < r_hi) {
         const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : run_end(r);
         const uint64_t base = (uint64_t)r * S;
         // an item is the remainder of its k-mer's placement hash; the region supplies the digits (kg_device.hpp "placement")
@@ -691,7 +701,7 @@ k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint
           const uint64_t i1 = i0 + (uint64_t)BATCH * BLOCK;
 #pragma unroll
           for (int u = 0; u < BATCH; ++u) { const uint64_t i = i1 + (uint64_t)u * BLOCK + tid; nxt[u] = i < end ? item(i) : EMPTY; }
-          if (!prefetched) { if (rn < g.R) prefetch(rn); prefetched = true; }     // issued AFTER the first batches: their wait does not cover these
+          if (!prefetched) { if (rn < r_hi) prefetch(rn); prefetched = true; }     // issued AFTER the first batches: their wait does not cover these
           const uint32_t nv = BATCH;                                                // (EMPTY entries -- padding, the tail -- are stepped over)
           uint32_t u = 0, slot = 0, probes = 0;
           unsigned long long key = EMPTY;
@@ -779,13 +789,14 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
     u32x4 kq[KP], cq[CP];
     __shared__ unsigned long long s_next_chunk;               // chunks of the run are handed out to the waves as they come free
 
+    const uint32_t r_hi = g.b_hi * g.P2;                       // regions [b_lo * P2, r_hi): this launch's
     auto run_end = [&](uint32_t r) -> uint64_t {
         if (bend && (r + 1) % g.P2 == 0) return bend[r / g.P2];
         return off2[r + 1];
     };
     auto next_region = [&](uint32_t from) {
         uint32_t r = from;
-        while (r < g.R && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
+        while (r < r_hi && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
         return r;
     };
     auto prefetch = [&](uint32_t r) {
@@ -796,9 +807,9 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
         for (int u = 0; u < CP; ++u) { const uint32_t i = (u * BLOCK + tid) * 4; cq[u] = *reinterpret_cast<const u32x4*>(t.counts + base + (i < S ? i : 0)); }
     };
 
-    uint32_t r = next_region(blockIdx.x);
-    if (r < g.R) prefetch(r);
-    while (r < g.R) {
+    uint32_t r = next_region(g.b_lo * g.P2 + blockIdx.x);
+    if (r < r_hi) prefetch(r);
+    while (r < r_hi) {
         const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : run_end(r);
         const uint64_t base = (uint64_t)r * S;
         const unsigned long long t_top = now();
@@ -1020,7 +1031,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                 if (STAMP) { const unsigned long long t_d = now(); st[1] += t_b - t_a; st[2] += t_c - t_b; st[3] += t_d - t_c; }
             }
         }
-        if (rn < g.R) prefetch(rn);                           // in flight behind the write-back
+        if (rn < r_hi) prefetch(rn);                           // in flight behind the write-back
         const unsigned long long t_w = now();
 
         // ---- write-back: LDS -> HBM, 16 bytes per lane and store ----
