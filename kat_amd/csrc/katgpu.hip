@@ -690,6 +690,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const size_t n_starts = n - k + 1;
     *done = 0;
     c->arena_borrowed = false;                    // a borrowed arena is only promised until the next count call
+    if (n < 64) return KATGPU_OK;                 // (the tile loader reads whole 16-byte pieces: direct path)
     // A table hopelessly small for this input (KAT's default -H against a whole run) would spill nearly every k-mer of the
     // first round: give it room for 1/16 of the starts first -- cheap while it is still small, and before the arena exists.
     if (!g_test_round_items && !t->disable_grow && t->d.cap < n_starts / 16) {
@@ -821,7 +822,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         uint64_t seg_cap = est_items / ((uint64_t)W * g.P1);
         seg_cap += seg_cap / 24 + SEG_PAD;
         if (g_test_l1_cpb) seg_cap = std::min<uint64_t>(seg_cap, g_test_l1_cpb);
-        const bool seg = l1_fast_ok && (g_l1_fast == 2 || (ratio_known && est_items >= ((uint64_t)64 << 20))) && (uint64_t)W * g.P1 * seg_cap <= l1_items;
+        const bool seg = l1_fast_ok && (g_l1_fast == 2 || (ratio_known && est_items >= ((uint64_t)64 << 20))) && (uint64_t)W * g.P1 * seg_cap <= l1_items &&
+                         seg_cap <= 0xFFFFFFFFULL /* the kernel's segment arithmetic is 32 x 32 -> 64 bits */;
         const uint64_t seg_slots = seg ? (uint64_t)W * seg_cap : 0;                // slots of one bucket
         uint64_t items = 0;
         unsigned long long ovf_l1 = 0;

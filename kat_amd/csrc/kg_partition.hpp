@@ -198,7 +198,7 @@ constexpr int P1_TILE_STARTS = P1_TILE_BYTES - CHUNK_OVERLAP;     // 8160
 constexpr int P1_LANES_WITH_STARTS = P1_TILE_STARTS / PART_ITEMS; // 510
 
 struct P1Lds {
-    uint64_t cursor[MAX_PARTS];
+    uint64_t cursor[MAX_PARTS];         // exact edition: next position of each bucket's run; segmented edition: the low word counts inside the segment
     uint32_t hist[MAX_PARTS];
     uint32_t off[MAX_PARTS];
     uint32_t wave_tot[16];
@@ -230,11 +230,35 @@ __device__ __forceinline__ uint64_t canon_if(uint64_t fwd, uint32_t k, bool cano
 // the k-mer whose window starts at tile position p, from the staged codes
 __device__ __forceinline__ uint64_t kmer_at(const uint32_t* code, uint32_t p, uint32_t k, bool canonical) {
     const uint32_t w = p >> 4, o = p & 15;
-    uint64_t hi = ((uint64_t)code[w] << 32) | code[w + 1];
-    if (o) hi = (hi << (2 * o)) | ((uint64_t)code[w + 2] >> (32 - 2 * o));
+    const uint32_t c0 = code[w], c1 = code[w + 1], c2 = code[w + 2];
+    // the 64 bits that start 2 o bits into c0 : c1 : c2 -- two funnel shifts (v_alignbit_b32 shifts right by its amount mod 32)
+    const uint32_t sh = (32 - 2 * o) & 31;
+    const uint32_t h1 = o ? __builtin_amdgcn_alignbit(c0, c1, sh) : c0, h0 = o ? __builtin_amdgcn_alignbit(c1, c2, sh) : c1;
+    const uint64_t hi = ((uint64_t)h1 << 32) | h0;
     return canon_if(hi >> (64 - 2 * k), k, canonical);
 }
 
+// The same in two steps, so that the load of the NEXT tile can be in flight while this one is worked on: `issue` is one
+// unconditional 16-byte load (a lane whose window crosses the end of the stream loads from the start of it instead -- a load inside a
+// branch is waited for at the end of the branch, which is what the one-step form below amounts to), `fix` looks at the result when it
+// is needed and takes the byte-wise path for those (rare) lanes.
+__device__ __forceinline__ u32x4 p1_tile_issue(const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off) {
+    const uint64_t off = tile_off + (uint64_t)threadIdx.x * PART_ITEMS;
+    return *reinterpret_cast<const u32x4*>(bases + (off + PART_ITEMS <= n ? off : 0));
+}
+__device__ __forceinline__ void p1_tile_fix(const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off, const u32x4& v, uint32_t (&w)[4]) {
+    const uint64_t off = tile_off + (uint64_t)threadIdx.x * PART_ITEMS;
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    if (off + PART_ITEMS > n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { uint64_t i = off + q * 4 + b; x |= (i < n ? (uint32_t)bases[i] : (uint32_t)'N') << (8 * b); }
+            w[q] = x;
+        }
+    }
+}
 __device__ __forceinline__ void p1_tile_load(const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off, uint32_t (&w)[4]) {
     const uint64_t off = tile_off + (uint64_t)threadIdx.x * PART_ITEMS;
     if (off + PART_ITEMS <= n) {
@@ -291,18 +315,17 @@ k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
     for (uint32_t b = tid; b < MAX_PARTS; b += P1_BLOCK) s_hist[b] = 0;
     uint32_t ones = 0;
     const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
-    uint32_t w[4], wn[4];
-    if (t0 < t1) p1_tile_load(bases, n, t0 * P1_TILE_STARTS, w);
+    u32x4 raw = p1_tile_issue(bases, n, (t0 < t1 ? t0 : 0) * P1_TILE_STARTS);
     for (uint64_t tile = t0; tile < t1; ++tile) {
-        if (tile + 1 < t1) p1_tile_load(bases, n, (tile + 1) * P1_TILE_STARTS, wn);
+        uint32_t w[4];
+        p1_tile_fix(bases, n, tile * P1_TILE_STARTS, raw, w);
+        raw = p1_tile_issue(bases, n, (tile + 1 < t1 ? tile + 1 : tile) * P1_TILE_STARTS);    // the next tile: in flight behind this one
         lds_barrier();
         uint32_t code, bad;
         encode16(w, code, bad);
         s_code[tid] = code; s_bad[tid] = bad;
         if (tid < 2) { s_code[P1_BLOCK + tid] = 0; s_bad[P1_BLOCK + tid] = 0xFFFF; }
         lds_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = wn[q];
         if (tid < P1_LANES_WITH_STARTS) {
             LaneWindow lw;
             lw.init(s_code, s_bad, tid, t.k);
@@ -337,29 +360,37 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
     const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;
     const bool canonical = t.canonical != 0;
     uint32_t ones = 0;
-    auto seg_base = [&](uint32_t b) -> uint64_t { return ((uint64_t)b * gridDim.x + blockIdx.x) * seg_cap; };
-    for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] = SEG ? seg_base(b) : offs[(uint64_t)blockIdx.x * P + b];
+    // segment (b, this workgroup) starts at seg_base(b): one 32 x 32 -> 64-bit multiply (segments and their capacity are 32-bit
+    // numbers: host-checked); the segmented edition's cursors count inside the segment
+    const uint32_t cap32 = (uint32_t)seg_cap;
+    auto seg_base = [&](uint32_t b) -> uint64_t { return (uint64_t)(b * gridDim.x + blockIdx.x) * cap32; };
+    for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] = SEG ? 0 : offs[(uint64_t)blockIdx.x * P + b];
     const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
-    uint32_t w[4], wn[4];
-    if (t0 < t1) p1_tile_load(bases, n, t0 * P1_TILE_STARTS, w);
+    u32x4 raw = p1_tile_issue(bases, n, (t0 < t1 ? t0 : 0) * P1_TILE_STARTS);
     for (uint64_t tile = t0; tile < t1; ++tile) {
-        if (tile + 1 < t1) p1_tile_load(bases, n, (tile + 1) * P1_TILE_STARTS, wn);
+        uint32_t w[4];
+        p1_tile_fix(bases, n, tile * P1_TILE_STARTS, raw, w);
+        raw = p1_tile_issue(bases, n, (tile + 1 < t1 ? tile + 1 : tile) * P1_TILE_STARTS);    // the next tile: in flight behind this one
         lds_barrier();                                   // previous tile's copy-out / cursor update done
         for (uint32_t b = tid; b < MAX_PARTS; b += P1_BLOCK) L.hist[b] = 0;
         p1_tile_stage(L, w);                               // ends with a barrier
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = wn[q];
         // sweep 1: bucket and rank of every valid window of this lane
         uint32_t br[PART_ITEMS];
         uint32_t valid = 0;
         if (tid < P1_LANES_WITH_STARTS) {
             LaneWindow lw;
             lw.init(L.code, L.bad, tid, k);
+            // the reverse complement rolls along with the window: out goes its last base, in comes the complement of the window's
+            // new last base at the top (seven operations instead of the sixteen of a bit-reversal per window)
+            uint64_t rc = kmer_revcomp(lw.fwd(), k);
+            const uint32_t top = 2 * k - 2;
 #pragma unroll
-            for (int j = 0; j < PART_ITEMS; ++j, lw.step()) {
+            for (int j = 0; j < PART_ITEMS; ++j) {
+                if (j) { lw.step(); rc = (rc >> 2) | ((uint64_t)(3u ^ ((uint32_t)lw.fwd() & 3u)) << top); }
                 br[j] = 0;
                 if (!lw.valid()) continue;
-                const uint64_t key = canon_if(lw.fwd(), k, canonical);
+                const uint64_t fw = lw.fwd();
+                const uint64_t key = canonical ? (rc < fw ? rc : fw) : fw;
                 if (key == EMPTY) { if (SEG) ++ones; continue; }               // exact edition: tallied by the count pass
                 const uint32_t b = place_digit1(place_stage1(key, g.pl), g.pl);
                 br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
@@ -384,9 +415,10 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         const uint32_t total = L.off[P - 1] + L.hist[P - 1];
         for (uint32_t idx = tid; idx < total; idx += P1_BLOCK) {
             const uint32_t v = L.pos[idx], b = v >> 16;
-            const uint64_t dst = L.cursor[b] + (idx - L.off[b]);
             const uint64_t key1 = kmer_at(L.code, v & 0xFFFF, k, canonical);
-            if (!SEG || dst < seg_base(b) + seg_cap) l1_buf[dst] = key1;
+            const uint32_t rel = (uint32_t)L.cursor[b] + (idx - L.off[b]);    // (segmented edition)
+            if (!SEG) l1_buf[L.cursor[b] + (idx - L.off[b])] = key1;
+            else if (rel < cap32) l1_buf[seg_base(b) + rel] = key1;
             else {                                                             // the segment is full: the overflow list
                 const unsigned long long at = atomicAdd(ovf_n, 1ULL);
                 if (at < ovf_cap) ovf_buf[at] = key1;
@@ -395,7 +427,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         lds_barrier();
         for (uint32_t b = tid; b < P; b += P1_BLOCK) {
             uint64_t c = L.cursor[b] + L.hist[b];
-            if (SEG) { const uint64_t lim = seg_base(b) + seg_cap; c = c < lim ? c : lim; }
+            if (SEG) c = c < cap32 ? c : cap32;
             L.cursor[b] = c;
         }
     }
@@ -404,8 +436,8 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         // what the segments have left is padded; a 16-lane group per bucket
         const uint32_t grp = tid >> 4, l16 = tid & 15;
         for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
-            const uint64_t lim = seg_base(b) + seg_cap;
-            for (uint64_t i = L.cursor[b] + l16; i < lim; i += 16) l1_buf[i] = EMPTY;
+            const uint64_t base = seg_base(b);
+            for (uint64_t i = L.cursor[b] + l16; i < cap32; i += 16) l1_buf[base + i] = EMPTY;
         }
         for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
         if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
