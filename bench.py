@@ -119,7 +119,7 @@ def pmc_traffic(a, world):
         base = name.replace("kg::", "").replace("void ", "").split("<")[0].split("(")[0]
         if base.startswith(("k_p1", "k_p2", "k_p3", "k_s1", "k_s2", "k_s3", "k_insert_keys")):
             kb += 2.0 * e.get("FETCH_SIZE_KB_total", 0.0) + e.get("WRITE_SIZE_KB_total", 0.0)
-            if base.startswith(("k_p3_apply", "k_s3_apply")):
+            if base.startswith(("k_p1v2_scatter", "k_s1")):          # one per round
                 rounds += e.get("launches", 0)
     if not rounds:
         return None, None
@@ -321,10 +321,11 @@ def main():
         part_ms = sum(prof[n]["ms"] for n in stage)
         direct_ms = prof["count"]["ms"]
         if part_ms >= direct_ms:
-            # partitioned counter: one "launch" = one round = the stage kernels over the round's k-mers
-            rounds = max(1, prof["part_apply"]["launches"])
+            # partitioned counter: one "launch" = one round = the stage kernels over the round's k-mers (level 1 once, level 2 and the
+            # apply once per pass of the round: per_kernel has their own launch counts)
+            rounds = max(1, prof["part_l1_scatter"]["launches"])
             stage_ms = part_ms + direct_ms
-            name = "count stage (partitioned): level-1 count+scan, level-1 scatter, level 2, apply per round"
+            name = "count stage (partitioned): per round level-1 scatter (+ count/scan when exact), then level 2 + apply in passes"
             per_kernel = {n: {"launches": prof[n]["launches"], "avg_ms": round(prof[n]["ms"] / max(1, prof[n]["launches"]), 3)} for n in stage}
         else:
             rounds = max(1, prof["count"]["launches"])

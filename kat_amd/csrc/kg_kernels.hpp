@@ -237,6 +237,7 @@ k_hist(DevTable t, uint32_t n_ovf, uint64_t base, uint64_t ceil_, uint64_t inc, 
 // ceil((double)count * scale) exactly as the host does it (src/gcp.cc:190, src/comp.hpp:303-306): one IEEE
 // double multiply, one ceil, no contraction possible.
 __device__ __forceinline__ uint64_t scale_count(uint64_t c, double scale) {
+    if (scale == 1.0) return c;            // (the default; uniform.  Every caller clamps to its bins, so counts beyond 2^53 end up the same)
     return c == 0 ? 0 : (uint64_t)ceil((double)c * scale);
 }
 
