@@ -620,7 +620,11 @@ static bool part_geometry(const DevTable& d, PartGeom* g) {
 // slack again + the run slack 1/16 + the group padding's allowance 2 * 1024 / tile), overflow list (8 B / 32)
 static double l2_items_per_l1_item(uint32_t hb) { return 1 + 1.0 / 16 + 2.0 * MAX_PARTS / l2_tile_items(hb); }
 // buckets per pass of level 2 + apply: a CU-full when the buckets are a whole number of those (alloc_dev_table sees to it), else all
-static uint32_t pass_buckets(uint32_t p1, uint32_t n_cu) { return n_cu && p1 > n_cu && p1 % n_cu == 0 ? n_cu : p1; }
+static const uint32_t g_test_pass_buckets = hook("KATGPU_TEST_PASS_BUCKETS") ? (uint32_t)strtoul(hook("KATGPU_TEST_PASS_BUCKETS"), nullptr, 10) : 0;   // tests: passes of this many buckets
+static uint32_t pass_buckets(uint32_t p1, uint32_t n_cu) {
+    if (g_test_pass_buckets) return std::max<uint32_t>(1, std::min(p1, g_test_pass_buckets));
+    return n_cu && p1 > n_cu && p1 % n_cu == 0 ? n_cu : p1;
+}
 // ... of which the level-2 buffer holds one pass = 1 / passes of a round
 static double arena_bytes_per_item(uint32_t hb, uint32_t passes) { return 8.0 * (1 + 1.0 / 24) + (4.0 + hb) * (1 + 1.0 / 24) * l2_items_per_l1_item(hb) / passes + 0.25 + 0.02; }
 
@@ -726,7 +730,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     PartGeom g0;
     if (!part_geometry(t->d, &g0)) return KATGPU_OK;                              // direct path
     const uint32_t hb0 = g0.hb;                                                  // a table that grows has more regions: never more remainder bits
-    const uint32_t passes0 = g0.P1 / pass_buckets(g0.P1, (uint32_t)c->n_cu);
+    const uint32_t passes0 = std::max<uint32_t>(1, g0.P1 / pass_buckets(g0.P1, (uint32_t)c->n_cu));   // (rounded down: the buffer never too small)
     const double per_item = arena_bytes_per_item(hb0, passes0);
     constexpr size_t SEG_PAD = 64;
     const size_t fixed_l1 = (size_t)W * MAX_PARTS * SEG_PAD;

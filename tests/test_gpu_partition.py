@@ -29,7 +29,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     (8192, 400000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "0"}),
     (2048, 250000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2", "KATGPU_TEST_L1_CPB": "3", "KATGPU_P1_WGS": "1"}),
     (512, 150000, 3, {"KATGPU_L1_FAST": "2", "KATGPU_TEST_L1_CPB": "2", "KATGPU_TEST_P2_OVF_CAP": "50", "KATGPU_P1_WGS": "1"}),
-    (1024, 200000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2", "KATGPU_TEST_GROW_NOMEM": "1"})])
+    (1024, 200000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2", "KATGPU_TEST_GROW_NOMEM": "1"}),
+    # pass_buckets: level 2 + apply go through a round's buckets in passes of this many (production: one CU-full, and only at
+    # sizes beyond these tests): the level-2 buffer holds one pass, every pass spills into its own part of the level-1 buffer, the
+    # overflow list and the fall back to the exact level 2 carry over from pass to pass
+    (512, 100000, 0, {"KATGPU_TEST_PASS_BUCKETS": "5"}), (1024, 3000000, 7, {"KATGPU_P2_FAST": "2", "KATGPU_TEST_PASS_BUCKETS": "3"}),
+    (2048, 250000, 3, {"KATGPU_P2_FAST": "2", "KATGPU_TEST_P2_OVF_CAP": "3", "KATGPU_TEST_PASS_BUCKETS": "2"}),
+    (512, 150000, 3, {"KATGPU_L1_FAST": "2", "KATGPU_TEST_L1_CPB": "2", "KATGPU_TEST_P2_OVF_CAP": "50", "KATGPU_P1_WGS": "1", "KATGPU_TEST_PASS_BUCKETS": "7"}),
+    (1024, 200000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2", "KATGPU_TEST_GROW_NOMEM": "1", "KATGPU_TEST_PASS_BUCKETS": "1"})])
 def test_partitioned_counter_matches_oracle(region_slots, round_items, spill_mod, extra):
     env = dict(os.environ, KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
                KATGPU_TEST_ROUND_ITEMS=str(round_items), KATGPU_TEST_SPILL_MOD=str(spill_mod))
