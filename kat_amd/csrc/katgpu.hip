@@ -309,6 +309,7 @@ static void pool_release(katgpu_ctx* c, void* p) {
 
 static const bool g_force_join = hook("KATGPU_FORCE_JOIN") != nullptr;  // tests: take the join form whenever it is legal
 static const bool g_no_join = hook("KATGPU_NO_JOIN") != nullptr;       // A/B switch: force comp's probe form
+static const bool g_no_seen = hook("KATGPU_NO_SEEN") != nullptr;       // A/B switch: pass 2 probes hash 1 even after a join pass 1
 static const uint32_t g_region_slots = hook("KATGPU_TEST_REGION_SLOTS") ? (uint32_t)strtoul(hook("KATGPU_TEST_REGION_SLOTS"), nullptr, 10) : REGION_SLOTS;
 
 constexpr uint32_t MAX_REGION_SLOTS = 12288;        // 144 KB of LDS in the apply / join kernels
@@ -2118,12 +2119,22 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
         if (scan->d.cap + probe->d.cap < ((uint64_t)64 << 20)) return true;        // small either way: take the join
         return 12.0 * (double)(scan->d.cap + probe->d.cap) / 2.2e12 < 1.3 * (double)scan->distinct / 55e9;
     };
+    // pass 1 as a join can leave a bit per slot of hash 2 ("hash 1 holds this k-mer"); pass 2 is then a scan of hash 2 (k_comp_seen)
+    const bool join_1 = same_grid && ident1 && (g_force_join || join_pays(t1, t2));
+    const uint32_t wpr = (t2->d.region_slots + 31) / 32;
+    const bool marked = join_1 && !g_no_seen && t1->d.canonical && t2->d.canonical && t2->ones == 0 && join1 + (size_t)wpr * 4 <= 150 * 1024;
+    uint32_t* seen_bits = nullptr;
+    if (marked) {
+        if (pool_alloc(c, (void**)&seen_bits, (size_t)t2->d.n_regions * wpr * 4) != hipSuccess) { (void)hipGetLastError(); seen_bits = nullptr; }
+        a.seen = seen_bits; a.seen_wpr = wpr;
+    }
     auto join_grid = [&](size_t lds, uint32_t regions) { return std::min<uint32_t>(regions, (uint32_t)c->n_cu * (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 4))); };
     {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap);
-        if (same_grid && ident1 && join1 <= 150 * 1024 && (g_force_join || join_pays(t1, t2))) {
+        if (join_1 && join1 <= 150 * 1024) {
+            const size_t j1 = join1 + (a.seen ? (size_t)wpr * 4 : 0);
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            hipLaunchKernelGGL(k_comp_join<1>, dim3(join_grid(join1, t1->d.n_regions)), dim3(512), join1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
+            hipLaunchKernelGGL(k_comp_join<1>, dim3(join_grid(j1, t1->d.n_regions)), dim3(512), j1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
         } else if (wide)
             hipLaunchKernelGGL((k_comp<1, true>), dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
         else
@@ -2131,7 +2142,9 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     }
     {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS2, t2->d.cap);
-        if (same_grid && ident2 && join2 <= 150 * 1024 && (g_force_join || join_pays(t2, t1))) {
+        if (a.seen && join1 <= 150 * 1024) {
+            hipLaunchKernelGGL(k_comp_seen, dim3(std::min<uint32_t>(t2->d.n_regions, (uint32_t)c->n_cu * 4)), dim3(512), lds2, c->stream, t2->d, t2->n_ovf, a);
+        } else if (same_grid && ident2 && join2 <= 150 * 1024 && (g_force_join || join_pays(t2, t1))) {
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             hipLaunchKernelGGL(k_comp_join<2>, dim3(join_grid(join2, t2->d.n_regions)), dim3(512), join2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
         } else if (wide)
@@ -2145,6 +2158,7 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     hipMemcpyAsync(spectra, d + mx_cells + 13, 4 * (size_t)ss * 8, hipMemcpyDeviceToHost, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
     hipFree(d);
+    if (seen_bits) pool_release(c, seen_bits);
     if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
     return KATGPU_OK;
 }

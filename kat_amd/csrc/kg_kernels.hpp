@@ -301,6 +301,8 @@ struct CompArgs {
     unsigned long long* main_mx;     // d1_bins x d2_bins
     unsigned long long* counters;    // 13
     unsigned long long* spectra;     // 4 x spec_size
+    uint32_t* seen;                  // join pass 1 -> pass 2: one bit per slot of hash 2, set when hash 1 holds the slot's key (null: off);
+    uint32_t seen_wpr;               // words per region of that bitmap
 };
 
 __device__ __forceinline__ uint32_t spectrum_bin(uint64_t c, uint32_t size) { return c >= size ? size - 1 : (uint32_t)c; }  // comp_counters.cc:130-140
@@ -451,6 +453,8 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
     const uint32_t Sa = ta.region_slots, Sb = tb.region_slots;
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(s_raw + ((16 * 8 + COMP_TILE * COMP_TILE * 4 + n_spec * 4 + 15) & ~15u));
     uint32_t* rc = reinterpret_cast<uint32_t*>(rk + Sb);
+    uint32_t* s_seen = rc + Sb;                                             // (a.seen) which slots of this region of hash 2 were found
+    const bool mark = PASS == 1 && a.seen != nullptr;
     comp_lds_init(a, PASS, s_acc, s_tile, s_spec);
     CompAcc acc;
     const uint32_t R = ta.n_regions;
@@ -459,6 +463,7 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
         const uint64_t bbase = (uint64_t)r * Sb, abase = (uint64_t)r * Sa;
         const RegionPlace rpb = region_place(tb, r);
         for (uint32_t i = threadIdx.x; i < Sb; i += blockDim.x) { rk[i] = tb.keys[bbase + i]; rc[i] = tb.counts[bbase + i]; }
+        if (mark) for (uint32_t i = threadIdx.x; i < a.seen_wpr; i += blockDim.x) s_seen[i] = 0;
         __syncthreads();
         constexpr int JB = 4;                                               // slots per lane in flight: keys and counts are loaded together
         for (uint32_t i0 = 0; i0 < Sa; i0 += JB * blockDim.x) {             // uniform trip count: ballots inside comp_account
@@ -481,13 +486,17 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
                     uint32_t s = home_offset_in(key, rpb);
                     for (uint32_t probe = 0; probe < Sb; ++probe) {
                         const unsigned long long cur = rk[s];
-                        if (cur == key) { cb = rc[s]; if (nb_ovf) cb += ovf_get(tb, key); break; }
+                        if (cur == key) { cb = rc[s]; if (nb_ovf) cb += ovf_get(tb, key); if (mark) atomicOr(&s_seen[s >> 5], 1u << (s & 31)); break; }
                         if (cur == EMPTY) break;
                         s = s + 1 == Sb ? 0 : s + 1;
                     }
                 }
                 comp_account<PASS>(occ, ca, cb, a, s_tile, s_spec, acc);
             }
+        }
+        if (mark) {                                                          // pass 2 will read this instead of probing hash 1
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < a.seen_wpr; i += blockDim.x) a.seen[(uint64_t)r * a.seen_wpr + i] = s_seen[i];
         }
     }
     {   // the all-ones key lives outside the slots: one lane of block 0 takes it through the HBM path
@@ -501,6 +510,45 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
         comp_account<PASS>(occ, ca, cb, a, s_tile, s_spec, acc);
     }
     comp_flush<PASS>(a, s_acc, s_tile, s_spec, acc);
+}
+
+// Pass 2 after a join pass 1 that marked what it found (CompArgs::seen): the k-mers of hash 2 that hash 1 does not hold are the
+// occupied slots whose bit is clear, so pass 2 is one scan of hash 2 and of a bit per slot -- no probe of hash 1 at all (the probe
+// form spends 1.3 random sector reads per k-mer of hash 2: 25 ms at config 4, 49 ms when hash 2 is a second read library).  Both
+// tables canonical (pass 2 probes the canonical form, src/comp.cc:447: only then is "found by pass 1" the same question), and the
+// all-ones key is never canonical, so there is no slot-less key to look after.
+__global__ void __launch_bounds__(512)
+k_comp_seen(DevTable ta /* hash 2 */, uint32_t na_ovf, CompArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_raw);
+    uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_raw + 16 * sizeof(unsigned long long));
+    uint32_t* s_spec = s_tile + COMP_TILE * COMP_TILE;
+    comp_lds_init(a, 2, s_acc, s_tile, s_spec);
+    CompAcc acc;
+    const uint32_t S = ta.region_slots, R = ta.n_regions;
+    constexpr int JB = 4;
+    for (uint32_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const uint64_t base = (uint64_t)r * S;
+        const uint32_t* seen = a.seen + (uint64_t)r * a.seen_wpr;
+        for (uint32_t i0 = 0; i0 < S; i0 += JB * blockDim.x) {               // uniform trip count: ballots inside comp_account
+            uint64_t keys[JB]; uint32_t cnts[JB], bits[JB];
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const uint32_t i = i0 + u * blockDim.x + threadIdx.x;
+                const uint32_t ic = i < S ? i : S - 1;                      // clamped: the loads stay in one basic block
+                keys[u] = ta.keys[base + ic]; cnts[u] = ta.counts[base + ic]; bits[u] = seen[ic >> 5] >> (ic & 31);
+                if (i >= S) keys[u] = EMPTY;
+            }
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const bool occ = keys[u] != EMPTY;
+                uint64_t ca = 0;
+                if (occ) { ca = cnts[u]; if (na_ovf) ca += ovf_get(ta, keys[u]); }
+                comp_account<2>(occ, ca, (uint64_t)(bits[u] & 1u), a, s_tile, s_spec, acc);
+            }
+        }
+    }
+    comp_flush<2>(a, s_acc, s_tile, s_spec, acc);
 }
 
 // ---- K5b: the third comp input (src/comp.cc:123-127,403-433,466-479) ----
