@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
             uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n,
             const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend, unsigned long long* __restrict__ stamps = nullptr) {
-    // STAMP: cycle stamps of wave 0 (tools/ab_apply.sh): [0] fill + sweep, [1] chunk loads + hash, [2] probe rounds, [3] queue push + drains,
+    // STAMP (diagnostic instantiation): cycle stamps of wave 0: [0] fill + sweep, [1] chunk loads + hash, [2] probe rounds, [3] queue push + drains,
     // [4] wait for the other waves, [5] write-back, [6] regions
     unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0};
     auto now = [&]() -> unsigned long long { return STAMP ? (unsigned long long)clock64() : 0ULL; };
