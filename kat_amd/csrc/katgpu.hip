@@ -75,6 +75,7 @@ struct katgpu_table {
     uint32_t n_regrows = 0;      // how often the table had to grow (the host mirror words the reference's warning from it)
     uint8_t carry[64];           // last k-1 bytes of the previous host batch of the current file
     uint32_t carry_n = 0;
+    bool lazy = false;           // the slots have not been initialised yet (KATGPU_LAZY_INIT, "lazy tables" below): TOUCH() or the first partition round does it
 };
 
 static int fail(katgpu_ctx* c, int code, const char* fmt, ...) {
@@ -324,7 +325,8 @@ constexpr int AP2_QCAP_BIG = 192;                   // its queue entries per wav
 // share its region function as well as its grid).
 static const uint32_t g_mz_min_regions = hook("KATGPU_MZ_MIN_REGIONS") ? (uint32_t)strtoul(hook("KATGPU_MZ_MIN_REGIONS"), nullptr, 10) : 0xFFFFFFFFu;
 
-static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1 = 0, uint32_t like_p2 = 0, int like_mz = -1) {
+static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1 = 0, uint32_t like_p2 = 0, int like_mz = -1,
+                           bool lazy = false /* leave the slots as they are: see "lazy tables" */) {
     DevTable d{};
     const uint64_t like_r = (uint64_t)like_p1 * like_p2;
     // capacity is a whole number of regions (kg_device.hpp: Probe); a table smaller than one region is a single short region
@@ -377,8 +379,10 @@ static int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t ca
         pool_release(c, d.keys); pool_release(c, d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs); hipFree(d.fail_buf);
         return fail(c, KATGPU_ERR_NOMEM, "device allocation of a %llu-slot table failed: %s", (unsigned long long)cap, hipGetErrorString(e));
     }
-    HIPCHK(c, hipMemsetAsync(d.keys, 0xFF, key_bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(d.counts, 0, cap * sizeof(uint32_t), c->stream));
+    if (!lazy) {
+        HIPCHK(c, hipMemsetAsync(d.keys, 0xFF, key_bytes, c->stream));
+        HIPCHK(c, hipMemsetAsync(d.counts, 0, cap * sizeof(uint32_t), c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_hi, 0, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ctrs, 0, CTR_WORDS * sizeof(uint64_t), c->stream));
@@ -393,6 +397,23 @@ static void free_dev_table(katgpu_ctx* c, DevTable& d) {
     d = DevTable{};
 }
 
+// ---- lazy tables (KATGPU_LAZY_INIT, a test hook: OFF) ----
+// A fresh table is memset (39 + 20 GB of writes for config 4's first table) and then READ by its first partition round.  A lazy
+// table skips the memset: its first partition round fills every region in LDS without loading it (k_p3_apply2<..., INIT>) and
+// writes every region back, visited or not by k-mers.  Anything else that looks at the slots first -- TOUCH() at the top of every
+// other entry point, the direct counter, a regrow -- initialises them the ordinary way.
+static const bool g_lazy_init = hook("KATGPU_LAZY_INIT") != nullptr;
+static int materialize(katgpu_table* t) {
+    if (!t->lazy) return KATGPU_OK;
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(t->d.keys, 0xFF, t->d.cap * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(t->d.counts, 0, t->d.cap * sizeof(uint32_t), c->stream));
+    t->lazy = false;
+    return KATGPU_OK;
+}
+#define TOUCH(T) do { katgpu_table* t__ = const_cast<katgpu_table*>(T); if (t__ && t__->lazy) { int rc__ = materialize(t__); if (rc__) return rc__; } } while (0)
+
 extern "C" int katgpu_table_create(katgpu_ctx* c, uint32_t k, int canonical, uint64_t size_hint, int disable_grow, katgpu_table** out) {
     if (!c || !out) return KATGPU_ERR_INVALID_ARG;
     *out = nullptr;
@@ -401,7 +422,8 @@ extern "C" int katgpu_table_create(katgpu_ctx* c, uint32_t k, int canonical, uin
     uint64_t cap = std::max<uint64_t>(size_hint ? size_hint : (1u << 20), 1024);
     katgpu_table* t = new katgpu_table();
     t->ctx = c; t->disable_grow = disable_grow;
-    int rc = alloc_dev_table(c, k, canonical, cap, &t->d);
+    t->lazy = g_lazy_init && k <= 32;
+    int rc = alloc_dev_table(c, k, canonical, cap, &t->d, 0, 0, -1, t->lazy);
     if (rc) { delete t; return rc; }
     *out = t;
     return KATGPU_OK;
@@ -416,8 +438,9 @@ extern "C" int katgpu_table_create_like(katgpu_ctx* c, const katgpu_table* like,
     uint64_t cap = std::max<uint64_t>(size_hint ? size_hint : (1u << 20), 1024);
     katgpu_table* t = new katgpu_table();
     t->ctx = c; t->disable_grow = disable_grow;
-    int rc = (k > 32) != (like->d.k > 32) ? alloc_dev_table(c, k, canonical, cap, &t->d)     // no common grid across key widths
-                                          : alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2, (int)like->d.mz);
+    t->lazy = g_lazy_init && k <= 32;
+    int rc = (k > 32) != (like->d.k > 32) ? alloc_dev_table(c, k, canonical, cap, &t->d, 0, 0, -1, t->lazy)     // no common grid across key widths
+                                          : alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2, (int)like->d.mz, t->lazy);
     if (rc) { delete t; return rc; }
     *out = t;
     return KATGPU_OK;
@@ -458,8 +481,15 @@ static int refresh_counters(katgpu_table* t) {
 static int regrow(katgpu_table* t, uint64_t new_cap) {
     katgpu_ctx* c = t->ctx;
     DevTable nd{};
-    int rc = alloc_dev_table(c, t->d.k, t->d.canonical, new_cap, &nd, t->d.n_regions > 1 ? t->d.p1 : 0, t->d.n_regions > 1 ? t->d.p2 : 0, (int)t->d.mz);
+    int rc = alloc_dev_table(c, t->d.k, t->d.canonical, new_cap, &nd, t->d.n_regions > 1 ? t->d.p1 : 0, t->d.n_regions > 1 ? t->d.p2 : 0, (int)t->d.mz, t->lazy);
     if (rc) return rc;
+    if (t->lazy) {                                             // never touched: there is nothing to re-insert (and nothing to read)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        free_dev_table(c, t->d);
+        t->d = nd;
+        ++t->n_regrows;
+        return refresh_counters(t);
+    }
     {
         ScopedTimer tm(c, KATGPU_K_REGROW, t->d.cap);
         if (t->d.keys_b) hipLaunchKernelGGL(k_regrow_w, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, nd, t->d, t->n_ovf);
@@ -717,6 +747,13 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         KG_LDS_ATTR((k_p3_apply2<512, 2, 4, 3, HB>), 150 * 1024); KG_LDS_ATTR((k_p3_apply2<512, 2, 4, 3, HB, false, true, true>), 150 * 1024);
         KG_FOR_HB(KG_ATTR_HB)
 #undef KG_ATTR_HB
+        if (g_lazy_init) {
+#define KG_ATTR_INIT(HB) \
+            KG_LDS_ATTR((k_p3_apply2<1024, 4, 4, 3, HB, false, true, true, AP2_QCAP, true>), 150 * 1024); KG_LDS_ATTR((k_p3_apply2<512, 4, 4, 3, HB, false, true, true, AP2_QCAP, true>), 150 * 1024); \
+            KG_LDS_ATTR((k_p3_apply2<512, 2, 4, 3, HB, false, true, true, AP2_QCAP, true>), 150 * 1024); KG_LDS_ATTR((k_p3_apply2<1024, 5, 4, 3, HB, false, true, true, AP2_QCAP_BIG, true>), 160 * 1024 - 256);
+            KG_ATTR_INIT(1) KG_ATTR_INIT(2)
+#undef KG_ATTR_INIT
+        }
 #define KG_ATTR_AP1(B, SPT) KG_LDS_ATTR((k_p3_apply<B, SPT, 4, false>), 150 * 1024); if (g_testing) KG_LDS_ATTR((k_p3_apply<B, SPT, 4, true>), 150 * 1024);
         KG_ATTR_AP1(1024, 4) KG_ATTR_AP1(1024, 8) KG_ATTR_AP1(1024, 12) KG_ATTR_AP1(512, 8) KG_ATTR_AP1(512, 16) KG_ATTR_AP1(512, 24)
 #undef KG_ATTR_AP1
@@ -794,6 +831,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         PartGeom g;
         if (!part_geometry(t->d, &g) || t->d.mz) break;                           // table too large for two levels: direct path; grown into minimizer regions: the other counter
         if (g.hb > hb0) break;                                                    // (cannot happen: see hb0) the level-2 carve would not hold these items
+        // a lazy table: this round's apply initialises every region itself (k_p3_apply2<..., INIT>) when it is the kind of round that can
+        const uint32_t blk0 = g_apply_block ? g_apply_block : (g.S <= 4096 ? 512 : 1024);
+        const bool init_round = t->lazy && t->distinct == 0 && !g_apply_noinline && g_apply_v != 1 && !g_test_spill_mod && g.S % 4 == 0 && g.S >= 64 &&
+                                g.S <= AP2_MAX_SLOTS && (blk0 == 512 ? g.S <= 4096 : true) && (g.hb == 1 || g.hb == 2);
+        if (t->lazy && !init_round) { rc = materialize(t); if (rc) return rc; }
         // (the segmented level 1 sizes its segments from this ratio, so it wants it even when one round takes everything)
         if (!ratio_known && !g_test_round_items && (n_starts - pos > round_items || (l1_fast_ok && n_starts - pos >= ((size_t)64 << 20)))) {
             const size_t probe_m = std::min<size_t>(n_starts - pos, (size_t)64 << 20) / tile_starts * tile_starts;
@@ -965,12 +1007,16 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                         // (INLINE_CLAIM) instead of all going through the queues; any later round loses by that (kg_partition.hpp)
                         const bool fresh = t->distinct == 0 && !g_apply_noinline;
     #define KG_APPLY2(B, KP, HB) do { \
-                            if (fresh) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, true, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
+                            if (init_round) { if constexpr (HB == 1 || HB == 2) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, true, true, AP2_QCAP, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, \
+                                                          (const uint8_t*)l2_buf, spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } \
+                            else if (fresh) hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, true, true>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
                                                           spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); \
                             else hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB>), dim3(grid2), dim3(B), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
                                                     spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } while (0)
     #define KG_APPLY2_BIG(HB) do { \
-                            if (fresh) hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, true, true, AP2_QCAP_BIG>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
+                            if (init_round) { if constexpr (HB == 1 || HB == 2) hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, true, true, AP2_QCAP_BIG, true>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, \
+                                                          (const uint8_t*)l2_buf, spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } \
+                            else if (fresh) hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, true, true, AP2_QCAP_BIG>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
                                                           spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); \
                             else hipLaunchKernelGGL((k_p3_apply2<1024, 5, 4, 3, HB, false, false, true, AP2_QCAP_BIG>), dim3(grid2), dim3(1024), lds2, c->stream, t->d, g, off2, (const uint8_t*)l2_buf, \
                                                     spill_buf, spill_n, run_len, bucket_end, (unsigned long long*)nullptr); } while (0)
@@ -1000,6 +1046,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 if (spilled) lists.push_back({spill_buf, spilled});
             }
             if (redo_round) continue;
+            if (init_round) t->lazy = false;                                       // every region has been written
             if (ovf_total) lists.push_back({ovf_buf, ovf_total});                  // what level 1 / level 2 could not place
             if (!lists.empty()) {                      // regions that ran out of slots, runs beyond their capacity: make room, then the direct path
                 uint64_t total = 0;
@@ -1025,6 +1072,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
 // level-1 digit into per-workgroup segments; exact count + scan + scatter when a segment list overflows or the round is small)
 // -> S2 (exact level 2) -> S3 (apply).  Same contract as count_partitioned.
 static int count_superkmer(katgpu_table* t, const uint8_t* dev_bases, size_t n, size_t* done) {
+    TOUCH(t);
     katgpu_ctx* c = t->ctx;
     const uint32_t k = t->d.k;
     const size_t n_starts = n - k + 1;
@@ -1241,6 +1289,7 @@ static int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
         pos += done;
     }
     while (pos < n_starts) {
+        TOUCH(t);                               // (a lazy table that the partitioned counter did not take)
         int rc = refresh_counters(t);
         if (rc) return rc;
         // largest batch that provably fits; if even a minimal one does not, grow first
@@ -1468,6 +1517,7 @@ extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_pa
 }
 
 extern "C" int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t* total, uint64_t* capacity) {
+    TOUCH(t);
     if (!t) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1487,6 +1537,7 @@ extern "C" int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t*
 }
 
 extern "C" int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n, int canonicalise, uint64_t* counts) {
+    TOUCH(t);
     if (!t || (n && (!keys || !counts))) return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "katgpu_table_get: use katgpu_table_get_wide;");
     if (!n) return KATGPU_OK;
@@ -1527,6 +1578,7 @@ static int launch_profile(katgpu_table* t, const uint8_t* dev_bases, size_t n, i
 }
 
 extern "C" int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_bases, size_t n, int canonicalise, uint64_t* dev_counts) {
+    TOUCH(t);
     if (!t || (n && (!dev_bases || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
     if (n < t->d.k) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;
@@ -1538,6 +1590,7 @@ extern "C" int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_b
 // Host form: the sequence goes through the device in batches of PROFILE_BATCH window starts (each batch re-sends the
 // k-1 bases it shares with the next one), so any length fits next to the table.
 extern "C" int katgpu_table_profile_host(katgpu_table* t, const char* bases, size_t n, int canonicalise, uint64_t* counts) {
+    TOUCH(t);
     if (!t || (n && (!bases || !counts))) return KATGPU_ERR_INVALID_ARG;
     const uint32_t k = t->d.k;
     if (n < k) return KATGPU_OK;
@@ -1571,6 +1624,7 @@ extern "C" int katgpu_table_profile_host(katgpu_table* t, const char* bases, siz
 // ------------------------------------------------------------------ partition / export / merge -------
 
 extern "C" int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, uint64_t* sizes) {
+    TOUCH(t);
     if (!t || !sizes || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1593,6 +1647,7 @@ extern "C" int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, u
 }
 
 extern "C" int katgpu_table_partition(katgpu_table* t, uint32_t n_parts, const uint64_t* offsets, uint64_t* dev_keys, uint64_t* dev_counts) {
+    TOUCH(t);
     if (!t || !offsets || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "katgpu_table_partition");
     katgpu_ctx* c = t->ctx;
@@ -1612,6 +1667,7 @@ extern "C" int katgpu_table_partition(katgpu_table* t, uint32_t n_parts, const u
 }
 
 extern "C" int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* counts, size_t cap, size_t* n_out) {
+    TOUCH(t);
     if (!t || !n_out) return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "katgpu_table_export: use katgpu_table_export_wide;");
     katgpu_ctx* c = t->ctx;
@@ -1636,6 +1692,7 @@ extern "C" int katgpu_table_export(katgpu_table* t, uint64_t* keys, uint64_t* co
 }
 
 extern "C" int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_keys, const uint64_t* dev_counts, size_t n) {
+    TOUCH(t);
     if (!t || (n && (!dev_keys || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "katgpu_table_merge_device");
     katgpu_ctx* c = t->ctx;
@@ -1662,6 +1719,7 @@ extern "C" int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_ke
 }
 
 extern "C" int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, const uint64_t* counts, size_t n) {
+    TOUCH(t);
     if (!t || (n && (!keys || !counts))) return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "katgpu_table_merge_host: use katgpu_table_merge_host_wide;");
     if (!n) return KATGPU_OK;
@@ -1680,6 +1738,7 @@ extern "C" int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, co
 // ------------------------------------------------------------------ wide tables (33 <= k <= 63): records in and out ----
 
 extern "C" int katgpu_table_export_wide(katgpu_table* t, uint64_t* keys_hi, uint64_t* keys_lo, uint64_t* counts, size_t cap, size_t* n_out) {
+    TOUCH(t);
     if (!t || !n_out) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_export_wide is for k > 32 tables (k = %u): use katgpu_table_export", t->d.k);
@@ -1705,6 +1764,7 @@ extern "C" int katgpu_table_export_wide(katgpu_table* t, uint64_t* keys_hi, uint
 }
 
 extern "C" int katgpu_table_partition_wide(katgpu_table* t, uint32_t n_parts, const uint64_t* offsets, uint64_t* dev_hi, uint64_t* dev_lo, uint64_t* dev_counts) {
+    TOUCH(t);
     if (!t || !offsets || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_partition_wide is for k > 32 tables (k = %u): use katgpu_table_partition", t->d.k);
@@ -1725,6 +1785,7 @@ extern "C" int katgpu_table_partition_wide(katgpu_table* t, uint32_t n_parts, co
 }
 
 extern "C" int katgpu_table_merge_device_wide(katgpu_table* t, const uint64_t* dev_hi, const uint64_t* dev_lo, const uint64_t* dev_counts, size_t n) {
+    TOUCH(t);
     if (!t || (n && (!dev_hi || !dev_lo || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_merge_device_wide is for k > 32 tables (k = %u): use katgpu_table_merge_device", t->d.k);
@@ -1748,6 +1809,7 @@ extern "C" int katgpu_table_merge_device_wide(katgpu_table* t, const uint64_t* d
 }
 
 extern "C" int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, const uint64_t* counts, size_t n) {
+    TOUCH(t);
     if (!t || (n && (!keys_hi || !keys_lo || !counts))) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_merge_host_wide is for k > 32 tables (k = %u): use katgpu_table_merge_host", t->d.k);
@@ -1769,6 +1831,7 @@ extern "C" int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* key
 }
 
 extern "C" int katgpu_table_get_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, size_t n, int canonicalise, uint64_t* counts) {
+    TOUCH(t);
     if (!t || (n && (!keys_hi || !keys_lo || !counts))) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_get_wide is for k > 32 tables (k = %u): use katgpu_table_get", t->d.k);
@@ -1811,6 +1874,7 @@ extern "C" int katgpu_table_geometry(const katgpu_table* t, katgpu_geometry* g) 
 }
 
 extern "C" int katgpu_table_extract_sizes(katgpu_table* t, uint32_t n_parts, uint32_t* dev_region_counts, uint64_t* part_sizes) {
+    TOUCH(t);
     if (!t || !dev_region_counts || !part_sizes || n_parts == 0 || n_parts > MAX_EXCHANGE_PARTS) return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
@@ -1833,6 +1897,7 @@ extern "C" int katgpu_table_extract_sizes(katgpu_table* t, uint32_t n_parts, uin
 
 extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint64_t* dev_keys, uint32_t* dev_counts,
                                     uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big) {
+    TOUCH(t);
     if (!t || !dev_region_counts || !dev_keys || !dev_counts || !n_big || n_parts == 0 || n_parts > MAX_EXCHANGE_PARTS || (big_cap && (!big_keys || !big_counts)))
         return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "the multi-GPU exchange");
@@ -1888,6 +1953,7 @@ extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uin
 }
 
 extern "C" int katgpu_table_clear(katgpu_table* t) {
+    TOUCH(t);
     if (!t) return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
@@ -1924,6 +1990,7 @@ static int merge_direct32(katgpu_table* t, const uint64_t* dev_keys, const uint3
 }
 
 extern "C" int katgpu_table_merge_device32(katgpu_table* t, const uint64_t* dev_keys, const uint32_t* dev_counts, size_t n) {
+    TOUCH(t);
     if (!t || (n && (!dev_keys || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "the multi-GPU exchange");
     HIPCHK(t->ctx, hipSetDevice(t->ctx->device));
@@ -1933,6 +2000,7 @@ extern "C" int katgpu_table_merge_device32(katgpu_table* t, const uint64_t* dev_
 static const bool g_no_merge_apply = hook("KATGPU_NO_MERGE_APPLY") != nullptr;    // A/B switch + tests: every source through the direct path
 
 extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source* src) {
+    TOUCH(t);
     if (!t || !src || n_src == 0 || g_lo > g_hi) return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
@@ -2030,6 +2098,7 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
 static int reducer_grid(katgpu_ctx* c, uint64_t slots, int blocks_per_cu) { return grid_for(c, slots, 256, blocks_per_cu); }
 
 extern "C" int katgpu_hist(katgpu_table* t, uint64_t base, uint64_t ceil_, uint64_t inc, uint64_t* out, size_t nb) {
+    TOUCH(t);
     if (!t || !out || nb == 0 || inc == 0 || ceil_ < base || nb != ceil_ + 1 - base) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2051,6 +2120,7 @@ extern "C" int katgpu_hist(katgpu_table* t, uint64_t base, uint64_t ceil_, uint6
 }
 
 extern "C" int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, uint64_t* out) {
+    TOUCH(t);
     if (!t || !out) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2082,6 +2152,8 @@ extern "C" int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, 
 
 extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int canon2, double d1_scale, double d2_scale,
                            uint32_t d1_bins, uint32_t d2_bins, uint64_t* main_mx, uint64_t counters[13], uint64_t* spectra) {
+    TOUCH(t1);
+    TOUCH(t2);
     (void)canon1;
     if (!t1 || !t2 || !main_mx || !counters || !spectra || d1_bins == 0 || d2_bins == 0) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t1->ctx;
@@ -2166,6 +2238,7 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
 extern "C" int katgpu_comp3(katgpu_table* t1, katgpu_table* t2, katgpu_table* t3, int canon1, int canon2, int canon3,
                             double d1_scale, double d2_scale, uint32_t d1_bins, uint32_t d2_bins, uint64_t* main_mx,
                             uint64_t* ends_mx, uint64_t* middle_mx, uint64_t* mixed_mx, uint64_t counters[13], uint64_t* spectra) {
+    TOUCH(t3);
     if (!t3 || !ends_mx || !middle_mx || !mixed_mx) return KATGPU_ERR_INVALID_ARG;
     int rc = katgpu_comp(t1, t2, canon1, canon2, d1_scale, d2_scale, d1_bins, d2_bins, main_mx, counters, spectra);
     if (rc) return rc;

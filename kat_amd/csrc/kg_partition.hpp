@@ -798,7 +798,8 @@ constexpr int AP2_LANE_PROBES = 12;                           // probes a queue 
 constexpr uint64_t AP2_SEGMENT = 0x7FF00000ULL;               // k-mers per walk: < 2^31
 
 template <int BLOCK, int KP /* 16-byte key loads per lane that cover a region */, int U, int NR, int HB /* high bytes of an item */, bool STAMP = false, bool INLINE_CLAIM = false, bool DYN = true,
-          int QCAP = AP2_QCAP /* queue entries per wave: what the region leaves of the LDS */>
+          int QCAP = AP2_QCAP /* queue entries per wave: what the region leaves of the LDS */,
+          bool INIT = false /* a table whose slots have never been written (katgpu.hip "lazy tables"): regions start EMPTY in LDS without a load, and EVERY region of the pass is visited and written back */>
 __global__ void __launch_bounds__(BLOCK)
 k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
             uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n,
@@ -828,11 +829,19 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
     };
     auto next_region = [&](uint32_t from) {
         uint32_t r = from;
+        if (INIT) return r;                                     // (regions without k-mers are written too)
         while (r < r_hi && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
         return r;
     };
     auto prefetch = [&](uint32_t r) {
         const uint64_t base = (uint64_t)r * S;
+        if (INIT) {
+#pragma unroll
+            for (int u = 0; u < KP; ++u) kq[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+            for (int u = 0; u < CP; ++u) cq[u] = u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; kq[u] = *reinterpret_cast<const u32x4*>(t.keys + base + (i < S ? i : 0)); }    // clamped, unconditional: stays in registers
 #pragma unroll
