@@ -1,8 +1,14 @@
 // kg_device.hpp -- device-side building blocks for gfx950: packed k-mer arithmetic and the HBM-resident
 // open-addressed count table.  CDNA4 only (wave64); no portability layer.
 //
-// Table layout ("KV12"): keys[cap] (u64, 0xFFFF..F = empty) and counts[cap] (u32) as two separate
-// arrays so that the slot scan of the reducers is two perfectly coalesced streams (8 B and 4 B per lane).
+// Two slot layouts for one-word k-mers (k <= 32):
+//  "P8" (packed, DevTable::cbits != 0): ONE 64-bit word per slot = (remainder << cbits) | count, 0 = empty.  The placement hash
+//       (below) is one to one, so the slot position (its region) already says the hash's digits and the slot keeps only the
+//       remainder -- Jellyfish's quotienting (JF/include/jellyfish/large_hash_array.hpp:169-171) -- and what is left of the word
+//       counts.  8 bytes per slot to sweep, scan and join instead of 12; a hit is one 64-bit add.  Used whenever the remainder
+//       leaves at least PACK_MIN_CBITS count bits (tables of >= 2^(2k-44) regions: every table of size).
+//  "KV12": keys[cap] (u64 k-mer, 0xFFFF..F = empty) and counts[cap] (u32) as two separate arrays (two coalesced streams for
+//       the slot scans).  Small tables, k = 32, and the two-word tables of k > 32 (a third array).
 // Counts are exact to 64 bits: whatever does not fit the 32-bit slot counter is chained into a small side table
 // (key -> extra amount), the same idea as Jellyfish's "large" entries
 // (deps/jellyfish-2.2.0/include/jellyfish/large_hash_array.hpp:668-700): count = counts[slot] + extra[key].  and
@@ -16,7 +22,9 @@
 namespace kg {
 
 constexpr uint64_t EMPTY = ~0ULL;
-constexpr uint32_t OVF_CAP = 4096;       // side table for amounts beyond 32 bits; a key needs > 2.1e9 hits to enter
+constexpr uint32_t OVF_CAP = 1u << 16;   // side table for amounts beyond the slot counter (32 bits, or cbits of a packed slot)
+constexpr uint32_t PACK_MIN_CBITS = 20;  // a packed slot counts to at least 2^20 - 1 in place (what is beyond goes to the side table)
+constexpr int MAX_PARTS = 1024;          // region digits per level of the partitioned counter (one lane per bucket in its scans): p1, p2 <= MAX_PARTS
 constexpr uint32_t REGION_SLOTS = 8192;  // default slots per region: 96 KB of LDS (8 B key + 4 B count) in the apply kernel
 
 // ctrs[] layout (u64 each)
@@ -26,14 +34,12 @@ constexpr int CTR_ONES = 64;       // count of the all-ones key
 constexpr int CTR_OVF_USED = 65;   // entries in the carry table
 constexpr int CTR_FULL = 66;       // != 0: an insert ran out of probes / carry table full
 constexpr int CTR_SCRATCH = 67;    // cursors / scratch for export & partition (8 words)
-constexpr int CTR_FAIL_N = 76;     // k-mers parked in fail_buf: their region was full (minimizer-region tables, below)
 constexpr int CTR_WORDS = 80;
-constexpr uint32_t FAIL_CAP = 1u << 20;   // entries of a table's fail list
 
 struct DevTable {
-    uint64_t* keys;
+    uint64_t* keys;        // KV12: the k-mer (EMPTY = free).  P8: (remainder << cbits) | count (0 = free)
     uint64_t* keys_b;      // wide tables only (k > 32, see "wide keys" below): the second key word per slot; nullptr otherwise
-    uint32_t* counts;
+    uint32_t* counts;      // nullptr for packed tables
     uint64_t cap;          // == n_regions * region_slots
     uint32_t n_regions;    // a k-mer hashes to one region and probes (linearly, wrapping) only inside it, so a region
     uint32_t region_slots; // is a self-contained little table that the partitioned counter can hold in LDS
@@ -43,9 +49,10 @@ struct DevTable {
     uint64_t* ctrs;       // CTR_WORDS
     uint32_t k;
     uint32_t canonical;
-    uint32_t mz;          // region keyed by the k-mer's minimizer instead of its hash ("minimizer regions" below); one-word tables only
     uint32_t n1, l2;      // one-word tables ("placement" below): bits of the level-1 remainder (from k and p1); p2 == 1 << l2
-    uint64_t* fail_buf;   // mz tables: [FAIL_CAP keys | FAIL_CAP amounts] of inserts that found their region full (the host grows and retries)
+    uint32_t cbits;       // packed tables: bits of the in-slot counter (64 - remainder bits); 0: KV12
+    const uint64_t* base1;// packed tables: base1[d] = place_base1(d) for d in [0, p1]: what decoding a slot into its k-mer needs
+    double inv_slots;     // packed tables: 1.0 / region_slots (slot index -> region without an integer division)
 };
 
 // ---- packed k-mer arithmetic (first base in the MSBs, A=0 C=1 G=2 T=3) ----
@@ -167,86 +174,41 @@ __device__ __host__ __forceinline__ uint32_t place_offset(uint64_t rem, const Pl
     return (uint32_t)(((uint64_t)top * S) >> 32);
 }
 
-// ---- minimizer regions (DevTable::mz) ----
-// The super-k-mer counter (kg_superkmer.hpp) partitions RUNS of consecutive k-mers, not k-mers, so every k-mer of a run must land
-// in one region: the region is a function of the k-mer's MINIMIZER -- the m-mer (m = min(k, 16)) of the k-mer whose canonical
-// form hashes lowest.  Both strands of a k-mer see the same canonical m-mers, so a k-mer and its reverse complement share the
-// region whether or not the table is canonical.  Inside the region a k-mer sits where its own hash puts it, as in any table.
-constexpr uint32_t MZ_M = 16;
-__device__ __forceinline__ uint32_t mz_order(uint32_t x) {        // lowbias32: a bijection on 32 bits; the minimizer order
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ uint32_t mz_mix(uint32_t x) {          // triple32: region digits come from this second mix of the winner
-    x ^= x >> 17; x *= 0xed5ad4bbU; x ^= x >> 11; x *= 0xac4c1b51U; x ^= x >> 15; x *= 0x31848babU; x ^= x >> 14;
-    return x;
-}
-// order value of the 2m-bit m-mer mm (first base in the MSBs of its 2m bits)
-__device__ __forceinline__ uint32_t mz_value(uint32_t mm, uint32_t m) {
-    uint32_t r = __brev(mm);
-    r = ((r >> 1) & 0x55555555U) | ((r & 0x55555555U) << 1);
-    r = ~r >> (32 - 2 * m);
-    return mz_order(r < mm ? r : mm);
-}
-__device__ __forceinline__ void mz_digits(uint32_t omin, uint32_t p1, uint32_t p2, uint32_t& b1, uint32_t& b2) {
-    const uint32_t h = mz_mix(omin);
-    b1 = __umulhi(h, p1);
-    b2 = __umulhi(mz_order(h ^ 0x5bd1e995U), p2);
-}
-// region of one packed k-mer: the slow form (w = k - m + 1 m-mers), for the direct path, lookups, regrow and merge
-__device__ __forceinline__ uint32_t region_mz(uint64_t key, uint32_t k, uint32_t p1, uint32_t p2) {
-    const uint32_t m = k < MZ_M ? k : MZ_M, w = k - m + 1;
-    const uint64_t top = key << (64 - 2 * k);                        // first base in bit 63
-    uint32_t omin = 0xFFFFFFFFU;
-    for (uint32_t i = 0; i < w; ++i) {
-        const uint32_t mm = (uint32_t)((top << (2 * i)) >> (64 - 2 * m));
-        const uint32_t o = mz_value(mm, m);
-        omin = o < omin ? o : omin;
-    }
-    uint32_t b1, b2;
-    mz_digits(omin, p1, p2, b1, b2);
-    return b1 * p2 + b2;
-}
-
 struct Probe {
     uint64_t base;   // first slot of the region
     uint32_t s;      // current offset inside the region
     uint32_t S;
+    uint64_t rem;    // the placement hash's remainder: what a packed slot holds of the k-mer
     __device__ __forceinline__ uint64_t pos() const { return base + s; }
     __device__ __forceinline__ void next() { s = s + 1 == S ? 0 : s + 1; }
 };
 // home offset of a k-mer inside its region (kernels that are handed the region -- the applies, the merges -- need only this)
 __device__ __forceinline__ uint32_t home_offset(const uint64_t key, const DevTable& t) {
-    if (t.mz) return offset_of_hash(mix64(key), t.region_slots);
     const Place pl = place_make(t.k, t.p1, t.n1, t.l2);
     return place_offset(place_hash(key, pl).rem, pl, t.region_slots);
 }
 // the same for kernels that go through one region's k-mers: the level-1 digit is the region's, so its base is computed once
-struct RegionPlace { Place pl; uint64_t base1; uint32_t S, mz; };
+struct RegionPlace { Place pl; uint64_t base1, d2_hi; uint32_t S; };
 __device__ __forceinline__ RegionPlace region_place(const DevTable& t, uint32_t region) {
     RegionPlace rp;
     rp.pl = place_make(t.k, t.p1, t.n1, t.l2);
-    rp.base1 = t.mz ? 0 : place_base1(region >> t.l2, rp.pl.n, rp.pl.p1);
-    rp.S = t.region_slots; rp.mz = t.mz;
+    rp.base1 = place_base1(region >> t.l2, rp.pl.n, rp.pl.p1);
+    rp.d2_hi = rp.pl.rb < 64 ? (uint64_t)(region & (t.p2 - 1)) << rp.pl.rb : 0ULL;
+    rp.S = t.region_slots;
     return rp;
 }
-__device__ __forceinline__ uint32_t home_offset_in(const uint64_t key, const RegionPlace& rp) {
-    if (rp.mz) return offset_of_hash(mix64(key), rp.S);
-    return place_offset(place_rem(place_stage2(place_stage1(key, rp.pl) - rp.base1, rp.pl), rp.pl), rp.pl, rp.S);
-}
+__device__ __forceinline__ uint64_t rem_in(const uint64_t key, const RegionPlace& rp) { return place_rem(place_stage2(place_stage1(key, rp.pl) - rp.base1, rp.pl), rp.pl); }
+__device__ __forceinline__ uint32_t home_offset_in(const uint64_t key, const RegionPlace& rp) { return place_offset(rem_in(key, rp), rp.pl, rp.S); }
+__device__ __forceinline__ uint64_t key_in(const uint64_t rem, const RegionPlace& rp) { return place_key(rp.base1, rp.d2_hi | rem, rp.pl); }
 __device__ __forceinline__ Probe probe_start(const uint64_t key, const DevTable& t) {
     Probe p;
     const uint32_t region_slots = t.region_slots;
     p.S = region_slots;
-    if (t.mz) {
-        p.base = (uint64_t)region_mz(key, t.k, t.p1, t.p2) * region_slots;
-        p.s = offset_of_hash(mix64(key), region_slots);
-        return p;
-    }
     const Place pl = place_make(t.k, t.p1, t.n1, t.l2);
     const Placed h = place_hash(key, pl);
     p.base = (uint64_t)((h.d1 << t.l2) | h.d2) * region_slots;
     p.s = place_offset(h.rem, pl, region_slots);
+    p.rem = h.rem;
     return p;
 }
 // owner part of a k-mer for the multi-GPU merge: a second, independent mix of the CANONICAL form
@@ -256,6 +218,8 @@ __device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t k, uint32_t 
 }
 
 // ---- carry side table ----
+// keyed by the k-mer (KV12 one-word tables) or by the SLOT (packed and wide tables: slots never move within a table's life, and a
+// regrow re-adds full counts)
 __device__ inline void ovf_add(const DevTable& t, uint64_t key, uint64_t hi /* extra amount */) {
     uint32_t p = (uint32_t)(mix64(key) >> 40) & (OVF_CAP - 1);
     for (uint32_t i = 0; i < OVF_CAP; ++i) {
@@ -276,32 +240,105 @@ __device__ inline uint64_t ovf_get(const DevTable& t, uint64_t key) {
     }
     return 0;
 }
+__device__ __forceinline__ bool ovf_by_slot(const DevTable& t) { return t.keys_b != nullptr || t.cbits != 0; }
 
-// full 64-bit count of an occupied slot (the side table is keyed by the k-mer; for wide tables, whose k-mer is two words, by
-// the slot -- slots never move within a table's life, and a regrow re-adds full counts)
-__device__ __forceinline__ uint64_t slot_count(const DevTable& t, uint64_t pos, uint64_t key, uint32_t n_ovf) {
-    uint64_t c = t.counts[pos];
-    if (n_ovf) c += ovf_get(t, t.keys_b ? pos : key);
-    return c;
+// ---- packed slots ----
+__device__ __host__ __forceinline__ uint64_t pk_cmask(uint32_t cbits) { return (1ULL << cbits) - 1; }
+__device__ __host__ __forceinline__ uint64_t pk_half(uint32_t cbits) { return 1ULL << (cbits - 1); }
+__device__ __forceinline__ uint64_t pk_count(uint64_t w, uint32_t cbits) { return w & pk_cmask(cbits); }
+__device__ __forceinline__ uint64_t pk_rem(uint64_t w, uint32_t cbits) { return w >> cbits; }
+__device__ __forceinline__ bool pk_holds(uint64_t w, uint64_t rem, uint32_t cbits) { return w != 0 && (w >> cbits) == rem; }
+// region of a slot index: pos / region_slots through the reciprocal (pos < 2^40, region_slots < 2^14: one correction step suffices)
+__device__ __forceinline__ uint32_t region_of_pos(const DevTable& t, uint64_t pos) {
+    uint32_t r = (uint32_t)((double)pos * t.inv_slots);
+    if ((uint64_t)r * t.region_slots > pos) --r;
+    else if ((uint64_t)(r + 1) * t.region_slots <= pos) ++r;
+    return r;
+}
+// the k-mer a packed slot holds (slow form: any slot; the region kernels use key_in)
+__device__ __forceinline__ uint64_t pk_key(const DevTable& t, uint64_t pos, uint64_t w) {
+    const Place pl = place_make(t.k, t.p1, t.n1, t.l2);
+    const uint32_t region = region_of_pos(t, pos);
+    const uint64_t d2_hi = pl.rb < 64 ? (uint64_t)(region & (t.p2 - 1)) << pl.rb : 0ULL;
+    return place_key(t.base1[region >> t.l2], d2_hi | (w >> t.cbits), pl);
+}
+// amount = q * half + r (r < half): the slot takes r (and, should that carry it past its field, gives `half` back), the side table q * half
+__device__ __forceinline__ void pk_split(uint64_t amount, uint32_t cbits, uint64_t& q, uint64_t& r) { q = amount >> (cbits - 1); r = amount & (pk_half(cbits) - 1); }
+
+// One slot of a one-word table, whatever its layout: occupied?, the k-mer, the in-slot count (the side table's part is slot_count's)
+struct SlotView { bool occ; uint64_t key; uint64_t cnt; };
+__device__ __forceinline__ SlotView slot_view(const DevTable& t, uint64_t pos) {
+    SlotView v;
+    const uint64_t w = t.keys[pos];
+    if (t.cbits) { v.occ = w != 0; v.cnt = pk_count(w, t.cbits); v.key = v.occ ? pk_key(t, pos, w) : EMPTY; }
+    else { v.occ = w != EMPTY; v.key = w; v.cnt = v.occ ? t.counts[pos] : 0; }
+    return v;
+}
+// ... of a region the caller walks (rp = region_place of that region)
+__device__ __forceinline__ SlotView slot_view_in(const DevTable& t, const RegionPlace& rp, uint64_t pos) {
+    SlotView v;
+    const uint64_t w = t.keys[pos];
+    if (t.cbits) { v.occ = w != 0; v.cnt = pk_count(w, t.cbits); v.key = v.occ ? key_in(pk_rem(w, t.cbits), rp) : EMPTY; }
+    else { v.occ = w != EMPTY; v.key = w; v.cnt = v.occ ? t.counts[pos] : 0; }
+    return v;
 }
 
-// An insert that walked its whole region without finding room.  Hash-placed regions never fill (the host keeps the table under
-// its fill limit and the hash spreads k-mers evenly); a minimizer-keyed region can, when one minimizer owns more distinct k-mers
-// than the average region holds.  Such k-mers are parked; the host grows the table and adds them again (katgpu.hip: retry_failed).
-__device__ inline bool table_park(const DevTable& t, uint64_t key, uint64_t amount) {
-    if (t.fail_buf) {
-        const unsigned long long at = atomicAdd((unsigned long long*)&t.ctrs[CTR_FAIL_N], 1ULL);
-        if (at < FAIL_CAP) { t.fail_buf[at] = key; t.fail_buf[FAIL_CAP + at] = amount; return false; }
-    }
+// full 64-bit count of an occupied slot: in-slot count + the side table's amount
+__device__ __forceinline__ uint64_t slot_total(const DevTable& t, uint64_t pos, uint64_t key, uint64_t in_slot, uint32_t n_ovf) {
+    uint64_t c = in_slot;
+    if (n_ovf) c += ovf_get(t, ovf_by_slot(t) ? pos : key);
+    return c;
+}
+__device__ __forceinline__ uint64_t slot_count(const DevTable& t, uint64_t pos, uint64_t key, uint32_t n_ovf) {      // KV12 and wide tables
+    return slot_total(t, pos, key, t.counts[pos], n_ovf);
+}
+
+// An insert that walked its whole region without finding room: the host keeps every table under its fill limit and the hash
+// spreads k-mers evenly, so this is "Hash full" (reported through CTR_FULL).
+__device__ inline bool table_full(const DevTable& t) {
     atomicOr((unsigned long long*)&t.ctrs[CTR_FULL], 1ULL);
     return false;
 }
 
+// insert-or-add into a packed table: claim and add are ONE compare-and-swap on the slot word (0 -> remainder | count).  The
+// direct path is checked throughout (a CAS loop): it serves small inputs, spill lists, merges and regrows.
+__device__ inline bool table_add_pk(const DevTable& t, uint64_t key, uint64_t amount, uint32_t& new_distinct) {
+    const uint32_t cb = t.cbits;
+    const uint64_t cmask = pk_cmask(cb), half = pk_half(cb);
+    Probe pr = probe_start(key, t);
+    uint64_t q, r;
+    pk_split(amount, cb, q, r);
+    for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
+        unsigned long long* slot = (unsigned long long*)&t.keys[pr.pos()];
+        unsigned long long w = *slot;
+        if (w == 0) {                                              // claim with the in-slot part of the amount (never 0: an occupied slot counts >= 1)
+            const uint64_t in = r ? r : half, qq = r ? q : q - 1;
+            w = atomicCAS(slot, 0ULL, (unsigned long long)((pr.rem << cb) | in));
+            if (w == 0) { ++new_distinct; if (qq) ovf_add(t, pr.pos(), qq * half); return true; }
+        }
+        if ((w >> cb) != pr.rem) continue;
+        if (r) {
+            for (;;) {
+                uint64_t c = (w & cmask) + r, qq = q;
+                if (c > cmask) { c -= half; ++qq; }                // (c >= half >= 1: the slot stays occupied)
+                const unsigned long long got = atomicCAS(slot, w, (unsigned long long)((w & ~cmask) | c));
+                if (got == w) { q = qq; break; }
+                w = got;
+            }
+        }
+        if (q) ovf_add(t, pr.pos(), q * half);
+        return true;
+    }
+    return table_full(t);
+}
+
 // ---- insert-or-add: the replacement for array_base::add (large_hash_array.hpp:298-302) ----
-// Claim = CAS on the key word; add = returning 32-bit atomic add whose carry is chained.  The first look at a
+// KV12: claim = CAS on the key word; add = returning 32-bit atomic add whose carry is chained.  The first look at a
 // slot is a plain load: keys are write-once, so a stale "empty" only costs the CAS we would have issued anyway.
 // new_distinct is accumulated per lane and flushed once per wave (one striped atomic instead of one per claim).
 __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint64_t amount, uint32_t& new_distinct) {
+    if (amount == 0) return true;                                  // (a stored k-mer always has a count: comp's pass forms rely on it)
+    if (t.cbits) return table_add_pk(t, key, amount, new_distinct);
     if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)amount); return true; }
     Probe pr = probe_start(key, t);
     for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
@@ -320,15 +357,17 @@ __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint6
             return true;
         }
     }
-    return table_park(t, key, amount);
+    return table_full(t);
 }
 
 // +1 on the hot path of K1: same claim protocol, but the counter add is a NO-RETURN atomic, so a lane never waits for
 // it (measured on MI355X: load + returning add chain 12-15 G k-mers/s, load + no-return add 20.7 G/s; the L2 atomic
 // units saturate at ~22 G adds/s).  Without the returned value a 32-bit wrap cannot be seen here; the host instead
 // guarantees it cannot happen: before the adds launched since the last k_sweep could lift any counter past 2^32-1 it
-// runs k_sweep, which moves 2^31 from every counter >= 2^31 into the side table (katgpu.hip: maybe_sweep).
+// runs k_sweep, which moves 2^31 from every counter >= 2^31 into the side table (kg_count.hip: maybe_sweep).
+// (Packed tables take the checked add: their in-slot counter may be as narrow as 20 bits.)
 __device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint32_t& new_distinct) {
+    if (t.cbits) return table_add_pk(t, key, 1ULL, new_distinct);
     if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], 1ULL); return true; }
     Probe pr = probe_start(key, t);
     for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
@@ -343,18 +382,23 @@ __device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint3
             return true;
         }
     }
-    return table_park(t, key, 1ULL);
+    return table_full(t);
 }
 
 // ---- lookup: get_val_for_key (large_hash_array.hpp:358-376) on an immutable table ----
 __device__ __forceinline__ uint64_t table_get(const DevTable& t, uint64_t key, uint32_t n_ovf) {
-    if (key == EMPTY) return t.ctrs[CTR_ONES];
+    if (!t.cbits && key == EMPTY) return t.ctrs[CTR_ONES];
     Probe pr = probe_start(key, t);
     for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
         const uint64_t pos = pr.pos();
-        uint64_t cur = t.keys[pos];
-        if (cur == key) return slot_count(t, pos, key, n_ovf);
-        if (cur == EMPTY) return 0;
+        const uint64_t cur = t.keys[pos];
+        if (t.cbits) {
+            if (cur == 0) return 0;
+            if ((cur >> t.cbits) == pr.rem) return slot_total(t, pos, key, pk_count(cur, t.cbits), n_ovf);
+        } else {
+            if (cur == key) return slot_count(t, pos, key, n_ovf);
+            if (cur == EMPTY) return 0;
+        }
     }
     return 0;
 }

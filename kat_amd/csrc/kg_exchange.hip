@@ -1,0 +1,247 @@
+// kg_exchange.hip -- the device side of the multi-GPU exchange: region-ordered extraction of a table's records by owner, the
+// in-place merge of received runs region by region in LDS, and the direct paths beside them (kg_comm.hip drives these over RCCL;
+// kat_amd/dist.py drives them over torch.distributed).
+#include "kg_host.hpp"
+#include "kg_kernels.hpp"
+
+// ------------------------------------------------------------------ region-ordered exchange -----------
+
+extern "C" int katgpu_place_keys(uint32_t k, uint32_t p1, uint32_t l2, const uint64_t* keys, size_t n, uint32_t* d1, uint32_t* d2, uint64_t* rem,
+                                 uint64_t* back, uint32_t* rem_bits) {
+    if (k < 1 || k > 32 || p1 < 1 || p1 > MAX_PARTS || l2 > 10 || (n && (!keys || !d1 || !d2 || !rem || !back))) return KATGPU_ERR_INVALID_ARG;
+    const Place pl = place_make(k, p1, place_n1(k, p1), l2);
+    if (rem_bits) *rem_bits = pl.rb;
+    for (size_t i = 0; i < n; ++i) {
+        const Placed h = place_hash(keys[i], pl);
+        d1[i] = h.d1; d2[i] = h.d2; rem[i] = h.rem;
+        back[i] = place_key(place_base1(h.d1, pl.n, pl.p1), (pl.rb < 64 ? (uint64_t)h.d2 << pl.rb : 0ULL) | h.rem, pl);
+    }
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_geometry(const katgpu_table* t, katgpu_geometry* g) {
+    if (!t || !g) return KATGPU_ERR_INVALID_ARG;
+    if (t->d.keys_b) return fail(t->ctx, KATGPU_ERR_K, "the multi-GPU exchange is not available for k > 32 (k = %u)", t->d.k);
+    g->k = t->d.k; g->canonical = t->d.canonical; g->n_regions = t->d.n_regions; g->region_slots = t->d.region_slots;
+    g->p1 = t->d.p1; g->p2 = t->d.p2; g->capacity = t->d.cap;
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_extract_sizes(katgpu_table* t, uint32_t n_parts, uint32_t* dev_region_counts, uint64_t* part_sizes) {
+    if (!t || !dev_region_counts || !part_sizes || n_parts == 0 || n_parts > MAX_EXCHANGE_PARTS) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    unsigned long long* d_tot = nullptr;
+    HIPCHK(c, hipMalloc(&d_tot, n_parts * 8));
+    {
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
+        hipLaunchKernelGGL(k_extract_count, dim3(std::min<uint32_t>(t->d.n_regions, (uint32_t)c->n_cu * 8)), dim3(EXTRACT_BLOCK), 0, c->stream, t->d, n_parts, dev_region_counts);
+        hipLaunchKernelGGL(k_rows_scan, dim3(n_parts), dim3(1024), 0, c->stream, (const uint32_t*)dev_region_counts, t->d.n_regions, (uint64_t)t->d.n_regions,
+                           (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, 0, d_tot);
+    }
+    hipMemcpyAsync(part_sizes, d_tot, n_parts * 8, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d_tot);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint64_t* dev_keys, uint32_t* dev_counts,
+                                    uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big) {
+    if (!t || !dev_region_counts || !dev_keys || !dev_counts || !n_big || n_parts == 0 || n_parts > MAX_EXCHANGE_PARTS || (big_cap && (!big_keys || !big_counts)))
+        return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    const uint32_t R = t->d.n_regions;
+    const uint32_t dev_big_cap = OVF_CAP + 8;
+    uint8_t* tmp = nullptr;          // [off u64 n_parts*R | totals n_parts | base n_parts | big_n | big keys | big counts]
+    const size_t off_bytes = (size_t)n_parts * R * 8;
+    const size_t bytes = off_bytes + (size_t)n_parts * 16 + 8 + (size_t)dev_big_cap * 16;
+    HIPCHK(c, hipMalloc((void**)&tmp, bytes));
+    uint64_t* d_off = (uint64_t*)tmp;
+    unsigned long long* d_tot = (unsigned long long*)(tmp + off_bytes);
+    uint64_t* d_base = (uint64_t*)(d_tot + n_parts);
+    unsigned long long* d_bign = (unsigned long long*)(d_base + n_parts);
+    uint64_t* d_bk = (uint64_t*)(d_bign + 1);
+    uint64_t* d_bc = d_bk + dev_big_cap;
+    std::vector<uint64_t> tot(n_parts), base(n_parts);
+    hipError_t e = hipSuccess;
+    {
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
+        hipLaunchKernelGGL(k_rows_scan, dim3(n_parts), dim3(1024), 0, c->stream, dev_region_counts, R, (uint64_t)R, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, 0, d_tot);
+        hipMemcpyAsync(tot.data(), d_tot, n_parts * 8, hipMemcpyDeviceToHost, c->stream);
+        e = hipStreamSynchronize(c->stream);
+        uint64_t run = 0;
+        for (uint32_t p = 0; p < n_parts; ++p) { base[p] = run; run += tot[p]; }
+        hipMemcpyAsync(d_base, base.data(), n_parts * 8, hipMemcpyHostToDevice, c->stream);
+        hipMemsetAsync(d_bign, 0, 8, c->stream);
+        hipLaunchKernelGGL(k_rows_scan, dim3(n_parts), dim3(1024), 0, c->stream, dev_region_counts, R, (uint64_t)R, (const uint64_t*)d_base, d_off, (uint64_t)R, 0, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_extract_write, dim3(std::min<uint32_t>(R, (uint32_t)c->n_cu * 8)), dim3(EXTRACT_BLOCK), 0, c->stream, t->d, t->n_ovf, n_parts, (const uint64_t*)d_off,
+                           dev_keys, dev_counts, d_bk, d_bc, d_bign, dev_big_cap);
+    }
+    unsigned long long nb = 0;
+    hipMemcpyAsync(&nb, d_bign, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    uint32_t out = 0;
+    rc = KATGPU_OK;
+    if (e == hipSuccess) {
+        if (nb > dev_big_cap) rc = fail(c, KATGPU_ERR_DEVICE, "extract: %llu counts above 32 bits", nb);
+        else {
+            std::vector<uint64_t> hk(nb), hc(nb);
+            if (nb) { e = hipMemcpy(hk.data(), d_bk, nb * 8, hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemcpy(hc.data(), d_bc, nb * 8, hipMemcpyDeviceToHost); }
+            if (t->ones) { hk.push_back(~0ULL); hc.push_back(t->ones); }          // the all-ones key has no slot (kg_device.hpp)
+            if (hk.size() > big_cap) rc = fail(c, KATGPU_ERR_INVALID_ARG, "extract: big list needs %zu entries", hk.size());
+            else { for (size_t i = 0; i < hk.size(); ++i) { big_keys[i] = hk[i]; big_counts[i] = hc[i]; } out = (uint32_t)hk.size(); }
+        }
+    }
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
+    *n_big = out;
+    return rc;
+}
+
+extern "C" int katgpu_table_clear(katgpu_table* t) {
+    if (!t) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevTable& d = t->d;
+    HIPCHK(c, hipMemsetAsync(d.keys, d.cbits ? 0 : 0xFF, d.cap * sizeof(uint64_t), c->stream));
+    if (d.counts) HIPCHK(c, hipMemsetAsync(d.counts, 0, d.cap * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(d.ovf_hi, 0, OVF_CAP * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(d.ctrs, 0, CTR_WORDS * sizeof(uint64_t), c->stream));
+    t->n_ovf = 0; t->distinct = 0; t->ones = 0; t->count_bound = 0; t->unchecked_adds = 0; t->carry_n = 0;
+    return KATGPU_OK;
+}
+
+static int merge_direct32(katgpu_table* t, const uint64_t* dev_keys, const uint32_t* dev_counts, size_t n) {
+    katgpu_ctx* c = t->ctx;
+    size_t pos = 0;
+    while (pos < n) {
+        int rc = refresh_counters(t); if (rc) return rc;
+        uint64_t room = (uint64_t)(load_limit(t->d) * (double)t->d.cap) > t->distinct ? (uint64_t)(load_limit(t->d) * (double)t->d.cap) - t->distinct : 0;
+        uint64_t want = n - pos;
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
+            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
+            if (rc) return rc;
+            continue;
+        }
+        const uint64_t take = std::min(want, room);
+        t->count_bound = 0xFFFFFFFFULL;
+        ScopedTimer tm(c, KATGPU_K_MERGE, take);
+        hipLaunchKernelGGL(k_merge32, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->d, dev_keys + pos, dev_counts + pos, (uint64_t)take);
+        pos += take;
+    }
+    return refresh_counters(t);
+}
+
+extern "C" int katgpu_table_merge_device32(katgpu_table* t, const uint64_t* dev_keys, const uint32_t* dev_counts, size_t n) {
+    if (!t || (n && (!dev_keys || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
+    HIPCHK(t->ctx, hipSetDevice(t->ctx->device));
+    return merge_direct32(t, dev_keys, dev_counts, n);
+}
+
+static const bool g_no_merge_apply = hook("KATGPU_NO_MERGE_APPLY") != nullptr;    // A/B switch + tests: every source through the direct path
+
+extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source* src) {
+    if (!t || !src || n_src == 0 || g_lo > g_hi) return KATGPU_ERR_INVALID_ARG;
+    NARROW_ONLY(t, "the multi-GPU exchange");
+    katgpu_ctx* c = t->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = refresh_counters(t); if (rc) return rc;
+    if (!c->merge_attr_set) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_apply<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_apply<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        c->merge_attr_set = true;
+    }
+    const size_t slot_bytes = t->d.cbits ? 8 : 12;
+    // sources ordered by this table's regions go through LDS; the rest (another grid, or the table has changed its grid) directly
+    std::vector<uint32_t> aligned, direct;
+    for (uint32_t i = 0; i < n_src; ++i) {
+        if (src[i].n_records == 0) continue;
+        if (!src[i].dev_keys || !src[i].dev_counts) return KATGPU_ERR_INVALID_ARG;
+        const bool ok = !g_no_merge_apply && src[i].dev_region_counts && src[i].p1 == t->d.p1 && src[i].p2 == t->d.p2 && g_hi <= t->d.n_regions &&
+                        (size_t)t->d.region_slots * slot_bytes <= 150 * 1024;
+        (ok ? aligned : direct).push_back(i);
+    }
+    const uint32_t n_reg = g_hi - g_lo;
+    for (size_t a0 = 0; a0 < aligned.size() && n_reg; a0 += MAX_MERGE_SRC) {
+        const uint32_t na = (uint32_t)std::min<size_t>(MAX_MERGE_SRC, aligned.size() - a0);
+        uint8_t* tmp = nullptr;        // [off: na * (n_reg + 1) u64 | deferred: n_reg u32 | n_deferred]
+        const size_t off_bytes = (size_t)na * (n_reg + 1) * 8;
+        HIPCHK(c, hipMalloc((void**)&tmp, off_bytes + (size_t)n_reg * 4 + 8));
+        uint64_t* d_off = (uint64_t*)tmp;
+        uint32_t* d_def = (uint32_t*)(tmp + off_bytes);
+        unsigned long long* d_ndef = (unsigned long long*)(tmp + off_bytes + (size_t)n_reg * 4);
+        MergeSrcs ms{};
+        ms.n = na;
+        uint64_t records = 0;
+        for (uint32_t q = 0; q < na; ++q) {
+            const katgpu_merge_source& s = src[aligned[a0 + q]];
+            hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, c->stream, s.dev_region_counts, n_reg, (uint64_t)n_reg, (const uint64_t*)nullptr,
+                               d_off + (size_t)q * (n_reg + 1), (uint64_t)(n_reg + 1), 1, (unsigned long long*)nullptr);
+            ms.s[q] = MergeSrc{s.dev_keys, s.dev_counts, d_off + (size_t)q * (n_reg + 1)};
+            records += s.n_records;
+        }
+        hipMemsetAsync(d_ndef, 0, 8, c->stream);
+        t->count_bound = 0xFFFFFFFFULL;
+        {
+            ScopedTimer tm(c, KATGPU_K_MERGE, records);
+            const size_t lds = (size_t)t->d.region_slots * slot_bytes;
+            const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2));
+            const dim3 grid(std::min<uint32_t>(n_reg, (uint32_t)c->n_cu * per_cu));
+            if (t->d.cbits) hipLaunchKernelGGL((k_merge_apply<1024, true>), grid, dim3(1024), lds, c->stream, t->d, g_lo, g_hi, ms, d_def, d_ndef);
+            else hipLaunchKernelGGL((k_merge_apply<1024, false>), grid, dim3(1024), lds, c->stream, t->d, g_lo, g_hi, ms, d_def, d_ndef);
+        }
+        unsigned long long ndef = 0;
+        hipMemcpyAsync(&ndef, d_ndef, 8, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(tmp); return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e)); }
+        if (ndef) {                                   // regions that could have overflowed: their runs go in directly (with growth)
+            std::vector<uint32_t> regs(ndef);
+            std::vector<uint64_t> off((size_t)na * (n_reg + 1));
+            e = hipMemcpy(regs.data(), d_def, ndef * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(off.data(), d_off, off.size() * 8, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { hipFree(tmp); return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e)); }
+            if (g_trace) fprintf(stderr, "[katgpu] merge: %llu region(s) deferred to the direct path\n", ndef);
+            // Room first, per REGION: the runs of one region all land in that region, so the global load says nothing here.
+            // After growing every region to hold what it has plus what arrives (at load 0.7) no insert below can fail.
+            uint64_t max_in = 0;
+            for (uint32_t g : regs) {
+                uint64_t in = 0;
+                for (uint32_t q = 0; q < na; ++q) { const uint64_t* o = off.data() + (size_t)q * (n_reg + 1); in += o[g - g_lo + 1] - o[g - g_lo]; }
+                max_in = std::max(max_in, in);
+            }
+            const uint64_t need_s = (uint64_t)(((double)t->d.region_slots + (double)max_in) / 0.7) + 1;
+            if (need_s > t->d.region_slots) {
+                if (t->disable_grow) rc = fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
+                else rc = regrow(t, (uint64_t)t->d.n_regions * need_s);
+            }
+            if (rc == KATGPU_OK) {                    // one launch for all deferred regions: every region now has the room
+                ScopedTimer tm(c, KATGPU_K_MERGE, max_in * ndef);
+                hipLaunchKernelGGL(k_merge_deferred, dim3((unsigned)std::min<unsigned long long>(ndef, (unsigned long long)c->n_cu * 8)), dim3(256), 0, c->stream,
+                                   t->d, g_lo, ms, (const uint32_t*)d_def, (uint32_t)ndef);
+                if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, KATGPU_ERR_DEVICE, "deferred merge");
+                else rc = refresh_counters(t);
+            }
+        }
+        hipFree(tmp);
+        if (rc) return rc;
+        if (ndef && (src[aligned[a0]].p1 != t->d.p1 || src[aligned[a0]].p2 != t->d.p2)) {      // the growth changed the grid: the rest goes direct
+            for (size_t a = a0 + na; a < aligned.size(); ++a) direct.push_back(aligned[a]);
+            break;
+        }
+    }
+    for (uint32_t i : direct) {
+        rc = merge_direct32(t, src[i].dev_keys, src[i].dev_counts, (size_t)src[i].n_records);
+        if (rc) return rc;
+    }
+    return refresh_counters(t);
+}
+

@@ -1,0 +1,153 @@
+// kg_host.hpp -- what the host-side translation units of libkatgpu.so share: the context and table objects behind the opaque
+// handles of include/katgpu.h, error plumbing, the allocation pool, launch timing.  The library is split by concern:
+//   kg_context.hip   context, pool, profile counters, device buffers, the synthetic workload
+//   kg_table.hip     table life cycle (create / regrow / stats), lookups and profiles, record export / merge
+//   kg_count.hip     counting: the direct kernel, the partitioned counter's host loop, the host feeder, katgpu_count*
+//   kg_scan.hip      device-side record scan of raw FASTQ / FASTA bytes (katgpu_count_files' fast path)
+//   kg_exchange.hip  region-ordered extraction / merge for the multi-GPU exchange
+//   kg_comm.hip      the exchange itself over RCCL (katgpu_comm_*)
+//   kg_reduce.hip    hist / gcp / comp
+// gfx950 only; there is no CPU path in this library.
+#pragma once
+#include "../../include/katgpu.h"
+#include "kg_device.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+using namespace kg;
+
+// ------------------------------------------------------------------ context ---------------------------
+
+struct katgpu_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;        // all kernels
+    hipStream_t copy_stream = nullptr;   // H2D staging
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    uint64_t prof_launches[KATGPU_K_NCLASSES] = {};
+    double prof_ms[KATGPU_K_NCLASSES] = {};
+    uint64_t prof_units[KATGPU_K_NCLASSES] = {};
+    // pending (not yet read back) event pairs: timing is resolved lazily so launches stay asynchronous
+    struct Pending { hipEvent_t a, b; int cls; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    // staging for host / file ingest: 2 pinned buffers feed 2 device rings (allocated on first use, kept)
+    uint8_t* pinned[2] = {nullptr, nullptr};
+    hipEvent_t pin_free[2] = {nullptr, nullptr};     // the H2D copy out of pinned[i] has finished
+    size_t stage_bytes = 0;
+    uint8_t* ring[2] = {nullptr, nullptr};           // resident stretches of the base stream, counted like any device-resident input
+    size_t ring_bytes = 0;
+    // Freed table arrays are parked here and handed out again to the next table of (nearly) the same size: on this
+    // driver a hipMalloc of tens of GB right after a hipFree of that much stalls for seconds (VRAM scrubbing), which
+    // would dominate a run that builds tables repeatedly.  Emptied by katgpu_shutdown or when an allocation fails.
+    struct Block { void* p; size_t bytes; };
+    std::vector<Block> pool;
+    std::unordered_map<void*, size_t> block_bytes;      // real size of every live pooled-class allocation
+    // scratch arena of the partitioned counter (level-1 / level-2 buffers, histograms); kept across calls
+    uint8_t* arena = nullptr;
+    size_t arena_bytes = 0;
+    std::unordered_set<const void*> lds_attr;   // kernels whose dynamic-LDS ceiling has been raised on this device
+    bool part_attr_set = false, merge_attr_set = false;   // the dynamic-LDS attributes of the partition / merge kernels have been set on this device
+    bool arena_busy = false;              // a partition round is using it: pool_alloc must not free it to satisfy a table growth
+    bool arena_borrowed = false;          // katgpu_scratch_acquire handed the arena out: it must not be freed behind the caller's back
+    int count_blocks_per_cu = 6;
+};
+
+struct katgpu_table {
+    katgpu_ctx* ctx = nullptr;
+    DevTable d{};
+    int disable_grow = 0;
+    uint32_t n_ovf = 0;          // refreshed by refresh_counters()
+    uint64_t distinct = 0;       // idem (slots in use + all-ones key)
+    uint64_t ones = 0;
+    // overflow guard of the unchecked (no-return) +1 adds: no 32-bit counter exceeds count_bound + unchecked_adds
+    uint64_t count_bound = 0;    // largest counter value possible at the last sweep (0 for a fresh table)
+    uint64_t unchecked_adds = 0; // window starts launched through k_count since then
+    uint32_t n_regrows = 0;      // how often the table had to grow (the host mirror words the reference's warning from it)
+    uint8_t carry[64];           // last k-1 bytes of the previous host batch of the current file
+    uint32_t carry_n = 0;
+};
+
+inline int fail(katgpu_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+// entry points that handle one-word k-mers only (lookups by 64-bit key, .jf, the multi-GPU exchange, sect/cold profiles)
+#define NARROW_ONLY(t, what)                                                                             \
+    do {                                                                                                 \
+        if ((t)->d.keys_b) return fail((t)->ctx, KATGPU_ERR_K, "%s is not available for k > 32 (k = %u)", what, (t)->d.k); \
+    } while (0)
+
+#define HIPCHK(c, expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return fail((c), _e == hipErrorOutOfMemory ? KATGPU_ERR_NOMEM : KATGPU_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- shared helpers (defined in kg_context.hip / kg_table.hip) ----
+void resolve_pending(katgpu_ctx* c);
+int grid_for(katgpu_ctx* c, uint64_t items, int block, int per_cu);
+void pool_trim(katgpu_ctx* c);
+hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes);
+void pool_release(katgpu_ctx* c, void* p);
+void release_arena(katgpu_ctx* c);
+
+inline double now_ms() {
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+}
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// Test hooks (KATGPU_TEST_*) and A/B switches are read only when KATGPU_TESTING is set: a production process ignores them, and the
+// kernels that honour one (the spill hook of the apply kernels) are separate instantiations it never launches.
+// What a deployment may tune stays plain (INTEGRATION.md lists them): KATGPU_TRACE, KATGPU_ARENA_FRACTION, KATGPU_RING_MB,
+// KATGPU_PART_MIN_STARTS, KATGPU_INGEST_*, KATGPU_DEVICE_SCAN.
+static const bool g_trace = getenv("KATGPU_TRACE") != nullptr;
+static const bool g_testing = getenv("KATGPU_TESTING") != nullptr;
+inline const char* hook(const char* name) { return g_testing ? getenv(name) : nullptr; }
+inline uint64_t hook_u64(const char* name, uint64_t dflt) { const char* v = hook(name); return v ? strtoull(v, nullptr, 10) : dflt; }
+
+// table geometry limits
+constexpr uint32_t AP2_MAX_SLOTS = 10240;           // the apply kernels: a region of at most this many slots (120 KB of KV12 region + 36 KB of queues; 80 KB packed)
+constexpr int AP2_QCAP_BIG = 192;                   // KV12 apply: queue entries per wave for regions beyond 8192 slots
+
+// table life cycle (kg_table.hip)
+int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1 = 0, uint32_t like_p2 = 0);
+void free_dev_table(katgpu_ctx* c, DevTable& d);
+int refresh_counters(katgpu_table* t);
+int regrow(katgpu_table* t, uint64_t new_cap);
+double load_limit(const DevTable& d);
+int ensure_room(katgpu_table* t, uint64_t incoming);
+// counting (kg_count.hip)
+int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n);
+
+// HIP events around a launch on the ctx stream; elapsed time is collected lazily.
+struct ScopedTimer {
+    katgpu_ctx* c; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(katgpu_ctx* c_, int cls_, uint64_t units) : c(c_), cls(cls_) {
+        auto take = [&]() { hipEvent_t e = nullptr; if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); } else hipEventCreate(&e); return e; };
+        a = take(); b = take();
+        hipEventRecord(a, c->stream);
+        c->prof_launches[cls] += 1; c->prof_units[cls] += units;
+    }
+    ~ScopedTimer() {
+        hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, cls});
+        if (c->pending.size() > 4096) resolve_pending(c);
+    }
+};
+

@@ -105,18 +105,18 @@ k_count(DevTable t, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_ch
 }
 
 // K2 / K7: add (key,count) records into a table.  src == another table's slots (regrow) or a record list (merge).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_regrow(DevTable dst, DevTable src, uint32_t src_n_ovf) {
     uint32_t new_distinct = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < src.cap; i += stride) {
-        uint64_t key = src.keys[i];
-        if (key != EMPTY) table_add(dst, key, slot_count(src, i, key, src_n_ovf), new_distinct);
+        const SlotView v = slot_view(src, i);
+        if (v.occ) table_add(dst, v.key, slot_total(src, i, v.key, v.cnt, src_n_ovf), new_distinct);
     }
     flush_distinct(dst, new_distinct);
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_merge(DevTable dst, const uint64_t* __restrict__ keys, const uint64_t* __restrict__ counts, uint64_t n) {
     uint32_t new_distinct = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -125,9 +125,9 @@ k_merge(DevTable dst, const uint64_t* __restrict__ keys, const uint64_t* __restr
     flush_distinct(dst, new_distinct);
 }
 
-// Overflow guard for table_inc's unchecked 32-bit adds: every counter >= thr gives thr to the side table.  Reports the
-// largest counter left behind (scratch[0], atomicMax) so the host knows how many more unchecked adds are safe.
-__global__ void __launch_bounds__(256)
+// Overflow guard for table_inc's unchecked 32-bit adds (KV12 tables; packed tables add checked): every counter >= thr gives thr to
+// the side table.  Reports the largest counter left behind (scratch[0], atomicMax) so the host knows how many more unchecked adds are safe.
+static __global__ void __launch_bounds__(256)
 k_sweep(DevTable t, uint32_t thr, unsigned long long* scratch) {
     uint32_t mx = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -147,13 +147,13 @@ k_sweep(DevTable t, uint32_t thr, unsigned long long* scratch) {
 }
 
 // Σ counts (table_stats "total")
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_total(DevTable t, uint32_t n_ovf, uint64_t* out) {
     uint64_t s = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.cap; i += stride) {
-        uint64_t key = t.keys[i];
-        if (key != EMPTY) s += slot_count(t, i, key, n_ovf);
+        const uint64_t w = t.keys[i];
+        if (t.cbits ? w != 0 : w != EMPTY) s += slot_total(t, i, w, t.cbits ? pk_count(w, t.cbits) : (uint64_t)t.counts[i], n_ovf);
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long*)out, (unsigned long long)s);
@@ -182,24 +182,28 @@ __device__ __forceinline__ void lds_inc_aggregated(uint32_t* bins, uint32_t idx,
 constexpr int SCAN_BLOCK = 1024;
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-struct Slots4 { uint64_t key[4]; uint32_t cnt[4]; };
+struct Slots4 { uint64_t w[4]; uint64_t cnt[4]; bool occ[4]; };     // w: the k-mer (KV12, wide: its first word) or the packed word
 // (the loads are unconditional, from a clamped address, and the lanes beyond the range are masked afterwards: loads issued inside
 // a branch make hipcc wait for them at the end of the branch, which turns every prefetch into a stall)
+template <bool PK>
 __device__ __forceinline__ Slots4 load_slots4(const DevTable& t, uint64_t i4 /* first slot, multiple of 4 */, bool in_range) {
     Slots4 r;
     const uint64_t at = in_range ? i4 : 0;
     const u64x2 a = *reinterpret_cast<const u64x2*>(t.keys + at), b = *reinterpret_cast<const u64x2*>(t.keys + at + 2);
-    const u32x4s c = *reinterpret_cast<const u32x4s*>(t.counts + at);
-    r.key[0] = in_range ? a.x : EMPTY; r.key[1] = in_range ? a.y : EMPTY; r.key[2] = in_range ? b.x : EMPTY; r.key[3] = in_range ? b.y : EMPTY;
-    r.cnt[0] = c.x; r.cnt[1] = c.y; r.cnt[2] = c.z; r.cnt[3] = c.w;
+    r.w[0] = a.x; r.w[1] = a.y; r.w[2] = b.x; r.w[3] = b.y;
+    if constexpr (PK) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { r.occ[j] = in_range && r.w[j] != 0; r.cnt[j] = pk_count(r.w[j], t.cbits); }
+    } else {
+        const u32x4s c = *reinterpret_cast<const u32x4s*>(t.counts + at);
+        r.cnt[0] = c.x; r.cnt[1] = c.y; r.cnt[2] = c.z; r.cnt[3] = c.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.occ[j] = in_range && r.w[j] != EMPTY;
+    }
     return r;
 }
-__device__ __forceinline__ uint64_t slot_count4(const DevTable& t, uint64_t pos, uint64_t key, uint32_t cnt, uint32_t n_ovf) {
-    uint64_t c = cnt;
-    if (n_ovf) c += ovf_get(t, t.keys_b ? pos : key);
-    return c;
-}
 
+template <bool PK>
 __global__ void __launch_bounds__(SCAN_BLOCK)
 k_hist(DevTable t, uint32_t n_ovf, uint64_t base, uint64_t ceil_, uint64_t inc, uint64_t nb,
        unsigned long long* __restrict__ out, uint32_t lds_bins) {
@@ -211,13 +215,13 @@ k_hist(DevTable t, uint32_t n_ovf, uint64_t base, uint64_t ceil_, uint64_t inc, 
     const uint64_t rounds = (quads + stride - 1) / stride;
     for (uint64_t r = 0; r < rounds; ++r) {              // uniform trip count: the aggregation uses whole-wave ballots
         const uint64_t q = first + r * stride;
-        const Slots4 s4 = load_slots4(t, q * 4, q < quads);
+        const Slots4 s4 = load_slots4<PK>(t, q * 4, q < quads);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool occ = s4.key[j] != EMPTY;
+            const bool occ = s4.occ[j];
             uint64_t idx = 0;
             if (occ) {
-                const uint64_t v = slot_count4(t, q * 4 + j, s4.key[j], s4.cnt[j], n_ovf);
+                const uint64_t v = slot_total(t, q * 4 + j, s4.w[j], s4.cnt[j], n_ovf);
                 idx = v < base ? 0 : (v > ceil_ ? nb - 1 : (inc == 1 ? v - base : (v - base) / inc));
             }
             const bool in_lds = occ && idx < lds_bins;
@@ -243,7 +247,7 @@ __device__ __forceinline__ uint64_t scale_count(uint64_t c, double scale) {
 
 // K4.  Gcp::analyseSlice (src/gcp.cc:179-197): row = popcount-based GC count, column = min(ceil(count*scale), bins).
 // The whole k x (bins+1) matrix is privatised in LDS as u32 when it fits (27 x 1001 x 4 B = 108 KB of the 160 KB).
-template <bool W>                                         // W: wide table (k > 32, kg_device.hpp "wide keys")
+template <bool W, bool PK>                                // W: wide table (k > 32, kg_device.hpp "wide keys"); PK: packed slots
 __global__ void __launch_bounds__(SCAN_BLOCK)
 k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long long* __restrict__ out, uint32_t use_lds) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
@@ -255,8 +259,15 @@ k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long lon
     for (uint64_t r = 0; r < rounds; ++r) {
         const uint64_t q = first + r * stride;
         const bool in_range = q < quads;
-        const Slots4 s4 = load_slots4(t, q * 4, in_range);
+        const Slots4 s4 = load_slots4<PK>(t, q * 4, in_range);
         uint64_t kb[4] = {0, 0, 0, 0};
+        RegionPlace rp{};
+        if constexpr (PK) {                                // the quad lies in one region (regions are whole quads): its digits once
+            const uint32_t region = region_of_pos(t, in_range ? q * 4 : 0);
+            rp.pl = place_make(t.k, t.p1, t.n1, t.l2);
+            rp.base1 = t.base1[region >> t.l2];
+            rp.d2_hi = rp.pl.rb < 64 ? (uint64_t)(region & (t.p2 - 1)) << rp.pl.rb : 0ULL;
+        }
         if constexpr (W) {
             const uint64_t at = in_range ? q * 4 : 0;
             const u64x2 a = *reinterpret_cast<const u64x2*>(t.keys_b + at), b = *reinterpret_cast<const u64x2*>(t.keys_b + at + 2);
@@ -264,12 +275,14 @@ k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long lon
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bool occ = s4.key[j] != EMPTY;
+            bool occ = s4.occ[j];
             uint32_t cell = 0;
             if (occ) {
                 uint32_t g;
-                if constexpr (W) g = keyw_gc(KeyW{s4.key[j], kb[j]}, k); else g = kmer_gc(s4.key[j], k);
-                uint64_t pos = scale_count(slot_count4(t, q * 4 + j, s4.key[j], s4.cnt[j], n_ovf), scale);
+                if constexpr (W) g = keyw_gc(KeyW{s4.w[j], kb[j]}, k);
+                else if constexpr (PK) g = kmer_gc(key_in(pk_rem(s4.w[j], t.cbits), rp), k);
+                else g = kmer_gc(s4.w[j], k);
+                uint64_t pos = scale_count(slot_total(t, q * 4 + j, s4.w[j], s4.cnt[j], n_ovf), scale);
                 if (pos > bins) pos = bins;
                 occ = g < k;                                   // the reference's matrix has k rows: GC == k never printed
                 cell = g * cols + (uint32_t)pos;
@@ -291,6 +304,7 @@ k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long lon
 
 // ---- K5: comp ----
 constexpr uint32_t COMP_TILE = 64;     // main-matrix cells [0,64) x [0,64) are privatised in LDS (u32)
+constexpr int JOIN_BLOCK = 1024;       // the join form: two workgroups per CU beside their LDS (result tile + spectra + the probed region)
 enum { CC_H1_TOTAL, CC_H2_TOTAL, CC_H3_TOTAL, CC_H1_DISTINCT, CC_H2_DISTINCT, CC_H3_DISTINCT, CC_H1_ONLY_TOTAL,
        CC_H2_ONLY_TOTAL, CC_H1_ONLY_DISTINCT, CC_H2_ONLY_DISTINCT, CC_SH_H1_TOTAL, CC_SH_H2_TOTAL, CC_SH_DISTINCT };
 
@@ -303,6 +317,7 @@ struct CompArgs {
     unsigned long long* spectra;     // 4 x spec_size
     uint32_t* seen;                  // join pass 1 -> pass 2: one bit per slot of hash 2, set when hash 1 holds the slot's key (null: off);
     uint32_t seen_wpr;               // words per region of that bitmap
+    uint32_t fold;                   // pass 1: spectra of the k-mers that land in the LDS tile are taken from the tile at the end (below)
 };
 
 __device__ __forceinline__ uint32_t spectrum_bin(uint64_t c, uint32_t size) { return c >= size ? size - 1 : (uint32_t)c; }  // comp_counters.cc:130-140
@@ -342,6 +357,10 @@ __device__ __forceinline__ void comp_account(bool occ, uint64_t ca, uint64_t cb,
     }
     lds_inc_aggregated(s_tile, cell, in_mx && in_tile);
     if (in_mx && !in_tile) atomicAdd(&a.main_mx[cell], 1ULL);
+    // CompArgs::fold (unscaled bins, more than COMP_TILE of them): a k-mer of pass 1 that lands in the tile has s1 == ca < 64 and
+    // s2 == cb < 64, so spectrum1, shared_spectrum1 and shared_spectrum2 are marginals of the tile -- comp_flush adds them; one LDS
+    // atomic per k-mer instead of four (the spectra's hot bins are the same few addresses for every lane of the chip)
+    if (PASS == 1 && a.fold) occ = occ && !in_tile;
     lds_inc_aggregated(s_spec, spectrum_bin(ca, a.spec_size), occ);                            // spectrum1 / spectrum2
     if (PASS == 1) {
         bool shared = occ && ca && cb;
@@ -374,7 +393,12 @@ __device__ __forceinline__ void comp_flush(const CompArgs& a, unsigned long long
         if (!v) continue;
         uint32_t r = i / COMP_TILE, c = i % COMP_TILE;
         if (r < a.d1_bins && c < a.d2_bins) atomicAdd(&a.main_mx[(uint64_t)r * a.d2_bins + c], (unsigned long long)v);
+        if (PASS == 1 && a.fold) {                                          // the tile's k-mers: spectrum1[ca], and when shared, shared_spectrum1[ca] / shared_spectrum2[cb]
+            atomicAdd(&s_spec[r], v);
+            if (r && c) { atomicAdd(&s_spec[a.spec_size + r], v); atomicAdd(&s_spec[2 * a.spec_size + c], v); }
+        }
     }
+    if (PASS == 1 && a.fold) __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_spec; i += blockDim.x) {
         uint32_t v = s_spec[i];
         if (!v) continue;
@@ -414,9 +438,8 @@ k_comp(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
         uint64_t key = EMPTY, ca = 0, cb = 0;
         bool occ = false;
         if (i < ta.cap) {
-            key = ta.keys[i];
-            occ = key != EMPTY;
-            if (occ) ca = slot_count(ta, i, key, na_ovf);
+            if constexpr (W) { key = ta.keys[i]; occ = key != EMPTY; if (occ) ca = slot_count(ta, i, key, na_ovf); }
+            else { const SlotView v = slot_view(ta, i); key = v.key; occ = v.occ; if (occ) ca = slot_total(ta, i, key, v.cnt, na_ovf); }
         } else if (i == ta.cap) {
             ca = ta.ctrs[CTR_ONES];
             occ = ca != 0;
@@ -442,8 +465,10 @@ k_comp(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
 // one table can only match region r of the other -- a partitioned hash join.  A persistent workgroup walks regions:
 // the probed table's region goes into LDS (coalesced), the scanned table's region streams past it, every probe is an
 // LDS probe.  HBM sees each table exactly once per pass, as a stream.
-template <int PASS>
-__global__ void __launch_bounds__(512)
+// PK: both tables packed (the same grid gives the same remainder bits, hence the same layout): 8 bytes per slot on either side,
+// and what is compared is the slot's remainder -- tables of one grid give one k-mer one remainder -- so no k-mer is ever decoded.
+template <int PASS, bool PK>
+__global__ void __launch_bounds__(JOIN_BLOCK)
 k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_raw);
@@ -452,9 +477,10 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
     const uint32_t n_spec = (PASS == 1 ? 3u : 1u) * a.spec_size;
     const uint32_t Sa = ta.region_slots, Sb = tb.region_slots;
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(s_raw + ((16 * 8 + COMP_TILE * COMP_TILE * 4 + n_spec * 4 + 15) & ~15u));
-    uint32_t* rc = reinterpret_cast<uint32_t*>(rk + Sb);
-    uint32_t* s_seen = rc + Sb;                                             // (a.seen) which slots of this region of hash 2 were found
+    uint32_t* rc = reinterpret_cast<uint32_t*>(rk + Sb);                     // (KV12 only)
+    uint32_t* s_seen = PK ? reinterpret_cast<uint32_t*>(rk + Sb) : rc + Sb;  // (a.seen) which slots of this region of hash 2 were found
     const bool mark = PASS == 1 && a.seen != nullptr;
+    const uint32_t cb_bits = tb.cbits;                                       // == ta.cbits when PK
     comp_lds_init(a, PASS, s_acc, s_tile, s_spec);
     CompAcc acc;
     const uint32_t R = ta.n_regions;
@@ -462,33 +488,53 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
         __syncthreads();
         const uint64_t bbase = (uint64_t)r * Sb, abase = (uint64_t)r * Sa;
         const RegionPlace rpb = region_place(tb, r);
-        for (uint32_t i = threadIdx.x; i < Sb; i += blockDim.x) { rk[i] = tb.keys[bbase + i]; rc[i] = tb.counts[bbase + i]; }
+        if constexpr (PK) {                                                  // 16 bytes per lane and load (Sb is a multiple of 4)
+            for (uint32_t i = threadIdx.x * 2; i < Sb; i += blockDim.x * 2)
+                *reinterpret_cast<u64x2*>(rk + i) = *reinterpret_cast<const u64x2*>(tb.keys + bbase + i);
+        } else {
+            for (uint32_t i = threadIdx.x; i < Sb; i += blockDim.x) { rk[i] = tb.keys[bbase + i]; rc[i] = tb.counts[bbase + i]; }
+        }
         if (mark) for (uint32_t i = threadIdx.x; i < a.seen_wpr; i += blockDim.x) s_seen[i] = 0;
         __syncthreads();
-        constexpr int JB = 4;                                               // slots per lane in flight: keys and counts are loaded together
+        constexpr int JB = 4;                                               // slots per lane in flight
         for (uint32_t i0 = 0; i0 < Sa; i0 += JB * blockDim.x) {             // uniform trip count: ballots inside comp_account
             uint64_t keys[JB]; uint32_t cnts[JB];
 #pragma unroll
             for (int u = 0; u < JB; ++u) {
                 const uint32_t i = i0 + u * blockDim.x + threadIdx.x;
                 const uint32_t ic = i < Sa ? i : Sa - 1;                    // clamped: the loads stay in one basic block
-                keys[u] = ta.keys[abase + ic]; cnts[u] = ta.counts[abase + ic];
-                if (i >= Sa) keys[u] = EMPTY;
+                keys[u] = ta.keys[abase + ic];
+                if constexpr (!PK) cnts[u] = ta.counts[abase + ic]; else cnts[u] = 0;
+                if (i >= Sa) keys[u] = PK ? 0ULL : EMPTY;
             }
 #pragma unroll
             for (int u = 0; u < JB; ++u) {
                 const uint64_t key = keys[u];
-                const bool occ = key != EMPTY;
+                const bool occ = PK ? key != 0 : key != EMPTY;
                 uint64_t ca = 0, cb = 0;
                 if (occ) {
-                    ca = cnts[u];
-                    if (na_ovf) ca += ovf_get(ta, key);
-                    uint32_t s = home_offset_in(key, rpb);
-                    for (uint32_t probe = 0; probe < Sb; ++probe) {
-                        const unsigned long long cur = rk[s];
-                        if (cur == key) { cb = rc[s]; if (nb_ovf) cb += ovf_get(tb, key); if (mark) atomicOr(&s_seen[s >> 5], 1u << (s & 31)); break; }
-                        if (cur == EMPTY) break;
-                        s = s + 1 == Sb ? 0 : s + 1;
+                    const uint32_t i = i0 + u * blockDim.x + threadIdx.x;
+                    if constexpr (PK) {
+                        ca = pk_count(key, cb_bits);
+                        if (na_ovf) ca += ovf_get(ta, abase + i);
+                        const uint64_t rem = pk_rem(key, cb_bits);
+                        uint32_t s = place_offset(rem, rpb.pl, Sb);
+                        for (uint32_t probe = 0; probe < Sb; ++probe) {
+                            const unsigned long long cur = rk[s];
+                            if (cur == 0) break;
+                            if ((cur >> cb_bits) == rem) { cb = pk_count(cur, cb_bits); if (nb_ovf) cb += ovf_get(tb, bbase + s); if (mark) atomicOr(&s_seen[s >> 5], 1u << (s & 31)); break; }
+                            s = s + 1 == Sb ? 0 : s + 1;
+                        }
+                    } else {
+                        ca = cnts[u];
+                        if (na_ovf) ca += ovf_get(ta, key);
+                        uint32_t s = home_offset_in(key, rpb);
+                        for (uint32_t probe = 0; probe < Sb; ++probe) {
+                            const unsigned long long cur = rk[s];
+                            if (cur == key) { cb = rc[s]; if (nb_ovf) cb += ovf_get(tb, key); if (mark) atomicOr(&s_seen[s >> 5], 1u << (s & 31)); break; }
+                            if (cur == EMPTY) break;
+                            s = s + 1 == Sb ? 0 : s + 1;
+                        }
                     }
                 }
                 comp_account<PASS>(occ, ca, cb, a, s_tile, s_spec, acc);
@@ -499,10 +545,10 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
             for (uint32_t i = threadIdx.x; i < a.seen_wpr; i += blockDim.x) a.seen[(uint64_t)r * a.seen_wpr + i] = s_seen[i];
         }
     }
-    {   // the all-ones key lives outside the slots: one lane of block 0 takes it through the HBM path
+    {   // the all-ones key lives outside the slots: one lane of block 0 takes it through the HBM path (KV12 tables of k = 32 only)
         uint64_t ca = 0, cb = 0;
         bool occ = false;
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!PK && blockIdx.x == 0 && threadIdx.x == 0) {
             ca = ta.ctrs[CTR_ONES];
             occ = ca != 0;
             if (occ) cb = table_get(tb, (PASS == 2 || a.canon_probe) ? kmer_canonical(EMPTY, ta.k) : EMPTY, nb_ovf);
@@ -517,6 +563,7 @@ k_comp_join(DevTable ta, uint32_t na_ovf, DevTable tb, uint32_t nb_ovf, CompArgs
 // form spends 1.3 random sector reads per k-mer of hash 2: 25 ms at config 4, 49 ms when hash 2 is a second read library).  Both
 // tables canonical (pass 2 probes the canonical form, src/comp.cc:447: only then is "found by pass 1" the same question), and the
 // all-ones key is never canonical, so there is no slot-less key to look after.
+template <bool PK>
 __global__ void __launch_bounds__(512)
 k_comp_seen(DevTable ta /* hash 2 */, uint32_t na_ovf, CompArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -536,14 +583,19 @@ k_comp_seen(DevTable ta /* hash 2 */, uint32_t na_ovf, CompArgs a) {
             for (int u = 0; u < JB; ++u) {
                 const uint32_t i = i0 + u * blockDim.x + threadIdx.x;
                 const uint32_t ic = i < S ? i : S - 1;                      // clamped: the loads stay in one basic block
-                keys[u] = ta.keys[base + ic]; cnts[u] = ta.counts[base + ic]; bits[u] = seen[ic >> 5] >> (ic & 31);
-                if (i >= S) keys[u] = EMPTY;
+                keys[u] = ta.keys[base + ic]; bits[u] = seen[ic >> 5] >> (ic & 31);
+                if constexpr (!PK) cnts[u] = ta.counts[base + ic]; else cnts[u] = 0;
+                if (i >= S) keys[u] = PK ? 0ULL : EMPTY;
             }
 #pragma unroll
             for (int u = 0; u < JB; ++u) {
-                const bool occ = keys[u] != EMPTY;
+                const bool occ = PK ? keys[u] != 0 : keys[u] != EMPTY;
                 uint64_t ca = 0;
-                if (occ) { ca = cnts[u]; if (na_ovf) ca += ovf_get(ta, keys[u]); }
+                if (occ) {
+                    const uint32_t i = i0 + u * blockDim.x + threadIdx.x;
+                    ca = PK ? pk_count(keys[u], ta.cbits) : (uint64_t)cnts[u];
+                    if (na_ovf) ca += ovf_get(ta, PK ? base + i : keys[u]);
+                }
                 comp_account<2>(occ, ca, (uint64_t)(bits[u] & 1u), a, s_tile, s_spec, acc);
             }
         }
@@ -575,8 +627,10 @@ k_comp3_pass1(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, DevTab
         const uint64_t i = first + r * stride;
         uint64_t key = EMPTY, c1 = 0;
         bool occ = false;
-        if (i < t1.cap) { key = t1.keys[i]; occ = key != EMPTY; if (occ) c1 = slot_count(t1, i, key, n1_ovf); }
-        else if (i == t1.cap) { c1 = t1.ctrs[CTR_ONES]; occ = c1 != 0; }
+        if (i < t1.cap) {
+            if constexpr (W) { key = t1.keys[i]; occ = key != EMPTY; if (occ) c1 = slot_count(t1, i, key, n1_ovf); }
+            else { const SlotView v = slot_view(t1, i); key = v.key; occ = v.occ; if (occ) c1 = slot_total(t1, i, key, v.cnt, n1_ovf); }
+        } else if (i == t1.cap) { c1 = t1.ctrs[CTR_ONES]; occ = c1 != 0; }
         uint32_t which = 0, cell = 0;
         bool in_tile = false;
         if (occ) {
@@ -611,12 +665,15 @@ k_comp3_pass1(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, DevTab
 }
 
 // updateHash3Counters (lib/src/comp_counters.cc:113-117): hash3_total, hash3_distinct
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_comp3_pass3(DevTable t3, uint32_t n3_ovf, unsigned long long* counters) {
     uint64_t tot = 0, dis = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t3.cap; i += stride) {
-        if (i < t3.cap) { const uint64_t key = t3.keys[i]; if (key != EMPTY) { tot += slot_count(t3, i, key, n3_ovf); ++dis; } }
+        if (i < t3.cap) {
+            const uint64_t w = t3.keys[i];
+            if (t3.cbits ? w != 0 : w != EMPTY) { tot += slot_total(t3, i, w, t3.cbits ? pk_count(w, t3.cbits) : (uint64_t)t3.counts[i], n3_ovf); ++dis; }
+        }
         else { const uint64_t c = t3.ctrs[CTR_ONES]; if (c) { tot += c; ++dis; } }
     }
     for (int off = 32; off > 0; off >>= 1) { tot += __shfl_down(tot, off, 64); dis += __shfl_down(dis, off, 64); }
@@ -624,7 +681,7 @@ k_comp3_pass3(DevTable t3, uint32_t n3_ovf, unsigned long long* counters) {
 }
 
 // ---- batch lookup (JellyfishHelper::getCount, lib/src/jellyfish_helper.cc:189-194) ----
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_get(DevTable t, uint32_t n_ovf, const uint64_t* __restrict__ keys, uint64_t n, int canonicalise, uint64_t* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = table_get(t, canonicalise ? kmer_canonical(keys[i], t.k) : keys[i], n_ovf);
@@ -711,7 +768,7 @@ k_partition(DevTable t, uint32_t n_ovf, uint32_t n_parts, unsigned long long* __
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.cap; i += stride) {
         uint64_t key = EMPTY, c = 0;
-        if (i < t.cap) { key = t.keys[i]; if (key == EMPTY) continue; c = slot_count(t, i, key, n_ovf); }
+        if (i < t.cap) { const SlotView v = slot_view(t, i); if (!v.occ) continue; key = v.key; c = slot_total(t, i, key, v.cnt, n_ovf); }
         else { c = t.ctrs[CTR_ONES]; if (!c) continue; }
         uint32_t part = n_parts > 1 ? owner_of(key, t.k, n_parts) : 0;
         unsigned long long at = atomicAdd(&sizes_or_cursors[part], 1ULL);
@@ -729,7 +786,7 @@ constexpr uint32_t MAX_EXCHANGE_PARTS = 256;
 constexpr int MAX_MERGE_SRC = 16;
 
 // pass 1: rcnt[p * R + g] = number of records of region g owned by part p.  One workgroup per region.
-__global__ void __launch_bounds__(EXTRACT_BLOCK)
+static __global__ void __launch_bounds__(EXTRACT_BLOCK)
 k_extract_count(DevTable t, uint32_t n_parts, uint32_t* __restrict__ rcnt) {
     __shared__ uint32_t s_cnt[MAX_EXCHANGE_PARTS];
     const uint32_t tid = threadIdx.x, S = t.region_slots;
@@ -737,9 +794,10 @@ k_extract_count(DevTable t, uint32_t n_parts, uint32_t* __restrict__ rcnt) {
         for (uint32_t p = tid; p < n_parts; p += EXTRACT_BLOCK) s_cnt[p] = 0;
         __syncthreads();
         const uint64_t base = (uint64_t)g * S;
+        const RegionPlace rp = region_place(t, g);
         for (uint32_t i = tid; i < S; i += EXTRACT_BLOCK) {
-            const uint64_t key = t.keys[base + i];
-            if (key != EMPTY) atomicAdd(&s_cnt[n_parts > 1 ? owner_of(key, t.k, n_parts) : 0], 1u);
+            const SlotView v = slot_view_in(t, rp, base + i);
+            if (v.occ) atomicAdd(&s_cnt[n_parts > 1 ? owner_of(v.key, t.k, n_parts) : 0], 1u);
         }
         __syncthreads();
         for (uint32_t p = tid; p < n_parts; p += EXTRACT_BLOCK) rcnt[(uint64_t)p * t.n_regions + g] = s_cnt[p];
@@ -749,7 +807,7 @@ k_extract_count(DevTable t, uint32_t n_parts, uint32_t* __restrict__ rcnt) {
 
 // Exclusive scan of each row of a u32 matrix into u64 (row_base[r] added when given); one workgroup per row.
 // off may be null (totals only); off rows have n_cols + 1 entries when `closed` (the last one is the row total).
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_rows_scan(const uint32_t* __restrict__ m, uint32_t n_cols, uint64_t row_stride, const uint64_t* __restrict__ row_base,
             uint64_t* __restrict__ off, uint64_t off_stride, int closed, unsigned long long* __restrict__ totals) {
     __shared__ uint64_t s_wave[16];
@@ -780,7 +838,7 @@ k_rows_scan(const uint32_t* __restrict__ m, uint32_t n_cols, uint64_t row_stride
 
 // pass 2: write the records.  off[p * R + g] = global index of the first record of (part p, region g).  Counts that do
 // not fit 32 bits travel in the `big` list (their record carries count 0, which a merge skips).
-__global__ void __launch_bounds__(EXTRACT_BLOCK)
+static __global__ void __launch_bounds__(EXTRACT_BLOCK)
 k_extract_write(DevTable t, uint32_t n_ovf, uint32_t n_parts, const uint64_t* __restrict__ off, uint64_t* __restrict__ out_keys,
                 uint32_t* __restrict__ out_counts, uint64_t* __restrict__ big_keys, uint64_t* __restrict__ big_counts,
                 unsigned long long* __restrict__ big_n, uint32_t big_cap) {
@@ -790,12 +848,14 @@ k_extract_write(DevTable t, uint32_t n_ovf, uint32_t n_parts, const uint64_t* __
         for (uint32_t p = tid; p < n_parts; p += EXTRACT_BLOCK) s_cur[p] = 0;
         __syncthreads();
         const uint64_t base = (uint64_t)g * S;
+        const RegionPlace rp = region_place(t, g);
         for (uint32_t i = tid; i < S; i += EXTRACT_BLOCK) {
-            const uint64_t key = t.keys[base + i];
-            if (key == EMPTY) continue;
+            const SlotView v = slot_view_in(t, rp, base + i);
+            if (!v.occ) continue;
+            const uint64_t key = v.key;
             const uint32_t p = n_parts > 1 ? owner_of(key, t.k, n_parts) : 0;
             const uint64_t at = off[(uint64_t)p * t.n_regions + g] + atomicAdd(&s_cur[p], 1u);
-            uint64_t c = slot_count(t, base + i, key, n_ovf);
+            uint64_t c = slot_total(t, base + i, key, v.cnt, n_ovf);
             if (c > 0xFFFFFFFFULL) {
                 const unsigned long long b = atomicAdd(big_n, 1ULL);
                 if (b < big_cap) { big_keys[b] = key; big_counts[b] = c; }
@@ -811,17 +871,18 @@ k_extract_write(DevTable t, uint32_t n_ovf, uint32_t n_parts, const uint64_t* __
 struct MergeSrc { const uint64_t* keys; const uint32_t* counts; const uint64_t* off; };   // off: u64[regions + 1], relative to keys / counts
 struct MergeSrcs { MergeSrc s[MAX_MERGE_SRC]; uint32_t n; };
 
-// Owner side: regions [g_lo, g_hi).  LDS: keys[S] (u64) | counts[S] (u32), the protocol of k_p3_apply with arbitrary
-// 32-bit amounts.  A region that could overflow (occupied + incoming > S) is not touched: its index goes to `deferred`
-// and the host sends its runs through the direct path after making room.
-template <int BLOCK>
+// Owner side: regions [g_lo, g_hi).  LDS: keys[S] (u64) | counts[S] (u32) (KV12) or the S packed words (PK); the protocol of the
+// apply kernels with arbitrary 32-bit amounts.  A region that could overflow (occupied + incoming > S) is not touched: its index
+// goes to `deferred` and the host sends its runs through the direct path after making room.
+template <int BLOCK, bool PK>
 __global__ void __launch_bounds__(BLOCK)
 k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t* __restrict__ deferred, unsigned long long* __restrict__ n_deferred) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ uint32_t s_occ;
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
-    uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)t.region_slots * 8);
-    const uint32_t tid = threadIdx.x, S = t.region_slots;
+    uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)t.region_slots * 8);      // (KV12 only)
+    const uint32_t tid = threadIdx.x, S = t.region_slots, cb = t.cbits;
+    const uint64_t cmask = PK ? pk_cmask(cb) : 0, half = PK ? pk_half(cb) : 0;
     uint32_t new_distinct = 0;
     for (uint32_t g = g_lo + blockIdx.x; g < g_hi; g += gridDim.x) {
         const uint32_t j = g - g_lo;
@@ -835,8 +896,8 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
         uint32_t occ = 0;
         for (uint32_t i = tid; i < S; i += BLOCK) {
             const uint64_t key = t.keys[base + i];
-            rk[i] = key; rc[i] = t.counts[base + i];
-            occ += key != EMPTY;
+            rk[i] = key;
+            if constexpr (PK) occ += key != 0; else { rc[i] = t.counts[base + i]; occ += key != EMPTY; }
         }
         for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
         if ((tid & 63) == 0 && occ) atomicAdd(&s_occ, occ);
@@ -852,24 +913,53 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
                 const uint32_t c = srcs.s[s].counts[i];
                 if (!c) continue;
                 const unsigned long long key = srcs.s[s].keys[i];
-                uint32_t slot = home_offset_in(key, rp);
-                for (uint32_t probe = 0; probe < S; ++probe) {                   // cannot fail: occupied + incoming <= S
-                    unsigned long long cur = rk[slot];
-                    if (cur == EMPTY) {
-                        cur = atomicCAS(&rk[slot], (unsigned long long)EMPTY, key);
-                        if (cur == EMPTY) { ++new_distinct; cur = key; }
+                if constexpr (PK) {
+                    const uint64_t rem = rem_in(key, rp);
+                    uint32_t slot = place_offset(rem, rp.pl, S);
+                    uint64_t q, r;
+                    pk_split((uint64_t)c, cb, q, r);
+                    for (uint32_t probe = 0; probe < S; ++probe) {               // cannot fail: occupied + incoming <= S
+                        unsigned long long w = rk[slot];
+                        if (w == 0) {
+                            const uint64_t in = r ? r : half, qq = r ? q : q - 1;
+                            w = atomicCAS(&rk[slot], 0ULL, (unsigned long long)((rem << cb) | in));
+                            if (w == 0) { ++new_distinct; if (qq) ovf_add(t, base + slot, qq * half); break; }
+                        }
+                        if ((w >> cb) == rem) {
+                            if (r) {
+                                for (;;) {
+                                    uint64_t cc = (w & cmask) + r, qq = q;
+                                    if (cc > cmask) { cc -= half; ++qq; }
+                                    const unsigned long long got = atomicCAS(&rk[slot], w, (unsigned long long)((w & ~cmask) | cc));
+                                    if (got == w) { q = qq; break; }
+                                    w = got;
+                                }
+                            }
+                            if (q) ovf_add(t, base + slot, q * half);
+                            break;
+                        }
+                        slot = slot + 1 == S ? 0 : slot + 1;
                     }
-                    if (cur == key) {
-                        const uint32_t old = atomicAdd(&rc[slot], c);
-                        if ((uint32_t)(old + c) < old) ovf_add(t, key, 1ULL << 32);
-                        break;
+                } else {
+                    uint32_t slot = home_offset_in(key, rp);
+                    for (uint32_t probe = 0; probe < S; ++probe) {               // cannot fail: occupied + incoming <= S
+                        unsigned long long cur = rk[slot];
+                        if (cur == EMPTY) {
+                            cur = atomicCAS(&rk[slot], (unsigned long long)EMPTY, key);
+                            if (cur == EMPTY) { ++new_distinct; cur = key; }
+                        }
+                        if (cur == key) {
+                            const uint32_t old = atomicAdd(&rc[slot], c);
+                            if ((uint32_t)(old + c) < old) ovf_add(t, key, 1ULL << 32);
+                            break;
+                        }
+                        slot = slot + 1 == S ? 0 : slot + 1;
                     }
-                    slot = slot + 1 == S ? 0 : slot + 1;
                 }
             }
         }
         __syncthreads();
-        for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
+        for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; if constexpr (!PK) t.counts[base + i] = rc[i]; }
         __syncthreads();
     }
     flush_distinct(t, new_distinct);
@@ -877,7 +967,7 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
 
 // The runs of the regions k_merge_apply deferred, through the direct path: one workgroup per deferred region, every source's
 // run of that region.  (One launch for all of them: when a whole table is too small, every region is on the list.)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_merge_deferred(DevTable t, uint32_t g_lo, MergeSrcs srcs, const uint32_t* __restrict__ deferred, uint32_t n_deferred) {
     uint32_t new_distinct = 0;
     for (uint32_t d = blockIdx.x; d < n_deferred; d += gridDim.x) {
@@ -894,7 +984,7 @@ k_merge_deferred(DevTable t, uint32_t g_lo, MergeSrcs srcs, const uint32_t* __re
 }
 
 // records with 32-bit counts through the direct path (sources of another grid, deferred regions)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_merge32(DevTable dst, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, uint64_t n) {
     uint32_t new_distinct = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -909,7 +999,7 @@ __device__ __forceinline__ uint32_t genome_code(uint64_t seed, uint64_t i) {
 }
 // contig_len == 0: n bases.  contig_len > 0: the assembly's base stream, an 'N' after every contig_len bases
 // (n counts output bytes, separators included).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_synth_genome(uint8_t* __restrict__ out, uint64_t n, uint64_t seed, uint64_t contig_len) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += stride) {
@@ -923,7 +1013,7 @@ k_synth_genome(uint8_t* __restrict__ out, uint64_t n, uint64_t seed, uint64_t co
     }
 }
 // one lane per base: reads are laid out with stride read_len+1 ('N' separator closes every record)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_synth_reads(const uint8_t* __restrict__ genome, uint64_t genome_len, uint8_t* __restrict__ out, uint64_t first_read,
               uint64_t n_reads, uint32_t read_len, uint32_t frag_len, uint32_t err_thresh, uint64_t seed) {
     const uint64_t rec = (uint64_t)read_len + 1, total = n_reads * rec;

@@ -7,7 +7,7 @@
 // region-local probing (kg_device.hpp: Probe); a round of the partitioned counter
 //   P1  radix-partitions the round's k-mers by the high part of their region index into P1 buckets  (8 B out / k-mer)
 //   P2  splits every bucket by the low part of the region index -> one contiguous run per region     (8 B in, 4 + HB B out)
-//   P3  loads a region (96 KB) into LDS, applies its run with LDS atomics, writes the region back     (4 + HB B in + 24 B/slot)
+//   P3  loads a region into LDS, applies its run with LDS atomics, writes the region back            (4 + HB B in + 16 B/slot packed, 24 KV12)
 // What level 2 writes is not the k-mer but the REMAINDER of its placement hash (kg_device.hpp "placement": the hash is one to one
 // and the region already says its digits): rb = 2k - log2(regions) bits, kept as two streams -- the low 32 bits and HB = 0, 1, 2
 // or 4 bytes of high bits (35 bits at the bench size: 5 bytes per k-mer instead of 8).
@@ -28,7 +28,6 @@ constexpr int TILE_ITEMS = PART_BLOCK * PART_ITEMS;           // 16384
 constexpr int L1_TILE_BYTES = TILE_ITEMS;                     // bytes staged per tile (16 per lane)
 constexpr int L1_TILE_STARTS = L1_TILE_BYTES - CHUNK_OVERLAP; // 16352 window starts per tile
 constexpr int L1_LANES_WITH_STARTS = L1_TILE_STARTS / PART_ITEMS;   // 1022
-constexpr int MAX_PARTS = 1024;                               // buckets per level (one lane per bucket in the scans)
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope release fence, which on gfx950
 // lowers to s_waitcnt vmcnt(0): every barrier placed after a run of global STORES (copy-out, region write-back) would
@@ -43,6 +42,7 @@ struct PartGeom {
                        // through level 2 + apply in as many passes as there are whole sets of n_CU buckets: the level-2 buffer holds one pass)
     uint32_t l2;       // P2 == 1 << l2
     uint32_t hb;       // bytes of a level-2 item beyond its low 32 bits: 0, 1, 2 or 4 (from pl.rb; "the level-2 buffer" below)
+    uint32_t cbits;    // the table's (kg_device.hpp: packed slots); 0: KV12
     Place pl;          // the placement hash's bit budget for this table (kg_device.hpp)
 };
 // ---- the level-2 buffer ----
@@ -165,7 +165,7 @@ __device__ __forceinline__ uint64_t block_exclusive_scan64(uint64_t v, uint64_t*
 }
 
 // ---- level 1 scan: offs[w][b] = start of workgroup w's run inside bucket b; l1_off[b] = start of bucket b; l1_off[P1] = items ----
-__global__ void __launch_bounds__(PART_BLOCK)
+static __global__ void __launch_bounds__(PART_BLOCK)
 k_p1_scan(PartGeom g, uint32_t n_wg, const uint32_t* __restrict__ hist1, uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_off) {
     __shared__ uint64_t s_base[MAX_PARTS + 1];
     const uint32_t b = threadIdx.x;
@@ -304,7 +304,7 @@ __device__ __forceinline__ void p1_scan_pair(uint32_t v0, uint32_t v1, uint32_t*
     e1 = t0 + p1 + i1 - v1;
 }
 
-__global__ void __launch_bounds__(P1_BLOCK)
+static __global__ void __launch_bounds__(P1_BLOCK)
 k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
              uint32_t* __restrict__ hist1) {
     __shared__ uint32_t s_hist[MAX_PARTS];
@@ -530,7 +530,7 @@ __device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, co
             const uint32_t b = L.grp_b[gi];
             const uint64_t dst = L.cursor[b] + (gi - L.goff[b]);
             const u32x4 lo = *reinterpret_cast<const u32x4*>(&L.st_lo[gi * 4]);
-            typename HiGroup<HB>::type hi;
+            typename HiGroup<HB>::type hi{};
             if (HB) hi = *reinterpret_cast<const typename HiGroup<HB>::type*>(&L.st_hi[gi * 4]);
             if (dst < L.lim[b]) l2_store_group<HB>(out, dst, lo, hi);
             else {                                                             // beyond the run's capacity: the overflow list
@@ -670,121 +670,9 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
     if (STAMP && tid == 0 && stamps) for (int i = 0; i < 6; ++i) atomicAdd(&stamps[i], st[i]);
 }
 
-// ---- level 3: apply a region's run to the region, in LDS ----
-// LDS: keys[S] (u64) | counts[S] (u32).  Insert = LDS CAS claim + LDS add (same protocol as table_inc, minus the HBM).
-// SPT = slots per lane held in registers while a region is prefetched (region_slots <= SPT * BLOCK).
-// Software pipeline: while region r's run is applied in LDS, region r' (the workgroup's next one) is already on its way
-// from HBM into registers, and r's write-back drains behind it -- the CU's memory pipe stays busy through the LDS phase.
-template <int BLOCK, int SPT, int BATCH = 4, bool TEST_SPILL = false /* honours spill_mod: instantiated for the test suite only */>
-__global__ void __launch_bounds__(BLOCK)
-k_p3_apply(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
-           uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint32_t spill_mod,
-           const uint32_t* __restrict__ cnt2 /* run lengths when k_p2_fast laid the runs out; null: off2[r + 1] ends run r */,
-           const uint64_t* __restrict__ bend /* exact level 2 over a chunked level 1: where the last run of each bucket ends */) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
-    uint32_t* rc = reinterpret_cast<uint32_t*>(lds_raw + (size_t)g.S * 8);
-    const uint32_t tid = threadIdx.x, S = g.S;
-    uint32_t new_distinct = 0;
-    uint64_t kk[SPT]; uint32_t cc[SPT];
-
-    const uint32_t r_hi = g.b_hi * g.P2;                       // regions [b_lo * P2, r_hi): this launch's
-    auto run_end = [&](uint32_t r) -> uint64_t {                  // exact layouts: run r ends where the next one starts
-        if (bend && (r + 1) % g.P2 == 0) return bend[r / g.P2];
-        return off2[r + 1];
-    };
-    auto next_region = [&](uint32_t from) {                       // first region >= from (stride gridDim) that received k-mers
-        uint32_t r = from;
-        while (r < r_hi && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
-        return r;
-    };
-    auto prefetch = [&](uint32_t r) {
-        const uint64_t base = (uint64_t)r * S;
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; kk[u] = i < S ? t.keys[base + i] : 0; cc[u] = i < S ? t.counts[base + i] : 0; }
-    };
-
-    uint32_t r = next_region(g.b_lo * g.P2 + blockIdx.x);
-    if (r < r_hi) prefetch(r);
-    while (r < r_hi) {
-        const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : run_end(r);
-        const uint64_t base = (uint64_t)r * S;
-        // an item is the remainder of its k-mer's placement hash; the region supplies the digits (kg_device.hpp "placement")
-        const uint64_t base1 = place_base1(r >> g.l2, g.pl.n, g.pl.p1), d2_hi = g.pl.rb < 64 ? (uint64_t)(r & (g.P2 - 1)) << g.pl.rb : 0ULL;
-        auto item = [&](uint64_t i) -> unsigned long long {            // EMPTY: padding
-            bool none;
-            const uint64_t rem = l2_get_any(g.hb, l2_buf, i, none);
-            return none ? EMPTY : place_key(base1, d2_hi | rem, g.pl);
-        };
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) { const uint32_t i = u * BLOCK + tid; if (i < S) { rk[i] = kk[u]; rc[i] = cc[u]; } }
-        lds_barrier();
-        const uint32_t rn = next_region(r + gridDim.x);
-        bool prefetched = false;
-        // Each lane walks ITS k-mers of the batch on its own: a lane that has placed one k-mer starts probing for its next
-        // while its neighbours are still on longer probe chains.  (With a per-k-mer loop the wave waits for the longest of
-        // 64 chains for every k-mer -- about 10 probes at load 0.6 -- and this LDS-latency-bound loop ran at a fifth of the
-        // speed; the lane-independent walk waits once, for the largest SUM of BATCH chains.)  The next batch is already on
-        // its way from HBM.
-        unsigned long long cur[BATCH], nxt[BATCH];
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) { const uint64_t i = beg + (uint64_t)u * BLOCK + tid; cur[u] = i < end ? item(i) : EMPTY; }
-        for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)BATCH * BLOCK) {
-          const uint64_t i1 = i0 + (uint64_t)BATCH * BLOCK;
-#pragma unroll
-          for (int u = 0; u < BATCH; ++u) { const uint64_t i = i1 + (uint64_t)u * BLOCK + tid; nxt[u] = i < end ? item(i) : EMPTY; }
-          if (!prefetched) { if (rn < r_hi) prefetch(rn); prefetched = true; }     // issued AFTER the first batches: their wait does not cover these
-          const uint32_t nv = BATCH;                                                // (EMPTY entries -- padding, the tail -- are stepped over)
-          uint32_t u = 0, slot = 0, probes = 0;
-          unsigned long long key = EMPTY;
-          auto start = [&]() {                                                      // load k-mer u into the walk state
-              while (u < nv) {
-                  key = cur[0];
-#pragma unroll
-                  for (int q = 1; q < BATCH; ++q) key = u == (uint32_t)q ? cur[q] : key;
-                  if (key == EMPTY) { ++u; continue; }
-                  slot = home_offset(key, t);
-                  probes = 0;
-                  if (!(TEST_SPILL && spill_mod && __umulhi((uint32_t)(mix64(key) >> 32), spill_mod) == 0)) break;   // test hook: 1 k-mer in spill_mod takes the spill path
-                  spill[atomicAdd(spill_n, 1ULL)] = key;
-                  ++u;
-              }
-          };
-          start();
-          while (__any(u < nv)) {
-              if (u < nv) {
-                  unsigned long long c0 = rk[slot];
-                  if (c0 == EMPTY) {
-                      c0 = atomicCAS(&rk[slot], (unsigned long long)EMPTY, key);
-                      if (c0 == EMPTY) { ++new_distinct; c0 = key; }
-                  }
-                  bool fin = false;
-                  if (c0 == key) {
-                      // LDS returning add: a 32-bit wrap is seen right here and chained into the side table, so a round may
-                      // carry any number of copies of one k-mer and needs no host-side overflow guard
-                      if (atomicAdd(&rc[slot], 1u) == 0xFFFFFFFFu) ovf_add(t, key, 1ULL << 32);
-                      fin = true;
-                  } else {
-                      slot = slot + 1 == S ? 0 : slot + 1;
-                      if (++probes == S) { spill[atomicAdd(spill_n, 1ULL)] = key; fin = true; }      // region full: direct path later
-                  }
-                  if (fin) { ++u; start(); }
-              }
-          }
-#pragma unroll
-          for (int q = 0; q < BATCH; ++q) cur[q] = nxt[q];
-        }
-        lds_barrier();
-        for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; t.counts[base + i] = rc[i]; }
-        lds_barrier();                                          // LDS is overwritten with the next region at the loop top
-        r = rn;
-    }
-    flush_distinct(t, new_distinct);
-}
-
-// ---- level 3, second edition: the walk as straight-line batches ----
-// k_p3_apply's walk is bound by dependent LDS round trips, not by LDS or VALU throughput (profiles/r01_partitioned_sq_counters.txt:
-// waves parked 67 % of their cycles, LDS array 15 % busy): every lane runs one probe chain at a time inside a divergent loop.
+// ---- level 3: apply a region's run to the region, in LDS (KV12 tables: keys[S] u64 | counts[S] u32) ----
+// A walk with one probe chain per lane inside a divergent loop (round 1's kernel) is bound by dependent LDS round trips, not by LDS
+// or VALU throughput (profiles/r01_partitioned_sq_counters.txt: waves parked 67 % of their cycles, LDS array 15 % busy).
 // Here a wave takes U k-mers per lane and runs NR probe rounds over all of them in straight-line code: U independent
 // ds_read_b64 in flight per wave and one wait per round; a k-mer whose slot holds its key gets a NO-RETURN ds_add and is done.
 // What is left after NR rounds -- k-mers that met an EMPTY slot (a new key: needs the CAS claim) or a chain longer than NR --
@@ -799,11 +687,12 @@ constexpr uint64_t AP2_SEGMENT = 0x7FF00000ULL;               // k-mers per walk
 
 template <int BLOCK, int KP /* 16-byte key loads per lane that cover a region */, int U, int NR, int HB /* high bytes of an item */, bool STAMP = false, bool INLINE_CLAIM = false, bool DYN = true,
           int QCAP = AP2_QCAP /* queue entries per wave: what the region leaves of the LDS */,
-          bool INIT = false /* a table whose slots have never been written (katgpu.hip "lazy tables"): regions start EMPTY in LDS without a load, and EVERY region of the pass is visited and written back */>
+          bool TEST_SPILL = false /* honours spill_mod (one k-mer in spill_mod takes the spill path): instantiated for the test suite only */>
 __global__ void __launch_bounds__(BLOCK)
 k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
             uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n,
-            const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend, unsigned long long* __restrict__ stamps = nullptr) {
+            const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend, unsigned long long* __restrict__ stamps = nullptr, uint32_t spill_mod = 0,
+            uint64_t seg_len = AP2_SEGMENT /* k-mers per walk; a multiple of 4 (tests shorten it) */) {
     // STAMP (diagnostic instantiation): cycle stamps of wave 0: [0] fill + sweep, [1] chunk loads + hash, [2] probe rounds, [3] queue push + drains,
     // [4] wait for the other waves, [5] write-back, [6] regions
     unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -829,19 +718,11 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
     };
     auto next_region = [&](uint32_t from) {
         uint32_t r = from;
-        if (INIT) return r;                                     // (regions without k-mers are written too)
         while (r < r_hi && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
         return r;
     };
     auto prefetch = [&](uint32_t r) {
         const uint64_t base = (uint64_t)r * S;
-        if (INIT) {
-#pragma unroll
-            for (int u = 0; u < KP; ++u) kq[u] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#pragma unroll
-            for (int u = 0; u < CP; ++u) cq[u] = u32x4{0u, 0u, 0u, 0u};
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; kq[u] = *reinterpret_cast<const u32x4*>(t.keys + base + (i < S ? i : 0)); }    // clamped, unconditional: stays in registers
 #pragma unroll
@@ -864,8 +745,8 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
         // the home slot comes straight from the remainder, the k-mer (what the slots hold) through the inverse hash
         const uint64_t base1 = place_base1(r >> g.l2, g.pl.n, g.pl.p1), d2_hi = g.pl.rb < 64 ? (uint64_t)(r & (g.P2 - 1)) << g.pl.rb : 0ULL;
 
-        for (uint64_t sbeg = beg; sbeg < end; sbeg += AP2_SEGMENT) {        // one segment, normally
-            const uint64_t n_run = (end - sbeg < AP2_SEGMENT ? end - sbeg : AP2_SEGMENT);
+        for (uint64_t sbeg = beg; sbeg < end; sbeg += seg_len) {            // one segment, normally
+            const uint64_t n_run = (end - sbeg < seg_len ? end - sbeg : seg_len);
             if (tid == 0) s_next_chunk = NW;                  // chunks 0 .. NW-1 are the waves' first ones
             lds_barrier();
             // counters that could wrap during this walk hand 2^31 to the side table (each lane looks at the quads it filled)
@@ -988,6 +869,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                     pend[u] = c_in && rem != L2Fmt<HB>::NONE;
                     slot[u] = place_offset(rem, g.pl, S);
                     cur[u] = place_key(base1, d2_hi | rem, g.pl);
+                    if (TEST_SPILL && spill_mod && pend[u] && __umulhi((uint32_t)(mix64(cur[u]) >> 32), spill_mod) == 0) { spill[atomicAdd(spill_n, 1ULL)] = cur[u]; pend[u] = false; }
                 }
                 const unsigned long long t_b = now();
                 // Probe rounds: U reads in flight, one wait; a match adds 1 and is done, a foreign key moves on, an EMPTY slot is
@@ -1071,6 +953,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                 c = c_next;
                 if (STAMP) { const unsigned long long t_d = now(); st[1] += t_b - t_a; st[2] += t_c - t_b; st[3] += t_d - t_c; }
             }
+            if (sbeg + seg_len < end) lds_barrier();               // another segment follows: no wave may still be grabbing chunks of this one when the counter is reset
         }
         if (rn < r_hi) prefetch(rn);                           // in flight behind the write-back
         const unsigned long long t_w = now();
@@ -1090,9 +973,286 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
     flush_distinct(t, new_distinct);
 }
 
+// ---- level 3 for packed tables (kg_device.hpp "P8": one 64-bit word per slot = remainder << cbits | count, 0 = free) ----
+// The same walk as k_p3_apply2 on 8-byte slots.  An item of the level-2 buffer IS what a slot stores (the remainder), so nothing is
+// decoded: the home slot comes from the remainder, a hit is `word >> cbits == remainder` and ONE no-return ds_add_u64, a claim is
+// one compare-and-swap 0 -> remainder | 1 (claim and first count together).  A region of 9344 slots is 73 KB instead of 110: two
+// 512-thread workgroups share a CU -- while one fills or writes back its region the other walks -- and the table is swept at 16
+// bytes per slot and round instead of 24.  Queue entries are one word: remainder | slot << 44 (remainders have at most 44 bits in a
+// packed table); the probes an entry has left follow from its distance to the remainder's home slot.
+// No-return adds cannot report a carry out of the count field, so none may happen: before a walk every counter above half its
+// range hands the excess to the side table (keyed by the slot), and a walk covers fewer than half the range (longer runs are
+// walked in segments; the host passes seg_len).
+constexpr int APK_LANE_PROBES = 12;
+constexpr uint32_t APK_SLOT_SHIFT = 44;
+
+template <int BLOCK, int KP /* 16-byte loads per lane that cover a region: two slots each */, int HB, bool INLINE_CLAIM = false, bool TEST_SPILL = false>
+__global__ void __launch_bounds__(BLOCK)
+k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
+              uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend,
+              uint32_t qcap /* queue entries per wave: what the region leaves of the LDS; >= 72 */, uint64_t seg_len /* k-mers per walk: a multiple of 4 below half the count range */,
+              uint32_t spill_mod) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int NW = BLOCK / 64, U = 4, NR = 3;
+    constexpr uint32_t CH = 64 * U;
+    const uint32_t S = g.S, cb = g.cbits;                     // S % 4 == 0 (host-checked)
+    const uint64_t cmask = pk_cmask(cb), half = pk_half(cb), rem_mask = (1ULL << APK_SLOT_SHIFT) - 1;
+    unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long* wq = rk + S + (size_t)wave * qcap;
+    uint32_t new_distinct = 0;
+    u32x4 kq[KP];
+    __shared__ unsigned long long s_next_chunk;               // chunks of the run are handed out to the waves as they come free
+
+    const uint32_t r_hi = g.b_hi * g.P2;                       // regions [b_lo * P2, r_hi): this launch's
+    auto run_end = [&](uint32_t r) -> uint64_t {
+        if (bend && (r + 1) % g.P2 == 0) return bend[r / g.P2];
+        return off2[r + 1];
+    };
+    auto next_region = [&](uint32_t from) {
+        uint32_t r = from;
+        while (r < r_hi && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
+        return r;
+    };
+    auto prefetch = [&](uint32_t r) {
+        const uint64_t base = (uint64_t)r * S;
+#pragma unroll
+        for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; kq[u] = *reinterpret_cast<const u32x4*>(t.keys + base + (i < S ? i : 0)); }    // clamped, unconditional: stays in registers
+    };
+    auto next_slot = [&](uint32_t s) -> uint32_t { return s + 1 == S ? 0 : s + 1; };
+    auto add1 = [&](uint32_t slot) { (void)__hip_atomic_fetch_add(&rk[slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+
+    uint32_t r = next_region(g.b_lo * g.P2 + blockIdx.x);
+    if (r < r_hi) prefetch(r);
+    while (r < r_hi) {
+        const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : run_end(r);
+        const uint64_t base = (uint64_t)r * S;
+        // ---- fill: registers -> LDS ----
+#pragma unroll
+        for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(rk + i) = kq[u]; }
+        const uint32_t rn = next_region(r + gridDim.x);
+        // what spilling a k-mer (region full, test hook) needs: the region's digits give the k-mer back
+        const uint64_t base1 = place_base1(r >> g.l2, g.pl.n, g.pl.p1), d2_hi = g.pl.rb < 64 ? (uint64_t)(r & (g.P2 - 1)) << g.pl.rb : 0ULL;
+        auto spill_rem = [&](uint64_t rem) { spill[atomicAdd(spill_n, 1ULL)] = place_key(base1, d2_hi | rem, g.pl); };
+
+        for (uint64_t sbeg = beg; sbeg < end; sbeg += seg_len) {            // one segment, normally
+            const uint64_t n_run = (end - sbeg < seg_len ? end - sbeg : seg_len);
+            if (tid == 0) s_next_chunk = NW;                  // chunks 0 .. NW-1 are the waves' first ones
+            lds_barrier();
+            // counters that could carry during this walk keep 1 .. half and hand the rest to the side table (each lane looks at the slots it filled)
+#pragma unroll 1
+            for (int u = 0; u < KP; ++u) {
+                const uint32_t i = (u * BLOCK + tid) * 2;
+                if (i >= S) break;
+                const u64x2 ww = *reinterpret_cast<const u64x2*>(rk + i);
+                if ((ww.x & cmask) <= half && (ww.y & cmask) <= half) continue;
+#pragma unroll 1
+                for (uint32_t j = 0; j < 2; ++j) {
+                    const unsigned long long w = rk[i + j];
+                    const uint64_t c = w & cmask;
+                    if (c <= half) continue;
+                    const uint64_t keep = ((c - 1) & (half - 1)) + 1;
+                    rk[i + j] = w - (c - keep);
+                    ovf_add(t, base + i + j, c - keep);
+                }
+            }
+            lds_barrier();
+
+            // ---- the walk ----
+            uint32_t q_n = 0;                                     // entries in this wave's queue (wave-uniform)
+            // One pass over up to 64 queue entries (taken from the tail).  Phase 1, one entry per lane: dependent probes with the
+            // claim, while at least 8 lanes are busy and for at most APK_LANE_PROBES probes.  Phase 2: what is left is on a long
+            // chain: the WAVE finishes such a k-mer, 64 consecutive slots per read.
+            auto drain_pass = [&](bool fin /* nothing will follow: leave no entry behind */) {
+                const uint32_t take = q_n < 64 ? q_n : 64;
+                q_n -= take;
+                bool live = lane < take;
+                uint64_t rem = 0; uint32_t slot = 0, budget = 0;
+                if (live) {
+                    const unsigned long long e = wq[q_n + lane];
+                    rem = e & rem_mask; slot = (uint32_t)(e >> APK_SLOT_SHIFT);
+                    const uint32_t home = place_offset(rem, g.pl, S);
+                    budget = S - (slot >= home ? slot - home : slot + S - home);       // probes left before the region has been walked once
+                }
+#pragma unroll 1
+                for (int rr = 0; rr < APK_LANE_PROBES; ++rr) {
+                    const int busy = __popcll(__ballot(live));
+                    if (busy == 0 || (busy < 8 && (fin || rr >= 4))) break;
+                    if (live) {
+                        unsigned long long w = rk[slot];
+                        if (w == 0) {
+                            w = atomicCAS(&rk[slot], 0ULL, (unsigned long long)((rem << cb) | 1ULL));
+                            if (w == 0) { ++new_distinct; live = false; }                  // claimed, counted
+                        }
+                        if (live) {
+                            if ((w >> cb) == rem) { add1(slot); live = false; }
+                            else {
+                                slot = next_slot(slot);
+                                if (--budget == 0) { spill_rem(rem); live = false; }       // region full: direct path later
+                            }
+                        }
+                    }
+                }
+                // the wave takes over what has had its APK_LANE_PROBES (all that is left, when nothing follows); the rest goes back
+                const bool lng = live && (fin || S - budget >= (uint32_t)(APK_LANE_PROBES + NR));
+                {
+                    const bool back = live && !lng;
+                    const unsigned long long m = __ballot(back);
+                    if (m) {
+                        const uint32_t at = q_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                        if (back) wq[at] = rem | ((unsigned long long)slot << APK_SLOT_SHIFT);
+                        q_n += (uint32_t)__popcll(m);
+                    }
+                }
+                unsigned long long todo = __ballot(lng);
+#pragma unroll 1
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const unsigned long long ck = __shfl((unsigned long long)rem, src, 64);  // wave-uniform from here on
+                    uint32_t cs = __shfl(slot, src, 64);
+                    int cbud = (int)__shfl(budget, src, 64);
+#pragma unroll 1
+                    for (;;) {
+                        uint32_t idx = cs + lane; if (idx >= S) idx -= S;                      // S >= 64 on this path (host-checked)
+                        const unsigned long long w = rk[idx];
+                        const unsigned long long mk = __ballot(w != 0 && (w >> cb) == ck), me = __ballot(w == 0);
+                        if (!(mk | me)) {                                                      // 64 foreign k-mers
+                            cbud -= 64; cs = cs + 64 >= S ? cs + 64 - S : cs + 64;
+                            if (cbud <= 0) { if (lane == 0) spill_rem(ck); break; }
+                            continue;
+                        }
+                        const int first = __ffsll((long long)(mk | me)) - 1;
+                        if (first >= cbud) { if (lane == 0) spill_rem(ck); break; }            // beyond the region's last unprobed slot
+                        if ((mk >> first) & 1) { if ((int)lane == first) add1(idx); break; }
+                        unsigned long long old = 0;                                            // a free slot comes first: claim it
+                        if ((int)lane == first) old = atomicCAS(&rk[idx], 0ULL, (unsigned long long)((ck << cb) | 1ULL));
+                        old = __shfl(old, first, 64);
+                        if (old == 0) { if ((int)lane == first) ++new_distinct; break; }
+                        if ((old >> cb) == ck) { if ((int)lane == first) add1(idx); break; }   // the same k-mer got there first
+                        cbud -= first; cs = cs + first >= S ? cs + first - S : cs + first;     // someone else's k-mer landed there: go on from that slot
+                    }
+                }
+            };
+
+            const uint64_t n_chunks = (n_run + CH - 1) / CH;         // chunk c = groups [64 c, 64 c + 64) of the run
+            const uint64_t n_grp = (n_run + 3) >> 2, g0 = sbeg >> 2;      // (runs start on group boundaries and end on "no item" padding)
+            u32x4 c_lo, n_lo;
+            typename HiGroup<HB>::type c_hi{}, n_hi{};
+            bool c_in, n_in;                                      // the lane's group lies inside the run
+            { const uint64_t gi = (uint64_t)wave * 64 + lane; c_in = gi < n_grp; l2_load_group<HB>(l2_buf, g0 + (c_in ? gi : 0), c_lo, c_hi); }
+            auto grab = [&]() -> uint64_t {
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(&s_next_chunk, 1ULL);
+                return __shfl(v, 0, 64);
+            };
+            for (uint64_t c = wave; c < n_chunks;) {
+                const uint64_t c_next = grab();
+                {                                             // next chunk: in flight behind this one (unconditional loads from a clamped index)
+                    const uint64_t gi = c_next * 64 + lane;
+                    n_in = gi < n_grp;
+                    l2_load_group<HB>(l2_buf, g0 + (n_in ? gi : 0), n_lo, n_hi);
+                }
+                uint64_t rem[U];
+                uint32_t slot[U];
+                bool pend[U];                                     // k-mer u still to be placed (lane masks in SGPRs)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    rem[u] = ((uint64_t)hi_of_group<HB>(c_hi, u) << 32) | (u == 0 ? c_lo.x : u == 1 ? c_lo.y : u == 2 ? c_lo.z : c_lo.w);
+                    pend[u] = c_in && rem[u] != L2Fmt<HB>::NONE;
+                    slot[u] = place_offset(rem[u], g.pl, S);
+                    if (TEST_SPILL && spill_mod && pend[u] && __umulhi((uint32_t)(mix64(place_key(base1, d2_hi | rem[u], g.pl)) >> 32), spill_mod) == 0) { spill_rem(rem[u]); pend[u] = false; }
+                }
+                // Probe rounds: U reads in flight, one wait; a match adds 1 and is done, a foreign k-mer moves on, a free slot is
+                // claimed (inline, or through the queue).  Lanes that are done take no part in the LDS operations.
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) {
+                    unsigned long long seen[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { seen[u] = 0; if (pend[u]) seen[u] = rk[slot[u]]; }
+                    bool claim[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const bool hit = pend[u] && seen[u] != 0 && (seen[u] >> cb) == rem[u];
+                        if (hit) add1(slot[u]);
+                        pend[u] = pend[u] && !hit;
+                        claim[u] = pend[u] && seen[u] == 0;
+                        slot[u] = (pend[u] && !claim[u]) ? next_slot(slot[u]) : slot[u];
+                    }
+                    // INLINE_CLAIM (a table's first round: nearly every k-mer is new): claims right here, U CAS in flight
+                    bool any_claim = false;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) any_claim = any_claim || claim[u];
+                    if (INLINE_CLAIM && __any(any_claim)) {
+                        unsigned long long got[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) { got[u] = 0; if (claim[u]) got[u] = atomicCAS(&rk[slot[u]], 0ULL, (unsigned long long)((rem[u] << cb) | 1ULL)); }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (claim[u]) {
+                                if (got[u] == 0) { ++new_distinct; pend[u] = false; }
+                                else if ((got[u] >> cb) == rem[u]) { add1(slot[u]); pend[u] = false; }
+                                else slot[u] = next_slot(slot[u]);                             // someone else's k-mer landed there
+                            }
+                        }
+                    }
+                }
+                // survivors -> queue.  Normal case: one wave-wide prefix sum; a chunk with more survivors than the queue has room for
+                // goes in one k-mer column at a time.
+                uint32_t mine = 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) mine += pend[u] ? 1u : 0u;
+                uint32_t tot = mine;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(tot, d, 64); if (lane >= (uint32_t)d) tot += o; }
+                const uint32_t total = __shfl(tot, 63, 64);
+                if (q_n + total <= qcap) {
+                    uint32_t at = q_n + tot - mine;
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (pend[u]) { wq[at] = rem[u] | ((unsigned long long)slot[u] << APK_SLOT_SHIFT); ++at; }
+                    q_n += total;
+                } else {
+                    uint32_t pm = 0;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) pm |= pend[u] ? 1u << u : 0u;
+#pragma unroll 1
+                    for (int it = 0; it < U; ++it) {
+                        const bool p = pm & 1;
+                        const unsigned long long m = __ballot(p);
+                        if (m) {
+                            while (q_n > qcap - 64) drain_pass(false);
+                            const uint32_t at = q_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                            if (p) wq[at] = rem[0] | ((unsigned long long)slot[0] << APK_SLOT_SHIFT);
+                            q_n += (uint32_t)__popcll(m);
+                        }
+                        pm >>= 1;
+#pragma unroll
+                        for (int u = 0; u + 1 < U; ++u) { rem[u] = rem[u + 1]; slot[u] = slot[u + 1]; }
+                    }
+                }
+                const bool last = c_next >= n_chunks;                     // the wave's last chunk empties the queue
+                while (q_n > (last ? 0u : 64u)) drain_pass(last);
+                c_lo = n_lo; c_hi = n_hi; c_in = n_in;
+                c = c_next;
+            }
+            if (sbeg + seg_len < end) lds_barrier();               // another segment follows: no wave may still be grabbing chunks of this one when the counter is reset
+        }
+        if (rn < r_hi) prefetch(rn);                           // in flight behind the write-back
+
+        // ---- write-back: LDS -> HBM, 16 bytes per lane and store ----
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(t.keys + base + i) = *reinterpret_cast<const u32x4*>(rk + i); }
+        lds_barrier();
+        r = rn;
+    }
+    flush_distinct(t, new_distinct);
+}
+
 // spilled k-mers (count 1 each) through the direct path.  Checked adds (table_add sees a 32-bit wrap itself): these lists
 // are short, and the unchecked table_inc would oblige the host to sweep the whole table first (katgpu.hip: maybe_sweep).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_insert_keys(DevTable t, const uint64_t* __restrict__ keys, uint64_t n) {
     uint32_t new_distinct = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;

@@ -86,7 +86,7 @@ k_count_w(DevTable t, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_
 }
 
 // K2 for wide tables: hash_counter::double_size (hash_counter.hpp:204-244)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_regrow_w(DevTable dst, DevTable src, uint32_t src_n_ovf) {
     uint32_t new_distinct = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -98,7 +98,7 @@ k_regrow_w(DevTable dst, DevTable src, uint32_t src_n_ovf) {
 }
 
 // K7 for wide tables: (hi, lo, count) records into a table
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_merge_w(DevTable dst, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, const uint64_t* __restrict__ counts, uint64_t n) {
     uint32_t new_distinct = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -108,7 +108,7 @@ k_merge_w(DevTable dst, const uint64_t* __restrict__ hi, const uint64_t* __restr
 }
 
 // every (k-mer, count) of the table, in slot order: a wave compacts its occupied lanes with one ballot and one cursor add
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_export_w(DevTable t, uint32_t n_ovf, uint64_t* __restrict__ hi, uint64_t* __restrict__ lo, uint64_t* __restrict__ counts, unsigned long long* cursor) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,7 +149,7 @@ k_partition_w(DevTable t, uint32_t n_ovf, uint32_t n_parts, unsigned long long* 
 }
 
 // batch lookup (JellyfishHelper::getCount, lib/src/jellyfish_helper.cc:189-194)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_get_w(DevTable t, uint32_t n_ovf, const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint64_t n, int canonicalise, uint64_t* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
