@@ -1,0 +1,87 @@
+"""The partitioned counter at the geometry `bench.py` runs -- not the tiny regions and rounds the hooks of
+tests/test_gpu_partition.py force -- compared k-mer by k-mer with the direct kernel ON THE DEVICE.
+
+The oracle cannot count 12 G k-mers in seconds, so the checker here is the product's own direct path (one atomic per k-mer,
+kg_kernels.hpp: k_count), which the parity suite pins to the oracle table-dump by table-dump at every size the oracle reaches:
+the same reads go once through `count_bases_device` as a whole (>= 32 M window starts: partition rounds with production
+thresholds -- the 512 x 1024 grid of 9344-slot regions of BASELINE.json's config 4, packed slots, 5-byte level-2 items, two passes of
+256 buckets) and once in slices below the threshold (the direct kernel) into a second table of the same grid.  katgpu_comp then joins
+the two: every k-mer of one must be in the other with the same count (all mass on the matrix diagonal, shared == distinct,
+shared totals == totals), and the histograms must agree bucket by bucket.  A bug that moves counts between k-mers while preserving
+the totals -- invisible to tests/test_gpu_scale_properties.py -- cannot pass this."""
+import numpy as np
+import pytest
+
+import kat_amd
+
+pytestmark = pytest.mark.gpu
+
+L = 150
+
+
+def _expected_distinct(inst, genome, k, err_ppm=2000):
+    p_err = 1.0 - (1.0 - err_ppm / 1e6) ** k
+    return int(min(inst, genome + inst * p_err * 1.05))
+
+
+def _both_ways(engine, k, n_reads, genome, hint):
+    g = engine.synth_genome(genome, seed=20260927)
+    reads = engine.synth_reads(g, genome, first_read=0, n_reads=n_reads, read_len=L, frag_len=350, err_ppm=2000, seed=1)
+    g.free()
+    engine.profile_reset()
+    tp = engine.table(k, True, size_hint=hint)
+    tp.count_bases_device(reads.ptr, reads.nbytes)
+    prof = engine.profile()
+    assert prof["part_apply"]["launches"] > 0 and prof["part_l1_scatter"]["launches"] > 0 and prof["count"]["launches"] == 0, prof
+    engine.profile_reset()
+    td = engine.table(k, True, size_hint=hint, like=tp)
+    rec = L + 1
+    step = 100_000                                            # 15.1 M window starts per call: below the partitioned counter's threshold
+    for a in range(0, n_reads, step):
+        b = min(n_reads, a + step)
+        td.count_bases_device(reads.ptr + a * rec, (b - a) * rec)
+    prof = engine.profile()
+    assert prof["part_apply"]["launches"] == 0 and prof["count"]["launches"] > 0, prof
+    reads.free()
+    return tp, td
+
+
+def _same_tables(tp, td, inst):
+    sp_, sd = tp.stats(), td.stats()
+    assert sp_["total"] == sd["total"] == inst
+    assert sp_["distinct"] == sd["distinct"]
+    assert sp_["capacity"] == sd["capacity"]
+    mx, cc, spec = kat_amd.comp(tp, td)
+    assert int(cc[0]) == int(cc[1]) == inst                                          # totals
+    assert int(cc[3]) == int(cc[4]) == int(cc[12]) == sp_["distinct"]                # distinct 1 == distinct 2 == shared
+    assert int(cc[10]) == int(cc[11]) == inst                                        # shared totals: every instance, on both sides
+    assert int(cc[6]) == int(cc[7]) == int(cc[8]) == int(cc[9]) == 0                 # nothing only in one
+    off = mx.copy()
+    np.fill_diagonal(off, 0)
+    assert int(off.sum()) == 0, "k-mers whose counts differ between the partitioned and the direct counter: %d" % int(off.sum())
+    assert int(np.trace(mx)) == sp_["distinct"]
+    assert np.array_equal(spec[0], spec[1]) and np.array_equal(spec[2], spec[3])
+    assert np.array_equal(tp.hist(high=100000), td.hist(high=100000))
+
+
+def test_config4_geometry_partitioned_equals_direct(engine):
+    """k = 27, the table of config 4 (300 M reads vs 1 Gbp: 4.9 G slots), filled from 100 M reads of that library: one full
+    12.4 G-item round in two passes.  ~40 GB per table, ~15 GB of reads, the arena: fits one MI355X."""
+    k, genome, n_reads = 27, 1_000_000_000, 100_000_000
+    hint = int(_expected_distinct(300_000_000 * (L - k + 1), genome, k) / 0.62) + (1 << 20)     # bench.py's hint1
+    tp, td = _both_ways(engine, k, n_reads, genome, hint)
+    geo = tp.geometry()
+    assert (geo.p1, geo.p2) == (512, 1024) and geo.region_slots > 8192, (geo.p1, geo.p2, geo.region_slots)
+    _same_tables(tp, td, n_reads * (L - k + 1))
+    tp.free(); td.free()
+    engine.release_scratch()
+
+
+def test_config5_geometry_partitioned_equals_direct(engine):
+    """k = 31 (6-byte level-2 items, 21-bit in-slot counters), the per-GPU table of config 5."""
+    k, genome, n_reads = 31, 1_000_000_000, 75_000_000
+    hint = int(_expected_distinct(n_reads * (L - k + 1), genome, k) / 0.62) + (1 << 20)        # bench.py --workload comp-rr
+    tp, td = _both_ways(engine, k, n_reads, genome, hint)
+    _same_tables(tp, td, n_reads * (L - k + 1))
+    tp.free(); td.free()
+    engine.release_scratch()

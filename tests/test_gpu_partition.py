@@ -1,4 +1,5 @@
 """The partitioned counter (kg_partition.hpp: two-level radix partition + regions applied in LDS) vs the oracle.
+(tests/test_gpu_bench_geometry.py runs it at the bench's geometry against the direct kernel.)
 
 Production thresholds send only >= 32 M-start inputs down this path; the test hooks force it for small inputs with
 small regions / rounds so that multi-round accumulation, region spills, regrows and ragged tiles are all exercised at
@@ -36,25 +37,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     (512, 100000, 0, {"KATGPU_TEST_PASS_BUCKETS": "5"}), (1024, 3000000, 7, {"KATGPU_P2_FAST": "2", "KATGPU_TEST_PASS_BUCKETS": "3"}),
     (2048, 250000, 3, {"KATGPU_P2_FAST": "2", "KATGPU_TEST_P2_OVF_CAP": "3", "KATGPU_TEST_PASS_BUCKETS": "2"}),
     (512, 150000, 3, {"KATGPU_L1_FAST": "2", "KATGPU_TEST_L1_CPB": "2", "KATGPU_TEST_P2_OVF_CAP": "50", "KATGPU_P1_WGS": "1", "KATGPU_TEST_PASS_BUCKETS": "7"}),
-    (1024, 200000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2", "KATGPU_TEST_GROW_NOMEM": "1", "KATGPU_TEST_PASS_BUCKETS": "1"})])
+    (1024, 200000, 0, {"KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2", "KATGPU_TEST_GROW_NOMEM": "1", "KATGPU_TEST_PASS_BUCKETS": "1"}),
+    # Slot layouts.  With these region sizes the k = 27 and k = 15 tables of the cases are packed (8-byte slots: remainder | count)
+    # once they have 2^10 regions or more, the k = 31 / 32 ones and every small table KV12, and tables regrow from one into the other
+    # in mid-call.  no_packed: every table KV12 (the apply, join and merge kernels of that layout).  ap_seg: the apply kernels walk
+    # a run in segments of this many k-mers (production: 2^31 resp. half the in-slot count range) -- several segments per region.
+    (512, 100000, 0, {"KATGPU_NO_PACKED": "1"}), (1024, 3000000, 7, {"KATGPU_NO_PACKED": "1", "KATGPU_P2_FAST": "2"}),
+    (8192, 400000, 0, {"KATGPU_NO_PACKED": "1", "KATGPU_L1_FAST": "2"}),
+    (512, 100000, 0, {"KATGPU_TEST_AP_SEG": "64"}), (2048, 250000, 0, {"KATGPU_TEST_AP_SEG": "1024", "KATGPU_P2_FAST": "2"}),
+    (1024, 3000000, 0, {"KATGPU_TEST_AP_SEG": "256", "KATGPU_NO_PACKED": "1"}),
+    (256, 3000000, 0, {}), (256, 3000000, 5, {"KATGPU_APPLY_PER_CU": "1"})])
 def test_partitioned_counter_matches_oracle(region_slots, round_items, spill_mod, extra):
     env = dict(os.environ, KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
                KATGPU_TEST_ROUND_ITEMS=str(round_items), KATGPU_TEST_SPILL_MOD=str(spill_mod))
-    env.update(extra)
-    r = subprocess.run([sys.executable, os.path.join(HERE, "partition_cases.py")], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "partition cases ok" in r.stdout
-
-
-# The super-k-mer counter (kg_superkmer.hpp) on tables with minimizer regions -- off in production this round, forced on here
-# for every table of two regions or more: segmented level 1 with overflow (tiny rounds: every segment is nearly all slack), exact
-# level 1, regrows from a one-region (hash-placed) table into minimizer regions in the middle of a call, spills out of full regions.
-@pytest.mark.parametrize("region_slots,round_starts,extra", [
-    (8192, 400000, {}), (512, 100000, {}), (2048, 250000, {"KATGPU_L1_FAST": "2"}),
-    (1024, 150000, {"KATGPU_L1_FAST": "2", "KATGPU_TEST_L1_CPB": "3"}), (4096, 300000, {"KATGPU_L1_FAST": "0", "KATGPU_TEST_GROW_NOMEM": "1"})])
-def test_superkmer_counter_matches_oracle(region_slots, round_starts, extra):
-    env = dict(os.environ, KATGPU_MZ_MIN_REGIONS="2", KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
-               KATGPU_TEST_ROUND_ITEMS=str(round_starts), KATGPU_TEST_SPILL_MOD="0")
     env.update(extra)
     r = subprocess.run([sys.executable, os.path.join(HERE, "partition_cases.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
