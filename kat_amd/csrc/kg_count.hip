@@ -198,9 +198,10 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
         while (per_cu > 1 && room(per_cu) < (long)(8 * 96 * 8)) --per_cu;                      // at least 96 queue entries per wave
         if (g_apply_per_cu) per_cu = std::min(per_cu, g_apply_per_cu);
         uint32_t blk = per_cu == 1 ? 1024 : 512;
-        if (g_apply_block == 512 || g_apply_block == 1024) blk = g_apply_block;
+        if (g_apply_block == 512 || g_apply_block == 768 || g_apply_block == 1024) blk = g_apply_block;
+        if (blk == 768 && (g.S > 7 * 768 * 2 || per_cu < 2)) blk = per_cu == 1 ? 1024 : 512;   // (the 768-thread shape covers 10752 slots and wants a partner on the CU)
         if (hooked) { blk = 1024; per_cu = 1; }
-        if (blk == 1024) per_cu = std::min<uint32_t>(per_cu, 2);
+        per_cu = std::min<uint32_t>(per_cu, 2048 / blk);
         const uint32_t nw = blk / 64;
         while (per_cu > 1 && room(per_cu) < (long)(nw * 72 * 8)) --per_cu;
         const uint32_t qcap = (uint32_t)std::min<long>(256, room(per_cu) / (long)(nw * 8));
@@ -209,14 +210,15 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
         const uint64_t seg_cap = (pk_half(g.cbits) - 1) & ~3ULL;                              // a walk adds less than half the count range
         const uint64_t seg_len = g_test_ap_seg ? std::min<uint64_t>(g_test_ap_seg, seg_cap) : std::min<uint64_t>(AP2_SEGMENT, seg_cap);
         const dim3 grid(std::min<uint32_t>(regions, n_cu * per_cu));
-#define KG_APK(B, KP, HB, INL, HK) do { KG_LDS_ATTR((k_p3_apply_pk<B, KP, HB, INL, HK>), LDS_BYTES - 256); \
-            hipLaunchKernelGGL((k_p3_apply_pk<B, KP, HB, INL, HK>), grid, dim3(B), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, \
+#define KG_APK(B, KP, HB, INL, HK, PF) do { KG_LDS_ATTR((k_p3_apply_pk<B, KP, HB, INL, HK, PF>), LDS_BYTES - 256); \
+            hipLaunchKernelGGL((k_p3_apply_pk<B, KP, HB, INL, HK, PF>), grid, dim3(B), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, \
                                qcap, seg_len, g_test_spill_mod); } while (0)
 #define KG_APK_SHAPE(HB) case HB: \
-            if (hooked) KG_APK(1024, 5, HB, false, true); \
-            else if (blk == 1024) { if (fresh) KG_APK(1024, 5, HB, true, false); else KG_APK(1024, 5, HB, false, false); } \
-            else if (g.S <= 4096) { if (fresh) KG_APK(512, 4, HB, true, false); else KG_APK(512, 4, HB, false, false); } \
-            else { if (fresh) KG_APK(512, 10, HB, true, false); else KG_APK(512, 10, HB, false, false); } \
+            if (hooked) KG_APK(1024, 5, HB, false, true, true); \
+            else if (blk == 1024) { if (fresh) KG_APK(1024, 5, HB, true, false, true); else KG_APK(1024, 5, HB, false, false, true); } \
+            else if (blk == 768) { if (fresh) KG_APK(768, 7, HB, true, false, false); else KG_APK(768, 7, HB, false, false, false); } \
+            else if (g.S <= 4096) { if (fresh) KG_APK(512, 4, HB, true, false, true); else KG_APK(512, 4, HB, false, false, true); } \
+            else { if (fresh) KG_APK(512, 10, HB, true, false, false); else KG_APK(512, 10, HB, false, false, false); } \
             break;
         switch (g.hb) { KG_APK_SHAPE(0) KG_APK_SHAPE(1) KG_APK_SHAPE(2) default: return fail(c, KATGPU_ERR_DEVICE, "packed apply: item width %u", g.hb); }
 #undef KG_APK_SHAPE

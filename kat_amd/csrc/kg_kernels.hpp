@@ -370,7 +370,7 @@ __device__ __forceinline__ void comp_account(bool occ, uint64_t ca, uint64_t cb,
 }
 
 // block-level flush of the accumulators, the matrix tile and the spectra (end of a comp kernel)
-template <int PASS>
+template <int PASS, bool TILE = true /* false: the tile is another pass's to flush (k_comp_fused) */>
 __device__ __forceinline__ void comp_flush(const CompArgs& a, unsigned long long* s_acc, uint32_t* s_tile, uint32_t* s_spec, const CompAcc& acc) {
     const uint32_t n_spec = (PASS == 1 ? 3u : 1u) * a.spec_size;
     block_sum_u64(s_acc, 0, acc.a_total); block_sum_u64(s_acc, 1, acc.a_distinct);
@@ -388,14 +388,16 @@ __device__ __forceinline__ void comp_flush(const CompArgs& a, unsigned long long
             atomicAdd(&a.counters[CC_H2_ONLY_TOTAL], s_acc[2]); atomicAdd(&a.counters[CC_H2_ONLY_DISTINCT], s_acc[3]);
         }
     }
-    for (uint32_t i = threadIdx.x; i < COMP_TILE * COMP_TILE; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; TILE && i < COMP_TILE * COMP_TILE; i += blockDim.x) {
         uint32_t v = s_tile[i];
         if (!v) continue;
         uint32_t r = i / COMP_TILE, c = i % COMP_TILE;
         if (r < a.d1_bins && c < a.d2_bins) atomicAdd(&a.main_mx[(uint64_t)r * a.d2_bins + c], (unsigned long long)v);
-        if (PASS == 1 && a.fold) {                                          // the tile's k-mers: spectrum1[ca], and when shared, shared_spectrum1[ca] / shared_spectrum2[cb]
+        // the tile's k-mers of pass 1 (row >= 1: a k-mer of hash 1 counts at least 1; row 0 is where pass 2 puts what only hash 2
+        // has): spectrum1[ca], and when shared, shared_spectrum1[ca] / shared_spectrum2[cb]
+        if (PASS == 1 && a.fold && r) {
             atomicAdd(&s_spec[r], v);
-            if (r && c) { atomicAdd(&s_spec[a.spec_size + r], v); atomicAdd(&s_spec[2 * a.spec_size + c], v); }
+            if (c) { atomicAdd(&s_spec[a.spec_size + r], v); atomicAdd(&s_spec[2 * a.spec_size + c], v); }
         }
     }
     if (PASS == 1 && a.fold) __syncthreads();
@@ -601,6 +603,111 @@ k_comp_seen(DevTable ta /* hash 2 */, uint32_t na_ovf, CompArgs a) {
         }
     }
     comp_flush<2>(a, s_acc, s_tile, s_spec, acc);
+}
+
+// K5 (fused join): both passes of Comp::compare in one sweep of the two tables, for packed tables of one grid whose k-mers are
+// stored canonical (then "the probe key is the stored key" holds for pass 1 AND pass 2).  Region r of the RESIDENT table sits in
+// LDS, region r of the STREAMED table flows past it and probes it; every streamed k-mer marks the resident slot it finds, and a
+// sweep of the resident region in LDS afterwards accounts for the slots nobody marked.  The host streams the table with FEWER
+// k-mers: the probes are then mostly successful ones (1.75 slots at load 0.6), where k_comp_join<1> -- hash 2 resident, hash 1
+// streamed whatever the sizes -- spent 3.6 slots and a wave-long wait on each of the 2 G error k-mers of a read set that an
+// assembly does not hold.
+//   SWAP = false: hash 1 resident, hash 2 streamed.  A streamed k-mer gives pass 2 its item (count in 2, found or not) and, when
+//                 found, pass 1 the pair (count in 1, count in 2); the sweep gives pass 1 the k-mers only hash 1 has.
+//   SWAP = true:  hash 2 resident, hash 1 streamed.  A streamed k-mer is pass 1's item (count in 1, count in 2 or 0); the sweep is
+//                 pass 2: every k-mer of hash 2, found or not.
+// LDS: 16 u64 accumulators (0-6 pass 1, 8-11 pass 2) | tile 64 x 64 u32 | spectra 3 x ss (pass 1) | spectrum ss (pass 2) | the
+// resident region's S words | S / 32 mark words.
+constexpr int FUSED_BLOCK = 1024, FUSED_KP = 5;               // 5 x 1024 x 2 slots: resident regions of up to 10240 slots
+template <bool SWAP>
+__global__ void __launch_bounds__(FUSED_BLOCK)
+k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_raw);
+    uint32_t* s_tile = reinterpret_cast<uint32_t*>(s_raw + 16 * sizeof(unsigned long long));
+    uint32_t* s_spec1 = s_tile + COMP_TILE * COMP_TILE;
+    uint32_t* s_spec2 = s_spec1 + 3 * a.spec_size;
+    const DevTable& tr = SWAP ? t2 : t1;                      // resident
+    const DevTable& ts = SWAP ? t1 : t2;                      // streamed
+    const uint32_t nr_ovf = SWAP ? n2_ovf : n1_ovf, ns_ovf = SWAP ? n1_ovf : n2_ovf;
+    const uint32_t Sr = tr.region_slots, Ss = ts.region_slots, cb = tr.cbits;          // one grid: one remainder width, one cbits
+    unsigned long long* rk = reinterpret_cast<unsigned long long*>(s_raw + ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * a.spec_size * 4 + 15) & ~15u));
+    uint32_t* s_mark = reinterpret_cast<uint32_t*>(rk + Sr);
+    const uint32_t mark_words = (Sr + 31) / 32;
+    const uint32_t tid = threadIdx.x;
+    comp_lds_init(a, 1, s_acc, s_tile, s_spec1);
+    for (uint32_t i = tid; i < a.spec_size; i += blockDim.x) s_spec2[i] = 0;
+    CompAcc acc1, acc2;
+    const Place pl = place_make(tr.k, tr.p1, tr.n1, tr.l2);
+    const uint32_t R = tr.n_regions;
+    u32x4s kq[FUSED_KP];
+    auto prefetch = [&](uint32_t r) {                          // the resident region, 16 bytes per lane and load, clamped and unconditional
+        const uint64_t base = (uint64_t)r * Sr;
+#pragma unroll
+        for (int u = 0; u < FUSED_KP; ++u) { const uint32_t i = (u * FUSED_BLOCK + tid) * 2; kq[u] = *reinterpret_cast<const u32x4s*>(tr.keys + base + (i < Sr ? i : 0)); }
+    };
+    if (blockIdx.x < R) prefetch(blockIdx.x);
+    for (uint32_t r = blockIdx.x; r < R; r += gridDim.x) {
+        __syncthreads();                                       // the previous region's sweep is through
+#pragma unroll
+        for (int u = 0; u < FUSED_KP; ++u) { const uint32_t i = (u * FUSED_BLOCK + tid) * 2; if (i < Sr) *reinterpret_cast<u32x4s*>(rk + i) = kq[u]; }
+        for (uint32_t i = tid; i < mark_words; i += blockDim.x) s_mark[i] = 0;
+        __syncthreads();
+        if (r + gridDim.x < R) prefetch(r + gridDim.x);          // the next one: in flight behind this region's work
+        const uint64_t rbase = (uint64_t)r * Sr, sbase = (uint64_t)r * Ss;
+        constexpr int JB = 4;
+        for (uint32_t i0 = 0; i0 < Ss; i0 += JB * blockDim.x) {            // uniform trip count: ballots inside comp_account
+            uint64_t w[JB];
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const uint32_t i = i0 + u * blockDim.x + tid;
+                w[u] = ts.keys[sbase + (i < Ss ? i : Ss - 1)];
+                if (i >= Ss) w[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const bool occ = w[u] != 0;
+                uint64_t cs = 0, cr = 0;                                     // count in the streamed table, in the resident one
+                if (occ) {
+                    const uint32_t i = i0 + u * blockDim.x + tid;
+                    cs = pk_count(w[u], cb);
+                    if (ns_ovf) cs += ovf_get(ts, sbase + i);
+                    const uint64_t rem = pk_rem(w[u], cb);
+                    uint32_t s = place_offset(rem, pl, Sr);
+                    for (uint32_t probe = 0; probe < Sr; ++probe) {
+                        const unsigned long long cur = rk[s];
+                        if (cur == 0) break;
+                        if ((cur >> cb) == rem) {
+                            cr = pk_count(cur, cb);
+                            if (nr_ovf) cr += ovf_get(tr, rbase + s);
+                            atomicOr(&s_mark[s >> 5], 1u << (s & 31));
+                            break;
+                        }
+                        s = s + 1 == Sr ? 0 : s + 1;
+                    }
+                }
+                if (SWAP) comp_account<1>(occ, cs, cr, a, s_tile, s_spec1, acc1);                       // streamed = hash 1
+                else {
+                    comp_account<1>(occ && cr != 0, cr, cs, a, s_tile, s_spec1, acc1);                   // the pair, seen from hash 1
+                    comp_account<2>(occ, cs, cr, a, s_tile, s_spec2, acc2);                              // streamed = hash 2
+                }
+            }
+        }
+        __syncthreads();                                       // every mark is in
+        for (uint32_t i0 = 0; i0 < Sr; i0 += blockDim.x) {                 // uniform trip count
+            const uint32_t i = i0 + tid;
+            const unsigned long long cur = i < Sr ? rk[i] : 0ULL;
+            const bool marked = i < Sr && ((s_mark[i >> 5] >> (i & 31)) & 1u);
+            uint64_t cr = 0;
+            if (cur != 0) { cr = pk_count(cur, cb); if (nr_ovf) cr += ovf_get(tr, rbase + i); }
+            if (SWAP) comp_account<2>(cur != 0, cr, marked ? 1ULL : 0ULL, a, s_tile, s_spec2, acc2);     // resident = hash 2: all of it
+            else comp_account<1>(cur != 0 && !marked, cr, 0ULL, a, s_tile, s_spec1, acc1);               // resident = hash 1: what hash 2 lacks
+        }
+    }
+    __syncthreads();
+    comp_flush<1>(a, s_acc, s_tile, s_spec1, acc1);
+    __syncthreads();
+    comp_flush<2, false>(a, s_acc + 8, s_tile, s_spec2, acc2);
 }
 
 // ---- K5b: the third comp input (src/comp.cc:123-127,403-433,466-479) ----

@@ -986,8 +986,9 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
 constexpr int APK_LANE_PROBES = 12;
 constexpr uint32_t APK_SLOT_SHIFT = 44;
 
-template <int BLOCK, int KP /* 16-byte loads per lane that cover a region: two slots each */, int HB, bool INLINE_CLAIM = false, bool TEST_SPILL = false>
-__global__ void __launch_bounds__(BLOCK)
+template <int BLOCK, int KP /* 16-byte loads per lane that cover a region: two slots each */, int HB, bool INLINE_CLAIM = false, bool TEST_SPILL = false,
+          bool PF = true /* the next region travels from HBM into registers behind the walk of this one (2 KP VGPRs across the walk); false: loaded when its turn comes -- for shapes with a second workgroup on the CU to cover that */>
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 768 ? 6 : 4))    // waves per SIMD: two 768-thread workgroups are six (80 VGPRs), every other shape four (128)
 k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend,
               uint32_t qcap /* queue entries per wave: what the region leaves of the LDS; >= 72 */, uint64_t seg_len /* k-mers per walk: a multiple of 4 below half the count range */,
@@ -1020,14 +1021,18 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
         for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; kq[u] = *reinterpret_cast<const u32x4*>(t.keys + base + (i < S ? i : 0)); }    // clamped, unconditional: stays in registers
     };
     auto next_slot = [&](uint32_t s) -> uint32_t { return s + 1 == S ? 0 : s + 1; };
-    auto add1 = [&](uint32_t slot) { (void)__hip_atomic_fetch_add(&rk[slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    // +1: the count lives in the low cbits <= 32 bits of the word and the sweep below rules a carry out of it out, so the add is a
+    // 32-bit one on the word's low half (a 64-bit LDS atomic costs about twice as much)
+    uint32_t* rk32 = reinterpret_cast<uint32_t*>(rk);
+    auto add1 = [&](uint32_t slot) { (void)__hip_atomic_fetch_add(&rk32[2 * slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
     uint32_t r = next_region(g.b_lo * g.P2 + blockIdx.x);
-    if (r < r_hi) prefetch(r);
+    if (PF && r < r_hi) prefetch(r);
     while (r < r_hi) {
         const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : run_end(r);
         const uint64_t base = (uint64_t)r * S;
         // ---- fill: registers -> LDS ----
+        if (!PF) prefetch(r);
 #pragma unroll
         for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(rk + i) = kq[u]; }
         const uint32_t rn = next_region(r + gridDim.x);
@@ -1238,7 +1243,7 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
             }
             if (sbeg + seg_len < end) lds_barrier();               // another segment follows: no wave may still be grabbing chunks of this one when the counter is reset
         }
-        if (rn < r_hi) prefetch(rn);                           // in flight behind the write-back
+        if (PF && rn < r_hi) prefetch(rn);                     // in flight behind the write-back
 
         // ---- write-back: LDS -> HBM, 16 bytes per lane and store ----
         lds_barrier();

@@ -7,6 +7,7 @@
 static const bool g_force_join = hook("KATGPU_FORCE_JOIN") != nullptr;  // tests: take the join form whenever it is legal
 static const bool g_no_join = hook("KATGPU_NO_JOIN") != nullptr;       // A/B switch: force comp's probe form
 static const bool g_no_seen = hook("KATGPU_NO_SEEN") != nullptr;       // A/B switch: pass 2 probes hash 1 even after a join pass 1
+static const bool g_no_fused = hook("KATGPU_NO_FUSED") != nullptr;     // A/B switch: comp as two passes even where the fused join applies
 static const bool g_no_fold = hook("KATGPU_NO_FOLD") != nullptr;       // A/B switch: spectra by their own LDS atomics even for the tile's k-mers
 static const uint32_t g_join_block = (uint32_t)hook_u64("KATGPU_JOIN_BLOCK", 512);   // A/B: threads per join workgroup (512 or 1024)
 
@@ -105,10 +106,16 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
         if (scan->d.cap + probe->d.cap < ((uint64_t)64 << 20)) return true;        // small either way: take the join
         return (double)sb * (double)(scan->d.cap + probe->d.cap) / 2.2e12 < 1.3 * (double)scan->distinct / 55e9;
     };
+    // Both tables packed, on one grid, canonical: ONE kernel does both passes (k_comp_fused), the table with fewer k-mers streaming
+    // past the other one's regions in LDS.
+    const bool swap = t1->distinct < t2->distinct;           // hash 1 is the smaller one: it streams, hash 2 is resident
+    const uint32_t s_res = swap ? t2->d.region_slots : t1->d.region_slots;
+    const size_t fused_lds = ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * (size_t)ss * 4 + 15) & ~(size_t)15) + (size_t)s_res * 8 + (size_t)((s_res + 31) / 32) * 4;
+    const bool fused = pk && same_grid && !g_no_fused && t1->d.canonical && t2->d.canonical && s_res <= (uint32_t)FUSED_KP * FUSED_BLOCK * 2 && fused_lds <= 160 * 1024 - 512;
     // pass 1 as a join can leave a bit per slot of hash 2 ("hash 1 holds this k-mer"); pass 2 is then a scan of hash 2 (k_comp_seen)
     const bool join_1 = same_grid && ident1 && (g_force_join || join_pays(t1, t2));
     const uint32_t wpr = (t2->d.region_slots + 31) / 32;
-    const bool marked = join_1 && !g_no_seen && t1->d.canonical && t2->d.canonical && t2->ones == 0 && join1 + (size_t)wpr * 4 <= 150 * 1024;
+    const bool marked = !fused && join_1 && !g_no_seen && t1->d.canonical && t2->d.canonical && t2->ones == 0 && join1 + (size_t)wpr * 4 <= 150 * 1024;
     uint32_t* seen_bits = nullptr;
     if (marked) {
         if (pool_alloc(c, (void**)&seen_bits, (size_t)t2->d.n_regions * wpr * 4) != hipSuccess) { (void)hipGetLastError(); seen_bits = nullptr; }
@@ -121,12 +128,20 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>((160 * 1024) / (align_up(lds + 64, 1280)), 2048 / jblk));
         return std::min<uint32_t>(regions, (uint32_t)c->n_cu * (uint32_t)per_cu);
     };
+    if (fused) {
+        ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap + t2->d.cap);
+        const uint32_t grid = std::min<uint32_t>(t1->d.n_regions, (uint32_t)c->n_cu);
+        if (swap) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    hipLaunchKernelGGL(k_comp_fused<true>, dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a); }
+        else { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+               hipLaunchKernelGGL(k_comp_fused<false>, dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a); }
+    }
 #define KG_JOIN(PASS, TA, TB, LDS) do { \
         if (pk) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<PASS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
                   hipLaunchKernelGGL((k_comp_join<PASS, true>), dim3(join_grid(LDS, TA->d.n_regions)), dim3(jblk), LDS, c->stream, TA->d, TA->n_ovf, TB->d, TB->n_ovf, a); } \
         else { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<PASS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
                hipLaunchKernelGGL((k_comp_join<PASS, false>), dim3(join_grid(LDS, TA->d.n_regions)), dim3(jblk), LDS, c->stream, TA->d, TA->n_ovf, TB->d, TB->n_ovf, a); } } while (0)
-    {
+    if (!fused) {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap);
         if (join_1 && join1 <= 150 * 1024) {
             const size_t j1 = join1 + (a.seen ? (size_t)wpr * 4 : 0);
@@ -136,7 +151,7 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
         else
             hipLaunchKernelGGL((k_comp<1, false>), dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
     }
-    {
+    if (!fused) {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS2, t2->d.cap);
         if (a.seen && join1 <= 150 * 1024) {
             const uint32_t grid = std::min<uint32_t>(t2->d.n_regions, (uint32_t)c->n_cu * 4);

@@ -250,7 +250,7 @@ def test_unchecked_add_sweep_guard(ko, tmp_path):
         "t = e.table(21, True, size_hint=1 << 14).count_bases(b)\n"
         "k, c = t.dump_sorted(); np.savez(%r, k=k, c=c, h=t.hist(1, 5000, 1), regrow=e.profile()['regrow']['launches'])\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "s.npy"), str(tmp_path / "out.npz"))
-    env = dict(os.environ, KATGPU_TEST_SWEEP_THR="64", KATGPU_TEST_MAX_STARTS="64")
+    env = dict(os.environ, KATGPU_TEST_SWEEP_THR="64", KATGPU_TEST_MAX_STARTS="64", KATGPU_NO_PACKED="1")   # (packed tables add checked: nothing to sweep)
     subprocess.run([sys.executable, "-c", code], env=env, check=True, timeout=600)
     got = np.load(tmp_path / "out.npz")
     ot = ko.Table(21, True).count_bases(s)
