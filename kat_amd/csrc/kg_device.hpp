@@ -300,14 +300,23 @@ __device__ inline bool table_full(const DevTable& t) {
     return false;
 }
 
-// insert-or-add into a packed table: claim and add are ONE compare-and-swap on the slot word (0 -> remainder | count).  The
-// direct path is checked throughout (a CAS loop): it serves small inputs, spill lists, merges and regrows.
+// insert-or-add into a packed table.  A claim is ONE compare-and-swap on the slot word (0 -> remainder | count): claim and first
+// count together.  INVARIANT of every kernel that writes packed slots: at kernel boundaries an occupied slot counts 1 .. half
+// (half = 2^(cbits-1)); what is beyond lives in the side table, keyed by the slot.  It is what lets the apply kernels add with
+// no-return LDS atomics (a walk adds less than half) and the +1 path below add with a plain atomic.
+//  UNIT (amount == 1; the direct counter, spill lists): atomicAdd on the word; the one add that lifts the count to half + 1 hands
+//       `half` to the side table.  No retry loop: a heavy hitter -- every lane of the chip on one slot -- costs what its atomics
+//       cost (a compare-and-swap loop there is quadratic: each success fails everyone else's expected value).  The count
+//       overshoots half + 1 only by the adds that land before the hand-over does (thousands at most; the field holds half - 1 more).
+//  general amounts (regrow, merges): a compare-and-swap loop that leaves the count in 1 .. half.  Its callers bring every k-mer
+//       once per source, so there is no contention to speak of.  One kernel uses one of the two forms, never both on a slot.
+template <bool UNIT>
 __device__ inline bool table_add_pk(const DevTable& t, uint64_t key, uint64_t amount, uint32_t& new_distinct) {
     const uint32_t cb = t.cbits;
     const uint64_t cmask = pk_cmask(cb), half = pk_half(cb);
     Probe pr = probe_start(key, t);
     uint64_t q, r;
-    pk_split(amount, cb, q, r);
+    pk_split(amount, cb, q, r);                                    // amount = q * half + r, r < half
     for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
         unsigned long long* slot = (unsigned long long*)&t.keys[pr.pos()];
         unsigned long long w = *slot;
@@ -317,10 +326,18 @@ __device__ inline bool table_add_pk(const DevTable& t, uint64_t key, uint64_t am
             if (w == 0) { ++new_distinct; if (qq) ovf_add(t, pr.pos(), qq * half); return true; }
         }
         if ((w >> cb) != pr.rem) continue;
+        if (UNIT) {
+            const unsigned long long old = atomicAdd(slot, 1ULL);
+            if ((old & cmask) == half) {                           // this add made it half + 1
+                atomicAdd(slot, (unsigned long long)(0ULL - half));     // (no borrow: the count is at least half + 1 until this lands)
+                ovf_add(t, pr.pos(), half);
+            }
+            return true;
+        }
         if (r) {
             for (;;) {
                 uint64_t c = (w & cmask) + r, qq = q;
-                if (c > cmask) { c -= half; ++qq; }                // (c >= half >= 1: the slot stays occupied)
+                if (c > half) { c -= half; ++qq; }                 // (old count <= half, r < half: 1 <= c <= half after this)
                 const unsigned long long got = atomicCAS(slot, w, (unsigned long long)((w & ~cmask) | c));
                 if (got == w) { q = qq; break; }
                 w = got;
@@ -338,7 +355,7 @@ __device__ inline bool table_add_pk(const DevTable& t, uint64_t key, uint64_t am
 // new_distinct is accumulated per lane and flushed once per wave (one striped atomic instead of one per claim).
 __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint64_t amount, uint32_t& new_distinct) {
     if (amount == 0) return true;                                  // (a stored k-mer always has a count: comp's pass forms rely on it)
-    if (t.cbits) return table_add_pk(t, key, amount, new_distinct);
+    if (t.cbits) return table_add_pk<false>(t, key, amount, new_distinct);
     if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)amount); return true; }
     Probe pr = probe_start(key, t);
     for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {
@@ -365,9 +382,9 @@ __device__ __forceinline__ bool table_add(const DevTable& t, uint64_t key, uint6
 // units saturate at ~22 G adds/s).  Without the returned value a 32-bit wrap cannot be seen here; the host instead
 // guarantees it cannot happen: before the adds launched since the last k_sweep could lift any counter past 2^32-1 it
 // runs k_sweep, which moves 2^31 from every counter >= 2^31 into the side table (kg_count.hip: maybe_sweep).
-// (Packed tables take the checked add: their in-slot counter may be as narrow as 20 bits.)
+// (Packed tables: table_add_pk<UNIT>, which needs no sweep -- its hand-over to the side table happens in place.)
 __device__ __forceinline__ bool table_inc(const DevTable& t, uint64_t key, uint32_t& new_distinct) {
-    if (t.cbits) return table_add_pk(t, key, 1ULL, new_distinct);
+    if (t.cbits) return table_add_pk<true>(t, key, 1ULL, new_distinct);
     if (key == EMPTY) { atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], 1ULL); return true; }
     Probe pr = probe_start(key, t);
     for (uint32_t probe = 0; probe < t.region_slots; ++probe, pr.next()) {

@@ -1036,7 +1036,7 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
                             if (r) {
                                 for (;;) {
                                     uint64_t cc = (w & cmask) + r, qq = q;
-                                    if (cc > cmask) { cc -= half; ++qq; }
+                                    if (cc > half) { cc -= half; ++qq; }                  // (the invariant of packed slots: 1 .. half)
                                     const unsigned long long got = atomicCAS(&rk[slot], w, (unsigned long long)((w & ~cmask) | cc));
                                     if (got == w) { q = qq; break; }
                                     w = got;

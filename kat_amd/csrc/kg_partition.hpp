@@ -980,9 +980,9 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
 // 512-thread workgroups share a CU -- while one fills or writes back its region the other walks -- and the table is swept at 16
 // bytes per slot and round instead of 24.  Queue entries are one word: remainder | slot << 44 (remainders have at most 44 bits in a
 // packed table); the probes an entry has left follow from its distance to the remainder's home slot.
-// No-return adds cannot report a carry out of the count field, so none may happen: before a walk every counter above half its
-// range hands the excess to the side table (keyed by the slot), and a walk covers fewer than half the range (longer runs are
-// walked in segments; the host passes seg_len).
+// No-return adds cannot report a carry out of the count field, so none may happen: a walk finds every counter in 1 .. half (the
+// invariant of packed tables, kg_device.hpp: table_add_pk), covers fewer k-mers than half the range (longer runs are walked in
+// segments; the host passes seg_len) and hands what it left above half to the side table (keyed by the slot) before it ends.
 constexpr int APK_LANE_PROBES = 12;
 constexpr uint32_t APK_SLOT_SHIFT = 44;
 
@@ -1043,24 +1043,6 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
         for (uint64_t sbeg = beg; sbeg < end; sbeg += seg_len) {            // one segment, normally
             const uint64_t n_run = (end - sbeg < seg_len ? end - sbeg : seg_len);
             if (tid == 0) s_next_chunk = NW;                  // chunks 0 .. NW-1 are the waves' first ones
-            lds_barrier();
-            // counters that could carry during this walk keep 1 .. half and hand the rest to the side table (each lane looks at the slots it filled)
-#pragma unroll 1
-            for (int u = 0; u < KP; ++u) {
-                const uint32_t i = (u * BLOCK + tid) * 2;
-                if (i >= S) break;
-                const u64x2 ww = *reinterpret_cast<const u64x2*>(rk + i);
-                if ((ww.x & cmask) <= half && (ww.y & cmask) <= half) continue;
-#pragma unroll 1
-                for (uint32_t j = 0; j < 2; ++j) {
-                    const unsigned long long w = rk[i + j];
-                    const uint64_t c = w & cmask;
-                    if (c <= half) continue;
-                    const uint64_t keep = ((c - 1) & (half - 1)) + 1;
-                    rk[i + j] = w - (c - keep);
-                    ovf_add(t, base + i + j, c - keep);
-                }
-            }
             lds_barrier();
 
             // ---- the walk ----
@@ -1241,7 +1223,25 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                 c_lo = n_lo; c_hi = n_hi; c_in = n_in;
                 c = c_next;
             }
-            if (sbeg + seg_len < end) lds_barrier();               // another segment follows: no wave may still be grabbing chunks of this one when the counter is reset
+            // ---- back to the invariant (kg_device.hpp: table_add_pk): a slot counts 1 .. half, the rest goes to the side table.  The walk
+            // found every counter there and added less than half, so none has carried; each lane looks at the slots it filled. ----
+            lds_barrier();                                        // every wave's adds of this segment are in (and no wave grabs chunks any more)
+#pragma unroll 1
+            for (int u = 0; u < KP; ++u) {
+                const uint32_t i = (u * BLOCK + tid) * 2;
+                if (i >= S) break;
+                const u64x2 ww = *reinterpret_cast<const u64x2*>(rk + i);
+                if ((ww.x & cmask) <= half && (ww.y & cmask) <= half) continue;
+#pragma unroll 1
+                for (uint32_t j = 0; j < 2; ++j) {
+                    const unsigned long long w = rk[i + j];
+                    const uint64_t c = w & cmask;
+                    if (c <= half) continue;
+                    const uint64_t keep = ((c - 1) & (half - 1)) + 1;
+                    rk[i + j] = w - (c - keep);
+                    ovf_add(t, base + i + j, c - keep);
+                }
+            }
         }
         if (PF && rn < r_hi) prefetch(rn);                     // in flight behind the write-back
 
@@ -1255,13 +1255,16 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
     flush_distinct(t, new_distinct);
 }
 
-// spilled k-mers (count 1 each) through the direct path.  Checked adds (table_add sees a 32-bit wrap itself): these lists
-// are short, and the unchecked table_inc would oblige the host to sweep the whole table first (katgpu.hip: maybe_sweep).
+// spilled k-mers (count 1 each) through the direct path.  KV12: checked adds (table_add sees a 32-bit wrap itself): these lists
+// are short, and the unchecked table_inc would oblige the host to sweep the whole table first (kg_count.hip: maybe_sweep).
 static __global__ void __launch_bounds__(256)
 k_insert_keys(DevTable t, const uint64_t* __restrict__ keys, uint64_t n) {
     uint32_t new_distinct = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) table_add(t, keys[i], 1ULL, new_distinct);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (t.cbits) table_add_pk<true>(t, keys[i], 1ULL, new_distinct);      // (a heavy hitter's spilled copies all land on one slot: no retry loops)
+        else table_add(t, keys[i], 1ULL, new_distinct);
+    }
     flush_distinct(t, new_distinct);
 }
 

@@ -20,6 +20,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def test_comp_forms_match_oracle(extra):
     env = dict(os.environ, KATGPU_TEST_REGION_SLOTS="512")
     env.update(extra)
-    r = subprocess.run([sys.executable, os.path.join(HERE, "comp_cases.py")], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "comp_cases.py")], env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "comp cases ok" in r.stdout

@@ -51,6 +51,6 @@ def test_partitioned_counter_matches_oracle(region_slots, round_items, spill_mod
     env = dict(os.environ, KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
                KATGPU_TEST_ROUND_ITEMS=str(round_items), KATGPU_TEST_SPILL_MOD=str(spill_mod))
     env.update(extra)
-    r = subprocess.run([sys.executable, os.path.join(HERE, "partition_cases.py")], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "partition_cases.py")], env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "partition cases ok" in r.stdout
