@@ -253,7 +253,8 @@ typedef enum katgpu_kernel {
     KATGPU_K_PART_APPLY = 10,/* regions updated in LDS (k_p3_apply) */
     KATGPU_K_PART_L1S = 11,  /* extract + level-1 scatter (k_p1_scatter) */
     KATGPU_K_PROFILE = 12,   /* per-position lookups (k_profile) */
-    KATGPU_K_NCLASSES = 13
+    KATGPU_K_SCAN = 13,      /* device-side record scan of raw FASTQ / FASTA bytes (kg_scan.hpp), units = raw bytes */
+    KATGPU_K_NCLASSES = 14
 } katgpu_kernel;
 int katgpu_profile_reset(katgpu_ctx* ctx);
 int katgpu_profile_get(katgpu_ctx* ctx, int kernel_class, uint64_t* launches, double* total_ms, uint64_t* units);

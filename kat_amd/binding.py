@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkatgpu.so")
 
-KERNEL_CLASSES = ("count", "regrow", "hist", "gcp", "comp_pass1", "comp_pass2", "partition", "merge", "part_l1_count", "part_l2", "part_apply", "part_l1_scatter", "profile")
+KERNEL_CLASSES = ("count", "regrow", "hist", "gcp", "comp_pass1", "comp_pass2", "partition", "merge", "part_l1_count", "part_l2", "part_apply", "part_l1_scatter", "profile", "scan")
 
 STATUS = {
     0: "ok", 1: "invalid argument", 2: "io", 3: "Unsupported format", 4: "Invalid fastq sequence",

@@ -586,7 +586,9 @@ extern "C" int katgpu_count_bases_device(katgpu_table* t, const uint8_t* dev_bas
 // KATGPU_RING_MB: size of each of the two device rings the host feeder fills (default 1024)
 static const size_t g_ring_bytes = (getenv("KATGPU_RING_MB") ? std::max<size_t>(1, strtoull(getenv("KATGPU_RING_MB"), nullptr, 10)) : 1024) << 20;
 
-static int ensure_staging(katgpu_ctx* c) {
+// want: bytes of stream the caller expects (0: unknown): small inputs get small rings (two 1 GiB rings for a 100-base call, or for
+// the CLI on the reference's 1000-read test files, would be most of the call's time and could fail on a full device)
+static int ensure_staging(katgpu_ctx* c, size_t want = 0) {
     if (!c->stage_bytes) {
         const size_t bytes = (size_t)64 << 20;
         for (int i = 0; i < 2; ++i) {
@@ -595,17 +597,25 @@ static int ensure_staging(katgpu_ctx* c) {
         }
         c->stage_bytes = bytes;
     }
-    if (!c->ring_bytes) {
-        for (int i = 0; i < 2; ++i) {
-            hipError_t e = hipMalloc((void**)&c->ring[i], g_ring_bytes);
+    size_t ring_want = g_ring_bytes;
+    if (want) ring_want = std::min(g_ring_bytes, std::max<size_t>((size_t)16 << 20, align_up(want + 4096, (size_t)16 << 20)));
+    if (c->ring_bytes && c->ring_bytes < ring_want) {              // grown for a bigger input
+        for (int i = 0; i < 2; ++i) { hipFree(c->ring[i]); c->ring[i] = nullptr; }
+        c->ring_bytes = 0;
+    }
+    for (; !c->ring_bytes; ring_want /= 2) {                       // halve on failure: a smaller ring is only more count calls
+        if (ring_want < ((size_t)1 << 20)) return fail(c, KATGPU_ERR_NOMEM, "no device memory for the staging rings");
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i) {
+            hipError_t e = hipMalloc((void**)&c->ring[i], ring_want);
             if (e != hipSuccess && c->arena && !c->arena_borrowed && !c->arena_busy) {       // the cached arena holds most of the free HBM: give it back
                 (void)hipGetLastError();
                 hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0;
-                e = hipMalloc((void**)&c->ring[i], g_ring_bytes);
+                e = hipMalloc((void**)&c->ring[i], ring_want);
             }
-            if (e != hipSuccess) { for (int j = 0; j < i; ++j) { hipFree(c->ring[j]); c->ring[j] = nullptr; } HIPCHK(c, e); }
+            if (e != hipSuccess) { (void)hipGetLastError(); for (int j = 0; j < i; ++j) { hipFree(c->ring[j]); c->ring[j] = nullptr; } ok = false; }
         }
-        c->ring_bytes = g_ring_bytes;
+        if (ok) c->ring_bytes = ring_want;
     }
     return KATGPU_OK;
 }
@@ -642,7 +652,7 @@ struct HostFeeder {
                 if (jobs.empty()) return;
                 j = jobs.front(); jobs.pop_front();
             }
-            int rc = worker_rc ? worker_rc : count_resident(t, c->ring[j.ring], j.n);
+            int rc = worker_rc ? worker_rc : count_resident(t, c->ring[j.ring], j.n);     // (after an error the queued rings are dropped, not counted)
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (rc && !worker_rc) { worker_rc = rc; worker_err = c->err; }
@@ -657,8 +667,8 @@ struct HostFeeder {
         cv.notify_all();
         worker.join();
     }
-    int begin() {
-        int rc = ensure_staging(c); if (rc) return rc;
+    int begin(size_t want = 0) {
+        int rc = ensure_staging(c, want); if (rc) return rc;
         tail_n = 0;
         worker = std::thread([this] { run(); });
         return open_ring();
@@ -743,7 +753,7 @@ extern "C" int katgpu_count_bases_host(katgpu_table* t, const uint8_t* bases, si
     HIPCHK(t->ctx, hipSetDevice(t->ctx->device));
     t->carry_n = 0;
     HostFeeder f(t);
-    int rc = f.begin(); if (rc) return rc;
+    int rc = f.begin(n); if (rc) return rc;
     rc = f.push(bases, n); if (rc) return rc;
     return f.finish();
 }
@@ -753,11 +763,23 @@ extern "C" int katgpu_count_files(katgpu_table* t, const char* const* paths, siz
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     t->carry_n = 0;
+    // Large plain FASTQ / FASTA files: raw bytes to the device, the record scan there (kg_scan.hip).  Files of a group never join and
+    // the table is a multiset, so the order in which the group's files are counted is free.
+    std::vector<const char*> rest;
+    std::vector<uint16_t> rest_trim;
+    size_t rest_bytes = 0;
+    for (size_t i = 0; i < n_paths; ++i) {
+        bool took = false;
+        int rc = count_file_device_scan(t, paths[i], trim5p ? trim5p[i] : 0, &took);
+        if (rc) return rc;
+        if (!took) { rest.push_back(paths[i]); rest_trim.push_back(trim5p ? trim5p[i] : 0); rest_bytes += (size_t)kg::file_size_or_zero(paths[i]); }
+    }
+    if (rest.empty()) return refresh_counters(t);
     HostFeeder f(t);
-    int rc = f.begin(); if (rc) return rc;
-    // the group's files -> one base stream (kg_ingest.hpp: thread team for large plain files, concurrent readers for gzip & co.)
+    int rc = f.begin(rest_bytes * 4); if (rc) return rc;           // (gzip inflates: be generous)
+    // the group's other files -> one base stream (kg_ingest.hpp: thread team for large plain files, concurrent readers for gzip & co.)
     std::string err;
-    rc = kg::stream_group(paths, n_paths, trim5p, t->d.k, [&](const uint8_t* p, size_t n) { return f.push(p, n); }, &err);
+    rc = kg::stream_group(rest.data(), rest.size(), trim5p ? rest_trim.data() : nullptr, t->d.k, [&](const uint8_t* p, size_t n) { return f.push(p, n); }, &err);
     if (rc) return err.empty() ? rc : fail(c, rc, "%s", err.c_str());
     return f.finish();
 }

@@ -134,6 +134,9 @@ double load_limit(const DevTable& d);
 int ensure_room(katgpu_table* t, uint64_t incoming);
 // counting (kg_count.hip)
 int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n);
+// large plain FASTQ / FASTA files: raw bytes to the device, record scan there (kg_scan.hip).  *took = false: not a file for this path
+bool device_scan_applies(const char* path, uint32_t trim5p, uint64_t* size_out, uint8_t* first_byte);
+int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, bool* took);
 
 // HIP events around a launch on the ctx stream; elapsed time is collected lazily.
 struct ScopedTimer {

@@ -206,6 +206,8 @@ struct Segment {
 
 }  // namespace
 
+int64_t find_record_start(ParseState::Type type, const uint8_t* buf, int64_t buf_off, int64_t len, int64_t from) { return find_cut(type, buf, buf_off, len, from); }
+
 // The conditions under which the team takes a file; *size_out / *first_byte for the caller that goes on.
 static bool team_applies_impl(const char* path, uint32_t trim5p, int64_t* size_out, uint8_t* first_byte) {
     if (trim5p) return false;                                // is.ignore(trim5p) swallows line starts: keep that case on the streaming path

@@ -43,6 +43,11 @@ private:
     void after_header();
 };
 
+// First GUESSED record start at file offset >= from, looking only at buf (= file bytes [buf_off, buf_off + len)): "\n>" for FASTA; "\n@", a
+// line, then "\n+" for FASTQ.  -1: none is certain inside the buffer.  A guess: whoever uses it checks it (the thread team against the
+// machine's state at the end of the piece before, the device scan against the structure of every record of the chunk).
+int64_t find_record_start(ParseState::Type type, const uint8_t* buf, int64_t buf_off, int64_t len, int64_t from);
+
 class SeqFileParser {
 public:
     SeqFileParser();
