@@ -43,7 +43,7 @@ WORKLOADS = {
     "comp-rr": (150_000_000, 1_000_000_000, 31, "kat comp reads-vs-reads"),
 }
 CONFIG_ALIAS = {2: "hist", 3: "gcp", 4: "comp", 5: "comp-rr"}
-PROFILE_JSON = "profiles/r02_final_pmc_fetch_write.json"
+PROFILE_JSON = "profiles/r03_final_pmc_fetch_write.json"
 
 
 def parse_args():
@@ -61,13 +61,15 @@ def parse_args():
     ap.add_argument("--err-ppm", type=int, default=2000, help="substitution errors per million bases (0.2 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> output files leg")
-    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end slice (written as FASTQ to a temp dir)")
+    ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end slice (written as FASTQ to a temp dir: 32 GB at the default)")
     ap.add_argument("--phases", action="store_true", help="sync + print per-phase wall time (diagnostic; perturbs the timing)")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--load", type=float, default=0.62, help="load factor the tables are pre-sized for (expected distinct k-mers / slots)")
     ap.add_argument("--hint-scale", type=float, default=1.0, help="diagnostic: scale the tables' size hints (e.g. 0.02: grown on the way)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: diagnostic only -- ranks may share one GPU, records are staged through host memory")
+    ap.add_argument("--dist-backend", default="native", choices=["native", "nccl", "gloo"],
+                    help="native: katgpu's own communicator (kg_comm.hip: RCCL, /dev/shm as its fall-back) -- torch.distributed (gloo) only "
+                         "hands out the id and times the run; nccl: the exchange as a torch.distributed protocol (kat_amd/dist.py) over RCCL; "
+                         "gloo: that protocol staged through host memory (diagnostic: ranks may share one GPU)")
     a = ap.parse_args()
     if a.config is not None:
         if a.workload is not None and a.workload != CONFIG_ALIAS[a.config]:
@@ -143,18 +145,57 @@ def main():
     import kat_amd
     from kat_amd import dist as kdist
 
+    L0 = a.read_len
+    native = a.dist_backend == "native"
     staged = a.dist_backend == "gloo"
-    if staged:
-        local_rank %= torch.cuda.device_count()
+    if staged or native:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        if staged:
-            dist.init_process_group("gloo")
+        if staged or native:
+            dist.init_process_group("gloo")                 # native: rendezvous, barriers and the timing all-reduce only
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = kat_amd.Engine(local_rank)
-    dev = torch.device("cpu") if staged else torch.device("cuda", local_rank)      # where collective tensors live
+    dev = torch.device("cpu") if (staged or native) else torch.device("cuda", local_rank)      # where torch's collective tensors live
+    # the native communicator; if it cannot be made, or its exchange fails on first contact, the run falls back to the staged
+    # torch.distributed protocol and says so in config.parallelism
+    comm, transport = None, None
+    if world > 1 and native:
+        try:
+            ids = [kat_amd.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = kat_amd.Comm(eng, rank, world, ids[0])
+            transport = "katgpu native exchange over %s" % ("RCCL" if comm.transport == "rccl" else "/dev/shm (%s)" % (comm.transport_note or "no RCCL"))
+        except Exception as ex:
+            comm, transport = None, "FALLBACK: torch.distributed gloo, staged through host memory (native communicator failed: %s)" % str(ex)[:200]
+        ok_all = torch.tensor([1 if comm is not None else 0])
+        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+        if not int(ok_all.item()) and comm is not None:
+            comm.free()
+            comm, transport = None, "FALLBACK: torch.distributed gloo, staged through host memory (a peer could not make the native communicator)"
+        if comm is not None:                                # first contact between the devices, on two tiny tables: a transport that fails does so here
+            try:
+                gp = eng.synth_genome(200_000, seed=5)
+                rp = eng.synth_reads(gp, 200_000, first_read=rank * 2000, n_reads=2000, read_len=L0, frag_len=350, err_ppm=2000, seed=9)
+                tp = eng.table(27, True, size_hint=1 << 21)
+                tp.count_bases_device(rp.ptr, rp.nbytes)
+                comm.exchange_merge(tp)
+                comm.allreduce_u64([np.arange(4, dtype=np.uint64)])
+                for x in (tp, rp, gp):
+                    x.free()
+                okp = 1
+            except Exception as ex:
+                okp, transport = 0, "FALLBACK: torch.distributed gloo, staged through host memory (the native exchange failed on first contact: %s)" % str(ex)[:200]
+            ok_all = torch.tensor([okp])
+            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+            if not int(ok_all.item()):
+                if okp:
+                    transport = "FALLBACK: torch.distributed gloo, staged through host memory (a peer's native exchange failed on first contact)"
+                comm = None
+        if comm is None:
+            staged = True
 
     def barrier():
         eng.sync()
@@ -223,8 +264,11 @@ def main():
 
     def exchange(t):
         if k > 32:                                          # wide tables: owner partition -> all-to-all -> rebuild (not in place)
-            return kdist.exchange_merge_wide(kdist.HipWideShard(t, staged=staged)).table
-        kdist.exchange_merge(kdist.HipShard(t, staged=staged))  # in place: the table keeps its storage and its region grid
+            return kdist.exchange_merge_wide(kdist.HipWideShard(t, staged=staged or native)).table
+        if comm is not None:
+            comm.exchange_merge(t)                          # katgpu_exchange_merge: in place, RCCL behind the C ABI
+        else:
+            kdist.exchange_merge(kdist.HipShard(t, staged=staged))  # in place: the table keeps its storage and its region grid
         return t
 
     def step(verify=False):
@@ -239,6 +283,9 @@ def main():
             t2.count_bases_device(in2_ptr, in2_bytes)
             tp = mark("alloc2+count_2", tp)
         results["distinct1_local"] = t1.stats(want_total=False)["distinct"]
+        if k <= 32:
+            g1_ = t1.geometry()
+            results["geo1"] = (int(g1_.p1), int(g1_.p2), t1.slot_bytes(), t2.slot_bytes() if t2 is not None else 0)
         if world > 1:
             t1 = exchange(t1)
             if t2 is not None:
@@ -252,7 +299,7 @@ def main():
             out = list(kat_amd.comp(t1, t2))
         tp = mark("reduce", tp)
         if world > 1:
-            out = kdist.allreduce_u64(out, dev)
+            out = comm.allreduce_u64(out) if comm is not None else kdist.allreduce_u64(out, dev)
         results["out"] = out
         st = t1.stats(want_total=verify)
         results["distinct1"], results["cap1"] = st["distinct"], st["capacity"]
@@ -327,6 +374,22 @@ def main():
             stage_ms = part_ms + direct_ms
             name = "count stage (partitioned): per round level-1 scatter (+ count/scan when exact), then level 2 + apply in passes"
             per_kernel = {n: {"launches": prof[n]["launches"], "avg_ms": round(prof[n]["ms"] / max(1, prof[n]["launches"]), 3)} for n in stage}
+            # each stage kernel against the roofline of its OWN bytes (what it has to move, not what the PMC counters say it moved):
+            #   level 1: the ASCII stream in, an 8-byte item per k-mer out;  level 2: those in, (4 + hb)-byte remainders out (hb from the
+            #   table's remainder bits);  apply: the remainders in + the table swept in and out once per round (slot_bytes per slot)
+            if k <= 32 and results.get("geo1") is not None:
+                p1_, p2_, slot_b1, slot_b2 = results["geo1"]
+                rb = int(kat_amd.binding.place_keys(k, p1_, max(0, p2_.bit_length() - 1), [])[4])
+                hb = 0 if rb <= 31 else 1 if rb <= 39 else 2 if rb <= 47 else 4
+                items = inst_reads + inst2_local
+                rounds1 = max(1, prof["part_l1_scatter"]["launches"] // a.steps - (1 if two_tables else 0))      # rounds of the first input
+                own = {"part_l1_scatter": (reads.nbytes + in2_bytes) + 8.0 * items,
+                       "part_l2": (8.0 + 4 + hb) * items,
+                       "part_apply": (4.0 + hb) * items + 2.0 * slot_b1 * cap1 * rounds1 + 2.0 * slot_b2 * cap2}
+                for n, b in own.items():
+                    ms = prof[n]["ms"] / a.steps
+                    if ms > 0:
+                        per_kernel[n].update({"own_bytes_per_step": int(b), "own_GBps": round(b / (ms / 1e3) / 1e9, 1), "own_frac": round(b / (ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)})
         else:
             rounds = max(1, prof["count"]["launches"])
             stage_ms = direct_ms
@@ -367,13 +430,19 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": desc, "reads_per_gpu": n_reads * (2 if wl == "comp-rr" else 1), "genome_bp": a.genome, "k": k,
-                       "parallelism": "reads sharded x%d, owner-partitioned merge over %s" % (world, "RCCL" if not staged else "gloo (staged, diagnostic)") if world > 1 else "single GPU"},
+                       "parallelism": "reads sharded x%d, owner-partitioned merge: %s" % (world, transport or ("torch.distributed RCCL" if not staged else "torch.distributed gloo (staged, diagnostic)")) if world > 1 else "single GPU"},
             "kmer_instances": total_instances, "distinct_table1": distinct1, "distinct_table2": distinct2 if two_tables else None,
             "result_accounts_for_every_kmer": bool(ok), "result_check": what,
             "kernel_ms_per_step": kernels_ms,
             "roofline": roof, "reducers": red, "cpu_baseline": cpu, "end_to_end": e2e,
         }
+        if comm is not None:
+            st = comm.stats()
+            line["exchange_ms_per_step"] = {k_: round(v / (a.steps + a.warmup), 3) for k_, v in st.items() if k_.endswith("_ms")}
+            line["exchange_bytes_sent_per_step"] = int(st["bytes_sent"] / (a.steps + a.warmup))
         print(json.dumps(line))
+    if comm is not None:
+        comm.free()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -438,8 +507,8 @@ def cpu_baseline(eng, a, k, L):
                                  "source": "SURVEY.md section 6: the reference's count phase ran at ~3 M k-mers/s/core (8-core Xeon, hand-built reference binary); x %d host cores, assuming it scales linearly (it does not: an upper bound)" % cores}}
 
 
-def write_fastq(path, bases, first_read, mate, read_len):
-    """bases: uint8 [n, read_len].  4-line FASTQ with fixed-width headers (@r<9-digit pair>/<mate>), quality 'I'."""
+def write_fastq(f, bases, first_read, mate, read_len):
+    """bases: uint8 [n, read_len] -> the open file f.  4-line FASTQ with fixed-width headers (@r<9-digit pair>/<mate>), quality 'I'."""
     n = bases.shape[0]
     rec = np.empty((n, 2 * read_len + 18), np.uint8)
     ids = np.arange(first_read, first_read + n, dtype=np.int64)
@@ -457,8 +526,7 @@ def write_fastq(path, bases, first_read, mate, read_len):
     rec[:, p + 2] = ord("\n")
     rec[:, p + 3:p + 3 + read_len] = ord("I")
     rec[:, p + 3 + read_len] = ord("\n")
-    with open(path, "wb") as f:
-        f.write(rec.tobytes())
+    f.write(rec.data)
 
 
 def end_to_end(eng, a, k, L):
@@ -473,19 +541,24 @@ def end_to_end(eng, a, k, L):
     n = min(a.e2e_reads, a.reads) & ~1
     gs = min(a.genome, max(10_000_000, n * 5))                               # ~30x coverage of the slice's genome
     tmp = tempfile.mkdtemp(prefix="katgpu_e2e_")
+    t_e2e0 = time.perf_counter()
     try:
         g = eng.synth_genome(gs, seed=99)
         files, inst, nbytes = [], 0, 0
 
-        def library(seed, tag):
-            r = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=seed)
-            h = r.download().reshape(n, L + 1)[:, :L]
-            r.free()
-            paths = []
-            for mate in (0, 1):
-                p = os.path.join(tmp, "%s_R%d.fastq" % (tag, mate + 1))
-                write_fastq(p, h[mate::2], 0, mate, L)
-                paths.append(p)
+        def library(seed, tag):                                                 # in slices of 8 M reads: the files are tens of GB
+            paths = [os.path.join(tmp, "%s_R%d.fastq" % (tag, m + 1)) for m in (0, 1)]
+            files = [open(p, "wb") for p in paths]
+            step = 8_000_000
+            for lo in range(0, n, step):
+                m = min(step, n - lo)
+                r = eng.synth_reads(g, gs, first_read=lo, n_reads=m, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=seed)
+                h = r.download().reshape(m, L + 1)[:, :L]
+                r.free()
+                for mate in (0, 1):
+                    write_fastq(files[mate], h[mate::2], lo // 2, mate, L)
+            for f in files:
+                f.close()
             return paths
         lib1 = library(5, "lib1")
         inst += n * (L - k + 1)
@@ -521,8 +594,9 @@ def end_to_end(eng, a, k, L):
             cmd += [" ".join(lib1), second]
         else:
             cmd += lib1
+        t_gen = time.perf_counter() - t_e2e0
         t0 = time.perf_counter()
-        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         dt = time.perf_counter() - t0
         if pr.returncode != 0:
             raise RuntimeError("katgpu %s exited %d: %s" % (tool, pr.returncode, (pr.stderr or pr.stdout)[-400:]))
@@ -530,6 +604,7 @@ def end_to_end(eng, a, k, L):
         return {"value": round(inst / dt, 1), "unit": "k-mers/s", "seconds": round(dt, 3), "input_bytes": nbytes,
                 "input_GB_per_s": round(nbytes / dt / 1e9, 2), "kmer_instances": inst,
                 "span": "process start -> output files closed (src/comp.cc:750 'Total runtime'), inputs in the page cache",
+                "files_written_in_s": round(t_gen, 1),
                 "command": "katgpu %s -t 16 -m %d -H %d on %d reads x %d bp (2 FASTQ files%s)" % (
                     tool, k, hint, n, L, {"comp": " + a %d bp FASTA assembly" % gs, "comp-rr": " + a second library"}.get(wl, "")),
                 "outputs": sorted(outs), "phases": [l.strip() for l in pr.stdout.splitlines() if "Time taken" in l or "Total runtime" in l][:8]}

@@ -89,6 +89,10 @@ int katgpu_table_create_like(katgpu_ctx* ctx, const katgpu_table* like, uint32_t
  * two device rings (KATGPU_RING_MB, default 1024 each); a full ring is counted (partition rounds for anything of size) on a
  * worker thread while the parser fills the other. */
 int katgpu_count_files(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p);
+/* The share of rank `rank` of `world` processes (one per GPU) in counting the group: every rank calls it with the same file list into
+ * a table of its own, then katgpu_exchange_merge makes the tables one (below).  Plain FASTQ files of size are cut between the ranks
+ * batch by batch, at record starts each rank finds for itself; every other file goes whole to one rank. */
+int katgpu_count_files_sharded(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p, int rank, int world);
 /* A base stream is what the reference's parser hands to mer_iterator: sequence bytes, records separated by any
  * byte outside ACGTacgt (the reference inserts 'N', mer_overlap_sequence_parser.hpp:202,234).  Every k-window
  * of every maximal ACGTacgt run is counted once. */
@@ -128,6 +132,9 @@ int      katgpu_table_canonical(const katgpu_table* t);
  * prints "Warning: Specified hash size insufficent - attempting to double hash size... success!" each time): the size hint
  * (KAT's -H) was too small.  A growth step here may more than double. */
 uint32_t katgpu_table_regrows(const katgpu_table* t);
+/* HBM bytes per slot: 8 = packed (one word: the placement hash's remainder | count -- the quotienting of
+ * JF/include/jellyfish/large_hash_array.hpp:169-171; every k <= 32 table of size), 12 = k-mer + 32-bit count (small tables), 20 = k > 32 */
+uint32_t katgpu_table_slot_bytes(const katgpu_table* t);
 
 /* JellyfishHelper::getCount (lib/src/jellyfish_helper.cc:189-194) for a batch of packed k-mers. */
 int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n, int canonicalise, uint64_t* counts);
@@ -236,6 +243,40 @@ int katgpu_table_merge_device32(katgpu_table* t, const uint64_t* dev_keys, const
  * by region in LDS, the others through the direct path.  Exact either way. */
 typedef struct { const uint64_t* dev_keys; const uint32_t* dev_counts; const uint32_t* dev_region_counts; uint64_t n_records; uint32_t p1, p2; } katgpu_merge_source;
 int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source* src);
+
+/* ---- the exchange itself, over RCCL: one process per GPU (kat_amd/csrc/kg_comm.hip) ----
+ * Replaces, across GPUs, what the reference does across threads of one process at the end of a run:
+ * ThreadedSparseMatrix::mergeThreadedMatricies (lib/include/kat/sparse_matrix.hpp:324-335), ThreadedCompCounters::merge
+ * (lib/src/comp_counters.cc:230-254), Histogram::merge (src/histogram.cc:146-160) -- and, before them, makes every k-mer's count
+ * whole on one rank, which one address space gives the reference for free.
+ *   rank 0:      katgpu_comm_unique_id(id); hand the KATGPU_COMM_ID_BYTES bytes to the other ranks (a file, a pipe, MPI, ...)
+ *   every rank:  katgpu_init(own device); katgpu_comm_init(ctx, rank, world, id, &comm);
+ *                count its share of the input into tables of the same size hint (-> the same region grid);
+ *                katgpu_exchange_merge(comm, table) for every table; reduce (katgpu_hist / _gcp / _comp);
+ *                katgpu_allreduce_u64(comm, result, n): every rank now holds the whole run's result.
+ * Transport: RCCL (librccl is dlopen'ed when the first id is made; grouped ncclSend / ncclRecv on a stream of its own, chunk c on
+ * the wire while chunk c-1 is merged) or, when RCCL cannot be had -- or ranks share a device, or KATGPU_COMM_TRANSPORT=shm -- files
+ * in /dev/shm (one node).  katgpu_comm_transport() says which; _note() why it is not RCCL.  world == 1 is legal and runs the whole
+ * protocol on the rank's own records. */
+#define KATGPU_COMM_ID_BYTES 256
+typedef struct katgpu_comm katgpu_comm;
+int  katgpu_comm_unique_id(void* id_out /* KATGPU_COMM_ID_BYTES */);
+int  katgpu_comm_init(katgpu_ctx* ctx, int rank, int world, const void* id, katgpu_comm** out);
+void katgpu_comm_free(katgpu_comm* comm);
+int  katgpu_comm_rank(const katgpu_comm* comm);
+int  katgpu_comm_world(const katgpu_comm* comm);
+const char* katgpu_comm_transport(const katgpu_comm* comm);        /* "rccl" | "shm" */
+const char* katgpu_comm_transport_note(const katgpu_comm* comm);   /* "" or why RCCL is not in use */
+int  katgpu_comm_barrier(katgpu_comm* comm);
+/* Route every record of `t` to its owner rank, in place: afterwards the table holds exactly the k-mers this rank owns, counts summed
+ * over all ranks; it keeps its storage and its region grid.  Collective: every rank calls it, with tables of one k / strand mode.
+ * k <= 32 (wide tables: katgpu_table_partition_wide + katgpu_table_merge_device_wide). */
+int  katgpu_exchange_merge(katgpu_comm* comm, katgpu_table* t);
+/* buf[i] = sum over ranks of buf[i], on every rank (host memory; collective) */
+int  katgpu_allreduce_u64(katgpu_comm* comm, uint64_t* buf, size_t n);
+/* wall time spent so far in extraction / on the wire (posting + waiting) / merging / all-reducing (ms), bytes sent, merge calls */
+int  katgpu_comm_stats(katgpu_comm* comm, double* ms_extract, double* ms_exchange, double* ms_merge, double* ms_allreduce,
+                       uint64_t* bytes_sent, uint64_t* merge_launches);
 
 /* ---- measurement ------------------------------------------------------------------------------------- */
 /* HIP-event timing of the kernels this ctx launched, per kernel class, accumulated since the last reset. */

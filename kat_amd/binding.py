@@ -34,6 +34,8 @@ EXPORTS = (
     "katgpu_table_partition_wide", "katgpu_table_merge_device_wide", "katgpu_table_regrows",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
     "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_ingest_jf_5ptrim_compat", "katgpu_place_keys",
+    "katgpu_count_files_sharded", "katgpu_table_slot_bytes", "katgpu_comm_unique_id", "katgpu_comm_init", "katgpu_comm_free", "katgpu_comm_rank", "katgpu_comm_world", "katgpu_comm_transport",
+    "katgpu_comm_transport_note", "katgpu_comm_barrier", "katgpu_exchange_merge", "katgpu_allreduce_u64", "katgpu_comm_stats",
 )
 
 
@@ -128,6 +130,8 @@ def load_library():
     L.katgpu_table_merge_host_wide.argtypes = [vp, vp, vp, vp, sz]
     L.katgpu_table_regrows.argtypes = [vp]
     L.katgpu_table_regrows.restype = u32
+    L.katgpu_table_slot_bytes.argtypes = [vp]
+    L.katgpu_table_slot_bytes.restype = u32
     L.katgpu_table_partition_wide.argtypes = [vp, u32, vp, vp, vp, vp]
     L.katgpu_table_merge_device_wide.argtypes = [vp, vp, vp, vp, sz]
     L.katgpu_parse_files.argtypes = [vp, sz, vp, u32, pp, C.POINTER(sz), cpp]
@@ -430,6 +434,12 @@ class Table:
         self.engine._chk(self.engine.L.katgpu_count_files(self.h, arr, n, tr))
         return self
 
+    def count_files_sharded(self, paths, rank, world, trim5p=None):
+        arr, n = _cpaths(paths)
+        tr = (C.c_uint16 * n)(*trim5p) if trim5p else None
+        self.engine._chk(self.engine.L.katgpu_count_files_sharded(self.h, arr, n, tr, int(rank), int(world)))
+        return self
+
     def count_bases(self, bases):
         """bases: host uint8 array / bytes (copied through pinned staging) or a DeviceBuffer (counted in place)."""
         if isinstance(bases, DeviceBuffer):
@@ -556,6 +566,10 @@ class Table:
         self.engine._chk(self.engine.L.katgpu_table_merge_device(self.h, dev_keys_ptr, dev_counts_ptr, n))
 
     # region-ordered exchange (dist.py)
+    def slot_bytes(self):
+        """HBM bytes per slot of this table: 8 (packed: remainder | count), 12 (KV12) or 20 (k > 32)."""
+        return int(self.engine.L.katgpu_table_slot_bytes(self.h))
+
     def geometry(self):
         g = Geometry()
         self.engine._chk(self.engine.L.katgpu_table_geometry(self.h, C.byref(g)))
@@ -603,6 +617,81 @@ def comp(t1, t2, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001):
     e._chk(e.L.katgpu_comp(t1.h, t2.h, int(t1.canonical), int(t2.canonical), d1_scale, d2_scale, d1_bins, d2_bins,
                            mx.ctypes.data, cc.ctypes.data, sp.ctypes.data))
     return mx, cc, sp
+
+
+COMM_ID_BYTES = 256
+
+
+class Comm:
+    """The native multi-GPU communicator (include/katgpu.h "the exchange itself": kg_comm.hip).  One per process / GPU.
+    rank 0 makes the id with Comm.unique_id() and hands it to the others by any side channel (a file, torch.distributed, MPI)."""
+
+    @staticmethod
+    def unique_id():
+        L = load_library()
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = L.katgpu_comm_unique_id(buf)
+        if rc:
+            raise KatGpuError(rc, "katgpu_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, engine, rank, world, comm_id):
+        self.engine = engine
+        L = engine.L
+        L.katgpu_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.katgpu_comm_free.argtypes = [C.c_void_p]
+        L.katgpu_comm_free.restype = None
+        L.katgpu_comm_transport.argtypes = [C.c_void_p]
+        L.katgpu_comm_transport.restype = C.c_char_p
+        L.katgpu_comm_transport_note.argtypes = [C.c_void_p]
+        L.katgpu_comm_transport_note.restype = C.c_char_p
+        L.katgpu_comm_barrier.argtypes = [C.c_void_p]
+        L.katgpu_exchange_merge.argtypes = [C.c_void_p, C.c_void_p]
+        L.katgpu_allreduce_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.katgpu_comm_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_uint64)] * 2
+        h = C.c_void_p()
+        assert len(comm_id) == COMM_ID_BYTES
+        engine._chk(L.katgpu_comm_init(engine.h, rank, world, comm_id, C.byref(h)))
+        self.h, self.rank, self.world = h, rank, world
+
+    @property
+    def transport(self):
+        return self.engine.L.katgpu_comm_transport(self.h).decode()
+
+    @property
+    def transport_note(self):
+        return self.engine.L.katgpu_comm_transport_note(self.h).decode()
+
+    def barrier(self):
+        self.engine._chk(self.engine.L.katgpu_comm_barrier(self.h))
+
+    def exchange_merge(self, table):
+        """In place: afterwards `table` holds the k-mers this rank owns, counts summed over all ranks."""
+        self.engine._chk(self.engine.L.katgpu_exchange_merge(self.h, table.h))
+        return table
+
+    def allreduce_u64(self, arrays):
+        """Sum uint64 numpy arrays over ranks; returns new arrays of the same shapes."""
+        flat = np.concatenate([np.ascontiguousarray(a, np.uint64).reshape(-1) for a in arrays]) if arrays else np.zeros(0, np.uint64)
+        self.engine._chk(self.engine.L.katgpu_allreduce_u64(self.h, flat.ctypes.data, flat.size))
+        out, o = [], 0
+        for a in arrays:
+            n = int(np.prod(a.shape))
+            out.append(flat[o:o + n].reshape(a.shape).copy())
+            o += n
+        return out
+
+    def stats(self):
+        d = [C.c_double() for _ in range(4)]
+        u = [C.c_uint64() for _ in range(2)]
+        self.engine._chk(self.engine.L.katgpu_comm_stats(self.h, *[C.byref(x) for x in d], *[C.byref(x) for x in u]))
+        return {"extract_ms": d[0].value, "exchange_ms": d[1].value, "merge_ms": d[2].value, "allreduce_ms": d[3].value,
+                "bytes_sent": u[0].value, "merge_calls": u[1].value}
+
+    def free(self):
+        if getattr(self, "h", None) and getattr(self.engine, "h", None):
+            self.engine.L.katgpu_comm_free(self.h)
+        self.h = None
 
 
 def comp3(t1, t2, t3, d1_scale=1.0, d2_scale=1.0, d1_bins=1001, d2_bins=1001):

@@ -20,15 +20,59 @@ namespace kat {
 // ---- engine singleton ----
 static katgpu_ctx* g_ctx = nullptr;
 
+int Engine::rank_ = 0, Engine::world_ = 1;
+bool Engine::dist_ = false;
+std::string Engine::id_file_;
+static katgpu_comm* g_comm = nullptr;
+
 katgpu_ctx* Engine::ctx() {
     if (!g_ctx) {
-        int rc = katgpu_init(-1, &g_ctx);
+        // --gpus N: rank r takes device r (mod the devices there are: ranks may share one -- the exchange then goes through /dev/shm)
+        int dev = -1;
+        if (dist_ && world_ > 1) {
+            const char* nd = getenv("KATGPU_VISIBLE_DEVICES");      // how many devices the launcher saw (kat_main.cc)
+            const int n = nd ? std::max(1, atoi(nd)) : 1;
+            dev = rank_ % n;
+        }
+        int rc = katgpu_init(dev, &g_ctx);
         if (rc) throw std::runtime_error("katgpu_init failed (status " + std::to_string(rc) + "): no gfx950 device; this build has no CPU path");
     }
     return g_ctx;
 }
 
+katgpu_comm* Engine::comm() {
+    if (g_comm || !dist_) return g_comm;
+    unsigned char id[KATGPU_COMM_ID_BYTES];
+    if (rank_ == 0) {
+        check(katgpu_comm_unique_id(id));
+        const std::string tmp = id_file_ + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) throw std::runtime_error("cannot write " + tmp);
+        fclose(f);
+        if (rename(tmp.c_str(), id_file_.c_str()) != 0) throw std::runtime_error("cannot publish " + id_file_);
+    } else {
+        FILE* f = nullptr;
+        for (int tries = 0; !(f = fopen(id_file_.c_str(), "rb")); ++tries) {
+            if (tries > 120000) throw std::runtime_error("rank 0 never published the communicator id (" + id_file_ + ")");
+            usleep(1000);
+        }
+        const size_t got = fread(id, 1, sizeof id, f);
+        fclose(f);
+        if (got != sizeof id) throw std::runtime_error("short communicator id in " + id_file_);
+    }
+    check(katgpu_comm_init(ctx(), rank_, world_, id, &g_comm));
+    if (speaker() && world_ > 1) {
+        const char* note = katgpu_comm_transport_note(g_comm);
+        std::cout << "Multi-GPU: " << world_ << " ranks, transport " << katgpu_comm_transport(g_comm) << (note && *note ? std::string(" (") + note + ")" : std::string()) << "\n";
+    }
+    return g_comm;
+}
+
+void Engine::exchange(katgpu_table* t) { if (dist_) check(katgpu_exchange_merge(comm(), t)); }
+void Engine::allreduce(uint64_t* buf, size_t n) { if (dist_) check(katgpu_allreduce_u64(comm(), buf, n)); }
+
 void Engine::shutdown() {
+    if (g_comm) { katgpu_comm_free(g_comm); g_comm = nullptr; }
     if (g_ctx) { katgpu_shutdown(g_ctx); g_ctx = nullptr; }
 }
 
@@ -120,7 +164,14 @@ void InputHandler::count(uint16_t threads, const katgpu_table* like) {      // l
     std::cout.flush();
     std::vector<const char*> paths;
     for (const auto& p : input) paths.push_back(p.c_str());
-    if (like) {
+    if (Engine::dist()) {
+        // one process per GPU: every rank counts its share of the group into a table of the SAME size hint (hence the same region
+        // grid), then the tables are made one by owner, in place
+        if (like) Engine::check(katgpu_table_create_like(Engine::ctx(), like, merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
+        else Engine::check(katgpu_table_create(Engine::ctx(), merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
+        Engine::check(katgpu_count_files_sharded(hash, paths.data(), paths.size(), trim5p.data(), Engine::rank(), Engine::world()));
+        Engine::exchange(hash);
+    } else if (like) {
         Engine::check(katgpu_table_create_like(Engine::ctx(), like, merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
         Engine::check(katgpu_count_files(hash, paths.data(), paths.size(), trim5p.data()));
     } else
@@ -145,6 +196,10 @@ void InputHandler::loadHash() {                                             // l
     if (rc) throw JellyfishException(katgpu_jf_last_error());
     canonical = katgpu_table_canonical(hash) != 0;                          // hashLoader->getCanonical() / getMerLen()
     merLen = (uint16_t)katgpu_table_k(hash);
+    if (Engine::dist()) {                                                   // every rank has read the file: rank 0's copy is the run's, shared out by owner
+        if (!Engine::speaker()) Engine::check(katgpu_table_clear(hash));
+        Engine::exchange(hash);
+    }
     std::cout << " done.";
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     char buf[64]; snprintf(buf, sizeof buf, "  Time taken: %.1fs\n\n", s);

@@ -32,12 +32,31 @@ struct CompException : KatException { using KatException::KatException; };
 struct FileSystemException : KatException { using KatException::KatException; };
 struct SectException : KatException { using KatException::KatException; };
 
-// One process-wide engine context (katgpu_init / katgpu_shutdown).
+// One process-wide engine context (katgpu_init / katgpu_shutdown), and -- under `katgpu <mode> --gpus N` -- this process's place among
+// the N that share the run: one per GPU, forked by kat_main.cc before any of them touches the device.  The reference has nothing to
+// put beside this (one process, std::thread workers whose results it merges at the end: ThreadedSparseMatrix::mergeThreadedMatricies
+// lib/include/kat/sparse_matrix.hpp:324-335, ThreadedCompCounters::merge lib/src/comp_counters.cc:230-254, Histogram::merge
+// src/histogram.cc:146-160); here every rank counts its share of the reads, the tables are made one by owner over RCCL
+// (katgpu_exchange_merge), the reducers run on the owned shards and their results are summed (katgpu_allreduce_u64).  Rank 0 speaks and
+// writes the files; the other ranks stay silent.
 class Engine {
 public:
     static katgpu_ctx* ctx();
     static void check(int status);      // throws the exception the reference would have thrown
     static void shutdown();
+    // multi-GPU
+    static void setDist(int rank, int world, const std::string& id_file) { rank_ = rank; world_ = world; id_file_ = id_file; dist_ = true; }
+    static bool dist() { return dist_; }            // --gpus was given (world 1 included: the protocol runs on the rank's own records)
+    static int rank() { return rank_; }
+    static int world() { return world_; }
+    static bool speaker() { return rank_ == 0; }    // writes the output files
+    static katgpu_comm* comm();                     // made on first use (rank 0 publishes the id through id_file)
+    static void exchange(katgpu_table* t);          // no-op without --gpus
+    static void allreduce(uint64_t* buf, size_t n); // idem
+private:
+    static int rank_, world_;
+    static bool dist_;
+    static std::string id_file_;
 };
 
 namespace mme {   // lib/include/kat/matrix_metadata_extractor.hpp:28-39

@@ -2,33 +2,36 @@
 // (src/kat.cc:178-305: option errors 1, KAT/boost exceptions 4, std::exception 5, const char* 6, anything else 7).
 #include "kat_host.hpp"
 
+#include <csignal>
 #include <cstring>
 #include <iostream>
+#include <string>
+#include <vector>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 static void usage() {
     std::cout << "The K-mer Analysis Toolkit, MI355X engine (katgpu): hist | gcp | comp | sect | cold\n"
                  "Usage: katgpu <mode> [options] <inputs>   (same options as `kat <mode>`; see INTEGRATION.md)\n";
 }
 
-int main(int argc, char* argv[]) {
+// `--gpus N` (katgpu only, every counting mode): N processes, one per GPU, forked here -- before anything touches the device, a HIP
+// context does not survive a fork -- and joined at the end; each knows its rank (Engine::setDist) and finds the others through a file
+// in which rank 0 leaves the communicator's id.  The exit code is the worst of the ranks'.
+static int run_mode(const std::string& mode, int argc, char* argv[]) {
+    if (mode == "hist") return kat::Histogram::main(argc, argv);
+    if (mode == "gcp") return kat::Gcp::main(argc, argv);
+    if (mode == "comp") return kat::Comp::main(argc, argv);
+    if (mode == "sect") return kat::Sect::main(argc, argv);
+    if (mode == "cold") return kat::Cold::main(argc, argv);
+    throw kat::OptionError("Could not recognise mode string: " + mode + " (this build carries hist, gcp, comp, sect and cold)");
+}
+
+static int guarded(const std::string& mode, int argc, char* argv[]) {
     int rc = 0;
     try {
-        if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) { usage(); return 1; }
-        const std::string mode = argv[1];
-        // a katgpu-only switch, valid in every mode: read FASTA inputs that carry a 5' trim exactly as the reference's parser does
-        // (the trim re-applied at each 4096-byte buffer fill) instead of once per record
-        int kept = 2;
-        for (int i = 2; i < argc; ++i) {
-            if (!strcmp(argv[i], "--jellyfish_5ptrim_compat")) katgpu_ingest_jf_5ptrim_compat(1);
-            else argv[kept++] = argv[i];
-        }
-        argc = kept;
-        if (mode == "hist") rc = kat::Histogram::main(argc - 1, argv + 1);
-        else if (mode == "gcp") rc = kat::Gcp::main(argc - 1, argv + 1);
-        else if (mode == "comp") rc = kat::Comp::main(argc - 1, argv + 1);
-        else if (mode == "sect") rc = kat::Sect::main(argc - 1, argv + 1);
-        else if (mode == "cold") rc = kat::Cold::main(argc - 1, argv + 1);
-        else throw kat::OptionError("Could not recognise mode string: " + mode + " (this build carries hist, gcp, comp, sect and cold)");
+        rc = run_mode(mode, argc, argv);
     } catch (kat::OptionError& e) {
         std::cerr << "Error: Parsing Command Line: " << e.what() << std::endl;
         rc = 1;
@@ -47,4 +50,71 @@ int main(int argc, char* argv[]) {
     }
     kat::Engine::shutdown();
     return rc;
+}
+
+int main(int argc, char* argv[]) {
+    if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) { usage(); return 1; }
+    const std::string mode = argv[1];
+    // katgpu-only switches, valid in every mode:
+    //   --jellyfish_5ptrim_compat   read FASTA inputs that carry a 5' trim exactly as the reference's parser does (the trim re-applied at
+    //                               each 4096-byte buffer fill) instead of once per record
+    //   --gpus N                    N processes, one per GPU (hist, gcp, comp)
+    int kept = 2, gpus = 0;
+    for (int i = 2; i < argc; ++i) {
+        if (!strcmp(argv[i], "--jellyfish_5ptrim_compat")) katgpu_ingest_jf_5ptrim_compat(1);
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (!strncmp(argv[i], "--gpus=", 7)) gpus = atoi(argv[i] + 7);
+        else argv[kept++] = argv[i];
+    }
+    argc = kept;
+    if (gpus < 0 || gpus > 256) { std::cerr << "Error: Parsing Command Line: --gpus takes 1 .. 256" << std::endl; return 1; }
+    if (gpus == 0) return guarded(mode, argc - 1, argv + 1);
+    if (mode != "hist" && mode != "gcp" && mode != "comp") { std::cerr << "Error: Parsing Command Line: --gpus applies to hist, gcp and comp" << std::endl; return 1; }
+
+    char id_file[] = "/tmp/katgpu-comm-XXXXXX";
+    const int fd = mkstemp(id_file);
+    if (fd < 0) { std::cerr << "Error: cannot create a rendezvous file in /tmp" << std::endl; return 5; }
+    close(fd);
+    unlink(id_file);                                          // rank 0 re-creates it (atomically, with the id inside)
+    // how many devices there are, without initialising HIP in this process: the ROCm sysfs nodes (one per GPU with a gfx target)
+    int n_dev = 0;
+    if (const char* v = getenv("KATGPU_VISIBLE_DEVICES")) n_dev = atoi(v);
+    if (n_dev <= 0) {
+        for (int i = 0; i < 64; ++i) {
+            const std::string p = "/sys/class/kfd/kfd/topology/nodes/" + std::to_string(i) + "/properties";
+            FILE* f = fopen(p.c_str(), "r");
+            if (!f) break;
+            char line[256];
+            while (fgets(line, sizeof line, f)) { unsigned long long v = 0; if (sscanf(line, "simd_count %llu", &v) == 1 && v > 0) ++n_dev; }
+            fclose(f);
+        }
+        if (n_dev <= 0) n_dev = 1;
+        setenv("KATGPU_VISIBLE_DEVICES", std::to_string(n_dev).c_str(), 1);
+    }
+    std::vector<pid_t> kids;
+    for (int r = 0; r < gpus; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) { std::cerr << "Error: fork failed" << std::endl; for (pid_t k : kids) kill(k, SIGTERM); return 5; }
+        if (pid == 0) {
+            kat::Engine::setDist(r, gpus, id_file);
+            if (r != 0) { if (!freopen("/dev/null", "w", stdout)) {} }          // rank 0 speaks
+            const int rc = guarded(mode, argc - 1, argv + 1);
+            fflush(stdout);
+            _exit(rc);
+        }
+        kids.push_back(pid);
+    }
+    int first_bad = 0;                                        // the run's exit code: that of the first rank that failed
+    for (size_t left = kids.size(); left; --left) {
+        int st = 0;
+        const pid_t k = wait(&st);
+        if (k < 0) { if (!first_bad) first_bad = 5; break; }
+        const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        if (rc && !first_bad) {
+            first_bad = rc;
+            for (pid_t o : kids) if (o != k) kill(o, SIGTERM);                    // the others would wait for it for ever
+        }
+    }
+    unlink(id_file);
+    return first_bad;
 }

@@ -49,6 +49,7 @@ void Histogram::execute() {                                                     
     else { input.loadHeader(); input.loadHash(); }
     data.assign(nb_buckets, 0);
     bin();
+    if (input.dumpHash && Engine::dist() && Engine::world() > 1) throw OptionError("-d (dump hash) cannot be combined with --gpus > 1: every rank holds only the k-mers it owns");
     if (input.dumpHash) input.dump(outputPrefix + "-hash.jf" + std::to_string(input.merLen), threads);      // :105-108
     // merge(): nothing to do -- the device reduces into one array (the reference sums T per-thread histograms, :146-160)
 }
@@ -58,6 +59,7 @@ void Histogram::bin() {                                                         
     cout << "Bining kmers ...";
     cout.flush();
     Engine::check(katgpu_hist(input.hash, base, ceil, inc, data.data(), nb_buckets));
+    Engine::allreduce(data.data(), data.size());                 // Histogram::merge (src/histogram.cc:146-160), across GPUs
     cout << " done.";
     cout.flush();
 }
@@ -74,6 +76,7 @@ void Histogram::print(std::ostream& out) {                                      
 }
 
 void Histogram::save() {                                                                          // src/histogram.cc:115-129
+    if (!Engine::speaker()) return;                              // --gpus: rank 0 holds the whole result and writes it
     PhaseTimer timer;
     cout << "Saving results to disk ...";
     cout.flush();
@@ -127,6 +130,7 @@ void Gcp::execute() {                                                           
     // header->key_len() / 2 rows == k rows: GC count == k has no row (src/gcp.cc:93)
     gcp_mx = Matrix64(katgpu_table_k(input.hash), (uint32_t)cvgBins + 1);
     analyse();
+    if (input.dumpHash && Engine::dist() && Engine::world() > 1) throw OptionError("-d (dump hash) cannot be combined with --gpus > 1: every rank holds only the k-mers it owns");
     if (input.dumpHash) input.dump(outputPrefix + "-hash.jf" + std::to_string(input.merLen), threads);      // :102-105
 }
 
@@ -135,6 +139,7 @@ void Gcp::analyse() {                                                           
     cout << "Analysing kmers in hash ...";
     cout.flush();
     Engine::check(katgpu_gcp(input.hash, cvgScale, cvgBins, gcp_mx.data()));
+    Engine::allreduce(gcp_mx.data(), (size_t)gcp_mx.width() * gcp_mx.height());     // Gcp::merge (src/gcp.cc:128-138), across GPUs
     cout << "done.";
     cout.flush();
 }
@@ -155,6 +160,7 @@ void Gcp::printMainMatrix(std::ostream& out) {                                  
 }
 
 void Gcp::save() {                                                                                // src/gcp.cc:112-126
+    if (!Engine::speaker()) return;                              // --gpus: rank 0 holds the whole result and writes it
     PhaseTimer timer;
     cout << "Saving results to disk ...";
     cout.flush();
@@ -231,6 +237,7 @@ void Comp::execute() {                                                          
     if (allLoad) setMerLen((uint8_t)katgpu_table_k(input[0].hash));
     for (size_t i = 0; i < inputSize(); i++) input[i].validateMerLen(getMerLen());
     compare();
+    if (input[0].dumpHash && Engine::dist() && Engine::world() > 1) throw OptionError("-d (dump hashes) cannot be combined with --gpus > 1: every rank holds only the k-mers it owns");
     if (input[0].dumpHash)                                       // :174-179
         for (size_t i = 0; i < inputSize(); i++)
             input[i].dump(outputPrefix + "-hash" + std::to_string(input[i].index) + ".jf" + std::to_string(getMerLen()), threads);
@@ -251,6 +258,12 @@ void Comp::compare() {                                                          
     else
         Engine::check(katgpu_comp(input[0].hash, input[1].hash, input[0].canonical, input[1].canonical, d1Scale, d2Scale, d1Bins, d2Bins,
                                   main_matrix.data(), counters, spectra.data()));
+    if (Engine::dist()) {                                        // Comp::merge (src/comp.cc:248-265) + ThreadedCompCounters::merge, across GPUs
+        Engine::allreduce(main_matrix.data(), (size_t)d1Bins * d2Bins);
+        if (doThirdHash()) { Engine::allreduce(ends_matrix.data(), (size_t)d1Bins * d2Bins); Engine::allreduce(middle_matrix.data(), (size_t)d1Bins * d2Bins); Engine::allreduce(mixed_matrix.data(), (size_t)d1Bins * d2Bins); }
+        Engine::allreduce(counters, 13);
+        Engine::allreduce(spectra.data(), spectra.size());
+    }
     comp_counters.loadDevice(counters, spectra.data());
     cout << " done.";
     cout.flush();
@@ -299,6 +312,7 @@ void Comp::printHist(std::ostream& out, InputHandler& in, vector<uint64_t>& hist
 }
 
 void Comp::save() {                                                                               // src/comp.cc:185-233
+    if (!Engine::speaker()) return;                              // --gpus: rank 0 holds the whole result and writes it
     PhaseTimer timer;
     cout << "Saving results to disk ...";
     cout.flush();

@@ -1,0 +1,607 @@
+// kg_comm.hip -- the multi-GPU exchange behind the C ABI: katgpu_comm_* / katgpu_exchange_merge / katgpu_allreduce_u64.
+//
+// What it replaces: the reference's only cross-worker reductions -- ThreadedSparseMatrix::mergeThreadedMatricies
+// (lib/include/kat/sparse_matrix.hpp:324-335), ThreadedCompCounters::merge (lib/src/comp_counters.cc:230-254), Histogram::merge
+// (src/histogram.cc:146-160) -- which sum per-thread results inside the one process Comp::execute drives (src/comp.cc:108-183).
+// Here the workers are one process per GPU.  Each counts its share of the reads into a LOCAL table; the tables are then merged by
+// OWNER (a hash of the canonical k-mer, kg_device.hpp: owner_of): every (k-mer, count) record travels to its owner rank, which adds
+// the counts -- exact integer sums, so the result is bit-identical to one GPU's.  Reducers run on the owned shards and their small
+// results are summed with one all-reduce (katgpu_allreduce_u64).
+//
+// The exchange is region-ordered and in place (include/katgpu.h "region-ordered exchange"; the device side is kg_exchange.hip):
+// the table is extracted once into a send list in the arena (8-byte key + 4-byte count, grouped by owner, ordered by region inside an
+// owner), emptied -- it becomes the owner table -- and the list travels in chunks of consecutive regions, chunk c on the wire
+// while chunk c-1 is applied region by region in LDS (k_merge_apply).
+//
+// Transports.  RCCL (dlopen'ed: a single-GPU process never loads it): one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd per
+// chunk on a stream of its own -- every peer at once, which is the shape xGMI's point-to-point links want -- and ncclAllGather /
+// ncclAllReduce for the small things.  SHM: ranks of one node stage their records through files in /dev/shm; slow, exact, needs
+// nothing but a shared file system -- it is what carries ranks that SHARE a GPU (the test suite on a one-GPU box: RCCL refuses two
+// ranks on one device) and what a run falls back to when RCCL cannot be loaded or refuses to initialise (KATGPU_COMM_TRANSPORT=
+// rccl | shm | auto).  The protocol above the transport is the same code.
+#include "kg_host.hpp"
+
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+// ---- RCCL through dlopen ----
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return r;
+#define KG_SYM(F) r.F = reinterpret_cast<decltype(r.F)>(dlsym(r.lib, "nccl" #F))
+    KG_SYM(GetUniqueId); KG_SYM(CommInitRank); KG_SYM(CommDestroy); KG_SYM(GroupStart); KG_SYM(GroupEnd); KG_SYM(Send); KG_SYM(Recv);
+    KG_SYM(AllGather); KG_SYM(AllReduce); KG_SYM(GetErrorString);
+#undef KG_SYM
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather && r.AllReduce && r.GetErrorString;
+    return r;
+}
+
+// ---- the id ranks share: [magic | 16 bytes of token (names the /dev/shm objects) | has_rccl | ncclUniqueId] ----
+constexpr uint32_t ID_MAGIC = 0x4B474331;      // "KGC1"
+struct CommId { uint32_t magic; uint32_t has_rccl; char token[24]; ncclUniqueId nccl; };
+static_assert(sizeof(CommId) <= KATGPU_COMM_ID_BYTES, "id");
+
+// ---- rendezvous block in /dev/shm: a sense-reversing barrier and a small mailbox per rank ----
+constexpr size_t MAILBOX = 64 * 1024;
+struct ShmHeader {
+    std::atomic<uint32_t> arrived;
+    std::atomic<uint32_t> generation;
+    std::atomic<uint32_t> attached;
+    uint32_t world;
+};
+
+struct Msg { int peer; void* dev; size_t bytes; };          // one side of a point-to-point transfer (device memory)
+
+}  // namespace
+
+struct katgpu_comm {
+    katgpu_ctx* ctx = nullptr;
+    int rank = 0, world = 1;
+    bool use_rccl = false;
+    ncclComm_t nccl = nullptr;
+    hipStream_t stream = nullptr;             // transport stream: chunk c travels while chunk c-1 is merged on the context's stream
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::string token;
+    ShmHeader* hdr = nullptr; uint8_t* boxes = nullptr; size_t shm_bytes = 0;
+    uint64_t seq = 0;                         // names the shm files of successive transfers
+    double ms_exchange = 0, ms_merge = 0, ms_extract = 0, ms_allreduce = 0;
+    uint64_t bytes_sent = 0, merge_launches = 0;
+    std::string transport_note;
+    uint8_t* host_stage = nullptr; size_t host_stage_bytes = 0;
+};
+
+namespace {
+
+int comm_fail(katgpu_comm* m, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (m && m->ctx) m->ctx->err = buf;
+    return code;
+}
+#define NCCLCHK(m, expr)                                                                                               \
+    do {                                                                                                               \
+        ncclResult_t _r = (expr);                                                                                      \
+        if (_r != ncclSuccess) return comm_fail((m), KATGPU_ERR_DEVICE, "%s: %s", #expr, rccl().GetErrorString(_r));  \
+    } while (0)
+
+std::string shm_name(const std::string& token, const char* what, uint64_t seq = 0, int a = 0, int b = 0) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "/dev/shm/katgpu-%s-%s-%llu-%d-%d", token.c_str(), what, (unsigned long long)seq, a, b);
+    return buf;
+}
+
+// every rank of the communicator: wait until all have arrived
+void shm_barrier(katgpu_comm* m) {
+    if (m->world == 1) return;
+    const uint32_t gen = m->hdr->generation.load(std::memory_order_acquire);
+    if (m->hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)m->world) {
+        m->hdr->arrived.store(0, std::memory_order_relaxed);
+        m->hdr->generation.store(gen + 1, std::memory_order_release);
+    } else {
+        for (uint32_t spins = 0; m->hdr->generation.load(std::memory_order_acquire) == gen; ++spins)
+            if (spins > 1000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// small host values through the mailboxes: out[r * n .. ) = rank r's n bytes
+int host_allgather(katgpu_comm* m, const void* mine, size_t n, void* out) {
+    if (n > MAILBOX) return comm_fail(m, KATGPU_ERR_INVALID_ARG, "host_allgather: %zu bytes per rank", n);
+    if (m->world == 1) { memcpy(out, mine, n); return KATGPU_OK; }
+    memcpy(m->boxes + (size_t)m->rank * MAILBOX, mine, n);
+    shm_barrier(m);
+    for (int r = 0; r < m->world; ++r) memcpy((uint8_t*)out + (size_t)r * n, m->boxes + (size_t)r * MAILBOX, n);
+    shm_barrier(m);
+    return KATGPU_OK;
+}
+
+int ensure_host_stage(katgpu_comm* m, size_t bytes) {
+    if (m->host_stage_bytes >= bytes) return KATGPU_OK;
+    if (m->host_stage) hipHostFree(m->host_stage);
+    m->host_stage = nullptr; m->host_stage_bytes = 0;
+    if (hipHostMalloc((void**)&m->host_stage, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return comm_fail(m, KATGPU_ERR_NOMEM, "pinned staging of %zu bytes", bytes); }
+    m->host_stage_bytes = bytes;
+    return KATGPU_OK;
+}
+
+// A group of point-to-point transfers, all ranks together.  RCCL: asynchronous on m->stream, *ev is recorded behind it.  SHM:
+// done when this returns (every send is a file in /dev/shm that its receiver reads and the sender removes).
+int transfer(katgpu_comm* m, const std::vector<Msg>& sends, const std::vector<Msg>& recvs, hipEvent_t ev) {
+    katgpu_ctx* c = m->ctx;
+    if (m->use_rccl) {
+        bool any = false;
+        for (auto& s : sends) any = any || s.bytes;
+        for (auto& r : recvs) any = any || r.bytes;
+        if (any) {
+            NCCLCHK(m, rccl().GroupStart());
+            for (auto& s : sends) if (s.bytes) NCCLCHK(m, rccl().Send(s.dev, s.bytes, ncclUint8, s.peer, m->nccl, m->stream));
+            for (auto& r : recvs) if (r.bytes) NCCLCHK(m, rccl().Recv(r.dev, r.bytes, ncclUint8, r.peer, m->nccl, m->stream));
+            NCCLCHK(m, rccl().GroupEnd());
+        }
+        for (auto& s : sends) m->bytes_sent += s.bytes;
+        if (ev) HIPCHK(c, hipEventRecord(ev, m->stream));
+        return KATGPU_OK;
+    }
+    const uint64_t seq = m->seq++;
+    size_t biggest = 0;
+    for (auto& s : sends) biggest = std::max(biggest, s.bytes);
+    for (auto& r : recvs) biggest = std::max(biggest, r.bytes);
+    int rc = ensure_host_stage(m, std::max<size_t>(biggest, 4096));
+    if (rc) return rc;
+    for (auto& s : sends) {
+        if (!s.bytes) continue;
+        HIPCHK(c, hipMemcpy(m->host_stage, s.dev, s.bytes, hipMemcpyDeviceToHost));
+        const std::string name = shm_name(m->token, "x", seq, m->rank, s.peer);
+        const int fd = ::open(name.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0600);
+        if (fd < 0) return comm_fail(m, KATGPU_ERR_IO, "cannot create %s", name.c_str());
+        size_t off = 0;
+        while (off < s.bytes) { const ssize_t w = ::write(fd, m->host_stage + off, s.bytes - off); if (w <= 0) { ::close(fd); return comm_fail(m, KATGPU_ERR_IO, "short write to %s", name.c_str()); } off += (size_t)w; }
+        ::close(fd);
+        m->bytes_sent += s.bytes;
+    }
+    shm_barrier(m);
+    for (auto& r : recvs) {
+        if (!r.bytes) continue;
+        const std::string name = shm_name(m->token, "x", seq, r.peer, m->rank);
+        const int fd = ::open(name.c_str(), O_RDONLY);
+        if (fd < 0) return comm_fail(m, KATGPU_ERR_IO, "cannot open %s", name.c_str());
+        size_t off = 0;
+        while (off < r.bytes) { const ssize_t g = ::read(fd, m->host_stage + off, r.bytes - off); if (g <= 0) { ::close(fd); return comm_fail(m, KATGPU_ERR_IO, "short read from %s", name.c_str()); } off += (size_t)g; }
+        ::close(fd);
+        ::unlink(name.c_str());
+        HIPCHK(c, hipMemcpy(r.dev, m->host_stage, r.bytes, hipMemcpyHostToDevice));
+    }
+    shm_barrier(m);
+    return KATGPU_OK;
+}
+int transfer_wait(katgpu_comm* m, hipEvent_t ev) {
+    if (m->use_rccl && ev) HIPCHK(m->ctx, hipEventSynchronize(ev));
+    return KATGPU_OK;
+}
+
+// out[r * n ..) = rank r's n u64 (host arrays)
+int allgather_u64(katgpu_comm* m, const uint64_t* mine, size_t n, uint64_t* out) {
+    katgpu_ctx* c = m->ctx;
+    if (m->world == 1) { memcpy(out, mine, n * 8); return KATGPU_OK; }
+    if (!m->use_rccl && n * 8 <= MAILBOX) return host_allgather(m, mine, n * 8, out);
+    uint64_t* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, (size_t)(m->world + 1) * n * 8));
+    int rc = KATGPU_OK;
+    if (hipMemcpy(d, mine, n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "allgather upload");
+    if (!rc && m->use_rccl) {
+        ncclResult_t r = rccl().AllGather(d, d + n, n, ncclUint64, m->nccl, m->stream);
+        if (r != ncclSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "ncclAllGather: %s", rccl().GetErrorString(r));
+        else if (hipStreamSynchronize(m->stream) != hipSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "allgather");
+    } else if (!rc) {
+        std::vector<Msg> s, rv;
+        for (int p = 0; p < m->world; ++p) {
+            if (p == m->rank) { if (hipMemcpy(d + n + (size_t)p * n, d, n * 8, hipMemcpyDeviceToDevice) != hipSuccess) rc = KATGPU_ERR_DEVICE; continue; }
+            s.push_back({p, d, n * 8});
+            rv.push_back({p, d + n + (size_t)p * n, n * 8});
+        }
+        if (!rc) rc = transfer(m, s, rv, nullptr);
+    }
+    if (!rc && hipMemcpy(out, d + n, (size_t)m->world * n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "allgather download");
+    hipFree(d);
+    return rc;
+}
+
+uint64_t host_revcomp(uint64_t x, uint32_t k) {
+    uint64_t r = 0;
+    for (uint32_t i = 0; i < k; ++i) { r = (r << 2) | (3 - (x & 3)); x >>= 2; }
+    return r;
+}
+uint32_t host_owner_of(uint64_t key, uint32_t k, uint32_t n_parts) {          // kg_device.hpp: owner_of
+    const uint64_t rc = host_revcomp(key, k), cn = rc < key ? rc : key;
+    return (uint32_t)(((unsigned __int128)mix64(cn ^ 0x9E3779B97F4A7C15ULL) * n_parts) >> 64);
+}
+
+double wall_ms() { return now_ms(); }
+
+}  // namespace
+
+// ------------------------------------------------------------------ the communicator ------------------
+
+extern "C" int katgpu_comm_unique_id(void* id_out) {
+    if (!id_out) return KATGPU_ERR_INVALID_ARG;
+    CommId id{};
+    id.magic = ID_MAGIC;
+    FILE* f = fopen("/dev/urandom", "rb");
+    uint8_t rnd[10] = {0};
+    if (f) { if (fread(rnd, 1, sizeof rnd, f) != sizeof rnd) rnd[0] = (uint8_t)getpid(); fclose(f); }
+    snprintf(id.token, sizeof id.token, "%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", rnd[0], rnd[1], rnd[2], rnd[3], rnd[4], rnd[5], rnd[6], rnd[7], rnd[8], rnd[9]);
+    const char* tr = getenv("KATGPU_COMM_TRANSPORT");
+    if (!(tr && !strcmp(tr, "shm")) && rccl().ok && rccl().GetUniqueId(&id.nccl) == ncclSuccess) id.has_rccl = 1;
+    memset(id_out, 0, KATGPU_COMM_ID_BYTES);
+    memcpy(id_out, &id, sizeof id);
+    return KATGPU_OK;
+}
+
+extern "C" void katgpu_comm_free(katgpu_comm* m) {
+    if (!m) return;
+    if (m->ctx) hipSetDevice(m->ctx->device);
+    if (m->nccl) rccl().CommDestroy(m->nccl);
+    for (auto& e : m->ev) if (e) hipEventDestroy(e);
+    if (m->stream) hipStreamDestroy(m->stream);
+    if (m->host_stage) hipHostFree(m->host_stage);
+    if (m->hdr) {
+        const bool last = m->hdr->attached.fetch_sub(1) == 1;
+        munmap((void*)m->hdr, m->shm_bytes);
+        if (last || m->rank == 0) ::unlink(shm_name(m->token, "hdr").c_str());
+    }
+    delete m;
+}
+
+extern "C" int katgpu_comm_init(katgpu_ctx* c, int rank, int world, const void* id_in, katgpu_comm** out) {
+    if (!c || !out || !id_in || world < 1 || rank < 0 || rank >= world || world > (int)MAX_EXCHANGE_PARTS_HOST) return KATGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    CommId id;
+    memcpy(&id, id_in, sizeof id);
+    if (id.magic != ID_MAGIC) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_comm_init: not an id made by katgpu_comm_unique_id");
+    HIPCHK(c, hipSetDevice(c->device));
+    katgpu_comm* m = new katgpu_comm();
+    m->ctx = c; m->rank = rank; m->world = world;
+    id.token[sizeof id.token - 1] = 0;
+    m->token = id.token;
+    // the rendezvous block: every rank maps it (rank order does not matter: O_CREAT, then ftruncate to the same size)
+    m->shm_bytes = sizeof(ShmHeader) + (size_t)world * MAILBOX;
+    const std::string hname = shm_name(m->token, "hdr");
+    const int fd = ::open(hname.c_str(), O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)m->shm_bytes) != 0) { if (fd >= 0) ::close(fd); delete m; return fail(c, KATGPU_ERR_IO, "cannot create %s", hname.c_str()); }
+    void* p = mmap(nullptr, m->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    ::close(fd);
+    if (p == MAP_FAILED) { delete m; return fail(c, KATGPU_ERR_IO, "cannot map %s", hname.c_str()); }
+    m->hdr = (ShmHeader*)p;                       // (a fresh file is zero-filled: counters start at 0)
+    m->boxes = (uint8_t*)p + sizeof(ShmHeader);
+    m->hdr->attached.fetch_add(1);
+    // wait for everyone (bounded: a rank that never shows up must not hang the others for ever)
+    const double t0 = wall_ms();
+    while (m->hdr->attached.load() < (uint32_t)world) {
+        if (wall_ms() - t0 > 120e3) { katgpu_comm_free(m); return fail(c, KATGPU_ERR_DEVICE, "katgpu_comm_init: %d rank(s) of %d showed up within 120 s", (int)m->hdr->attached.load(), world); }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    HIPCHK(c, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    for (auto& e : m->ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // transport: RCCL when every rank can have it
+    const char* tr = getenv("KATGPU_COMM_TRANSPORT");
+    const bool want_rccl = !(tr && !strcmp(tr, "shm")) && id.has_rccl && rccl().ok;
+    uint32_t mine = 0;
+    if (want_rccl) {
+        ncclResult_t r = rccl().CommInitRank(&m->nccl, world, id.nccl, rank);
+        if (r == ncclSuccess) mine = 1;
+        else { m->nccl = nullptr; m->transport_note = std::string("RCCL refused to initialise (") + rccl().GetErrorString(r) + ")"; (void)hipGetLastError(); }
+    } else m->transport_note = tr && !strcmp(tr, "shm") ? "KATGPU_COMM_TRANSPORT=shm" : (id.has_rccl ? "librccl could not be loaded here" : "no RCCL id (librccl missing where the id was made)");
+    std::vector<uint32_t> all((size_t)world);
+    int rc = host_allgather(m, &mine, sizeof mine, all.data());
+    if (rc) { katgpu_comm_free(m); return rc; }
+    m->use_rccl = true;
+    for (uint32_t v : all) m->use_rccl = m->use_rccl && v;
+    if (!m->use_rccl && m->nccl) { rccl().CommDestroy(m->nccl); m->nccl = nullptr; if (m->transport_note.empty()) m->transport_note = "a peer could not initialise RCCL"; }
+    if (tr && !strcmp(tr, "rccl") && !m->use_rccl) { std::string why = m->transport_note; katgpu_comm_free(m); return fail(c, KATGPU_ERR_DEVICE, "KATGPU_COMM_TRANSPORT=rccl: %s", why.c_str()); }
+    if (g_trace) fprintf(stderr, "[katgpu] comm: rank %d of %d, transport %s%s%s\n", rank, world, m->use_rccl ? "RCCL" : "SHM (staged through /dev/shm)", m->transport_note.empty() ? "" : ": ", m->transport_note.c_str());
+    *out = m;
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_comm_rank(const katgpu_comm* m) { return m ? m->rank : -1; }
+extern "C" int katgpu_comm_world(const katgpu_comm* m) { return m ? m->world : 0; }
+extern "C" const char* katgpu_comm_transport(const katgpu_comm* m) { return !m ? "" : m->use_rccl ? "rccl" : "shm"; }
+extern "C" const char* katgpu_comm_transport_note(const katgpu_comm* m) { return m ? m->transport_note.c_str() : ""; }
+
+extern "C" int katgpu_comm_barrier(katgpu_comm* m) {
+    if (!m) return KATGPU_ERR_INVALID_ARG;
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
+    HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    shm_barrier(m);
+    return KATGPU_OK;
+}
+
+extern "C" int katgpu_comm_stats(katgpu_comm* m, double* ms_extract, double* ms_exchange, double* ms_merge, double* ms_allreduce, uint64_t* bytes_sent, uint64_t* merge_launches) {
+    if (!m) return KATGPU_ERR_INVALID_ARG;
+    if (ms_extract) *ms_extract = m->ms_extract;
+    if (ms_exchange) *ms_exchange = m->ms_exchange;
+    if (ms_merge) *ms_merge = m->ms_merge;
+    if (ms_allreduce) *ms_allreduce = m->ms_allreduce;
+    if (bytes_sent) *bytes_sent = m->bytes_sent;
+    if (merge_launches) *merge_launches = m->merge_launches;
+    return KATGPU_OK;
+}
+
+// Sum of `n` u64 over all ranks, in place, every rank gets the result: the small results of the reducers (hist 80 KB, gcp 216 KB,
+// comp 8 MB + counters) -- what mergeThreadedMatricies / ThreadedCompCounters::merge / Histogram::merge do for threads.
+extern "C" int katgpu_allreduce_u64(katgpu_comm* m, uint64_t* buf, size_t n) {
+    if (!m || (n && !buf)) return KATGPU_ERR_INVALID_ARG;
+    if (m->world == 1 || n == 0) return KATGPU_OK;
+    katgpu_ctx* c = m->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    const double t0 = wall_ms();
+    int rc = KATGPU_OK;
+    if (m->use_rccl) {
+        uint64_t* d = nullptr;
+        HIPCHK(c, hipMalloc((void**)&d, n * 8));
+        if (hipMemcpy(d, buf, n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "allreduce upload");
+        if (!rc) {
+            ncclResult_t r = rccl().AllReduce(d, d, n, ncclUint64, ncclSum, m->nccl, m->stream);
+            if (r != ncclSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "ncclAllReduce: %s", rccl().GetErrorString(r));
+            else if (hipStreamSynchronize(m->stream) != hipSuccess || hipMemcpy(buf, d, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "allreduce");
+        }
+        hipFree(d);
+    } else {
+        // every rank writes its vector, reads all of them (host memory only: the vectors are small)
+        const uint64_t seq = m->seq++;
+        const std::string mine = shm_name(m->token, "r", seq, m->rank, 0);
+        FILE* f = fopen(mine.c_str(), "wb");
+        if (!f || fwrite(buf, 8, n, f) != n) rc = comm_fail(m, KATGPU_ERR_IO, "cannot write %s", mine.c_str());
+        if (f) fclose(f);
+        shm_barrier(m);
+        std::vector<uint64_t> other(n);
+        for (int r = 0; r < m->world && !rc; ++r) {
+            if (r == m->rank) continue;
+            const std::string name = shm_name(m->token, "r", seq, r, 0);
+            FILE* g = fopen(name.c_str(), "rb");
+            if (!g || fread(other.data(), 8, n, g) != n) rc = comm_fail(m, KATGPU_ERR_IO, "cannot read %s", name.c_str());
+            if (g) fclose(g);
+            if (!rc) for (size_t i = 0; i < n; ++i) buf[i] += other[i];
+        }
+        shm_barrier(m);
+        ::unlink(mine.c_str());
+    }
+    m->ms_allreduce += wall_ms() - t0;
+    return rc;
+}
+
+// ------------------------------------------------------------------ the exchange ----------------------
+
+static size_t xalign(size_t n, size_t a = 256) { return (n + a - 1) / a * a; }
+static size_t exchange_bytes(uint64_t total_send, uint64_t set_records) {
+    return xalign(8 * std::max<uint64_t>(total_send, 1)) + xalign(4 * std::max<uint64_t>(total_send, 1)) +
+           2 * (xalign(8 * std::max<uint64_t>(set_records, 1)) + xalign(4 * std::max<uint64_t>(set_records, 1))) + 256;
+}
+
+// Route every record of `t` to its owner rank, IN PLACE: on return the table holds exactly the k-mers this rank owns, their counts
+// summed over all ranks.  It keeps its storage and its region grid (a second table created "like" the first still joins with it
+// region by region).  Every rank of the communicator calls this, with tables of one k / one strand mode.  world == 1 runs the whole
+// protocol on the rank's own send list (extraction, clear, region-by-region merge): the table comes back as it was.
+extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
+    if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = m->ctx;
+    NARROW_ONLY(t, "katgpu_exchange_merge (wide tables: katgpu_table_partition_wide + katgpu_table_merge_device_wide)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int world = m->world, rank = m->rank;
+    const double t_begin = wall_ms();
+
+    // ---- geometry of every rank's table: which senders are ordered by MY regions ----
+    katgpu_geometry geo;
+    int rc = katgpu_table_geometry(t, &geo);
+    if (rc) return rc;
+    const uint64_t g_mine[6] = {geo.k, geo.canonical, geo.n_regions, geo.region_slots, geo.p1, geo.p2};
+    std::vector<uint64_t> geos((size_t)world * 6);
+    rc = allgather_u64(m, g_mine, 6, geos.data());
+    if (rc) return rc;
+    for (int s = 0; s < world; ++s)
+        if (geos[(size_t)s * 6] != geo.k || geos[(size_t)s * 6 + 1] != geo.canonical) return fail(c, KATGPU_ERR_MISMATCH, "katgpu_exchange_merge: ranks disagree on k / canonical");
+    auto R_of = [&](int s) { return (uint32_t)geos[(size_t)s * 6 + 2]; };
+    const uint32_t R = geo.n_regions;
+    uint32_t R_min = R;
+    for (int s = 0; s < world; ++s) R_min = std::min(R_min, R_of(s));
+
+    // ---- pass 1: how many records go where, per region ----
+    uint32_t* d_cnt = nullptr;                                    // [world x R] u32: records of region g owned by part p (small: outside the arena)
+    HIPCHK(c, hipMalloc((void**)&d_cnt, (size_t)world * R * 4 + 64));
+    struct Free { void* p; ~Free() { hipFree(p); } } free_cnt{d_cnt};
+    std::vector<uint64_t> sizes((size_t)world);
+    rc = katgpu_table_extract_sizes(t, (uint32_t)world, d_cnt, sizes.data());
+    if (rc) return rc;
+    uint64_t total_send = 0;
+    for (uint64_t s : sizes) total_send += s;
+    std::vector<uint64_t> s_all((size_t)world * world);
+    rc = allgather_u64(m, sizes.data(), (size_t)world, s_all.data());
+    if (rc) return rc;
+    std::vector<uint64_t> recv_from((size_t)world);
+    for (int s = 0; s < world; ++s) recv_from[s] = s_all[(size_t)s * world + rank];         // what each peer holds for me
+    // the region counts of what I will receive: row `rank` of every peer's matrix
+    std::vector<uint32_t*> d_rcnt((size_t)world, nullptr);
+    struct FreeAll { std::vector<uint32_t*>& v; int self; ~FreeAll() { for (size_t i = 0; i < v.size(); ++i) if ((int)i != self) hipFree(v[i]); } } free_rcnt{d_rcnt, rank};
+    {
+        std::vector<Msg> sends, recvs;
+        for (int p = 0; p < world; ++p) {
+            if (p == rank) { d_rcnt[p] = d_cnt + (size_t)rank * R; continue; }
+            HIPCHK(c, hipMalloc((void**)&d_rcnt[p], (size_t)R_of(p) * 4 + 64));
+            sends.push_back({p, d_cnt + (size_t)p * R, (size_t)R * 4});
+            recvs.push_back({p, d_rcnt[p], (size_t)R_of(p) * 4});
+        }
+        rc = transfer(m, sends, recvs, m->ev[0]);
+        if (!rc) rc = transfer_wait(m, m->ev[0]);
+        if (rc) return rc;
+    }
+    // prefix sums on the host (cnt: mine, per owner; rcnt: per sender, of the records it holds for me)
+    std::vector<std::vector<uint64_t>> cnt_cum((size_t)world), rcnt_cum((size_t)world);
+    {
+        std::vector<uint32_t> h;
+        for (int p = 0; p < world; ++p) {
+            h.resize(R);
+            HIPCHK(c, hipMemcpy(h.data(), d_cnt + (size_t)p * R, (size_t)R * 4, hipMemcpyDeviceToHost));
+            cnt_cum[p].assign((size_t)R + 1, 0);
+            for (uint32_t g = 0; g < R; ++g) cnt_cum[p][g + 1] = cnt_cum[p][g] + h[g];
+            h.resize(R_of(p));
+            HIPCHK(c, hipMemcpy(h.data(), d_rcnt[p], (size_t)R_of(p) * 4, hipMemcpyDeviceToHost));
+            rcnt_cum[p].assign((size_t)R_of(p) + 1, 0);
+            for (uint32_t g = 0; g < R_of(p); ++g) rcnt_cum[p][g + 1] = rcnt_cum[p][g] + h[g];
+        }
+    }
+    std::vector<uint64_t> part_base((size_t)world + 1, 0);
+    for (int p = 0; p < world; ++p) part_base[p + 1] = part_base[p] + sizes[p];
+
+    // ---- chunks of consecutive regions, as few as the exchange scratch allows (>= 4 for the overlap) ----
+    uint64_t recv_other = 0;
+    for (int s = 0; s < world; ++s) if (s != rank) recv_other += recv_from[s];
+    uint32_t C = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)hook_u64("KATGPU_TEST_EXCHANGE_CHUNKS", 4), R_min));
+    void* arena = nullptr; size_t cap = 0;
+    {
+        const size_t want = exchange_bytes(total_send, (recv_other + C - 1) / C * 5 / 4);
+        rc = katgpu_scratch_acquire(c, 0, &arena, &cap);
+        if (!rc && cap < want && katgpu_scratch_acquire(c, want, &arena, &cap) != KATGPU_OK) rc = katgpu_scratch_acquire(c, 0, &arena, &cap);   // (keeps the old arena when the larger one cannot be had)
+        if (rc) return rc;
+    }
+    std::vector<std::vector<uint64_t>> bounds((size_t)world);    // region boundaries of the chunks, per sender's grid
+    std::vector<std::vector<uint64_t>> recv_sz((size_t)world);   // [sender][chunk]
+    uint64_t set_records = 1;
+    for (;;) {
+        for (int s = 0; s < world; ++s) {
+            bounds[s].resize((size_t)C + 1);
+            for (uint32_t i = 0; i <= C; ++i) bounds[s][i] = (uint64_t)i * R_of(s) / C;
+            recv_sz[s].resize(C);
+            for (uint32_t i = 0; i < C; ++i) recv_sz[s][i] = rcnt_cum[s][bounds[s][i + 1]] - rcnt_cum[s][bounds[s][i]];
+        }
+        set_records = 1;
+        for (uint32_t i = 0; i < C; ++i) { uint64_t x = 0; for (int s = 0; s < world; ++s) if (s != rank) x += recv_sz[s][i]; set_records = std::max(set_records, x); }
+        uint64_t fits = exchange_bytes(total_send, set_records) <= cap ? 1 : 0;
+        std::vector<uint64_t> all((size_t)world);
+        rc = allgather_u64(m, &fits, 1, all.data());
+        if (rc) return rc;
+        bool ok = true;
+        for (uint64_t v : all) ok = ok && v;
+        if (ok) break;
+        if (C >= R_min) return fail(c, KATGPU_ERR_NOMEM, "katgpu_exchange_merge: the send list and one region's receive buffers do not fit the exchange scratch");
+        C = std::min(C * 2, R_min);
+    }
+    std::vector<std::vector<uint64_t>> send_off((size_t)world);  // [owner][chunk boundary]: index into the send list
+    for (int p = 0; p < world; ++p) {
+        send_off[p].resize((size_t)C + 1);
+        for (uint32_t i = 0; i <= C; ++i) send_off[p][i] = part_base[p] + cnt_cum[p][bounds[rank][i]];
+    }
+
+    // ---- pass 2: the send list; the emptied table becomes the owner table ----
+    uint8_t* a = (uint8_t*)arena;
+    uint64_t* skeys = (uint64_t*)a;           a += xalign(8 * std::max<uint64_t>(total_send, 1));
+    uint32_t* scounts = (uint32_t*)a;         a += xalign(4 * std::max<uint64_t>(total_send, 1));
+    uint64_t* rkeys[2]; uint32_t* rcounts[2];
+    for (int i = 0; i < 2; ++i) { rkeys[i] = (uint64_t*)a; a += xalign(8 * set_records); rcounts[i] = (uint32_t*)a; a += xalign(4 * set_records); }
+    constexpr uint32_t BIG = 4200;
+    std::vector<uint64_t> big_keys(BIG), big_counts(BIG);
+    uint32_t n_big = 0;
+    rc = katgpu_table_extract(t, (uint32_t)world, d_cnt, skeys, scounts, big_keys.data(), big_counts.data(), BIG, &n_big);
+    if (rc) return rc;
+    rc = katgpu_table_clear(t);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));                   // the send list is complete before the transport stream reads it
+    m->ms_extract += wall_ms() - t_begin;
+
+    struct Layout { int s; uint64_t o, n; };
+    auto post = [&](uint32_t ch, std::vector<Layout>& layout) -> int {
+        std::vector<Msg> sends, recvs;
+        uint64_t o = 0;
+        layout.clear();
+        for (int s = 0; s < world; ++s) {
+            if (s == rank) continue;
+            const uint64_t a0 = send_off[s][ch], n_out = send_off[s][ch + 1] - a0;
+            if (n_out) { sends.push_back({s, skeys + a0, (size_t)n_out * 8}); sends.push_back({s, scounts + a0, (size_t)n_out * 4}); }
+            const uint64_t n_in = recv_sz[s][ch];
+            if (n_in) { recvs.push_back({s, rkeys[ch & 1] + o, (size_t)n_in * 8}); recvs.push_back({s, rcounts[ch & 1] + o, (size_t)n_in * 4}); }
+            layout.push_back({s, o, n_in});
+            o += n_in;
+        }
+        return transfer(m, sends, recvs, m->ev[ch & 1]);
+    };
+    auto merge = [&](uint32_t ch, const std::vector<Layout>& layout) -> int {
+        const uint32_t my_lo = (uint32_t)bounds[rank][ch], my_hi = (uint32_t)bounds[rank][ch + 1];
+        std::vector<katgpu_merge_source> src;
+        const uint64_t a0 = send_off[rank][ch], n_own = send_off[rank][ch + 1] - a0;
+        if (n_own) src.push_back({skeys + a0, scounts + a0, d_rcnt[rank] + my_lo, n_own, geo.p1, geo.p2});
+        for (auto& l : layout) {
+            if (!l.n) continue;
+            const bool same_regions = bounds[l.s][ch] == my_lo && bounds[l.s][ch + 1] == my_hi && geos[(size_t)l.s * 6 + 4] == geo.p1 && geos[(size_t)l.s * 6 + 5] == geo.p2;
+            src.push_back({rkeys[ch & 1] + l.o, rcounts[ch & 1] + l.o, same_regions ? d_rcnt[l.s] + my_lo : nullptr, l.n, (uint32_t)geos[(size_t)l.s * 6 + 4], (uint32_t)geos[(size_t)l.s * 6 + 5]});
+        }
+        if (src.empty()) return KATGPU_OK;
+        ++m->merge_launches;
+        return katgpu_table_merge_regions(t, my_lo, my_hi, (uint32_t)src.size(), src.data());
+    };
+    std::vector<Layout> lay[2];
+    for (uint32_t ch = 0; ch <= C; ++ch) {
+        if (ch < C) {                                             // chunk ch goes on the wire ...
+            const double t0 = wall_ms();
+            rc = post(ch, lay[ch & 1]);
+            if (rc) return rc;
+            m->ms_exchange += wall_ms() - t0;
+        }
+        if (ch > 0) {                                             // ... while chunk ch - 1 is applied
+            double t0 = wall_ms();
+            rc = transfer_wait(m, m->ev[(ch - 1) & 1]);
+            if (rc) return rc;
+            m->ms_exchange += wall_ms() - t0;
+            t0 = wall_ms();
+            rc = merge(ch - 1, lay[(ch - 1) & 1]);
+            if (rc) return rc;
+            m->ms_merge += wall_ms() - t0;
+        }
+    }
+
+    // ---- out-of-band records: counts above 32 bits and the all-ones k-mer (a handful) ----
+    std::vector<uint64_t> mine((size_t)1 + 2 * BIG, 0), everyone((size_t)world * (1 + 2 * BIG));
+    mine[0] = n_big;
+    for (uint32_t i = 0; i < n_big; ++i) { mine[1 + i] = big_keys[i]; mine[1 + BIG + i] = big_counts[i]; }
+    rc = allgather_u64(m, mine.data(), mine.size(), everyone.data());
+    if (rc) return rc;
+    std::vector<uint64_t> ok_keys, ok_counts;
+    for (int s = 0; s < world; ++s) {
+        const uint64_t* e = everyone.data() + (size_t)s * (1 + 2 * BIG);
+        for (uint64_t i = 0; i < e[0] && i < BIG; ++i)
+            if (host_owner_of(e[1 + i], geo.k, (uint32_t)world) == (uint32_t)rank) { ok_keys.push_back(e[1 + i]); ok_counts.push_back(e[1 + BIG + i]); }
+    }
+    if (!ok_keys.empty()) { rc = katgpu_table_merge_host(t, ok_keys.data(), ok_counts.data(), ok_keys.size()); if (rc) return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    shm_barrier(m);                                               // nobody reuses its arena while a peer may still be reading from it
+    return refresh_counters(t);
+}

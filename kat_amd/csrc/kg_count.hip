@@ -758,8 +758,10 @@ extern "C" int katgpu_count_bases_host(katgpu_table* t, const uint8_t* bases, si
     return f.finish();
 }
 
-extern "C" int katgpu_count_files(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p) {
-    if (!t || !paths) return KATGPU_ERR_INVALID_ARG;
+// rank / world: this process's share of the group in a multi-GPU run.  Plain FASTQ files big enough for the device scan are cut
+// between the ranks batch by batch (kg_scan.hip); every other file goes whole to rank (index mod world).
+static int count_files_impl(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p, int rank, int world) {
+    if (!t || !paths || world < 1 || rank < 0 || rank >= world) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     t->carry_n = 0;
@@ -768,11 +770,20 @@ extern "C" int katgpu_count_files(katgpu_table* t, const char* const* paths, siz
     std::vector<const char*> rest;
     std::vector<uint16_t> rest_trim;
     size_t rest_bytes = 0;
+    size_t whole = 0;                                              // files that are dealt whole, counted over the group
     for (size_t i = 0; i < n_paths; ++i) {
+        const uint32_t trim = trim5p ? trim5p[i] : 0;
         bool took = false;
-        int rc = count_file_device_scan(t, paths[i], trim5p ? trim5p[i] : 0, &took);
+        uint8_t first = 0;
+        if (world > 1 && device_scan_applies(paths[i], trim, nullptr, &first) && first == '@') {
+            int rc = count_file_device_scan(t, paths[i], trim, &took, rank, world);
+            if (rc) return rc;
+            if (took) continue;
+        }
+        if (world > 1 && (int)(whole++ % (size_t)world) != rank) continue;       // another rank's file
+        int rc = count_file_device_scan(t, paths[i], trim, &took);
         if (rc) return rc;
-        if (!took) { rest.push_back(paths[i]); rest_trim.push_back(trim5p ? trim5p[i] : 0); rest_bytes += (size_t)kg::file_size_or_zero(paths[i]); }
+        if (!took) { rest.push_back(paths[i]); rest_trim.push_back((uint16_t)trim); rest_bytes += (size_t)kg::file_size_or_zero(paths[i]); }
     }
     if (rest.empty()) return refresh_counters(t);
     HostFeeder f(t);
@@ -782,6 +793,13 @@ extern "C" int katgpu_count_files(katgpu_table* t, const char* const* paths, siz
     rc = kg::stream_group(rest.data(), rest.size(), trim5p ? rest_trim.data() : nullptr, t->d.k, [&](const uint8_t* p, size_t n) { return f.push(p, n); }, &err);
     if (rc) return err.empty() ? rc : fail(c, rc, "%s", err.c_str());
     return f.finish();
+}
+
+extern "C" int katgpu_count_files(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p) {
+    return count_files_impl(t, paths, n_paths, trim5p, 0, 1);
+}
+extern "C" int katgpu_count_files_sharded(katgpu_table* t, const char* const* paths, size_t n_paths, const uint16_t* trim5p, int rank, int world) {
+    return count_files_impl(t, paths, n_paths, trim5p, rank, world);
 }
 
 extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_paths, uint32_t k, int canonical,

@@ -121,6 +121,7 @@ static const bool g_testing = getenv("KATGPU_TESTING") != nullptr;
 inline const char* hook(const char* name) { return g_testing ? getenv(name) : nullptr; }
 inline uint64_t hook_u64(const char* name, uint64_t dflt) { const char* v = hook(name); return v ? strtoull(v, nullptr, 10) : dflt; }
 
+constexpr int MAX_EXCHANGE_PARTS_HOST = 256;        // ranks of an exchange (kg_kernels.hpp: MAX_EXCHANGE_PARTS)
 // table geometry limits
 constexpr uint32_t AP2_MAX_SLOTS = 10240;           // the apply kernels: a region of at most this many slots (120 KB of KV12 region + 36 KB of queues; 80 KB packed)
 constexpr int AP2_QCAP_BIG = 192;                   // KV12 apply: queue entries per wave for regions beyond 8192 slots
@@ -136,7 +137,7 @@ int ensure_room(katgpu_table* t, uint64_t incoming);
 int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n);
 // large plain FASTQ / FASTA files: raw bytes to the device, record scan there (kg_scan.hip).  *took = false: not a file for this path
 bool device_scan_applies(const char* path, uint32_t trim5p, uint64_t* size_out, uint8_t* first_byte);
-int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, bool* took);
+int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, bool* took, int rank = 0, int world = 1);   // world > 1: this rank's batches of a FASTQ file
 
 // HIP events around a launch on the ctx stream; elapsed time is collected lazily.
 struct ScopedTimer {

@@ -59,6 +59,12 @@ struct RawFeeder {
     uint64_t size = 0;
     ScanType type = SCAN_FASTQ;
     size_t batch = 0, segment = 0, overlap = 0, buf_bytes = 0;
+    // Sharding over the ranks of a multi-GPU run (FASTQ only): rank r takes batches r, r + world, ...  A chunk's two ends are found
+    // from the file bytes around its batch's nominal ends by ONE function (kg_ingest: find_record_start) -- the rank that owns the
+    // batch before computes the same cut from the same bytes -- so the chunks tile the file without talking to each other.
+    int shard_rank = 0, shard_world = 1;
+    std::vector<uint64_t> my;                                     // the batches this feeder processes, in order
+    static constexpr size_t PRE = 64;                             // bytes read in front of a batch: a record that starts exactly at the nominal cut needs its '\n'
     static constexpr size_t HEAD = 64;                            // carry area in front of an output buffer (k - 1 <= 62 bytes), keeps the payload 16-byte aligned
     // two batch buffers: pinned host, raw device, output device
     uint8_t* pin[2] = {nullptr, nullptr};
@@ -74,10 +80,10 @@ struct RawFeeder {
     // readers
     std::vector<std::thread> readers;
     std::mutex mu; std::condition_variable cv;
-    uint64_t next_seg = 0;                                        // global segment counter (batch b = segments [b * spb, (b + 1) * spb))
-    uint64_t n_batches = 0, spb = 0;                              // segments per batch (the last one of a batch also covers the overlap)
-    std::vector<uint32_t> done_segs;                              // per batch: segments read and enqueued
-    uint64_t consumed = 0;                                        // batches the main thread is through with: batch b may be read when b < consumed + 2
+    uint64_t next_seg = 0;                                        // segment counter over my batches (my[j] = segments [j * spb, (j + 1) * spb))
+    uint64_t n_batches = 0, spb = 0;                              // batches of the file; segments per batch (a batch's first one also reads PRE, its last one the overlap)
+    std::vector<uint32_t> done_segs;                              // per my[j]: segments read and enqueued
+    uint64_t consumed = 0;                                        // of my batches, how many the main thread is through with: my[j] may be read when j < consumed + 2
     bool stop = false, io_error = false;
 
     RawFeeder(katgpu_table* t_, const char* p) : t(t_), c(t_->ctx), path(p) {}
@@ -102,9 +108,10 @@ struct RawFeeder {
         if (fd >= 0) { ::close(fd); fd = -1; }
     }
 
-    int setup(uint64_t file_size, uint8_t first) {
+    int setup(uint64_t file_size, uint8_t first, int rank, int world) {
         size = file_size;
         type = first == '@' ? SCAN_FASTQ : SCAN_FASTA;
+        shard_rank = rank; shard_world = world;
         batch = g_test_scan_batch ? g_test_scan_batch : g_scan_batch;
         segment = g_test_scan_segment ? g_test_scan_segment : std::min(g_scan_segment, batch);
         overlap = g_test_scan_overlap ? g_test_scan_overlap : g_scan_overlap_dflt;
@@ -114,11 +121,13 @@ struct RawFeeder {
         batch = std::min<size_t>(batch, (size_t)((size + segment - 1) / segment * segment));       // a small file: one batch of its own size
         spb = batch / segment;
         n_batches = (size + batch - 1) / batch;
-        buf_bytes = batch + overlap + 64;
-        done_segs.assign(n_batches, 0);
+        for (uint64_t b = (uint64_t)rank; b < n_batches; b += (uint64_t)world) my.push_back(b);
+        buf_bytes = PRE + batch + overlap + 64;
+        done_segs.assign(my.size(), 0);
+        if (my.empty()) return KATGPU_OK;
         fd = ::open(path, O_RDONLY);
         if (fd < 0) return fail(c, KATGPU_ERR_IO, "Could not find input file at: %s", path);
-        const int nb = n_batches > 1 ? 2 : 1;
+        const int nb = my.size() > 1 ? 2 : 1;
         for (int i = 0; i < nb; ++i) {
             HIPCHK(c, hipHostMalloc((void**)&pin[i], buf_bytes, hipHostMallocDefault));
             HIPCHK(c, pool_alloc(c, (void**)&raw[i], buf_bytes));
@@ -140,8 +149,8 @@ struct RawFeeder {
         return KATGPU_OK;
     }
 
-    // file range of batch b as read: [b * batch, min(size, (b + 1) * batch + overlap))
-    uint64_t batch_lo(uint64_t b) const { return b * (uint64_t)batch; }
+    // file range of batch b as read: [base, hi_read) = [b * batch - PRE, min(size, (b + 1) * batch + overlap)); buffer byte 0 = file byte base
+    uint64_t batch_base(uint64_t b) const { return b ? b * (uint64_t)batch - PRE : 0; }
     uint64_t batch_hi_read(uint64_t b) const { return std::min<uint64_t>(size, (b + 1) * (uint64_t)batch + overlap); }
 
     void read_loop() {
@@ -150,42 +159,43 @@ struct RawFeeder {
             uint64_t seg;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || io_error || (next_seg < n_batches * spb && next_seg / spb < consumed + 2); });
-                if (stop || io_error || next_seg >= n_batches * spb) return;
+                cv.wait(lk, [&] { return stop || io_error || next_seg >= my.size() * spb || next_seg / spb < consumed + 2; });
+                if (stop || io_error || next_seg >= my.size() * spb) return;
                 seg = next_seg++;
             }
-            const uint64_t b = seg / spb, s = seg % spb;
-            const int buf = (int)(b & 1);
-            // segment s of batch b: [lo + s * segment, lo + (s + 1) * segment); the batch's last segment also reads the overlap
-            uint64_t f0 = batch_lo(b) + s * (uint64_t)segment, f1 = s + 1 == spb ? batch_hi_read(b) : std::min<uint64_t>(size, f0 + segment);
+            const uint64_t j = seg / spb, s = seg % spb, b = my[j];
+            const int buf = (int)(j & 1);
+            // segment s of batch b: [b * batch + s * segment, ... + segment); the first one also reads PRE, the last one the overlap
+            const uint64_t f0 = s ? b * (uint64_t)batch + s * (uint64_t)segment : batch_base(b);
+            const uint64_t f1 = s + 1 == spb ? batch_hi_read(b) : std::min<uint64_t>(size, b * (uint64_t)batch + (s + 1) * (uint64_t)segment);
             bool ok = true;
             if (f0 < f1) {
-                uint8_t* dst = pin[buf] + (f0 - batch_lo(b));
+                uint8_t* dst = pin[buf] + (f0 - batch_base(b));
                 uint64_t got = 0;
                 while (got < f1 - f0) {
                     const ssize_t r = pread(fd, dst + got, (size_t)std::min<uint64_t>(f1 - f0 - got, (uint64_t)1 << 30), (off_t)(f0 + got));
                     if (r <= 0) { ok = false; break; }
                     got += (uint64_t)r;
                 }
-                if (ok && hipMemcpyAsync(raw[buf] + (f0 - batch_lo(b)), dst, (size_t)(f1 - f0), hipMemcpyHostToDevice, up[buf]) != hipSuccess) ok = false;
+                if (ok && hipMemcpyAsync(raw[buf] + (f0 - batch_base(b)), dst, (size_t)(f1 - f0), hipMemcpyHostToDevice, up[buf]) != hipSuccess) ok = false;
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!ok) io_error = true;
-                ++done_segs[b];
+                ++done_segs[j];
             }
             cv.notify_all();
         }
     }
 
     // wait until every segment of batch b is in pinned memory and its copy enqueued, then until the copies have landed
-    int wait_batch(uint64_t b) {
+    int wait_batch(uint64_t j) {
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return io_error || done_segs[b] == spb; });
+            cv.wait(lk, [&] { return io_error || done_segs[j] == spb; });
             if (io_error) return fail(c, KATGPU_ERR_IO, "read error on %s", path);
         }
-        HIPCHK(c, hipStreamSynchronize(up[b & 1]));
+        HIPCHK(c, hipStreamSynchronize(up[j & 1]));
         return KATGPU_OK;
     }
     void batch_consumed() {
@@ -284,23 +294,36 @@ struct RawFeeder {
         return KATGPU_OK;
     }
 
+    // first record start at or after file offset `nominal` (FASTQ), as every rank computes it: from the bytes [nominal - 1, nominal + overlap)
+    int64_t fastq_cut(const uint8_t* buf, uint64_t base, uint64_t hi_read, uint64_t nominal) const {
+        const uint64_t lim = std::min<uint64_t>(hi_read, nominal + overlap);
+        return kg::find_record_start(kg::ParseState::FASTQ, buf, (int64_t)base, (int64_t)(lim - base), (int64_t)nominal);
+    }
+
     int run() {
         const uint32_t k = t->d.k;
+        const bool sharded = shard_world > 1;
         uint64_t cut_lo = 0;                                      // file offset where the next chunk starts: a proven record / line start
         uint8_t carry[HEAD]; uint32_t carry_n = 0;                // last k-1 bytes of the base stream so far (host copy, for the fall-back)
         int prev_buf = -1; uint64_t prev_out_n = 0;
-        for (uint64_t b = 0; b < n_batches; ++b) {
-            int rc = wait_batch(b);
+        for (uint64_t j = 0; j < my.size(); ++j) {
+            int rc = wait_batch(j);
             if (rc) return rc;
-            const int buf = (int)(b & 1);
-            const uint64_t lo = batch_lo(b), hi_read = batch_hi_read(b);
+            const uint64_t b = my[j];
+            const int buf = (int)(j & 1);
+            const uint64_t lo = batch_base(b), hi_read = batch_hi_read(b);
+            bool cut_ok = true;
+            if (sharded) {                                        // this chunk's start, found the way the owner of batch b - 1 finds its chunk's end
+                cut_lo = 0;
+                if (b) { const int64_t f = fastq_cut(pin[buf], lo, hi_read, b * (uint64_t)batch); if (f < 0) cut_ok = false; else cut_lo = (uint64_t)f; }
+                prev_buf = -1; prev_out_n = 0;                    // (FASTQ chunks end on a record's 'N': nothing to carry between them)
+            }
             // the chunk's end: the first record start (FASTQ) / line start (FASTA) at or after the nominal end, inside what was read
             uint64_t cut_hi = size;
-            bool cut_ok = true;
             if (b + 1 < n_batches) {
                 const uint64_t nominal = (b + 1) * (uint64_t)batch;
                 if (type == SCAN_FASTQ) {
-                    const int64_t f = kg::find_record_start(kg::ParseState::FASTQ, pin[buf], (int64_t)lo, (int64_t)(hi_read - lo), (int64_t)nominal);
+                    const int64_t f = fastq_cut(pin[buf], lo, hi_read, nominal);
                     if (f < 0) cut_ok = false; else cut_hi = (uint64_t)f;
                 } else {
                     const uint8_t* nl = (const uint8_t*)memchr(pin[buf] + (nominal - 1 - lo), '\n', (size_t)(hi_read - (nominal - 1)));
@@ -312,6 +335,8 @@ struct RawFeeder {
                 rc = scan(buf, cut_lo - lo, cut_hi - lo, &valid, &out_n);
                 if (rc) return rc;
             }
+            if (!valid && sharded)
+                return fail(c, KATGPU_ERR_FASTQ, "%s: batch %llu is not plain four-line FASTQ (or holds a '\\r'): such a file cannot be cut between GPUs -- run it on one", path, (unsigned long long)b);
             if (!valid) {
                 if (g_trace) fprintf(stderr, "[katgpu] device scan: batch %llu of %s goes to the host parser (and the rest of the file with it)\n", (unsigned long long)b, path);
                 if (prev_buf >= 0 && carry_n == 0 && prev_out_n) {                           // what the stream ended on, for the windows across the hand-over
@@ -334,7 +359,7 @@ struct RawFeeder {
                 prev_buf = buf; prev_out_n = out_n;
             } else HIPCHK(c, hipStreamSynchronize(c->stream));    // the scan's kernels are through with raw[buf]
             cut_lo = cut_hi;
-            batch_consumed();                                     // raw[buf] / pin[buf] may take batch b + 2 (out[buf] is rewritten by ITS scan, on this stream)
+            batch_consumed();                                     // raw[buf] / pin[buf] may take my batch after next (out[buf] is rewritten by ITS scan, on this stream)
         }
         return KATGPU_OK;
     }
@@ -343,7 +368,7 @@ struct RawFeeder {
 }  // namespace
 
 // One large plain file through the device scan.  *took = false: not a file for this path (nothing was counted).
-int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, bool* took) {
+int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, bool* took, int rank, int world) {
     *took = false;
     uint64_t size = 0; uint8_t first = 0;
     if (!device_scan_applies(path, trim5p, &size, &first)) return KATGPU_OK;
@@ -353,7 +378,8 @@ int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, b
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < ((size_t)6 << 30)) release_arena(c);    // the cached arena holds most of the free HBM: the batch buffers come first
     }
     RawFeeder f(t, path);
-    int rc = f.setup(size, first);
+    if (world > 1 && first != '@') return KATGPU_OK;              // only FASTQ is cut between ranks (the caller deals whole files otherwise)
+    int rc = f.setup(size, first, rank, world);
     if (rc == KATGPU_ERR_NOMEM) { (void)hipGetLastError(); return KATGPU_OK; }      // no room for the batch buffers: the streaming path and its smaller rings
     if (rc == KATGPU_OK) { *took = true; rc = f.run(); }
     if (rc == KATGPU_OK) rc = refresh_counters(t);

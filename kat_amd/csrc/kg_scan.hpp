@@ -165,7 +165,6 @@ k_emit(const uint8_t* __restrict__ raw, uint64_t n, uint32_t n_tiles, const uint
         if (off >= n || L >= n_lines) continue;                                  // (bytes after the last newline belong to no line: the host keeps chunks whole)
         uint32_t ls = L ? NL[L - 1] + 1 : 0, oo = out_off[L];
         bool header = TYPE == SCAN_FASTA && raw[ls] == '>';
-#pragma unroll
         for (int b = 0; b < SC_BYTES; ++b) {
             const uint64_t i = off + b;
             if (i >= n || L >= n_lines) break;

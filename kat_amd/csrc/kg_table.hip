@@ -126,6 +126,7 @@ extern "C" void katgpu_table_free(katgpu_table* t) {
 
 extern "C" uint32_t katgpu_table_k(const katgpu_table* t) { return t ? t->d.k : 0; }
 extern "C" uint32_t katgpu_table_regrows(const katgpu_table* t) { return t ? t->n_regrows : 0; }
+extern "C" uint32_t katgpu_table_slot_bytes(const katgpu_table* t) { return !t ? 0 : t->d.keys_b ? 20 : t->d.cbits ? 8 : 12; }
 extern "C" int katgpu_table_canonical(const katgpu_table* t) { return t ? (int)t->d.canonical : 0; }
 
 // read the counter block back (one small D2H; synchronises the compute stream)

@@ -181,3 +181,37 @@ def test_comp_stats_and_matrix_through_the_reference_code(engine, refdata, tmp_p
     assert lines[0].split() == ["90", "120", str(int(mx.max())), "1", "15"]
     assert lines[7].split() == ["120", "90", str(int(mx.max())), str(int(mx.sum()))]
     t1.free(); t2.free()
+
+
+@pytest.mark.parametrize("gpus,env", [(1, {"KATGPU_COMM_TRANSPORT": "rccl"}), (2, {"KATGPU_COMM_TRANSPORT": "shm"}), (3, {"KATGPU_COMM_TRANSPORT": "shm"})])
+def test_gpus_switch_writes_the_single_gpu_files(tmp_path, gpus, env):
+    """`katgpu <mode> --gpus N` (kat_main.cc forks N ranks; kg_comm.hip merges their tables by owner and sums the reducers' results):
+    byte for byte the files of the plain run.  --gpus 1 takes the RCCL branch with one rank; 2 and 3 ranks share this box's one GPU, which
+    only the /dev/shm transport carries (RCCL refuses two ranks on a device) -- the protocol above the transport is the same code.
+    The FASTQ files are big enough for the device scan with the test's batch size, so the ranks cut them between themselves."""
+    g = synth.genome(300000, seed=20260927)
+    synth.write_fasta(str(tmp_path / "asm.fa"), g, contig_len=50000)
+    synth.write_fastq_pair(str(tmp_path / "lib_R1.fq"), str(tmp_path / "lib_R2.fq"), synth.reads(g, 0, 40000, seed=1))
+    base_env = dict(os.environ, KATGPU_TEST_SCAN_BATCH="1048576", KATGPU_TEST_SCAN_SEGMENT="262144", KATGPU_TEST_SCAN_OVERLAP="8192", KATGPU_TRACE="1")
+
+    def go(extra, name, e):
+        r = subprocess.run([EXE] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, (name, r.stdout[-1500:], r.stderr[-3000:])
+        return r
+    go(["comp", "-m27", "-H", "3000000", "-o", "one", "lib_R?.fq", "asm.fa"], "comp", base_env)
+    go(["hist", "-m27", "-H", "3000000", "-o", "one.hist", "lib_R1.fq", "lib_R2.fq"], "hist", base_env)
+    go(["gcp", "-m27", "-H", "3000000", "-o", "one_gcp", "lib_R1.fq", "lib_R2.fq"], "gcp", base_env)
+    e = dict(base_env, **env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = go(["comp", "--gpus", str(gpus), "-m27", "-H", "3000000", "-o", "many", "lib_R?.fq", "asm.fa"], "comp --gpus", e)
+    if gpus > 1:
+        assert "Multi-GPU: %d ranks, transport shm" % gpus in r.stdout
+    go(["hist", "--gpus=%d" % gpus, "-m27", "-H", "3000000", "-o", "many.hist", "lib_R1.fq", "lib_R2.fq"], "hist --gpus", e)
+    go(["gcp", "--gpus", str(gpus), "-m27", "-H", "3000000", "-o", "many_gcp", "lib_R1.fq", "lib_R2.fq"], "gcp --gpus", e)
+    for a, b in (("one-main.mx", "many-main.mx"), ("one.hist", "many.hist"), ("one_gcp.mx", "many_gcp.mx")):
+        x, y = (tmp_path / a).read_bytes(), (tmp_path / b).read_bytes()
+        assert x.replace(b"one", b"many") == y.replace(b"one", b"many"), (a, b)
+    sx, sy = (tmp_path / "one.stats").read_text(), (tmp_path / "many.stats").read_text()
+    assert sx == sy
+    r = subprocess.run([EXE, "hist", "--gpus", "2", "-d", "-m27", "-o", "x.hist", "lib_R1.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 1 and "--gpus" in r.stderr

@@ -1,0 +1,61 @@
+"""The native exchange (include/katgpu.h: katgpu_comm_* / katgpu_exchange_merge / katgpu_allreduce_u64; kg_comm.hip) end to end:
+N processes count shards, merge by owner in place, reduce on the owned shards, all-reduce -- bit-identical to one process.
+On a one-GPU box the ranks share the device, which RCCL refuses, so world > 1 runs the SHM transport (the same protocol code above
+it: region-ordered extraction, chunked grouped transfers overlapped with k_merge_apply, out-of-band records); world == 1 runs the
+RCCL transport itself (communicator, stream, events, ncclAllGather / ncclAllReduce with one rank; grouped send / recv have no peer)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+K, G, N_READS, CONTIG = 27, 400000, 60000, 50000
+
+
+def _run(tmp_path, world, mode, env_extra):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_extra)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "comm_rank.py"), str(r), str(world), str(tmp_path / "id.bin"), str(tmp_path), mode],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=400)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(o[-3000:] for o in outs)
+    return outs[0]
+
+
+def _check(ko, tmp_path, world, mode):
+    from kat_amd import synth
+    got = np.load(tmp_path / "sharded.npz")
+    k = 31 if mode == "rr31" else K
+    g = synth.genome(G, seed=11)
+    o1 = ko.Table(k, True).count_bases(synth.reads(g, 0, N_READS, seed=1))
+    o1.add(12345, world * (1 << 33) + world * (world - 1) // 2)
+    o2 = ko.Table(k, True).count_bases(synth.reads(g, 0, N_READS, seed=2) if mode == "rr31" else synth.stream_of_contigs(g, CONTIG))
+    mx, cc, sp = ko.comp(o1, o2, 1.0, 1.0, 201, 101)
+    assert np.array_equal(got["cc"], cc) and np.array_equal(got["mx"], mx) and np.array_equal(got["sp"], sp)
+    assert np.array_equal(got["h"], o1.hist(1, 300, 1)) and np.array_equal(got["gm"], o1.gcp(1.0, 100))
+
+
+@pytest.mark.parametrize("world,mode,extra", [
+    (2, "same", {}), (3, "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "7"}), (2, "mixed", {}), (2, "rr31", {}),
+    (2, "same", {"KATGPU_TEST_REGION_SLOTS": "512"})])                    # packed tables on the wire's both ends
+def test_native_exchange_ranks_sharing_one_gpu(ko, tmp_path, world, mode, extra):
+    out = _run(tmp_path, world, mode, dict(extra, KATGPU_COMM_TRANSPORT="shm"))
+    assert "transport: shm" in out
+    _check(ko, tmp_path, world, mode)
+
+
+def test_native_exchange_single_rank_over_rccl(ko, tmp_path):
+    out = _run(tmp_path, 1, "same", {"KATGPU_COMM_TRANSPORT": "rccl"})
+    assert "transport: rccl" in out, out[-2000:]
+    _check(ko, tmp_path, 1, "same")
