@@ -48,6 +48,10 @@ static int guarded(const std::string& mode, int argc, char* argv[]) {
         std::cerr << "Error: Exception of unknown type!" << std::endl;
         rc = 7;
     }
+    // The outputs are closed; what is left is giving tens of GB of device memory back block by block, which the driver does faster --
+    // and regardless -- when the process ends.  (KATGPU_ORDERLY_EXIT=1 frees everything the long way: leak checkers, tests.)
+    std::cout.flush(); std::cerr.flush(); fflush(nullptr);
+    if (!getenv("KATGPU_ORDERLY_EXIT") && !kat::Engine::dist()) _exit(rc);
     kat::Engine::shutdown();
     return rc;
 }

@@ -116,9 +116,9 @@ int comm_fail(katgpu_comm* m, int code, const char* fmt, ...) {
         if (_r != ncclSuccess) return comm_fail((m), KATGPU_ERR_DEVICE, "%s: %s", #expr, rccl().GetErrorString(_r));  \
     } while (0)
 
-std::string shm_name(const std::string& token, const char* what, uint64_t seq = 0, int a = 0, int b = 0) {
-    char buf[160];
-    snprintf(buf, sizeof buf, "/dev/shm/katgpu-%s-%s-%llu-%d-%d", token.c_str(), what, (unsigned long long)seq, a, b);
+std::string shm_name(const std::string& token, const char* what, uint64_t seq = 0, int a = 0, int b = 0, int idx = 0) {
+    char buf[176];
+    snprintf(buf, sizeof buf, "/dev/shm/katgpu-%s-%s-%llu-%d-%d-%d", token.c_str(), what, (unsigned long long)seq, a, b, idx);
     return buf;
 }
 
@@ -179,10 +179,13 @@ int transfer(katgpu_comm* m, const std::vector<Msg>& sends, const std::vector<Ms
     for (auto& r : recvs) biggest = std::max(biggest, r.bytes);
     int rc = ensure_host_stage(m, std::max<size_t>(biggest, 4096));
     if (rc) return rc;
+    // (a group may carry several messages for one peer -- keys, then counts: the n-th to a peer meets the n-th from it)
+    std::vector<int> nth((size_t)m->world, 0);
     for (auto& s : sends) {
+        const int idx = nth[s.peer]++;
         if (!s.bytes) continue;
         HIPCHK(c, hipMemcpy(m->host_stage, s.dev, s.bytes, hipMemcpyDeviceToHost));
-        const std::string name = shm_name(m->token, "x", seq, m->rank, s.peer);
+        const std::string name = shm_name(m->token, "x", seq, m->rank, s.peer, idx);
         const int fd = ::open(name.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0600);
         if (fd < 0) return comm_fail(m, KATGPU_ERR_IO, "cannot create %s", name.c_str());
         size_t off = 0;
@@ -191,9 +194,11 @@ int transfer(katgpu_comm* m, const std::vector<Msg>& sends, const std::vector<Ms
         m->bytes_sent += s.bytes;
     }
     shm_barrier(m);
+    std::fill(nth.begin(), nth.end(), 0);
     for (auto& r : recvs) {
+        const int idx = nth[r.peer]++;
         if (!r.bytes) continue;
-        const std::string name = shm_name(m->token, "x", seq, r.peer, m->rank);
+        const std::string name = shm_name(m->token, "x", seq, r.peer, m->rank, idx);
         const int fd = ::open(name.c_str(), O_RDONLY);
         if (fd < 0) return comm_fail(m, KATGPU_ERR_IO, "cannot open %s", name.c_str());
         size_t off = 0;

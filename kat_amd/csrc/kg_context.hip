@@ -29,11 +29,13 @@ extern "C" int katgpu_init(int device, katgpu_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return KATGPU_ERR_DEVICE; }
+    if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] context on device %d (%d CUs)\n", since_load(), device, c->n_cu);
     *out = c;
     return KATGPU_OK;
 }
 
 void resolve_pending(katgpu_ctx* c) {
+    std::lock_guard<std::mutex> lk(c->prof_mu);
     for (auto& p : c->pending) {
         hipEventSynchronize(p.b);
         float ms = 0;
@@ -48,6 +50,7 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream); hipStreamSynchronize(c->copy_stream);
     resolve_pending(c);
+    scan_cache_release(c);
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
     if (c->arena) hipFree(c->arena);
@@ -68,6 +71,7 @@ extern "C" int katgpu_release_scratch(katgpu_ctx* c) {
     if (!c) return KATGPU_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    scan_cache_release(c);
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
     if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }

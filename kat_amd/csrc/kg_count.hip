@@ -296,7 +296,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                                (fixed_l1 + fixed_l2 + 4096) * 8 + 4096;
     size_t want_items = n_starts;
     if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
-    const size_t want_bytes = small_bytes + (size_t)((per_item + 0.5) * (double)want_items);
+    size_t want_bytes = small_bytes + (size_t)((per_item + 0.5) * (double)want_items);
+    if (c->arena_limit) want_bytes = std::min(want_bytes, std::max(c->arena_limit, small_bytes + 18 * ((size_t)64 << 20)));      // (the file feeders: more rounds, less to allocate)
     if (c->arena_bytes < want_bytes) {                                           // the arena could be more useful than it is
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
@@ -306,8 +307,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 18 * std::min<size_t>(want_items, (size_t)64 << 20)) {
             if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
             if (!g_test_round_items && bytes < small_bytes + 18 * ((size_t)1 << 20)) return KATGPU_OK;   // no room for a useful round: direct path
+            const double t_ar = now_ms();
             if (hipMalloc((void**)&c->arena, bytes) != hipSuccess) { (void)hipGetLastError(); c->arena = nullptr; return KATGPU_OK; }   // direct path
             c->arena_bytes = bytes;
+            if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] partition arena of %.1f GB: %.0f ms\n", since_load(), bytes / 1e9, now_ms() - t_ar);
         }
     }
     struct Busy { katgpu_ctx* c; explicit Busy(katgpu_ctx* c_) : c(c_) { c->arena_busy = true; } ~Busy() { c->arena_busy = false; } } busy(c);
@@ -785,7 +788,8 @@ static int count_files_impl(katgpu_table* t, const char* const* paths, size_t n_
         if (rc) return rc;
         if (!took) { rest.push_back(paths[i]); rest_trim.push_back((uint16_t)trim); rest_bytes += (size_t)kg::file_size_or_zero(paths[i]); }
     }
-    if (rest.empty()) return refresh_counters(t);
+    if (rest.empty()) { int wrc = table_wait(t); return wrc ? wrc : refresh_counters(t); }
+    { int wrc = table_wait(t); if (wrc) return wrc; }                // (the streaming feeder does not overlap the allocation)
     HostFeeder f(t);
     int rc = f.begin(rest_bytes * 4); if (rc) return rc;           // (gzip inflates: be generous)
     // the group's other files -> one base stream (kg_ingest.hpp: thread team for large plain files, concurrent readers for gzip & co.)
@@ -811,8 +815,31 @@ extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_pa
         for (size_t i = 0; i < n_paths; ++i) bytes += kg::file_size_or_zero(paths[i]);
         size_hint = std::max<uint64_t>(1u << 20, bytes);
     }
+    // Big plain files: the table (and the feeders' arena) are allocated on a thread of their own while the device scan already reads
+    // and parses into its accumulation buffers -- tens of GB of hipMalloc take about as long as the first GBs of the files take to arrive.
+    uint64_t scan_bytes = 0;
+    for (size_t i = 0; i < n_paths; ++i) { uint64_t sz = 0; if (device_scan_applies(paths[i], trim5p ? trim5p[i] : 0, &sz, nullptr)) scan_bytes += sz; }
     katgpu_table* t = nullptr;
-    int rc = katgpu_table_create(c, k, canonical, size_hint, disable_grow, &t);
+    int rc;
+    if (scan_bytes >= ((uint64_t)4 << 30) && k >= 1 && k <= KATGPU_MAX_K && !getenv("KATGPU_SYNC_ALLOC")) {
+        HIPCHK(c, hipSetDevice(c->device));
+        t = new katgpu_table();
+        t->ctx = c; t->disable_grow = disable_grow;
+        t->d.k = k; t->d.canonical = canonical ? 1 : 0;                    // what the feeders' own threads look at before the slots exist
+        const uint64_t cap = std::max<uint64_t>(size_hint, 1024);
+        const size_t arena_bytes = (size_t)16 << 30;
+        t->alloc_thread = std::thread([c, t, k, canonical, cap, arena_bytes]() {
+            hipSetDevice(c->device);
+            DevTable d{};
+            const int arc = alloc_dev_table(c, k, canonical, cap, &d);
+            if (arc) { t->alloc_rc = arc; t->alloc_err = c->err; return; }
+            t->d = d;
+            if (!c->arena && hipMalloc((void**)&c->arena, arena_bytes) == hipSuccess) c->arena_bytes = arena_bytes; else (void)hipGetLastError();
+            if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] table and arena allocated (beside the feeders)\n", since_load());
+        });
+        rc = KATGPU_OK;
+    } else
+        rc = katgpu_table_create(c, k, canonical, size_hint, disable_grow, &t);
     if (rc) return rc;
     rc = katgpu_count_files(t, paths, n_paths, trim5p);
     if (rc) { katgpu_table_free(t); return rc; }

@@ -19,7 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -41,6 +43,7 @@ struct katgpu_ctx {
     // pending (not yet read back) event pairs: timing is resolved lazily so launches stay asynchronous
     struct Pending { hipEvent_t a, b; int cls; };
     std::vector<Pending> pending;
+    std::mutex prof_mu;                  // the profile counters and the event pool: the feeders count on a worker thread
     std::vector<hipEvent_t> event_pool;
     // staging for host / file ingest: 2 pinned buffers feed 2 device rings (allocated on first use, kept)
     uint8_t* pinned[2] = {nullptr, nullptr};
@@ -60,9 +63,25 @@ struct katgpu_ctx {
     std::unordered_set<const void*> lds_attr;   // kernels whose dynamic-LDS ceiling has been raised on this device
     bool part_attr_set = false, merge_attr_set = false;   // the dynamic-LDS attributes of the partition / merge kernels have been set on this device
     bool arena_busy = false;              // a partition round is using it: pool_alloc must not free it to satisfy a table growth
+    size_t arena_limit = 0;               // != 0: count calls size the arena to at most this (the file feeders: their rounds are bounded by what arrives)
     bool arena_borrowed = false;          // katgpu_scratch_acquire handed the arena out: it must not be freed behind the caller's back
     int count_blocks_per_cu = 6;
+    // the device scan's buffers (kg_scan.hip), kept across files and tables: one pinned segment per reader thread (pinning a GiB costs a
+    // quarter of a second -- more than moving it: the readers stage through 8 MiB each, not through whole batches), two batches of raw
+    // bytes and of output on the device, the line arrays.  Freed by katgpu_release_scratch / katgpu_shutdown.
+    struct ScanCache {
+        std::vector<uint8_t*> pin_seg; std::vector<hipStream_t> seg_stream; size_t pin_seg_bytes = 0;
+        uint8_t *raw[2] = {nullptr, nullptr}, *acc[2] = {nullptr, nullptr}, *raw_al = nullptr;
+        size_t acc_bytes = 0;
+        uint32_t *tile_cnt = nullptr, *NL = nullptr, *len_off = nullptr, *line_tile_sum = nullptr;
+        uint64_t *tile_off = nullptr, *line_tile_off = nullptr;
+        unsigned long long* flags = nullptr;
+        hipStream_t up[2] = {nullptr, nullptr};
+        size_t buf_bytes = 0; int n_buf = 0;
+        uint64_t cap_lines = 0;
+    } scan;
 };
+void scan_cache_release(katgpu_ctx* c);      // kg_scan.hip
 
 struct katgpu_table {
     katgpu_ctx* ctx = nullptr;
@@ -77,6 +96,12 @@ struct katgpu_table {
     uint32_t n_regrows = 0;      // how often the table had to grow (the host mirror words the reference's warning from it)
     uint8_t carry[64];           // last k-1 bytes of the previous host batch of the current file
     uint32_t carry_n = 0;
+    // katgpu_count allocates the table on a thread of its own while the feeders already read and parse (tens of GB of hipMalloc cost a
+    // second: as long as the first GBs of the files take to arrive); whoever needs the slots first calls table_wait
+    std::thread alloc_thread;
+    std::mutex alloc_mu;
+    int alloc_rc = 0;
+    std::string alloc_err;
 };
 
 inline int fail(katgpu_ctx* c, int code, const char* fmt, ...) {
@@ -112,6 +137,8 @@ inline double now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
 }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static const double g_t_loaded = now_ms();           // when the library was loaded: KATGPU_TRACE stamps are relative to it
+inline double since_load() { return now_ms() - g_t_loaded; }
 // Test hooks (KATGPU_TEST_*) and A/B switches are read only when KATGPU_TESTING is set: a production process ignores them, and the
 // kernels that honour one (the spill hook of the apply kernels) are separate instantiations it never launches.
 // What a deployment may tune stays plain (INTEGRATION.md lists them): KATGPU_TRACE, KATGPU_ARENA_FRACTION, KATGPU_RING_MB,
@@ -133,6 +160,7 @@ int refresh_counters(katgpu_table* t);
 int regrow(katgpu_table* t, uint64_t new_cap);
 double load_limit(const DevTable& d);
 int ensure_room(katgpu_table* t, uint64_t incoming);
+int table_wait(katgpu_table* t);               // the table's device arrays exist (katgpu_count allocates them asynchronously)
 // counting (kg_count.hip)
 int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n);
 // large plain FASTQ / FASTA files: raw bytes to the device, record scan there (kg_scan.hip).  *took = false: not a file for this path
@@ -143,6 +171,7 @@ int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, b
 struct ScopedTimer {
     katgpu_ctx* c; int cls; hipEvent_t a = nullptr, b = nullptr;
     ScopedTimer(katgpu_ctx* c_, int cls_, uint64_t units) : c(c_), cls(cls_) {
+        std::lock_guard<std::mutex> lk(c->prof_mu);
         auto take = [&]() { hipEvent_t e = nullptr; if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); } else hipEventCreate(&e); return e; };
         a = take(); b = take();
         hipEventRecord(a, c->stream);
@@ -150,8 +179,9 @@ struct ScopedTimer {
     }
     ~ScopedTimer() {
         hipEventRecord(b, c->stream);
-        c->pending.push_back({a, b, cls});
-        if (c->pending.size() > 4096) resolve_pending(c);
+        bool full;
+        { std::lock_guard<std::mutex> lk(c->prof_mu); c->pending.push_back({a, b, cls}); full = c->pending.size() > 4096; }
+        if (full) resolve_pending(c);
     }
 };
 

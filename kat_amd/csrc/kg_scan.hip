@@ -1,8 +1,8 @@
 // kg_scan.hip -- katgpu_count_files' fast path for large plain FASTQ / FASTA files: the host moves raw file bytes, the device parses.
 //
-//   reader threads: pread 32 MiB segments of the file straight into pre-faulted PINNED memory, each followed by its own H2D copy
-//                   (so reading and copying overlap inside a batch, and several copies are in flight)
-//   the caller's thread, per batch of 1 GiB of file: find the record-aligned cut at the batch's end (host: two memchr), run the
+//   reader threads: pread 8 MiB segments of the file into a PINNED segment of their own, each followed by its own H2D copy on the
+//                   thread's stream (reading and copying overlap across the threads; a dozen copies are in flight)
+//   the caller's thread, per batch of 512 MiB of file: find the record-aligned cut at the batch's end (host: two memchr), run the
 //                   record scan on the device (kg_scan.hpp), read three words back, and hand the compacted base stream -- a
 //                   resident buffer like any other -- to count_resident, i.e. to the partitioned counter.
 // While a batch is scanned and counted the readers fill the other batch buffer.  The host parses nothing: the 16-thread parser team
@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 
@@ -24,10 +25,11 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-static const size_t g_scan_batch = (size_t)std::max<uint64_t>(1, getenv("KATGPU_SCAN_BATCH_MB") ? strtoull(getenv("KATGPU_SCAN_BATCH_MB"), nullptr, 10) : 1024) << 20;
-static const size_t g_scan_segment = (size_t)std::max<uint64_t>(1, getenv("KATGPU_SCAN_SEGMENT_MB") ? strtoull(getenv("KATGPU_SCAN_SEGMENT_MB"), nullptr, 10) : 32) << 20;
+static const size_t g_scan_batch = (size_t)std::max<uint64_t>(1, getenv("KATGPU_SCAN_BATCH_MB") ? strtoull(getenv("KATGPU_SCAN_BATCH_MB"), nullptr, 10) : 512) << 20;
+static const size_t g_scan_segment = (size_t)std::max<uint64_t>(1, getenv("KATGPU_SCAN_SEGMENT_MB") ? strtoull(getenv("KATGPU_SCAN_SEGMENT_MB"), nullptr, 10) : 8) << 20;
+static const size_t g_scan_acc = (size_t)std::max<uint64_t>(64, getenv("KATGPU_SCAN_ACC_MB") ? strtoull(getenv("KATGPU_SCAN_ACC_MB"), nullptr, 10) : 4096) << 20;   // base stream counted per call
 static const size_t g_scan_overlap_dflt = (size_t)1 << 20;        // how far past a batch's nominal end its cut may lie (a record, a FASTA line)
-static const unsigned g_scan_threads = (unsigned)std::max<uint64_t>(1, getenv("KATGPU_SCAN_THREADS") ? strtoull(getenv("KATGPU_SCAN_THREADS"), nullptr, 10) : 12);
+static const unsigned g_scan_threads = (unsigned)std::max<uint64_t>(1, getenv("KATGPU_SCAN_THREADS") ? strtoull(getenv("KATGPU_SCAN_THREADS"), nullptr, 10) : 16);
 static const uint64_t g_scan_min_bytes = getenv("KATGPU_SCAN_MIN_BYTES") ? strtoull(getenv("KATGPU_SCAN_MIN_BYTES"), nullptr, 10) : ((uint64_t)64 << 20);
 static const bool g_scan_off = getenv("KATGPU_DEVICE_SCAN") && atoi(getenv("KATGPU_DEVICE_SCAN")) == 0;
 // tests: small batches / overlaps (bytes) so that little files cross many cuts; force the host fall-back from batch N on
@@ -66,17 +68,17 @@ struct RawFeeder {
     std::vector<uint64_t> my;                                     // the batches this feeder processes, in order
     static constexpr size_t PRE = 64;                             // bytes read in front of a batch: a record that starts exactly at the nominal cut needs its '\n'
     static constexpr size_t HEAD = 64;                            // carry area in front of an output buffer (k - 1 <= 62 bytes), keeps the payload 16-byte aligned
-    // two batch buffers: pinned host, raw device, output device
-    uint8_t* pin[2] = {nullptr, nullptr};
+    // two batch buffers on the device: raw bytes, output; on the host only the bytes around a batch's two ends (where the cuts are looked for)
+    std::vector<uint8_t> edge_lo[2], edge_hi[2];                  // file bytes [base, base + PRE + overlap) and [nominal end - 1, hi_read) of the batch in buffer i
     uint8_t* raw[2] = {nullptr, nullptr};
-    uint8_t* out[2] = {nullptr, nullptr};
+    uint8_t* acc[2] = {nullptr, nullptr};                         // accumulation buffers of base stream: HEAD + acc_bytes each
+    size_t acc_bytes = 0, acc_fill = 0; int acc_cur = 0;
     uint8_t* raw_al = nullptr;                                    // a chunk starts at a record, i.e. anywhere: the scan reads it from a 16-byte aligned copy (one D2D copy, ~0.5 ms per GiB)
     // the scan's arrays (one set: scans of successive batches are serial on the compute stream)
     uint32_t *tile_cnt = nullptr, *NL = nullptr, *len_off = nullptr, *line_tile_sum = nullptr;
     uint64_t *tile_off = nullptr, *line_tile_off = nullptr;
     unsigned long long* flags = nullptr;
     uint64_t cap_lines = 0;
-    hipStream_t up[2] = {nullptr, nullptr};                       // one upload stream per batch buffer
     // readers
     std::vector<std::thread> readers;
     std::mutex mu; std::condition_variable cv;
@@ -85,6 +87,7 @@ struct RawFeeder {
     std::vector<uint32_t> done_segs;                              // per my[j]: segments read and enqueued
     uint64_t consumed = 0;                                        // of my batches, how many the main thread is through with: my[j] may be read when j < consumed + 2
     bool stop = false, io_error = false;
+    size_t n_readers = 0;
 
     RawFeeder(katgpu_table* t_, const char* p) : t(t_), c(t_->ctx), path(p) {}
     ~RawFeeder() { shutdown(); release(); }
@@ -95,17 +98,45 @@ struct RawFeeder {
         for (auto& th : readers) if (th.joinable()) th.join();
         readers.clear();
     }
-    void release() {
-        for (int i = 0; i < 2; ++i) {
-            if (up[i]) { hipStreamSynchronize(up[i]); hipStreamDestroy(up[i]); up[i] = nullptr; }
-            if (pin[i]) { hipHostFree(pin[i]); pin[i] = nullptr; }
-            if (raw[i]) { pool_release(c, raw[i]); raw[i] = nullptr; }
-            if (out[i]) { pool_release(c, out[i]); out[i] = nullptr; }
-        }
-        if (raw_al) { pool_release(c, raw_al); raw_al = nullptr; }
-        hipFree(tile_cnt); hipFree(NL); hipFree(len_off); hipFree(line_tile_sum); hipFree(tile_off); hipFree(line_tile_off); hipFree(flags);
-        tile_cnt = NL = len_off = line_tile_sum = nullptr; tile_off = line_tile_off = nullptr; flags = nullptr;
+    void release() {                                              // (the buffers stay with the context: scan_cache_release)
+        for (auto st : c->scan.seg_stream) hipStreamSynchronize(st);
         if (fd >= 0) { ::close(fd); fd = -1; }
+    }
+    // the context's cached buffers, (re)made when this file wants bigger ones
+    int acquire(int nb, unsigned threads) {
+        katgpu_ctx::ScanCache& sc = c->scan;
+        const size_t seg_bytes = PRE + segment + overlap + 64;
+        if (sc.buf_bytes < buf_bytes || sc.n_buf < nb || sc.pin_seg_bytes < seg_bytes || sc.pin_seg.size() < threads || sc.acc_bytes < acc_bytes) {
+            scan_cache_release(c);
+            sc.buf_bytes = buf_bytes; sc.n_buf = nb; sc.pin_seg_bytes = seg_bytes; sc.acc_bytes = acc_bytes;
+            for (int i = 0; i < 2; ++i) HIPCHK(c, hipMalloc((void**)&sc.acc[i], HEAD + acc_bytes));
+            for (unsigned i = 0; i < threads; ++i) {
+                uint8_t* p = nullptr; hipStream_t st = nullptr;
+                HIPCHK(c, hipHostMalloc((void**)&p, seg_bytes, hipHostMallocDefault));
+                sc.pin_seg.push_back(p);
+                HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                sc.seg_stream.push_back(st);
+            }
+            for (int i = 0; i < nb; ++i) {
+                HIPCHK(c, hipMalloc((void**)&sc.raw[i], buf_bytes));
+            }
+            HIPCHK(c, hipMalloc((void**)&sc.raw_al, buf_bytes));
+            const uint64_t n_tiles = (buf_bytes + SC_TILE - 1) / SC_TILE;
+            sc.cap_lines = buf_bytes / 16 + 4096;
+            HIPCHK(c, hipMalloc((void**)&sc.tile_cnt, (n_tiles + 1) * 4));
+            HIPCHK(c, hipMalloc((void**)&sc.tile_off, (n_tiles + 2) * 8));
+            HIPCHK(c, hipMalloc((void**)&sc.NL, sc.cap_lines * 4));
+            HIPCHK(c, hipMalloc((void**)&sc.len_off, sc.cap_lines * 4));
+            HIPCHK(c, hipMalloc((void**)&sc.line_tile_sum, (sc.cap_lines / SC_BLOCK + 2) * 4));
+            HIPCHK(c, hipMalloc((void**)&sc.line_tile_off, (sc.cap_lines / SC_BLOCK + 3) * 8));
+            HIPCHK(c, hipMalloc((void**)&sc.flags, SCF_WORDS * 8));
+        }
+        for (int i = 0; i < 2; ++i) { raw[i] = sc.raw[i]; acc[i] = sc.acc[i]; }
+        acc_bytes = sc.acc_bytes;
+        raw_al = sc.raw_al; tile_cnt = sc.tile_cnt; tile_off = sc.tile_off; NL = sc.NL; len_off = sc.len_off;
+        line_tile_sum = sc.line_tile_sum; line_tile_off = sc.line_tile_off; flags = sc.flags; cap_lines = sc.cap_lines;
+        buf_bytes = sc.buf_bytes;                                 // (possibly larger than asked for: only ever a bound)
+        return KATGPU_OK;
     }
 
     int setup(uint64_t file_size, uint8_t first, int rank, int world) {
@@ -127,25 +158,15 @@ struct RawFeeder {
         if (my.empty()) return KATGPU_OK;
         fd = ::open(path, O_RDONLY);
         if (fd < 0) return fail(c, KATGPU_ERR_IO, "Could not find input file at: %s", path);
-        const int nb = my.size() > 1 ? 2 : 1;
-        for (int i = 0; i < nb; ++i) {
-            HIPCHK(c, hipHostMalloc((void**)&pin[i], buf_bytes, hipHostMallocDefault));
-            HIPCHK(c, pool_alloc(c, (void**)&raw[i], buf_bytes));
-            HIPCHK(c, pool_alloc(c, (void**)&out[i], HEAD + buf_bytes));
-            HIPCHK(c, hipStreamCreateWithFlags(&up[i], hipStreamNonBlocking));
-        }
-        HIPCHK(c, pool_alloc(c, (void**)&raw_al, buf_bytes));
-        const uint64_t n_tiles = (buf_bytes + SC_TILE - 1) / SC_TILE;
-        cap_lines = buf_bytes / 16 + 4096;
-        HIPCHK(c, hipMalloc((void**)&tile_cnt, (n_tiles + 1) * 4));
-        HIPCHK(c, hipMalloc((void**)&tile_off, (n_tiles + 2) * 8));
-        HIPCHK(c, hipMalloc((void**)&NL, cap_lines * 4));
-        HIPCHK(c, hipMalloc((void**)&len_off, cap_lines * 4));
-        HIPCHK(c, hipMalloc((void**)&line_tile_sum, (cap_lines / SC_BLOCK + 2) * 4));
-        HIPCHK(c, hipMalloc((void**)&line_tile_off, (cap_lines / SC_BLOCK + 3) * 8));
-        HIPCHK(c, hipMalloc((void**)&flags, SCF_WORDS * 8));
-        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g_scan_threads, (size + segment - 1) / segment));
-        for (unsigned i = 0; i < T; ++i) readers.emplace_back([this] { read_loop(); });
+        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g_scan_threads, (size / world + segment - 1) / segment));
+        // accumulation buffers: what the file will give (FASTQ: the sequence lines, a bit under half of it), within KATGPU_SCAN_ACC_MB each
+        acc_bytes = std::max<size_t>(buf_bytes, std::min<size_t>(g_scan_acc, (size_t)((double)size / world * (type == SCAN_FASTQ ? 0.6 : 1.02)) + ((size_t)1 << 20)));
+        if (g_test_scan_batch) acc_bytes = std::max<size_t>(buf_bytes, (size_t)hook_u64("KATGPU_TEST_SCAN_ACC", 3 * buf_bytes));
+        const double t_acq = now_ms();
+        { int rc = acquire(my.size() > 1 ? 2 : 1, T); if (rc) { scan_cache_release(c); return rc; } }   // (a half-made cache must not pass for a whole one)
+        if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] device scan buffers: %.0f ms\n", since_load(), now_ms() - t_acq);
+        n_readers = T;
+        for (unsigned i = 0; i < T; ++i) readers.emplace_back([this, i] { read_loop(i); });
         return KATGPU_OK;
     }
 
@@ -153,8 +174,10 @@ struct RawFeeder {
     uint64_t batch_base(uint64_t b) const { return b ? b * (uint64_t)batch - PRE : 0; }
     uint64_t batch_hi_read(uint64_t b) const { return std::min<uint64_t>(size, (b + 1) * (uint64_t)batch + overlap); }
 
-    void read_loop() {
+    void read_loop(unsigned me) {
         hipSetDevice(c->device);
+        uint8_t* const mine = c->scan.pin_seg[me];
+        const hipStream_t st = c->scan.seg_stream[me];
         for (;;) {
             uint64_t seg;
             {
@@ -170,14 +193,15 @@ struct RawFeeder {
             const uint64_t f1 = s + 1 == spb ? batch_hi_read(b) : std::min<uint64_t>(size, b * (uint64_t)batch + (s + 1) * (uint64_t)segment);
             bool ok = true;
             if (f0 < f1) {
-                uint8_t* dst = pin[buf] + (f0 - batch_base(b));
                 uint64_t got = 0;
                 while (got < f1 - f0) {
-                    const ssize_t r = pread(fd, dst + got, (size_t)std::min<uint64_t>(f1 - f0 - got, (uint64_t)1 << 30), (off_t)(f0 + got));
+                    const ssize_t r = pread(fd, mine + got, (size_t)std::min<uint64_t>(f1 - f0 - got, (uint64_t)1 << 30), (off_t)(f0 + got));
                     if (r <= 0) { ok = false; break; }
                     got += (uint64_t)r;
                 }
-                if (ok && hipMemcpyAsync(raw[buf] + (f0 - batch_base(b)), dst, (size_t)(f1 - f0), hipMemcpyHostToDevice, up[buf]) != hipSuccess) ok = false;
+                // (done means landed: this thread's pinned segment is free again, and the main thread may scan the batch)
+                if (ok && (hipMemcpyAsync(raw[buf] + (f0 - batch_base(b)), mine, (size_t)(f1 - f0), hipMemcpyHostToDevice, st) != hipSuccess ||
+                           hipStreamSynchronize(st) != hipSuccess)) ok = false;
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -195,7 +219,18 @@ struct RawFeeder {
             cv.wait(lk, [&] { return io_error || done_segs[j] == spb; });
             if (io_error) return fail(c, KATGPU_ERR_IO, "read error on %s", path);
         }
-        HIPCHK(c, hipStreamSynchronize(up[j & 1]));
+        // the bytes around the batch's two ends, for the cuts (the page cache has just served them to the readers)
+        const uint64_t b = my[j], base = batch_base(b), hi_read = batch_hi_read(b);
+        const int buf = (int)(j & 1);
+        auto grab = [&](std::vector<uint8_t>& v, uint64_t f0, uint64_t f1) -> bool {
+            v.resize((size_t)(f1 > f0 ? f1 - f0 : 0));
+            uint64_t got = 0;
+            while (got < v.size()) { const ssize_t r = pread(fd, v.data() + got, v.size() - got, (off_t)(f0 + got)); if (r <= 0) return false; got += (uint64_t)r; }
+            return true;
+        };
+        const uint64_t nominal = std::min<uint64_t>(size, (b + 1) * (uint64_t)batch);
+        if (!grab(edge_lo[buf], base, std::min<uint64_t>(hi_read, base + PRE + overlap)) || !grab(edge_hi[buf], nominal ? nominal - 1 : 0, hi_read))
+            return fail(c, KATGPU_ERR_IO, "read error on %s", path);
         return KATGPU_OK;
     }
     void batch_consumed() {
@@ -203,46 +238,116 @@ struct RawFeeder {
         cv.notify_all();
     }
 
-    // The record scan of raw[buf][lo, hi) into out[buf] + HEAD.  *valid: the device vouches for the chunk; *out_n: bytes of base stream.
-    int scan(int buf, uint64_t lo, uint64_t hi, bool* valid, uint64_t* out_n) {
+    // The record scan of raw[buf][lo, hi), on the context's second stream (the counting worker owns the first).  Phase 1 (measure): lines,
+    // structure checks, output size.  *valid: the device vouches for the chunk; *out_n: bytes of base stream it will give.
+    struct Measured { const uint8_t* src; uint64_t n, n_lines; uint32_t n_tiles; };
+    int scan_measure(int buf, uint64_t lo, uint64_t hi, bool* valid, uint64_t* out_n, Measured* ms) {
+        const hipStream_t st = c->copy_stream;
         const uint8_t* src = raw[buf] + lo;
         const uint64_t n = hi - lo;
         *valid = false; *out_n = 0;
+        ms->src = src; ms->n = n; ms->n_lines = 0; ms->n_tiles = 0;
         if (n == 0) { *valid = true; return KATGPU_OK; }
         if (reinterpret_cast<uintptr_t>(src) & 15) {
-            HIPCHK(c, hipMemcpyAsync(raw_al, src, n, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(raw_al, src, n, hipMemcpyDeviceToDevice, st));
             src = raw_al;
         }
         const uint32_t n_tiles = (uint32_t)((n + SC_TILE - 1) / SC_TILE);
         const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 16);
-        ScopedTimer tm(c, KATGPU_K_SCAN, n);
-        HIPCHK(c, hipMemsetAsync(flags, 0, SCF_WORDS * 8, c->stream));
-        hipLaunchKernelGGL(k_nl_count, dim3(grid), dim3(SC_BLOCK), 0, c->stream, src, n, n_tiles, tile_cnt, flags);
-        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)tile_cnt, n_tiles, (uint64_t)n_tiles, (const uint64_t*)nullptr, tile_off,
+        { std::lock_guard<std::mutex> lk(c->prof_mu); c->prof_launches[KATGPU_K_SCAN] += 1; c->prof_units[KATGPU_K_SCAN] += n; }
+        HIPCHK(c, hipMemsetAsync(flags, 0, SCF_WORDS * 8, st));
+        hipLaunchKernelGGL(k_nl_count, dim3(grid), dim3(SC_BLOCK), 0, st, src, n, n_tiles, tile_cnt, flags);
+        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)tile_cnt, n_tiles, (uint64_t)n_tiles, (const uint64_t*)nullptr, tile_off,
                            (uint64_t)(n_tiles + 1), 1, (unsigned long long*)&flags[SCF_LINES]);
         unsigned long long h[SCF_WORDS];
-        HIPCHK(c, hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
         const uint64_t n_lines = h[SCF_LINES];
         if (h[SCF_BAD] || n_lines == 0 || n_lines > cap_lines || (type == SCAN_FASTQ && (n_lines & 3))) return KATGPU_OK;     // the host's
         const uint64_t n_ltiles = (n_lines + SC_BLOCK - 1) / SC_BLOCK;
         const int lgrid = (int)std::min<uint64_t>(n_ltiles, (uint64_t)c->n_cu * 16);
-        hipLaunchKernelGGL(k_nl_write, dim3(grid), dim3(SC_BLOCK), 0, c->stream, src, n, n_tiles, (const uint64_t*)tile_off, NL, cap_lines);
-        if (type == SCAN_FASTQ) hipLaunchKernelGGL(k_line_len<SCAN_FASTQ>, dim3(lgrid), dim3(SC_BLOCK), 0, c->stream, src, (const uint32_t*)NL, n_lines, len_off, line_tile_sum, flags);
-        else hipLaunchKernelGGL(k_line_len<SCAN_FASTA>, dim3(lgrid), dim3(SC_BLOCK), 0, c->stream, src, (const uint32_t*)NL, n_lines, len_off, line_tile_sum, flags);
-        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)line_tile_sum, (uint32_t)n_ltiles, (uint64_t)n_ltiles, (const uint64_t*)nullptr,
+        hipLaunchKernelGGL(k_nl_write, dim3(grid), dim3(SC_BLOCK), 0, st, src, n, n_tiles, (const uint64_t*)tile_off, NL, cap_lines);
+        if (type == SCAN_FASTQ) hipLaunchKernelGGL(k_line_len<SCAN_FASTQ>, dim3(lgrid), dim3(SC_BLOCK), 0, st, src, (const uint32_t*)NL, n_lines, len_off, line_tile_sum, flags);
+        else hipLaunchKernelGGL(k_line_len<SCAN_FASTA>, dim3(lgrid), dim3(SC_BLOCK), 0, st, src, (const uint32_t*)NL, n_lines, len_off, line_tile_sum, flags);
+        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)line_tile_sum, (uint32_t)n_ltiles, (uint64_t)n_ltiles, (const uint64_t*)nullptr,
                            line_tile_off, (uint64_t)(n_ltiles + 1), 1, (unsigned long long*)&flags[SCF_OUT]);
-        HIPCHK(c, hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
         if (h[SCF_BAD] || h[SCF_OUT] > buf_bytes) return KATGPU_OK;
-        hipLaunchKernelGGL(k_line_off, dim3(lgrid), dim3(SC_BLOCK), 0, c->stream, n_lines, len_off, (const uint64_t*)line_tile_off);
-        uint8_t* dst = out[buf] + HEAD;
-        if (type == SCAN_FASTQ) hipLaunchKernelGGL(k_emit<SCAN_FASTQ>, dim3(grid), dim3(SC_BLOCK), 0, c->stream, src, n, n_tiles, (const uint64_t*)tile_off, (const uint32_t*)NL,
-                                                   (const uint32_t*)len_off, n_lines, dst);
-        else hipLaunchKernelGGL(k_emit<SCAN_FASTA>, dim3(grid), dim3(SC_BLOCK), 0, c->stream, src, n, n_tiles, (const uint64_t*)tile_off, (const uint32_t*)NL,
-                                (const uint32_t*)len_off, n_lines, dst);
-        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(k_line_off, dim3(lgrid), dim3(SC_BLOCK), 0, st, n_lines, len_off, (const uint64_t*)line_tile_off);
+        ms->src = src; ms->n_lines = n_lines; ms->n_tiles = n_tiles;
         *valid = true; *out_n = h[SCF_OUT];
+        return KATGPU_OK;
+    }
+    // Phase 2 (emit): the chunk's base stream to dst (asynchronous on the second stream)
+    int scan_emit(const Measured& ms, uint8_t* dst) {
+        if (!ms.n_lines) return KATGPU_OK;
+        const hipStream_t st = c->copy_stream;
+        const int grid = (int)std::min<uint64_t>(ms.n_tiles, (uint64_t)c->n_cu * 16);
+        if (type == SCAN_FASTQ) hipLaunchKernelGGL(k_emit<SCAN_FASTQ>, dim3(grid), dim3(SC_BLOCK), 0, st, ms.src, ms.n, ms.n_tiles, (const uint64_t*)tile_off, (const uint32_t*)NL,
+                                                   (const uint32_t*)len_off, ms.n_lines, dst);
+        else hipLaunchKernelGGL(k_emit<SCAN_FASTA>, dim3(grid), dim3(SC_BLOCK), 0, st, ms.src, ms.n, ms.n_tiles, (const uint64_t*)tile_off, (const uint32_t*)NL,
+                                (const uint32_t*)len_off, ms.n_lines, dst);
+        HIPCHK(c, hipGetLastError());
+        return KATGPU_OK;
+    }
+
+    // ---- the counting worker: a full accumulation buffer is a resident stretch of the base stream; it is counted (partition rounds
+    // sized like a resident input's: the table is swept once per GBs of stream, not once per batch) while the next one fills ----
+    std::thread worker;
+    std::mutex wmu; std::condition_variable wcv;
+    struct Job { int a; size_t n; };
+    std::deque<Job> jobs;
+    bool acc_busy[2] = {false, false}, wstop = false;
+    int worker_rc = KATGPU_OK; std::string worker_err;
+    double worker_ms = 0;
+    void work() {
+        hipSetDevice(c->device);
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(wmu);
+                wcv.wait(lk, [&] { return wstop || !jobs.empty(); });
+                if (jobs.empty()) return;
+                j = jobs.front(); jobs.pop_front();
+            }
+            const double t0 = now_ms();
+            int rc = worker_rc ? worker_rc : table_wait(t);                                // (katgpu_count allocates the table beside us)
+            if (!rc) rc = count_resident(t, acc[j.a], j.n);                                // (after an error the queued buffers are dropped)
+            {
+                std::lock_guard<std::mutex> lk(wmu);
+                if (rc && !worker_rc) { worker_rc = rc; worker_err = c->err; }
+                acc_busy[j.a] = false;
+                worker_ms += now_ms() - t0;
+            }
+            wcv.notify_all();
+        }
+    }
+    void stop_worker() {
+        if (!worker.joinable()) return;
+        { std::lock_guard<std::mutex> lk(wmu); wstop = true; }
+        wcv.notify_all();
+        worker.join();
+    }
+    // hand acc[acc_cur] (HEAD + acc_fill bytes) to the worker and open the other buffer with the stream's last k-1 bytes in its head
+    int submit(bool last) {
+        const uint32_t k = t->d.k;
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));          // every chunk emitted into it has landed
+        const int other = acc_cur ^ 1;
+        {
+            std::unique_lock<std::mutex> lk(wmu);
+            if (acc_fill) { acc_busy[acc_cur] = true; jobs.push_back({acc_cur, HEAD + acc_fill}); }
+            wcv.notify_all();
+            wcv.wait(lk, [&] { return last ? (!acc_busy[0] && !acc_busy[1] && jobs.empty()) : !acc_busy[other]; });
+            if (worker_rc) return fail(c, worker_rc, "%s", worker_err.c_str());
+        }
+        if (last) return KATGPU_OK;
+        HIPCHK(c, hipMemsetAsync(acc[other], 'N', HEAD, c->copy_stream));
+        if (acc_fill) {
+            const uint32_t cn = (uint32_t)std::min<uint64_t>(acc_fill, k - 1);
+            HIPCHK(c, hipMemcpyAsync(acc[other] + HEAD - cn, acc[acc_cur] + HEAD + acc_fill - cn, cn, hipMemcpyDeviceToDevice, c->copy_stream));
+        }
+        acc_cur = other; acc_fill = 0;
         return KATGPU_OK;
     }
 
@@ -275,18 +380,18 @@ struct RawFeeder {
         if (rc == KATGPU_OK && !ps.end_ok()) return fail(c, KATGPU_ERR_FASTQ, "Invalid fastq sequence");
         return rc;
     }
-    // a host piece of the base stream -> out[0] -> count_resident (the fall-back is rare: no pipelining)
+    // a host piece of the base stream -> acc[0] -> count_resident (the fall-back is rare: no pipelining; the worker is idle by then)
     int count_host_stream(const uint8_t* p, size_t n) {
         size_t pos = 0;
         const uint32_t k = t->d.k;
         while (pos < n && n - pos >= k) {
-            const size_t take = std::min(n - pos, buf_bytes);
+            const size_t take = std::min(n - pos, acc_bytes);
             uint8_t head[HEAD];
             memset(head, 'N', HEAD);
-            HIPCHK(c, hipMemcpyAsync(out[0], head, HEAD, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(out[0] + HEAD, p + pos, take, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(acc[0], head, HEAD, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(acc[0] + HEAD, p + pos, take, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            int rc = count_resident(t, out[0], HEAD + take);
+            int rc = count_resident(t, acc[0], HEAD + take);
             if (rc) return rc;
             if (take == n - pos) break;
             pos += take - (k - 1);
@@ -305,67 +410,99 @@ struct RawFeeder {
         const bool sharded = shard_world > 1;
         uint64_t cut_lo = 0;                                      // file offset where the next chunk starts: a proven record / line start
         uint8_t carry[HEAD]; uint32_t carry_n = 0;                // last k-1 bytes of the base stream so far (host copy, for the fall-back)
-        int prev_buf = -1; uint64_t prev_out_n = 0;
+        double ms_wait = 0, ms_scan = 0, ms_count = 0;
+        const double t_run = now_ms();
+        struct Report { RawFeeder* f; double *w, *s, *n, t0; ~Report() { if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] device scan of %s: %.1f GB in %.0f ms (%.1f GB/s): waiting for readers + H2D %.0f ms, scan %.0f ms, waiting for the counter %.0f ms (it counted for %.0f ms); %u reader threads, %zu MiB segments, %zu MiB accumulated per count\n",
+                                 since_load(), f->path, f->size / 1e9, now_ms() - t0, f->size / 1e6 / std::max(1.0, now_ms() - t0), *w, *s, *n, f->worker_ms, (unsigned)f->n_readers, f->segment >> 20, f->acc_bytes >> 20); } } report{this, &ms_wait, &ms_scan, &ms_count, t_run};
+        struct StopWorker { RawFeeder* f; ~StopWorker() { f->stop_worker(); } } stop_w{this};
+        worker = std::thread([this] { work(); });
+        struct Limit { katgpu_ctx* c; size_t old; ~Limit() { c->arena_limit = old; } } limit{c, c->arena_limit};
+        c->arena_limit = (size_t)16 << 30;                     // rounds of what an accumulation buffer holds: a modest arena does (allocating 100 GB costs seconds)
+        HIPCHK(c, hipMemsetAsync(acc[0], 'N', HEAD, c->copy_stream));
+        acc_cur = 0; acc_fill = 0;
         for (uint64_t j = 0; j < my.size(); ++j) {
+            double t0 = now_ms();
             int rc = wait_batch(j);
             if (rc) return rc;
+            ms_wait += now_ms() - t0;
             const uint64_t b = my[j];
             const int buf = (int)(j & 1);
             const uint64_t lo = batch_base(b), hi_read = batch_hi_read(b);
             bool cut_ok = true;
             if (sharded) {                                        // this chunk's start, found the way the owner of batch b - 1 finds its chunk's end
                 cut_lo = 0;
-                if (b) { const int64_t f = fastq_cut(pin[buf], lo, hi_read, b * (uint64_t)batch); if (f < 0) cut_ok = false; else cut_lo = (uint64_t)f; }
-                prev_buf = -1; prev_out_n = 0;                    // (FASTQ chunks end on a record's 'N': nothing to carry between them)
+                if (b) { const int64_t f = fastq_cut(edge_lo[buf].data(), lo, lo + edge_lo[buf].size(), b * (uint64_t)batch); if (f < 0) cut_ok = false; else cut_lo = (uint64_t)f; }
             }
             // the chunk's end: the first record start (FASTQ) / line start (FASTA) at or after the nominal end, inside what was read
             uint64_t cut_hi = size;
             if (b + 1 < n_batches) {
                 const uint64_t nominal = (b + 1) * (uint64_t)batch;
                 if (type == SCAN_FASTQ) {
-                    const int64_t f = fastq_cut(pin[buf], lo, hi_read, nominal);
+                    const int64_t f = fastq_cut(edge_hi[buf].data(), nominal - 1, hi_read, nominal);
                     if (f < 0) cut_ok = false; else cut_hi = (uint64_t)f;
                 } else {
-                    const uint8_t* nl = (const uint8_t*)memchr(pin[buf] + (nominal - 1 - lo), '\n', (size_t)(hi_read - (nominal - 1)));
-                    if (!nl) cut_ok = false; else cut_hi = lo + (uint64_t)(nl - pin[buf]) + 1;
+                    const uint8_t* nl = (const uint8_t*)memchr(edge_hi[buf].data(), '\n', edge_hi[buf].size());
+                    if (!nl) cut_ok = false; else cut_hi = (nominal - 1) + (uint64_t)(nl - edge_hi[buf].data()) + 1;
                 }
-            } else if (size && pin[buf][size - 1 - lo] != '\n') cut_ok = false;              // a last line without its newline: the host machine knows what to do
+            } else if (size && (edge_hi[buf].empty() || edge_hi[buf].back() != '\n')) cut_ok = false;              // a last line without its newline: the host machine knows what to do
             bool valid = false; uint64_t out_n = 0;
+            Measured msd{};
+            t0 = now_ms();
             if (cut_ok && cut_lo <= cut_hi && b < g_test_scan_fail_at) {
-                rc = scan(buf, cut_lo - lo, cut_hi - lo, &valid, &out_n);
+                rc = scan_measure(buf, cut_lo - lo, cut_hi - lo, &valid, &out_n, &msd);
                 if (rc) return rc;
             }
+            ms_scan += now_ms() - t0;
             if (!valid && sharded)
                 return fail(c, KATGPU_ERR_FASTQ, "%s: batch %llu is not plain four-line FASTQ (or holds a '\\r'): such a file cannot be cut between GPUs -- run it on one", path, (unsigned long long)b);
             if (!valid) {
                 if (g_trace) fprintf(stderr, "[katgpu] device scan: batch %llu of %s goes to the host parser (and the rest of the file with it)\n", (unsigned long long)b, path);
-                if (prev_buf >= 0 && carry_n == 0 && prev_out_n) {                           // what the stream ended on, for the windows across the hand-over
-                    carry_n = (uint32_t)std::min<uint64_t>(prev_out_n, k - 1);
-                    HIPCHK(c, hipMemcpy(carry, out[prev_buf] + HEAD + prev_out_n - carry_n, carry_n, hipMemcpyDeviceToHost));
+                if (acc_fill) {                                   // what the stream ended on, for the windows across the hand-over
+                    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+                    carry_n = (uint32_t)std::min<uint64_t>(acc_fill, k - 1);
+                    HIPCHK(c, hipMemcpy(carry, acc[acc_cur] + HEAD + acc_fill - carry_n, carry_n, hipMemcpyDeviceToHost));
+                } else {                                          // ... which may lie in the head of a freshly opened buffer
+                    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+                    carry_n = k - 1;
+                    HIPCHK(c, hipMemcpy(carry, acc[acc_cur] + HEAD - carry_n, carry_n, hipMemcpyDeviceToHost));
                 }
                 shutdown();
+                rc = submit(true);                                // what the device has parsed is counted first; the worker is idle afterwards
+                if (rc) return rc;
+                stop_worker();
+                rc = table_wait(t);
+                if (rc) return rc;
                 return host_rest(cut_lo, carry, carry_n);
             }
-            // the carry: the previous chunk's last k-1 output bytes, right in front of this chunk's (FASTA chunks cut a record's sequence anywhere between two lines)
-            uint8_t* o = out[buf];
-            HIPCHK(c, hipMemsetAsync(o, 'N', HEAD, c->stream));
-            if (prev_buf >= 0 && prev_out_n) {
-                const uint32_t cn = (uint32_t)std::min<uint64_t>(prev_out_n, k - 1);
-                HIPCHK(c, hipMemcpyAsync(o + HEAD - cn, out[prev_buf] + HEAD + prev_out_n - cn, cn, hipMemcpyDeviceToDevice, c->stream));
-            }
-            if (out_n) {
-                rc = count_resident(t, o, HEAD + out_n);         // (ends synchronised with the stream)
-                if (rc) return rc;
-                prev_buf = buf; prev_out_n = out_n;
-            } else HIPCHK(c, hipStreamSynchronize(c->stream));    // the scan's kernels are through with raw[buf]
+            t0 = now_ms();
+            if (acc_fill + out_n > acc_bytes) { rc = submit(false); if (rc) return rc; }      // this chunk opens the other buffer
+            ms_count += now_ms() - t0;
+            t0 = now_ms();
+            rc = scan_emit(msd, acc[acc_cur] + HEAD + acc_fill);
+            if (rc) return rc;
+            acc_fill += out_n;
+            HIPCHK(c, hipStreamSynchronize(c->copy_stream));      // the scan's kernels are through with raw[buf]
+            ms_scan += now_ms() - t0;
             cut_lo = cut_hi;
-            batch_consumed();                                     // raw[buf] / pin[buf] may take my batch after next (out[buf] is rewritten by ITS scan, on this stream)
+            batch_consumed();                                     // raw[buf] may take my batch after next
         }
-        return KATGPU_OK;
+        const double t0 = now_ms();
+        int rc = submit(true);
+        ms_count += now_ms() - t0;
+        return rc;
     }
 };
 
 }  // namespace
+
+void scan_cache_release(katgpu_ctx* c) {
+    katgpu_ctx::ScanCache& sc = c->scan;
+    for (auto st : sc.seg_stream) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+    for (auto p : sc.pin_seg) hipHostFree(p);
+    for (int i = 0; i < 2; ++i) { hipFree(sc.raw[i]); hipFree(sc.acc[i]); }
+    hipFree(sc.raw_al); hipFree(sc.tile_cnt); hipFree(sc.NL); hipFree(sc.len_off); hipFree(sc.line_tile_sum); hipFree(sc.tile_off); hipFree(sc.line_tile_off); hipFree(sc.flags);
+    sc = katgpu_ctx::ScanCache{};
+}
 
 // One large plain file through the device scan.  *took = false: not a file for this path (nothing was counted).
 int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, bool* took, int rank, int world) {
@@ -373,7 +510,7 @@ int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, b
     uint64_t size = 0; uint8_t first = 0;
     if (!device_scan_applies(path, trim5p, &size, &first)) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;
-    if (c->arena && !c->arena_busy && !c->arena_borrowed) {
+    if (!t->alloc_thread.joinable() && c->arena && !c->arena_busy && !c->arena_borrowed) {      // (not while katgpu_count's allocation thread is at work)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < ((size_t)6 << 30)) release_arena(c);    // the cached arena holds most of the free HBM: the batch buffers come first
     }
@@ -382,6 +519,7 @@ int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, b
     int rc = f.setup(size, first, rank, world);
     if (rc == KATGPU_ERR_NOMEM) { (void)hipGetLastError(); return KATGPU_OK; }      // no room for the batch buffers: the streaming path and its smaller rings
     if (rc == KATGPU_OK) { *took = true; rc = f.run(); }
+    if (rc == KATGPU_OK) rc = table_wait(t);
     if (rc == KATGPU_OK) rc = refresh_counters(t);
     return rc;
 }

@@ -75,7 +75,7 @@ int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevT
     HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_hi, 0, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ctrs, 0, CTR_WORDS * sizeof(uint64_t), c->stream));
-    if (g_trace) { const double t1 = now_ms(); hipStreamSynchronize(c->stream); fprintf(stderr, "[katgpu] table alloc: mallocs+enqueue %.1f ms, memsets done after %.1f ms more\n", t1 - t0, now_ms() - t1); }
+    if (g_trace) { const double t1 = now_ms(); hipStreamSynchronize(c->stream); fprintf(stderr, "[katgpu +%.0f ms] table alloc: mallocs+enqueue %.1f ms, memsets done after %.1f ms more\n", since_load(), t1 - t0, now_ms() - t1); }
     *out = d;
     return KATGPU_OK;
 }
@@ -116,8 +116,16 @@ extern "C" int katgpu_table_create_like(katgpu_ctx* c, const katgpu_table* like,
     return KATGPU_OK;
 }
 
+int table_wait(katgpu_table* t) {
+    std::lock_guard<std::mutex> lk(t->alloc_mu);
+    if (t->alloc_thread.joinable()) t->alloc_thread.join();
+    if (t->alloc_rc) return fail(t->ctx, t->alloc_rc, "%s", t->alloc_err.c_str());
+    return KATGPU_OK;
+}
+
 extern "C" void katgpu_table_free(katgpu_table* t) {
     if (!t) return;
+    (void)table_wait(t);
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
     free_dev_table(t->ctx, t->d);

@@ -213,5 +213,6 @@ def test_gpus_switch_writes_the_single_gpu_files(tmp_path, gpus, env):
         assert x.replace(b"one", b"many") == y.replace(b"one", b"many"), (a, b)
     sx, sy = (tmp_path / "one.stats").read_text(), (tmp_path / "many.stats").read_text()
     assert sx == sy
-    r = subprocess.run([EXE, "hist", "--gpus", "2", "-d", "-m27", "-o", "x.hist", "lib_R1.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=e)
+    r = subprocess.run([EXE, "hist", "--gpus", "2", "-d", "-m27", "-o", "x.hist", "lib_R1.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                       env=dict(e, KATGPU_COMM_TRANSPORT="shm"))
     assert r.returncode == 1 and "--gpus" in r.stderr
