@@ -43,7 +43,8 @@ WORKLOADS = {
     "comp-rr": (150_000_000, 1_000_000_000, 31, "kat comp reads-vs-reads"),
 }
 CONFIG_ALIAS = {2: "hist", 3: "gcp", 4: "comp", 5: "comp-rr"}
-PROFILE_JSON = "profiles/r03_final_pmc_fetch_write.json"
+PROFILE_JSON = {"comp": "profiles/r03_final_pmc_fetch_write.json", "hist": "profiles/r03_final_hist_pmc_fetch_write.json",
+                "gcp": "profiles/r03_final_gcp_pmc_fetch_write.json", "comp-rr": "profiles/r03_final_comp-rr_pmc_fetch_write.json"}
 
 
 def parse_args():
@@ -109,8 +110,8 @@ def pmc_traffic(a, world):
     (tools/profile_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs with --kernel-trace; units KB; FETCH_SIZE doubled, as
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  The workload is seeded, so the traffic of a round is
     reproducible; counters cannot be collected from inside the timed run.  None when the workload is not the profiled one."""
-    path = os.path.join(ROOT, PROFILE_JSON)
-    if world != 1 or a.workload != "comp" or not a.default_size or (a.contig, a.read_len, a.err_ppm) != (1_000_000, 150, 2000):
+    path = os.path.join(ROOT, PROFILE_JSON[a.workload])
+    if world != 1 or not a.default_size or (a.contig, a.read_len, a.err_ppm) != (1_000_000, 150, 2000):
         return None, None
     try:
         prof = json.load(open(path))
@@ -125,7 +126,7 @@ def pmc_traffic(a, world):
                 rounds += e.get("launches", 0)
     if not rounds:
         return None, None
-    return int(kb * 1024 / rounds), "%s: (2 x FETCH_SIZE + WRITE_SIZE) of the count-stage kernels / %d rounds" % (PROFILE_JSON, rounds)
+    return int(kb * 1024 / rounds), "%s: (2 x FETCH_SIZE + WRITE_SIZE) of the count-stage kernels / %d rounds" % (PROFILE_JSON[a.workload], rounds)
 
 
 def main():

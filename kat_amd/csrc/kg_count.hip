@@ -92,9 +92,9 @@ static const uint32_t g_p2_fast = hook("KATGPU_P2_FAST") ? (uint32_t)strtoul(hoo
 static const uint64_t g_test_p2_ovf_cap = hook("KATGPU_TEST_P2_OVF_CAP") ? strtoull(hook("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
 static const uint32_t g_test_spill_mod = hook("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(hook("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 static const uint64_t g_test_ap_seg = hook_u64("KATGPU_TEST_AP_SEG", 0) & ~3ULL;   // tests: k-mers per walk segment of the apply kernels (several segments per run)
+static const uint32_t g_apply_nr = (uint32_t)hook_u64("KATGPU_APPLY_NR", 2);            // A/B: probe rounds of the packed apply at the bench's shape (1, 2 or 3)
 static const uint32_t g_apply_per_cu = (uint32_t)hook_u64("KATGPU_APPLY_PER_CU", 0);   // A/B: packed apply workgroups per CU (0: as many as the LDS holds)
 
-static const bool g_p2_stamp = hook("KATGPU_P2_STAMP") != nullptr;       // diagnostic: per-phase cycle stamps of k_p2_fast
 static const uint32_t g_test_hb = hook("KATGPU_TEST_HB") ? (uint32_t)strtoul(hook("KATGPU_TEST_HB"), nullptr, 10) : 0;   // A/B: wider level-2 items than needed (1, 2, 4)
 static bool part_geometry(const DevTable& d, PartGeom* g) {
     g->R = d.n_regions; g->S = d.region_slots; g->P1 = d.p1; g->P2 = d.p2; g->l2 = d.l2;
@@ -210,15 +210,19 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
         const uint64_t seg_cap = (pk_half(g.cbits) - 1) & ~3ULL;                              // a walk adds less than half the count range
         const uint64_t seg_len = g_test_ap_seg ? std::min<uint64_t>(g_test_ap_seg, seg_cap) : std::min<uint64_t>(AP2_SEGMENT, seg_cap);
         const dim3 grid(std::min<uint32_t>(regions, n_cu * per_cu));
-#define KG_APK(B, KP, HB, INL, HK, PF) do { KG_LDS_ATTR((k_p3_apply_pk<B, KP, HB, INL, HK, PF>), LDS_BYTES - 256); \
-            hipLaunchKernelGGL((k_p3_apply_pk<B, KP, HB, INL, HK, PF>), grid, dim3(B), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, \
+#define KG_APK(B, KP, HB, INL, HK, PF, NR) do { KG_LDS_ATTR((k_p3_apply_pk<B, KP, HB, INL, HK, PF, NR>), LDS_BYTES - 256); \
+            hipLaunchKernelGGL((k_p3_apply_pk<B, KP, HB, INL, HK, PF, NR>), grid, dim3(B), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, \
                                qcap, seg_len, g_test_spill_mod); } while (0)
+        // probe rounds before the queue: 2 (measured at the bench size, same box: 163 ms per step against 177 with 3 and 198 with inline
+        // claims in every round); a table's first round claims inline and keeps 3
 #define KG_APK_SHAPE(HB) case HB: \
-            if (hooked) KG_APK(1024, 5, HB, false, true, true); \
-            else if (blk == 1024) { if (fresh) KG_APK(1024, 5, HB, true, false, true); else KG_APK(1024, 5, HB, false, false, true); } \
-            else if (blk == 768) { if (fresh) KG_APK(768, 7, HB, true, false, false); else KG_APK(768, 7, HB, false, false, false); } \
-            else if (g.S <= 4096) { if (fresh) KG_APK(512, 4, HB, true, false, true); else KG_APK(512, 4, HB, false, false, true); } \
-            else { if (fresh) KG_APK(512, 10, HB, true, false, false); else KG_APK(512, 10, HB, false, false, false); } \
+            if (hooked) KG_APK(1024, 5, HB, false, true, true, 3); \
+            else if (blk == 1024) { if (fresh) KG_APK(1024, 5, HB, true, false, true, 3); else KG_APK(1024, 5, HB, false, false, true, 2); } \
+            else if (blk == 768) { if (fresh) KG_APK(768, 7, HB, true, false, false, 3); else KG_APK(768, 7, HB, false, false, false, 2); } \
+            else if (g.S <= 4096) { if (fresh) KG_APK(512, 4, HB, true, false, true, 3); else KG_APK(512, 4, HB, false, false, true, 2); } \
+            else if (HB == 1 && g_apply_nr == 1 && !fresh) KG_APK(512, 10, 1, false, false, false, 1); \
+            else if (HB == 1 && g_apply_nr == 3 && !fresh) KG_APK(512, 10, 1, false, false, false, 3); \
+            else { if (fresh) KG_APK(512, 10, HB, true, false, false, 3); else KG_APK(512, 10, HB, false, false, false, 2); } \
             break;
         switch (g.hb) { KG_APK_SHAPE(0) KG_APK_SHAPE(1) KG_APK_SHAPE(2) default: return fail(c, KATGPU_ERR_DEVICE, "packed apply: item width %u", g.hb); }
 #undef KG_APK_SHAPE
@@ -459,21 +463,6 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 const bool try_fast = try_fast0 && p2_fast_ok;
                 const uint32_t grid_l2 = std::min<uint32_t>(g.b_hi - g.b_lo, W2);
                 HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
-                if (try_fast && g_p2_stamp && g.hb == 1) {         // diagnostic: cycle stamps of wave 0 of every workgroup
-                    unsigned long long* d_st = nullptr;
-                    HIPCHK(c, hipMalloc((void**)&d_st, 64));
-                    HIPCHK(c, hipMemsetAsync(d_st, 0, 64, c->stream));
-                    KG_LDS_ATTR((k_p2_fast<1, true>), sizeof(P2Lds<1>));
-                    hipLaunchKernelGGL((k_p2_fast<1, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<1>), c->stream, g, l1_off, l1_buf, l2_buf,
-                                       off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, d_st);
-                    unsigned long long h[8];
-                    HIPCHK(c, hipMemcpyAsync(h, d_st, 48, hipMemcpyDeviceToHost, c->stream));
-                    HIPCHK(c, hipStreamSynchronize(c->stream));
-                    hipFree(d_st);
-                    const double n = (double)std::max<unsigned long long>(1, h[5]);
-                    fprintf(stderr, "[katgpu] k_p2_fast stamps per tile (cycles, wave 0): loads %.0f, hash+rank %.0f, scan %.0f, staging %.0f, copy-out %.0f; %llu tiles\n",
-                            h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5]);
-                } else
                 if (try_fast) {
                     ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
 #define KG_P2F(HB) case HB: hipLaunchKernelGGL(k_p2_fast<HB>, dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \

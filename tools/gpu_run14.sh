@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+for v in "KATGPU_APPLY_NR=1" "KATGPU_APPLY_NR=2"; do
+  env KATGPU_TESTING=1 $v timeout 300 python bench.py --steps 3 --warmup 1 --no-e2e --no-cpu-baseline > gpurun_out/r3_ab4_$v.json 2> gpurun_out/r3_ab4_$v.err
+  python3 -c "
+import json; d=json.load(open('gpurun_out/r3_ab4_$v.json')); print('$v', d['ms_per_step'], d['kernel_ms_per_step'])"
+done
