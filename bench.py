@@ -402,16 +402,26 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": rounds, "avg_launch_ms": round(stage_ms / rounds, 3),
                 "alg_bytes_per_launch": int(alg_bytes_step * a.steps / rounds), "per_kernel": per_kernel}
-        # the reducers' own roofline (hist / gcp 12 B x C; comp 12 B x (C1 + C2) scan + 12 B x (D1 + D2) probes)
+        # the reducers' own roofline.  SURVEY.md 8(d) prices them at 12 B per slot (hist / gcp: 12 B x C; comp: 12 B x (C1 + C2) scan
+        # + 12 B x (D1 + D2) probes) -- the reference's key + count.  A packed table stores 8 B per slot and the fused join probes in
+        # LDS, so the kernels MOVE less than the formula: `frac` is priced on the bytes the slots really hold (slot_bytes x slots, the
+        # conservative figure; it agrees with the PMC passes in profiles/), `survey_formula` carries the 12-byte figure beside it.
         slot = 20.0 if k > 32 else 12.0
+        sb1, sb2 = (results["geo1"][2], results["geo1"][3]) if results.get("geo1") is not None else (slot, slot)
+        sb1, sb2 = float(sb1 or slot), float(sb2 or slot)
+
+        def red_entry(ms, moved, formula):
+            gbps = lambda b: round(b / (ms / 1e3) / 1e9, 1) if ms else None
+            return {"avg_ms": round(ms, 3), "alg_bytes": int(moved), "achieved_GBps": gbps(moved),
+                    "survey_formula": {"alg_bytes": int(formula), "achieved_GBps": gbps(formula)}}
         red = {}
         if wl in ("hist", "gcp"):
             ms = prof[wl]["ms"] / max(1, prof[wl]["launches"])
-            red["k_" + wl] = {"avg_ms": round(ms, 3), "alg_bytes": int(slot * cap1), "achieved_GBps": round(slot * cap1 / (ms / 1e3) / 1e9, 1) if ms else None}
+            red["k_" + wl] = red_entry(ms, sb1 * cap1, slot * cap1)
         else:
             ms = (prof["comp_pass1"]["ms"] + prof["comp_pass2"]["ms"]) / max(1, prof["comp_pass1"]["launches"])
-            b = slot * (cap1 + cap2) + slot * (results["distinct1"] + results.get("distinct2", 0))
-            red["k_comp pass 1 + pass 2"] = {"avg_ms": round(ms, 3), "alg_bytes": int(b), "achieved_GBps": round(b / (ms / 1e3) / 1e9, 1) if ms else None}
+            red["k_comp pass 1 + pass 2"] = red_entry(ms, sb1 * cap1 + sb2 * cap2,
+                                                      slot * (cap1 + cap2) + slot * (results["distinct1"] + results.get("distinct2", 0)))
         for v in red.values():
             v["frac"] = round(v["achieved_GBps"] / HBM_PEAK_GBPS, 4) if v["achieved_GBps"] else None
         kernels_ms = {n: round(v["ms"] / a.steps, 3) for n, v in prof.items() if v["launches"]}

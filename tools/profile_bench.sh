@@ -4,7 +4,8 @@
 #                                         <tag>_{hist,gcp,comp-rr}_bench.json / _kernel_stats.csv, <tag>_sq_counters.txt
 # The default workload (config 4) runs three ways: plain (the JSON line, with the CPU baseline and the end-to-end leg),
 # --kernel-trace --stats (per-kernel durations), and two --pmc passes (FETCH_SIZE, WRITE_SIZE; counters are collected in their own
-# runs, with --kernel-trace only).  The other workloads: plain, --kernel-trace --stats, and ONE --pmc pass with both counters.
+# runs, with --kernel-trace only).  The other workloads: plain, --kernel-trace --stats, and the same two --pmc passes (tools/profile_pmc_workload.sh: the two
+# counters cannot be collected in one pass on gfx950 -- rocprofv3 aborts with "exceeds the capabilities of the hardware" and then hangs).
 # Then config 4 from files to files at full size (tools/e2e_config4.py) -> <tag>_e2e_config4.json.
 set -u
 tag=${1:-r03_final}
@@ -41,22 +42,7 @@ for w in hist gcp comp-rr; do
   rm -rf /tmp/prof_w /tmp/prof_wp
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_w -- python "$root/bench.py" --workload $w $quiet > /dev/null 2> "$out/${tag}_${w}_stats.err"
   find /tmp/prof_w -name '*kernel_stats.csv' -exec cp {} "$out/${tag}_${w}_kernel_stats.csv" \;
-  timeout 600 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_wp -- python "$root/bench.py" --workload $w $quiet > /dev/null 2> "$out/${tag}_${w}_pmc.err"
-  python - "$out/${tag}_${w}_pmc_fetch_write.json" <<'PY'
-import csv, glob, json, re, sys
-agg = {}
-for f in glob.glob("/tmp/prof_wp/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        k = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
-        name = row["Counter_Name"]
-        if name not in ("FETCH_SIZE", "WRITE_SIZE"):
-            continue
-        e = agg.setdefault(k, {"launches": 0})
-        e[name + "_KB_total"] = e.get(name + "_KB_total", 0.0) + float(row["Counter_Value"])
-        if name == "FETCH_SIZE":
-            e["launches"] += 1
-json.dump(agg, open(sys.argv[1], "w"), indent=1)
-PY
+  bash "$root/tools/profile_pmc_workload.sh" "$tag" $w
 done
 timeout 900 env KATGPU_SCAN_THREADS=32 python "$root/tools/e2e_config4.py" > "$out/${tag}_e2e_config4.json" 2> "$out/${tag}_e2e_config4.err"
 # SQ view of the stage kernels (one partition round of a reduced config): wave cycles, waits, issue, LDS conflicts
