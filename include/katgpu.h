@@ -291,7 +291,7 @@ typedef enum katgpu_kernel {
     KATGPU_K_MERGE = 7,
     KATGPU_K_PART_L1 = 8,    /* partitioned counter: extract + level-1 bucket histogram (k_p1_count + k_p1_scan) */
     KATGPU_K_PART_L2 = 9,    /* level-2 partition: one run per table region (k_p2) */
-    KATGPU_K_PART_APPLY = 10,/* regions updated in LDS (k_p3_apply) */
+    KATGPU_K_PART_APPLY = 10,/* regions updated in LDS (k_p3_apply_pk, k_p3_apply2) */
     KATGPU_K_PART_L1S = 11,  /* extract + level-1 scatter (k_p1_scatter) */
     KATGPU_K_PROFILE = 12,   /* per-position lookups (k_profile) */
     KATGPU_K_SCAN = 13,      /* device-side record scan of raw FASTQ / FASTA bytes (kg_scan.hpp), units = raw bytes */
