@@ -33,8 +33,8 @@ typedef struct katgpu_table katgpu_table;
  * in two words -- counted and reduced (count*, stats, hist, gcp, comp, comp3) exactly like the narrow ones; records move
  * through the *_wide entry points as (hi, lo) = the upper and lower 64 bits of the 2k-bit word (first base most significant,
  * A=0 C=1 G=2 T=3, as mer_dna: JF/include/jellyfish/mer_dna.hpp:235-258); .jf files and the sect/cold profile work for both.
- * Entry points that take 64-bit keys and the region-ordered exchange return KATGPU_ERR_K for a wide table (its exchange is
- * katgpu_table_partition_sizes + katgpu_table_partition_wide + katgpu_table_merge_device_wide). */
+ * Entry points that take 64-bit keys and the region-ordered extraction calls return KATGPU_ERR_K for a wide table (its exchange --
+ * katgpu_exchange_merge does it -- is katgpu_table_partition_sizes + katgpu_table_partition_wide + katgpu_table_merge_device_wide). */
 #define KATGPU_MAX_K 63
 
 typedef enum katgpu_status {
@@ -270,7 +270,7 @@ const char* katgpu_comm_transport_note(const katgpu_comm* comm);   /* "" or why 
 int  katgpu_comm_barrier(katgpu_comm* comm);
 /* Route every record of `t` to its owner rank, in place: afterwards the table holds exactly the k-mers this rank owns, counts summed
  * over all ranks; it keeps its storage and its region grid.  Collective: every rank calls it, with tables of one k / strand mode.
- * k <= 32 (wide tables: katgpu_table_partition_wide + katgpu_table_merge_device_wide). */
+ * Wide tables (k > 32) take the simple route: records grouped by owner, all to all, the table emptied and refilled (it may grow). */
 int  katgpu_exchange_merge(katgpu_comm* comm, katgpu_table* t);
 /* buf[i] = sum over ranks of buf[i], on every rank (host memory; collective) */
 int  katgpu_allreduce_u64(katgpu_comm* comm, uint64_t* buf, size_t n);

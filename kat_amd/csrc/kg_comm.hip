@@ -414,6 +414,62 @@ static size_t exchange_bytes(uint64_t total_send, uint64_t set_records) {
            2 * (xalign(8 * std::max<uint64_t>(set_records, 1)) + xalign(4 * std::max<uint64_t>(set_records, 1))) + 256;
 }
 
+// Wide tables (k > 32): the simple exchange -- records (hi, lo, count) grouped by owner, all to all, the table emptied and refilled
+// with what arrived.  Not region-ordered: the wide table's hash is not one to one and its slots are 20 bytes in three arrays, which the
+// LDS merge is not built for; wide tables count through the direct kernel and merge through it too (k_merge_w).  The table keeps its
+// handle; it grows if its owner share is larger than what it held.
+static int exchange_merge_wide(katgpu_comm* m, katgpu_table* t) {
+    katgpu_ctx* c = m->ctx;
+    const int world = m->world, rank = m->rank;
+    const uint64_t mine[2] = {t->d.k, t->d.canonical};
+    std::vector<uint64_t> all((size_t)world * 2);
+    int rc = allgather_u64(m, mine, 2, all.data());
+    if (rc) return rc;
+    for (int s = 0; s < world; ++s)
+        if (all[(size_t)s * 2] != mine[0] || all[(size_t)s * 2 + 1] != mine[1]) return fail(c, KATGPU_ERR_MISMATCH, "katgpu_exchange_merge: ranks disagree on k / canonical");
+    double t0 = wall_ms();
+    std::vector<uint64_t> sizes((size_t)world), s_all((size_t)world * world);
+    rc = katgpu_table_partition_sizes(t, (uint32_t)world, sizes.data());
+    if (rc) return rc;
+    rc = allgather_u64(m, sizes.data(), (size_t)world, s_all.data());
+    if (rc) return rc;
+    std::vector<uint64_t> send_off((size_t)world + 1, 0), recv_off((size_t)world + 1, 0);
+    for (int p = 0; p < world; ++p) { send_off[p + 1] = send_off[p] + sizes[p]; recv_off[p + 1] = recv_off[p] + s_all[(size_t)p * world + rank]; }
+    const uint64_t ns = std::max<uint64_t>(send_off[world], 1), nr = std::max<uint64_t>(recv_off[world], 1);
+    uint64_t* buf = nullptr;
+    if (hipMalloc((void**)&buf, (ns + nr) * 24) != hipSuccess) { (void)hipGetLastError(); return fail(c, KATGPU_ERR_NOMEM, "wide exchange: %llu + %llu records of 24 bytes", (unsigned long long)ns, (unsigned long long)nr); }
+    struct Free { void* p; ~Free() { hipFree(p); } } free_buf{buf};
+    uint64_t* snd[3] = {buf, buf + ns, buf + 2 * ns};                      // hi | lo | counts, each grouped by owner
+    uint64_t* rcv[3] = {buf + 3 * ns, buf + 3 * ns + nr, buf + 3 * ns + 2 * nr};
+    rc = katgpu_table_partition_wide(t, (uint32_t)world, send_off.data(), snd[0], snd[1], snd[2]);      // (returns with the records written)
+    if (rc) return rc;
+    m->ms_extract += wall_ms() - t0;
+    t0 = wall_ms();
+    std::vector<Msg> sends, recvs;
+    for (int p = 0; p < world; ++p) {
+        const uint64_t n_out = sizes[p], n_in = recv_off[p + 1] - recv_off[p];
+        for (int a = 0; a < 3; ++a) {
+            if (p == rank) { if (n_out) HIPCHK(c, hipMemcpyAsync(rcv[a] + recv_off[p], snd[a] + send_off[p], n_out * 8, hipMemcpyDeviceToDevice, m->stream)); continue; }
+            sends.push_back({p, snd[a] + send_off[p], (size_t)n_out * 8});
+            recvs.push_back({p, rcv[a] + recv_off[p], (size_t)n_in * 8});
+        }
+    }
+    rc = transfer(m, sends, recvs, m->ev[0]);
+    if (!rc) rc = transfer_wait(m, m->ev[0]);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(m->stream));
+    m->ms_exchange += wall_ms() - t0;
+    t0 = wall_ms();
+    rc = katgpu_table_clear(t);
+    if (!rc) rc = katgpu_table_merge_device_wide(t, rcv[0], rcv[1], rcv[2], (size_t)recv_off[world]);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ++m->merge_launches;
+    m->ms_merge += wall_ms() - t0;
+    shm_barrier(m);
+    return refresh_counters(t);
+}
+
 // Route every record of `t` to its owner rank, IN PLACE: on return the table holds exactly the k-mers this rank owns, their counts
 // summed over all ranks.  It keeps its storage and its region grid (a second table created "like" the first still joins with it
 // region by region).  Every rank of the communicator calls this, with tables of one k / one strand mode.  world == 1 runs the whole
@@ -421,8 +477,8 @@ static size_t exchange_bytes(uint64_t total_send, uint64_t set_records) {
 extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
     if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = m->ctx;
-    NARROW_ONLY(t, "katgpu_exchange_merge (wide tables: katgpu_table_partition_wide + katgpu_table_merge_device_wide)");
     HIPCHK(c, hipSetDevice(c->device));
+    if (t->d.keys_b) return exchange_merge_wide(m, t);
     const int world = m->world, rank = m->rank;
     const double t_begin = wall_ms();
 

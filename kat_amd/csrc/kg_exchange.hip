@@ -106,11 +106,10 @@ extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uin
 
 extern "C" int katgpu_table_clear(katgpu_table* t) {
     if (!t) return KATGPU_ERR_INVALID_ARG;
-    NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     DevTable& d = t->d;
-    HIPCHK(c, hipMemsetAsync(d.keys, d.cbits ? 0 : 0xFF, d.cap * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(d.keys, d.cbits ? 0 : 0xFF, d.cap * sizeof(uint64_t) * (d.keys_b ? 2 : 1), c->stream));     // (wide: keys_b follows keys)
     if (d.counts) HIPCHK(c, hipMemsetAsync(d.counts, 0, d.cap * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_hi, 0, OVF_CAP * sizeof(uint64_t), c->stream));

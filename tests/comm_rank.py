@@ -31,7 +31,8 @@ def main():
             time.sleep(0.01)
         cid = open(id_file, "rb").read()
     comm = kat_amd.Comm(eng, rank, world, cid)
-    k = 31 if mode == "rr31" else K
+    k = 31 if mode == "rr31" else 45 if mode == "wide45" else K
+    wide = k > 32
     g = synth.genome(G, seed=11)
     lo, hi = kdist.shard_range(N_READS // 2, rank, world)
     reads = synth.reads(g, 2 * lo, 2 * (hi - lo), seed=1)
@@ -45,18 +46,28 @@ def main():
     ab.upload(asm)
     hint = (1 << 22) if not (mode == "mixed" and rank == 1) else (1 << 24)      # "mixed": rank 1's grid differs: its records take the direct path
     t1 = eng.table(k, True, size_hint=hint).count_bases_device(rb.ptr, reads.size)
-    t2 = eng.table(k, True, size_hint=1 << 20, like=t1).count_bases_device(ab.ptr, asm.size)
-    t1.merge_host(np.array([12345], np.uint64), np.array([(1 << 33) + rank], np.uint64))      # travels out of band
-    g1 = t1.geometry()
-    before = t1.dump_sorted() if world == 1 else None
-    comm.exchange_merge(t1)
-    comm.exchange_merge(t2)
-    assert (t1.geometry().p1, t1.geometry().p2) == (g1.p1, g1.p2)
+    t2 = eng.table(k, True, size_hint=1 << 20, like=None if wide else t1).count_bases_device(ab.ptr, asm.size)
+    if wide:                                                                     # k > 32: records (hi, lo, count) all to all, the table refilled
+        t1.merge_host_wide([0], [12345], [(1 << 33) + rank])
+        before = t1.dump_sorted_wide() if world == 1 else None
+        comm.exchange_merge(t1)
+        comm.exchange_merge(t2)
+        hi, lo, counts = t1.dump_sorted_wide()
+        assert (kdist.owner_of_wide(hi, lo, k, world) == rank).all()
+        if world == 1:
+            assert all(np.array_equal(a, b) for a, b in zip(before, (hi, lo, counts)))
+    else:
+        t1.merge_host(np.array([12345], np.uint64), np.array([(1 << 33) + rank], np.uint64))      # travels out of band
+        g1 = t1.geometry()
+        before = t1.dump_sorted() if world == 1 else None
+        comm.exchange_merge(t1)
+        comm.exchange_merge(t2)
+        assert (t1.geometry().p1, t1.geometry().p2) == (g1.p1, g1.p2)
+        keys, counts = t1.dump_sorted()
+        assert (kdist.owner_of(keys, k, world) == rank).all()
+        if world == 1:                                                           # the protocol on the rank's own records: the table it found
+            assert np.array_equal(before[0], keys) and np.array_equal(before[1], counts)
     assert eng.profile()["merge"]["launches"] > 0
-    keys, counts = t1.dump_sorted()
-    assert (kdist.owner_of(keys, k, world) == rank).all()
-    if world == 1:                                                               # the protocol on the rank's own records: the table it found
-        assert np.array_equal(before[0], keys) and np.array_equal(before[1], counts)
     mx, cc, sp = kat_amd.comp(t1, t2, 1.0, 1.0, 201, 101)
     h, gm = t1.hist(1, 300, 1), t1.gcp(1.0, 100)
     mx, cc, sp, h, gm = comm.allreduce_u64([mx, cc, sp, h, gm])

@@ -82,6 +82,18 @@ def main():
                     assert eng.profile()["scan"]["launches"] > 0, (name, "the device scan did not run")
                 got.free()
                 n += 1
+        # k > 32 behind the same scan: the stream goes to the wide counter (batch cuts carry k - 1 = 44 bases for FASTA)
+        for name in ("reads.fq", "contigs.fa"):
+            path = os.path.join(tmp, name)
+            want = ko.WideTable(45, True).count_bases(kat_amd.parse_file(path))
+            eng.profile_reset()
+            got = eng.table(45, True, size_hint=1 << 18)
+            got.count_files([path])
+            for a, b in zip(got.dump_sorted_wide(), want.dump_sorted()):
+                assert np.array_equal(a, b), (name, "k = 45")
+            assert eng.profile()["scan"]["launches"] > 0, (name, "k = 45: the device scan did not run")
+            got.free()
+            n += 1
         # a group: scanned files and streamed ones (gzip) into one table
         import gzip
         gz = os.path.join(tmp, "more.fq.gz")

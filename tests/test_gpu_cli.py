@@ -213,6 +213,11 @@ def test_gpus_switch_writes_the_single_gpu_files(tmp_path, gpus, env):
         assert x.replace(b"one", b"many") == y.replace(b"one", b"many"), (a, b)
     sx, sy = (tmp_path / "one.stats").read_text(), (tmp_path / "many.stats").read_text()
     assert sx == sy
+    # k > 32: the wide exchange (records all to all, the table refilled) behind the same switch
+    go(["comp", "-m41", "-H", "3000000", "-o", "w_one", "lib_R?.fq", "asm.fa"], "comp k=41", base_env)
+    go(["comp", "--gpus", str(gpus), "-m41", "-H", "3000000", "-o", "w_many", "lib_R?.fq", "asm.fa"], "comp k=41 --gpus", e)
+    assert (tmp_path / "w_one-main.mx").read_bytes().replace(b"w_one", b"w_many") == (tmp_path / "w_many-main.mx").read_bytes()
+    assert (tmp_path / "w_one.stats").read_text() == (tmp_path / "w_many.stats").read_text()
     r = subprocess.run([EXE, "hist", "--gpus", "2", "-d", "-m27", "-o", "x.hist", "lib_R1.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
                        env=dict(e, KATGPU_COMM_TRANSPORT="shm"))
     assert r.returncode == 1 and "--gpus" in r.stderr

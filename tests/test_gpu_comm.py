@@ -36,11 +36,12 @@ def _run(tmp_path, world, mode, env_extra):
 def _check(ko, tmp_path, world, mode):
     from kat_amd import synth
     got = np.load(tmp_path / "sharded.npz")
-    k = 31 if mode == "rr31" else K
+    k = 31 if mode == "rr31" else 45 if mode == "wide45" else K
+    T = ko.WideTable if k > 32 else ko.Table
     g = synth.genome(G, seed=11)
-    o1 = ko.Table(k, True).count_bases(synth.reads(g, 0, N_READS, seed=1))
+    o1 = T(k, True).count_bases(synth.reads(g, 0, N_READS, seed=1))
     o1.add(12345, world * (1 << 33) + world * (world - 1) // 2)
-    o2 = ko.Table(k, True).count_bases(synth.reads(g, 0, N_READS, seed=2) if mode == "rr31" else synth.stream_of_contigs(g, CONTIG))
+    o2 = T(k, True).count_bases(synth.reads(g, 0, N_READS, seed=2) if mode == "rr31" else synth.stream_of_contigs(g, CONTIG))
     mx, cc, sp = ko.comp(o1, o2, 1.0, 1.0, 201, 101)
     assert np.array_equal(got["cc"], cc) and np.array_equal(got["mx"], mx) and np.array_equal(got["sp"], sp)
     assert np.array_equal(got["h"], o1.hist(1, 300, 1)) and np.array_equal(got["gm"], o1.gcp(1.0, 100))
@@ -48,14 +49,16 @@ def _check(ko, tmp_path, world, mode):
 
 @pytest.mark.parametrize("world,mode,extra", [
     (2, "same", {}), (3, "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "7"}), (2, "mixed", {}), (2, "rr31", {}),
-    (2, "same", {"KATGPU_TEST_REGION_SLOTS": "512"})])                    # packed tables on the wire's both ends
+    (2, "same", {"KATGPU_TEST_REGION_SLOTS": "512"}),                     # packed tables on the wire's both ends
+    (3, "wide45", {})])                                                   # k = 45: the wide exchange (records all to all, table refilled)
 def test_native_exchange_ranks_sharing_one_gpu(ko, tmp_path, world, mode, extra):
     out = _run(tmp_path, world, mode, dict(extra, KATGPU_COMM_TRANSPORT="shm"))
     assert "transport: shm" in out
     _check(ko, tmp_path, world, mode)
 
 
-def test_native_exchange_single_rank_over_rccl(ko, tmp_path):
-    out = _run(tmp_path, 1, "same", {"KATGPU_COMM_TRANSPORT": "rccl"})
+@pytest.mark.parametrize("mode", ["same", "wide45"])
+def test_native_exchange_single_rank_over_rccl(ko, tmp_path, mode):
+    out = _run(tmp_path, 1, mode, {"KATGPU_COMM_TRANSPORT": "rccl"})
     assert "transport: rccl" in out, out[-2000:]
-    _check(ko, tmp_path, 1, "same")
+    _check(ko, tmp_path, 1, mode)
