@@ -93,6 +93,7 @@ static const uint64_t g_test_p2_ovf_cap = hook("KATGPU_TEST_P2_OVF_CAP") ? strto
 static const uint32_t g_test_spill_mod = hook("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(hook("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
 static const uint64_t g_test_ap_seg = hook_u64("KATGPU_TEST_AP_SEG", 0) & ~3ULL;   // tests: k-mers per walk segment of the apply kernels (several segments per run)
 static const uint32_t g_apply_nr = (uint32_t)hook_u64("KATGPU_APPLY_NR", 2);            // A/B: probe rounds of the packed apply at the bench's shape (1, 2 or 3)
+static const uint32_t g_apply_min_q = (uint32_t)hook_u64("KATGPU_APPLY_MIN_Q", 72);     // A/B: queue entries per wave the SECOND workgroup of a CU must leave (>= 72)
 static const uint32_t g_apply_per_cu = (uint32_t)hook_u64("KATGPU_APPLY_PER_CU", 0);   // A/B: packed apply workgroups per CU (0: as many as the LDS holds)
 
 static const uint32_t g_test_hb = hook("KATGPU_TEST_HB") ? (uint32_t)strtoul(hook("KATGPU_TEST_HB"), nullptr, 10) : 0;   // A/B: wider level-2 items than needed (1, 2, 4)
@@ -195,7 +196,10 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
         const size_t region_b = (size_t)g.S * 8;
         auto room = [&](uint32_t wgs) -> long { return (long)(LDS_BYTES / wgs / LDS_GRANULE * LDS_GRANULE) - 64 - (long)region_b; };   // bytes left for the queues
         uint32_t per_cu = 4;
-        while (per_cu > 1 && room(per_cu) < (long)(8 * 96 * 8)) --per_cu;                      // at least 96 queue entries per wave
+        // room for the queues of eight waves: 96 entries each for a third and fourth workgroup, 72 for the second -- a second workgroup is worth
+        // short queues (config 5's 9656-slot regions leave exactly 72: apply 103.5 -> 98.2 ms per step against one 1024-thread workgroup)
+        auto min_q = [&](uint32_t wgs) -> long { return 8L * 8 * (wgs == 2 ? std::max<uint32_t>(g_apply_min_q, 72) : 96); };
+        while (per_cu > 1 && room(per_cu) < min_q(per_cu)) --per_cu;
         if (g_apply_per_cu) per_cu = std::min(per_cu, g_apply_per_cu);
         uint32_t blk = per_cu == 1 ? 1024 : 512;
         if (g_apply_block == 512 || g_apply_block == 768 || g_apply_block == 1024) blk = g_apply_block;
