@@ -264,10 +264,10 @@ def main():
         return t_prev
 
     def exchange(t):
-        if k > 32:                                          # wide tables: owner partition -> all-to-all -> rebuild (not in place)
-            return kdist.exchange_merge_wide(kdist.HipWideShard(t, staged=staged or native)).table
         if comm is not None:
-            comm.exchange_merge(t)                          # katgpu_exchange_merge: in place, RCCL behind the C ABI
+            comm.exchange_merge(t)                          # katgpu_exchange_merge: in place, RCCL behind the C ABI (k > 32: records all to all, the table refilled)
+        elif k > 32:                                        # wide tables: owner partition -> all-to-all -> rebuild (not in place)
+            return kdist.exchange_merge_wide(kdist.HipWideShard(t, staged=staged)).table
         else:
             kdist.exchange_merge(kdist.HipShard(t, staged=staged))  # in place: the table keeps its storage and its region grid
         return t
