@@ -5,6 +5,7 @@
 #include "kg_ingest.hpp"
 #include "kg_kernels.hpp"
 #include "kg_partition.hpp"
+#include "kg_partition_wide.hpp"
 #include "kg_wide.hpp"
 
 #include <condition_variable>
@@ -533,6 +534,154 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     return refresh_counters(t);
 }
 
+// The same for wide tables (kg_partition_wide.hpp): 16-byte items, exact level 1 and level 2, one pass of level 2 + apply per round.
+// Arena: [hist1 | offs | l1_off | off2 | spill_n | level-1 buffer | level-2 buffer], 32 bytes per k-mer of a round; the spill list
+// of a round lies in its level-1 buffer, which is dead by then.
+static bool wide_part_geometry(const DevTable& d) {
+    return d.keys_b && d.p1 <= (uint32_t)MAX_PARTS && d.p2 <= (uint32_t)MAX_PARTS && d.region_slots % 4 == 0 && d.region_slots >= 64 && d.region_slots <= WIDE_AP_MAX_SLOTS &&
+           (uint64_t)d.p1 * d.p2 == d.n_regions;
+}
+static int count_partitioned_w(katgpu_table* t, const uint8_t* dev_bases, size_t n, size_t* done) {
+    katgpu_ctx* c = t->ctx;
+    const uint32_t k = t->d.k;
+    const size_t n_starts = n - k + 1;
+    *done = 0;
+    c->arena_borrowed = false;
+    if (n < 4096 || !wide_part_geometry(t->d)) return KATGPU_OK;               // direct path
+    if (!g_test_round_items && !t->disable_grow && t->d.cap < n_starts / 16) {     // (as count_partitioned: room for 1/16 of the starts first)
+        uint64_t nc = t->d.cap; while (nc < n_starts / 16) nc *= 2;
+        int grc = regrow(t, nc);
+        if (grc) return grc;
+        if (!wide_part_geometry(t->d)) return KATGPU_OK;
+    }
+    const uint32_t W = (uint32_t)c->n_cu * 3;                                  // level-1 workgroups (512 threads, 12 KB of LDS)
+    const size_t tile_starts = W1_TILE_STARTS;
+    const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) + align_up((MAX_PARTS + 1) * 8, 256) +
+                               align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) + 256 + 4096;
+    size_t want_items = n_starts;
+    if (g_test_round_items) want_items = std::min<size_t>(want_items, g_test_round_items);
+    size_t want_bytes = small_bytes + 32 * (want_items + 64);
+    if (c->arena_limit) want_bytes = std::min(want_bytes, std::max(c->arena_limit, small_bytes + 32 * ((size_t)64 << 20)));
+    if (c->arena_bytes < want_bytes) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        free_b += c->arena_bytes;
+        const size_t bytes = std::min<size_t>(want_bytes, (size_t)(g_arena_fraction * (double)free_b));
+        if (bytes > c->arena_bytes + c->arena_bytes / 2 || c->arena_bytes < small_bytes + 32 * std::min<size_t>(want_items + 64, (size_t)64 << 20)) {
+            if (c->arena) { HIPCHK(c, hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
+            if (!g_test_round_items && bytes < small_bytes + 32 * ((size_t)1 << 20)) return KATGPU_OK;
+            if (hipMalloc((void**)&c->arena, bytes) != hipSuccess) { (void)hipGetLastError(); c->arena = nullptr; return KATGPU_OK; }
+            c->arena_bytes = bytes;
+            if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] partition arena of %.1f GB (wide k-mers)\n", since_load(), bytes / 1e9);
+        }
+    }
+    struct Busy { katgpu_ctx* c; explicit Busy(katgpu_ctx* c_) : c(c_) { c->arena_busy = true; } ~Busy() { c->arena_busy = false; } } busy(c);
+    uint8_t* a = c->arena;
+    uint32_t* hist1 = (uint32_t*)a;               a += align_up((size_t)W * MAX_PARTS * 4, 256);
+    uint64_t* offs = (uint64_t*)a;                a += align_up((size_t)W * MAX_PARTS * 8, 256);
+    uint64_t* l1_off = (uint64_t*)a;              a += align_up((MAX_PARTS + 1) * 8, 256);
+    uint64_t* off2 = (uint64_t*)a;                a += align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256);
+    unsigned long long* spill_n = (unsigned long long*)a; a += 256;
+    const size_t round_items = std::min<size_t>(want_items, (c->arena_bytes - small_bytes) / 32);
+    u64x2* l1_buf = (u64x2*)a;
+    u64x2* l2_buf = l1_buf + round_items;
+    if (!g_test_round_items && round_items < ((size_t)1 << 20) && round_items < n_starts) return KATGPU_OK;
+    if (round_items < tile_starts && round_items < n_starts) return KATGPU_OK;
+
+    size_t pos = 0;
+    while (pos < n_starts) {
+        int rc = refresh_counters(t);
+        if (rc) return rc;
+        if ((double)t->distinct > 0.6 * (double)t->d.cap) {
+            bool lost = false;
+            rc = grow_beside_arena(t, 0, t->d.cap * 2, KeyLists(), &lost);
+            if (rc) return rc;
+            if (lost) break;                                                      // the caller re-enters with a fresh arena
+        }
+        if (!wide_part_geometry(t->d)) break;
+        const DevTable d = t->d;
+        size_t m = std::min(n_starts - pos, round_items);                          // items <= starts: a round always fits its buffers
+        if (m < n_starts - pos) {
+            const size_t rounds_left = (n_starts - pos + m - 1) / m;               // balance the remaining rounds
+            m = std::min(m, (n_starts - pos + rounds_left - 1) / rounds_left + tile_starts);
+            m -= m % tile_starts;                                                  // whole tiles: the next round starts 16-byte aligned
+            if (!m) break;
+        }
+        const size_t nb = m + k - 1;
+        const uint8_t* p = dev_bases + pos;
+        const uint64_t n_tiles = (m + tile_starts - 1) / tile_starts;
+        const uint64_t tiles_per_wg = (n_tiles + W - 1) / W;
+        PartGeom g{};
+        g.P1 = d.p1;                                                               // (all k_p1_scan looks at)
+        HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
+        {
+            ScopedTimer tm(c, KATGPU_K_PART_L1, m);
+            hipLaunchKernelGGL(k_w1<false>, dim3(W), dim3(W1_BLOCK), 0, c->stream, d, d.p1, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1, (const uint64_t*)nullptr, (u64x2*)nullptr);
+            hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
+        }
+        uint64_t items = 0;
+        HIPCHK(c, hipMemcpyAsync(&items, &l1_off[d.p1], sizeof items, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (g_trace) fprintf(stderr, "[katgpu] partition round (wide k-mers): %zu starts -> %llu items (buffer %zu items, arena %.1f GB)\n", m, (unsigned long long)items, round_items, c->arena_bytes / 1e9);
+        if (items > round_items) return fail(c, KATGPU_ERR_DEVICE, "wide partition round: %llu items from %zu starts", (unsigned long long)items, m);
+        if (items) {
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
+                hipLaunchKernelGGL(k_w1<true>, dim3(W), dim3(W1_BLOCK), 0, c->stream, d, d.p1, p, (uint64_t)nb, n_tiles, tiles_per_wg, (uint32_t*)nullptr, (const uint64_t*)offs, l1_buf);
+            }
+            {
+                ScopedTimer tm(c, KATGPU_K_PART_L2, items);
+                hipLaunchKernelGGL(k_w2, dim3(std::min<uint32_t>(d.p1, (uint32_t)c->n_cu)), dim3(PART_BLOCK), 0, c->stream, d.p1, d.p2, (const uint64_t*)l1_off, (const u64x2*)l1_buf, l2_buf, off2);
+            }
+            {
+                const size_t lds = (size_t)d.region_slots * 20;
+                KG_LDS_ATTR(k_w3_apply, LDS_BYTES - 256);
+                ScopedTimer tm(c, KATGPU_K_PART_APPLY, items);
+                hipLaunchKernelGGL(k_w3_apply, dim3(std::min<uint32_t>(d.n_regions, (uint32_t)c->n_cu)), dim3(W3_BLOCK), lds, c->stream, d, (const uint64_t*)off2, (const u64x2*)l2_buf,
+                                   l1_buf /* the spill list: the level-1 buffer is dead */, spill_n, g_test_spill_mod);
+            }
+            HIPCHK(c, hipGetLastError());
+            unsigned long long spilled = 0;
+            HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (spilled) {                              // regions that ran out of slots: make room, then the direct path
+                if (g_trace) fprintf(stderr, "[katgpu]   %llu k-mers spilled by full regions\n", spilled);
+                rc = g_test_grow_nomem ? KATGPU_ERR_NOMEM : ensure_room(t, spilled);
+                if (rc == KATGPU_ERR_NOMEM) {           // no room for the larger table beside the arena: park the list on the host, give the arena up
+                    (void)hipGetLastError();
+                    std::vector<uint64_t> host;
+                    try { host.resize((size_t)spilled * 2); } catch (...) { return fail(c, KATGPU_ERR_NOMEM, "no host memory to park %llu spilled k-mers", spilled); }
+                    HIPCHK(c, hipMemcpy(host.data(), l1_buf, (size_t)spilled * 16, hipMemcpyDeviceToHost));
+                    release_arena(c);
+                    rc = ensure_room(t, spilled);
+                    if (rc) return rc;
+                    const size_t chunk = std::min<size_t>(spilled, (size_t)16 << 20);
+                    u64x2* dbuf = nullptr;
+                    HIPCHK(c, pool_alloc(c, (void**)&dbuf, chunk * 16));
+                    for (size_t i = 0; i < spilled && rc == KATGPU_OK; i += chunk) {
+                        const size_t mm = std::min(chunk, (size_t)spilled - i);
+                        if (hipMemcpyAsync(dbuf, host.data() + 2 * i, mm * 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(c, KATGPU_ERR_DEVICE, "spill upload"); break; }
+                        ScopedTimer tm(c, KATGPU_K_COUNT, mm);
+                        hipLaunchKernelGGL(k_insert_keys_w, dim3(grid_for(c, mm, 256, 6)), dim3(256), 0, c->stream, t->d, (const u64x2*)dbuf, (uint64_t)mm);
+                        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, KATGPU_ERR_DEVICE, "spill insert");
+                    }
+                    pool_release(c, dbuf);
+                    if (rc) return rc;
+                    pos += m;
+                    break;                              // the caller re-enters with a fresh arena
+                }
+                if (rc) return rc;
+                ScopedTimer tm(c, KATGPU_K_COUNT, spilled);
+                hipLaunchKernelGGL(k_insert_keys_w, dim3(grid_for(c, spilled, 256, 6)), dim3(256), 0, c->stream, t->d, (const u64x2*)l1_buf, (uint64_t)spilled);
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
+        }
+        pos += m;
+    }
+    *done = pos;
+    return refresh_counters(t);
+}
+
 // Count a resident base stream.  The stream is cut into sub-batches so that "distinct + sub-batch starts" stays under
 // the load limit (the table can then never fill in the middle of a launch); consecutive sub-batches overlap by k-1.
 int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
@@ -545,6 +694,13 @@ int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
     while (!t->d.keys_b && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
         size_t done = 0;                        // returns early (done < remaining) when a table growth cost it the arena
         int prc = count_partitioned(t, dev_bases + pos, n - pos, &done);
+        if (prc) return prc;
+        if (!done) break;
+        pos += done;
+    }
+    while (t->d.keys_b && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
+        size_t done = 0;                        // wide tables: kg_partition_wide.hpp
+        int prc = count_partitioned_w(t, dev_bases + pos, n - pos, &done);
         if (prc) return prc;
         if (!done) break;
         pos += done;

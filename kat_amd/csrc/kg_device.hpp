@@ -26,6 +26,7 @@ constexpr uint32_t OVF_CAP = 1u << 16;   // side table for amounts beyond the sl
 constexpr uint32_t PACK_MIN_CBITS = 20;  // a packed slot counts to at least 2^20 - 1 in place (what is beyond goes to the side table)
 constexpr int MAX_PARTS = 1024;          // region digits per level of the partitioned counter (one lane per bucket in its scans): p1, p2 <= MAX_PARTS
 constexpr uint32_t REGION_SLOTS = 8192;  // default slots per region: 96 KB of LDS (8 B key + 4 B count) in the apply kernel
+constexpr uint32_t REGION_SLOTS_WIDE = 6144;   // ... of a wide table (k > 32: 20 B per slot, 120 KB)
 
 // ctrs[] layout (u64 each)
 constexpr int CTR_DISTINCT0 = 0;   // 64 stripes, summed on the host

@@ -12,20 +12,23 @@ static const bool g_no_packed = hook("KATGPU_NO_PACKED") != nullptr;   // tests 
 int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1, uint32_t like_p2) {
     DevTable d{};
     const uint64_t like_r = (uint64_t)like_p1 * like_p2;
+    // slots per region: a wide slot is 20 bytes (two key words + the count), and the wide apply kernel holds a region in LDS like the
+    // narrow ones do (kg_partition_wide.hpp): 6144 slots = 120 KB
+    const uint32_t rs = k > 32 ? std::min<uint32_t>(g_region_slots, REGION_SLOTS_WIDE) : g_region_slots;
     // capacity is a whole number of regions (kg_device.hpp: Probe); a table smaller than one region is a single short region
     // (regions of fewer than 256 slots are not worth a common grid: the spread of the region loads would eat the table's fill limit)
     if (like_r > 1 && (cap + like_r - 1) / like_r <= AP2_MAX_SLOTS - 4 && (cap + like_r - 1) / like_r >= 256) {
         d.p1 = like_p1; d.p2 = like_p2; d.n_regions = (uint32_t)like_r;
         d.region_slots = (uint32_t)((std::max<uint64_t>((cap + like_r - 1) / like_r, 16) + 3) & ~3ULL);   // whole 16-byte lines of keys and counts per region
-    } else if (cap <= g_region_slots) { d.n_regions = d.p1 = d.p2 = 1; d.region_slots = (uint32_t)((cap + 3) & ~3ULL); }
+    } else if (cap <= rs) { d.n_regions = d.p1 = d.p2 = 1; d.region_slots = (uint32_t)((cap + 3) & ~3ULL); }
     else {
-        const uint64_t nr = (cap + g_region_slots - 1) / g_region_slots;
+        const uint64_t nr = (cap + rs - 1) / rs;
         if (nr > 0x3FFFFFFFULL) return fail(c, KATGPU_ERR_NOMEM, "table of %llu slots exceeds the region index", (unsigned long long)cap);
         uint32_t p2 = 1;
         while ((uint64_t)p2 * p2 < nr) ++p2;                   // two radix digits of about the same size
         if (k <= 32) { uint32_t q = 1; while (q < p2) q <<= 1; p2 = q; }   // one-word tables: the level-2 digit is a bit field of the placement hash
         d.p2 = p2; d.p1 = (uint32_t)((nr + p2 - 1) / p2);
-        d.region_slots = g_region_slots;
+        d.region_slots = rs;
         // Level 2 of the partitioned counter works one bucket per workgroup and CU at a time: 584 buckets on 256 CUs are three
         // passes of which the last keeps 72 CUs busy.  With more buckets than CUs, make them a whole number of passes -- fewer,
         // larger regions if the apply kernel's LDS holds them (AP2_MAX_SLOTS), else more, smaller ones.

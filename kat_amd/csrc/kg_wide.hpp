@@ -3,9 +3,9 @@
 // are the narrow ones with the second key word read where the k-mer itself matters.
 //
 // Replaces the same reference code as the narrow kernels -- mer_iterator + multi-word mer_dna (mer_iterator.hpp:59-89,
-// mer_dna.hpp:235-258,330-378) and hash_counter::add -- for k-mers that take two machine words.  The wide path is the direct
-// counter only (global atomics, ~ the first-round kernel of the narrow path); the partitioned counter is built around 8-byte
-// items and serves k <= 32, which is where KAT's defaults and BASELINE.json's configurations live.
+// mer_dna.hpp:235-258,330-378) and hash_counter::add -- for k-mers that take two machine words.  k_count_w is the direct counter
+// (global atomics, ~ the first-round kernel of the narrow path): small inputs and whatever the partitioned counter leaves; inputs of
+// size go through kg_partition_wide.hpp (16-byte items through two radix levels, regions applied in LDS).
 #pragma once
 #include "kg_kernels.hpp"
 

@@ -348,3 +348,20 @@ def test_wide_ranks_sharing_one_gpu_match_single_process(engine, ko, tmp_path, w
     mx, cc, sp = ko.comp(o1, o2, 1.0, 1.0, 201, 101)
     assert np.array_equal(got["cc"], cc) and np.array_equal(got["mx"], mx) and np.array_equal(got["sp"], sp)
     assert np.array_equal(got["h"], o1.hist(1, 300, 1)) and np.array_equal(got["gm"], o1.gcp(1.0, 100))
+
+
+@pytest.mark.parametrize("region_slots,round_items,spill_mod,extra", [
+    (512, 100000, 0, {}), (1024, 3000000, 7, {}), (6144, 400000, 0, {}), (256, 150000, 5, {"KATGPU_TEST_GROW_NOMEM": "1"})])
+def test_partitioned_counter_wide(region_slots, round_items, spill_mod, extra):
+    """The partitioned counter for k > 32 (kg_partition_wide.hpp: 16-byte items through two exact radix levels, regions of 20-byte slots
+    applied in LDS) against the wide oracle, with hooks that force it for small inputs: several rounds per call, regions that fill
+    and spill, regrows in mid-call, growth that loses the arena."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
+               KATGPU_TEST_ROUND_ITEMS=str(round_items), KATGPU_TEST_SPILL_MOD=str(spill_mod))
+    env.update(extra)
+    r = subprocess.run([sys.executable, os.path.join(here, "wide_partition_cases.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "wide partition cases ok" in r.stdout
