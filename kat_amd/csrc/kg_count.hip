@@ -977,7 +977,7 @@ extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_pa
         t->d.k = k; t->d.canonical = canonical ? 1 : 0;                    // what the feeders' own threads look at before the slots exist
         const uint64_t cap = std::max<uint64_t>(size_hint, 1024);
         const size_t arena_bytes = (size_t)16 << 30;
-        t->alloc_thread = std::thread([c, t, k, canonical, cap, arena_bytes]() {
+        t->alloc_thread = std::thread([c, t, k, canonical, cap]() {
             hipSetDevice(c->device);
             DevTable d{};
             const int arc = alloc_dev_table(c, k, canonical, cap, &d);
