@@ -64,15 +64,16 @@ int main(int argc, char* argv[]) {
     //                               each 4096-byte buffer fill) instead of once per record
     //   --gpus N                    N processes, one per GPU (hist, gcp, comp)
     int kept = 2, gpus = 0;
+    bool gpus_given = false;
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "--jellyfish_5ptrim_compat")) katgpu_ingest_jf_5ptrim_compat(1);
-        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
-        else if (!strncmp(argv[i], "--gpus=", 7)) gpus = atoi(argv[i] + 7);
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { gpus = atoi(argv[++i]); gpus_given = true; }
+        else if (!strncmp(argv[i], "--gpus=", 7)) { gpus = atoi(argv[i] + 7); gpus_given = true; }
         else argv[kept++] = argv[i];
     }
     argc = kept;
-    if (gpus < 0 || gpus > 256) { std::cerr << "Error: Parsing Command Line: --gpus takes 1 .. 256" << std::endl; return 1; }
-    if (gpus == 0) return guarded(mode, argc - 1, argv + 1);
+    if (gpus_given && (gpus < 1 || gpus > 256)) { std::cerr << "Error: Parsing Command Line: --gpus takes 1 .. 256" << std::endl; return 1; }
+    if (!gpus_given) return guarded(mode, argc - 1, argv + 1);
     if (mode != "hist" && mode != "gcp" && mode != "comp") { std::cerr << "Error: Parsing Command Line: --gpus applies to hist, gcp and comp" << std::endl; return 1; }
 
     char id_file[] = "/tmp/katgpu-comm-XXXXXX";

@@ -49,3 +49,20 @@ def test_no_cpu_fallback():
         r = subprocess.run([exe, "hist", "-m", "27", os.path.join(ROOT, "tests", "golden", "refdata", "sect_test.fa")],
                            capture_output=True, text=True, cwd=os.environ.get("TMPDIR", "/tmp"))
         assert r.returncode == 5 and "no gfx950 device" in r.stderr
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK), reason="a GPU is visible")
+def test_gpus_launcher_fails_fast_without_a_device(tmp_path):
+    """`katgpu <mode> --gpus N` forks its ranks before any HIP call: without a device every rank fails at katgpu_init and the launcher
+    returns that exit code at once (no rank waits for an id nobody will send); the option's range is checked before anything runs."""
+    exe = os.path.join(ROOT, "kat_amd", "bin", "katgpu")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    fq = os.path.join(ROOT, "tests", "golden", "refdata", "ecoli_r1.1K.fastq")
+    r = subprocess.run([exe, "hist", "--gpus", "2", "-m", "27", "-o", "x.hist", fq], capture_output=True, text=True, cwd=tmp_path, timeout=60)
+    assert r.returncode == 5 and "no gfx950 device" in r.stderr
+    assert not (tmp_path / "x.hist").exists()
+    r = subprocess.run([exe, "hist", "--gpus", "300", "-m", "27", fq], capture_output=True, text=True, cwd=tmp_path, timeout=60)
+    assert r.returncode == 1 and "--gpus takes 1 .. 256" in r.stderr
+    r = subprocess.run([exe, "comp", "--gpus=0", "-m", "27", fq, fq], capture_output=True, text=True, cwd=tmp_path, timeout=60)
+    assert r.returncode == 1 and "--gpus" in r.stderr
