@@ -112,8 +112,10 @@ extern "C" int katgpu_table_create_like(katgpu_ctx* c, const katgpu_table* like,
     uint64_t cap = std::max<uint64_t>(size_hint ? size_hint : (1u << 20), 1024);
     katgpu_table* t = new katgpu_table();
     t->ctx = c; t->disable_grow = disable_grow;
-    int rc = (k > 32) != (like->d.k > 32) ? alloc_dev_table(c, k, canonical, cap, &t->d)     // no common grid across key widths
-                                          : alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2);
+    // (no common grid across key widths; none for wide tables either: nothing joins or merges them region by region, and a grid
+    // handed down could make regions the wide apply kernel cannot hold)
+    int rc = k > 32 || like->d.k > 32 ? alloc_dev_table(c, k, canonical, cap, &t->d)
+                                      : alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2);
     if (rc) { delete t; return rc; }
     *out = t;
     return KATGPU_OK;
