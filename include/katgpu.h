@@ -82,7 +82,8 @@ int katgpu_count(katgpu_ctx* ctx, const char* const* paths, size_t n_paths, uint
 int katgpu_table_create(katgpu_ctx* ctx, uint32_t k, int canonical, uint64_t size_hint, int disable_grow,
                         katgpu_table** out);
 /* As katgpu_table_create, but with the region grid of `like` (the table this one will be compared with): katgpu_comp then
- * joins the two region against region in LDS instead of probing HBM.  Falls back to an own grid if the sizes are too far apart. */
+ * joins the two region against region in LDS instead of probing HBM.  Falls back to an own grid if the sizes are too far apart,
+ * and for k > 32 (wide tables are compared by probes). */
 int katgpu_table_create_like(katgpu_ctx* ctx, const katgpu_table* like, uint32_t k, int canonical, uint64_t size_hint,
                              int disable_grow, katgpu_table** out);
 /* Files and host buffers take the same counter as device-resident input: the parsed stream goes through pinned staging into
