@@ -203,8 +203,7 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
         while (per_cu > 1 && room(per_cu) < min_q(per_cu)) --per_cu;
         if (g_apply_per_cu) per_cu = std::min(per_cu, g_apply_per_cu);
         uint32_t blk = per_cu == 1 ? 1024 : 512;
-        if (g_apply_block == 512 || g_apply_block == 768 || g_apply_block == 1024) blk = g_apply_block;
-        if (blk == 768 && (g.S > 7 * 768 * 2 || per_cu < 2)) blk = per_cu == 1 ? 1024 : 512;   // (the 768-thread shape covers 10752 slots and wants a partner on the CU)
+        if (g_apply_block == 512 || g_apply_block == 1024) blk = g_apply_block;
         if (hooked) { blk = 1024; per_cu = 1; }
         per_cu = std::min<uint32_t>(per_cu, 2048 / blk);
         const uint32_t nw = blk / 64;
@@ -223,7 +222,6 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
 #define KG_APK_SHAPE(HB) case HB: \
             if (hooked) KG_APK(1024, 5, HB, false, true, true, 3); \
             else if (blk == 1024) { if (fresh) KG_APK(1024, 5, HB, true, false, true, 3); else KG_APK(1024, 5, HB, false, false, true, 2); } \
-            else if (blk == 768) { if (fresh) KG_APK(768, 7, HB, true, false, false, 3); else KG_APK(768, 7, HB, false, false, false, 2); } \
             else if (g.S <= 4096) { if (fresh) KG_APK(512, 4, HB, true, false, true, 3); else KG_APK(512, 4, HB, false, false, true, 2); } \
             else if (HB == 1 && g_apply_nr == 1 && !fresh) KG_APK(512, 10, 1, false, false, false, 1); \
             else if (HB == 1 && g_apply_nr == 3 && !fresh) KG_APK(512, 10, 1, false, false, false, 3); \

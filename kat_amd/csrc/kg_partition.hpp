@@ -989,7 +989,7 @@ constexpr uint32_t APK_SLOT_SHIFT = 44;
 template <int BLOCK, int KP /* 16-byte loads per lane that cover a region: two slots each */, int HB, bool INLINE_CLAIM = false, bool TEST_SPILL = false,
           bool PF = true /* the next region travels from HBM into registers behind the walk of this one (2 KP VGPRs across the walk); false: loaded when its turn comes -- for shapes with a second workgroup on the CU to cover that */,
           int NR = 3 /* probe rounds before a k-mer goes to the queue */>
-__global__ void __launch_bounds__(BLOCK, (BLOCK == 768 ? 6 : 4))    // waves per SIMD: two 768-thread workgroups are six (80 VGPRs), every other shape four (128)
+__global__ void __launch_bounds__(BLOCK, 4)    // four waves per SIMD (128 VGPRs): two 512-thread workgroups or one of 1024 threads (a 768-thread shape at six waves spilled: 225 ms against 177)
 k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend,
               uint32_t qcap /* queue entries per wave: what the region leaves of the LDS; >= 72 */, uint64_t seg_len /* k-mers per walk: a multiple of 4 below half the count range */,
