@@ -120,10 +120,11 @@ int  katgpu_ingest_jf_5ptrim_compat(int on);
 
 /* The placement hash of one-word tables (kg_device.hpp "placement"; the counterpart of the invertible hash + remainder storage of
  * JF/include/jellyfish/large_hash_array.hpp:169-171), on the host, for a table of p1 x 2^l2 regions: per key the two region digits,
- * the remainder a partition item carries, and the key the inverse gives back.  *rem_bits = bits of a remainder.  No GPU needed;
- * the parity tests use it to check that the hash is one to one and that its inverse is its inverse. */
+ * the remainder a partition item carries, the key the inverse gives back and (offset != NULL) the home slot inside a region of
+ * region_slots slots.  *rem_bits = bits of a remainder.  No GPU needed; the parity tests use it to check that the hash is one to
+ * one, that its inverse is its inverse and that it spreads k-mers evenly. */
 int katgpu_place_keys(uint32_t k, uint32_t p1, uint32_t l2, const uint64_t* keys, size_t n, uint32_t* d1, uint32_t* d2, uint64_t* rem,
-                      uint64_t* back, uint32_t* rem_bits);
+                      uint64_t* back, uint32_t* rem_bits, uint32_t region_slots, uint32_t* offset);
 
 /* distinct k-mers, sum of counts, slots allocated */
 int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t* total, uint64_t* capacity);

@@ -182,19 +182,22 @@ def jf_5ptrim_compat(on):
     return bool(L.katgpu_ingest_jf_5ptrim_compat(int(bool(on))))
 
 
-def place_keys(k, p1, l2, keys):
-    """Host edition of the one-word tables' placement hash: (d1, d2, remainder, inverse(key), remainder bits).  Needs no GPU."""
+def place_keys(k, p1, l2, keys, region_slots=0):
+    """Host edition of the one-word tables' placement hash: (d1, d2, remainder, inverse(key), remainder bits) and, with region_slots,
+    the home slots as a sixth value.  Needs no GPU."""
     L = load_library()
     keys = np.ascontiguousarray(keys, dtype=np.uint64)
     n = keys.size
     d1, d2 = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
     rem, back = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
     rb = C.c_uint32()
-    L.katgpu_place_keys.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    rc = L.katgpu_place_keys(k, p1, l2, keys.ctypes.data, n, d1.ctypes.data, d2.ctypes.data, rem.ctypes.data, back.ctypes.data, C.addressof(rb))
+    off = np.zeros(n if region_slots else 0, np.uint32)
+    L.katgpu_place_keys.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    rc = L.katgpu_place_keys(k, p1, l2, keys.ctypes.data, n, d1.ctypes.data, d2.ctypes.data, rem.ctypes.data, back.ctypes.data, C.addressof(rb),
+                             region_slots, off.ctypes.data if region_slots else None)
     if rc:
         raise KatGpuError(rc, "katgpu_place_keys")
-    return d1, d2, rem, back, rb.value
+    return (d1, d2, rem, back, rb.value, off) if region_slots else (d1, d2, rem, back, rb.value)
 
 
 def hist_geometry(low, high):

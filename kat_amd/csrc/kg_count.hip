@@ -88,6 +88,7 @@ static const uint32_t g_apply_block = hook("KATGPU_APPLY_BLOCK") ? (uint32_t)str
 // level 1 without its counting pass (kg_partition.hpp: k_p1v2_scatter<true>, one fixed-capacity segment per workgroup and bucket):
 // 0 = never, 1 = for rounds of at least 64 M k-mers (the default), 2 = always (tests)
 static const uint32_t g_test_l1_cpb = hook("KATGPU_TEST_L1_CPB") ? (uint32_t)strtoul(hook("KATGPU_TEST_L1_CPB"), nullptr, 10) : 0;   // tests: segment capacity (forces overflow)
+static const bool g_l1_lean = hook_u64("KATGPU_L1_LEAN", 1) != 0;   // A/B: 0 = level 1's ranking sweep in its 64-bit form (kg_l1_lean.hpp is the 32-bit one)
 static const uint32_t g_l1_fast = hook("KATGPU_L1_FAST") ? (uint32_t)strtoul(hook("KATGPU_L1_FAST"), nullptr, 10) : 1;
 static const uint32_t g_p2_fast = hook("KATGPU_P2_FAST") ? (uint32_t)strtoul(hook("KATGPU_P2_FAST"), nullptr, 10) : 1;
 static const uint64_t g_test_p2_ovf_cap = hook("KATGPU_TEST_P2_OVF_CAP") ? strtoull(hook("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
@@ -103,6 +104,7 @@ static bool part_geometry(const DevTable& d, PartGeom* g) {
     g->b_lo = 0; g->b_hi = d.p1;
     g->pl = place_make(d.k, d.p1, d.n1, d.l2);
     g->hb = std::max(l2_hi_bytes(g->pl.rb), g_test_hb);
+    g->hb1 = l2_hi_bytes(g->pl.n1);
     g->cbits = d.cbits;
     if (d.cbits && g->hb > 2) g->hb = 2;                       // (a packed table's remainder has at most 44 bits)
     // the apply kernels hold a region of whole 16-byte lines, at least a wave's worth of slots, in LDS
@@ -334,8 +336,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / per_item));
     const size_t l1_items = round_items + round_items / 24 + fixed_l1;
     const size_t l2_items = ((size_t)((double)l1_items * l2_items_per_l1_item(hb0) / passes0) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 4096 + 3) & ~(size_t)3;
-    uint64_t* l1_buf = (uint64_t*)a;
-    uint8_t* l2_buf = (uint8_t*)(l1_buf + l1_items);                               // level-2 items, groups of 4
+    uint8_t* l1_buf = a;                                                            // level-1 items, groups of 4, 8 bytes of room per item (kg_partition.hpp "the level-1 buffer")
+    uint8_t* l2_buf = l1_buf + l1_items * 8;                                        // level-2 items, groups of 4
     uint64_t* ovf_buf = (uint64_t*)(l2_buf + align_up(l2_items / 4 * l2_group_bytes(hb0), 16));
     const uint64_t ovf_cap = g_test_p2_ovf_cap ? g_test_p2_ovf_cap : round_items / 32 + 1024;
     bool p2_fast_ok = g_p2_fast != 0, l1_fast_ok = g_l1_fast != 0;
@@ -391,9 +393,12 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         uint64_t seg_cap = est_items / ((uint64_t)W * g.P1);
         seg_cap += seg_cap / 24 + SEG_PAD;
         if (g_test_l1_cpb) seg_cap = std::min<uint64_t>(seg_cap, g_test_l1_cpb);
-        const bool seg = l1_fast_ok && (g_l1_fast == 2 || (ratio_known && est_items >= ((uint64_t)64 << 20))) && (uint64_t)W * g.P1 * seg_cap <= l1_items &&
-                         seg_cap <= 0xFFFFFFFFULL /* the kernel's segment arithmetic is 32 x 32 -> 64 bits */;
-        const uint64_t seg_slots = seg ? (uint64_t)W * seg_cap : 0;                // slots of one bucket
+        seg_cap = (seg_cap + 3) & ~3ULL;                                            // whole groups
+        const bool seg = l1_fast_ok && (g_l1_fast == 2 || (ratio_known && est_items >= ((uint64_t)64 << 20))) && (uint64_t)W * g.P1 * seg_cap + 4 * (uint64_t)g.P1 <= l1_items &&
+                         seg_cap < (1u << 24) && 8 * (uint64_t)W * seg_cap + 32 <= 0xFFFFFFFFULL /* the kernel's segment arithmetic: 24 x 8 and 32 x 32 -> 64 bits */;
+        const uint64_t seg_slots = seg ? (uint64_t)W * seg_cap : 0;                // items of one bucket
+        const uint32_t bucket_stride = (uint32_t)(8 * seg_slots + 32);             // bytes (l1_bucket_base)
+        const bool lean = g_l1_lean && lean_applies(k, g.pl.n1);
         uint64_t items = 0;
         unsigned long long ovf_l1 = 0;
         HIPCHK(c, hipMemsetAsync(spill_n, 0, 2 * sizeof(unsigned long long), c->stream));          // spill_n, ovf_n
@@ -401,8 +406,12 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             items = est_items;                                                    // the exact number is not needed (and not known)
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
-                hipLaunchKernelGGL(k_p1v2_scatter<true>, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)nullptr, l1_buf,
-                                   seg_cap, ovf_buf, ovf_n, ovf_cap);
+                if (lean)
+                    hipLaunchKernelGGL((k_p1v2_scatter<true, true>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)nullptr, (const uint64_t*)nullptr, l1_buf,
+                                       (uint32_t)seg_cap, bucket_stride, ovf_buf, ovf_n, ovf_cap);
+                else
+                    hipLaunchKernelGGL((k_p1v2_scatter<true, false>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)nullptr, (const uint64_t*)nullptr, l1_buf,
+                                       (uint32_t)seg_cap, bucket_stride, ovf_buf, ovf_n, ovf_cap);
             }
             HIPCHK(c, hipMemcpyAsync(&ovf_l1, ovf_n, sizeof ovf_l1, hipMemcpyDeviceToHost, c->stream));      // read at the next synchronisation
             if (g_trace) fprintf(stderr, "[katgpu] partition round (segmented level 1): %zu starts, ~%llu items, %llu k-mers per segment (arena %.1f GB)\n", m, (unsigned long long)items, (unsigned long long)seg_cap, c->arena_bytes / 1e9);
@@ -422,8 +431,12 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             }
             if (items) {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
-                hipLaunchKernelGGL(k_p1v2_scatter<false>, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, l1_buf,
-                                   (uint64_t)0, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
+                if (lean)
+                    hipLaunchKernelGGL((k_p1v2_scatter<false, true>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, (const uint64_t*)l1_off, l1_buf,
+                                       0u, 0u, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
+                else
+                    hipLaunchKernelGGL((k_p1v2_scatter<false, false>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, (const uint64_t*)l1_off, l1_buf,
+                                       0u, 0u, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
             }
         }
         if (items) {
@@ -460,7 +473,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             for (uint32_t b_lo = 0; b_lo < g.P1 && !redo_round; b_lo += step) {
                 g.b_lo = b_lo; g.b_hi = std::min(g.P1, b_lo + step);
                 const uint64_t pass_items = std::max<uint64_t>(1, (uint64_t)((double)items * (g.b_hi - g.b_lo) / g.P1));
-                uint64_t* spill_buf = l1_buf + lbeg(b_lo);                         // this pass's part of the level-1 buffer: dead once its level 2 is through
+                uint64_t* spill_buf = (uint64_t*)(l1_buf + l1_bucket_base(lbeg(b_lo), b_lo));   // this pass's part of the level-1 buffer (8 bytes per item): dead once its level 2 is through
                 const uint32_t* run_len = nullptr;
                 unsigned long long overflowed = ovf_total;
                 const bool try_fast = try_fast0 && p2_fast_ok;

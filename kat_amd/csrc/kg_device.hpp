@@ -52,7 +52,6 @@ struct DevTable {
     uint32_t canonical;
     uint32_t n1, l2;      // one-word tables ("placement" below): bits of the level-1 remainder (from k and p1); p2 == 1 << l2
     uint32_t cbits;       // packed tables: bits of the in-slot counter (64 - remainder bits); 0: KV12
-    const uint64_t* base1;// packed tables: base1[d] = place_base1(d) for d in [0, p1]: what decoding a slot into its k-mer needs
     double inv_slots;     // packed tables: 1.0 / region_slots (slot index -> region without an integer division)
 };
 
@@ -90,89 +89,106 @@ __device__ __forceinline__ uint32_t digit1_of_hash(uint64_t h, uint32_t p1) { re
 __device__ __forceinline__ uint32_t digit2_of_hash(uint64_t h, uint32_t p2) { return __umulhi((uint32_t)(h >> 12), p2); }
 __device__ __forceinline__ uint32_t region_of_hash(uint64_t h, uint32_t p1, uint32_t p2) { return digit1_of_hash(h, p1) * p2 + digit2_of_hash(h, p2); }
 __device__ __forceinline__ uint32_t offset_of_hash(uint64_t h, uint32_t region_slots) { return __umulhi((uint32_t)h, region_slots); }
-// ---- placement of one-word k-mers (k <= 32): an invertible hash on 2k bits, cut into digits ----
+// ---- placement of one-word k-mers (k <= 32): a one-to-one map of the 2k-bit k-mer onto (digit 1, digit 2, remainder) ----
 // Jellyfish stores only what the slot position does not already say about a key (its hash is an invertible matrix product and the
-// array keeps the remainder, JF/include/jellyfish/large_hash_array.hpp:169-171).  Same idea for the partitioned counter: the
-// placement hash is one to one on the n = 2k-bit k-mer space, built from two multiply / xor-shift stages so that each digit comes
-// off the top and what is below it is again a number to hash:
-//     a = key ^ (key >> ceil(n/2));    y1 = a * C1 mod 2^n;    d1 = floor(T(y1) * p1 / 2^32), T = the top 32 bits of y1 (level-1 digit);
-//                                      r1 = y1 - base1(d1)     (base1(d) = the smallest y1 whose digit is d):  n1 bits
-//     b = r1 ^ (r1 >> ceil(n1/2));     y2 = b * C2 mod 2^n1;   d2 = top l2 bits of y2 (level-2 digit, p2 = 2^l2);  rem = the rb = n1 - l2 bits below
-// region = d1 * p2 + d2, home offset = rem's top 32 bits scaled to the region's slots.  (key) -> (d1, d2, rem) is one to one, so an
-// item that sits in region r's run needs only `rem` -- 35 bits at k = 27 with ~2^19 regions, against 64 for the k-mer -- and the
-// apply kernel gets the k-mer back with the inverse (place_key).  A multiply by an odd constant is a bijection mod 2^n whose TOP bits
-// depend on every input bit; x ^ (x >> s) with 2s >= n is its own inverse.  p1 is any number <= 1024 (so that a table of any size
-// has full-size regions), which is why r1 is a difference and not a bit field.
-constexpr uint64_t PLACE_C1 = 0xff51afd7ed558ccdULL, PLACE_C2 = 0xc4ceb9fe1a85ec53ULL;
-constexpr uint64_t inv_mod_2_64(uint64_t a) { uint64_t x = a; for (int i = 0; i < 6; ++i) x *= 2 - a * x; return x; }   // Newton: doubles the correct low bits
-constexpr uint64_t PLACE_C1_INV = inv_mod_2_64(PLACE_C1), PLACE_C2_INV = inv_mod_2_64(PLACE_C2);
-static_assert(PLACE_C1 * PLACE_C1_INV == 1 && PLACE_C2 * PLACE_C2_INV == 1, "modular inverses");
+// array keeps the remainder, JF/include/jellyfish/large_hash_array.hpp:169-171).  Same idea for the partitioned counter, built so
+// that every level PEELS bits off the k-mer instead of re-hashing it (two Feistel-style steps: a field is displaced by a hash of
+// the bits below it, which stay as they are):
+//     key = H : L      (L = the low n1 bits, H < 2^hb1 <= p1 the bits above; hb1 = floor(log2 p1), n1 = 2k - hb1)
+//     d1  = (H + g1(L)) mod p1                                   level-1 digit; r1 = L is what a level-1 item carries (n1 bits)
+//     L   = H2 : L2    (L2 = the low rb = n1 - l2 bits)
+//     d2  = H2 ^ g2(L2)                                          level-2 digit (p2 = 2^l2); rem = L2 is what a level-2 item and a packed slot carry
+//     home offset = g3(rem) scaled to the region's slots
+// region = d1 * p2 + d2.  g1, g2, g3 are three multiplicative hashes (fold to 32 bits, xor-shift, one 32-bit multiply by an odd
+// constant; the TOP bits are used, which depend on every input bit) -- they need not be invertible: given (d1, d2, rem), H2 = d2 ^
+// g2(rem), L = H2 : rem, H = (d1 - g1(L)) mod p1.  (key) -> (d1, d2, rem) is one to one, digits are uniform whenever the hashed low
+// bits are, and NOTHING is multiplied in 64 bits: level 1 spends one 32-bit multiply per k-mer, level 2 one, the apply one, and the
+// items shrink as they go (8 -> 6 -> 5 bytes at k = 27 with 2^19 regions).  The first edition (two multiply / xor-shift stages on
+// 2k and n1 bits) cost level 1 and level 2 five 32-bit multiplies and a dozen 64-bit shifts per k-mer each.
+// p1 is any number <= 1024 (so that a table of any size has full-size regions); p2 a power of two.
+constexpr uint32_t PLACE_G1 = 0x9E3779B1u, PLACE_G2 = 0x85EBCA6Bu, PLACE_G3 = 0xC2B2AE35u;   // odd
 
 struct Place {             // the bit budget of one table: wave-uniform, a handful of SGPRs
     uint32_t n, p1;        // 2k; level-1 digits
-    uint32_t n1, rb;       // bits of r1; bits below the level-2 digit (the remainder an item carries)
-    uint32_t s0, s1;       // xor-shift distances of the two stages
-    uint64_t m0, m1;       // masks of n and n1 bits
+    uint32_t n1, rb;       // bits of r1 (the k-mer's low bits a level-1 item carries); bits of the remainder (what a level-2 item and a packed slot carry)
+    uint32_t l2e;          // bits of the level-2 digit's field: min(l2, n1)
+    uint64_t m1, mr;       // masks of n1 and rb bits
 };
 __device__ __host__ __forceinline__ uint64_t low_mask(uint32_t bits) { return bits >= 64 ? ~0ULL : (1ULL << bits) - 1; }
-__device__ __host__ __forceinline__ uint32_t place_top32(uint64_t y1, uint32_t n) { return n >= 32 ? (uint32_t)(y1 >> (n - 32)) : (uint32_t)(y1 << (32 - n)); }
-// the smallest n-bit y1 whose level-1 digit is d (d == p1: 2^n, one past the last); one 64-bit division: callers keep d uniform
-// where it matters (a bucket, a region)
-__device__ __host__ __forceinline__ uint64_t place_base1(uint32_t d, uint32_t n, uint32_t p1) {
-    if (d == 0) return 0;
-    const uint64_t tb = (((uint64_t)d << 32) + p1 - 1) / p1;                      // smallest T with floor(T * p1 / 2^32) >= d; <= 2^32
-    return n >= 32 ? tb << (n - 32) : (tb + (1ULL << (32 - n)) - 1) >> (32 - n);
+__device__ __host__ __forceinline__ uint32_t place_mul24(uint32_t a, uint32_t b) {   // a, b < 2^24, product < 2^32: the full-rate multiply
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
 }
-// bits of the widest r1 (host: once per table)
+// 32 well-mixed bits (the top ones) of up to 64 input bits
+__device__ __host__ __forceinline__ uint32_t place_mix(uint32_t lo, uint32_t hi, uint32_t c) {
+    uint32_t x = lo ^ ((hi << 19) | (hi >> 13));
+    x ^= x >> 15;
+    return x * c;
+}
+__device__ __host__ __forceinline__ uint32_t place_mix(uint64_t v, uint32_t c) { return place_mix((uint32_t)v, (uint32_t)(v >> 32), c); }
+// bits of r1 (host: once per table)
 inline uint32_t place_n1(uint32_t k, uint32_t p1) {
+    uint32_t hb1 = 0;
+    while ((2u << hb1) <= p1) ++hb1;                               // floor(log2 p1)
     const uint32_t n = 2 * k;
-    unsigned __int128 widest = 0, prev = 0;
-    for (uint32_t d = 1; d <= p1; ++d) {
-        const unsigned __int128 b = d == p1 ? (unsigned __int128)1 << n : (unsigned __int128)place_base1(d, n, p1);
-        if (b > prev && b - prev - 1 > widest) widest = b - prev - 1;          // (a digit without keys -- p1 > 4^k -- has no r1)
-        prev = b;
-    }
-    uint32_t bits = 0;
-    while (bits < 64 && (widest >> bits)) ++bits;
-    return bits;
+    return n > hb1 ? n - hb1 : 0;
 }
 __device__ __host__ __forceinline__ Place place_make(uint32_t k, uint32_t p1, uint32_t n1, uint32_t l2) {
     Place p;
     p.n = 2 * k; p.p1 = p1; p.n1 = n1;
-    p.rb = n1 - (l2 < n1 ? l2 : n1);                               // (a key space smaller than the grid: the digit just stays small)
-    p.s0 = (p.n + 1) / 2; p.s1 = (n1 + 1) / 2;
-    p.m0 = low_mask(p.n); p.m1 = low_mask(n1);
+    p.l2e = l2 < n1 ? l2 : n1;                                     // (a key space smaller than the grid: the digit just stays small)
+    p.rb = n1 - p.l2e;
+    p.m1 = low_mask(n1); p.mr = low_mask(p.rb);
     return p;
 }
 struct Placed { uint32_t d1, d2; uint64_t rem; };
-__device__ __host__ __forceinline__ uint64_t place_stage1(uint64_t key, const Place& p) { return ((key ^ (key >> p.s0)) * PLACE_C1) & p.m0; }   // y1
-__device__ __host__ __forceinline__ uint32_t place_digit1(uint64_t y1, const Place& p) { return (uint32_t)(((uint64_t)place_top32(y1, p.n) * p.p1) >> 32); }
-__device__ __host__ __forceinline__ uint64_t place_stage2(uint64_t r1, const Place& p) { return ((r1 ^ (r1 >> p.s1)) * PLACE_C2) & p.m1; }     // y2 = d2 : rem
+// g1 scaled to [0, p1): (22 hash bits * p1) >> 22 (p1 <= 1024)
+__device__ __host__ __forceinline__ uint32_t place_g1(uint32_t l_lo, uint32_t l_hi, const Place& p) { return place_mul24(place_mix(l_lo, l_hi, PLACE_G1) >> 10, p.p1) >> 22; }
+__device__ __host__ __forceinline__ uint32_t place_g2(uint32_t r_lo, uint32_t r_hi, const Place& p) { return p.l2e ? place_mix(r_lo, r_hi, PLACE_G2) >> (32 - p.l2e) : 0u; }
+// level-1 digit of a k-mer
+__device__ __host__ __forceinline__ uint32_t place_digit1_of(uint64_t key, const Place& p) {
+    const uint64_t L = key & p.m1;
+    const uint32_t H = p.n1 < 64 ? (uint32_t)(key >> p.n1) : 0u;
+    uint32_t d = H + place_g1((uint32_t)L, (uint32_t)(L >> 32), p);
+    return d >= p.p1 ? d - p.p1 : d;
+}
+// level-2 digit and remainder of r1 (= the k-mer's low n1 bits)
+__device__ __host__ __forceinline__ uint32_t place_digit2_of(uint64_t r1, const Place& p) {
+    const uint64_t L2 = r1 & p.mr;
+    const uint32_t H2 = p.rb < 64 ? (uint32_t)(r1 >> p.rb) : 0u;
+    return H2 ^ place_g2((uint32_t)L2, (uint32_t)(L2 >> 32), p);
+}
+// y2 = d2 : rem, the form the level-2 digit and the remainder travel in together (n1 <= 64 bits); "base1" is what the inverse needs
+// to know of the level-1 digit: the digit (a name from the first edition, where it was the smallest hash value of the digit)
+__device__ __host__ __forceinline__ uint64_t place_base1(uint32_t d, const Place&) { return d; }
+__device__ __host__ __forceinline__ uint64_t place_stage2(uint64_t r1, const Place& p) { return (p.rb < 64 ? (uint64_t)place_digit2_of(r1, p) << p.rb : 0ULL) | (r1 & p.mr); }   // y2 = d2 : rem
 __device__ __host__ __forceinline__ uint32_t place_digit2(uint64_t y2, const Place& p) { return p.rb < 64 ? (uint32_t)(y2 >> p.rb) : 0u; }
-__device__ __host__ __forceinline__ uint64_t place_rem(uint64_t y2, const Place& p) { return y2 & low_mask(p.rb); }
+__device__ __host__ __forceinline__ uint64_t place_rem(uint64_t y2, const Place& p) { return y2 & p.mr; }
 __device__ __host__ __forceinline__ Placed place_hash(uint64_t key, const Place& p) {
-    const uint64_t y1 = place_stage1(key, p);
-    const uint32_t T = place_top32(y1, p.n);
-    const uint64_t tp = (uint64_t)T * p.p1;                                       // d1 : fraction
     Placed r;
-    r.d1 = (uint32_t)(tp >> 32);
-    // base1(d1) without the 64-bit division: T is (fraction / p1) steps above the first T of its digit
-    const uint32_t tb = T - (uint32_t)tp / p.p1;
-    const uint64_t base1 = p.n >= 32 ? (uint64_t)tb << (p.n - 32) : ((uint64_t)tb + (1ULL << (32 - p.n)) - 1) >> (32 - p.n);
-    const uint64_t y2 = place_stage2(y1 - base1, p);
-    r.d2 = place_digit2(y2, p); r.rem = place_rem(y2, p);
+    r.d1 = place_digit1_of(key, p);
+    r.d2 = place_digit2_of(key & p.m1, p);
+    r.rem = key & p.mr;
     return r;
 }
-// the inverse; base1 = place_base1(d1, ...) (the caller's: uniform over a region)
-__device__ __host__ __forceinline__ uint64_t place_key(uint64_t base1, uint64_t y2, const Place& p) {
-    const uint64_t b = (y2 * PLACE_C2_INV) & p.m1, r1 = b ^ (b >> p.s1);
-    const uint64_t a = ((base1 + r1) * PLACE_C1_INV) & p.m0;
-    return a ^ (a >> p.s0);
+// the inverse: the k-mer of remainder `rem` in region (d1, d2) (the digits are the caller's: uniform over a region)
+__device__ __host__ __forceinline__ uint64_t place_key_d(uint32_t d1, uint32_t d2, uint64_t rem, const Place& p) {
+    const uint32_t H2 = d2 ^ place_g2((uint32_t)rem, (uint32_t)(rem >> 32), p);
+    const uint64_t L = (p.rb < 64 ? (uint64_t)H2 << p.rb : 0ULL) | rem;
+    uint32_t H = d1 + p.p1 - place_g1((uint32_t)L, (uint32_t)(L >> 32), p);
+    H = H >= p.p1 ? H - p.p1 : H;
+    return (p.n1 < 64 ? (uint64_t)H << p.n1 : 0ULL) | L;
 }
-// home offset inside a region of S slots from the remainder: its top 32 bits (the best mixed ones), scaled without a division
+// ... from base1 = place_base1(d1) and y2 = d2 : rem
+__device__ __host__ __forceinline__ uint64_t place_key(uint64_t base1, uint64_t y2, const Place& p) { return place_key_d((uint32_t)base1, place_digit2(y2, p), y2 & p.mr, p); }
+// home offset inside a region of S slots from the remainder: 18 hash bits scaled with the full-rate multiply (regions have fewer
+// than 2^14 slots wherever a region is walked; the general form is for one-region tables of any size)
 __device__ __host__ __forceinline__ uint32_t place_offset(uint64_t rem, const Place& p, uint32_t S) {
-    const uint32_t top = p.rb >= 32 ? (uint32_t)(rem >> (p.rb - 32)) : (uint32_t)(rem << (32 - p.rb));
-    return (uint32_t)(((uint64_t)top * S) >> 32);
+    const uint32_t h = place_mix((uint32_t)rem, (uint32_t)(rem >> 32), PLACE_G3);
+    return S < (1u << 14) ? place_mul24(h >> 14, S) >> 18 : (uint32_t)(((uint64_t)h * S) >> 32);
 }
 
 struct Probe {
@@ -189,18 +205,18 @@ __device__ __forceinline__ uint32_t home_offset(const uint64_t key, const DevTab
     return place_offset(place_hash(key, pl).rem, pl, t.region_slots);
 }
 // the same for kernels that go through one region's k-mers: the level-1 digit is the region's, so its base is computed once
-struct RegionPlace { Place pl; uint64_t base1, d2_hi; uint32_t S; };
+struct RegionPlace { Place pl; uint32_t d1, d2; uint32_t S; };
 __device__ __forceinline__ RegionPlace region_place(const DevTable& t, uint32_t region) {
     RegionPlace rp;
     rp.pl = place_make(t.k, t.p1, t.n1, t.l2);
-    rp.base1 = place_base1(region >> t.l2, rp.pl.n, rp.pl.p1);
-    rp.d2_hi = rp.pl.rb < 64 ? (uint64_t)(region & (t.p2 - 1)) << rp.pl.rb : 0ULL;
+    rp.d1 = region >> t.l2;
+    rp.d2 = region & (t.p2 - 1);
     rp.S = t.region_slots;
     return rp;
 }
-__device__ __forceinline__ uint64_t rem_in(const uint64_t key, const RegionPlace& rp) { return place_rem(place_stage2(place_stage1(key, rp.pl) - rp.base1, rp.pl), rp.pl); }
+__device__ __forceinline__ uint64_t rem_in(const uint64_t key, const RegionPlace& rp) { return key & rp.pl.mr; }      // (of a k-mer that lies in the region)
 __device__ __forceinline__ uint32_t home_offset_in(const uint64_t key, const RegionPlace& rp) { return place_offset(rem_in(key, rp), rp.pl, rp.S); }
-__device__ __forceinline__ uint64_t key_in(const uint64_t rem, const RegionPlace& rp) { return place_key(rp.base1, rp.d2_hi | rem, rp.pl); }
+__device__ __forceinline__ uint64_t key_in(const uint64_t rem, const RegionPlace& rp) { return place_key_d(rp.d1, rp.d2, rem, rp.pl); }
 __device__ __forceinline__ Probe probe_start(const uint64_t key, const DevTable& t) {
     Probe p;
     const uint32_t region_slots = t.region_slots;
@@ -260,8 +276,7 @@ __device__ __forceinline__ uint32_t region_of_pos(const DevTable& t, uint64_t po
 __device__ __forceinline__ uint64_t pk_key(const DevTable& t, uint64_t pos, uint64_t w) {
     const Place pl = place_make(t.k, t.p1, t.n1, t.l2);
     const uint32_t region = region_of_pos(t, pos);
-    const uint64_t d2_hi = pl.rb < 64 ? (uint64_t)(region & (t.p2 - 1)) << pl.rb : 0ULL;
-    return place_key(t.base1[region >> t.l2], d2_hi | (w >> t.cbits), pl);
+    return place_key_d(region >> t.l2, region & (t.p2 - 1), w >> t.cbits, pl);
 }
 // amount = q * half + r (r < half): the slot takes r (and, should that carry it past its field, gives `half` back), the side table q * half
 __device__ __forceinline__ void pk_split(uint64_t amount, uint32_t cbits, uint64_t& q, uint64_t& r) { q = amount >> (cbits - 1); r = amount & (pk_half(cbits) - 1); }

@@ -7,14 +7,15 @@
 // ------------------------------------------------------------------ region-ordered exchange -----------
 
 extern "C" int katgpu_place_keys(uint32_t k, uint32_t p1, uint32_t l2, const uint64_t* keys, size_t n, uint32_t* d1, uint32_t* d2, uint64_t* rem,
-                                 uint64_t* back, uint32_t* rem_bits) {
+                                 uint64_t* back, uint32_t* rem_bits, uint32_t region_slots, uint32_t* offset) {
     if (k < 1 || k > 32 || p1 < 1 || p1 > MAX_PARTS || l2 > 10 || (n && (!keys || !d1 || !d2 || !rem || !back))) return KATGPU_ERR_INVALID_ARG;
     const Place pl = place_make(k, p1, place_n1(k, p1), l2);
     if (rem_bits) *rem_bits = pl.rb;
     for (size_t i = 0; i < n; ++i) {
         const Placed h = place_hash(keys[i], pl);
         d1[i] = h.d1; d2[i] = h.d2; rem[i] = h.rem;
-        back[i] = place_key(place_base1(h.d1, pl.n, pl.p1), (pl.rb < 64 ? (uint64_t)h.d2 << pl.rb : 0ULL) | h.rem, pl);
+        back[i] = place_key(place_base1(h.d1, pl), (pl.rb < 64 ? (uint64_t)h.d2 << pl.rb : 0ULL) | h.rem, pl);
+        if (offset && region_slots) offset[i] = place_offset(h.rem, pl, region_slots);
     }
     return KATGPU_OK;
 }

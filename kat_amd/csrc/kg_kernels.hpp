@@ -265,8 +265,8 @@ k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long lon
         if constexpr (PK) {                                // the quad lies in one region (regions are whole quads): its digits once
             const uint32_t region = region_of_pos(t, in_range ? q * 4 : 0);
             rp.pl = place_make(t.k, t.p1, t.n1, t.l2);
-            rp.base1 = t.base1[region >> t.l2];
-            rp.d2_hi = rp.pl.rb < 64 ? (uint64_t)(region & (t.p2 - 1)) << rp.pl.rb : 0ULL;
+            rp.d1 = region >> t.l2;
+            rp.d2 = region & (t.p2 - 1);
         }
         if constexpr (W) {
             const uint64_t at = in_range ? q * 4 : 0;

@@ -5,12 +5,13 @@
 // ~22 G/s whatever the table size -- so the direct kernel (k_count: one atomic per instance) tops out near 15 G k-mers/s.
 // This path removes the per-instance global atomic.  The table is made of regions of `region_slots` slots with
 // region-local probing (kg_device.hpp: Probe); a round of the partitioned counter
-//   P1  radix-partitions the round's k-mers by the high part of their region index into P1 buckets  (8 B out / k-mer)
-//   P2  splits every bucket by the low part of the region index -> one contiguous run per region     (8 B in, 4 + HB B out)
+//   P1  radix-partitions the round's k-mers by the high part of their region index into P1 buckets  (4 + HB1 B out / k-mer)
+//   P2  splits every bucket by the low part of the region index -> one contiguous run per region     (4 + HB1 B in, 4 + HB B out)
 //   P3  loads a region into LDS, applies its run with LDS atomics, writes the region back            (4 + HB B in + 16 B/slot packed, 24 KV12)
-// What level 2 writes is not the k-mer but the REMAINDER of its placement hash (kg_device.hpp "placement": the hash is one to one
-// and the region already says its digits): rb = 2k - log2(regions) bits, kept as two streams -- the low 32 bits and HB = 0, 1, 2
-// or 4 bytes of high bits (35 bits at the bench size: 5 bytes per k-mer instead of 8).
+// An item is not the k-mer but what its position does not already say (kg_device.hpp "placement": the map k-mer -> (digit 1, digit 2,
+// remainder) is one to one and each level peels its digit off): level 1 writes the k-mer's low n1 = 2k - log2(p1) bits, level 2 its
+// low rb = n1 - log2(p2) bits, each as the low 32 bits + HB = 0, 1, 2 or 4 bytes of high bits (45 and 35 bits at the bench size: 6
+// and 5 bytes per k-mer instead of 8 and 8).
 // so HBM sees only streaming traffic.  Level 1 is exact two-pass (histogram, scan, scatter) with per-workgroup running
 // cursors held in LDS: no global atomic per k-mer, deterministic placement.  Level 2 normally runs in ONE pass
 // (k_p2_fast: equal-capacity runs sized from the uniform hash, an overflow list for what does not fit, the exact
@@ -19,6 +20,9 @@
 // direct path after a regrow.
 #pragma once
 #include "kg_kernels.hpp"
+#include "kg_l1_lean.hpp"
+
+#include <type_traits>
 
 namespace kg {
 
@@ -42,6 +46,7 @@ struct PartGeom {
                        // through level 2 + apply in as many passes as there are whole sets of n_CU buckets: the level-2 buffer holds one pass)
     uint32_t l2;       // P2 == 1 << l2
     uint32_t hb;       // bytes of a level-2 item beyond its low 32 bits: 0, 1, 2 or 4 (from pl.rb; "the level-2 buffer" below)
+    uint32_t hb1;      // ... of a level-1 item (from pl.n1; "the level-1 buffer" below)
     uint32_t cbits;    // the table's (kg_device.hpp: packed slots); 0: KV12
     Place pl;          // the placement hash's bit budget for this table (kg_device.hpp)
 };
@@ -197,15 +202,38 @@ constexpr int P1_TILE_BYTES = P1_BLOCK * PART_ITEMS;              // 8192
 constexpr int P1_TILE_STARTS = P1_TILE_BYTES - CHUNK_OVERLAP;     // 8160
 constexpr int P1_LANES_WITH_STARTS = P1_TILE_STARTS / PART_ITEMS; // 510
 
-struct P1Lds {
-    uint64_t cursor[MAX_PARTS];         // exact edition: next position of each bucket's run; segmented edition: the low word counts inside the segment
+// ---- the level-1 buffer ----
+// A level-1 item is r1 = the k-mer's low n1 bits (kg_device.hpp "placement": the bucket says the rest), kept like a level-2 item: the
+// low 32 bits + HB1 = 0, 1, 2 or 4 bytes of high bits, in groups of four = 16 + 4 HB1 contiguous bytes (24 at the bench size: 6 bytes
+// per k-mer where the k-mer itself took 8; level 2 loads a group with two instructions).  Bucket b's groups start at byte
+// l1_bucket_base(first item of b, b): the buffer keeps 8 bytes per item whatever the group size, because a pass's part of it, once
+// its level 2 is through, is the spill list of that pass's apply -- 8-byte k-mers, as many as there were items in the worst case.
+// The all-ones item is "no item" (segment padding): n1 < 8 (4 + HB1) wherever this path runs (part_geometry).
+__device__ __host__ __forceinline__ uint64_t l1_bucket_base(uint64_t first_item, uint32_t b) { return 8 * first_item + 32ULL * b; }   // (+ 32 b: a bucket's last group may hold up to three items more than the bucket)
+__device__ __forceinline__ void l1_put(uint8_t* __restrict__ bucket, uint64_t group_byte, uint32_t q, uint32_t hb1, uint32_t lo, uint32_t hi) {
+    uint8_t* grp = bucket + group_byte;
+    reinterpret_cast<uint32_t*>(grp)[q] = lo;
+    if (hb1 == 1) grp[16 + q] = (uint8_t)hi;
+    else if (hb1 == 2) reinterpret_cast<uint16_t*>(grp + 16)[q] = (uint16_t)hi;
+    else if (hb1 == 4) reinterpret_cast<uint32_t*>(grp + 16)[q] = hi;
+}
+
+// LEAN (k_p1v2_scatter<SEG, true>): the tile's reverse-complement stream is staged next to the codes (rcode), so that the copy-out reads
+// the k-mer of the strand the ranking sweep chose instead of recomputing the canonical form; the segmented edition's cursors count
+// inside a segment and fit 32 bits, which pays for rcode (three workgroups per CU: 3 x 1280-byte granules to spare).
+template <bool LEAN = false, bool SEG = false>
+struct P1LdsT {
+    typedef typename std::conditional<SEG, uint32_t, uint64_t>::type cursor_t;
+    cursor_t cursor[MAX_PARTS];         // next item of each bucket's run, counted from the bucket's first item (exact edition) / inside the segment (segmented)
     uint32_t hist[MAX_PARTS];
     uint32_t off[MAX_PARTS];
     uint32_t wave_tot[16];
     uint32_t code[P1_BLOCK + 2];
     uint32_t bad[P1_BLOCK + 2];
-    uint32_t pos[P1_TILE_BYTES];        // per staged k-mer: bucket << 16 | tile position  (52 KB in all: three workgroups per CU)
+    uint32_t rcode[LEAN ? P1_BLOCK + 2 : 1];   // LEAN: word v = reverse complement of code word 511 - v (the tile read backwards on the other strand)
+    uint32_t pos[P1_TILE_BYTES];        // per staged k-mer: bucket << 16 | strand << 15 (LEAN) | tile position  (50 KB in all: three workgroups per CU)
 };
+typedef P1LdsT<false, false> P1Lds;
 
 struct LaneWindow {                       // the 96-bit sliding window of kg_kernels.hpp's K1, as an object
     uint64_t hi, lo, m;
@@ -259,6 +287,7 @@ __device__ __forceinline__ void p1_tile_fix(const uint8_t* __restrict__ bases, u
         }
     }
 }
+
 __device__ __forceinline__ void p1_tile_load(const uint8_t* __restrict__ bases, uint64_t n, uint64_t tile_off, uint32_t (&w)[4]) {
     const uint64_t off = tile_off + (uint64_t)threadIdx.x * PART_ITEMS;
     if (off + PART_ITEMS <= n) {
@@ -275,13 +304,15 @@ __device__ __forceinline__ void p1_tile_load(const uint8_t* __restrict__ bases, 
     }
 }
 
-__device__ __forceinline__ void p1_tile_stage(P1Lds& L, const uint32_t (&w)[4]) {
+template <bool LEAN, bool SEG>
+__device__ __forceinline__ void p1_tile_stage(P1LdsT<LEAN, SEG>& L, const uint32_t (&w)[4]) {
     const uint32_t tid = threadIdx.x;
     uint32_t code, bad;
     encode16(w, code, bad);
     L.code[tid] = code;
     L.bad[tid] = bad;
-    if (tid < 2) { L.code[P1_BLOCK + tid] = 0; L.bad[P1_BLOCK + tid] = 0xFFFF; }
+    if (LEAN) L.rcode[P1_BLOCK - 1 - tid] = lean_revcomp16(code);
+    if (tid < 2) { L.code[P1_BLOCK + tid] = 0; L.bad[P1_BLOCK + tid] = 0xFFFF; if (LEAN) L.rcode[P1_BLOCK + tid] = 0; }
     lds_barrier();
 }
 
@@ -334,7 +365,7 @@ k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
                 if (!lw.valid()) continue;
                 const uint64_t key = canon_if(lw.fwd(), t.k, canonical);
                 if (key == EMPTY) { ++ones; continue; }
-                atomicAdd(&s_hist[place_digit1(place_stage1(key, g.pl), g.pl)], 1u);
+                atomicAdd(&s_hist[place_digit1_of(key, g.pl)], 1u);
             }
         }
     }
@@ -344,27 +375,30 @@ k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
     if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
 }
 
-// SEG = false: the exact edition -- every workgroup's share of every bucket was counted first (k_p1v2_count, k_p1_scan), `offs`
-// holds where it starts.  SEG = true: no counting pass -- bucket b is cut into one SEGMENT of seg_cap k-mers per workgroup
-// (segment (b, w) starts at (b * gridDim + w) * seg_cap); the hash spreads a workgroup's k-mers evenly, so a capacity of the
-// expected share + 1/24 + 64 holds them (5 sigma at the bench size); what a full segment cannot take goes to the overflow list
-// (-> direct path; if that overflows too the host redoes the round with the exact edition), what a segment has left at the
-// end is padded with EMPTY, which level 2 skips (the all-ones k-mer never is an item).  Saves the second decode + hash of the
-// whole input (k_p1v2_count: 70 ms of the bench step) for ~4 % more level-1 bytes.
-template <bool SEG>
+// SEG = false: the exact edition -- every workgroup's share of every bucket was counted first (k_p1v2_count, k_p1_scan): `offs`
+// holds where it starts, l1_off where the bucket does.  SEG = true: no counting pass -- bucket b is cut into one SEGMENT of seg_cap
+// items per workgroup (segment (b, w) = items [w * seg_cap, (w + 1) * seg_cap) of bucket b; seg_cap a multiple of 4: whole groups);
+// the placement spreads a workgroup's k-mers evenly, so a capacity of the expected share + 1/24 + 64 holds them (5 sigma at the bench
+// size); what a full segment cannot take goes to the overflow list as a k-mer (-> direct path; if that overflows too the host redoes
+// the round with the exact edition), what a segment has left at the end is padded with "no item", which level 2 skips.  Saves
+// the second decode + hash of the whole input (k_p1v2_count: 70 ms of the bench step) for ~4 % more level-1 bytes.
+// LEAN: the ranking sweep on 32-bit halves and a copy-out that reads the chosen strand's k-mer off the staged stream of that strand
+// (kg_l1_lean.hpp; host-checked arithmetic).
+template <bool SEG, bool LEAN = false>
 __global__ void __launch_bounds__(P1_BLOCK, 6)                // six waves per SIMD = three workgroups per CU (g_p1_wgs): at most 80 VGPRs
 k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
-               const uint64_t* __restrict__ offs, uint64_t* __restrict__ l1_buf, uint64_t seg_cap, uint64_t* __restrict__ ovf_buf,
-               unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
-    __shared__ __attribute__((aligned(16))) P1Lds L;
+               const uint64_t* __restrict__ offs, const uint64_t* __restrict__ l1_off, uint8_t* __restrict__ l1_buf, uint32_t seg_cap /* SEG: < 2^24 */,
+               uint32_t bucket_stride /* SEG: bytes from one bucket's first group to the next's, < 2^32 */,
+               uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
+    __shared__ __attribute__((aligned(16))) P1LdsT<LEAN, SEG> L;
+    typedef typename P1LdsT<LEAN, SEG>::cursor_t cursor_t;
     const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;
     const bool canonical = t.canonical != 0;
+    const uint32_t hb1 = g.hb1, gs1 = 16 + 4 * hb1;
     uint32_t ones = 0;
-    // segment (b, this workgroup) starts at seg_base(b): one 32 x 32 -> 64-bit multiply (segments and their capacity are 32-bit
-    // numbers: host-checked); the segmented edition's cursors count inside the segment
-    const uint32_t cap32 = (uint32_t)seg_cap;
-    auto seg_base = [&](uint32_t b) -> uint64_t { return (uint64_t)(b * gridDim.x + blockIdx.x) * cap32; };
-    for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] = SEG ? 0 : offs[(uint64_t)blockIdx.x * P + b];
+    // SEG: this workgroup's segment of bucket b starts seg_off bytes into the bucket (whole groups)
+    const uint64_t seg_off = SEG ? (uint64_t)blockIdx.x * (seg_cap >> 2) * gs1 : 0;
+    for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] = SEG ? (cursor_t)0 : (cursor_t)(offs[(uint64_t)blockIdx.x * P + b] - l1_off[b]);
     const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
     u32x4 raw = p1_tile_issue(bases, n, (t0 < t1 ? t0 : 0) * P1_TILE_STARTS);
     for (uint64_t tile = t0; tile < t1; ++tile) {
@@ -377,7 +411,25 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         // sweep 1: bucket and rank of every valid window of this lane
         uint32_t br[PART_ITEMS];
         uint32_t valid = 0;
-        if (tid < P1_LANES_WITH_STARTS) {
+        if (LEAN && tid < P1_LANES_WITH_STARTS) {
+            const LeanGeom lg = lean_geom(k, canonical, g.pl.n1);
+            const uint32_t v16 = lean_valid16(L.bad[tid], L.bad[tid + 1], L.bad[tid + 2], k);
+            LeanWin w{L.code[tid], L.code[tid + 1], L.code[tid + 2], 0, 0};
+            uint32_t f_hi, f_lo;
+            lean_fwd(w, lg, f_hi, f_lo);
+            { const uint64_t rc0 = kmer_revcomp(((uint64_t)f_hi << 32) | f_lo, k); w.rc_hi = (uint32_t)(rc0 >> 32); w.rc_lo = (uint32_t)rc0; }
+#pragma unroll
+            for (int j = 0; j < PART_ITEMS; ++j) {
+                if (j) { lean_step(w); lean_fwd(w, lg, f_hi, f_lo); lean_rc_roll(w, lg, f_lo); }
+                uint32_t key_hi, key_lo;
+                bool took_rc;                                                // the reverse complement is the canonical form
+                const uint32_t b = lean_digit1(w, lg, g.pl, f_hi, f_lo, key_hi, key_lo, took_rc);
+                const uint32_t strand = took_rc ? 0x8000u : 0u;
+                br[j] = 0;                                                   // (k <= 31: no k-mer is the all-ones word)
+                if (v16 & (0x8000u >> j)) { br[j] = (b << 16) | strand | atomicAdd(&L.hist[b], 1u); valid |= 1u << j; }
+            }
+        }
+        if (!LEAN && tid < P1_LANES_WITH_STARTS) {
             LaneWindow lw;
             lw.init(L.code, L.bad, tid, k);
             // the reverse complement rolls along with the window: out goes its last base, in comes the complement of the window's
@@ -392,7 +444,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                 const uint64_t fw = lw.fwd();
                 const uint64_t key = canonical ? (rc < fw ? rc : fw) : fw;
                 if (key == EMPTY) { if (SEG) ++ones; continue; }               // exact edition: tallied by the count pass
-                const uint32_t b = place_digit1(place_stage1(key, g.pl), g.pl);
+                const uint32_t b = place_digit1_of(key, g.pl);
                 br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
                 valid |= 1u << j;
             }
@@ -406,72 +458,103 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         // sweep 2: park the tile position of every k-mer in its bucket's run
 #pragma unroll
         for (int j = 0; j < PART_ITEMS; ++j)
-            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & 0xFFFF)] = (br[j] & 0xFFFF0000u) | (tid * PART_ITEMS + j);
+            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & (LEAN ? 0x7FFFu : 0xFFFFu))] = (br[j] & (LEAN ? 0xFFFF8000u : 0xFFFF0000u)) | (tid * PART_ITEMS + j);
         lds_barrier();
         // copy-out, one staged k-mer per lane and step: its bucket travels with its position, so no lane idles on a short run
         // and the steps are independent of each other (a loop over buckets serialised ~24 LDS round trips per lane group and
-        // was 57 % of this kernel: cycle stamps; same-box A/B 228 -> 216 ms).  Neighbouring lanes still write neighbouring addresses
+        // was 57 % of this kernel: cycle stamps; same-box A/B 228 -> 216 ms).  Neighbouring lanes still write neighbouring items
         // inside a run.
         const uint32_t total = L.off[P - 1] + L.hist[P - 1];
         for (uint32_t idx = tid; idx < total; idx += P1_BLOCK) {
             const uint32_t v = L.pos[idx], b = v >> 16;
-            const uint64_t key1 = kmer_at(L.code, v & 0xFFFF, k, canonical);
-            const uint32_t rel = (uint32_t)L.cursor[b] + (idx - L.off[b]);    // (segmented edition)
-            if (!SEG) l1_buf[L.cursor[b] + (idx - L.off[b])] = key1;
-            else if (rel < cap32) l1_buf[seg_base(b) + rel] = key1;
-            else {                                                             // the segment is full: the overflow list
-                const unsigned long long at = atomicAdd(ovf_n, 1ULL);
-                if (at < ovf_cap) ovf_buf[at] = key1;
+            uint64_t key1;
+            if (LEAN) {                                                    // the chosen strand's k-mer, read off that strand's stream
+                const uint32_t p = v & 0x7FFFu, rc = v & 0x8000u;
+                key1 = lean_kmer_at(rc ? L.rcode : L.code, rc ? P1_TILE_BYTES - k - p : p, k);
+            } else key1 = kmer_at(L.code, v & 0xFFFF, k, canonical);
+            const uint64_t r1 = key1 & g.pl.m1;
+            const uint32_t ahead = idx - L.off[b];
+            if (SEG) {
+                const uint32_t rel = (uint32_t)L.cursor[b] + ahead;         // item of the segment (32-bit: seg_cap < 2^24, a tile adds < 2^13)
+                if (rel < seg_cap) l1_put(l1_buf + ((uint64_t)b * bucket_stride + seg_off), __umul24(rel >> 2, gs1), rel & 3, hb1, (uint32_t)r1, (uint32_t)(r1 >> 32));
+                else {                                                       // the segment is full: the overflow list
+                    const unsigned long long at = atomicAdd(ovf_n, 1ULL);
+                    if (at < ovf_cap) ovf_buf[at] = key1;
+                }
+            } else {
+                const uint64_t i = (uint64_t)L.cursor[b] + ahead;           // item of the bucket
+                l1_put(l1_buf + l1_bucket_base(l1_off[b], b), (i >> 2) * gs1, (uint32_t)i & 3, hb1, (uint32_t)r1, (uint32_t)(r1 >> 32));
             }
         }
         lds_barrier();
         for (uint32_t b = tid; b < P; b += P1_BLOCK) {
-            uint64_t c = L.cursor[b] + L.hist[b];
-            if (SEG) c = c < cap32 ? c : cap32;
-            L.cursor[b] = c;
+            uint64_t c = (uint64_t)L.cursor[b] + L.hist[b];
+            if (SEG) c = c < seg_cap ? c : seg_cap;
+            L.cursor[b] = (cursor_t)c;
         }
     }
     if (SEG) {
         lds_barrier();
-        // what the segments have left is padded; a 16-lane group per bucket
+        // what the segments have left is padded with "no item"; a 16-lane group per bucket
         const uint32_t grp = tid >> 4, l16 = tid & 15;
         for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
-            const uint64_t base = seg_base(b);
-            for (uint64_t i = L.cursor[b] + l16; i < cap32; i += 16) l1_buf[base + i] = EMPTY;
+            uint8_t* base = l1_buf + ((uint64_t)b * bucket_stride + seg_off);
+            for (uint32_t i = (uint32_t)L.cursor[b] + l16; i < seg_cap; i += 16) l1_put(base, __umul24(i >> 2, gs1), i & 3, hb1, 0xFFFFFFFFu, 0xFFFFFFFFu);
         }
         for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
         if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
     }
 }
 
-// where bucket b1 of the level-1 buffer lies: exact layout (l1_off) or segmented (seg_slots = workgroups x seg_cap slots per
-// bucket, EMPTY-padded)
-__device__ __forceinline__ void l1_bucket_range(const uint64_t* __restrict__ l1_off, uint64_t seg_slots, uint32_t b1, uint64_t& beg, uint64_t& end) {
-    if (seg_slots) { beg = (uint64_t)b1 * seg_slots; end = beg + seg_slots; }
-    else { beg = l1_off[b1]; end = l1_off[b1 + 1]; }
+// bucket b1 of the level-1 buffer: its number of items (segment padding included) and where its groups lie.  Exact layout (l1_off)
+// or segmented (seg_slots = workgroups x seg_cap items per bucket, "no item"-padded).
+__device__ __forceinline__ void l1_bucket_range(const uint64_t* __restrict__ l1_off, uint64_t seg_slots, uint32_t b1, uint64_t& first, uint64_t& n_items) {
+    if (seg_slots) { first = (uint64_t)b1 * seg_slots; n_items = seg_slots; }
+    else { first = l1_off[b1]; n_items = l1_off[b1 + 1] - first; }
 }
 
 // ---- level 2 ----
-// What level 2 writes is the placement hash below the level-1 digit (y2 = digit : remainder, kg_device.hpp): the digit sorts, the
-// remainder alone reaches HBM.
-// the N k-mers of a lane for one tile of bucket [beg, end) of the level-1 buffer; bit j of the result = item j is a k-mer (not past
-// the end, not segment padding)
-template <int N>
-__device__ __forceinline__ uint32_t p2_tile_load(const uint64_t* __restrict__ l1_buf, uint64_t tbeg, uint64_t end, bool padded, uint64_t (&key)[N]) {
+// A level-1 item is r1, the part of the k-mer below the level-1 digit (kg_device.hpp "placement"): its top bits, displaced by a hash of
+// the rest, are the level-2 digit, which sorts; the rest alone -- the remainder -- reaches HBM.
+// The N items of a lane for one tile (items [tbeg, tbeg + N * 1024), tbeg a multiple of 4) of a bucket of n_items items whose groups
+// start at `bucket`: lane t takes groups t, t + 1024, ... of the tile: N / 4 loads of 16 bytes + N / 4 of 4 HB1.  Bit j of the result
+// = item j is there (not past the end, not padding).
+template <int N, int HB1>
+__device__ __forceinline__ uint32_t p2_tile_load_hb(const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, uint64_t (&key)[N]) {
     // unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch (the compiler pulled
     // the padding test into the branch of each load: sixteen serialised round trips to HBM, 29 K of a tile's 54 K cycles)
-    // (Issuing the next tile's loads behind the staging, so that they fly during the copy-out, moved the wait instead of removing it:
-    // the loads queue behind the stores.  Level 2 now moves its 14 bytes per k-mer at 3.5 TB/s.)
+    static_assert(N % 4 == 0, "whole groups");
+    constexpr uint64_t NONE1 = L2Fmt<HB1>::NONE;
+    const uint64_t n_grp = (n_items + 3) >> 2;
+    u32x4 lo[N / 4];
+    typename HiGroup<HB1>::type hi[N / 4];
+#pragma unroll
+    for (int u = 0; u < N / 4; ++u) {
+        const uint64_t gi = (tbeg >> 2) + (uint64_t)u * PART_BLOCK + threadIdx.x;
+        hi[u] = typename HiGroup<HB1>::type{};
+        l2_load_group<HB1>(bucket, gi < n_grp ? gi : n_grp - 1, lo[u], hi[u]);
+    }
     uint32_t valid = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const uint64_t i = tbeg + (uint64_t)j * PART_BLOCK + threadIdx.x;
-        key[j] = l1_buf[i < end ? i : end - 1];
-        valid |= i < end ? 1u << j : 0u;
-    }
+    for (int u = 0; u < N / 4; ++u) {
+        const uint64_t i0 = tbeg + 4 * ((uint64_t)u * PART_BLOCK + threadIdx.x);
 #pragma unroll
-    for (int j = 0; j < N; ++j) if (padded && key[j] == EMPTY) valid &= ~(1u << j);      // segment padding
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t v = ((uint64_t)hi_of_group<HB1>(hi[u], q) << 32) | (q == 0 ? lo[u].x : q == 1 ? lo[u].y : q == 2 ? lo[u].z : lo[u].w);
+            key[4 * u + q] = v;
+            valid |= (i0 + q < n_items && v != NONE1) ? 1u << (4 * u + q) : 0u;
+        }
+    }
     return valid;
+}
+template <int N>
+__device__ __forceinline__ uint32_t p2_tile_load(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, uint64_t (&key)[N]) {
+    switch (hb1) {                                                             // (wave-uniform)
+    case 0: return p2_tile_load_hb<N, 0>(bucket, tbeg, n_items, key);
+    case 1: return p2_tile_load_hb<N, 1>(bucket, tbeg, n_items, key);
+    case 2: return p2_tile_load_hb<N, 2>(bucket, tbeg, n_items, key);
+    default: return p2_tile_load_hb<N, 4>(bucket, tbeg, n_items, key);
+    }
 }
 
 // Counting-sort one tile's k-mers of a bucket by their level-2 digit through LDS and append every digit's run at this workgroup's
@@ -480,7 +563,7 @@ __device__ __forceinline__ uint32_t p2_tile_load(const uint64_t* __restrict__ l1
 // fit goes to the overflow list as a k-mer (through the inverse hash).  Not GROUPED (the exact edition): item by item at exact
 // positions.  All 1024 lanes must call it (barriers inside).
 template <int HB, bool GROUPED, bool STAMP = false>
-__device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, const uint64_t base1, const uint64_t (&key)[L2Fmt<HB>::N], uint32_t valid,
+__device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, const uint32_t b1, const uint64_t (&key)[L2Fmt<HB>::N], uint32_t valid,
                                               uint8_t* __restrict__ out, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap,
                                               unsigned long long* st = nullptr /* STAMP: cycles of [1] hash + rank, [2] scan, [3] staging, [4] copy-out */) {
     constexpr int N = L2Fmt<HB>::N;
@@ -492,13 +575,11 @@ __device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, co
     if (tid < MAX_PARTS) L.hist[tid] = 0;
     lds_barrier();
     uint32_t br[N];                                           // digit << 16 | rank inside the tile's run
-    uint64_t y2[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        br[j] = 0; y2[j] = 0;
+        br[j] = 0;
         if (valid >> j & 1) {
-            y2[j] = place_stage2(place_stage1(key[j], g.pl) - base1, g.pl);
-            const uint32_t b = place_digit2(y2[j], g.pl);
+            const uint32_t b = place_digit2_of(key[j], g.pl);      // (key[j] = r1: one 32-bit multiply)
             br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
         }
     }
@@ -517,7 +598,7 @@ __device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, co
     for (int j = 0; j < N; ++j)
         if (valid >> j & 1) {
             const uint32_t b = br[j] >> 16, slot = L.goff[b] * (GROUPED ? 4u : 1u) + (br[j] & 0xFFFF);
-            const uint64_t rem = place_rem(y2[j], g.pl);
+            const uint64_t rem = key[j] & g.pl.mr;
             L.st_lo[slot] = (uint32_t)rem;
             if (HB) L.st_hi[slot] = (hi_t)(rem >> 32);
             if (GROUPED) L.grp_b[slot >> 2] = (uint16_t)b;
@@ -539,7 +620,7 @@ __device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, co
                     const uint64_t rem = ((uint64_t)hi_of_group<HB>(hi, q) << 32) | (q == 0 ? lo.x : q == 1 ? lo.y : q == 2 ? lo.z : lo.w);
                     if (rem == L2Fmt<HB>::NONE) continue;
                     const unsigned long long at = atomicAdd(ovf_n, 1ULL);
-                    if (at < ovf_cap) ovf_buf[at] = place_key(base1, (g.pl.rb < 64 ? (uint64_t)b << g.pl.rb : 0ULL) | rem, g.pl);
+                    if (at < ovf_cap) ovf_buf[at] = place_key_d(b1, b, rem, g.pl);
                 }
             }
         }
@@ -568,18 +649,18 @@ __device__ __host__ __forceinline__ uint64_t p2_exact_base(uint64_t beg, uint32_
 // multiple of 4: runs begin on group boundaries; the up to three items between a run's last k-mer and the next run are "no item").
 template <int HB>
 __global__ void __launch_bounds__(PART_BLOCK)
-k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
+k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
      uint64_t* __restrict__ off2, uint64_t seg_slots, uint64_t* __restrict__ bend /* end of bucket b1's last run: the next bucket's runs start later */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     P2Lds<HB>& L = *reinterpret_cast<P2Lds<HB>*>(lds_raw);
     constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
-    uint64_t beg0, end0;
-    l1_bucket_range(l1_off, seg_slots, g.b_lo, beg0, end0);
+    uint64_t beg0, n0;
+    l1_bucket_range(l1_off, seg_slots, g.b_lo, beg0, n0);
     for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
-        uint64_t beg, end;
-        l1_bucket_range(l1_off, seg_slots, b1, beg, end);
-        const uint64_t base1 = place_base1(b1, g.pl.n, g.pl.p1);
+        uint64_t beg, n_items;
+        l1_bucket_range(l1_off, seg_slots, b1, beg, n_items);
+        const uint8_t* bucket = l1_buf + l1_bucket_base(beg, b1);
         const uint64_t obeg = p2_exact_base(beg, b1, g.P2) - p2_exact_base(beg0, g.b_lo, g.P2);   // the level-2 buffer holds this pass only
         lds_barrier();
         // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
@@ -587,13 +668,12 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
         unsigned long long* h64 = reinterpret_cast<unsigned long long*>(L.cursor);
         if (tid < MAX_PARTS) h64[tid] = 0;
         lds_barrier();
-        for (uint64_t i0 = beg; i0 < end; i0 += (uint64_t)8 * PART_BLOCK) {                   // 8 coalesced loads in flight per lane
-            uint64_t v[8];
+        for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
+            uint64_t key[N];
+            const uint32_t valid = p2_tile_load<N>(g.hb1, bucket, tbeg, n_items, key);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const uint64_t i = i0 + (uint64_t)u * PART_BLOCK + tid; const uint64_t x = l1_buf[i < end ? i : end - 1]; v[u] = i < end ? x : EMPTY; }   // (clamped, unconditional: see p2_tile_load)
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (v[u] != EMPTY) atomicAdd(&h64[place_digit2(place_stage2(place_stage1(v[u], g.pl) - base1, g.pl), g.pl)], 1ULL);
+            for (int j = 0; j < N; ++j)
+                if (valid >> j & 1) atomicAdd(&h64[place_digit2_of(key[j], g.pl)], 1ULL);
         }
         lds_barrier();
         const uint64_t mine = tid < g.P2 ? h64[tid] : 0;
@@ -606,11 +686,11 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict
         }
         if (b1 == g.b_hi - 1 && tid == g.P2 - 1) off2[(uint64_t)g.b_hi * g.P2] = obeg + excl + ((mine + 3) & ~3ULL);
         if (bend && tid == g.P2 - 1) bend[b1] = obeg + excl + ((mine + 3) & ~3ULL);             // the runs of a bucket stop short of the next bucket's
-        for (uint64_t tbeg = beg; tbeg < end; tbeg += L2Fmt<HB>::TILE) {                       // pass B
+        for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {                     // pass B
             uint64_t key[N];
-            const uint32_t valid = p2_tile_load<N>(l1_buf, tbeg, end, seg_slots != 0, key);
+            const uint32_t valid = p2_tile_load<N>(g.hb1, bucket, tbeg, n_items, key);
             lds_barrier();
-            scatter_tile2<HB, false>(L, g, base1, key, valid, l2_buf, nullptr, nullptr, 0);
+            scatter_tile2<HB, false>(L, g, b1, key, valid, l2_buf, nullptr, nullptr, 0);
         }
     }
 }
@@ -631,7 +711,7 @@ __device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t 
 
 template <int HB, bool STAMP = false>
 __global__ void __launch_bounds__(PART_BLOCK)
-k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
+k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
           uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
           uint64_t ovf_cap, uint64_t seg_slots, unsigned long long* __restrict__ stamps = nullptr) {
     // STAMP (diagnostic, KATGPU_P2_STAMP): cycles of wave 0: [0] tile loads, [1] hash + rank, [2] scan, [3] staging, [4] copy-out, [5] tiles
@@ -640,14 +720,14 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
     P2Lds<HB>& L = *reinterpret_cast<P2Lds<HB>*>(lds_raw);
     constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
-    uint64_t beg0, end0;
-    l1_bucket_range(l1_off, seg_slots, g.b_lo, beg0, end0);
+    uint64_t beg0, n0;
+    l1_bucket_range(l1_off, seg_slots, g.b_lo, beg0, n0);
     for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
-        uint64_t beg, end;
-        l1_bucket_range(l1_off, seg_slots, b1, beg, end);
-        const uint64_t cap = p2_region_cap(end - beg, g.P2, L2Fmt<HB>::TILE);
+        uint64_t beg, n_items;
+        l1_bucket_range(l1_off, seg_slots, b1, beg, n_items);
+        const uint8_t* bucket = l1_buf + l1_bucket_base(beg, b1);
+        const uint64_t cap = p2_region_cap(n_items, g.P2, L2Fmt<HB>::TILE);
         const uint64_t obase = p2_out_base(beg, b1, g.P2, L2Fmt<HB>::TILE) - p2_out_base(beg0, g.b_lo, g.P2, L2Fmt<HB>::TILE);   // the level-2 buffer holds this pass only
-        const uint64_t base1 = place_base1(b1, g.pl.n, g.pl.p1);
         lds_barrier();
         if (tid < g.P2) {
             const uint64_t start = obase + (uint64_t)tid * cap;                // items; the cursor counts groups
@@ -655,14 +735,14 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint64_t* __res
             L.lim[tid] = (start + cap) >> 2;
             off2[(uint64_t)b1 * g.P2 + tid] = start;
         }
-        for (uint64_t tbeg = beg; tbeg < end; tbeg += L2Fmt<HB>::TILE) {
+        for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
             const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
             uint64_t key[N];
-            const uint32_t valid = p2_tile_load<N>(l1_buf, tbeg, end, seg_slots != 0, key);
+            const uint32_t valid = p2_tile_load<N>(g.hb1, bucket, tbeg, n_items, key);
             if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
             lds_barrier();
             if (STAMP) { st[0] += (unsigned long long)clock64() - ta; st[5] += 1; }
-            scatter_tile2<HB, true, STAMP>(L, g, base1, key, valid, l2_buf, ovf_buf, ovf_n, ovf_cap, st);
+            scatter_tile2<HB, true, STAMP>(L, g, b1, key, valid, l2_buf, ovf_buf, ovf_n, ovf_cap, st);
         }
         lds_barrier();
         if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = (uint32_t)((L.cursor[tid] << 2) - (obase + (uint64_t)tid * cap));
@@ -743,7 +823,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
         const uint32_t rn = next_region(r + gridDim.x);
         // an item is the remainder of its k-mer's placement hash; the region supplies the digits (kg_device.hpp "placement"):
         // the home slot comes straight from the remainder, the k-mer (what the slots hold) through the inverse hash
-        const uint64_t base1 = place_base1(r >> g.l2, g.pl.n, g.pl.p1), d2_hi = g.pl.rb < 64 ? (uint64_t)(r & (g.P2 - 1)) << g.pl.rb : 0ULL;
+        const uint32_t rd1 = r >> g.l2, rd2 = r & (g.P2 - 1);
 
         for (uint64_t sbeg = beg; sbeg < end; sbeg += seg_len) {            // one segment, normally
             const uint64_t n_run = (end - sbeg < seg_len ? end - sbeg : seg_len);
@@ -868,7 +948,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                     const uint64_t rem = ((uint64_t)hi_of_group<HB>(c_hi, u) << 32) | (u == 0 ? c_lo.x : u == 1 ? c_lo.y : u == 2 ? c_lo.z : c_lo.w);
                     pend[u] = c_in && rem != L2Fmt<HB>::NONE;
                     slot[u] = place_offset(rem, g.pl, S);
-                    cur[u] = place_key(base1, d2_hi | rem, g.pl);
+                    cur[u] = place_key_d(rd1, rd2, rem, g.pl);
                     if (TEST_SPILL && spill_mod && pend[u] && __umulhi((uint32_t)(mix64(cur[u]) >> 32), spill_mod) == 0) { spill[atomicAdd(spill_n, 1ULL)] = cur[u]; pend[u] = false; }
                 }
                 const unsigned long long t_b = now();
@@ -1038,8 +1118,8 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
         for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(rk + i) = kq[u]; }
         const uint32_t rn = next_region(r + gridDim.x);
         // what spilling a k-mer (region full, test hook) needs: the region's digits give the k-mer back
-        const uint64_t base1 = place_base1(r >> g.l2, g.pl.n, g.pl.p1), d2_hi = g.pl.rb < 64 ? (uint64_t)(r & (g.P2 - 1)) << g.pl.rb : 0ULL;
-        auto spill_rem = [&](uint64_t rem) { spill[atomicAdd(spill_n, 1ULL)] = place_key(base1, d2_hi | rem, g.pl); };
+        const uint32_t rd1 = r >> g.l2, rd2 = r & (g.P2 - 1);
+        auto spill_rem = [&](uint64_t rem) { spill[atomicAdd(spill_n, 1ULL)] = place_key_d(rd1, rd2, rem, g.pl); };
 
         for (uint64_t sbeg = beg; sbeg < end; sbeg += seg_len) {            // one segment, normally
             const uint64_t n_run = (end - sbeg < seg_len ? end - sbeg : seg_len);
@@ -1149,7 +1229,7 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                     rem[u] = ((uint64_t)hi_of_group<HB>(c_hi, u) << 32) | (u == 0 ? c_lo.x : u == 1 ? c_lo.y : u == 2 ? c_lo.z : c_lo.w);
                     pend[u] = c_in && rem[u] != L2Fmt<HB>::NONE;
                     slot[u] = place_offset(rem[u], g.pl, S);
-                    if (TEST_SPILL && spill_mod && pend[u] && __umulhi((uint32_t)(mix64(place_key(base1, d2_hi | rem[u], g.pl)) >> 32), spill_mod) == 0) { spill_rem(rem[u]); pend[u] = false; }
+                    if (TEST_SPILL && spill_mod && pend[u] && __umulhi((uint32_t)(mix64(place_key_d(rd1, rd2, rem[u], g.pl)) >> 32), spill_mod) == 0) { spill_rem(rem[u]); pend[u] = false; }
                 }
                 // Probe rounds: U reads in flight, one wait; a match adds 1 and is done, a foreign k-mer moves on, a free slot is
                 // claimed (inline, or through the queue).  Lanes that are done take no part in the LDS operations.

@@ -63,14 +63,8 @@ int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevT
     if (e == hipSuccess) e = hipMalloc(&d.ovf_keys, OVF_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&d.ovf_hi, OVF_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&d.ctrs, CTR_WORDS * sizeof(uint64_t));
-    if (e == hipSuccess && d.cbits) {                          // what decoding a slot into its k-mer needs: the level-1 digits' bases
-        std::vector<uint64_t> b1((size_t)d.p1 + 1);
-        for (uint32_t i = 0; i <= d.p1; ++i) b1[i] = i == d.p1 ? 0 : place_base1(i, 2 * k, d.p1);
-        e = hipMalloc((void**)&d.base1, b1.size() * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMemcpy(const_cast<uint64_t*>(d.base1), b1.data(), b1.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
-    }
     if (e != hipSuccess) {
-        pool_release(c, d.keys); pool_release(c, d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs); hipFree(const_cast<uint64_t*>(d.base1));
+        pool_release(c, d.keys); pool_release(c, d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
         return fail(c, KATGPU_ERR_NOMEM, "device allocation of a %llu-slot table failed: %s", (unsigned long long)cap, hipGetErrorString(e));
     }
     HIPCHK(c, hipMemsetAsync(d.keys, d.cbits ? 0 : 0xFF, key_bytes, c->stream));
@@ -85,7 +79,7 @@ int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevT
 
 void free_dev_table(katgpu_ctx* c, DevTable& d) {
     pool_release(c, d.keys); pool_release(c, d.counts);
-    hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs); hipFree(const_cast<uint64_t*>(d.base1));
+    hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
     d = DevTable{};
 }
 

@@ -46,7 +46,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     (8192, 400000, 0, {"KATGPU_NO_PACKED": "1", "KATGPU_L1_FAST": "2"}),
     (512, 100000, 0, {"KATGPU_TEST_AP_SEG": "64"}), (2048, 250000, 0, {"KATGPU_TEST_AP_SEG": "1024", "KATGPU_P2_FAST": "2"}),
     (1024, 3000000, 0, {"KATGPU_TEST_AP_SEG": "256", "KATGPU_NO_PACKED": "1"}),
-    (256, 3000000, 0, {}), (256, 3000000, 5, {"KATGPU_APPLY_PER_CU": "1"})])
+    (256, 3000000, 0, {}), (256, 3000000, 5, {"KATGPU_APPLY_PER_CU": "1"}),
+    # l1_lean=0: level 1's ranking sweep and copy-out in their 64-bit form (the default is the 32-bit one of kg_l1_lean.hpp), both
+    # editions of level 1
+    (512, 100000, 0, {"KATGPU_L1_LEAN": "0"}), (1024, 3000000, 7, {"KATGPU_L1_LEAN": "0", "KATGPU_L1_FAST": "2"}),
+    (8192, 400000, 0, {"KATGPU_L1_LEAN": "0", "KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2"})])
 def test_partitioned_counter_matches_oracle(region_slots, round_items, spill_mod, extra):
     env = dict(os.environ, KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
                KATGPU_TEST_ROUND_ITEMS=str(round_items), KATGPU_TEST_SPILL_MOD=str(spill_mod))

@@ -8,27 +8,37 @@ import pytest
 from kat_amd.binding import place_keys
 
 M64 = (1 << 64) - 1
-C1, C2 = 0xff51afd7ed558ccd, 0xc4ceb9fe1a85ec53
+M32 = 0xFFFFFFFF
+G1, G2, G3 = 0x9E3779B1, 0x85EBCA6B, 0xC2B2AE35
+
+
+def mix(v, c):
+    """fold to 32 bits, xor-shift, one 32-bit multiply by an odd constant (place_mix)"""
+    lo, hi = v & M32, (v >> 32) & M32
+    x = lo ^ (((hi << 19) | (hi >> 13)) & M32)
+    x ^= x >> 15
+    return (x * c) & M32
 
 
 def model(key, k, p1, l2):
-    """exact integers: two multiply / xor-shift stages; digit 1 = floor(top32(y1) * p1 / 2^32), r1 = y1 - (first y1 of that digit)"""
+    """exact integers: key = H : L (L = the low n1 bits); d1 = (H + g1(L)) mod p1; L = H2 : L2 (L2 = the low rb bits);
+    d2 = H2 ^ g2(L2); rem = L2"""
     n = 2 * k
-    top32 = lambda y: (y >> (n - 32)) if n >= 32 else (y << (32 - n)) & 0xFFFFFFFF
-    def base1(d):
-        if d == 0:
-            return 0
-        tb = -((-(d << 32)) // p1)
-        return tb << (n - 32) if n >= 32 else -((-tb) // (1 << (32 - n)))
-    widest = max((((1 << n) if d + 1 == p1 else base1(d + 1)) - base1(d) - 1 for d in range(p1)), default=0)
-    n1 = max(widest, 0).bit_length()
-    rb = n1 - min(l2, n1)
-    y1 = ((key ^ (key >> ((n + 1) // 2))) * C1) & ((1 << n) - 1)
-    d1 = (top32(y1) * p1) >> 32
-    r1 = y1 - base1(d1)
-    assert 0 <= r1 < (1 << n1)
-    y2 = ((r1 ^ (r1 >> ((n1 + 1) // 2))) * C2) & ((1 << n1) - 1)
-    return d1, y2 >> rb, y2 & ((1 << rb) - 1), rb
+    hb1 = p1.bit_length() - 1
+    n1 = max(n - hb1, 0)
+    l2e = min(l2, n1)
+    rb = n1 - l2e
+    L, H = key & ((1 << n1) - 1), key >> n1
+    assert H < p1
+    d1 = (H + (((mix(L, G1) >> 10) * p1) >> 22)) % p1
+    L2, H2 = L & ((1 << rb) - 1), L >> rb
+    d2 = H2 ^ ((mix(L2, G2) >> (32 - l2e)) if l2e else 0)
+    return d1, d2, L2, rb
+
+
+def model_offset(rem, S):
+    h = mix(rem, G3)
+    return ((h >> 14) * S) >> 18 if S < (1 << 14) else (h * S) >> 32
 
 
 CASES = [(27, 584, 10), (27, 1024, 9), (31, 777, 10), (32, 1000, 10), (32, 1, 0), (16, 5, 3), (15, 37, 6), (7, 1, 0), (5, 3, 2),
@@ -68,7 +78,7 @@ def test_placement_spreads_canonical_kmers_evenly():
         key = (key << np.uint64(2)) | bases[i:G - k + 1 + i]
         rc |= (np.uint64(3) - bases[i:G - k + 1 + i]) << np.uint64(2 * i)
     can = np.minimum(key, rc)
-    d1, d2, rem, back, rb = place_keys(k, 584, 10, can)
+    d1, d2, rem, back, rb, off = place_keys(k, 584, 10, can, region_slots=8192)
     assert rb == 35 and (back == can).all()
     b = np.bincount(d1, minlength=584)
     mean = can.size / 584
@@ -76,7 +86,7 @@ def test_placement_spreads_canonical_kmers_evenly():
     sub = np.bincount(d2, minlength=1024)
     mean2 = can.size / 1024
     assert abs(sub - mean2).max() < 6 * mean2 ** 0.5
-    off = ((rem >> np.uint64(rb - 32)) * np.uint64(8192)) >> np.uint64(32)
+    assert all(int(off[i]) == model_offset(int(rem[i]), 8192) for i in range(0, can.size, 997))
     o = np.bincount(off.astype(np.int64), minlength=8192)
-    mo = can.size / 8192
+    mo = off.size / 8192
     assert 0.8 < o.var() / mo < 1.25
