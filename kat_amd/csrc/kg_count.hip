@@ -280,7 +280,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const size_t tile_starts = P1_TILE_STARTS;
 #define KG_FOR_HB(M) M(0) M(1) M(2) M(4)
     if (!c->part_attr_set) {
-#define KG_ATTR_HB(HB) KG_LDS_ATTR((k_p2<HB>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB>), sizeof(P2Lds<HB>));
+#define KG_ATTR_HB(HB) KG_LDS_ATTR((k_p2<HB, false>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, false>), sizeof(P2Lds<HB>)); \
+                       KG_LDS_ATTR((k_p2<HB, true>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, true>), sizeof(P2Lds<HB>));
         KG_FOR_HB(KG_ATTR_HB)
 #undef KG_ATTR_HB
         c->part_attr_set = true;
@@ -393,12 +394,18 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         uint64_t seg_cap = est_items / ((uint64_t)W * g.P1);
         seg_cap += seg_cap / 24 + SEG_PAD;
         if (g_test_l1_cpb) seg_cap = std::min<uint64_t>(seg_cap, g_test_l1_cpb);
+        const uint64_t cap_plain = seg_cap;                                         // k-mers a segment is expected to take at most (what the spill list must hold: 8 bytes each)
+        // groups (kg_partition.hpp: k_p1v2_scatter): a bucket's k-mers of a tile are padded to whole groups, 1.5 items per tile and bucket on average
+        if (g.hb1 != 4 && !g_test_l1_cpb) seg_cap += std::min<uint64_t>(3 * seg_cap, 2 * tiles_per_wg);
         seg_cap = (seg_cap + 3) & ~3ULL;                                            // whole groups
-        const bool seg = l1_fast_ok && (g_l1_fast == 2 || (ratio_known && est_items >= ((uint64_t)64 << 20))) && (uint64_t)W * g.P1 * seg_cap + 4 * (uint64_t)g.P1 <= l1_items &&
-                         seg_cap < (1u << 24) && 8 * (uint64_t)W * seg_cap + 32 <= 0xFFFFFFFFULL /* the kernel's segment arithmetic: 24 x 8 and 32 x 32 -> 64 bits */;
+        const uint64_t stride64 = std::max<uint64_t>(8 * (uint64_t)W * cap_plain, (uint64_t)(4 + g.hb1) * W * seg_cap) + 32;   // bytes of a bucket (l1_bucket_base's + 32)
+        const bool seg = l1_fast_ok && (g_l1_fast == 2 || (ratio_known && est_items >= ((uint64_t)64 << 20))) && stride64 * g.P1 <= (uint64_t)l1_items * 8 &&
+                         seg_cap < (1u << 24) && stride64 <= 0xFFFFFFFFULL /* the kernel's segment arithmetic: 24 x 8 and 32 x 32 -> 64 bits */;
         const uint64_t seg_slots = seg ? (uint64_t)W * seg_cap : 0;                // items of one bucket
-        const uint32_t bucket_stride = (uint32_t)(8 * seg_slots + 32);             // bytes (l1_bucket_base)
+        const uint32_t bucket_stride = (uint32_t)stride64;
+        g.l1_stride = seg ? stride64 : 0;
         const bool lean = g_l1_lean && lean_applies(k, g.pl.n1);
+        const bool pb512 = g.P1 <= 512;
         uint64_t items = 0;
         unsigned long long ovf_l1 = 0;
         HIPCHK(c, hipMemsetAsync(spill_n, 0, 2 * sizeof(unsigned long long), c->stream));          // spill_n, ovf_n
@@ -406,12 +413,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             items = est_items;                                                    // the exact number is not needed (and not known)
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
-                if (lean)
-                    hipLaunchKernelGGL((k_p1v2_scatter<true, true>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)nullptr, (const uint64_t*)nullptr, l1_buf,
-                                       (uint32_t)seg_cap, bucket_stride, ovf_buf, ovf_n, ovf_cap);
-                else
-                    hipLaunchKernelGGL((k_p1v2_scatter<true, false>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)nullptr, (const uint64_t*)nullptr, l1_buf,
-                                       (uint32_t)seg_cap, bucket_stride, ovf_buf, ovf_n, ovf_cap);
+#define KG_L1S(LEAN, PB) hipLaunchKernelGGL((k_p1v2_scatter<true, LEAN, PB>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, \
+                                               (const uint64_t*)nullptr, (const uint64_t*)nullptr, l1_buf, (uint32_t)seg_cap, bucket_stride, ovf_buf, ovf_n, ovf_cap)
+                if (lean) { if (pb512) KG_L1S(true, 512); else KG_L1S(true, MAX_PARTS); }
+                else { if (pb512) KG_L1S(false, 512); else KG_L1S(false, MAX_PARTS); }
+#undef KG_L1S
             }
             HIPCHK(c, hipMemcpyAsync(&ovf_l1, ovf_n, sizeof ovf_l1, hipMemcpyDeviceToHost, c->stream));      // read at the next synchronisation
             if (g_trace) fprintf(stderr, "[katgpu] partition round (segmented level 1): %zu starts, ~%llu items, %llu k-mers per segment (arena %.1f GB)\n", m, (unsigned long long)items, (unsigned long long)seg_cap, c->arena_bytes / 1e9);
@@ -473,7 +479,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             for (uint32_t b_lo = 0; b_lo < g.P1 && !redo_round; b_lo += step) {
                 g.b_lo = b_lo; g.b_hi = std::min(g.P1, b_lo + step);
                 const uint64_t pass_items = std::max<uint64_t>(1, (uint64_t)((double)items * (g.b_hi - g.b_lo) / g.P1));
-                uint64_t* spill_buf = (uint64_t*)(l1_buf + l1_bucket_base(lbeg(b_lo), b_lo));   // this pass's part of the level-1 buffer (8 bytes per item): dead once its level 2 is through
+                // this pass's part of the level-1 buffer, dead once its level 2 is through: the pass's spill list (room for 8 bytes per k-mer)
+                auto l1_at = [&](uint32_t b) -> uint64_t { return seg ? (uint64_t)b * g.l1_stride : l1_bucket_base(lbeg(b), b); };
+                uint64_t* spill_buf = (uint64_t*)(l1_buf + l1_at(b_lo));
+                g.spill_cap = (l1_at(g.b_hi) - l1_at(b_lo)) / 8;
                 const uint32_t* run_len = nullptr;
                 unsigned long long overflowed = ovf_total;
                 const bool try_fast = try_fast0 && p2_fast_ok;
@@ -481,7 +490,9 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
                 if (try_fast) {
                     ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
-#define KG_P2F(HB) case HB: hipLaunchKernelGGL(k_p2_fast<HB>, dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+#define KG_P2F(HB) case HB: if (g.hb1 == 4) hipLaunchKernelGGL((k_p2_fast<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+                                               off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); \
+                            else hipLaunchKernelGGL((k_p2_fast<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); break;
                     switch (g.hb) { KG_FOR_HB(KG_P2F) }
 #undef KG_P2F
@@ -506,8 +517,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 }
                 if (!run_len) {
                     ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
-#define KG_P2(HB) case HB: hipLaunchKernelGGL(k_p2<HB>, dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
-                                              off2, seg_slots, bend); break;
+#define KG_P2(HB) case HB: if (g.hb1 == 4) hipLaunchKernelGGL((k_p2<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, off2, seg_slots, bend); \
+                           else hipLaunchKernelGGL((k_p2<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, off2, seg_slots, bend); break;
                     switch (g.hb) { KG_FOR_HB(KG_P2) }
 #undef KG_P2
                 }
@@ -522,6 +533,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 unsigned long long spilled = 0;
                 HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (spilled > g.spill_cap)       // (more k-mers without a slot than the pass's segments were sized for: a table far too small, met by a 5-sigma round)
+                    return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full: %llu k-mers of a partition pass found no slot (the list holds %llu); raise the size hint", spilled, (unsigned long long)g.spill_cap);
                 if (spilled) lists.push_back({spill_buf, spilled});
             }
             if (redo_round) continue;

@@ -174,6 +174,12 @@ __device__ __host__ __forceinline__ Placed place_hash(uint64_t key, const Place&
     r.rem = key & p.mr;
     return r;
 }
+// the k-mer of a level-1 item: its low n1 bits r1 and its level-1 digit
+__device__ __host__ __forceinline__ uint64_t place_key_r1(uint32_t d1, uint64_t r1, const Place& p) {
+    uint32_t H = d1 + p.p1 - place_g1((uint32_t)r1, (uint32_t)(r1 >> 32), p);
+    H = H >= p.p1 ? H - p.p1 : H;
+    return (p.n1 < 64 ? (uint64_t)H << p.n1 : 0ULL) | r1;
+}
 // the inverse: the k-mer of remainder `rem` in region (d1, d2) (the digits are the caller's: uniform over a region)
 __device__ __host__ __forceinline__ uint64_t place_key_d(uint32_t d1, uint32_t d2, uint64_t rem, const Place& p) {
     const uint32_t H2 = d2 ^ place_g2((uint32_t)rem, (uint32_t)(rem >> 32), p);

@@ -38,6 +38,11 @@ constexpr int L1_LANES_WITH_STARTS = L1_TILE_STARTS / PART_ITEMS;   // 1022
 // stall the whole workgroup until those stores are acknowledged by L2.  Nothing in these kernels hands global data from
 // one lane to another inside a launch, so only LDS traffic has to be complete here.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// a k-mer that found no room in its region -> the pass's spill list
+__device__ __forceinline__ void spill_put(uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, uint64_t cap, uint64_t key) {
+    const unsigned long long at = atomicAdd(spill_n, 1ULL);
+    if (at < cap) spill[at] = key;
+}
 
 struct PartGeom {
     uint32_t R, S;     // regions, slots per region (the table's)
@@ -47,6 +52,8 @@ struct PartGeom {
     uint32_t l2;       // P2 == 1 << l2
     uint32_t hb;       // bytes of a level-2 item beyond its low 32 bits: 0, 1, 2 or 4 (from pl.rb; "the level-2 buffer" below)
     uint32_t hb1;      // ... of a level-1 item (from pl.n1; "the level-1 buffer" below)
+    uint64_t l1_stride;// segmented level 1: bytes from one bucket's first group to the next's in the level-1 buffer; 0: the exact layout
+    uint64_t spill_cap;// k-mers the apply's spill list holds (this pass's part of the level-1 buffer); what is beyond is counted, not written: the host fails the call
     uint32_t cbits;    // the table's (kg_device.hpp: packed slots); 0: KV12
     Place pl;          // the placement hash's bit budget for this table (kg_device.hpp)
 };
@@ -210,30 +217,40 @@ constexpr int P1_LANES_WITH_STARTS = P1_TILE_STARTS / PART_ITEMS; // 510
 // its level 2 is through, is the spill list of that pass's apply -- 8-byte k-mers, as many as there were items in the worst case.
 // The all-ones item is "no item" (segment padding): n1 < 8 (4 + HB1) wherever this path runs (part_geometry).
 __device__ __host__ __forceinline__ uint64_t l1_bucket_base(uint64_t first_item, uint32_t b) { return 8 * first_item + 32ULL * b; }   // (+ 32 b: a bucket's last group may hold up to three items more than the bucket)
-__device__ __forceinline__ void l1_put(uint8_t* __restrict__ bucket, uint64_t group_byte, uint32_t q, uint32_t hb1, uint32_t lo, uint32_t hi) {
+template <uint32_t HB1>
+__device__ __forceinline__ void l1_put(uint8_t* __restrict__ bucket, uint64_t group_byte, uint32_t q, uint32_t lo, uint32_t hi) {
     uint8_t* grp = bucket + group_byte;
     reinterpret_cast<uint32_t*>(grp)[q] = lo;
-    if (hb1 == 1) grp[16 + q] = (uint8_t)hi;
-    else if (hb1 == 2) reinterpret_cast<uint16_t*>(grp + 16)[q] = (uint16_t)hi;
-    else if (hb1 == 4) reinterpret_cast<uint32_t*>(grp + 16)[q] = hi;
+    if (HB1 == 1) grp[16 + q] = (uint8_t)hi;
+    else if (HB1 == 2) reinterpret_cast<uint16_t*>(grp + 16)[q] = (uint16_t)hi;
+    else if (HB1 == 4) reinterpret_cast<uint32_t*>(grp + 16)[q] = hi;
+}
+__device__ __forceinline__ void l1_put_any(uint8_t* __restrict__ bucket, uint64_t group_byte, uint32_t q, uint32_t hb1, uint32_t lo, uint32_t hi) {
+    if (hb1 == 0) l1_put<0>(bucket, group_byte, q, lo, hi);
+    else if (hb1 == 1) l1_put<1>(bucket, group_byte, q, lo, hi);
+    else if (hb1 == 2) l1_put<2>(bucket, group_byte, q, lo, hi);
+    else l1_put<4>(bucket, group_byte, q, lo, hi);
 }
 
 // LEAN (k_p1v2_scatter<SEG, true>): the tile's reverse-complement stream is staged next to the codes (rcode), so that the copy-out reads
 // the k-mer of the strand the ranking sweep chose instead of recomputing the canonical form; the segmented edition's cursors count
 // inside a segment and fit 32 bits, which pays for rcode (three workgroups per CU: 3 x 1280-byte granules to spare).
-template <bool LEAN = false, bool SEG = false>
+// PB: bucket capacity of the per-bucket arrays (512 when the table has at most 512 level-1 digits -- the bench's tables --, else
+// MAX_PARTS): with 512 the segmented editions stay at three workgroups per CU although their staged runs are padded to whole groups.
+template <bool LEAN = false, bool SEG = false, int PB = MAX_PARTS>
 struct P1LdsT {
     typedef typename std::conditional<SEG, uint32_t, uint64_t>::type cursor_t;
-    cursor_t cursor[MAX_PARTS];         // next item of each bucket's run, counted from the bucket's first item (exact edition) / inside the segment (segmented)
-    uint32_t hist[MAX_PARTS];
-    uint32_t off[MAX_PARTS];
+    cursor_t cursor[PB];                // next item of each bucket's run, counted from the bucket's first item (exact edition) / inside the segment (segmented)
+    uint32_t hist[PB + (LEAN ? 64 : 0)];   // (LEAN: + one dump counter per lane of a wave, for the windows that hold no k-mer)
+    uint32_t off[PB];
     uint32_t wave_tot[16];
     uint32_t code[P1_BLOCK + 2];
     uint32_t bad[P1_BLOCK + 2];
     uint32_t rcode[LEAN ? P1_BLOCK + 2 : 1];   // LEAN: word v = reverse complement of code word 511 - v (the tile read backwards on the other strand)
-    uint32_t pos[P1_TILE_BYTES];        // per staged k-mer: bucket << 16 | strand << 15 (LEAN) | tile position  (50 KB in all: three workgroups per CU)
+    uint32_t pad_[2];                   // (pos starts on a 16-byte boundary: the grouped copy-out reads it four entries at a time)
+    uint32_t pos[P1_TILE_BYTES + (SEG ? 3 * PB : 0)];   // per staged k-mer: bucket << 16 | strand << 15 (LEAN) | tile position; SEG: a bucket's run padded to whole groups of four
 };
-typedef P1LdsT<false, false> P1Lds;
+constexpr uint32_t P1_PAD = 0xFFFFFFFFu;   // "no k-mer" in pos[] (the bucket field of an entry is at most 1023)
 
 struct LaneWindow {                       // the 96-bit sliding window of kg_kernels.hpp's K1, as an object
     uint64_t hi, lo, m;
@@ -304,8 +321,8 @@ __device__ __forceinline__ void p1_tile_load(const uint8_t* __restrict__ bases, 
     }
 }
 
-template <bool LEAN, bool SEG>
-__device__ __forceinline__ void p1_tile_stage(P1LdsT<LEAN, SEG>& L, const uint32_t (&w)[4]) {
+template <bool LEAN, bool SEG, int PB>
+__device__ __forceinline__ void p1_tile_stage(P1LdsT<LEAN, SEG, PB>& L, const uint32_t (&w)[4]) {
     const uint32_t tid = threadIdx.x;
     uint32_t code, bad;
     encode16(w, code, bad);
@@ -384,17 +401,24 @@ k_p1v2_count(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t
 // the second decode + hash of the whole input (k_p1v2_count: 70 ms of the bench step) for ~4 % more level-1 bytes.
 // LEAN: the ranking sweep on 32-bit halves and a copy-out that reads the chosen strand's k-mer off the staged stream of that strand
 // (kg_l1_lean.hpp; host-checked arithmetic).
-template <bool SEG, bool LEAN = false>
-__global__ void __launch_bounds__(P1_BLOCK, 6)                // six waves per SIMD = three workgroups per CU (g_p1_wgs): at most 80 VGPRs
+// The segmented edition writes WHOLE GROUPS (HB1 <= 2): a bucket's k-mers of a tile are padded to a multiple of four in LDS ("no item")
+// and leave as groups, one lane per group and two stores per four k-mers -- 16 bytes of low words + 4 HB1 of high parts -- where
+// item-by-item stores (a dword and a short per k-mer, 16-byte pieces 24 bytes apart) measured 178 ms for the bench's level 1
+// against 157 with one 8-byte store per k-mer: the kernel is bound by how many write requests reach the memory system, not by bytes
+// or instructions.  The padding (1.5 items per tile and bucket, 11 % at the bench's 13 k-mers per tile and bucket) is room the 8
+// bytes per item of the buffer have.  HB1 = 4 (8-byte items: n1 > 48) keeps one item per lane: there a padded group would not fit.
+template <bool SEG, bool LEAN = false, int PB = MAX_PARTS>
+__global__ void __launch_bounds__(P1_BLOCK, SEG && PB == 512 ? 6 : 4)   // six waves per SIMD = three workgroups per CU (g_p1_wgs): at most 80 VGPRs; the other shapes' LDS holds two workgroups
 k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
-               const uint64_t* __restrict__ offs, const uint64_t* __restrict__ l1_off, uint8_t* __restrict__ l1_buf, uint32_t seg_cap /* SEG: < 2^24 */,
+               const uint64_t* __restrict__ offs, const uint64_t* __restrict__ l1_off, uint8_t* __restrict__ l1_buf, uint32_t seg_cap /* SEG: < 2^24, a multiple of 4 */,
                uint32_t bucket_stride /* SEG: bytes from one bucket's first group to the next's, < 2^32 */,
                uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
-    __shared__ __attribute__((aligned(16))) P1LdsT<LEAN, SEG> L;
-    typedef typename P1LdsT<LEAN, SEG>::cursor_t cursor_t;
-    const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;
+    __shared__ __attribute__((aligned(16))) P1LdsT<LEAN, SEG, PB> L;
+    typedef typename P1LdsT<LEAN, SEG, PB>::cursor_t cursor_t;
+    const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;           // P <= PB (host-checked)
     const bool canonical = t.canonical != 0;
     const uint32_t hb1 = g.hb1, gs1 = 16 + 4 * hb1;
+    const bool grouped = SEG && hb1 != 4;                          // runs staged and written as whole groups
     uint32_t ones = 0;
     // SEG: this workgroup's segment of bucket b starts seg_off bytes into the bucket (whole groups)
     const uint64_t seg_off = SEG ? (uint64_t)blockIdx.x * (seg_cap >> 2) * gs1 : 0;
@@ -404,30 +428,39 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
     for (uint64_t tile = t0; tile < t1; ++tile) {
         uint32_t w[4];
         p1_tile_fix(bases, n, tile * P1_TILE_STARTS, raw, w);
-        raw = p1_tile_issue(bases, n, (tile + 1 < t1 ? tile + 1 : tile) * P1_TILE_STARTS);    // the next tile: in flight behind this one
         lds_barrier();                                   // previous tile's copy-out / cursor update done
-        for (uint32_t b = tid; b < MAX_PARTS; b += P1_BLOCK) L.hist[b] = 0;
+        for (uint32_t b = tid; b < PB; b += P1_BLOCK) L.hist[b] = 0;
         p1_tile_stage(L, w);                               // ends with a barrier
         // sweep 1: bucket and rank of every valid window of this lane
         uint32_t br[PART_ITEMS];
         uint32_t valid = 0;
         if (LEAN && tid < P1_LANES_WITH_STARTS) {
+            // Straight-line: every window is worked whatever its flags say (a lane-divergent branch saves nothing), a window that
+            // holds a flagged base ranks in one of 64 dump counters (hist[MAX_PARTS + lane]) instead of a bucket, and a rank is
+            // looked at two windows after its atomic was issued: up to three LDS round trips in flight per lane where a branch per
+            // window waited for each (sixteen serialised round trips per lane and tile).
             const LeanGeom lg = lean_geom(k, canonical, g.pl.n1);
             const uint32_t v16 = lean_valid16(L.bad[tid], L.bad[tid + 1], L.bad[tid + 2], k);
             LeanWin w{L.code[tid], L.code[tid + 1], L.code[tid + 2], 0, 0};
             uint32_t f_hi, f_lo;
             lean_fwd(w, lg, f_hi, f_lo);
             { const uint64_t rc0 = kmer_revcomp(((uint64_t)f_hi << 32) | f_lo, k); w.rc_hi = (uint32_t)(rc0 >> 32); w.rc_lo = (uint32_t)rc0; }
+            valid = v16;                                                     // bit 15 - j: window j (k <= 31: no k-mer is the all-ones word)
+            const uint32_t dump = PB + (tid & 63);
+            uint32_t rk[PART_ITEMS];
 #pragma unroll
             for (int j = 0; j < PART_ITEMS; ++j) {
                 if (j) { lean_step(w); lean_fwd(w, lg, f_hi, f_lo); lean_rc_roll(w, lg, f_lo); }
                 uint32_t key_hi, key_lo;
                 bool took_rc;                                                // the reverse complement is the canonical form
                 const uint32_t b = lean_digit1(w, lg, g.pl, f_hi, f_lo, key_hi, key_lo, took_rc);
-                const uint32_t strand = took_rc ? 0x8000u : 0u;
-                br[j] = 0;                                                   // (k <= 31: no k-mer is the all-ones word)
-                if (v16 & (0x8000u >> j)) { br[j] = (b << 16) | strand | atomicAdd(&L.hist[b], 1u); valid |= 1u << j; }
+                const bool ok = (v16 & (0x8000u >> j)) != 0;
+                rk[j] = atomicAdd(&L.hist[ok ? b : dump], 1u);
+                br[j] = (b << 16) | (took_rc ? 0x8000u : 0u);
+                if (j >= 2) br[j - 2] |= rk[j - 2];
             }
+#pragma unroll
+            for (int j = PART_ITEMS - 2; j < PART_ITEMS; ++j) br[j] |= rk[j];
         }
         if (!LEAN && tid < P1_LANES_WITH_STARTS) {
             LaneWindow lw;
@@ -449,46 +482,138 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                 valid |= 1u << j;
             }
         }
+        raw = p1_tile_issue(bases, n, (tile + 1 < t1 ? tile + 1 : tile) * P1_TILE_STARTS);    // the next tile: in flight behind the rest of this one (issued here, not before the sweep: four registers the sweep needs)
         lds_barrier();
         uint32_t e0, e1;
-        p1_scan_pair(tid < P ? L.hist[tid] : 0, tid + P1_BLOCK < P ? L.hist[tid + P1_BLOCK] : 0, L.wave_tot, e0, e1);
-        L.off[tid] = e0;
-        L.off[tid + P1_BLOCK] = e1;
+        {
+            const uint32_t h0 = tid < P ? L.hist[tid] : 0, h1 = PB > P1_BLOCK && tid + P1_BLOCK < P ? L.hist[tid + P1_BLOCK] : 0;
+            p1_scan_pair(grouped ? (h0 + 3) >> 2 : h0, grouped ? (h1 + 3) >> 2 : h1, L.wave_tot, e0, e1);     // grouped: off[] counts groups
+            L.off[tid] = e0;
+            if (PB > P1_BLOCK) L.off[tid + P1_BLOCK] = e1;
+            if (grouped) {                                   // what a run leaves of its last group is "no k-mer"
+                for (uint32_t q = h0; q & 3; ++q) L.pos[4 * e0 + q] = P1_PAD;
+                if (PB > P1_BLOCK) for (uint32_t q = h1; q & 3; ++q) L.pos[4 * e1 + q] = P1_PAD;
+            }
+        }
         lds_barrier();
         // sweep 2: park the tile position of every k-mer in its bucket's run
 #pragma unroll
         for (int j = 0; j < PART_ITEMS; ++j)
-            if (valid >> j & 1) L.pos[L.off[br[j] >> 16] + (br[j] & (LEAN ? 0x7FFFu : 0xFFFFu))] = (br[j] & (LEAN ? 0xFFFF8000u : 0xFFFF0000u)) | (tid * PART_ITEMS + j);
-        lds_barrier();
-        // copy-out, one staged k-mer per lane and step: its bucket travels with its position, so no lane idles on a short run
-        // and the steps are independent of each other (a loop over buckets serialised ~24 LDS round trips per lane group and
-        // was 57 % of this kernel: cycle stamps; same-box A/B 228 -> 216 ms).  Neighbouring lanes still write neighbouring items
-        // inside a run.
-        const uint32_t total = L.off[P - 1] + L.hist[P - 1];
-        for (uint32_t idx = tid; idx < total; idx += P1_BLOCK) {
-            const uint32_t v = L.pos[idx], b = v >> 16;
-            uint64_t key1;
-            if (LEAN) {                                                    // the chosen strand's k-mer, read off that strand's stream
-                const uint32_t p = v & 0x7FFFu, rc = v & 0x8000u;
-                key1 = lean_kmer_at(rc ? L.rcode : L.code, rc ? P1_TILE_BYTES - k - p : p, k);
-            } else key1 = kmer_at(L.code, v & 0xFFFF, k, canonical);
-            const uint64_t r1 = key1 & g.pl.m1;
-            const uint32_t ahead = idx - L.off[b];
-            if (SEG) {
-                const uint32_t rel = (uint32_t)L.cursor[b] + ahead;         // item of the segment (32-bit: seg_cap < 2^24, a tile adds < 2^13)
-                if (rel < seg_cap) l1_put(l1_buf + ((uint64_t)b * bucket_stride + seg_off), __umul24(rel >> 2, gs1), rel & 3, hb1, (uint32_t)r1, (uint32_t)(r1 >> 32));
-                else {                                                       // the segment is full: the overflow list
-                    const unsigned long long at = atomicAdd(ovf_n, 1ULL);
-                    if (at < ovf_cap) ovf_buf[at] = key1;
-                }
-            } else {
-                const uint64_t i = (uint64_t)L.cursor[b] + ahead;           // item of the bucket
-                l1_put(l1_buf + l1_bucket_base(l1_off[b], b), (i >> 2) * gs1, (uint32_t)i & 3, hb1, (uint32_t)r1, (uint32_t)(r1 >> 32));
+            if (valid >> (LEAN ? 15 - j : j) & 1) {
+                const uint32_t run0 = L.off[br[j] >> 16];
+                L.pos[(grouped ? 4 * run0 : run0) + (br[j] & (LEAN ? 0x7FFFu : 0xFFFFu))] = (br[j] & (LEAN ? 0xFFFF8000u : 0xFFFF0000u)) | (tid * PART_ITEMS + j);
             }
+        lds_barrier();
+        // the k-mer of a staged entry (the chosen strand's, read off that strand's stream) from three code words
+        auto entry_src = [&](uint32_t v, const uint32_t*& src, uint32_t& wd, uint32_t& o) {
+            uint32_t p = v & (LEAN ? 0x7FFFu : 0xFFFFu);
+            src = L.code;
+            if (LEAN && (v & 0x8000u)) { p = P1_TILE_BYTES - k - p; src = L.rcode; }   // the other strand's stream, read backwards
+            wd = p >> 4; o = p & 15;
+        };
+        auto entry_key = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t o) -> uint64_t {
+            // the 64 bits that start 2 o bits into c0 : c1 : c2 (v_alignbit_b32 shifts right by its amount mod 32)
+            const uint32_t sh = (32 - 2 * o) & 31;
+            const uint32_t h1 = o ? __builtin_amdgcn_alignbit(c0, c1, sh) : c0, h0 = o ? __builtin_amdgcn_alignbit(c1, c2, sh) : c1;
+            uint64_t key1 = (((uint64_t)h1 << 32) | h0) >> (64 - 2 * k);
+            if (!LEAN) key1 = canon_if(key1, k, canonical);
+            return key1;
+        };
+        const uint32_t lastb = P - 1;
+        const uint32_t total = L.off[lastb] + (grouped ? (L.hist[lastb] + 3) >> 2 : L.hist[lastb]);      // groups (grouped) / k-mers
+        // copy-out, grouped: one staged group per lane and step
+        auto copy_out_groups = [&](auto hb1_tag) {
+            constexpr int HB1 = decltype(hb1_tag)::value;
+            const uint32_t seg_groups = seg_cap >> 2;
+            for (uint32_t gi = tid; gi < total; gi += P1_BLOCK) {
+                const u32x4 e = *reinterpret_cast<const u32x4*>(&L.pos[4 * gi]);
+                const uint32_t ev[4] = {e.x, e.y, e.z, e.w};
+                const uint32_t b = e.x >> 16;                      // (a group's first entry is a k-mer)
+                uint32_t c0[4], c1[4], c2[4], o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t* src; uint32_t wd;
+                    entry_src(ev[q] == P1_PAD ? 0u : ev[q], src, wd, o[q]);
+                    c0[q] = src[wd]; c1[q] = src[wd + 1]; c2[q] = src[wd + 2];
+                }
+                const uint32_t grel = ((uint32_t)L.cursor[b] >> 2) + (gi - L.off[b]);     // group of the segment
+                uint32_t lo[4], hi[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t r1 = entry_key(c0[q], c1[q], c2[q], o[q]) & g.pl.m1;
+                    const bool pad = ev[q] == P1_PAD;
+                    lo[q] = pad ? 0xFFFFFFFFu : (uint32_t)r1;
+                    hi[q] = pad ? 0xFFFFFFFFu : (uint32_t)(r1 >> 32);
+                }
+                if (grel < seg_groups) {
+                    const u32x4 glo = {lo[0], lo[1], lo[2], lo[3]};
+                    typename HiGroup<HB1>::type ghi{};
+                    if constexpr (HB1 == 1) ghi = (hi[0] & 0xFFu) | ((hi[1] & 0xFFu) << 8) | ((hi[2] & 0xFFu) << 16) | (hi[3] << 24);
+                    if constexpr (HB1 == 2) { ghi.x = (hi[0] & 0xFFFFu) | (hi[1] << 16); ghi.y = (hi[2] & 0xFFFFu) | (hi[3] << 16); }
+                    uint8_t* segp = l1_buf + ((uint64_t)b * bucket_stride + seg_off);
+                    l2_store_group<HB1>(segp, grel, glo, ghi);
+                } else {                                             // the segment is full: the overflow list
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (ev[q] != P1_PAD) {                        // (the k-mer back from the item and the bucket)
+                            const unsigned long long at = atomicAdd(ovf_n, 1ULL);
+                            if (at < ovf_cap) ovf_buf[at] = place_key_r1(b, ((uint64_t)hi[q] << 32) | lo[q], g.pl);
+                        }
+                }
+            }
+        };
+        // copy-out, one staged k-mer per lane and step (the exact edition; 8-byte items): its bucket travels with its position, so
+        // no lane idles on a short run and the steps are independent of each other (a loop over buckets serialised ~24 LDS round
+        // trips per lane group and was 57 % of this kernel: cycle stamps; same-box A/B 228 -> 216 ms).  Neighbouring lanes still
+        // write neighbouring items inside a run.  Four steps at a time: the three dependent LDS round trips of a step (position;
+        // code words; cursor and run start) overlap with those of the other three.
+        auto copy_out = [&](auto hb1_tag) {
+            constexpr uint32_t HB1 = decltype(hb1_tag)::value, GS1 = 16 + 4 * HB1;
+            constexpr int CU = 4;
+            for (uint32_t idx0 = tid; idx0 < total; idx0 += CU * P1_BLOCK) {
+                uint32_t v[CU], c0[CU], c1[CU], c2[CU], o[CU], run0[CU];
+                cursor_t cur[CU];
+#pragma unroll
+                for (int u = 0; u < CU; ++u) { const uint32_t i = idx0 + u * P1_BLOCK; v[u] = L.pos[i < total ? i : idx0]; }
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const uint32_t* src; uint32_t wd;
+                    entry_src(v[u], src, wd, o[u]);
+                    c0[u] = src[wd]; c1[u] = src[wd + 1]; c2[u] = src[wd + 2];
+                    const uint32_t b = v[u] >> 16;
+                    cur[u] = L.cursor[b]; run0[u] = L.off[b];
+                }
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const uint32_t idx = idx0 + u * P1_BLOCK;
+                    if (idx >= total) break;
+                    const uint32_t b = v[u] >> 16;
+                    const uint64_t key1 = entry_key(c0[u], c1[u], c2[u], o[u]);
+                    const uint64_t r1 = key1 & g.pl.m1;
+                    const uint32_t ahead = idx - run0[u];
+                    if (SEG) {
+                        const uint32_t rel = (uint32_t)cur[u] + ahead;      // item of the segment (32-bit: seg_cap < 2^24, a tile adds < 2^13)
+                        if (rel < seg_cap) l1_put<HB1>(l1_buf + ((uint64_t)b * bucket_stride + seg_off), __umul24(rel >> 2, GS1), rel & 3, (uint32_t)r1, (uint32_t)(r1 >> 32));
+                        else {                                               // the segment is full: the overflow list
+                            const unsigned long long at = atomicAdd(ovf_n, 1ULL);
+                            if (at < ovf_cap) ovf_buf[at] = key1;
+                        }
+                    } else {
+                        const uint64_t i = (uint64_t)cur[u] + ahead;        // item of the bucket
+                        l1_put<HB1>(l1_buf + l1_bucket_base(l1_off[b], b), (i >> 2) * GS1, (uint32_t)i & 3, (uint32_t)r1, (uint32_t)(r1 >> 32));
+                    }
+                }
+            }
+        };
+        switch (hb1) {                                                     // (wave-uniform; decided outside the loops)
+        case 0: if (SEG) copy_out_groups(std::integral_constant<int, 0>{}); else copy_out(std::integral_constant<uint32_t, 0>{}); break;
+        case 1: if (SEG) copy_out_groups(std::integral_constant<int, 1>{}); else copy_out(std::integral_constant<uint32_t, 1>{}); break;
+        case 2: if (SEG) copy_out_groups(std::integral_constant<int, 2>{}); else copy_out(std::integral_constant<uint32_t, 2>{}); break;
+        default: copy_out(std::integral_constant<uint32_t, 4>{}); break;
         }
         lds_barrier();
         for (uint32_t b = tid; b < P; b += P1_BLOCK) {
-            uint64_t c = (uint64_t)L.cursor[b] + L.hist[b];
+            uint64_t c = (uint64_t)L.cursor[b] + (grouped ? (L.hist[b] + 3) & ~3u : L.hist[b]);
             if (SEG) c = c < seg_cap ? c : seg_cap;
             L.cursor[b] = (cursor_t)c;
         }
@@ -499,18 +624,20 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         const uint32_t grp = tid >> 4, l16 = tid & 15;
         for (uint32_t b = grp; b < P; b += P1_BLOCK / 16) {
             uint8_t* base = l1_buf + ((uint64_t)b * bucket_stride + seg_off);
-            for (uint32_t i = (uint32_t)L.cursor[b] + l16; i < seg_cap; i += 16) l1_put(base, __umul24(i >> 2, gs1), i & 3, hb1, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            for (uint32_t i = (uint32_t)L.cursor[b] + l16; i < seg_cap; i += 16) l1_put_any(base, __umul24(i >> 2, gs1), i & 3, hb1, 0xFFFFFFFFu, 0xFFFFFFFFu);
         }
         for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
         if ((tid & 63) == 0 && ones) atomicAdd((unsigned long long*)&t.ctrs[CTR_ONES], (unsigned long long)ones);
     }
 }
 
-// bucket b1 of the level-1 buffer: its number of items (segment padding included) and where its groups lie.  Exact layout (l1_off)
-// or segmented (seg_slots = workgroups x seg_cap items per bucket, "no item"-padded).
-__device__ __forceinline__ void l1_bucket_range(const uint64_t* __restrict__ l1_off, uint64_t seg_slots, uint32_t b1, uint64_t& first, uint64_t& n_items) {
-    if (seg_slots) { first = (uint64_t)b1 * seg_slots; n_items = seg_slots; }
-    else { first = l1_off[b1]; n_items = l1_off[b1 + 1] - first; }
+// bucket b1 of the level-1 buffer: its first item and number of items (in items of the round; segment and group padding
+// included) and the byte its groups start at.  Exact layout (l1_off) or segmented (seg_slots = workgroups x seg_cap items per bucket,
+// "no item"-padded, buckets l1_stride bytes apart).
+__device__ __forceinline__ uint64_t l1_bucket_range(const PartGeom& g, const uint64_t* __restrict__ l1_off, uint64_t seg_slots, uint32_t b1, uint64_t& first, uint64_t& n_items) {
+    if (seg_slots) { first = (uint64_t)b1 * seg_slots; n_items = seg_slots; return (uint64_t)b1 * g.l1_stride; }
+    first = l1_off[b1]; n_items = l1_off[b1 + 1] - first;
+    return l1_bucket_base(first, b1);
 }
 
 // ---- level 2 ----
@@ -519,42 +646,96 @@ __device__ __forceinline__ void l1_bucket_range(const uint64_t* __restrict__ l1_
 // The N items of a lane for one tile (items [tbeg, tbeg + N * 1024), tbeg a multiple of 4) of a bucket of n_items items whose groups
 // start at `bucket`: lane t takes groups t, t + 1024, ... of the tile: N / 4 loads of 16 bytes + N / 4 of 4 HB1.  Bit j of the result
 // = item j is there (not past the end, not padding).
+// A tile's items in registers: the low words and the high parts, the latter two 16-bit halves to a register when an item has at most
+// 48 bits (W1 = false: HB1 <= 2; 24 registers for 16 items where 64-bit k-mers took 32), one register each otherwise.
+template <int N, bool W1>
+struct TileItems {
+    uint32_t lo[N];
+    uint32_t hi[W1 ? N : N / 2];
+    __device__ __forceinline__ uint64_t r1(int j) const {
+        const uint32_t h = W1 ? hi[j] : (hi[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        return ((uint64_t)h << 32) | lo[j];
+    }
+};
 template <int N, int HB1>
-__device__ __forceinline__ uint32_t p2_tile_load_hb(const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, uint64_t (&key)[N]) {
-    // unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch (the compiler pulled
-    // the padding test into the branch of each load: sixteen serialised round trips to HBM, 29 K of a tile's 54 K cycles)
+__device__ __forceinline__ uint32_t p2_tile_load_hb(const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, HB1 == 4>& it) {
+    // Unconditional loads (a load inside a branch is waited for at the end of the branch: the compiler once pulled a padding test
+    // into the branch of each load -- sixteen serialised round trips to HBM, 29 K of a tile's 54 K cycles), and not even a clamped
+    // index: what lies behind a bucket's last group is the next bucket, and behind the level-1 buffer the level-2 buffer (the arena
+    // carve, kg_count.hip), so a tile's N / 4 groups per lane are always mapped memory; what they hold is masked below.
     static_assert(N % 4 == 0, "whole groups");
-    constexpr uint64_t NONE1 = L2Fmt<HB1>::NONE;
-    const uint64_t n_grp = (n_items + 3) >> 2;
+    constexpr uint32_t HI_NONE = HB1 == 0 ? 0u : HB1 == 1 ? 0xFFu : HB1 == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+    // everything below the tile's first group is 32-bit: items counted from the tile's start
+    const uint64_t left = n_items - tbeg;                                      // (tbeg < n_items)
+    const uint32_t t_items = left < (uint64_t)N * PART_BLOCK ? (uint32_t)left : (uint32_t)N * PART_BLOCK;
+    const uint8_t* mine = bucket + (tbeg >> 2) * L2Fmt<HB1>::GS + threadIdx.x * L2Fmt<HB1>::GS;
     u32x4 lo[N / 4];
     typename HiGroup<HB1>::type hi[N / 4];
 #pragma unroll
     for (int u = 0; u < N / 4; ++u) {
-        const uint64_t gi = (tbeg >> 2) + (uint64_t)u * PART_BLOCK + threadIdx.x;
         hi[u] = typename HiGroup<HB1>::type{};
-        l2_load_group<HB1>(bucket, gi < n_grp ? gi : n_grp - 1, lo[u], hi[u]);
+        l2_load_group<HB1>(mine, (uint64_t)u * PART_BLOCK, lo[u], hi[u]);
     }
     uint32_t valid = 0;
 #pragma unroll
     for (int u = 0; u < N / 4; ++u) {
-        const uint64_t i0 = tbeg + 4 * ((uint64_t)u * PART_BLOCK + threadIdx.x);
+        const uint32_t i0 = 4 * ((uint32_t)u * PART_BLOCK + threadIdx.x);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint64_t v = ((uint64_t)hi_of_group<HB1>(hi[u], q) << 32) | (q == 0 ? lo[u].x : q == 1 ? lo[u].y : q == 2 ? lo[u].z : lo[u].w);
-            key[4 * u + q] = v;
-            valid |= (i0 + q < n_items && v != NONE1) ? 1u << (4 * u + q) : 0u;
+            const uint32_t l = q == 0 ? lo[u].x : q == 1 ? lo[u].y : q == 2 ? lo[u].z : lo[u].w, h = hi_of_group<HB1>(hi[u], q);
+            it.lo[4 * u + q] = l;
+            if (HB1 == 4) it.hi[4 * u + q] = h;
+            valid |= (i0 + q < t_items && !(l == 0xFFFFFFFFu && h == HI_NONE)) ? 1u << (4 * u + q) : 0u;
+        }
+        if (HB1 != 4) {                                                       // two high parts to a register
+            it.hi[2 * u] = hi_of_group<HB1>(hi[u], 0) | (hi_of_group<HB1>(hi[u], 1) << 16);
+            it.hi[2 * u + 1] = hi_of_group<HB1>(hi[u], 2) | (hi_of_group<HB1>(hi[u], 3) << 16);
         }
     }
     return valid;
 }
+// The narrow forms (HB1 = 0, 1, 2) in ONE code path -- a three-way switch over the templated loader left the compiler with three
+// sets of values to keep (18 spilled registers at the bench's shape): 16 + 8 bytes are loaded per group whatever HB1 is (what lies
+// behind a shorter group is the next group: mapped, ignored), and one v_perm_b32 per register puts the high parts where TileItems
+// wants them, its selector chosen by HB1 (wave-uniform).
 template <int N>
-__device__ __forceinline__ uint32_t p2_tile_load(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, uint64_t (&key)[N]) {
-    switch (hb1) {                                                             // (wave-uniform)
-    case 0: return p2_tile_load_hb<N, 0>(bucket, tbeg, n_items, key);
-    case 1: return p2_tile_load_hb<N, 1>(bucket, tbeg, n_items, key);
-    case 2: return p2_tile_load_hb<N, 2>(bucket, tbeg, n_items, key);
-    default: return p2_tile_load_hb<N, 4>(bucket, tbeg, n_items, key);
+__device__ __forceinline__ uint32_t p2_tile_load_narrow(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, false>& it) {
+    static_assert(N % 4 == 0, "whole groups");
+    const uint32_t gs1 = 16 + 4 * hb1, hi_none = hb1 == 0 ? 0u : hb1 == 1 ? 0xFFu : 0xFFFFu;
+    // v_perm_b32(y, x, sel): selector bytes 0-3 take x's bytes, 4-7 y's, 0x0C gives 0.  HB1 = 2: (x, y) are the pairs already; HB1 = 1:
+    // x holds four bytes -> {x0, 0, x1, 0}, {x2, 0, x3, 0}; HB1 = 0: nothing
+    const uint32_t sel0 = hb1 == 2 ? 0x03020100u : hb1 == 1 ? 0x0C010C00u : 0x0C0C0C0Cu, sel1 = hb1 == 2 ? 0x07060504u : hb1 == 1 ? 0x0C030C02u : 0x0C0C0C0Cu;
+    const uint64_t left = n_items - tbeg;                                      // (tbeg < n_items)
+    const uint32_t t_items = left < (uint64_t)N * PART_BLOCK ? (uint32_t)left : (uint32_t)N * PART_BLOCK;
+    const uint8_t* mine = bucket + ((tbeg >> 2) + threadIdx.x) * gs1;
+    u32x4 lo[N / 4];
+    u32x2 hi[N / 4];
+#pragma unroll
+    for (int u = 0; u < N / 4; ++u) {
+        const uint8_t* p = mine + (uint64_t)u * PART_BLOCK * gs1;
+        lo[u] = *reinterpret_cast<const u32x4_a4*>(p);
+        hi[u] = *reinterpret_cast<const u32x2_a4*>(p + 16);
     }
+    uint32_t valid = 0;
+#pragma unroll
+    for (int u = 0; u < N / 4; ++u) {
+        const uint32_t i0 = 4 * ((uint32_t)u * PART_BLOCK + threadIdx.x);
+        const uint32_t h01 = __builtin_amdgcn_perm(hi[u].y, hi[u].x, sel0), h23 = __builtin_amdgcn_perm(hi[u].y, hi[u].x, sel1);
+        it.hi[2 * u] = h01; it.hi[2 * u + 1] = h23;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t l = q == 0 ? lo[u].x : q == 1 ? lo[u].y : q == 2 ? lo[u].z : lo[u].w;
+            const uint32_t h = ((q < 2 ? h01 : h23) >> (16 * (q & 1))) & 0xFFFFu;
+            it.lo[4 * u + q] = l;
+            valid |= (i0 + q < t_items && !(l == 0xFFFFFFFFu && h == hi_none)) ? 1u << (4 * u + q) : 0u;
+        }
+    }
+    return valid;
+}
+template <int N, bool W1>
+__device__ __forceinline__ uint32_t p2_tile_load(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, W1>& it) {
+    if constexpr (W1) return p2_tile_load_hb<N, 4>(bucket, tbeg, n_items, it);
+    else return p2_tile_load_narrow<N>(hb1, bucket, tbeg, n_items, it);
 }
 
 // Counting-sort one tile's k-mers of a bucket by their level-2 digit through LDS and append every digit's run at this workgroup's
@@ -562,8 +743,8 @@ __device__ __forceinline__ uint32_t p2_tile_load(uint32_t hb1, const uint8_t* __
 // one 16-byte store of low words + one of high parts per four k-mers -- into a run with a capacity (lim[], in groups); what does not
 // fit goes to the overflow list as a k-mer (through the inverse hash).  Not GROUPED (the exact edition): item by item at exact
 // positions.  All 1024 lanes must call it (barriers inside).
-template <int HB, bool GROUPED, bool STAMP = false>
-__device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, const uint32_t b1, const uint64_t (&key)[L2Fmt<HB>::N], uint32_t valid,
+template <int HB, bool GROUPED, bool W1, bool STAMP = false>
+__device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, const uint32_t b1, const TileItems<L2Fmt<HB>::N, W1>& key, uint32_t valid,
                                               uint8_t* __restrict__ out, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap,
                                               unsigned long long* st = nullptr /* STAMP: cycles of [1] hash + rank, [2] scan, [3] staging, [4] copy-out */) {
     constexpr int N = L2Fmt<HB>::N;
@@ -579,7 +760,7 @@ __device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, co
     for (int j = 0; j < N; ++j) {
         br[j] = 0;
         if (valid >> j & 1) {
-            const uint32_t b = place_digit2_of(key[j], g.pl);      // (key[j] = r1: one 32-bit multiply)
+            const uint32_t b = place_digit2_of(key.r1(j), g.pl);   // (one 32-bit multiply)
             br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
         }
     }
@@ -598,7 +779,7 @@ __device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, co
     for (int j = 0; j < N; ++j)
         if (valid >> j & 1) {
             const uint32_t b = br[j] >> 16, slot = L.goff[b] * (GROUPED ? 4u : 1u) + (br[j] & 0xFFFF);
-            const uint64_t rem = key[j] & g.pl.mr;
+            const uint64_t rem = key.r1(j) & g.pl.mr;
             L.st_lo[slot] = (uint32_t)rem;
             if (HB) L.st_hi[slot] = (hi_t)(rem >> 32);
             if (GROUPED) L.grp_b[slot >> 2] = (uint16_t)b;
@@ -647,7 +828,7 @@ __device__ __host__ __forceinline__ uint64_t p2_exact_base(uint64_t beg, uint32_
 
 // The exact edition: one workgroup per level-1 bucket: histogram by digit, scan, scatter.  off2[r] = start of region r's run (a
 // multiple of 4: runs begin on group boundaries; the up to three items between a run's last k-mer and the next run are "no item").
-template <int HB>
+template <int HB, bool W1 /* level-1 items of more than 48 bits (HB1 = 4) */>
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
      uint64_t* __restrict__ off2, uint64_t seg_slots, uint64_t* __restrict__ bend /* end of bucket b1's last run: the next bucket's runs start later */) {
@@ -656,11 +837,10 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict_
     constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
     uint64_t beg0, n0;
-    l1_bucket_range(l1_off, seg_slots, g.b_lo, beg0, n0);
+    l1_bucket_range(g, l1_off, seg_slots, g.b_lo, beg0, n0);
     for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
         uint64_t beg, n_items;
-        l1_bucket_range(l1_off, seg_slots, b1, beg, n_items);
-        const uint8_t* bucket = l1_buf + l1_bucket_base(beg, b1);
+        const uint8_t* bucket = l1_buf + l1_bucket_range(g, l1_off, seg_slots, b1, beg, n_items);
         const uint64_t obeg = p2_exact_base(beg, b1, g.P2) - p2_exact_base(beg0, g.b_lo, g.P2);   // the level-2 buffer holds this pass only
         lds_barrier();
         // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
@@ -669,11 +849,11 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict_
         if (tid < MAX_PARTS) h64[tid] = 0;
         lds_barrier();
         for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
-            uint64_t key[N];
-            const uint32_t valid = p2_tile_load<N>(g.hb1, bucket, tbeg, n_items, key);
+            TileItems<N, W1> key;
+            const uint32_t valid = p2_tile_load<N, W1>(g.hb1, bucket, tbeg, n_items, key);
 #pragma unroll
             for (int j = 0; j < N; ++j)
-                if (valid >> j & 1) atomicAdd(&h64[place_digit2_of(key[j], g.pl)], 1ULL);
+                if (valid >> j & 1) atomicAdd(&h64[place_digit2_of(key.r1(j), g.pl)], 1ULL);
         }
         lds_barrier();
         const uint64_t mine = tid < g.P2 ? h64[tid] : 0;
@@ -687,10 +867,10 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict_
         if (b1 == g.b_hi - 1 && tid == g.P2 - 1) off2[(uint64_t)g.b_hi * g.P2] = obeg + excl + ((mine + 3) & ~3ULL);
         if (bend && tid == g.P2 - 1) bend[b1] = obeg + excl + ((mine + 3) & ~3ULL);             // the runs of a bucket stop short of the next bucket's
         for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {                     // pass B
-            uint64_t key[N];
-            const uint32_t valid = p2_tile_load<N>(g.hb1, bucket, tbeg, n_items, key);
+            TileItems<N, W1> key;
+            const uint32_t valid = p2_tile_load<N, W1>(g.hb1, bucket, tbeg, n_items, key);
             lds_barrier();
-            scatter_tile2<HB, false>(L, g, b1, key, valid, l2_buf, nullptr, nullptr, 0);
+            scatter_tile2<HB, false, W1>(L, g, b1, key, valid, l2_buf, nullptr, nullptr, 0);
         }
     }
 }
@@ -709,7 +889,7 @@ __device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t 
     return (beg + (beg >> 4) + 2 * (uint64_t)P2 * (beg / tile) + (uint64_t)b1 * P2 * 32 + 3) & ~3ULL;
 }
 
-template <int HB, bool STAMP = false>
+template <int HB, bool W1, bool STAMP = false>
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
           uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
@@ -721,11 +901,10 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
     constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
     uint64_t beg0, n0;
-    l1_bucket_range(l1_off, seg_slots, g.b_lo, beg0, n0);
+    l1_bucket_range(g, l1_off, seg_slots, g.b_lo, beg0, n0);
     for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
         uint64_t beg, n_items;
-        l1_bucket_range(l1_off, seg_slots, b1, beg, n_items);
-        const uint8_t* bucket = l1_buf + l1_bucket_base(beg, b1);
+        const uint8_t* bucket = l1_buf + l1_bucket_range(g, l1_off, seg_slots, b1, beg, n_items);
         const uint64_t cap = p2_region_cap(n_items, g.P2, L2Fmt<HB>::TILE);
         const uint64_t obase = p2_out_base(beg, b1, g.P2, L2Fmt<HB>::TILE) - p2_out_base(beg0, g.b_lo, g.P2, L2Fmt<HB>::TILE);   // the level-2 buffer holds this pass only
         lds_barrier();
@@ -737,12 +916,12 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
         }
         for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
             const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
-            uint64_t key[N];
-            const uint32_t valid = p2_tile_load<N>(g.hb1, bucket, tbeg, n_items, key);
+            TileItems<N, W1> key;
+            const uint32_t valid = p2_tile_load<N, W1>(g.hb1, bucket, tbeg, n_items, key);
             if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
             lds_barrier();
             if (STAMP) { st[0] += (unsigned long long)clock64() - ta; st[5] += 1; }
-            scatter_tile2<HB, true, STAMP>(L, g, b1, key, valid, l2_buf, ovf_buf, ovf_n, ovf_cap, st);
+            scatter_tile2<HB, true, W1, STAMP>(L, g, b1, key, valid, l2_buf, ovf_buf, ovf_n, ovf_cap, st);
         }
         lds_barrier();
         if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = (uint32_t)((L.cursor[tid] << 2) - (obase + (uint64_t)tid * cap));
@@ -869,7 +1048,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                         if (c0 == key) { add1(slot); live = false; }
                         else {
                             slot = slot + 1 == S ? 0 : slot + 1;
-                            if (--budget == 0) { spill[atomicAdd(spill_n, 1ULL)] = key; live = false; }     // region full: direct path later
+                            if (--budget == 0) { spill_put(spill, spill_n, g.spill_cap, key); live = false; }     // region full: direct path later
                         }
                     }
                 }
@@ -899,11 +1078,11 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                         const unsigned long long mk = __ballot(c0 == ck), me = __ballot(c0 == EMPTY);
                         if (!(mk | me)) {                                                      // 64 foreign keys
                             cb -= 64; cs = cs + 64 >= S ? cs + 64 - S : cs + 64;
-                            if (cb <= 0) { if (lane == 0) spill[atomicAdd(spill_n, 1ULL)] = ck; break; }
+                            if (cb <= 0) { if (lane == 0) spill_put(spill, spill_n, g.spill_cap, ck); break; }
                             continue;
                         }
                         const int first = __ffsll((long long)(mk | me)) - 1;
-                        if (first >= cb) { if (lane == 0) spill[atomicAdd(spill_n, 1ULL)] = ck; break; }   // beyond the region's last unprobed slot
+                        if (first >= cb) { if (lane == 0) spill_put(spill, spill_n, g.spill_cap, ck); break; }   // beyond the region's last unprobed slot
                         unsigned long long got = ck;                                           // what the slot holds after this step
                         if (!((mk >> first) & 1)) {                                            // EMPTY comes first: claim it
                             unsigned long long old = EMPTY;
@@ -949,7 +1128,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                     pend[u] = c_in && rem != L2Fmt<HB>::NONE;
                     slot[u] = place_offset(rem, g.pl, S);
                     cur[u] = place_key_d(rd1, rd2, rem, g.pl);
-                    if (TEST_SPILL && spill_mod && pend[u] && __umulhi((uint32_t)(mix64(cur[u]) >> 32), spill_mod) == 0) { spill[atomicAdd(spill_n, 1ULL)] = cur[u]; pend[u] = false; }
+                    if (TEST_SPILL && spill_mod && pend[u] && __umulhi((uint32_t)(mix64(cur[u]) >> 32), spill_mod) == 0) { spill_put(spill, spill_n, g.spill_cap, cur[u]); pend[u] = false; }
                 }
                 const unsigned long long t_b = now();
                 // Probe rounds: U reads in flight, one wait; a match adds 1 and is done, a foreign key moves on, an EMPTY slot is
@@ -1119,7 +1298,7 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
         const uint32_t rn = next_region(r + gridDim.x);
         // what spilling a k-mer (region full, test hook) needs: the region's digits give the k-mer back
         const uint32_t rd1 = r >> g.l2, rd2 = r & (g.P2 - 1);
-        auto spill_rem = [&](uint64_t rem) { spill[atomicAdd(spill_n, 1ULL)] = place_key_d(rd1, rd2, rem, g.pl); };
+        auto spill_rem = [&](uint64_t rem) { spill_put(spill, spill_n, g.spill_cap, place_key_d(rd1, rd2, rem, g.pl)); };
 
         for (uint64_t sbeg = beg; sbeg < end; sbeg += seg_len) {            // one segment, normally
             const uint64_t n_run = (end - sbeg < seg_len ? end - sbeg : seg_len);
