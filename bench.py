@@ -551,7 +551,17 @@ def end_to_end(eng, a, k, L):
     wl = a.workload
     n = min(a.e2e_reads, a.reads) & ~1
     gs = min(a.genome, max(10_000_000, n * 5))                               # ~30x coverage of the slice's genome
-    tmp = tempfile.mkdtemp(prefix="katgpu_e2e_")
+    # the inputs go where reading them back cannot depend on this process's own write-back: /dev/shm (RAM-backed by construction)
+    # when it has the room, else the default temp dir (page cache; the line says which)
+    need = int(n * (2 * L + 14) * 1.02) + (gs if wl == "comp" else n * (2 * L + 14)) + (1 << 30)
+    tmp_root = None
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize > need + (8 << 30):
+            tmp_root = "/dev/shm"
+    except OSError:
+        pass
+    tmp = tempfile.mkdtemp(prefix="katgpu_e2e_", dir=tmp_root)
     t_e2e0 = time.perf_counter()
     try:
         g = eng.synth_genome(gs, seed=99)
@@ -607,12 +617,35 @@ def end_to_end(eng, a, k, L):
             cmd += lib1
         t_gen = time.perf_counter() - t_e2e0
         t0 = time.perf_counter()
-        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, KATGPU_TIMING="1"))
         dt = time.perf_counter() - t0
         if pr.returncode != 0:
             raise RuntimeError("katgpu %s exited %d: %s" % (tool, pr.returncode, (pr.stderr or pr.stdout)[-400:]))
         outs = [f for f in os.listdir(tmp) if f.startswith("out")]
-        return {"value": round(inst / dt, 1), "unit": "k-mers/s", "seconds": round(dt, 3), "input_bytes": nbytes,
+        # where the span went: the binary's own timing lines (KATGPU_TIMING=1): per phase of the run and per input file
+        phases, per_file = {}, []
+        for line in pr.stderr.splitlines():
+            if not line.startswith("katgpu_timing "):
+                continue
+            try:
+                rec = json.loads(line[len("katgpu_timing "):])
+            except ValueError:
+                continue
+            if "phase" in rec:
+                key = rec["phase"] if rec["phase"] != "count" else "count_input_%d" % (1 + sum(1 for q in phases if q.startswith("count_input_")))
+                phases[key + "_ms"] = rec["ms"]
+            elif "file" in rec:
+                rec["file"] = os.path.basename(rec["file"])
+                rec["GB_per_s"] = round(rec["bytes"] / max(rec["wall_ms"], 1e-3) / 1e6, 2)
+                per_file.append(rec)
+        accounted = sum(v for q, v in phases.items() if q != "total_ms")
+        breakdown = {"process_wall_ms": round(dt * 1e3, 1), "phases": phases, "unaccounted_ms": round(dt * 1e3 - accounted, 1),
+                     "files": per_file,
+                     "reading": "per file: wall = the file's whole pass; reader_wait = the main thread waiting for file bytes to reach the device (reader threads: "
+                                "pread into pinned memory, then their own H2D copy; pread / h2d per thread say which of the two it was); scan = the record scan "
+                                "on the device; counter_wait = waiting for the counting worker; counting = what the worker spent (hidden under the rest unless "
+                                "counter_wait says otherwise)"}
+        return {"value": round(inst / dt, 1), "breakdown": breakdown, "inputs_in": tmp_root or tempfile.gettempdir(), "unit": "k-mers/s", "seconds": round(dt, 3), "input_bytes": nbytes,
                 "input_GB_per_s": round(nbytes / dt / 1e9, 2), "kmer_instances": inst,
                 "span": "process start -> output files closed (src/comp.cc:750 'Total runtime'), inputs in the page cache",
                 "files_written_in_s": round(t_gen, 1),

@@ -34,7 +34,9 @@ katgpu_ctx* Engine::ctx() {
             const int n = nd ? std::max(1, atoi(nd)) : 1;
             dev = rank_ % n;
         }
+        const double t0 = timing_now_ms();
         int rc = katgpu_init(dev, &g_ctx);
+        timing_line("device_init", timing_now_ms() - t0);
         if (rc) throw std::runtime_error("katgpu_init failed (status " + std::to_string(rc) + "): no gfx950 device; this build has no CPU path");
     }
     return g_ctx;
@@ -184,6 +186,7 @@ void InputHandler::count(uint16_t threads, const katgpu_table* like) {      // l
     std::cout << " done.";
     std::cout.flush();
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    timing_line("count", s * 1e3, input.empty() ? "" : input[0].c_str());
     char buf[64]; snprintf(buf, sizeof buf, "  Time taken: %.1fs\n\n", s);   // auto_cpu_timer(1, "  Time taken: %ws\n\n")
     std::cout << buf;
 }

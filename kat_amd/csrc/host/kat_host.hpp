@@ -8,7 +8,10 @@
 #pragma once
 #include <katgpu.h>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <ostream>
 #include <stdexcept>
@@ -16,6 +19,15 @@
 #include <vector>
 
 namespace kat {
+
+// KATGPU_TIMING=1: one "katgpu_timing {json}" line on stderr per phase of a run (process start -> device ready, each input's count,
+// the reduction, the output files) next to the library's own per-file lines: what bench.py's end_to_end.breakdown is made of.
+// Costs nothing otherwise; the KAT-format "Time taken" lines on stdout stay as they are (0.1 s resolution).
+inline double timing_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline void timing_line(const char* phase, double ms, const char* what = "") {
+    static const bool on = getenv("KATGPU_TIMING") != nullptr;
+    if (on) fprintf(stderr, "katgpu_timing {\"phase\": \"%s\", \"what\": \"%s\", \"ms\": %.1f}\n", phase, what, ms);
+}
 
 const uint16_t DEFAULT_MER_LEN = 27;            // lib/include/kat/jellyfish_helper.hpp:76
 const uint64_t DEFAULT_HASH_SIZE = 100000000;   // lib/include/kat/jellyfish_helper.hpp:75

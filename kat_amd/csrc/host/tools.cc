@@ -18,9 +18,11 @@ namespace {
 struct PhaseTimer {     // boost::timer::auto_cpu_timer(1, "  Time taken: %ws\n\n")
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     const char* fmt;
-    explicit PhaseTimer(const char* f = "  Time taken: %.1fs\n\n") : fmt(f) {}
+    const char* phase;  // KATGPU_TIMING: the phase's name in the "katgpu_timing" line
+    explicit PhaseTimer(const char* f = "  Time taken: %.1fs\n\n", const char* ph = "reduce") : fmt(f), phase(ph) {}
     ~PhaseTimer() {
         char buf[128];
+        timing_line(phase, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         snprintf(buf, sizeof buf, fmt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         cout << buf;
         cout.flush();
@@ -98,7 +100,7 @@ int Histogram::main(int argc, char* argv[]) {                                   
         return 1;
     }
     vector<uint16_t> trim = parseTrimList(pa.get("5ptrim", "0"));
-    PhaseTimer total("KAT HIST completed.\nTotal runtime: %.1fs\n\n");
+    PhaseTimer total("KAT HIST completed.\nTotal runtime: %.1fs\n\n", "total");
     cout << "Running KAT in HIST mode" << endl << "------------------------" << endl << endl;
     Histogram histo(pa.positional, std::stoull(pa.get("low", "1")), std::stoull(pa.get("high", "10000")), std::stoull(pa.get("inc", "1")));
     histo.setOutputPrefix(pa.get("output_prefix", "kat.hist"));
@@ -110,7 +112,7 @@ int Histogram::main(int argc, char* argv[]) {                                   
     histo.setDumpHash(pa.has("dump_hash"));
     histo.setVerbose(pa.has("verbose"));
     histo.execute();
-    histo.save();
+    { const double t0 = timing_now_ms(); histo.save(); timing_line("write_outputs", timing_now_ms() - t0); }
     return 0;
 }
 
@@ -182,7 +184,7 @@ int Gcp::main(int argc, char* argv[]) {                                         
         return 1;
     }
     vector<uint16_t> trim = parseTrimList(pa.get("5ptrim", "0"));
-    PhaseTimer total("KAT GCP completed.\nTotal runtime: %.1fs\n\n");
+    PhaseTimer total("KAT GCP completed.\nTotal runtime: %.1fs\n\n", "total");
     cout << "Running KAT in GCP mode" << endl << "-----------------------" << endl << endl;
     Gcp gcp(pa.positional);
     gcp.setOutputPrefix(pa.get("output_prefix", "kat-gcp"));
@@ -196,7 +198,7 @@ int Gcp::main(int argc, char* argv[]) {                                         
     gcp.setDumpHash(pa.has("dump_hash"));
     gcp.setVerbose(pa.has("verbose"));
     gcp.execute();
-    gcp.save();
+    { const double t0 = timing_now_ms(); gcp.save(); timing_line("write_outputs", timing_now_ms() - t0); }
     return 0;
 }
 
@@ -358,7 +360,7 @@ int Comp::main(int argc, char* argv[]) {                                        
         cout << "Usage: kat comp [options] <input_1> <input_2> [<input_3>]\n\nCompares jellyfish K-mer count hashes.\n" << endl;
         return 1;
     }
-    PhaseTimer total("KAT COMP completed.\nTotal runtime: %.1fs\n\n");
+    PhaseTimer total("KAT COMP completed.\nTotal runtime: %.1fs\n\n", "total");
     cout << "Running KAT in COMP mode" << endl << "------------------------" << endl << endl;
     const bool verbose = pa.has("verbose");
     if (pa.positional.empty() || pa.positional[0].empty()) throw CompException("Nothing specified for input group 1");
@@ -393,7 +395,7 @@ int Comp::main(int argc, char* argv[]) {                                        
     comp.setOutputHists(pa.has("output_hists"));
     comp.setVerbose(verbose);
     comp.execute();
-    comp.save();
+    { const double t0 = timing_now_ms(); comp.save(); timing_line("write_outputs", timing_now_ms() - t0); }
     cout << endl << "Summary statistics" << endl << "------------------" << endl << endl;
     comp.printCounters(cout);
     return 0;

@@ -404,6 +404,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         const uint64_t seg_slots = seg ? (uint64_t)W * seg_cap : 0;                // items of one bucket
         const uint32_t bucket_stride = (uint32_t)stride64;
         g.l1_stride = seg ? stride64 : 0;
+        g.l1_real = seg ? (uint64_t)W * cap_plain : 0;
         const bool lean = g_l1_lean && lean_applies(k, g.pl.n1);
         const bool pb512 = g.P1 <= 512;
         uint64_t items = 0;
@@ -414,7 +415,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
 #define KG_L1S(LEAN, PB) hipLaunchKernelGGL((k_p1v2_scatter<true, LEAN, PB>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, \
-                                               (const uint64_t*)nullptr, (const uint64_t*)nullptr, l1_buf, (uint32_t)seg_cap, bucket_stride, ovf_buf, ovf_n, ovf_cap)
+                                               (const uint64_t*)nullptr, (const uint64_t*)nullptr, l1_buf, (uint32_t)seg_cap, bucket_stride, (uint32_t)cap_plain, ovf_buf, ovf_n, ovf_cap)
                 if (lean) { if (pb512) KG_L1S(true, 512); else KG_L1S(true, MAX_PARTS); }
                 else { if (pb512) KG_L1S(false, 512); else KG_L1S(false, MAX_PARTS); }
 #undef KG_L1S
@@ -439,10 +440,10 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
                 if (lean)
                     hipLaunchKernelGGL((k_p1v2_scatter<false, true>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, (const uint64_t*)l1_off, l1_buf,
-                                       0u, 0u, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
+                                       0u, 0u, 0u, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
                 else
                     hipLaunchKernelGGL((k_p1v2_scatter<false, false>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, (const uint64_t*)l1_off, l1_buf,
-                                       0u, 0u, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
+                                       0u, 0u, 0u, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
             }
         }
         if (items) {
@@ -454,7 +455,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 HIPCHK(c, hipMemcpyAsync(h_l1_off.data(), l1_off, (g.P1 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
             }
-            auto lbeg = [&](uint32_t b) -> uint64_t { return seg ? (uint64_t)b * seg_slots : h_l1_off[b]; };
+            auto lbeg = [&](uint32_t b) -> uint64_t { return seg ? (uint64_t)b * g.l1_real : h_l1_off[b]; };      // k-mers before bucket b (segmented: their bound)
             const uint32_t tile2 = l2_tile_items(g.hb);
             auto pass_extent = [&](uint32_t b_lo, uint32_t b_hi) -> uint64_t {       // bound of what level 2 writes for these buckets, in items (either edition)
                 const uint64_t nn = lbeg(b_hi) - lbeg(b_lo);

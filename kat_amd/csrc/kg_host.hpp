@@ -144,6 +144,7 @@ inline double since_load() { return now_ms() - g_t_loaded; }
 // What a deployment may tune stays plain (INTEGRATION.md lists them): KATGPU_TRACE, KATGPU_ARENA_FRACTION, KATGPU_RING_MB,
 // KATGPU_PART_MIN_STARTS, KATGPU_INGEST_*, KATGPU_DEVICE_SCAN.
 static const bool g_trace = getenv("KATGPU_TRACE") != nullptr;
+static const bool g_timing = getenv("KATGPU_TIMING") != nullptr;   // one "katgpu_timing {json}" line on stderr per file / phase: what bench.py's end_to_end.breakdown is made of
 static const bool g_testing = getenv("KATGPU_TESTING") != nullptr;
 inline const char* hook(const char* name) { return g_testing ? getenv(name) : nullptr; }
 inline uint64_t hook_u64(const char* name, uint64_t dflt) { const char* v = hook(name); return v ? strtoull(v, nullptr, 10) : dflt; }

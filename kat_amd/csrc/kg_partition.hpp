@@ -53,6 +53,7 @@ struct PartGeom {
     uint32_t hb;       // bytes of a level-2 item beyond its low 32 bits: 0, 1, 2 or 4 (from pl.rb; "the level-2 buffer" below)
     uint32_t hb1;      // ... of a level-1 item (from pl.n1; "the level-1 buffer" below)
     uint64_t l1_stride;// segmented level 1: bytes from one bucket's first group to the next's in the level-1 buffer; 0: the exact layout
+    uint64_t l1_real;  // segmented level 1: k-mers a bucket holds at most (workgroups x the segments' k-mer capacity; its slots -- group padding included -- are more): what level 2's runs and the spill list are sized by
     uint64_t spill_cap;// k-mers the apply's spill list holds (this pass's part of the level-1 buffer); what is beyond is counted, not written: the host fails the call
     uint32_t cbits;    // the table's (kg_device.hpp: packed slots); 0: KV12
     Place pl;          // the placement hash's bit budget for this table (kg_device.hpp)
@@ -242,6 +243,7 @@ struct P1LdsT {
     typedef typename std::conditional<SEG, uint32_t, uint64_t>::type cursor_t;
     cursor_t cursor[PB];                // next item of each bucket's run, counted from the bucket's first item (exact edition) / inside the segment (segmented)
     uint32_t hist[PB + (LEAN ? 64 : 0)];   // (LEAN: + one dump counter per lane of a wave, for the windows that hold no k-mer)
+    uint32_t real[SEG ? PB : 1];        // SEG: k-mers in each bucket's segment so far (the cursor counts slots: k-mers + group padding)
     uint32_t off[PB];
     uint32_t wave_tot[16];
     uint32_t code[P1_BLOCK + 2];
@@ -412,6 +414,7 @@ __global__ void __launch_bounds__(P1_BLOCK, SEG && PB == 512 ? 6 : 4)   // six w
 k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_t n, uint64_t n_tiles, uint64_t tiles_per_wg,
                const uint64_t* __restrict__ offs, const uint64_t* __restrict__ l1_off, uint8_t* __restrict__ l1_buf, uint32_t seg_cap /* SEG: < 2^24, a multiple of 4 */,
                uint32_t bucket_stride /* SEG: bytes from one bucket's first group to the next's, < 2^32 */,
+               uint32_t seg_real /* SEG: k-mers a segment takes at most (<= seg_cap; the slots beyond are room for group padding) */,
                uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
     __shared__ __attribute__((aligned(16))) P1LdsT<LEAN, SEG, PB> L;
     typedef typename P1LdsT<LEAN, SEG, PB>::cursor_t cursor_t;
@@ -422,7 +425,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
     uint32_t ones = 0;
     // SEG: this workgroup's segment of bucket b starts seg_off bytes into the bucket (whole groups)
     const uint64_t seg_off = SEG ? (uint64_t)blockIdx.x * (seg_cap >> 2) * gs1 : 0;
-    for (uint32_t b = tid; b < P; b += P1_BLOCK) L.cursor[b] = SEG ? (cursor_t)0 : (cursor_t)(offs[(uint64_t)blockIdx.x * P + b] - l1_off[b]);
+    for (uint32_t b = tid; b < P; b += P1_BLOCK) { L.cursor[b] = SEG ? (cursor_t)0 : (cursor_t)(offs[(uint64_t)blockIdx.x * P + b] - l1_off[b]); if (SEG) L.real[b] = 0; }
     const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
     u32x4 raw = p1_tile_issue(bases, n, (t0 < t1 ? t0 : 0) * P1_TILE_STARTS);
     for (uint64_t tile = t0; tile < t1; ++tile) {
@@ -536,7 +539,10 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                     entry_src(ev[q] == P1_PAD ? 0u : ev[q], src, wd, o[q]);
                     c0[q] = src[wd]; c1[q] = src[wd + 1]; c2[q] = src[wd + 2];
                 }
-                const uint32_t grel = ((uint32_t)L.cursor[b] >> 2) + (gi - L.off[b]);     // group of the segment
+                const uint32_t gahead = gi - L.off[b];
+                const uint32_t grel = ((uint32_t)L.cursor[b] >> 2) + gahead;              // group of the segment
+                // a segment takes seg_real k-mers at most (the groups of a run before this one are full ones)
+                const bool room = grel < seg_groups && L.real[b] + 4 * gahead + 4 <= seg_real;
                 uint32_t lo[4], hi[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -545,7 +551,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                     lo[q] = pad ? 0xFFFFFFFFu : (uint32_t)r1;
                     hi[q] = pad ? 0xFFFFFFFFu : (uint32_t)(r1 >> 32);
                 }
-                if (grel < seg_groups) {
+                if (room) {
                     const u32x4 glo = {lo[0], lo[1], lo[2], lo[3]};
                     typename HiGroup<HB1>::type ghi{};
                     if constexpr (HB1 == 1) ghi = (hi[0] & 0xFFu) | ((hi[1] & 0xFFu) << 8) | ((hi[2] & 0xFFu) << 16) | (hi[3] << 24);
@@ -593,7 +599,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                     const uint32_t ahead = idx - run0[u];
                     if (SEG) {
                         const uint32_t rel = (uint32_t)cur[u] + ahead;      // item of the segment (32-bit: seg_cap < 2^24, a tile adds < 2^13)
-                        if (rel < seg_cap) l1_put<HB1>(l1_buf + ((uint64_t)b * bucket_stride + seg_off), __umul24(rel >> 2, GS1), rel & 3, (uint32_t)r1, (uint32_t)(r1 >> 32));
+                        if (rel < seg_real) l1_put<HB1>(l1_buf + ((uint64_t)b * bucket_stride + seg_off), __umul24(rel >> 2, GS1), rel & 3, (uint32_t)r1, (uint32_t)(r1 >> 32));
                         else {                                               // the segment is full: the overflow list
                             const unsigned long long at = atomicAdd(ovf_n, 1ULL);
                             if (at < ovf_cap) ovf_buf[at] = key1;
@@ -613,9 +619,15 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         }
         lds_barrier();
         for (uint32_t b = tid; b < P; b += P1_BLOCK) {
-            uint64_t c = (uint64_t)L.cursor[b] + (grouped ? (L.hist[b] + 3) & ~3u : L.hist[b]);
-            if (SEG) c = c < seg_cap ? c : seg_cap;
-            L.cursor[b] = (cursor_t)c;
+            if (!SEG) L.cursor[b] = (cursor_t)((uint64_t)L.cursor[b] + L.hist[b]);
+            else if (!grouped) { const uint32_t c = (uint32_t)L.cursor[b] + L.hist[b]; L.cursor[b] = (cursor_t)(c < seg_real ? c : seg_real); }
+            else {                                           // the groups that were written: a prefix of the run's, by both limits (copy_out_groups)
+                const uint32_t h = L.hist[b], gc = (h + 3) >> 2, cur = (uint32_t)L.cursor[b], re = L.real[b];
+                const uint32_t by_slots = (seg_cap - cur) >> 2, by_real = (seg_real - re) >> 2;
+                const uint32_t w = gc < by_slots ? (gc < by_real ? gc : by_real) : (by_slots < by_real ? by_slots : by_real);
+                L.cursor[b] = (cursor_t)(cur + 4 * w);
+                L.real[b] = re + (h < 4 * w ? h : 4 * w);
+            }
         }
     }
     if (SEG) {
@@ -634,9 +646,10 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
 // bucket b1 of the level-1 buffer: its first item and number of items (in items of the round; segment and group padding
 // included) and the byte its groups start at.  Exact layout (l1_off) or segmented (seg_slots = workgroups x seg_cap items per bucket,
 // "no item"-padded, buckets l1_stride bytes apart).
-__device__ __forceinline__ uint64_t l1_bucket_range(const PartGeom& g, const uint64_t* __restrict__ l1_off, uint64_t seg_slots, uint32_t b1, uint64_t& first, uint64_t& n_items) {
-    if (seg_slots) { first = (uint64_t)b1 * seg_slots; n_items = seg_slots; return (uint64_t)b1 * g.l1_stride; }
-    first = l1_off[b1]; n_items = l1_off[b1 + 1] - first;
+// first / n_real: the k-mers before this bucket / in it (segmented: their bounds) -- what level 2 places and sizes its runs by
+__device__ __forceinline__ uint64_t l1_bucket_range(const PartGeom& g, const uint64_t* __restrict__ l1_off, uint64_t seg_slots, uint32_t b1, uint64_t& first, uint64_t& n_items, uint64_t& n_real) {
+    if (seg_slots) { first = (uint64_t)b1 * g.l1_real; n_items = seg_slots; n_real = g.l1_real; return (uint64_t)b1 * g.l1_stride; }
+    first = l1_off[b1]; n_items = n_real = l1_off[b1 + 1] - first;
     return l1_bucket_base(first, b1);
 }
 
@@ -836,11 +849,11 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict_
     P2Lds<HB>& L = *reinterpret_cast<P2Lds<HB>*>(lds_raw);
     constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
-    uint64_t beg0, n0;
-    l1_bucket_range(g, l1_off, seg_slots, g.b_lo, beg0, n0);
+    uint64_t beg0, n0, nr0;
+    l1_bucket_range(g, l1_off, seg_slots, g.b_lo, beg0, n0, nr0);
     for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
-        uint64_t beg, n_items;
-        const uint8_t* bucket = l1_buf + l1_bucket_range(g, l1_off, seg_slots, b1, beg, n_items);
+        uint64_t beg, n_items, n_real;
+        const uint8_t* bucket = l1_buf + l1_bucket_range(g, l1_off, seg_slots, b1, beg, n_items, n_real);
         const uint64_t obeg = p2_exact_base(beg, b1, g.P2) - p2_exact_base(beg0, g.b_lo, g.P2);   // the level-2 buffer holds this pass only
         lds_barrier();
         // pass A histogram in 64 bits (a heavy-hitter k-mer may put more than 2^32 items of a round into one region):
@@ -900,12 +913,12 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
     P2Lds<HB>& L = *reinterpret_cast<P2Lds<HB>*>(lds_raw);
     constexpr int N = L2Fmt<HB>::N;
     const uint32_t tid = threadIdx.x;
-    uint64_t beg0, n0;
-    l1_bucket_range(g, l1_off, seg_slots, g.b_lo, beg0, n0);
+    uint64_t beg0, n0, nr0;
+    l1_bucket_range(g, l1_off, seg_slots, g.b_lo, beg0, n0, nr0);
     for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
-        uint64_t beg, n_items;
-        const uint8_t* bucket = l1_buf + l1_bucket_range(g, l1_off, seg_slots, b1, beg, n_items);
-        const uint64_t cap = p2_region_cap(n_items, g.P2, L2Fmt<HB>::TILE);
+        uint64_t beg, n_items, n_real;
+        const uint8_t* bucket = l1_buf + l1_bucket_range(g, l1_off, seg_slots, b1, beg, n_items, n_real);
+        const uint64_t cap = p2_region_cap(n_real, g.P2, L2Fmt<HB>::TILE);
         const uint64_t obase = p2_out_base(beg, b1, g.P2, L2Fmt<HB>::TILE) - p2_out_base(beg0, g.b_lo, g.P2, L2Fmt<HB>::TILE);   // the level-2 buffer holds this pass only
         lds_barrier();
         if (tid < g.P2) {

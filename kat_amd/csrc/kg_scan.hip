@@ -88,6 +88,7 @@ struct RawFeeder {
     uint64_t consumed = 0;                                        // of my batches, how many the main thread is through with: my[j] may be read when j < consumed + 2
     bool stop = false, io_error = false;
     size_t n_readers = 0;
+    std::atomic<uint64_t> us_pread{0}, us_h2d{0};                 // summed over the reader threads: in pread / in their H2D copy (enqueue + landing)
 
     RawFeeder(katgpu_table* t_, const char* p) : t(t_), c(t_->ctx), path(p) {}
     ~RawFeeder() { shutdown(); release(); }
@@ -106,14 +107,17 @@ struct RawFeeder {
     int acquire(int nb, unsigned threads) {
         katgpu_ctx::ScanCache& sc = c->scan;
         const size_t seg_bytes = PRE + segment + overlap + 64;
-        if (sc.buf_bytes < buf_bytes || sc.n_buf < nb || sc.pin_seg_bytes < seg_bytes || sc.pin_seg.size() < threads || sc.acc_bytes < acc_bytes) {
+        if (sc.buf_bytes < buf_bytes || sc.n_buf < nb || sc.pin_seg_bytes < seg_bytes || sc.pin_seg.size() < 2 * (size_t)threads || sc.acc_bytes < acc_bytes) {
             scan_cache_release(c);
             sc.buf_bytes = buf_bytes; sc.n_buf = nb; sc.pin_seg_bytes = seg_bytes; sc.acc_bytes = acc_bytes;
             for (int i = 0; i < 2; ++i) HIPCHK(c, hipMalloc((void**)&sc.acc[i], HEAD + acc_bytes));
-            for (unsigned i = 0; i < threads; ++i) {
-                uint8_t* p = nullptr; hipStream_t st = nullptr;
-                HIPCHK(c, hipHostMalloc((void**)&p, seg_bytes, hipHostMallocDefault));
-                sc.pin_seg.push_back(p);
+            for (unsigned i = 0; i < threads; ++i) {              // two pinned segments and one stream per reader
+                hipStream_t st = nullptr;
+                for (int h = 0; h < 2; ++h) {
+                    uint8_t* p = nullptr;
+                    HIPCHK(c, hipHostMalloc((void**)&p, seg_bytes, hipHostMallocDefault));
+                    sc.pin_seg.push_back(p);
+                }
                 HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
                 sc.seg_stream.push_back(st);
             }
@@ -174,42 +178,69 @@ struct RawFeeder {
     uint64_t batch_base(uint64_t b) const { return b ? b * (uint64_t)batch - PRE : 0; }
     uint64_t batch_hi_read(uint64_t b) const { return std::min<uint64_t>(size, (b + 1) * (uint64_t)batch + overlap); }
 
+    // A reader alternates between its two pinned segments: while the copy of one is on its way to the device the thread is already
+    // in pread for the other (one copy and one pread in flight per reader); a segment counts as done -- its pinned memory free again,
+    // its bytes the main thread's to scan -- when its copy has landed, which the thread learns one segment later.
     void read_loop(unsigned me) {
         hipSetDevice(c->device);
-        uint8_t* const mine = c->scan.pin_seg[me];
+        uint8_t* const seg_mem[2] = {c->scan.pin_seg[2 * me], c->scan.pin_seg[2 * me + 1]};
         const hipStream_t st = c->scan.seg_stream[me];
-        for (;;) {
+        hipEvent_t landed[2] = {nullptr, nullptr};
+        bool ev_ok = hipEventCreateWithFlags(&landed[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&landed[1], hipEventDisableTiming) == hipSuccess;
+        int64_t in_flight[2] = {-1, -1};                          // my-batch index j of the copy in flight from each segment
+        auto retire = [&](int h, bool ok) {                        // the copy from segment h has landed (or failed)
+            if (in_flight[h] < 0) return;
+            const double t0 = now_ms();
+            if (ok && hipEventSynchronize(landed[h]) != hipSuccess) ok = false;
+            us_h2d += (uint64_t)((now_ms() - t0) * 1e3);
+            { std::lock_guard<std::mutex> lk(mu); if (!ok) io_error = true; ++done_segs[(size_t)in_flight[h]]; }
+            in_flight[h] = -1;
+            cv.notify_all();
+        };
+        for (int h = 0;; h ^= 1) {
             uint64_t seg;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || io_error || next_seg >= my.size() * spb || next_seg / spb < consumed + 2; });
-                if (stop || io_error || next_seg >= my.size() * spb) return;
+                // (a reader that would have to wait for the main thread first lets its copy in flight land: the main thread may be waiting for exactly that segment)
+                while (!(stop || io_error || next_seg >= my.size() * spb || next_seg / spb < consumed + 2)) {
+                    if (in_flight[0] >= 0 || in_flight[1] >= 0) { lk.unlock(); retire(h, ev_ok); retire(h ^ 1, ev_ok); lk.lock(); continue; }
+                    cv.wait(lk);
+                }
+                if (stop || io_error || next_seg >= my.size() * spb) break;
                 seg = next_seg++;
             }
+            retire(h, ev_ok);                                       // this segment's previous copy: long landed, normally
+            uint8_t* const mine = seg_mem[h];
             const uint64_t j = seg / spb, s = seg % spb, b = my[j];
             const int buf = (int)(j & 1);
             // segment s of batch b: [b * batch + s * segment, ... + segment); the first one also reads PRE, the last one the overlap
             const uint64_t f0 = s ? b * (uint64_t)batch + s * (uint64_t)segment : batch_base(b);
             const uint64_t f1 = s + 1 == spb ? batch_hi_read(b) : std::min<uint64_t>(size, b * (uint64_t)batch + (s + 1) * (uint64_t)segment);
-            bool ok = true;
-            if (f0 < f1) {
+            bool ok = ev_ok;
+            if (ok && f0 < f1) {
+                const double ta = now_ms();
                 uint64_t got = 0;
                 while (got < f1 - f0) {
                     const ssize_t r = pread(fd, mine + got, (size_t)std::min<uint64_t>(f1 - f0 - got, (uint64_t)1 << 30), (off_t)(f0 + got));
                     if (r <= 0) { ok = false; break; }
                     got += (uint64_t)r;
                 }
-                // (done means landed: this thread's pinned segment is free again, and the main thread may scan the batch)
+                const double tb = now_ms();
+                us_pread += (uint64_t)((tb - ta) * 1e3);
                 if (ok && (hipMemcpyAsync(raw[buf] + (f0 - batch_base(b)), mine, (size_t)(f1 - f0), hipMemcpyHostToDevice, st) != hipSuccess ||
-                           hipStreamSynchronize(st) != hipSuccess)) ok = false;
+                           hipEventRecord(landed[h], st) != hipSuccess)) ok = false;
+                us_h2d += (uint64_t)((now_ms() - tb) * 1e3);
+                if (ok) { in_flight[h] = (int64_t)j; continue; }
             }
-            {
+            {                                                       // an empty segment, or an error: nothing in flight from it
                 std::lock_guard<std::mutex> lk(mu);
                 if (!ok) io_error = true;
                 ++done_segs[j];
             }
             cv.notify_all();
         }
+        retire(0, ev_ok); retire(1, ev_ok);
+        for (int h = 0; h < 2; ++h) if (landed[h]) hipEventDestroy(landed[h]);
     }
 
     // wait until every segment of batch b is in pinned memory and its copy enqueued, then until the copies have landed
@@ -412,7 +443,12 @@ struct RawFeeder {
         uint8_t carry[HEAD]; uint32_t carry_n = 0;                // last k-1 bytes of the base stream so far (host copy, for the fall-back)
         double ms_wait = 0, ms_scan = 0, ms_count = 0;
         const double t_run = now_ms();
-        struct Report { RawFeeder* f; double *w, *s, *n, t0; ~Report() { if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] device scan of %s: %.1f GB in %.0f ms (%.1f GB/s): waiting for readers + H2D %.0f ms, scan %.0f ms, waiting for the counter %.0f ms (it counted for %.0f ms); %u reader threads, %zu MiB segments, %zu MiB accumulated per count\n",
+        struct Report { RawFeeder* f; double *w, *s, *n, t0; ~Report() {
+            if (g_timing) fprintf(stderr, "katgpu_timing {\"file\": \"%s\", \"bytes\": %llu, \"wall_ms\": %.1f, \"reader_wait_ms\": %.1f, \"scan_ms\": %.1f, \"counter_wait_ms\": %.1f, \"counting_ms\": %.1f, "
+                                  "\"reader_threads\": %u, \"pread_ms_per_thread\": %.1f, \"h2d_ms_per_thread\": %.1f, \"segment_MiB\": %zu}\n",
+                                  f->path, (unsigned long long)f->size, now_ms() - t0, *w, *s, *n, f->worker_ms, (unsigned)f->n_readers,
+                                  f->us_pread.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->us_h2d.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->segment >> 20);
+            if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] device scan of %s: %.1f GB in %.0f ms (%.1f GB/s): waiting for readers + H2D %.0f ms, scan %.0f ms, waiting for the counter %.0f ms (it counted for %.0f ms); %u reader threads, %zu MiB segments, %zu MiB accumulated per count\n",
                                  since_load(), f->path, f->size / 1e9, now_ms() - t0, f->size / 1e6 / std::max(1.0, now_ms() - t0), *w, *s, *n, f->worker_ms, (unsigned)f->n_readers, f->segment >> 20, f->acc_bytes >> 20); } } report{this, &ms_wait, &ms_scan, &ms_count, t_run};
         struct StopWorker { RawFeeder* f; ~StopWorker() { f->stop_worker(); } } stop_w{this};
         worker = std::thread([this] { work(); });
