@@ -529,6 +529,13 @@ __device__ __forceinline__ uint64_t table_get_w(const DevTable& t, KeyW key, uin
     return 0;
 }
 
+// A lane's value for the whole wave, the lane wave-uniform (a ballot's first set bit, lane 0 ...): v_readlane_b32, a few cycles --
+// __shfl of a uniform lane is a ds_bpermute through the LDS crossbar, ~200 cycles of latency on gfx950 (tools/ubench_valu.hip).
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ uint64_t lane_value(uint64_t v, int src) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+}
+
 // flush a per-lane "new distinct" tally: wave reduction, lane 0 adds into one of 64 stripes
 __device__ __forceinline__ void flush_distinct(const DevTable& t, uint32_t new_distinct) {
     uint32_t v = new_distinct;

@@ -166,7 +166,7 @@ __device__ __forceinline__ void lds_inc_aggregated(uint32_t* bins, uint32_t idx,
     unsigned long long live = __ballot(active);
     if (!live) return;
     int leader = __ffsll((long long)live) - 1;
-    uint32_t lead_idx = __shfl(idx, leader, 64);
+    uint32_t lead_idx = lane_value(idx, leader);
     bool same = active && idx == lead_idx;
     unsigned long long peers = __ballot(same);
     if ((int)(threadIdx.x & 63) == leader) atomicAdd(&bins[lead_idx], (uint32_t)__popcll(peers));

@@ -212,8 +212,9 @@ constexpr int P1_LANES_WITH_STARTS = P1_TILE_STARTS / PART_ITEMS; // 510
 
 // ---- the level-1 buffer ----
 // A level-1 item is r1 = the k-mer's low n1 bits (kg_device.hpp "placement": the bucket says the rest), kept like a level-2 item: the
-// low 32 bits + HB1 = 0, 1, 2 or 4 bytes of high bits, in groups of four = 16 + 4 HB1 contiguous bytes (24 at the bench size: 6 bytes
-// per k-mer where the k-mer itself took 8; level 2 loads a group with two instructions).  Bucket b's groups start at byte
+// low 32 bits + HB1 = 0, 1 or 2 bytes of high bits, in groups of four = 16 + 4 HB1 contiguous bytes (24 at the bench size: 6 bytes
+// per k-mer where the k-mer itself took 8; level 2 loads a group with two instructions); items of more than 48 bits (HB1 = 4) are plain
+// 64-bit words, one store each.  Bucket b's groups start at byte
 // l1_bucket_base(first item of b, b): the buffer keeps 8 bytes per item whatever the group size, because a pass's part of it, once
 // its level 2 is through, is the spill list of that pass's apply -- 8-byte k-mers, as many as there were items in the worst case.
 // The all-ones item is "no item" (segment padding): n1 < 8 (4 + HB1) wherever this path runs (part_geometry).
@@ -221,10 +222,10 @@ __device__ __host__ __forceinline__ uint64_t l1_bucket_base(uint64_t first_item,
 template <uint32_t HB1>
 __device__ __forceinline__ void l1_put(uint8_t* __restrict__ bucket, uint64_t group_byte, uint32_t q, uint32_t lo, uint32_t hi) {
     uint8_t* grp = bucket + group_byte;
+    if (HB1 == 4) { reinterpret_cast<uint64_t*>(grp)[q] = ((uint64_t)hi << 32) | lo; return; }      // 8-byte items: as they are, one store (a "group" is four of them)
     reinterpret_cast<uint32_t*>(grp)[q] = lo;
     if (HB1 == 1) grp[16 + q] = (uint8_t)hi;
     else if (HB1 == 2) reinterpret_cast<uint16_t*>(grp + 16)[q] = (uint16_t)hi;
-    else if (HB1 == 4) reinterpret_cast<uint32_t*>(grp + 16)[q] = hi;
 }
 __device__ __forceinline__ void l1_put_any(uint8_t* __restrict__ bucket, uint64_t group_byte, uint32_t q, uint32_t hb1, uint32_t lo, uint32_t hi) {
     if (hb1 == 0) l1_put<0>(bucket, group_byte, q, lo, hi);
@@ -670,46 +671,35 @@ struct TileItems {
         return ((uint64_t)h << 32) | lo[j];
     }
 };
-template <int N, int HB1>
-__device__ __forceinline__ uint32_t p2_tile_load_hb(const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, HB1 == 4>& it) {
+// the wide form (HB1 = 4): 64-bit items, two to a 16-byte load
+template <int N>
+__device__ __forceinline__ uint32_t p2_tile_load_wide(const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, true>& it) {
     // Unconditional loads (a load inside a branch is waited for at the end of the branch: the compiler once pulled a padding test
     // into the branch of each load -- sixteen serialised round trips to HBM, 29 K of a tile's 54 K cycles), and not even a clamped
-    // index: what lies behind a bucket's last group is the next bucket, and behind the level-1 buffer the level-2 buffer (the arena
-    // carve, kg_count.hip), so a tile's N / 4 groups per lane are always mapped memory; what they hold is masked below.
-    static_assert(N % 4 == 0, "whole groups");
-    constexpr uint32_t HI_NONE = HB1 == 0 ? 0u : HB1 == 1 ? 0xFFu : HB1 == 2 ? 0xFFFFu : 0xFFFFFFFFu;
-    // everything below the tile's first group is 32-bit: items counted from the tile's start
+    // index: what lies behind a bucket's last item is the next bucket, and behind the level-1 buffer the level-2 buffer (the arena
+    // carve, kg_count.hip), so a tile's loads are always of mapped memory; what they hold is masked below.
+    static_assert(N % 2 == 0, "pairs");
     const uint64_t left = n_items - tbeg;                                      // (tbeg < n_items)
     const uint32_t t_items = left < (uint64_t)N * PART_BLOCK ? (uint32_t)left : (uint32_t)N * PART_BLOCK;
-    const uint8_t* mine = bucket + (tbeg >> 2) * L2Fmt<HB1>::GS + threadIdx.x * L2Fmt<HB1>::GS;
-    u32x4 lo[N / 4];
-    typename HiGroup<HB1>::type hi[N / 4];
+    const uint8_t* mine = bucket + (tbeg + 2 * threadIdx.x) * 8;
+    u32x4 w[N / 2];
 #pragma unroll
-    for (int u = 0; u < N / 4; ++u) {
-        hi[u] = typename HiGroup<HB1>::type{};
-        l2_load_group<HB1>(mine, (uint64_t)u * PART_BLOCK, lo[u], hi[u]);
-    }
+    for (int u = 0; u < N / 2; ++u) w[u] = *reinterpret_cast<const u32x4_a4*>(mine + (uint64_t)u * PART_BLOCK * 16);
     uint32_t valid = 0;
 #pragma unroll
-    for (int u = 0; u < N / 4; ++u) {
-        const uint32_t i0 = 4 * ((uint32_t)u * PART_BLOCK + threadIdx.x);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t l = q == 0 ? lo[u].x : q == 1 ? lo[u].y : q == 2 ? lo[u].z : lo[u].w, h = hi_of_group<HB1>(hi[u], q);
-            it.lo[4 * u + q] = l;
-            if (HB1 == 4) it.hi[4 * u + q] = h;
-            valid |= (i0 + q < t_items && !(l == 0xFFFFFFFFu && h == HI_NONE)) ? 1u << (4 * u + q) : 0u;
-        }
-        if (HB1 != 4) {                                                       // two high parts to a register
-            it.hi[2 * u] = hi_of_group<HB1>(hi[u], 0) | (hi_of_group<HB1>(hi[u], 1) << 16);
-            it.hi[2 * u + 1] = hi_of_group<HB1>(hi[u], 2) | (hi_of_group<HB1>(hi[u], 3) << 16);
-        }
+    for (int u = 0; u < N / 2; ++u) {
+        const uint32_t i0 = 2 * ((uint32_t)u * PART_BLOCK + threadIdx.x);
+        it.lo[2 * u] = w[u].x; it.hi[2 * u] = w[u].y; it.lo[2 * u + 1] = w[u].z; it.hi[2 * u + 1] = w[u].w;
+        valid |= (i0 < t_items && (w[u].x & w[u].y) != 0xFFFFFFFFu) ? 1u << (2 * u) : 0u;
+        valid |= (i0 + 1 < t_items && (w[u].z & w[u].w) != 0xFFFFFFFFu) ? 1u << (2 * u + 1) : 0u;
     }
     return valid;
 }
 // The narrow forms (HB1 = 0, 1, 2) in ONE code path -- a three-way switch over the templated loader left the compiler with three
 // sets of values to keep (18 spilled registers at the bench's shape): 16 + 8 bytes are loaded per group whatever HB1 is (what lies
-// behind a shorter group is the next group: mapped, ignored), and one v_perm_b32 per register puts the high parts where TileItems
+// behind a shorter group is the next group, behind a bucket's last one the next bucket, behind the level-1 buffer the level-2 buffer
+// -- mapped, ignored; loads are unconditional because a load inside a branch is waited for at the end of the branch), and one
+// v_perm_b32 per register puts the high parts where TileItems
 // wants them, its selector chosen by HB1 (wave-uniform).
 template <int N>
 __device__ __forceinline__ uint32_t p2_tile_load_narrow(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, false>& it) {
@@ -747,7 +737,7 @@ __device__ __forceinline__ uint32_t p2_tile_load_narrow(uint32_t hb1, const uint
 }
 template <int N, bool W1>
 __device__ __forceinline__ uint32_t p2_tile_load(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, W1>& it) {
-    if constexpr (W1) return p2_tile_load_hb<N, 4>(bucket, tbeg, n_items, it);
+    if constexpr (W1) return p2_tile_load_wide<N>(bucket, tbeg, n_items, it);
     else return p2_tile_load_narrow<N>(hb1, bucket, tbeg, n_items, it);
 }
 
@@ -1081,9 +1071,9 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                 while (todo) {
                     const int src = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    const unsigned long long ck = __shfl(key, src, 64);                      // wave-uniform from here on
-                    uint32_t cs = __shfl(slot, src, 64);
-                    int cb = (int)__shfl(budget, src, 64);
+                    const unsigned long long ck = lane_value((uint64_t)key, src);            // wave-uniform from here on
+                    uint32_t cs = lane_value(slot, src);
+                    int cb = (int)lane_value(budget, src);
 #pragma unroll 1
                     for (;;) {
                         uint32_t idx = cs + lane; if (idx >= S) idx -= S;                      // S >= 64 on this path (host-checked)
@@ -1100,7 +1090,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                         if (!((mk >> first) & 1)) {                                            // EMPTY comes first: claim it
                             unsigned long long old = EMPTY;
                             if ((int)lane == first) old = atomicCAS(&rk[idx], (unsigned long long)EMPTY, ck);
-                            old = __shfl(old, first, 64);
+                            old = lane_value((uint64_t)old, first);
                             if (old == EMPTY) { if ((int)lane == first) ++new_distinct; }
                             else got = old;
                         }
@@ -1123,7 +1113,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
             auto grab = [&]() -> uint64_t {
                 unsigned long long v = 0;
                 if (lane == 0) v = atomicAdd(&s_next_chunk, 1ULL);
-                return __shfl(v, 0, 64);
+                return lane_value((uint64_t)v, 0);
             };
             for (uint64_t c = wave; c < n_chunks;) {
                 const unsigned long long t_a = now();
@@ -1187,18 +1177,20 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                 const unsigned long long t_c = now();
                 // survivors -> queue (q_n <= 64 here).  Normal case: one wave-wide prefix sum; a chunk with more survivors than the
                 // queue holds (a nearly empty table: every k-mer is new) goes in one k-mer column at a time.
-                uint32_t mine = 0;
+                unsigned long long pm_u[U];                           // (ballots, not a shuffle scan: see k_p3_apply_pk)
+                uint32_t total = 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u) mine += pend[u] ? 1u : 0u;
-                uint32_t tot = mine;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(tot, d, 64); if (lane >= (uint32_t)d) tot += o; }
-                const uint32_t total = __shfl(tot, 63, 64);
+                for (int u = 0; u < U; ++u) { pm_u[u] = __ballot(pend[u]); total += (uint32_t)__popcll(pm_u[u]); }
                 if (total <= QCAP - 64) {
-                    uint32_t at = q_n + tot - mine;
+                    uint32_t at = q_n;
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (pend[u]) { wqk[at] = cur[u]; wqs[at] = slot[u] | ((S - NR) << 16); ++at; }
+                    for (int u = 0; u < U; ++u) {
+                        if (pend[u]) {
+                            const uint32_t i = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm_u[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm_u[u], 0));
+                            wqk[i] = cur[u]; wqs[i] = slot[u] | ((S - NR) << 16);
+                        }
+                        at += (uint32_t)__popcll(pm_u[u]);
+                    }
                     q_n += total;
                 } else {
                     uint32_t pm = 0;
@@ -1369,9 +1361,9 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                 while (todo) {
                     const int src = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    const unsigned long long ck = __shfl((unsigned long long)rem, src, 64);  // wave-uniform from here on
-                    uint32_t cs = __shfl(slot, src, 64);
-                    int cbud = (int)__shfl(budget, src, 64);
+                    const unsigned long long ck = lane_value((uint64_t)rem, src);            // wave-uniform from here on
+                    uint32_t cs = lane_value(slot, src);
+                    int cbud = (int)lane_value(budget, src);
 #pragma unroll 1
                     for (;;) {
                         uint32_t idx = cs + lane; if (idx >= S) idx -= S;                      // S >= 64 on this path (host-checked)
@@ -1387,7 +1379,7 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                         if ((mk >> first) & 1) { if ((int)lane == first) add1(idx); break; }
                         unsigned long long old = 0;                                            // a free slot comes first: claim it
                         if ((int)lane == first) old = atomicCAS(&rk[idx], 0ULL, (unsigned long long)((ck << cb) | 1ULL));
-                        old = __shfl(old, first, 64);
+                        old = lane_value((uint64_t)old, first);
                         if (old == 0) { if ((int)lane == first) ++new_distinct; break; }
                         if ((old >> cb) == ck) { if ((int)lane == first) add1(idx); break; }   // the same k-mer got there first
                         cbud -= first; cs = cs + first >= S ? cs + first - S : cs + first;     // someone else's k-mer landed there: go on from that slot
@@ -1404,7 +1396,7 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
             auto grab = [&]() -> uint64_t {
                 unsigned long long v = 0;
                 if (lane == 0) v = atomicAdd(&s_next_chunk, 1ULL);
-                return __shfl(v, 0, 64);
+                return lane_value((uint64_t)v, 0);
             };
             for (uint64_t c = wave; c < n_chunks;) {
                 const uint64_t c_next = grab();
@@ -1459,18 +1451,19 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                 }
                 // survivors -> queue.  Normal case: one wave-wide prefix sum; a chunk with more survivors than the queue has room for
                 // goes in one k-mer column at a time.
-                uint32_t mine = 0;
+                // (ballots, not a shuffle scan: six dependent ds_bpermute -- ~200 cycles each on gfx950, tools/ubench_valu.hip -- were a
+                // third of a chunk's time; a ballot and a bit count are a handful of cycles)
+                unsigned long long pm_u[U];
+                uint32_t total = 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u) mine += pend[u] ? 1u : 0u;
-                uint32_t tot = mine;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(tot, d, 64); if (lane >= (uint32_t)d) tot += o; }
-                const uint32_t total = __shfl(tot, 63, 64);
+                for (int u = 0; u < U; ++u) { pm_u[u] = __ballot(pend[u]); total += (uint32_t)__popcll(pm_u[u]); }
                 if (q_n + total <= qcap) {
-                    uint32_t at = q_n + tot - mine;
+                    uint32_t at = q_n;
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (pend[u]) { wq[at] = rem[u] | ((unsigned long long)slot[u] << APK_SLOT_SHIFT); ++at; }
+                    for (int u = 0; u < U; ++u) {
+                        if (pend[u]) wq[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm_u[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm_u[u], 0))] = rem[u] | ((unsigned long long)slot[u] << APK_SLOT_SHIFT);
+                        at += (uint32_t)__popcll(pm_u[u]);
+                    }
                     q_n += total;
                 } else {
                     uint32_t pm = 0;
