@@ -97,6 +97,8 @@ static const uint64_t g_test_ap_seg = hook_u64("KATGPU_TEST_AP_SEG", 0) & ~3ULL;
 static const uint32_t g_apply_nr = (uint32_t)hook_u64("KATGPU_APPLY_NR", 2);            // A/B: probe rounds of the packed apply at the bench's shape (1, 2 or 3)
 static const uint32_t g_apply_min_q = (uint32_t)hook_u64("KATGPU_APPLY_MIN_Q", 72);     // A/B: queue entries per wave the SECOND workgroup of a CU must leave (>= 72)
 static const uint32_t g_apply_per_cu = (uint32_t)hook_u64("KATGPU_APPLY_PER_CU", 0);   // A/B: packed apply workgroups per CU (0: as many as the LDS holds)
+static const uint32_t g_apply_ug = (uint32_t)hook_u64("KATGPU_APPLY_UG", 1);           // A/B: groups per lane and chunk in the bench-shape apply (1 or 2)
+static const bool g_apply_stamp = hook_u64("KATGPU_APPLY_STAMP", 0) != 0;              // diagnostic: the bench-shape apply with cycle stamps (printed per pass)
 
 static const uint32_t g_test_hb = hook("KATGPU_TEST_HB") ? (uint32_t)strtoul(hook("KATGPU_TEST_HB"), nullptr, 10) : 0;   // A/B: wider level-2 items than needed (1, 2, 4)
 static bool part_geometry(const DevTable& d, PartGeom* g) {
@@ -227,6 +229,10 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
             else if (g.S <= 4096) { if (fresh) KG_APK(512, 4, HB, true, false, true, 3); else KG_APK(512, 4, HB, false, false, true, 2); } \
             else if (HB == 1 && g_apply_nr == 1 && !fresh) KG_APK(512, 10, 1, false, false, false, 1); \
             else if (HB == 1 && g_apply_nr == 3 && !fresh) KG_APK(512, 10, 1, false, false, false, 3); \
+            else if (HB == 1 && g_apply_stamp && !fresh) { KG_LDS_ATTR((k_p3_apply_pk<512, 10, 1, false, false, false, 2, true>), LDS_BYTES - 256); \
+                hipLaunchKernelGGL((k_p3_apply_pk<512, 10, 1, false, false, false, 2, true>), grid, dim3(512), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, qcap, seg_len, g_test_spill_mod); } \
+            else if (HB == 1 && g_apply_ug == 2 && !fresh) { KG_LDS_ATTR((k_p3_apply_pk<512, 10, 1, false, false, false, 2, false, 2>), LDS_BYTES - 256); \
+                hipLaunchKernelGGL((k_p3_apply_pk<512, 10, 1, false, false, false, 2, false, 2>), grid, dim3(512), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, qcap, seg_len, g_test_spill_mod); } \
             else { if (fresh) KG_APK(512, 10, HB, true, false, false, 3); else KG_APK(512, 10, HB, false, false, false, 2); } \
             break;
         switch (g.hb) { KG_APK_SHAPE(0) KG_APK_SHAPE(1) KG_APK_SHAPE(2) default: return fail(c, KATGPU_ERR_DEVICE, "packed apply: item width %u", g.hb); }
@@ -334,6 +340,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     a += align_up((size_t)MAX_PARTS * 4, 256);
     unsigned long long* spill_n = (unsigned long long*)a;
     unsigned long long* ovf_n = spill_n + 1;      a += 256;
+    if (g_apply_stamp) HIPCHK(c, hipMemset(spill_n + 8, 0, 7 * sizeof(unsigned long long)));
     const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / per_item));
     const size_t l1_items = round_items + round_items / 24 + fixed_l1;
     const size_t l2_items = ((size_t)((double)l1_items * l2_items_per_l1_item(hb0) / passes0) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 4096 + 3) & ~(size_t)3;
@@ -534,6 +541,14 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 unsigned long long spilled = 0;
                 HIPCHK(c, hipMemcpyAsync(&spilled, spill_n, sizeof spilled, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (g_apply_stamp) {
+                    unsigned long long st[7];
+                    HIPCHK(c, hipMemcpy(st, spill_n + 8, sizeof st, hipMemcpyDeviceToHost));
+                    HIPCHK(c, hipMemset(spill_n + 8, 0, sizeof st));
+                    const double tot = (double)(st[0] + st[1] + st[3] + st[4]);
+                    if (st[5]) fprintf(stderr, "[katgpu] apply stamps (wave 0 of every workgroup, cycles summed): fill %.3g (%.0f %%)  walk %.3g (%.0f %%; drains %.0f %% of the walk)  barrier + sweep %.3g (%.0f %%)  write-back %.3g (%.0f %%); %llu regions, %.1f chunks per wave and region, %.0f cycles per region\n",
+                                       (double)st[0], 100 * st[0] / tot, (double)st[1], 100 * st[1] / tot, 100.0 * st[2] / std::max(1.0, (double)st[1]), (double)st[3], 100 * st[3] / tot, (double)st[4], 100 * st[4] / tot, st[5], (double)st[6] / st[5], tot / st[5]);
+                }
                 if (spilled > g.spill_cap)       // (more k-mers without a slot than the pass's segments were sized for: a table far too small, met by a 5-sigma round)
                     return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full: %llu k-mers of a partition pass found no slot (the list holds %llu); raise the size hint", spilled, (unsigned long long)g.spill_cap);
                 if (spilled) lists.push_back({spill_buf, spilled});

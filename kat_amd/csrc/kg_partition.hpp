@@ -1252,14 +1252,16 @@ constexpr uint32_t APK_SLOT_SHIFT = 44;
 
 template <int BLOCK, int KP /* 16-byte loads per lane that cover a region: two slots each */, int HB, bool INLINE_CLAIM = false, bool TEST_SPILL = false,
           bool PF = true /* the next region travels from HBM into registers behind the walk of this one (2 KP VGPRs across the walk); false: loaded when its turn comes -- for shapes with a second workgroup on the CU to cover that */,
-          int NR = 3 /* probe rounds before a k-mer goes to the queue */>
+          int NR = 3 /* probe rounds before a k-mer goes to the queue */,
+          bool STAMP = false /* diagnostic (KATGPU_APPLY_STAMP): wave 0's cycles per phase, added into spill_n[8 ..]: [8] fill, [9] walk, [10] of it drains, [11] wait for the other waves + sweep, [12] write-back, [13] regions, [14] chunks */,
+          int UG = 1 /* groups of the level-2 buffer a lane takes per chunk: 4 UG k-mers in flight per lane and probe round */>
 __global__ void __launch_bounds__(BLOCK, 4)    // four waves per SIMD (128 VGPRs): two 512-thread workgroups or one of 1024 threads (a 768-thread shape at six waves spilled: 225 ms against 177)
 k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend,
               uint32_t qcap /* queue entries per wave: what the region leaves of the LDS; >= 72 */, uint64_t seg_len /* k-mers per walk: a multiple of 4 below half the count range */,
               uint32_t spill_mod) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int NW = BLOCK / 64, U = 4;
+    constexpr int NW = BLOCK / 64, U = 4 * UG;
     constexpr uint32_t CH = 64 * U;
     const uint32_t S = g.S, cb = g.cbits;                     // S % 4 == 0 (host-checked)
     const uint64_t cmask = pk_cmask(cb), half = pk_half(cb), rem_mask = (1ULL << APK_SLOT_SHIFT) - 1;
@@ -1291,11 +1293,14 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
     uint32_t* rk32 = reinterpret_cast<uint32_t*>(rk);
     auto add1 = [&](uint32_t slot) { (void)__hip_atomic_fetch_add(&rk32[2 * slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
+    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return STAMP ? (unsigned long long)clock64() : 0ULL; };
     uint32_t r = next_region(g.b_lo * g.P2 + blockIdx.x);
     if (PF && r < r_hi) prefetch(r);
     while (r < r_hi) {
         const uint64_t beg = off2[r], end = cnt2 ? beg + cnt2[r] : run_end(r);
         const uint64_t base = (uint64_t)r * S;
+        const unsigned long long t_fill = now();
         // ---- fill: registers -> LDS ----
         if (!PF) prefetch(r);
 #pragma unroll
@@ -1309,6 +1314,8 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
             const uint64_t n_run = (end - sbeg < seg_len ? end - sbeg : seg_len);
             if (tid == 0) s_next_chunk = NW;                  // chunks 0 .. NW-1 are the waves' first ones
             lds_barrier();
+            const unsigned long long t_walk = now();
+            st[0] += t_walk - t_fill;
 
             // ---- the walk ----
             uint32_t q_n = 0;                                     // entries in this wave's queue (wave-uniform)
@@ -1316,6 +1323,8 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
             // claim, while at least 8 lanes are busy and for at most APK_LANE_PROBES probes.  Phase 2: what is left is on a long
             // chain: the WAVE finishes such a k-mer, 64 consecutive slots per read.
             auto drain_pass = [&](bool fin /* nothing will follow: leave no entry behind */) {
+                const unsigned long long t_dr = now();
+                struct DrainStamp { unsigned long long& acc; unsigned long long t0; bool on; __device__ ~DrainStamp() { if (on) acc += (unsigned long long)clock64() - t0; } } drain_stamp{st[2], t_dr, STAMP};
                 const uint32_t take = q_n < 64 ? q_n : 64;
                 q_n -= take;
                 bool live = lane < take;
@@ -1389,10 +1398,15 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
 
             const uint64_t n_chunks = (n_run + CH - 1) / CH;         // chunk c = groups [64 c, 64 c + 64) of the run
             const uint64_t n_grp = (n_run + 3) >> 2, g0 = sbeg >> 2;      // (runs start on group boundaries and end on "no item" padding)
-            u32x4 c_lo, n_lo;
-            typename HiGroup<HB>::type c_hi{}, n_hi{};
-            bool c_in, n_in;                                      // the lane's group lies inside the run
-            { const uint64_t gi = (uint64_t)wave * 64 + lane; c_in = gi < n_grp; l2_load_group<HB>(l2_buf, g0 + (c_in ? gi : 0), c_lo, c_hi); }
+            u32x4 c_lo[UG], n_lo[UG];
+            typename HiGroup<HB>::type c_hi[UG], n_hi[UG];
+            bool c_in[UG], n_in[UG];                              // the lane's group lies inside the run
+#pragma unroll
+            for (int gq = 0; gq < UG; ++gq) {
+                const uint64_t gi = ((uint64_t)wave * UG + gq) * 64 + lane;
+                c_in[gq] = gi < n_grp; c_hi[gq] = typename HiGroup<HB>::type{}; n_hi[gq] = typename HiGroup<HB>::type{};
+                l2_load_group<HB>(l2_buf, g0 + (c_in[gq] ? gi : 0), c_lo[gq], c_hi[gq]);
+            }
             auto grab = [&]() -> uint64_t {
                 unsigned long long v = 0;
                 if (lane == 0) v = atomicAdd(&s_next_chunk, 1ULL);
@@ -1400,18 +1414,20 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
             };
             for (uint64_t c = wave; c < n_chunks;) {
                 const uint64_t c_next = grab();
-                {                                             // next chunk: in flight behind this one (unconditional loads from a clamped index)
-                    const uint64_t gi = c_next * 64 + lane;
-                    n_in = gi < n_grp;
-                    l2_load_group<HB>(l2_buf, g0 + (n_in ? gi : 0), n_lo, n_hi);
+#pragma unroll
+                for (int gq = 0; gq < UG; ++gq) {             // next chunk: in flight behind this one (unconditional loads from a clamped index)
+                    const uint64_t gi = (c_next * UG + gq) * 64 + lane;
+                    n_in[gq] = gi < n_grp;
+                    l2_load_group<HB>(l2_buf, g0 + (n_in[gq] ? gi : 0), n_lo[gq], n_hi[gq]);
                 }
                 uint64_t rem[U];
                 uint32_t slot[U];
                 bool pend[U];                                     // k-mer u still to be placed (lane masks in SGPRs)
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    rem[u] = ((uint64_t)hi_of_group<HB>(c_hi, u) << 32) | (u == 0 ? c_lo.x : u == 1 ? c_lo.y : u == 2 ? c_lo.z : c_lo.w);
-                    pend[u] = c_in && rem[u] != L2Fmt<HB>::NONE;
+                    const int gq = u >> 2, q = u & 3;
+                    rem[u] = ((uint64_t)hi_of_group<HB>(c_hi[gq], q) << 32) | (q == 0 ? c_lo[gq].x : q == 1 ? c_lo[gq].y : q == 2 ? c_lo[gq].z : c_lo[gq].w);
+                    pend[u] = c_in[gq] && rem[u] != L2Fmt<HB>::NONE;
                     slot[u] = place_offset(rem[u], g.pl, S);
                     if (TEST_SPILL && spill_mod && pend[u] && __umulhi((uint32_t)(mix64(place_key_d(rd1, rd2, rem[u], g.pl)) >> 32), spill_mod) == 0) { spill_rem(rem[u]); pend[u] = false; }
                 }
@@ -1457,6 +1473,7 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                 uint32_t total = 0;
 #pragma unroll
                 for (int u = 0; u < U; ++u) { pm_u[u] = __ballot(pend[u]); total += (uint32_t)__popcll(pm_u[u]); }
+                if (UG > 1) while (q_n && q_n + total > qcap) drain_pass(false);    // (twice the k-mers per chunk: make room first)
                 if (q_n + total <= qcap) {
                     uint32_t at = q_n;
 #pragma unroll
@@ -1486,9 +1503,13 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                 }
                 const bool last = c_next >= n_chunks;                     // the wave's last chunk empties the queue
                 while (q_n > (last ? 0u : 64u)) drain_pass(last);
-                c_lo = n_lo; c_hi = n_hi; c_in = n_in;
+#pragma unroll
+                for (int gq = 0; gq < UG; ++gq) { c_lo[gq] = n_lo[gq]; c_hi[gq] = n_hi[gq]; c_in[gq] = n_in[gq]; }
                 c = c_next;
+                if (STAMP) st[6] += 1;
             }
+            const unsigned long long t_post = now();
+            st[1] += t_post - t_walk;
             // ---- back to the invariant (kg_device.hpp: table_add_pk): a slot counts 1 .. half, the rest goes to the side table.  The walk
             // found every counter there and added less than half, so none has carried; each lane looks at the slots it filled. ----
             lds_barrier();                                        // every wave's adds of this segment are in (and no wave grabs chunks any more)
@@ -1508,16 +1529,20 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                     ovf_add(t, base + i + j, c - keep);
                 }
             }
+            if (STAMP) st[3] += now() - t_post;
         }
         if (PF && rn < r_hi) prefetch(rn);                     // in flight behind the write-back
 
         // ---- write-back: LDS -> HBM, 16 bytes per lane and store ----
         lds_barrier();
+        const unsigned long long t_wb = now();
 #pragma unroll
         for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(t.keys + base + i) = *reinterpret_cast<const u32x4*>(rk + i); }
         lds_barrier();
+        if (STAMP) { st[4] += now() - t_wb; st[5] += 1; }
         r = rn;
     }
+    if (STAMP && tid == 0) { for (int i = 0; i < 7; ++i) atomicAdd(&spill_n[8 + i], st[i]); }
     flush_distinct(t, new_distinct);
 }
 
