@@ -38,6 +38,10 @@ katgpu_ctx* Engine::ctx() {
         int rc = katgpu_init(dev, &g_ctx);
         timing_line("device_init", timing_now_ms() - t0);
         if (rc) throw std::runtime_error("katgpu_init failed (status " + std::to_string(rc) + "): no gfx950 device; this build has no CPU path");
+        // --gpus N: the ranks meet NOW, right after the fork, while all of them are known to be alive -- not at the first exchange, which
+        // a rank reaches when it has counted its share: whole files (gzip, FASTA) are dealt rank by rank, and ranks finishing minutes
+        // apart would run into the rendezvous' time-outs although nothing is wrong
+        if (dist_ && world_ > 1) comm();
     }
     return g_ctx;
 }

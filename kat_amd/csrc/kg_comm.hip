@@ -80,7 +80,11 @@ struct ShmHeader {
     std::atomic<uint32_t> generation;
     std::atomic<uint32_t> attached;
     uint32_t world;
+    std::atomic<uint32_t> aborted;   // a rank that fails inside a collective raises it: its peers leave their barriers with an error instead of waiting for ever
 };
+// how long a rank waits for its peers at a barrier or for a transfer to land before it gives up (a peer that died, a wedged link): the
+// run then ends with an error through katgpu_last_error instead of hanging until someone kills it
+static const double g_comm_timeout_ms = 1e3 * (getenv("KATGPU_COMM_TIMEOUT_S") ? std::max(1.0, atof(getenv("KATGPU_COMM_TIMEOUT_S"))) : 600.0);
 
 struct Msg { int peer; void* dev; size_t bytes; };          // one side of a point-to-point transfer (device memory)
 
@@ -108,6 +112,7 @@ int comm_fail(katgpu_comm* m, int code, const char* fmt, ...) {
     char buf[1024];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     if (m && m->ctx) m->ctx->err = buf;
+    if (m && m->hdr) m->hdr->aborted.store(1, std::memory_order_release);      // the peers are, or will be, waiting for this rank
     return code;
 }
 #define NCCLCHK(m, expr)                                                                                               \
@@ -122,16 +127,37 @@ std::string shm_name(const std::string& token, const char* what, uint64_t seq = 
     return buf;
 }
 
-// every rank of the communicator: wait until all have arrived
-void shm_barrier(katgpu_comm* m) {
-    if (m->world == 1) return;
+// every rank of the communicator: wait until all have arrived -- or until a peer has failed (ShmHeader::aborted) or the time-out passed
+int shm_barrier(katgpu_comm* m) {
+    if (m->world == 1) return KATGPU_OK;
+    if (m->hdr->aborted.load(std::memory_order_acquire)) return comm_fail(m, KATGPU_ERR_DEVICE, "a peer rank failed (rank %d leaves the barrier)", m->rank);
     const uint32_t gen = m->hdr->generation.load(std::memory_order_acquire);
     if (m->hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)m->world) {
         m->hdr->arrived.store(0, std::memory_order_relaxed);
         m->hdr->generation.store(gen + 1, std::memory_order_release);
     } else {
-        for (uint32_t spins = 0; m->hdr->generation.load(std::memory_order_acquire) == gen; ++spins)
-            if (spins > 1000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        const double t0 = now_ms();
+        for (uint32_t spins = 0; m->hdr->generation.load(std::memory_order_acquire) == gen; ++spins) {
+            if (spins <= 1000) continue;
+            if (m->hdr->aborted.load(std::memory_order_acquire)) return comm_fail(m, KATGPU_ERR_DEVICE, "a peer rank failed (rank %d leaves the barrier)", m->rank);
+            if (now_ms() - t0 > g_comm_timeout_ms) return comm_fail(m, KATGPU_ERR_DEVICE, "rank %d waited %.0f s at a barrier for its peers (KATGPU_COMM_TIMEOUT_S)", m->rank, g_comm_timeout_ms / 1e3);
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+    return KATGPU_OK;
+}
+// wait for the transport stream (or an event on it) the same way: a collective whose peer never posts its side would sit in
+// hipStreamSynchronize for ever
+int comm_wait(katgpu_comm* m, hipEvent_t ev /* or null: the whole stream */, const char* what) {
+    const double t0 = now_ms();
+    for (uint32_t spins = 0;; ++spins) {
+        const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(m->stream);
+        if (e == hipSuccess) return KATGPU_OK;
+        if (e != hipErrorNotReady) return comm_fail(m, KATGPU_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+        if (spins < 2000) continue;
+        if (m->hdr && m->hdr->aborted.load(std::memory_order_acquire)) return comm_fail(m, KATGPU_ERR_DEVICE, "%s: a peer rank failed", what);
+        if (now_ms() - t0 > g_comm_timeout_ms) return comm_fail(m, KATGPU_ERR_DEVICE, "%s: rank %d waited %.0f s for the transfer (KATGPU_COMM_TIMEOUT_S)", what, m->rank, g_comm_timeout_ms / 1e3);
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
 }
 
@@ -140,10 +166,10 @@ int host_allgather(katgpu_comm* m, const void* mine, size_t n, void* out) {
     if (n > MAILBOX) return comm_fail(m, KATGPU_ERR_INVALID_ARG, "host_allgather: %zu bytes per rank", n);
     if (m->world == 1) { memcpy(out, mine, n); return KATGPU_OK; }
     memcpy(m->boxes + (size_t)m->rank * MAILBOX, mine, n);
-    shm_barrier(m);
+    int rc = shm_barrier(m);
+    if (rc) return rc;
     for (int r = 0; r < m->world; ++r) memcpy((uint8_t*)out + (size_t)r * n, m->boxes + (size_t)r * MAILBOX, n);
-    shm_barrier(m);
-    return KATGPU_OK;
+    return shm_barrier(m);
 }
 
 int ensure_host_stage(katgpu_comm* m, size_t bytes) {
@@ -184,7 +210,7 @@ int transfer(katgpu_comm* m, const std::vector<Msg>& sends, const std::vector<Ms
     for (auto& s : sends) {
         const int idx = nth[s.peer]++;
         if (!s.bytes) continue;
-        HIPCHK(c, hipMemcpy(m->host_stage, s.dev, s.bytes, hipMemcpyDeviceToHost));
+        if (hipMemcpy(m->host_stage, s.dev, s.bytes, hipMemcpyDeviceToHost) != hipSuccess) return comm_fail(m, KATGPU_ERR_DEVICE, "staging a message for rank %d", s.peer);
         const std::string name = shm_name(m->token, "x", seq, m->rank, s.peer, idx);
         const int fd = ::open(name.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0600);
         if (fd < 0) return comm_fail(m, KATGPU_ERR_IO, "cannot create %s", name.c_str());
@@ -193,7 +219,8 @@ int transfer(katgpu_comm* m, const std::vector<Msg>& sends, const std::vector<Ms
         ::close(fd);
         m->bytes_sent += s.bytes;
     }
-    shm_barrier(m);
+    rc = shm_barrier(m);
+    if (rc) return rc;
     std::fill(nth.begin(), nth.end(), 0);
     for (auto& r : recvs) {
         const int idx = nth[r.peer]++;
@@ -205,13 +232,12 @@ int transfer(katgpu_comm* m, const std::vector<Msg>& sends, const std::vector<Ms
         while (off < r.bytes) { const ssize_t g = ::read(fd, m->host_stage + off, r.bytes - off); if (g <= 0) { ::close(fd); return comm_fail(m, KATGPU_ERR_IO, "short read from %s", name.c_str()); } off += (size_t)g; }
         ::close(fd);
         ::unlink(name.c_str());
-        HIPCHK(c, hipMemcpy(r.dev, m->host_stage, r.bytes, hipMemcpyHostToDevice));
+        if (hipMemcpy(r.dev, m->host_stage, r.bytes, hipMemcpyHostToDevice) != hipSuccess) return comm_fail(m, KATGPU_ERR_DEVICE, "unstaging a message from rank %d", r.peer);
     }
-    shm_barrier(m);
-    return KATGPU_OK;
+    return shm_barrier(m);
 }
 int transfer_wait(katgpu_comm* m, hipEvent_t ev) {
-    if (m->use_rccl && ev) HIPCHK(m->ctx, hipEventSynchronize(ev));
+    if (m->use_rccl && ev) return comm_wait(m, ev, "exchange");
     return KATGPU_OK;
 }
 
@@ -227,7 +253,7 @@ int allgather_u64(katgpu_comm* m, const uint64_t* mine, size_t n, uint64_t* out)
     if (!rc && m->use_rccl) {
         ncclResult_t r = rccl().AllGather(d, d + n, n, ncclUint64, m->nccl, m->stream);
         if (r != ncclSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "ncclAllGather: %s", rccl().GetErrorString(r));
-        else if (hipStreamSynchronize(m->stream) != hipSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "allgather");
+        else rc = comm_wait(m, nullptr, "allgather");
     } else if (!rc) {
         std::vector<Msg> s, rv;
         for (int p = 0; p < m->world; ++p) {
@@ -313,11 +339,18 @@ extern "C" int katgpu_comm_init(katgpu_ctx* c, int rank, int world, const void* 
     // wait for everyone (bounded: a rank that never shows up must not hang the others for ever)
     const double t0 = wall_ms();
     while (m->hdr->attached.load() < (uint32_t)world) {
-        if (wall_ms() - t0 > 120e3) { katgpu_comm_free(m); return fail(c, KATGPU_ERR_DEVICE, "katgpu_comm_init: %d rank(s) of %d showed up within 120 s", (int)m->hdr->attached.load(), world); }
+        if (wall_ms() - t0 > 120e3) {
+            const int seen = (int)m->hdr->attached.load();        // (before the block is unmapped)
+            katgpu_comm_free(m);
+            return fail(c, KATGPU_ERR_DEVICE, "katgpu_comm_init: %d rank(s) of %d showed up within 120 s", seen, world);
+        }
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
-    HIPCHK(c, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    for (auto& e : m->ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    {   // (every way out from here on gives the communicator back: katgpu_comm_free copes with a half-made one)
+        hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        for (auto& ev : m->ev) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) { katgpu_comm_free(m); return fail(c, KATGPU_ERR_DEVICE, "katgpu_comm_init: %s", hipGetErrorString(e)); }
+    }
     // transport: RCCL when every rank can have it
     const char* tr = getenv("KATGPU_COMM_TRANSPORT");
     const bool want_rccl = !(tr && !strcmp(tr, "shm")) && id.has_rccl && rccl().ok;
@@ -348,8 +381,7 @@ extern "C" int katgpu_comm_barrier(katgpu_comm* m) {
     if (!m) return KATGPU_ERR_INVALID_ARG;
     HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
     HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
-    shm_barrier(m);
-    return KATGPU_OK;
+    return shm_barrier(m);
 }
 
 extern "C" int katgpu_comm_stats(katgpu_comm* m, double* ms_extract, double* ms_exchange, double* ms_merge, double* ms_allreduce, uint64_t* bytes_sent, uint64_t* merge_launches) {
@@ -379,7 +411,7 @@ extern "C" int katgpu_allreduce_u64(katgpu_comm* m, uint64_t* buf, size_t n) {
         if (!rc) {
             ncclResult_t r = rccl().AllReduce(d, d, n, ncclUint64, ncclSum, m->nccl, m->stream);
             if (r != ncclSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "ncclAllReduce: %s", rccl().GetErrorString(r));
-            else if (hipStreamSynchronize(m->stream) != hipSuccess || hipMemcpy(buf, d, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "allreduce");
+            else if ((rc = comm_wait(m, nullptr, "allreduce")) == KATGPU_OK && hipMemcpy(buf, d, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = comm_fail(m, KATGPU_ERR_DEVICE, "allreduce");
         }
         hipFree(d);
     } else {
@@ -389,7 +421,7 @@ extern "C" int katgpu_allreduce_u64(katgpu_comm* m, uint64_t* buf, size_t n) {
         FILE* f = fopen(mine.c_str(), "wb");
         if (!f || fwrite(buf, 8, n, f) != n) rc = comm_fail(m, KATGPU_ERR_IO, "cannot write %s", mine.c_str());
         if (f) fclose(f);
-        shm_barrier(m);
+        if (!rc) rc = shm_barrier(m);                            // (a rank that could not write has raised the abort flag: its peers leave here too)
         std::vector<uint64_t> other(n);
         for (int r = 0; r < m->world && !rc; ++r) {
             if (r == m->rank) continue;
@@ -399,7 +431,7 @@ extern "C" int katgpu_allreduce_u64(katgpu_comm* m, uint64_t* buf, size_t n) {
             if (g) fclose(g);
             if (!rc) for (size_t i = 0; i < n; ++i) buf[i] += other[i];
         }
-        shm_barrier(m);
+        if (!rc) rc = shm_barrier(m);
         ::unlink(mine.c_str());
     }
     m->ms_allreduce += wall_ms() - t0;
@@ -457,7 +489,8 @@ static int exchange_merge_wide(katgpu_comm* m, katgpu_table* t) {
     rc = transfer(m, sends, recvs, m->ev[0]);
     if (!rc) rc = transfer_wait(m, m->ev[0]);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(m->stream));
+    rc = comm_wait(m, nullptr, "exchange");
+    if (rc) return rc;
     m->ms_exchange += wall_ms() - t0;
     t0 = wall_ms();
     rc = katgpu_table_clear(t);
@@ -466,8 +499,8 @@ static int exchange_merge_wide(katgpu_comm* m, katgpu_table* t) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     ++m->merge_launches;
     m->ms_merge += wall_ms() - t0;
-    shm_barrier(m);
-    return refresh_counters(t);
+    rc = shm_barrier(m);
+    return rc ? rc : refresh_counters(t);
 }
 
 // Route every record of `t` to its owner rank, IN PLACE: on return the table holds exactly the k-mers this rank owns, their counts
@@ -663,6 +696,6 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
     }
     if (!ok_keys.empty()) { rc = katgpu_table_merge_host(t, ok_keys.data(), ok_counts.data(), ok_keys.size()); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    shm_barrier(m);                                               // nobody reuses its arena while a peer may still be reading from it
-    return refresh_counters(t);
+    rc = shm_barrier(m);                                          // nobody reuses its arena while a peer may still be reading from it
+    return rc ? rc : refresh_counters(t);
 }

@@ -97,7 +97,6 @@ static const uint64_t g_test_ap_seg = hook_u64("KATGPU_TEST_AP_SEG", 0) & ~3ULL;
 static const uint32_t g_apply_nr = (uint32_t)hook_u64("KATGPU_APPLY_NR", 2);            // A/B: probe rounds of the packed apply at the bench's shape (1, 2 or 3)
 static const uint32_t g_apply_min_q = (uint32_t)hook_u64("KATGPU_APPLY_MIN_Q", 72);     // A/B: queue entries per wave the SECOND workgroup of a CU must leave (>= 72)
 static const uint32_t g_apply_per_cu = (uint32_t)hook_u64("KATGPU_APPLY_PER_CU", 0);   // A/B: packed apply workgroups per CU (0: as many as the LDS holds)
-static const uint32_t g_apply_ug = (uint32_t)hook_u64("KATGPU_APPLY_UG", 1);           // A/B: groups per lane and chunk in the bench-shape apply (1 or 2)
 static const bool g_apply_stamp = hook_u64("KATGPU_APPLY_STAMP", 0) != 0;              // diagnostic: the bench-shape apply with cycle stamps (printed per pass)
 
 static const uint32_t g_test_hb = hook("KATGPU_TEST_HB") ? (uint32_t)strtoul(hook("KATGPU_TEST_HB"), nullptr, 10) : 0;   // A/B: wider level-2 items than needed (1, 2, 4)
@@ -231,8 +230,6 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
             else if (HB == 1 && g_apply_nr == 3 && !fresh) KG_APK(512, 10, 1, false, false, false, 3); \
             else if (HB == 1 && g_apply_stamp && !fresh) { KG_LDS_ATTR((k_p3_apply_pk<512, 10, 1, false, false, false, 2, true>), LDS_BYTES - 256); \
                 hipLaunchKernelGGL((k_p3_apply_pk<512, 10, 1, false, false, false, 2, true>), grid, dim3(512), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, qcap, seg_len, g_test_spill_mod); } \
-            else if (HB == 1 && g_apply_ug == 2 && !fresh) { KG_LDS_ATTR((k_p3_apply_pk<512, 10, 1, false, false, false, 2, false, 2>), LDS_BYTES - 256); \
-                hipLaunchKernelGGL((k_p3_apply_pk<512, 10, 1, false, false, false, 2, false, 2>), grid, dim3(512), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, qcap, seg_len, g_test_spill_mod); } \
             else { if (fresh) KG_APK(512, 10, HB, true, false, false, 3); else KG_APK(512, 10, HB, false, false, false, 2); } \
             break;
         switch (g.hb) { KG_APK_SHAPE(0) KG_APK_SHAPE(1) KG_APK_SHAPE(2) default: return fail(c, KATGPU_ERR_DEVICE, "packed apply: item width %u", g.hb); }
@@ -968,9 +965,13 @@ static int count_files_impl(katgpu_table* t, const char* const* paths, size_t n_
         bool took = false;
         uint8_t first = 0;
         if (world > 1 && device_scan_applies(paths[i], trim, nullptr, &first) && first == '@') {
+            // a FASTQ file the ranks share out batch by batch: every rank takes this branch (the test is a property of the file), and a
+            // rank that cannot -- no room for its batch buffers -- fails the run: falling back to the whole-file dealing on ONE rank
+            // would count the file's batches twice or not at all, and put that rank's file counter out of step with the others'
             int rc = count_file_device_scan(t, paths[i], trim, &took, rank, world);
             if (rc) return rc;
-            if (took) continue;
+            if (!took) return fail(c, KATGPU_ERR_NOMEM, "rank %d of %d: no device memory for the batch buffers of %s (a file the ranks share out cannot fall back to the streaming reader on one of them)", rank, world, paths[i]);
+            continue;
         }
         if (world > 1 && (int)(whole++ % (size_t)world) != rank) continue;       // another rank's file
         int rc = count_file_device_scan(t, paths[i], trim, &took);

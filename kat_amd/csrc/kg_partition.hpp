@@ -1254,7 +1254,9 @@ template <int BLOCK, int KP /* 16-byte loads per lane that cover a region: two s
           bool PF = true /* the next region travels from HBM into registers behind the walk of this one (2 KP VGPRs across the walk); false: loaded when its turn comes -- for shapes with a second workgroup on the CU to cover that */,
           int NR = 3 /* probe rounds before a k-mer goes to the queue */,
           bool STAMP = false /* diagnostic (KATGPU_APPLY_STAMP): wave 0's cycles per phase, added into spill_n[8 ..]: [8] fill, [9] walk, [10] of it drains, [11] wait for the other waves + sweep, [12] write-back, [13] regions, [14] chunks */,
-          int UG = 1 /* groups of the level-2 buffer a lane takes per chunk: 4 UG k-mers in flight per lane and probe round */>
+          int UG = 1 /* groups of the level-2 buffer a lane takes per chunk: 4 UG k-mers in flight per lane and probe round.  Two measured
+                        171.9 ms per step against 168.3 with one at the bench's shape (same box, round 4): the walk is bound by VALU issue at four waves per
+                        SIMD (cycle stamps: 5.3 K cycles per chunk and wave = four waves x ~350 wave instructions x 4 cycles), not by LDS round trips */>
 __global__ void __launch_bounds__(BLOCK, 4)    // four waves per SIMD (128 VGPRs): two 512-thread workgroups or one of 1024 threads (a 768-thread shape at six waves spilled: 225 ms against 177)
 k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend,

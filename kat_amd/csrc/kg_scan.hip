@@ -22,7 +22,9 @@
 #include <thread>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
 #include <unistd.h>
 
 static const size_t g_scan_batch = (size_t)std::max<uint64_t>(1, getenv("KATGPU_SCAN_BATCH_MB") ? strtoull(getenv("KATGPU_SCAN_BATCH_MB"), nullptr, 10) : 512) << 20;
@@ -32,6 +34,12 @@ static const size_t g_scan_overlap_dflt = (size_t)1 << 20;        // how far pas
 static const unsigned g_scan_threads = (unsigned)std::max<uint64_t>(1, getenv("KATGPU_SCAN_THREADS") ? strtoull(getenv("KATGPU_SCAN_THREADS"), nullptr, 10) : 16);
 static const uint64_t g_scan_min_bytes = getenv("KATGPU_SCAN_MIN_BYTES") ? strtoull(getenv("KATGPU_SCAN_MIN_BYTES"), nullptr, 10) : ((uint64_t)64 << 20);
 static const bool g_scan_off = getenv("KATGPU_DEVICE_SCAN") && atoi(getenv("KATGPU_DEVICE_SCAN")) == 0;
+// How the readers get a file's bytes into their pinned segments: pread, or -- files on tmpfs (/dev/shm) -- a memcpy out of a mapping of
+// the file.  Measured on the MI355X boxes' hosts (tools/reader_bench.hip, 16 threads, the FIRST read of a freshly written file, which
+// is what a run pays): page-cache files pread at 230-330 GB/s, but tmpfs files at 16-27 GB/s (and no faster with more threads: every
+// page's first pread moves it between the kernel's shared-memory LRU lists, under one lock), where the same bytes come out of a
+// mapping at 120 GB/s.  KATGPU_SCAN_MMAP=0 / 1 forces one or the other.
+static const int g_scan_mmap = getenv("KATGPU_SCAN_MMAP") ? atoi(getenv("KATGPU_SCAN_MMAP")) : -1;
 // tests: small batches / overlaps (bytes) so that little files cross many cuts; force the host fall-back from batch N on
 static const size_t g_test_scan_batch = (size_t)hook_u64("KATGPU_TEST_SCAN_BATCH", 0), g_test_scan_overlap = (size_t)hook_u64("KATGPU_TEST_SCAN_OVERLAP", 0);
 static const size_t g_test_scan_segment = (size_t)hook_u64("KATGPU_TEST_SCAN_SEGMENT", 0);
@@ -89,6 +97,7 @@ struct RawFeeder {
     bool stop = false, io_error = false;
     size_t n_readers = 0;
     std::atomic<uint64_t> us_pread{0}, us_h2d{0};                 // summed over the reader threads: in pread / in their H2D copy (enqueue + landing)
+    const uint8_t* map = nullptr;                                 // the file, mapped (tmpfs: see g_scan_mmap); null: pread
 
     RawFeeder(katgpu_table* t_, const char* p) : t(t_), c(t_->ctx), path(p) {}
     ~RawFeeder() { shutdown(); release(); }
@@ -101,6 +110,7 @@ struct RawFeeder {
     }
     void release() {                                              // (the buffers stay with the context: scan_cache_release)
         for (auto st : c->scan.seg_stream) hipStreamSynchronize(st);
+        if (map) { munmap(const_cast<uint8_t*>(map), (size_t)size); map = nullptr; }
         if (fd >= 0) { ::close(fd); fd = -1; }
     }
     // the context's cached buffers, (re)made when this file wants bigger ones
@@ -115,7 +125,7 @@ struct RawFeeder {
                 hipStream_t st = nullptr;
                 for (int h = 0; h < 2; ++h) {
                     uint8_t* p = nullptr;
-                    HIPCHK(c, hipHostMalloc((void**)&p, seg_bytes, hipHostMallocDefault));
+                    HIPCHK(c, hipHostMalloc((void**)&p, seg_bytes, hipHostMallocNonCoherent));   // (written by the CPU, read by the copy engine: the coarse-grained kind copies a quarter faster, tools/reader_bench.hip)
                     sc.pin_seg.push_back(p);
                 }
                 HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -162,6 +172,14 @@ struct RawFeeder {
         if (my.empty()) return KATGPU_OK;
         fd = ::open(path, O_RDONLY);
         if (fd < 0) return fail(c, KATGPU_ERR_IO, "Could not find input file at: %s", path);
+        {
+            struct statfs sfs;
+            const bool tmpfs = fstatfs(fd, &sfs) == 0 && (unsigned long)sfs.f_type == 0x01021994UL /* TMPFS_MAGIC */;
+            if (g_scan_mmap == 1 || (g_scan_mmap < 0 && tmpfs)) {
+                void* p = mmap(nullptr, (size_t)size, PROT_READ, MAP_SHARED, fd, 0);
+                if (p != MAP_FAILED) { map = (const uint8_t*)p; madvise(p, (size_t)size, MADV_SEQUENTIAL); }
+            }
+        }
         const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g_scan_threads, (size / world + segment - 1) / segment));
         // accumulation buffers: what the file will give (FASTQ: the sequence lines, a bit under half of it), within KATGPU_SCAN_ACC_MB each
         acc_bytes = std::max<size_t>(buf_bytes, std::min<size_t>(g_scan_acc, (size_t)((double)size / world * (type == SCAN_FASTQ ? 0.6 : 1.02)) + ((size_t)1 << 20)));
@@ -220,6 +238,7 @@ struct RawFeeder {
             if (ok && f0 < f1) {
                 const double ta = now_ms();
                 uint64_t got = 0;
+                if (map) { memcpy(mine, map + f0, (size_t)(f1 - f0)); got = f1 - f0; }
                 while (got < f1 - f0) {
                     const ssize_t r = pread(fd, mine + got, (size_t)std::min<uint64_t>(f1 - f0 - got, (uint64_t)1 << 30), (off_t)(f0 + got));
                     if (r <= 0) { ok = false; break; }
@@ -445,9 +464,10 @@ struct RawFeeder {
         const double t_run = now_ms();
         struct Report { RawFeeder* f; double *w, *s, *n, t0; ~Report() {
             if (g_timing) fprintf(stderr, "katgpu_timing {\"file\": \"%s\", \"bytes\": %llu, \"wall_ms\": %.1f, \"reader_wait_ms\": %.1f, \"scan_ms\": %.1f, \"counter_wait_ms\": %.1f, \"counting_ms\": %.1f, "
-                                  "\"reader_threads\": %u, \"pread_ms_per_thread\": %.1f, \"h2d_ms_per_thread\": %.1f, \"segment_MiB\": %zu}\n",
+                                  "\"reader_threads\": %u, \"pread_ms_per_thread\": %.1f, \"h2d_ms_per_thread\": %.1f, \"segment_MiB\": %zu, \"read_by\": \"%s\"}\n",
                                   f->path, (unsigned long long)f->size, now_ms() - t0, *w, *s, *n, f->worker_ms, (unsigned)f->n_readers,
-                                  f->us_pread.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->us_h2d.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->segment >> 20);
+                                  f->us_pread.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->us_h2d.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->segment >> 20,
+                                  f->map ? "memcpy out of a mapping (tmpfs)" : "pread");
             if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] device scan of %s: %.1f GB in %.0f ms (%.1f GB/s): waiting for readers + H2D %.0f ms, scan %.0f ms, waiting for the counter %.0f ms (it counted for %.0f ms); %u reader threads, %zu MiB segments, %zu MiB accumulated per count\n",
                                  since_load(), f->path, f->size / 1e9, now_ms() - t0, f->size / 1e6 / std::max(1.0, now_ms() - t0), *w, *s, *n, f->worker_ms, (unsigned)f->n_readers, f->segment >> 20, f->acc_bytes >> 20); } } report{this, &ms_wait, &ms_scan, &ms_count, t_run};
         struct StopWorker { RawFeeder* f; ~StopWorker() { f->stop_worker(); } } stop_w{this};
