@@ -283,8 +283,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const size_t tile_starts = P1_TILE_STARTS;
 #define KG_FOR_HB(M) M(0) M(1) M(2) M(4)
     if (!c->part_attr_set) {
-#define KG_ATTR_HB(HB) KG_LDS_ATTR((k_p2<HB, false>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, false>), sizeof(P2Lds<HB>)); \
-                       KG_LDS_ATTR((k_p2<HB, true>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, true>), sizeof(P2Lds<HB>));
+#define KG_ATTR_HB(HB) KG_LDS_ATTR((k_p2<HB, false>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, false>), sizeof(P2FLds<HB>)); \
+                       KG_LDS_ATTR((k_p2<HB, true>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, true>), sizeof(P2FLds<HB>));
         KG_FOR_HB(KG_ATTR_HB)
 #undef KG_ATTR_HB
         c->part_attr_set = true;
@@ -495,9 +495,9 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
                 if (try_fast) {
                     ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
-#define KG_P2F(HB) case HB: if (g.hb1 == 4) hipLaunchKernelGGL((k_p2_fast<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+#define KG_P2F(HB) case HB: if (g.hb1 == 4) hipLaunchKernelGGL((k_p2_fast<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); \
-                            else hipLaunchKernelGGL((k_p2_fast<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+                            else hipLaunchKernelGGL((k_p2_fast<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); break;
                     switch (g.hb) { KG_FOR_HB(KG_P2F) }
 #undef KG_P2F

@@ -41,9 +41,10 @@ def test_no_scratch_and_the_stage_kernels_keep_their_budgets(tmp_path):
     ks = kernels(tmp_path)
     assert len(ks) > 100
     # No kernel of the library spills -- but for two shapes the register allocator lands one step past its budget on: the bench's
-    # level-1 scatter keeps ONE dword across its tile loop (a store and a load per 8160-start tile), and the exact level 2 -- the
-    # fall-back of the one-pass edition -- a handful in its item-by-item copy-out.
-    allowed = {"k_p1v2_scatter<true, true, 512>": 8, "k_p2<": 40}
+    # level-1 scatter keeps ONE dword across its tile loop (a store and a load per 8160-start tile), the exact level 2 -- the
+    # fall-back of the one-pass edition -- a handful in its item-by-item copy-out, and the one-pass level 2 parks up to two dozen
+    # loop-invariant values (addresses it hoisted out of its unrolled phases) in its prologue and reloads one or two per phase.
+    allowed = {"k_p1v2_scatter<true, true, 512>": 8, "k_p2<": 40, "k_p2_fast<": 100}
     spilled = {n: v for n, v in ks.items() if v["scratch"] > max([lim for pre, lim in allowed.items() if n.startswith(pre)], default=0)}
     assert not spilled, spilled
 
