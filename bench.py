@@ -645,6 +645,8 @@ def end_to_end(eng, a, k, L):
                                 "pread into pinned memory, then their own H2D copy; pread / h2d per thread say which of the two it was); scan = the record scan "
                                 "on the device; counter_wait = waiting for the counting worker; counting = what the worker spent (hidden under the rest unless "
                                 "counter_wait says otherwise)"}
+        if os.environ.get("KATGPU_TRACE"):                 # diagnostic: the library's own time line of the run
+            breakdown["trace"] = [l for l in pr.stderr.splitlines() if l.startswith("[katgpu")][:80]
         return {"value": round(inst / dt, 1), "breakdown": breakdown, "inputs_in": tmp_root or tempfile.gettempdir(), "unit": "k-mers/s", "seconds": round(dt, 3), "input_bytes": nbytes,
                 "input_GB_per_s": round(nbytes / dt / 1e9, 2), "kmer_instances": inst,
                 "span": "process start -> output files closed (src/comp.cc:750 'Total runtime'), inputs in the page cache",

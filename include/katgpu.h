@@ -113,10 +113,6 @@ int  katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** bases, size_
 int  katgpu_parse_files(const char* const* paths, size_t n_paths, const uint16_t* trim5p, uint32_t k,
                         uint8_t** bases, size_t* n, const char** err_msg);
 void katgpu_free_host(void* p);
-/* --jellyfish_5ptrim_compat (process-wide; returns the previous setting): FASTA files with a 5' trim are read the way the reference's
- * parser really reads them -- the trim is re-applied at the start of every 4096-byte buffer fill, in the middle of records
- * (mer_overlap_sequence_parser.hpp:198, quirk B7 of SURVEY.md) -- instead of once per record.  FASTQ is identical either way. */
-int  katgpu_ingest_jf_5ptrim_compat(int on);
 
 /* The placement hash of one-word tables (kg_device.hpp "placement"; the counterpart of the invertible hash + remainder storage of
  * JF/include/jellyfish/large_hash_array.hpp:169-171), on the host, for a table of p1 x 2^l2 regions: per key the two region digits,

@@ -33,7 +33,7 @@ EXPORTS = (
     "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
     "katgpu_table_partition_wide", "katgpu_table_merge_device_wide", "katgpu_table_regrows",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
-    "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_ingest_jf_5ptrim_compat", "katgpu_place_keys",
+    "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_place_keys",
     "katgpu_count_files_sharded", "katgpu_table_slot_bytes", "katgpu_comm_unique_id", "katgpu_comm_init", "katgpu_comm_free", "katgpu_comm_rank", "katgpu_comm_world", "katgpu_comm_transport",
     "katgpu_comm_transport_note", "katgpu_comm_barrier", "katgpu_exchange_merge", "katgpu_allreduce_u64", "katgpu_comm_stats",
 )
@@ -173,13 +173,6 @@ def parse_files(paths, k, trim5p=None):
     out = np.frombuffer(C.string_at(p, n.value), dtype=np.uint8).copy() if n.value else np.zeros(0, np.uint8)
     L.katgpu_free_host(p)
     return out
-
-
-def jf_5ptrim_compat(on):
-    """Process-wide switch: FASTA 5' trim the way the reference's parser really applies it (quirk B7).  Returns the old setting."""
-    L = load_library()
-    L.katgpu_ingest_jf_5ptrim_compat.argtypes = [C.c_int]
-    return bool(L.katgpu_ingest_jf_5ptrim_compat(int(bool(on))))
 
 
 def place_keys(k, p1, l2, keys, region_slots=0):

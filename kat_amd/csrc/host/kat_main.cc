@@ -59,15 +59,12 @@ static int guarded(const std::string& mode, int argc, char* argv[]) {
 int main(int argc, char* argv[]) {
     if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) { usage(); return 1; }
     const std::string mode = argv[1];
-    // katgpu-only switches, valid in every mode:
-    //   --jellyfish_5ptrim_compat   read FASTA inputs that carry a 5' trim exactly as the reference's parser does (the trim re-applied at
-    //                               each 4096-byte buffer fill) instead of once per record
+    // the katgpu-only switch, valid in every counting mode:
     //   --gpus N                    N processes, one per GPU (hist, gcp, comp)
     int kept = 2, gpus = 0;
     bool gpus_given = false;
     for (int i = 2; i < argc; ++i) {
-        if (!strcmp(argv[i], "--jellyfish_5ptrim_compat")) katgpu_ingest_jf_5ptrim_compat(1);
-        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { gpus = atoi(argv[++i]); gpus_given = true; }
+        if (!strcmp(argv[i], "--gpus") && i + 1 < argc) { gpus = atoi(argv[++i]); gpus_given = true; }
         else if (!strncmp(argv[i], "--gpus=", 7)) { gpus = atoi(argv[i] + 7); gpus_given = true; }
         else argv[kept++] = argv[i];
     }

@@ -646,104 +646,6 @@ int stream_run_concurrent(const char* const* paths, const uint16_t* trim5p, size
     return last_file != SIZE_MAX ? sink(&sep, 1) : KATGPU_OK;            // the run ends as a file does
 }
 
-// ---- Jellyfish's FASTA 5' trim, as it really behaves (quirk B7; --jellyfish_5ptrim_compat) ----
-// read_fasta (JF/include/jellyfish/mer_overlap_sequence_parser.hpp:189-216) fills 4096-byte buffers and sets newread = true on
-// ENTRY, so read_sequence (:250-262) skips `trim5p` characters at the start of every buffer fill, in the middle of records,
-// newlines and '>' included, and the k-1 seam bytes of the previous buffer are joined to whatever follows.  Reproducing that takes
-// the reference's buffer arithmetic (which depends on k and on every line length since the start of the file) and its istream
-// semantics (sentry / eofbit / failbit), so this is a literal restatement over the file's bytes, not the block state machine;
-// it is used only when the switch is on, the file is FASTA and its trim is > 0.  Checked against the real parser
-// (oracle/_ref/jf_ref kmerst) in tests/test_oracle_vs_reference.py.
-std::atomic<int> g_jf_trim_compat{0};
-
-struct IStreamSim {                                  // the subset of std::istream the parser uses, on a byte array
-    const uint8_t* d; size_t n; size_t p = 0; bool eofbit = false, failbit = false; size_t gcount = 0;
-    bool good() const { return !eofbit && !failbit; }
-    bool ok() const { return !failbit; }                                  // operator bool
-    bool sentry() { if (!good()) { failbit = true; return false; } return true; }
-    int peek() { gcount = 0; if (!sentry()) return -1; if (p >= n) { eofbit = true; return -1; } return d[p]; }
-    void get1() { gcount = 0; if (!sentry()) return; if (p >= n) { eofbit = failbit = true; return; } ++p; gcount = 1; }
-    void ignore(size_t cnt) {                                             // ignore(n): no delimiter
-        gcount = 0; if (!sentry()) return;
-        const size_t take = std::min(cnt, n - p);
-        p += take; gcount = take;
-        if (take < cnt) eofbit = true;
-    }
-    void ignore_line() {                                                  // ignore(max, '\n')
-        gcount = 0; if (!sentry()) return;
-        const uint8_t* nl = (const uint8_t*)memchr(d + p, '\n', n - p);
-        if (nl) { gcount = (size_t)(nl - (d + p)) + 1; p += gcount; } else { gcount = n - p; p = n; eofbit = true; }
-    }
-    void getline_keep(std::vector<uint8_t>& out, size_t cap) {            // get(s, cap): up to cap - 1 characters, stops BEFORE '\n'
-        gcount = 0; if (!sentry()) return;
-        const size_t lim = std::min(cap - 1, n - p);
-        const uint8_t* nl = (const uint8_t*)memchr(d + p, '\n', lim);
-        const size_t take = nl ? (size_t)(nl - (d + p)) : lim;
-        out.insert(out.end(), d + p, d + p + take);
-        p += take; gcount = take;
-        if (p >= n) eofbit = true;                                        // the character after the last one taken is EOF
-        if (take == 0) failbit = true;
-    }
-    void skip_newlines() { while (peek() == '\n') get1(); }
-};
-
-// the base stream the reference's consumers see for one FASTA file: the buffers' new bytes one after the other (a buffer that
-// starts without a seam -- the one before it held fewer than k-1 bytes -- is cut off from what precedes it by an 'N')
-int parse_fasta_jf_compat(const uint8_t* data, size_t n, uint32_t k, uint32_t trim5p, std::vector<uint8_t>& out) {
-    const size_t buf_size = 4096;                        // lib/src/jellyfish_helper.cc: the parser's buffers
-    IStreamSim is{data, n};
-    if (is.peek() != '>') return KATGPU_ERR_FORMAT;
-    is.ignore_line();                                    // open_next_file: "Pass header"
-    bool have_seam = false, first = true;
-    std::vector<uint8_t> buf;
-    while (is.good()) {                                  // produce(): one read_fasta per buffer while the stream is good
-        buf.clear();
-        size_t read = have_seam ? k - 1 : 0;              // the seam bytes are already in `out`
-        if (!have_seam && !first) out.push_back('N');
-        first = false;
-        bool newread = true;
-        while (is.good() && read < buf_size - k - 1) {
-            // read_sequence(is, read, start, '>', newread ? trim5p : 0)
-            size_t nread = read;
-            if (newread && trim5p > 0) { is.skip_newlines(); is.ignore(trim5p); }
-            while (is.ok() && nread < buf_size - 1 && is.peek() != '>') {
-                is.skip_newlines();
-                is.getline_keep(buf, buf_size - nread);
-                nread += is.gcount;
-                is.skip_newlines();
-            }
-            read = nread;
-            if (is.peek() == '>') { buf.push_back('N'); ++read; is.ignore_line(); newread = true; }
-            else newread = false;
-        }
-        out.insert(out.end(), buf.begin(), buf.end());
-        have_seam = read >= (size_t)(k - 1);
-    }
-    return KATGPU_OK;
-}
-
-int stream_one_jf_compat(const char* path, uint32_t trim5p, uint32_t k, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err, bool* handled) {
-    *handled = false;
-    gzFile gz = gzopen(path, "rb");
-    if (!gz) return KATGPU_OK;                           // the ordinary path reports it
-    std::vector<uint8_t> raw;
-    std::vector<uint8_t> blk((size_t)4 << 20);
-    for (;;) {
-        const int r = gzread(gz, blk.data(), (unsigned)blk.size());
-        if (r <= 0) break;
-        if (raw.empty() && blk[0] != '>') { gzclose(gz); return KATGPU_OK; }     // not FASTA: the ordinary path
-        raw.insert(raw.end(), blk.begin(), blk.begin() + r);
-    }
-    gzclose(gz);
-    if (raw.empty()) return KATGPU_OK;
-    std::vector<uint8_t> out;
-    int rc = parse_fasta_jf_compat(raw.data(), raw.size(), k, trim5p, out);
-    if (rc) { *err = "Unsupported format"; return rc; }
-    *handled = true;
-    if (!out.empty()) { rc = sink(out.data(), out.size()); if (rc) { err->clear(); return rc; } }
-    return KATGPU_OK;
-}
-
 int stream_one(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err) {
     SeqFileParser parser;
     int rc = parser.open(path, trim5p, err);
@@ -767,17 +669,6 @@ int stream_group(const char* const* paths, size_t n_paths, const uint16_t* trim5
     size_t i = 0;
     while (i < n_paths) {
         const uint32_t trim = trim5p ? trim5p[i] : 0;
-        if (trim > 0 && g_jf_trim_compat.load()) {          // FASTA with a 5' trim, the reference's way (quirk B7)
-            bool handled = false;
-            int rc = stream_one_jf_compat(paths[i], trim, k, sink, err, &handled);
-            if (rc) return rc;
-            if (handled) {
-                rc = sink(&sep, 1);
-                if (rc) { err->clear(); return rc; }
-                ++i;
-                continue;
-            }
-        }
         if (team_applies(paths[i], trim) || bgzf_applies(paths[i])) {
             // a large plain file or a BGZF file: its thread team (same bytes out as the streaming parser)
             int rc = parse_file_parallel(paths[i], trim, sink, err);
@@ -790,8 +681,7 @@ int stream_group(const char* const* paths, size_t n_paths, const uint16_t* trim5
             continue;
         }
         size_t j = i + 1;                                    // the run of streaming files that starts here
-        while (j < n_paths && !team_applies(paths[j], trim5p ? trim5p[j] : 0) && !bgzf_applies(paths[j]) &&
-               !((trim5p ? trim5p[j] : 0) > 0 && g_jf_trim_compat.load())) ++j;
+        while (j < n_paths && !team_applies(paths[j], trim5p ? trim5p[j] : 0) && !bgzf_applies(paths[j])) ++j;
         const unsigned readers = (unsigned)std::min<size_t>(max_readers, j - i);
         int rc;
         if (readers <= 1) {
@@ -854,8 +744,3 @@ extern "C" int katgpu_parse_files(const char* const* paths, size_t n_paths, cons
 }
 
 extern "C" void katgpu_free_host(void* p) { free(p); }
-
-extern "C" int katgpu_ingest_jf_5ptrim_compat(int on) {
-    const int was = kg::g_jf_trim_compat.exchange(on ? 1 : 0);
-    return was;
-}

@@ -792,7 +792,7 @@ __device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, co
 template <int HB>
 struct P2FLds {
     uint32_t cur[MAX_PARTS];           // groups written into each sub-bucket's run so far
-    uint32_t hist[MAX_PARTS + 64];     // k-mers of the tile per sub-bucket (+ one dump counter per lane of a wave: the slots that hold no k-mer)
+    uint32_t hist[MAX_PARTS];          // k-mers of the tile per sub-bucket
     uint32_t goff[MAX_PARTS];          // first staged group of the sub-bucket's k-mers of this tile
     uint32_t wave_tot[32];
     uint32_t pad_[32];                 // (st_lo starts on a 16-byte boundary)
@@ -805,9 +805,8 @@ static_assert(sizeof(P2FLds<0>) <= 160 * 1024 && sizeof(P2FLds<1>) <= 160 * 1024
 // Counting-sort one tile's k-mers of a bucket by their level-2 digit through LDS and append every digit's groups to its run: a digit's
 // k-mers of the tile are padded to whole groups of four in LDS ("no item") and leave as groups -- one 16-byte store of low words + one
 // of high parts per four k-mers; what does not fit its run goes to the overflow list as a k-mer (through the inverse).  All 1024
-// lanes must call it (barriers inside).  Straight-line where it can be: ranks are taken for every slot (a slot without a k-mer ranks
-// in a dump counter) and looked at two slots later, staging reads its run starts four at a time, the copy-out works two groups per
-// lane at once -- the dependent LDS round trips of a phase overlap instead of queueing behind a branch each.
+// lanes must call it (barriers inside).  The copy-out works two groups per lane at once, so that the dependent LDS round trips of the
+// two overlap.
 template <int HB, bool W1, bool STAMP = false>
 __device__ __forceinline__ void scatter_tile2_fast(P2FLds<HB>& L, const PartGeom g, const uint32_t b1, const TileItems<L2Fmt<HB>::N, W1>& key, uint32_t valid,
                                                    uint8_t* __restrict__ out /* the bucket's first run */, uint32_t capg /* groups per run */,
@@ -822,18 +821,16 @@ __device__ __forceinline__ void scatter_tile2_fast(P2FLds<HB>& L, const PartGeom
     if (tid < MAX_PARTS) L.hist[tid] = 0;
     lds_barrier();
     uint32_t br[N];                                           // digit << 16 | rank inside the tile's run
-    {
-        const uint32_t dump = MAX_PARTS + (tid & 63);
-        uint32_t rk[N];
+    // (A branch per slot, each waiting for its rank: taking the ranks of every slot -- those without a k-mer in a dump counter, as level
+    // 1 does -- and looking at them later left the compiler with sixteen digits in flight and seventeen spilled registers at the
+    // bench's shape, and a spill costs this kernel a trip to memory per phase: 179 ms per step against 145-150.)
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
+    for (int j = 0; j < N; ++j) {
+        br[j] = 0;
+        if (valid >> j & 1) {
             const uint32_t b = place_digit2_of(key.r1(j), g.pl);   // (one 32-bit multiply)
-            rk[j] = atomicAdd(&L.hist[(valid >> j & 1) ? b : dump], 1u);
-            br[j] = b << 16;
-            if (j >= 2) br[j - 2] |= rk[j - 2];
+            br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
         }
-#pragma unroll
-        for (int j = N - 2; j < N; ++j) br[j] |= rk[j];
     }
     lds_barrier();
     const unsigned long long t1 = now();

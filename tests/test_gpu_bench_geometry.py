@@ -9,12 +9,17 @@ thresholds -- the 512 x 1024 grid of 9344-slot regions of BASELINE.json's config
 the two: every k-mer of one must be in the other with the same count (all mass on the matrix diagonal, shared == distinct,
 shared totals == totals), and the histograms must agree bucket by bucket.  A bug that moves counts between k-mers while preserving
 the totals -- invisible to tests/test_gpu_scale_properties.py -- cannot pass this."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
 import kat_amd
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 L = 150
 
@@ -75,6 +80,43 @@ def test_config4_geometry_partitioned_equals_direct(engine):
     _same_tables(tp, td, n_reads * (L - k + 1))
     tp.free(); td.free()
     engine.release_scratch()
+
+
+def test_config4_full_size_partitioned_equals_direct(engine):
+    """The whole of config 4's read library -- 300 M reads, 37.2 G k-mer instances, the three partition rounds of the bench step -- against
+    the direct kernel (one global atomic per k-mer, ~3 s).  The reads are generated in slices (the table, its twin and the arena
+    leave no room for 45 GB of them at once): a slice is counted both ways, then the next."""
+    k, genome, n_reads, step = 27, 1_000_000_000, 300_000_000, 100_000_000
+    hint = int(_expected_distinct(n_reads * (L - k + 1), genome, k) / 0.62) + (1 << 20)
+    g = engine.synth_genome(genome, seed=20260927)
+    tp = engine.table(k, True, size_hint=hint)
+    td = engine.table(k, True, size_hint=hint, like=tp)
+    rec = L + 1
+    for first in range(0, n_reads, step):
+        reads = engine.synth_reads(g, genome, first_read=first, n_reads=step, read_len=L, frag_len=350, err_ppm=2000, seed=1)
+        engine.profile_reset()
+        tp.count_bases_device(reads.ptr, reads.nbytes)
+        prof = engine.profile()
+        assert prof["part_apply"]["launches"] > 0 and prof["count"]["launches"] == 0, prof
+        engine.profile_reset()
+        for a in range(0, step, 100_000):                      # 15.1 M window starts per call: below the partitioned counter's threshold
+            td.count_bases_device(reads.ptr + a * rec, min(100_000, step - a) * rec)
+        prof = engine.profile()
+        assert prof["part_apply"]["launches"] == 0 and prof["count"]["launches"] > 0, prof
+        reads.free()
+    g.free()
+    _same_tables(tp, td, n_reads * (L - k + 1))
+    tp.free(); td.free()
+    engine.release_scratch()
+
+
+def test_config4_geometry_prefix_against_the_oracle():
+    """The anchor that is not product against product: a 600 K-read prefix of config 4's library through the partitioned counter at
+    config 4's table geometry, dump against the CPU oracle's (tests/bench_geometry_oracle_case.py)."""
+    env = dict(os.environ, KATGPU_TESTING="1", KATGPU_PART_MIN_STARTS="0", KATGPU_P2_FAST="2")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "bench_geometry_oracle_case.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "bench geometry vs oracle ok" in r.stdout
 
 
 def test_config5_geometry_partitioned_equals_direct(engine):

@@ -42,9 +42,9 @@ def test_no_scratch_and_the_stage_kernels_keep_their_budgets(tmp_path):
     assert len(ks) > 100
     # No kernel of the library spills -- but for two shapes the register allocator lands one step past its budget on: the bench's
     # level-1 scatter keeps ONE dword across its tile loop (a store and a load per 8160-start tile), the exact level 2 -- the
-    # fall-back of the one-pass edition -- a handful in its item-by-item copy-out, and the one-pass level 2 parks up to two dozen
-    # loop-invariant values (addresses it hoisted out of its unrolled phases) in its prologue and reloads one or two per phase.
-    allowed = {"k_p1v2_scatter<true, true, 512>": 8, "k_p2<": 40, "k_p2_fast<": 100}
+    # fall-back of the one-pass edition -- a handful in its item-by-item copy-out, and the one-pass level 2 of 6-byte items from 6-byte
+    # items (remainders of 40-47 bits: not the bench's shape) four loop-invariant values.
+    allowed = {"k_p1v2_scatter<true, true, 512>": 8, "k_p2<": 40, "k_p2_fast<2, false": 24}
     spilled = {n: v for n, v in ks.items() if v["scratch"] > max([lim for pre, lim in allowed.items() if n.startswith(pre)], default=0)}
     assert not spilled, spilled
 
@@ -67,7 +67,7 @@ def test_no_scratch_and_the_stage_kernels_keep_their_budgets(tmp_path):
     every("k_p3_apply_pk<", vgpr=128)
     every("k_p3_apply2<", vgpr=128)
     # the packed shape the bench runs must leave room for its partner on the CU
-    every("k_p3_apply_pk<512, 10, 1, false, false, false, 2>", vgpr=128, lds=64)
+    every("k_p3_apply_pk<512, 10, 1, false, false, false, 2, false, 1>", vgpr=128, lds=64)
     every("k_comp_fused<", vgpr=128)
     every("k_merge_apply<", vgpr=128)
     every("k_w3_apply", vgpr=128)

@@ -350,47 +350,3 @@ def test_five_prime_trim_against_the_reference_parser(ko, tmp_path):
     total = lambda b: sum(int(l.split()[1]) for l in b.splitlines())
     assert total(mine) == (9000 - 3 - 6) + (14000 - 3 - 6) and total(theirs) < total(mine)
     assert kat_amd.parse_file(str(big), 3).size == 9000 - 3 + 1 + 14000 - 3
-
-
-@have_ref
-def test_five_prime_trim_compat_switch_reads_fasta_the_reference_way(ko, tmp_path):
-    """katgpu_ingest_jf_5ptrim_compat(1): the product's ingest reproduces quirk B7 -- the base stream of a FASTA file with a 5' trim,
-    counted, equals what the reference's own parser (mer_overlap_sequence_parser.hpp:189-262, through jf_ref) yields: records longer
-    than a 4096-byte buffer, line-wrapped records, many short records, gzip, a second file in the group, and a k that moves the
-    buffer boundary.  Off again, the documented once-per-record trim is back."""
-    rng = np.random.default_rng(5)
-    rnd = lambda n: "".join(rng.choice(list("ACGT"), n))
-    big = tmp_path / "big.fa"
-    big.write_text(">a\n" + rnd(9000) + "\n>b\n" + "\n".join(rnd(70) for _ in range(200)) + "\n")
-    wrapped = tmp_path / "wrapped.fa"
-    wrapped.write_text("".join(">c%d desc\n%s\n" % (i, "\n".join(rnd(int(rng.integers(1, 120))) for _ in range(int(rng.integers(1, 90))))) for i in range(40)))
-    short = tmp_path / "short.fa"
-    short.write_text("".join(">s%d\n%s\n" % (i, rnd(int(rng.integers(1, 40)))) for i in range(900)))
-    noeol = tmp_path / "noeol.fa"
-    noeol.write_text(">x\n" + rnd(4090) + "\n>y\n" + rnd(5000))                        # no newline at the end of the file
-    import gzip
-    gz = tmp_path / "big.fa.gz"
-    gz.write_bytes(gzip.compress(big.read_bytes()))
-    fq = tmp_path / "t.fq"
-    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in enumerate(rnd(int(rng.integers(12, 90))) for _ in range(300))))
-
-    def product(paths, k, c, trims):
-        t = ko.Table(k, c)
-        t.count_bases(kat_amd.parse_files(paths, k, trims))
-        keys, counts = t.dump_sorted()
-        return "".join("%s %d\n" % (ko.decode(int(a), k), int(b)) for a, b in zip(keys, counts)).encode()
-
-    from kat_amd.binding import jf_5ptrim_compat
-    was = jf_5ptrim_compat(True)
-    try:
-        for f in (big, wrapped, short, noeol):
-            for trim in (1, 3, 10, 75):
-                for k, c in ((7, True), (21, False), (31, True)):
-                    assert product([str(f)], k, c, [trim]) == ref_kmers_trim([str(f)], k, c, [trim]), (f.name, trim, k)
-        assert product([str(gz)], 21, True, [3]) == ref_kmers_trim([str(big)], 21, True, [3])
-        group, trims = [str(big), str(fq), str(wrapped)], [3, 2, 0]
-        assert product(group, 21, True, trims) == ref_kmers_trim(group, 21, True, trims)
-    finally:
-        jf_5ptrim_compat(was)
-    assert product([str(big)], 7, True, [3]) != ref_kmers_trim([str(big)], 7, True, [3])
-    assert kat_amd.parse_files([str(big)], 7, [3]).size == 9000 - 3 + 1 + 14000 - 3 + 1
