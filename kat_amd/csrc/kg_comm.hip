@@ -55,10 +55,14 @@ Rccl& rccl() {
     static bool tried = false;
     if (tried) return r;
     tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (r.lib) break;
-    }
+    // (tests: KATGPU_RCCL_LIB names a stand-in that lets ranks SHARING a GPU take this branch -- tests/native/fake_rccl.cc; read only
+    // under KATGPU_TESTING=1, like every hook)
+    if (const char* test_lib = hook("KATGPU_RCCL_LIB")) r.lib = dlopen(test_lib, RTLD_NOW | RTLD_LOCAL);
+    else
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
     if (!r.lib) return r;
 #define KG_SYM(F) r.F = reinterpret_cast<decltype(r.F)>(dlsym(r.lib, "nccl" #F))
     KG_SYM(GetUniqueId); KG_SYM(CommInitRank); KG_SYM(CommDestroy); KG_SYM(GroupStart); KG_SYM(GroupEnd); KG_SYM(Send); KG_SYM(Recv);

@@ -110,7 +110,11 @@ struct RawFeeder {
     }
     void release() {                                              // (the buffers stay with the context: scan_cache_release)
         for (auto st : c->scan.seg_stream) hipStreamSynchronize(st);
-        if (map) { munmap(const_cast<uint8_t*>(map), (size_t)size); map = nullptr; }
+        if (map) {                                                // (tearing down the page tables of a 16 GB mapping takes ~0.2 s: not on the run's critical path)
+            uint8_t* p = const_cast<uint8_t*>(map); const size_t n = (size_t)size;
+            std::thread([p, n] { munmap(p, n); }).detach();
+            map = nullptr;
+        }
         if (fd >= 0) { ::close(fd); fd = -1; }
     }
     // the context's cached buffers, (re)made when this file wants bigger ones
@@ -121,13 +125,9 @@ struct RawFeeder {
             scan_cache_release(c);
             sc.buf_bytes = buf_bytes; sc.n_buf = nb; sc.pin_seg_bytes = seg_bytes; sc.acc_bytes = acc_bytes;
             for (int i = 0; i < 2; ++i) HIPCHK(c, hipMalloc((void**)&sc.acc[i], HEAD + acc_bytes));
-            for (unsigned i = 0; i < threads; ++i) {              // two pinned segments and one stream per reader
-                hipStream_t st = nullptr;
-                for (int h = 0; h < 2; ++h) {
-                    uint8_t* p = nullptr;
-                    HIPCHK(c, hipHostMalloc((void**)&p, seg_bytes, hipHostMallocNonCoherent));   // (written by the CPU, read by the copy engine: the coarse-grained kind copies a quarter faster, tools/reader_bench.hip)
-                    sc.pin_seg.push_back(p);
-                }
+            for (unsigned i = 0; i < threads; ++i) {              // two pinned segments and one stream per reader; the readers pin their own
+                hipStream_t st = nullptr;                         // segments when they start (read_loop): 32 x 8 MiB pinned one after the other cost 80 ms
+                sc.pin_seg.push_back(nullptr); sc.pin_seg.push_back(nullptr);
                 HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
                 sc.seg_stream.push_back(st);
             }
@@ -201,10 +201,14 @@ struct RawFeeder {
     // its bytes the main thread's to scan -- when its copy has landed, which the thread learns one segment later.
     void read_loop(unsigned me) {
         hipSetDevice(c->device);
+        bool ev_ok = true;
+        for (int h = 0; h < 2; ++h)                               // (this reader's slots of the context's cache: nobody else touches them)
+            if (!c->scan.pin_seg[2 * me + h] &&                   // written by the CPU, read by the copy engine: the coarse-grained kind copies a quarter faster (tools/reader_bench.hip)
+                hipHostMalloc((void**)&c->scan.pin_seg[2 * me + h], c->scan.pin_seg_bytes, hipHostMallocNonCoherent) != hipSuccess) { c->scan.pin_seg[2 * me + h] = nullptr; ev_ok = false; }
         uint8_t* const seg_mem[2] = {c->scan.pin_seg[2 * me], c->scan.pin_seg[2 * me + 1]};
         const hipStream_t st = c->scan.seg_stream[me];
         hipEvent_t landed[2] = {nullptr, nullptr};
-        bool ev_ok = hipEventCreateWithFlags(&landed[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&landed[1], hipEventDisableTiming) == hipSuccess;
+        ev_ok = ev_ok && hipEventCreateWithFlags(&landed[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&landed[1], hipEventDisableTiming) == hipSuccess;
         int64_t in_flight[2] = {-1, -1};                          // my-batch index j of the copy in flight from each segment
         auto retire = [&](int h, bool ok) {                        // the copy from segment h has landed (or failed)
             if (in_flight[h] < 0) return;
@@ -554,7 +558,7 @@ struct RawFeeder {
 void scan_cache_release(katgpu_ctx* c) {
     katgpu_ctx::ScanCache& sc = c->scan;
     for (auto st : sc.seg_stream) { hipStreamSynchronize(st); hipStreamDestroy(st); }
-    for (auto p : sc.pin_seg) hipHostFree(p);
+    for (auto p : sc.pin_seg) if (p) hipHostFree(p);
     for (int i = 0; i < 2; ++i) { hipFree(sc.raw[i]); hipFree(sc.acc[i]); }
     hipFree(sc.raw_al); hipFree(sc.tile_cnt); hipFree(sc.NL); hipFree(sc.len_off); hipFree(sc.line_tile_sum); hipFree(sc.tile_off); hipFree(sc.line_tile_off); hipFree(sc.flags);
     sc = katgpu_ctx::ScanCache{};

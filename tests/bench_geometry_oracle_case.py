@@ -34,7 +34,7 @@ def main():
     prof = eng.profile()
     geo = t.geometry()
     assert (geo.p1, geo.p2) == (512, 1024) and geo.region_slots > 8192, (geo.p1, geo.p2, geo.region_slots)
-    assert prof["part_l1_scatter"]["launches"] > 0 and prof["part_l1_count"]["launches"] <= 1 and prof["part_l2"]["launches"] >= 2 and prof["part_apply"]["launches"] >= 2 and prof["count"]["launches"] == 0, prof
+    assert prof["part_l1_scatter"]["launches"] > 0 and prof["part_l1_count"]["launches"] <= 1 and prof["part_l2"]["launches"] >= 2 and prof["part_apply"]["launches"] >= 2 and prof["count"]["units"] < 100000, prof     # (the direct kernel: a tail of a few windows at most)
     host = reads.download()
     reads.free()
     o = ko.Table(K, True).count_bases(host)

@@ -57,6 +57,30 @@ def test_native_exchange_ranks_sharing_one_gpu(ko, tmp_path, world, mode, extra)
     _check(ko, tmp_path, world, mode)
 
 
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    """tests/native/fake_rccl.cc built into a shared library: the ten nccl* entry points kg_comm.hip resolves, over /dev/shm + hipMemcpy,
+    for ranks that share a device (real RCCL refuses them)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    so = str(tmp_path_factory.mktemp("fakerccl") / "libfakerccl.so")
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "-O1", os.path.join(HERE, "native", "fake_rccl.cc"), "-o", so], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return so
+
+
+@pytest.mark.parametrize("world,mode,extra", [
+    (2, "same", {}), (3, "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "7"}), (2, "mixed", {}), (3, "rr31", {"KATGPU_TEST_EXCHANGE_CHUNKS": "3"}),
+    (2, "wide45", {})])
+def test_native_exchange_rccl_branch_with_several_ranks(ko, tmp_path, fake_rccl, world, mode, extra):
+    """The RCCL transport code of kg_comm.hip -- grouped ncclSend / ncclRecv per chunk on the transport stream, events, the chunk
+    double-buffering against k_merge_apply, ncclAllGather of the sizes, ncclAllReduce of the results -- with 2 and 3 ranks: the
+    library behind the calls is the stand-in (the box has one GPU), everything above it is the product's."""
+    out = _run(tmp_path, world, mode, dict(extra, KATGPU_COMM_TRANSPORT="rccl", KATGPU_RCCL_LIB=fake_rccl, KATGPU_TESTING="1"))
+    assert "transport: rccl" in out, out[-2000:]
+    _check(ko, tmp_path, world, mode)
+
+
 @pytest.mark.parametrize("mode", ["same", "wide45"])
 def test_native_exchange_single_rank_over_rccl(ko, tmp_path, mode):
     out = _run(tmp_path, 1, mode, {"KATGPU_COMM_TRANSPORT": "rccl"})
