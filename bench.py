@@ -67,10 +67,6 @@ def parse_args():
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--load", type=float, default=0.62, help="load factor the tables are pre-sized for (expected distinct k-mers / slots)")
     ap.add_argument("--hint-scale", type=float, default=1.0, help="diagnostic: scale the tables' size hints (e.g. 0.02: grown on the way)")
-    ap.add_argument("--dist-backend", default="native", choices=["native", "nccl", "gloo"],
-                    help="native: katgpu's own communicator (kg_comm.hip: RCCL, /dev/shm as its fall-back) -- torch.distributed (gloo) only "
-                         "hands out the id and times the run; nccl: the exchange as a torch.distributed protocol (kat_amd/dist.py) over RCCL; "
-                         "gloo: that protocol staged through host memory (diagnostic: ranks may share one GPU)")
     a = ap.parse_args()
     if a.config is not None:
         if a.workload is not None and a.workload != CONFIG_ALIAS[a.config]:
@@ -147,56 +143,30 @@ def main():
     from kat_amd import dist as kdist
 
     L0 = a.read_len
-    native = a.dist_backend == "native"
-    staged = a.dist_backend == "gloo"
-    if staged or native:
-        local_rank %= max(1, torch.cuda.device_count())
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        if staged or native:
-            dist.init_process_group("gloo")                 # native: rendezvous, barriers and the timing all-reduce only
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")                     # rendezvous, barriers and the timing all-reduce only: the data path is katgpu's own communicator
     eng = kat_amd.Engine(local_rank)
-    dev = torch.device("cpu") if (staged or native) else torch.device("cuda", local_rank)      # where torch's collective tensors live
-    # the native communicator; if it cannot be made, or its exchange fails on first contact, the run falls back to the staged
-    # torch.distributed protocol and says so in config.parallelism
-    comm, transport = None, None
-    if world > 1 and native:
-        try:
-            ids = [kat_amd.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = kat_amd.Comm(eng, rank, world, ids[0])
-            transport = "katgpu native exchange over %s" % ("RCCL" if comm.transport == "rccl" else "/dev/shm (%s)" % (comm.transport_note or "no RCCL"))
-        except Exception as ex:
-            comm, transport = None, "FALLBACK: torch.distributed gloo, staged through host memory (native communicator failed: %s)" % str(ex)[:200]
-        ok_all = torch.tensor([1 if comm is not None else 0])
-        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
-        if not int(ok_all.item()) and comm is not None:
-            comm.free()
-            comm, transport = None, "FALLBACK: torch.distributed gloo, staged through host memory (a peer could not make the native communicator)"
-        if comm is not None:                                # first contact between the devices, on two tiny tables: a transport that fails does so here
-            try:
-                gp = eng.synth_genome(200_000, seed=5)
-                rp = eng.synth_reads(gp, 200_000, first_read=rank * 2000, n_reads=2000, read_len=L0, frag_len=350, err_ppm=2000, seed=9)
-                tp = eng.table(27, True, size_hint=1 << 21)
-                tp.count_bases_device(rp.ptr, rp.nbytes)
-                comm.exchange_merge(tp)
-                comm.allreduce_u64([np.arange(4, dtype=np.uint64)])
-                for x in (tp, rp, gp):
-                    x.free()
-                okp = 1
-            except Exception as ex:
-                okp, transport = 0, "FALLBACK: torch.distributed gloo, staged through host memory (the native exchange failed on first contact: %s)" % str(ex)[:200]
-            ok_all = torch.tensor([okp])
-            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
-            if not int(ok_all.item()):
-                if okp:
-                    transport = "FALLBACK: torch.distributed gloo, staged through host memory (a peer's native exchange failed on first contact)"
-                comm = None
-        if comm is None:
-            staged = True
+    # The native communicator (kg_comm.hip behind the C ABI: RCCL over xGMI, /dev/shm when ranks share a device or RCCL cannot be had --
+    # the line says which).  One code path: a communicator that cannot be made, or whose first exchange fails, fails the run.
+    comm, transport, comm_info = None, None, None
+    if world > 1:
+        ids = [kat_amd.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = kat_amd.Comm(eng, rank, world, ids[0])
+        transport = "katgpu native exchange over %s" % ("RCCL" if comm.transport == "rccl" else "/dev/shm (%s)" % (comm.transport_note or "no RCCL"))
+        # first contact between the devices, on two tiny tables: a transport that cannot work says so here, not after minutes of counting
+        gp = eng.synth_genome(200_000, seed=5)
+        rp = eng.synth_reads(gp, 200_000, first_read=rank * 2000, n_reads=2000, read_len=L0, frag_len=350, err_ppm=2000, seed=9)
+        tp = eng.table(27, True, size_hint=1 << 21)
+        tp.count_bases_device(rp.ptr, rp.nbytes)
+        comm.exchange_merge(tp)
+        seen = comm.allreduce_u64([np.ones(1, dtype=np.uint64)])[0]
+        comm_info = {"transport": comm.transport, "note": comm.transport_note, "ranks_seen": int(seen[0])}
+        for x in (tp, rp, gp):
+            x.free()
 
     def barrier():
         eng.sync()
@@ -264,12 +234,7 @@ def main():
         return t_prev
 
     def exchange(t):
-        if comm is not None:
-            comm.exchange_merge(t)                          # katgpu_exchange_merge: in place, RCCL behind the C ABI (k > 32: records all to all, the table refilled)
-        elif k > 32:                                        # wide tables: owner partition -> all-to-all -> rebuild (not in place)
-            return kdist.exchange_merge_wide(kdist.HipWideShard(t, staged=staged)).table
-        else:
-            kdist.exchange_merge(kdist.HipShard(t, staged=staged))  # in place: the table keeps its storage and its region grid
+        comm.exchange_merge(t)                              # katgpu_exchange_merge: in place, RCCL behind the C ABI (k > 32: records all to all, the table refilled)
         return t
 
     def step(verify=False):
@@ -300,7 +265,7 @@ def main():
             out = list(kat_amd.comp(t1, t2))
         tp = mark("reduce", tp)
         if world > 1:
-            out = comm.allreduce_u64(out) if comm is not None else kdist.allreduce_u64(out, dev)
+            out = comm.allreduce_u64(out)
         results["out"] = out
         st = t1.stats(want_total=verify)
         results["distinct1"], results["cap1"] = st["distinct"], st["capacity"]
@@ -327,12 +292,12 @@ def main():
     def allsum(v):
         if world == 1:
             return int(v)
-        t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        t = torch.tensor([int(v)], dtype=torch.int64, device="cpu")
         dist.all_reduce(t)
         return int(t.item())
 
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     d1_local, cap1, cap2 = results["distinct1_local"], results["cap1"], results.get("cap2", 0)
@@ -441,7 +406,7 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": desc, "reads_per_gpu": n_reads * (2 if wl == "comp-rr" else 1), "genome_bp": a.genome, "k": k,
-                       "parallelism": "reads sharded x%d, owner-partitioned merge: %s" % (world, transport or ("torch.distributed RCCL" if not staged else "torch.distributed gloo (staged, diagnostic)")) if world > 1 else "single GPU"},
+                       "parallelism": "reads sharded x%d, owner-partitioned merge: %s" % (world, transport) if world > 1 else "single GPU", "comm": comm_info},
             "kmer_instances": total_instances, "distinct_table1": distinct1, "distinct_table2": distinct2 if two_tables else None,
             "result_accounts_for_every_kmer": bool(ok), "result_check": what,
             "kernel_ms_per_step": kernels_ms,

@@ -122,6 +122,11 @@ void katgpu_free_host(void* p);
 int katgpu_place_keys(uint32_t k, uint32_t p1, uint32_t l2, const uint64_t* keys, size_t n, uint32_t* d1, uint32_t* d2, uint64_t* rem,
                       uint64_t* back, uint32_t* rem_bits, uint32_t region_slots, uint32_t* offset);
 
+/* A hint: a table of about size_hint slots for k-mers of length k will be asked for soon (katgpu_count / katgpu_table_create*).  Its
+ * memory is allocated now, on a thread of the library's, beside whatever the caller does next -- `kat comp` calls it for its second
+ * input before it counts the first (InputHandler::count of input 2 follows input 1's, src/comp.cc:139-143).  Returns at once. */
+int katgpu_reserve(katgpu_ctx* ctx, uint32_t k, uint64_t size_hint);
+
 /* distinct k-mers, sum of counts, slots allocated */
 int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t* total, uint64_t* capacity);
 uint32_t katgpu_table_k(const katgpu_table* t);

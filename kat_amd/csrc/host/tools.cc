@@ -225,6 +225,8 @@ void Comp::execute() {                                                          
     if (doThirdHash()) { ends_matrix = Matrix64(d1Bins, d2Bins); middle_matrix = Matrix64(d1Bins, d2Bins); mixed_matrix = Matrix64(d1Bins, d2Bins); }
     comp_counters = CompCounters(input[0].getSingleInput(), input[1].getSingleInput(), doThirdHash() ? input[2].getSingleInput() : "",
                                  std::min(d1Bins, d2Bins));
+    for (size_t i = 1; i < inputSize(); i++)                     // (the later inputs' tables: their memory is allocated while the first input is read)
+        if (input[i].mode == InputHandler::COUNT && !(Engine::dist() && Engine::world() > 1)) katgpu_reserve(Engine::ctx(), getMerLen(), input[i].hashSize);
     for (size_t i = 0; i < inputSize(); i++) {                  // sequentially, one input after the other (:139-143)
         InputHandler& in = input[i];
         if (in.mode == InputHandler::COUNT) in.count(threads, i > 0 ? input[0].hash : nullptr);

@@ -50,7 +50,9 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream); hipStreamSynchronize(c->copy_stream);
     resolve_pending(c);
+    if (c->reserve_thread.joinable()) c->reserve_thread.join();
     scan_cache_release(c);
+    retired_maps_release(c, 0);
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
     if (c->arena) hipFree(c->arena);
@@ -67,6 +69,27 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
 
 // Give the parked table arrays and the partition arena back to the driver (they are re-acquired on demand).  Callers that
 // are about to allocate large buffers of their own on the same device (the multi-GPU exchange does) call this first.
+// The memory of a table that will be asked for soon, allocated now on a thread of the library's and parked where the table's
+// allocation finds it (the pool): a hipMalloc of 13 GB takes ~0.14 s, which `kat comp`'s second input would otherwise spend between
+// its first input's last byte and its own first.  A hint: a table of another size simply does not find it (and a trim gives it back).
+extern "C" int katgpu_reserve(katgpu_ctx* c, uint32_t k, uint64_t size_hint) {
+    if (!c || k < 1 || k > KATGPU_MAX_K) return KATGPU_ERR_INVALID_ARG;
+    if (c->reserve_thread.joinable()) c->reserve_thread.join();
+    const uint64_t cap = std::max<uint64_t>(size_hint, 1024);
+    // packed 8-byte slots are what every one-word table of size gets (kg_table.hip); a grid's rounding adds at most four slots per region
+    const size_t bytes = (size_t)((cap + ((uint64_t)4 << 20)) * 8);
+    if (k > 32 || bytes < ((size_t)1 << 30)) return KATGPU_OK;                   // (wide tables are three arrays; small ones cost nothing to allocate)
+    c->reserve_bytes.store(bytes);
+    c->reserve_thread = std::thread([c, bytes]() {
+        hipSetDevice(c->device);
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); c->reserve_bytes.store(0); return; }
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        c->pool.push_back({p, bytes});
+    });
+    return KATGPU_OK;
+}
+
 extern "C" int katgpu_release_scratch(katgpu_ctx* c) {
     if (!c) return KATGPU_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -153,12 +176,21 @@ int grid_for(katgpu_ctx* c, uint64_t items, int block, int per_cu) {
 
 // ------------------------------------------------------------------ allocation pool ------------------
 
-void pool_trim(katgpu_ctx* c) {
+static void pool_trim_locked(katgpu_ctx* c) {
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
 }
+void pool_trim(katgpu_ctx* c) {
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    pool_trim_locked(c);
+}
 
 hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes) {
+    {   // a reservation in flight that could be what is asked for: wait for it (katgpu_reserve)
+        const size_t rb = c->reserve_bytes.load();
+        if (rb >= bytes && rb <= bytes + bytes / 4 && c->reserve_thread.joinable() && std::this_thread::get_id() != c->reserve_thread.get_id()) c->reserve_thread.join();
+    }
+    std::lock_guard<std::mutex> lk(c->pool_mu);
     size_t got = bytes;
     size_t* got_bytes = &got;
     struct Reg { katgpu_ctx* c; void** p; size_t* b; ~Reg() { if (*p) c->block_bytes[*p] = *b; } } reg{c, p, got_bytes};
@@ -175,7 +207,7 @@ hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes) {
     const bool arena_free = c->arena && !c->arena_borrowed && !c->arena_busy;
     if (e != hipSuccess && (!c->pool.empty() || arena_free)) {    // give cached scratch back and retry once
         (void)hipGetLastError();
-        pool_trim(c);
+        pool_trim_locked(c);
         if (arena_free) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
         e = hipMalloc(p, bytes);
     }
@@ -185,6 +217,7 @@ hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes) {
 
 void pool_release(katgpu_ctx* c, void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
     auto it = c->block_bytes.find(p);
     const size_t bytes = it == c->block_bytes.end() ? 0 : it->second;
     if (it != c->block_bytes.end()) c->block_bytes.erase(it);

@@ -99,7 +99,6 @@ static const uint32_t g_apply_min_q = (uint32_t)hook_u64("KATGPU_APPLY_MIN_Q", 7
 static const uint32_t g_apply_per_cu = (uint32_t)hook_u64("KATGPU_APPLY_PER_CU", 0);   // A/B: packed apply workgroups per CU (0: as many as the LDS holds)
 static const bool g_apply_stamp = hook_u64("KATGPU_APPLY_STAMP", 0) != 0;              // diagnostic: the bench-shape apply with cycle stamps (printed per pass)
 
-static const uint32_t g_p2_variant = (uint32_t)hook_u64("KATGPU_P2_VARIANT", 0);   // A/B: 1 = the one-pass level 2 before its own tile routine
 static const uint32_t g_test_hb = hook("KATGPU_TEST_HB") ? (uint32_t)strtoul(hook("KATGPU_TEST_HB"), nullptr, 10) : 0;   // A/B: wider level-2 items than needed (1, 2, 4)
 static bool part_geometry(const DevTable& d, PartGeom* g) {
     g->R = d.n_regions; g->S = d.region_slots; g->P1 = d.p1; g->P2 = d.p2; g->l2 = d.l2;
@@ -496,10 +495,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
                 if (try_fast) {
                     ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
-#define KG_P2F(HB) case HB: if (g_p2_variant == 1 && g.hb1 != 4) { KG_LDS_ATTR((k_p2_fast_v1<HB, false>), sizeof(P2LdsV1<HB>)); \
-                                hipLaunchKernelGGL((k_p2_fast_v1<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2LdsV1<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
-                                               off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); } \
-                            else if (g.hb1 == 4) hipLaunchKernelGGL((k_p2_fast<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+#define KG_P2F(HB) case HB: if (g.hb1 == 4) hipLaunchKernelGGL((k_p2_fast<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); \
                             else hipLaunchKernelGGL((k_p2_fast<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); break;

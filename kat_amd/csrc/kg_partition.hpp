@@ -998,150 +998,6 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
     if (STAMP && tid == 0 && stamps) for (int i = 0; i < 6; ++i) atomicAdd(&stamps[i], st[i]);
 }
 
-// ==== A/B (KATGPU_P2_VARIANT=1): the one-pass level 2 as it was before its own tile routine (64-bit cursors + limits in LDS, group
-// owners written by every k-mer, one group per lane and step in the copy-out) -- to be deleted with the loser of the comparison ====
-// LDS carve of the level-2 kernels (dynamic shared memory, 16-byte aligned base)
-template <int HB>
-struct P2LdsV1 {
-    uint64_t cursor[MAX_PARTS];        // next free group (fast edition) / item (exact edition) of each sub-bucket's run, THIS workgroup's
-    uint64_t lim[MAX_PARTS];           // fast edition: first group beyond the run
-    uint32_t hist[MAX_PARTS];          // k-mers of the tile per sub-bucket
-    uint32_t goff[MAX_PARTS];          // where the sub-bucket's k-mers of this tile are staged: first group (fast) / first slot (exact)
-    uint32_t wave_tot[32];
-    uint32_t pad_[28];                 // (st_lo starts on a 16-byte boundary)
-    uint32_t st_lo[L2Fmt<HB>::NS];     // staged remainders, grouped by sub-bucket: low words ...
-    typename HiWord<HB>::type st_hi[HB ? L2Fmt<HB>::NS : 4];   // ... high parts ...
-    uint16_t grp_b[L2Fmt<HB>::NS / 4]; // ... and the sub-bucket of every staged group
-};
-static_assert(sizeof(P2LdsV1<0>) <= 160 * 1024 && sizeof(P2LdsV1<1>) <= 160 * 1024 && sizeof(P2LdsV1<2>) <= 160 * 1024 && sizeof(P2LdsV1<4>) <= 160 * 1024, "LDS");
-
-// Counting-sort one tile's k-mers of a bucket by their level-2 digit through LDS and append every digit's run at this workgroup's
-// cursor.  GROUPED (the fast edition): a digit's k-mers of the tile are padded to whole groups of four in LDS and leave as groups --
-// one 16-byte store of low words + one of high parts per four k-mers -- into a run with a capacity (lim[], in groups); what does not
-// fit goes to the overflow list as a k-mer (through the inverse hash).  Not GROUPED (the exact edition): item by item at exact
-// positions.  All 1024 lanes must call it (barriers inside).
-template <int HB, bool GROUPED, bool W1, bool STAMP = false>
-__device__ __forceinline__ void scatter_tile2_v1(P2LdsV1<HB>& L, const PartGeom g, const uint32_t b1, const TileItems<L2Fmt<HB>::N, W1>& key, uint32_t valid,
-                                              uint8_t* __restrict__ out, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap,
-                                              unsigned long long* st = nullptr /* STAMP: cycles of [1] hash + rank, [2] scan, [3] staging, [4] copy-out */) {
-    constexpr int N = L2Fmt<HB>::N;
-    auto now = [&]() -> unsigned long long { return STAMP ? (unsigned long long)clock64() : 0ULL; };
-    const unsigned long long t0 = now();
-    typedef typename HiWord<HB>::type hi_t;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t P = g.P2;
-    if (tid < MAX_PARTS) L.hist[tid] = 0;
-    lds_barrier();
-    uint32_t br[N];                                           // digit << 16 | rank inside the tile's run
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        br[j] = 0;
-        if (valid >> j & 1) {
-            const uint32_t b = place_digit2_of(key.r1(j), g.pl);   // (one 32-bit multiply)
-            br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
-        }
-    }
-    lds_barrier();
-    const unsigned long long t1 = now();
-    uint32_t total;                                           // staged groups (GROUPED) / k-mers of the tile
-    const uint32_t mine = tid < P ? L.hist[tid] : 0;
-    const uint32_t excl = block_exclusive_scan(GROUPED ? (mine + 3) >> 2 : mine, L.wave_tot, &total);
-    if (tid < MAX_PARTS) L.goff[tid] = excl;
-    if (GROUPED && tid < P) {                                 // the last group of the run: what the k-mers leave is "no item"
-        for (uint32_t q = mine; q & 3; ++q) { L.st_lo[excl * 4 + q] = 0xFFFFFFFFu; if (HB) L.st_hi[excl * 4 + q] = (hi_t)~(hi_t)0; }
-    }
-    lds_barrier();
-    const unsigned long long t2 = now();
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-        if (valid >> j & 1) {
-            const uint32_t b = br[j] >> 16, slot = L.goff[b] * (GROUPED ? 4u : 1u) + (br[j] & 0xFFFF);
-            const uint64_t rem = key.r1(j) & g.pl.mr;
-            L.st_lo[slot] = (uint32_t)rem;
-            if (HB) L.st_hi[slot] = (hi_t)(rem >> 32);
-            if (GROUPED) L.grp_b[slot >> 2] = (uint16_t)b;
-        }
-    lds_barrier();
-    const unsigned long long t3 = now();
-    if (GROUPED) {
-        // copy-out, one staged group per lane and step: the steps are independent of each other
-        for (uint32_t gi = tid; gi < total; gi += PART_BLOCK) {
-            const uint32_t b = L.grp_b[gi];
-            const uint64_t dst = L.cursor[b] + (gi - L.goff[b]);
-            const u32x4 lo = *reinterpret_cast<const u32x4*>(&L.st_lo[gi * 4]);
-            typename HiGroup<HB>::type hi{};
-            if (HB) hi = *reinterpret_cast<const typename HiGroup<HB>::type*>(&L.st_hi[gi * 4]);
-            if (dst < L.lim[b]) l2_store_group<HB>(out, dst, lo, hi);
-            else {                                                             // beyond the run's capacity: the overflow list
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint64_t rem = ((uint64_t)hi_of_group<HB>(hi, q) << 32) | (q == 0 ? lo.x : q == 1 ? lo.y : q == 2 ? lo.z : lo.w);
-                    if (rem == L2Fmt<HB>::NONE) continue;
-                    const unsigned long long at = atomicAdd(ovf_n, 1ULL);
-                    if (at < ovf_cap) ovf_buf[at] = place_key_d(b1, b, rem, g.pl);
-                }
-            }
-        }
-        lds_barrier();
-        if (STAMP && st) { const unsigned long long t4 = now(); st[1] += t1 - t0; st[2] += t2 - t1; st[3] += t3 - t2; st[4] += t4 - t3; }
-        if (tid < P) { const uint64_t room = L.lim[tid] - L.cursor[tid], want = (mine + 3) >> 2; L.cursor[tid] += want <= room ? want : room; }
-    } else {
-        // copy-out, one k-mer per lane and step; its sub-bucket: the last one whose staged run starts at or before it
-        for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
-            uint32_t lo_b = 0, hi_b = P - 1;
-            while (lo_b < hi_b) { const uint32_t mid = (lo_b + hi_b + 1) >> 1; if (L.goff[mid] <= idx) lo_b = mid; else hi_b = mid - 1; }
-            // (an empty sub-bucket shares its successor's start, so the last one found is never empty)
-            const uint64_t rem = ((uint64_t)(HB ? (uint32_t)L.st_hi[idx] : 0u) << 32) | L.st_lo[idx];
-            l2_put<HB>(out, L.cursor[lo_b] + (idx - L.goff[lo_b]), rem);
-        }
-        lds_barrier();
-        if (tid < P) L.cursor[tid] += mine;
-    }
-    // (the next tile's first barrier orders the cursor update before the next use)
-}
-
-template <int HB, bool W1, bool STAMP = false>
-__global__ void __launch_bounds__(PART_BLOCK)
-k_p2_fast_v1(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
-          uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
-          uint64_t ovf_cap, uint64_t seg_slots, unsigned long long* __restrict__ stamps = nullptr) {
-    // STAMP (diagnostic, KATGPU_P2_STAMP): cycles of wave 0: [0] tile loads, [1] hash + rank, [2] scan, [3] staging, [4] copy-out, [5] tiles
-    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    P2LdsV1<HB>& L = *reinterpret_cast<P2LdsV1<HB>*>(lds_raw);
-    constexpr int N = L2Fmt<HB>::N;
-    const uint32_t tid = threadIdx.x;
-    uint64_t beg0, n0, nr0;
-    l1_bucket_range(g, l1_off, seg_slots, g.b_lo, beg0, n0, nr0);
-    for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
-        uint64_t beg, n_items, n_real;
-        const uint8_t* bucket = l1_buf + l1_bucket_range(g, l1_off, seg_slots, b1, beg, n_items, n_real);
-        const uint64_t cap = p2_region_cap(n_real, g.P2, L2Fmt<HB>::TILE);
-        const uint64_t obase = p2_out_base(beg, b1, g.P2, L2Fmt<HB>::TILE) - p2_out_base(beg0, g.b_lo, g.P2, L2Fmt<HB>::TILE);   // the level-2 buffer holds this pass only
-        lds_barrier();
-        if (tid < g.P2) {
-            const uint64_t start = obase + (uint64_t)tid * cap;                // items; the cursor counts groups
-            L.cursor[tid] = start >> 2;
-            L.lim[tid] = (start + cap) >> 2;
-            off2[(uint64_t)b1 * g.P2 + tid] = start;
-        }
-        for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
-            const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
-            TileItems<N, W1> key;
-            const uint32_t valid = p2_tile_load<N, W1>(g.hb1, bucket, tbeg, n_items, key);
-            if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
-            lds_barrier();
-            if (STAMP) { st[0] += (unsigned long long)clock64() - ta; st[5] += 1; }
-            scatter_tile2_v1<HB, true, W1, STAMP>(L, g, b1, key, valid, l2_buf, ovf_buf, ovf_n, ovf_cap, st);
-        }
-        lds_barrier();
-        if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = (uint32_t)((L.cursor[tid] << 2) - (obase + (uint64_t)tid * cap));
-    }
-    if (STAMP && tid == 0 && stamps) for (int i = 0; i < 6; ++i) atomicAdd(&stamps[i], st[i]);
-}
-
-// ==== end of the A/B block ====
-
 // ---- level 3: apply a region's run to the region, in LDS (KV12 tables: keys[S] u64 | counts[S] u32) ----
 // A walk with one probe chain per lane inside a divergent loop (round 1's kernel) is bound by dependent LDS round trips, not by LDS
 // or VALU throughput (profiles/r01_partitioned_sq_counters.txt: waves parked 67 % of their cycles, LDS array 15 % busy).

@@ -110,10 +110,11 @@ struct RawFeeder {
     }
     void release() {                                              // (the buffers stay with the context: scan_cache_release)
         for (auto st : c->scan.seg_stream) hipStreamSynchronize(st);
-        if (map) {                                                // (tearing down the page tables of a 16 GB mapping takes ~0.2 s: not on the run's critical path)
-            uint8_t* p = const_cast<uint8_t*>(map); const size_t n = (size_t)size;
-            std::thread([p, n] { munmap(p, n); }).detach();
+        if (map) {                                                // (kg_host.hpp: retired_maps -- unmapping now would stall the next file's mapping for ~0.2 s)
+            c->retired_maps.push_back({const_cast<uint8_t*>(map), (size_t)size});
+            c->retired_map_bytes += (size_t)size;
             map = nullptr;
+            retired_maps_release(c, (size_t)1 << 40);             // (address space is not scarce; page tables are 0.2 % of what is mapped)
         }
         if (fd >= 0) { ::close(fd); fd = -1; }
     }
@@ -554,6 +555,14 @@ struct RawFeeder {
 };
 
 }  // namespace
+
+void retired_maps_release(katgpu_ctx* c, size_t keep_bytes) {
+    while (!c->retired_maps.empty() && c->retired_map_bytes > keep_bytes) {
+        munmap(c->retired_maps.front().first, c->retired_maps.front().second);
+        c->retired_map_bytes -= c->retired_maps.front().second;
+        c->retired_maps.erase(c->retired_maps.begin());
+    }
+}
 
 void scan_cache_release(katgpu_ctx* c) {
     katgpu_ctx::ScanCache& sc = c->scan;

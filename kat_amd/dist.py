@@ -1,26 +1,12 @@
-"""One process per GPU: read sharding + owner-partitioned merge of the per-GPU partial tables over torch.distributed.
+"""The multi-GPU exchange as a MODEL in Python over torch.distributed, and the host mirrors of the device's owner functions.
 
-KAT has no distributed path (one process, std::thread); this is the exchange step BASELINE.json's north_star asks
-for.  Each rank counts its own shard of the input into a LOCAL partial table.  Every (k-mer, count) record is then
-routed to owner(k-mer) (a hash of the canonical form, kg_device.hpp: owner_of) with grouped point-to-point sends --
-on RCCL one ncclGroupStart/End of ncclSend/ncclRecv pairs that drives all xGMI links of the fully connected node at
-once, which suits xGMI better than a ring all-reduce would -- and the owner adds the counts (exact integer sums, so
-the result is bit-identical to a single-GPU run).  Reducers then run on the owned shards and their small outputs
-(80 KB hist / 216 KB gcp / 8 MB comp matrix + counters) are summed with one all-reduce.
-
-The exchange is REGION-ORDERED and IN PLACE (include/katgpu.h, "region-ordered exchange"):
-  * ranks count into tables of the same region grid, so a k-mer sits in the same region index everywhere;
-  * the sender extracts its table once into a send list (8-byte key + 4-byte count per record, grouped by owner and,
-    inside an owner, ordered by region), then EMPTIES the table: the emptied table is the owner table, so the
-    exchange allocates nothing next to the tables (the send list and the receive buffers live in katgpu's arena);
-  * the list travels in C chunks of consecutive regions, double buffered: while chunk c is on the wire, the owner
-    applies chunk c-1 -- the runs of each region from every rank -- to that region in LDS (k_merge_apply): no global
-    atomic per record, no re-partitioning on the receiving side, one sweep of the owner table in total;
-  * a sender whose grid differs (its table regrew differently) is still exact: its records go through the direct path.
-
-The table object is duck-typed (geometry / begin_exchange / exchange_buffers / extract / clear / merge_chunk /
-merge_big) so that the CPU gloo tests drive the same code with an oracle-backed stand-in; the product adapter is
-HipShard.
+The product's exchange is native: kat_amd/csrc/kg_comm.hip behind the C ABI (katgpu_comm_* / katgpu_exchange_merge /
+katgpu_allreduce_u64; `kat_amd.Comm`, `katgpu <mode> --gpus N`, `bench.py --gpus N`).  What lives here is what the CPU-side tests of
+that protocol need (tests/test_dist_gloo.py: world 2 / 3 / 4 over gloo, an oracle-backed stand-in for the table): the same
+region-ordered, chunked, in-place protocol -- per-region counts all to all, the send list in chunks of consecutive regions with
+chunk c on the wire while chunk c-1 is applied, out-of-band records for counts above 32 bits -- written against a duck-typed shard
+(geometry / begin_exchange / exchange_buffers / extract / clear / merge_chunk / merge_big), plus shard_range (how reads and contigs
+are dealt to ranks) and owner_of / owner_of_wide (kg_device.hpp: owner_of, owner_of_w), which the GPU tests check the device against.
 """
 import numpy as np
 import torch
@@ -29,161 +15,19 @@ import torch.distributed as dist
 BIG_CAP = 4200
 
 
-def _align(n, a=256):
-    return (int(n) + a - 1) // a * a
-
-
-class HipShard:
-    """Adapter over a kat_amd.Table.  Exchange tensors are torch views of katgpu's arena (plumbing only); with
-    staged=True they are host tensors instead (gloo transport: two ranks on one GPU in the tests)."""
-
-    def __init__(self, table, staged=False):
-        self.table = table
-        self.cuda = torch.device("cuda", torch.cuda.current_device())
-        self.staged = staged
-        self.device = torch.device("cpu") if staged else self.cuda
-        self._cnt_buf = None
-
-    def geometry(self):
-        g = self.table.geometry()
-        return np.array([g.k, g.canonical, g.n_regions, g.region_slots, g.p1, g.p2], dtype=np.int64)
-
-    def begin_exchange(self, n_parts):
-        """Pass 1 of the extraction: (records per owner, int32 tensor [n_parts, n_regions] of records per owner and region)."""
-        eng = self.table.engine
-        R = int(self.table.geometry().n_regions)
-        self._cnt_buf = eng.alloc(4 * n_parts * R + 64)                     # small (27 MB at 8 x 860 K regions): outside the arena
-        sizes = self.table.extract_sizes(n_parts, self._cnt_buf.ptr).astype(np.int64)
-        from .binding import ScratchView
-        cnt = torch.as_tensor(ScratchView(self._cnt_buf.ptr, 4 * n_parts * R), device=self.cuda).view(torch.int32).view(n_parts, R)
-        self._cnt_dev = cnt
-        return sizes, (cnt.cpu() if self.staged else cnt)
-
-    def exchange_capacity(self, want_bytes):
-        """Bytes of exchange scratch available (the arena, grown to want_bytes when it is smaller and the device has room)."""
-        eng = self.table.engine
-        cap = eng.scratch(0).capacity
-        if cap < want_bytes:
-            try:
-                cap = eng.scratch(want_bytes).capacity          # keeps the old arena when the larger one cannot be had
-            except Exception:
-                cap = eng.scratch(0).capacity
-        return cap
-
-    @staticmethod
-    def exchange_bytes(total_send, set_records):
-        return _align(8 * max(total_send, 1)) + _align(4 * max(total_send, 1)) + 2 * (_align(8 * max(set_records, 1)) + _align(4 * max(set_records, 1))) + 256
-
-    def exchange_buffers(self, total_send, set_records):
-        """send keys / counts (int64 / int32, total_send records) and two receive sets of set_records records."""
-        eng = self.table.engine
-        nbytes = self.exchange_bytes(total_send, set_records)
-        raw = torch.as_tensor(eng.scratch(nbytes), device=self.cuda)
-        o = 0
-
-        def take(n, width, dtype):
-            nonlocal o
-            t = raw[o:o + width * max(n, 1)].view(dtype)
-            o += _align(width * max(n, 1))
-            return t
-        b = {"send_keys": take(total_send, 8, torch.int64), "send_counts": take(total_send, 4, torch.int32)}
-        dev_sets = [(take(set_records, 8, torch.int64), take(set_records, 4, torch.int32)) for _ in range(2)]
-        if self.staged:
-            b["dev_sets"] = dev_sets
-            b["recv"] = [(torch.empty(max(set_records, 1), dtype=torch.int64), torch.empty(max(set_records, 1), dtype=torch.int32)) for _ in range(2)]
-        else:
-            b["recv"] = dev_sets
-        self._bufs = b
-        return b
-
-    def extract(self, n_parts, bufs):
-        """Pass 2: fill the send list; returns the out-of-band records (counts above 32 bits, the all-ones k-mer)."""
-        big = self.table.extract(n_parts, self._cnt_buf.ptr, bufs["send_keys"].data_ptr(), bufs["send_counts"].data_ptr())
-        if self.staged:
-            bufs["send_keys_dev"], bufs["send_counts_dev"] = bufs["send_keys"], bufs["send_counts"]
-            bufs["send_keys"], bufs["send_counts"] = bufs["send_keys"].cpu(), bufs["send_counts"].cpu()
-        return big
-
-    def clear(self):
-        self.table.clear()
-
-    def wait_transport(self):
-        """Host-side wait for what the transport has delivered so far (NOT a device-wide sync: the next chunk stays in flight)."""
-        if not self.staged:
-            torch.cuda.current_stream().synchronize()
-
-    def merge_chunk(self, g_lo, g_hi, sources, set_index):
-        """sources: dicts with keys / counts (tensor slices), rcnt (int32 slice of the sender's region counts for [g_lo, g_hi), or
-        None), n, p1, p2, own (the slice lives in the send list)."""
-        src = []
-        if self.staged:                                                     # host tensors -> the device-side sets
-            dk, dc = self._bufs["dev_sets"][set_index]
-            o = 0
-            for s in sources:
-                n = int(s["n"])
-                if s["own"]:
-                    k_ptr = self._bufs["send_keys_dev"].data_ptr() + 8 * int(s["offset"])
-                    c_ptr = self._bufs["send_counts_dev"].data_ptr() + 4 * int(s["offset"])
-                else:
-                    dk[o:o + n].copy_(s["keys"][:n])
-                    dc[o:o + n].copy_(s["counts"][:n])
-                    k_ptr, c_ptr = dk[o:o + n].data_ptr() if n else 0, dc[o:o + n].data_ptr() if n else 0
-                    o += n
-                r = s["rcnt"]
-                if r is not None:
-                    r = r.to(self.cuda) if r.device.type == "cpu" else r
-                    s["_keep"] = r
-                src.append((k_ptr, c_ptr, r.data_ptr() if r is not None and r.numel() else None, n, int(s["p1"]), int(s["p2"])))
-            torch.cuda.synchronize()
-        else:
-            for s in sources:
-                n = int(s["n"])
-                r = s["rcnt"]
-                src.append((s["keys"].data_ptr() if n else 0, s["counts"].data_ptr() if n else 0,
-                            r.data_ptr() if r is not None and r.numel() else None, n, int(s["p1"]), int(s["p2"])))
-        src = [x for x in src if x[3]]
-        if src:
-            self.table.merge_regions(int(g_lo), int(g_hi), src)
-
-    def merge_big(self, keys, counts):
-        if len(keys):
-            self.table.merge_host(keys, counts)
-
-    def end_exchange(self):
-        if self._cnt_buf is not None:
-            self.table.engine.sync()
-            self._cnt_buf.free()
-            self._cnt_buf = None
-        self._bufs = None
-
-    def free(self):
-        self.table.free()
-
-
 def _exchange_rows(rows_out, rows_in, rank, world, group):
     """rows_out[p] -> rank p; rows_in[s] <- rank s (grouped point-to-point)."""
-    ops = []
-    for p in range(world):
-        if p == rank:
-            continue
-        if rows_out[p].numel():
-            ops.append(dist.P2POp(dist.isend, rows_out[p], p, group))
-        if rows_in[p].numel():
-            ops.append(dist.P2POp(dist.irecv, rows_in[p], p, group))
+    ops = [dist.P2POp(dist.isend, rows_out[p], p, group) for p in range(world) if p != rank and rows_out[p].numel()]
+    ops += [dist.P2POp(dist.irecv, rows_in[p], p, group) for p in range(world) if p != rank and rows_in[p].numel()]
     for r in (dist.batch_isend_irecv(ops) if ops else []):
         r.wait()
 
 
-def exchange_merge(shard, group=None, min_chunks=4, force=False):
-    """Route every record of `shard` to its owner rank, IN PLACE: on return the same shard holds exactly the k-mers this
-    rank owns, with their counts summed over all ranks.  The table keeps its storage and its region grid (a second table created
-    "like" the first still joins with it region by region).
-
-    world_size == 1: the local table already is the owner table (force=True runs the protocol all the same -- extraction,
-    clear, region-by-region merge of the rank's own send list, the collectives -- which is how a single-GPU box exercises it).
-    """
+def exchange_merge(shard, group=None, min_chunks=4):
+    """Route every record of `shard` to its owner rank, IN PLACE: on return the same shard holds exactly the k-mers this rank owns,
+    their counts summed over all ranks; the table keeps its storage and its region grid.  world_size == 1: nothing to do."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 and not (force and dist.is_initialized()):
+    if world == 1:
         return shard
     rank = dist.get_rank(group)
     dev = shard.device
@@ -200,9 +44,6 @@ def exchange_merge(shard, group=None, min_chunks=4, force=False):
     # ---- pass 1: how many records go where, per region ----
     sizes, cnt = shard.begin_exchange(world)                                  # cnt: int32 [world, R_mine]
     total_send = int(sizes.sum())
-    s_all = [torch.empty(world, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(s_all, torch.from_numpy(sizes).to(dev), group=group)
-    recv_from = np.array([int(s[rank]) for s in s_all], dtype=np.int64)       # what each peer holds for me
     rcnt = [cnt[rank] if s == rank else torch.empty(int(R_of[s]), dtype=torch.int32, device=dev) for s in range(world)]
     _exchange_rows([cnt[p] for p in range(world)], rcnt, rank, world, group)
     cnt_host = cnt.cpu().numpy().view(np.uint32).astype(np.int64)             # [world, R_mine]
@@ -211,22 +52,11 @@ def exchange_merge(shard, group=None, min_chunks=4, force=False):
     cnt_cum = [np.concatenate([[0], np.cumsum(cnt_host[p])]) for p in range(world)]          # records of part p before region g
     rcnt_cum = [np.concatenate([[0], np.cumsum(rcnt_host[s_])]) for s_ in range(world)]
 
-    # ---- chunks of consecutive regions, as few as the exchange scratch allows (>= min_chunks for the overlap) ----
-    recv_other = int(recv_from.sum() - recv_from[rank])
+    # ---- chunks of consecutive regions (the product picks as few as its exchange scratch allows; the model takes min_chunks) ----
     C = max(1, min(int(min_chunks), int(R_of.min())))
-    cap = shard.exchange_capacity(shard.exchange_bytes(total_send, -(-recv_other // max(C, 1)) * 5 // 4)) if hasattr(shard, "exchange_capacity") else None
-    while True:
-        bounds = [(np.arange(C + 1, dtype=np.int64) * int(R_of[s])) // C for s in range(world)]       # region boundaries per sender
-        recv_sz = np.stack([np.diff(rcnt_cum[s][bounds[s]]) for s in range(world)]).astype(np.int64)                # [sender, chunk]
-        set_records = int(max(1, max(int(recv_sz[:, c].sum() - recv_sz[rank, c]) for c in range(C))))
-        fits = 1 if cap is None or shard.exchange_bytes(total_send, set_records) <= cap else 0
-        f = torch.tensor([fits], dtype=torch.int64, device=dev)
-        dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
-        if int(f.item()) or C >= int(R_of.min()):
-            if not int(f.item()):
-                raise MemoryError("exchange_merge: the send list and one region's receive buffers do not fit the exchange scratch")
-            break
-        C = min(C * 2, int(R_of.min()))
+    bounds = [(np.arange(C + 1, dtype=np.int64) * int(R_of[s])) // C for s in range(world)]                          # region boundaries per sender
+    recv_sz = np.stack([np.diff(rcnt_cum[s][bounds[s]]) for s in range(world)]).astype(np.int64)                    # [sender, chunk]
+    set_records = int(max(1, max(int(recv_sz[:, c].sum() - recv_sz[rank, c]) for c in range(C))))
     send_off = np.stack([part_base[p] + cnt_cum[p][bounds[rank]] for p in range(world)]).astype(np.int64)            # [owner, chunk boundary]
 
     # ---- pass 2: the send list; the emptied table becomes the owner table ----
@@ -242,14 +72,9 @@ def exchange_merge(shard, group=None, min_chunks=4, force=False):
             if s == rank:
                 continue
             n_out = int(send_off[s][c + 1] - send_off[s][c])
-            if n_out:
-                a = int(send_off[s][c])
-                ops.append(dist.P2POp(dist.isend, skeys[a:a + n_out], s, group))
-                ops.append(dist.P2POp(dist.isend, scounts[a:a + n_out], s, group))
-            n_in = int(recv_sz[s][c])
-            if n_in:
-                ops.append(dist.P2POp(dist.irecv, rk[o:o + n_in], s, group))
-                ops.append(dist.P2POp(dist.irecv, rc[o:o + n_in], s, group))
+            a, n_in = int(send_off[s][c]), int(recv_sz[s][c])
+            ops += [dist.P2POp(dist.isend, b[a:a + n_out], s, group) for b in (skeys, scounts) if n_out]
+            ops += [dist.P2POp(dist.irecv, b[o:o + n_in], s, group) for b in (rk, rc) if n_in]
             layout.append((s, o, n_in))
             o += n_in
         return (dist.batch_isend_irecv(ops) if ops else []), layout
@@ -273,8 +98,6 @@ def exchange_merge(shard, group=None, min_chunks=4, force=False):
             reqs, layout = pending
             for r in reqs:
                 r.wait()
-            if hasattr(shard, "wait_transport"):
-                shard.wait_transport()
             merge(c - 1, layout)
         pending = cur
 
@@ -292,8 +115,6 @@ def exchange_merge(shard, group=None, min_chunks=4, force=False):
         bk, bc = t[1:1 + n].view(np.uint64), t[1 + BIG_CAP:1 + BIG_CAP + n].view(np.uint64)
         own = owner_of(bk, k, world) == rank if n else np.zeros(0, bool)
         shard.merge_big(bk[own], bc[own])
-    if hasattr(shard, "end_exchange"):
-        shard.end_exchange()
     return shard
 
 
@@ -304,13 +125,8 @@ def allreduce_u64(arrays, device, group=None):
     flat = np.concatenate([np.ascontiguousarray(a, np.uint64).reshape(-1) for a in arrays]).view(np.int64)
     t = torch.from_numpy(flat.copy()).to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    res = t.cpu().numpy().view(np.uint64)
-    out, o = [], 0
-    for a in arrays:
-        n = int(np.prod(a.shape))
-        out.append(res[o:o + n].reshape(a.shape).copy())
-        o += n
-    return out
+    parts = np.split(t.cpu().numpy().view(np.uint64), np.cumsum([int(np.prod(a.shape)) for a in arrays])[:-1])
+    return [p.reshape(a.shape).copy() for p, a in zip(parts, arrays)]
 
 
 def shard_range(n_items, rank, world):
@@ -349,7 +165,7 @@ def owner_of(keys, k, n_parts):
     return mulhi64(_mix64(c ^ np.uint64(0x9E3779B97F4A7C15)), np.uint64(n_parts)).astype(np.int64)
 
 
-# ---- k > 32 ("wide" tables): the k-mer is (hi, lo), the upper / lower 64 bits of its 2k-bit word -----------------------
+# ---- k > 32 ("wide" tables): the k-mer is (hi, lo), the upper / lower 64 bits of its 2k-bit word ----
 
 def _revcomp_wide(hi, lo, k):
     """Reverse complement of 2k-bit words given as (hi, lo) uint64 arrays, 33 <= k <= 64 (base-by-base, vectorised over records)."""
@@ -380,86 +196,3 @@ def owner_of_wide(hi, lo, k, n_parts):
     with np.errstate(over="ignore"):
         h = _mix64(b ^ (a * np.uint64(0x9E3779B97F4A7C15)))
     return mulhi64(_mix64(h ^ np.uint64(0x9E3779B97F4A7C15)), np.uint64(n_parts)).astype(np.int64)
-
-
-class HipWideShard:
-    """Adapter over a wide kat_amd.Table (k > 32) for exchange_merge_wide.  Record buffers are plain torch tensors (device, or host
-    with staged=True for the gloo tests): this exchange is the simple one -- partition by owner, all-to-all, rebuild -- not the
-    region-ordered in-place protocol of the one-word tables, whose LDS merge is built around 12-byte slots."""
-
-    def __init__(self, table, staged=False):
-        assert table.k > 32
-        self.table = table
-        self.k = table.k
-        self.canonical = table.canonical
-        self.staged = staged
-        self.cuda = torch.device("cuda", torch.cuda.current_device())
-        self.device = torch.device("cpu") if staged else self.cuda
-
-    def part_sizes(self, n_parts):
-        return self.table.partition_sizes(n_parts).astype(np.int64)
-
-    def partition(self, n_parts, offsets, total):
-        """(hi, lo, counts) int64 tensors of `total` records on self.device, part p starting at offsets[p]."""
-        dev = [torch.empty(max(total, 1), dtype=torch.int64, device=self.cuda) for _ in range(3)]
-        self.table.partition_wide(n_parts, offsets, dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr())
-        return [t.cpu() for t in dev] if self.staged else dev
-
-    def rebuild(self, hi, lo, counts, n):
-        """Replace the table by one holding exactly these n records (equal k-mers summed)."""
-        eng = self.table.engine
-        old = self.table
-        new = eng.table(self.k, self.canonical, size_hint=max(int(n / 0.6) + 1024, 1 << 16))
-        old.free()
-        if n:
-            dev = [t[:n].to(self.cuda).contiguous() for t in (hi, lo, counts)]
-            new.merge_device_wide(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), n)
-            eng.sync()
-        self.table = new
-
-    def free(self):
-        self.table.free()
-
-
-def exchange_merge_wide(shard, group=None, force=False):
-    """exchange_merge for wide tables: every (k-mer, count) record goes to owner_of_w(k-mer); on return shard.table holds exactly
-    the k-mers this rank owns, counts summed over ranks (exact integer sums: bit-identical to one process).  The shard is
-    duck-typed (part_sizes / partition / rebuild) like the one-word exchange's."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 and not (force and dist.is_initialized()):
-        return shard
-    rank = dist.get_rank(group)
-    dev = shard.device
-    meta = torch.tensor([shard.k, int(shard.canonical)], dtype=torch.int64, device=dev)
-    metas = [torch.empty_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    if any(int(m[0]) != shard.k or int(m[1]) != int(shard.canonical) for m in metas):
-        raise ValueError("exchange_merge_wide: ranks disagree on k / canonical")
-    sizes = shard.part_sizes(world)                                          # records I hold for each owner
-    s_all = [torch.empty(world, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(s_all, torch.from_numpy(sizes).to(dev), group=group)
-    recv_from = np.array([int(s[rank]) for s in s_all], dtype=np.int64)      # what each peer holds for me
-    send_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    recv_off = np.concatenate([[0], np.cumsum(recv_from)]).astype(np.int64)
-    send = shard.partition(world, send_off[:-1].astype(np.uint64), int(send_off[-1]))
-    recv = [torch.empty(max(int(recv_off[-1]), 1), dtype=torch.int64, device=dev) for _ in range(3)]
-    ops = []
-    for p in range(world):
-        a, n_out = int(send_off[p]), int(sizes[p])
-        b, n_in = int(recv_off[p]), int(recv_from[p])
-        if p == rank:
-            for r, s in zip(recv, send):
-                r[b:b + n_in].copy_(s[a:a + n_out])
-            continue
-        for r, s in zip(recv, send):
-            if n_out:
-                ops.append(dist.P2POp(dist.isend, s[a:a + n_out], p, group))
-            if n_in:
-                ops.append(dist.P2POp(dist.irecv, r[b:b + n_in], p, group))
-    for r in (dist.batch_isend_irecv(ops) if ops else []):
-        r.wait()
-    if dev.type == "cuda":
-        torch.cuda.current_stream().synchronize()
-    del send
-    shard.rebuild(recv[0], recv[1], recv[2], int(recv_off[-1]))
-    return shard

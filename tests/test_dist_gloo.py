@@ -1,8 +1,9 @@
-"""world_size-2 gloo run of the multi-GPU path (kat_amd/dist.py) on CPU.
+"""world_size 2 / 3 / 4 gloo runs of the multi-GPU path on CPU.
 
-The exchange / merge / all-reduce plumbing is the product's; the per-rank table is an oracle-backed stand-in (the HIP
-table needs a GPU), so what is covered here is: read sharding, owner routing, grouped send/recv, result reduction --
-and that the sharded answer is bit-identical to the single-process one."""
+The product's exchange is native (kg_comm.hip; tests/test_gpu_comm.py runs it on the GPU).  Here its protocol runs as the Python model
+of kat_amd/dist.py over gloo, the per-rank table an oracle-backed stand-in (the HIP table needs a GPU): read sharding, owner
+routing, the region-ordered chunked exchange with its ordering claims CHECKED, out-of-band records, result reduction -- and the
+sharded answer must be bit-identical to the single-process one."""
 import os
 import socket
 
@@ -14,10 +15,12 @@ import torch.multiprocessing as mp
 
 from kat_amd import dist as kdist
 from kat_amd import synth
+from kat_amd.dist import owner_of_wide  # noqa: F401
+
 
 
 class OracleShard:
-    """Same duck type as kat_amd.dist.HipShard, backed by the CPU oracle table.  Its "region grid" is R buckets of a hash
+    """The duck type kat_amd.dist.exchange_merge is written against, backed by the CPU oracle table.  Its "region grid" is R buckets of a hash
     of the k-mer, so the region-ordered protocol (per-region counts, chunks of consecutive regions, runs per region) is
     exercised and CHECKED here: merge_chunk asserts that every aligned source really is ordered the way it claims."""
 
@@ -158,6 +161,50 @@ def test_shard_range_covers_everything():
 
 # ---------------------------------------------------------------- k > 32: exchange_merge_wide --------------------------------
 
+def exchange_merge_wide(shard, group=None, force=False):
+    """exchange_merge for wide tables: every (k-mer, count) record goes to owner_of_w(k-mer); on return shard.table holds exactly
+    the k-mers this rank owns, counts summed over ranks (exact integer sums: bit-identical to one process).  The shard is
+    duck-typed (part_sizes / partition / rebuild) like the one-word exchange's."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and not (force and dist.is_initialized()):
+        return shard
+    rank = dist.get_rank(group)
+    dev = shard.device
+    meta = torch.tensor([shard.k, int(shard.canonical)], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    if any(int(m[0]) != shard.k or int(m[1]) != int(shard.canonical) for m in metas):
+        raise ValueError("exchange_merge_wide: ranks disagree on k / canonical")
+    sizes = shard.part_sizes(world)                                          # records I hold for each owner
+    s_all = [torch.empty(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(s_all, torch.from_numpy(sizes).to(dev), group=group)
+    recv_from = np.array([int(s[rank]) for s in s_all], dtype=np.int64)      # what each peer holds for me
+    send_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    recv_off = np.concatenate([[0], np.cumsum(recv_from)]).astype(np.int64)
+    send = shard.partition(world, send_off[:-1].astype(np.uint64), int(send_off[-1]))
+    recv = [torch.empty(max(int(recv_off[-1]), 1), dtype=torch.int64, device=dev) for _ in range(3)]
+    ops = []
+    for p in range(world):
+        a, n_out = int(send_off[p]), int(sizes[p])
+        b, n_in = int(recv_off[p]), int(recv_from[p])
+        if p == rank:
+            for r, s in zip(recv, send):
+                r[b:b + n_in].copy_(s[a:a + n_out])
+            continue
+        for r, s in zip(recv, send):
+            if n_out:
+                ops.append(dist.P2POp(dist.isend, s[a:a + n_out], p, group))
+            if n_in:
+                ops.append(dist.P2POp(dist.irecv, r[b:b + n_in], p, group))
+    for r in (dist.batch_isend_irecv(ops) if ops else []):
+        r.wait()
+    if dev.type == "cuda":
+        torch.cuda.current_stream().synchronize()
+    del send
+    shard.rebuild(recv[0], recv[1], recv[2], int(recv_off[-1]))
+    return shard
+
+
 class OracleWideShard:
     """Same duck type as kat_amd.dist.HipWideShard (part_sizes / partition / rebuild), backed by the wide CPU oracle table."""
 
@@ -205,8 +252,8 @@ def _wide_worker(rank, world, port, out_dir):
     t1 = ko.WideTable(KW, True).count_bases(reads)
     t2 = ko.WideTable(KW, False).count_bases(asm)
     t1.add((1 << 85) + 12345, (1 << 33) + rank)                                # a count above 32 bits travels like any other
-    o1 = kdist.exchange_merge_wide(OracleWideShard(t1)).table
-    o2 = kdist.exchange_merge_wide(OracleWideShard(t2)).table
+    o1 = exchange_merge_wide(OracleWideShard(t1)).table
+    o2 = exchange_merge_wide(OracleWideShard(t2)).table
     hi_, lo_, _ = o1.dump_sorted()
     assert (kdist.owner_of_wide(hi_, lo_, KW, world) == rank).all()
     mx, cc, sp = ko.comp(o1, o2, 1.0, 1.0, 101, 101)

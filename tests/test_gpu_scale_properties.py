@@ -1,5 +1,4 @@
-"""Larger inputs (generated and counted on the device) checked through size-independent properties, plus the torch
-plumbing of the multi-GPU exchange on one GPU."""
+"""Larger inputs (generated and counted on the device) checked through size-independent properties."""
 import numpy as np
 import pytest
 
@@ -73,39 +72,3 @@ def test_device_owner_matches_host_mirror(engine):
         keys = dk.download(np.uint64)
         part_of = np.repeat(np.arange(n_parts), sizes.astype(np.int64))
         assert np.array_equal(kdist.owner_of(keys, 23, n_parts), part_of)
-
-
-def test_hipshard_torch_plumbing(engine):
-    """HipShard moves records through torch CUDA tensors that alias katgpu's arena (what RCCL sends and receives); applying
-    every owner's slice of the send list back to the emptied table rebuilds it."""
-    import torch
-    torch.cuda.set_device(0)
-    g = synth.genome(80000, seed=12)
-    src = engine.table(27, True).count_bases(synth.reads(g, 0, 5000, seed=7))
-    ka, ca = src.dump_sorted()
-    shard = kdist.HipShard(src)
-    geo = shard.geometry()
-    sizes, cnt = shard.begin_exchange(4)
-    assert cnt.is_cuda and cnt.dtype == torch.int32 and tuple(cnt.shape) == (4, int(geo[2]))
-    assert np.array_equal(cnt.sum(1).cpu().numpy(), sizes)
-    total = int(sizes.sum())
-    bufs = shard.exchange_buffers(total, 1000)
-    ks, cs = bufs["send_keys"], bufs["send_counts"]
-    assert ks.is_cuda and ks.dtype == torch.int64 and ks.numel() == total and cs.dtype == torch.int32
-    assert all(rk.numel() == 1000 and rc.numel() == 1000 for rk, rc in bufs["recv"])
-    arena = engine.scratch(0)
-    assert arena.ptr <= ks.data_ptr() < arena.ptr + arena.capacity          # views into the arena: no allocation next to it
-    big = shard.extract(4, bufs)
-    assert len(big[0]) == 0
-    assert np.array_equal(np.sort(ks.cpu().numpy().view(np.uint64)), ka) and int(cs.sum()) == int(ca.sum())
-    shard.clear()
-    off = np.concatenate([[0], np.cumsum(sizes)])
-    R = int(geo[2])
-    for p in (2, 0, 3, 1):                                                  # one owner's slice per call, as if from four peers
-        a, b = int(off[p]), int(off[p + 1])
-        shard.merge_chunk(0, R, [dict(keys=ks[a:b], counts=cs[a:b], rcnt=cnt[p], n=b - a, p1=geo[4], p2=geo[5], own=False, offset=0)], 0)
-    shard.end_exchange()
-    kb, cb = src.dump_sorted()
-    assert np.array_equal(ka, kb) and np.array_equal(ca, cb)
-    out = kdist.allreduce_u64([np.arange(5, dtype=np.uint64)], torch.device("cuda", 0))      # world 1: identity
-    assert np.array_equal(out[0], np.arange(5, dtype=np.uint64))

@@ -299,57 +299,6 @@ def test_wide_checksums_at_scale(engine):
         assert np.array_equal(x, y)
 
 
-def _wide_dist_worker(rank, world, port, out_dir):
-    import torch
-    import torch.distributed as dist
-    from kat_amd import dist as kdist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    eng = kat_amd.Engine(0)
-    k, G, n_reads, contig = 45, 400000, 40000, 50000
-    g = synth.genome(G, seed=11)
-    lo, hi = kdist.shard_range(n_reads // 2, rank, world)
-    reads = synth.reads(g, 2 * lo, 2 * (hi - lo), seed=1)
-    c_lo, c_hi = kdist.shard_range(G // contig, rank, world)
-    asm = synth.stream_of_contigs(g[c_lo * contig:c_hi * contig], contig)
-    t1 = eng.table(k, True, size_hint=1 << 22).count_bases(reads)
-    t2 = eng.table(k, False, size_hint=1 << 20).count_bases(asm)
-    t1.merge_host_wide([1 << 21], [12345], [(1 << 33) + rank])
-    o1 = kdist.exchange_merge_wide(kdist.HipWideShard(t1, staged=True)).table
-    o2 = kdist.exchange_merge_wide(kdist.HipWideShard(t2, staged=True)).table
-    hi_, lo_, _ = o1.dump_sorted()
-    assert (kdist.owner_of_wide(hi_, lo_, k, world) == rank).all()           # the device's owner function == its host mirror
-    mx, cc, sp = kat_amd.comp(o1, o2, 1.0, 1.0, 201, 101)
-    h, gm = o1.hist(1, 300, 1), o1.gcp(1.0, 100)
-    mx, cc, sp, h, gm = kdist.allreduce_u64([mx, cc, sp, h, gm], torch.device("cpu"))
-    if rank == 0:
-        np.savez(os.path.join(out_dir, "wide.npz"), mx=mx, cc=cc, sp=sp, h=h, gm=gm)
-    dist.barrier()
-    dist.destroy_process_group()
-    eng.close()
-
-
-@pytest.mark.parametrize("world", [2, 3])
-def test_wide_ranks_sharing_one_gpu_match_single_process(engine, ko, tmp_path, world):
-    """The multi-GPU path at k = 45 (exchange_merge_wide: owner partition -> all-to-all -> rebuild), gloo carrying the records
-    between ranks that share this GPU: bit-identical to one process."""
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_wide_dist_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    got = np.load(tmp_path / "wide.npz")
-    k, G, n_reads, contig = 45, 400000, 40000, 50000
-    g = synth.genome(G, seed=11)
-    o1 = ko.WideTable(k, True).count_bases(synth.reads(g, 0, n_reads, seed=1))
-    o1.add(((1 << 21) << 64) | 12345, world * (1 << 33) + world * (world - 1) // 2)
-    o2 = ko.WideTable(k, False).count_bases(synth.stream_of_contigs(g, contig))
-    mx, cc, sp = ko.comp(o1, o2, 1.0, 1.0, 201, 101)
-    assert np.array_equal(got["cc"], cc) and np.array_equal(got["mx"], mx) and np.array_equal(got["sp"], sp)
-    assert np.array_equal(got["h"], o1.hist(1, 300, 1)) and np.array_equal(got["gm"], o1.gcp(1.0, 100))
-
-
 @pytest.mark.parametrize("region_slots,round_items,spill_mod,extra", [
     (512, 100000, 0, {}), (1024, 3000000, 7, {}), (6144, 400000, 0, {}), (256, 150000, 5, {"KATGPU_TEST_GROW_NOMEM": "1"})])
 def test_partitioned_counter_wide(region_slots, round_items, spill_mod, extra):
