@@ -115,13 +115,8 @@ struct Place {             // the bit budget of one table: wave-uniform, a handf
     uint64_t m1, mr;       // masks of n1 and rb bits
 };
 __device__ __host__ __forceinline__ uint64_t low_mask(uint32_t bits) { return bits >= 64 ? ~0ULL : (1ULL << bits) - 1; }
-__device__ __host__ __forceinline__ uint32_t place_mul24(uint32_t a, uint32_t b) {   // a, b < 2^24, product < 2^32: the full-rate multiply
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul24(a, b);
-#else
-    return a * b;
-#endif
-}
+// floor(h * n / 2^32): a 32-bit hash scaled to [0, n) with one v_mul_hi_u32 (full rate on gfx950: tools/ubench_valu.hip)
+__device__ __host__ __forceinline__ uint32_t place_scale(uint32_t h, uint32_t n) { return (uint32_t)(((uint64_t)h * n) >> 32); }
 // 32 well-mixed bits (the top ones) of up to 64 input bits
 __device__ __host__ __forceinline__ uint32_t place_mix(uint32_t lo, uint32_t hi, uint32_t c) {
     uint32_t x = lo ^ ((hi << 19) | (hi >> 13));
@@ -145,8 +140,8 @@ __device__ __host__ __forceinline__ Place place_make(uint32_t k, uint32_t p1, ui
     return p;
 }
 struct Placed { uint32_t d1, d2; uint64_t rem; };
-// g1 scaled to [0, p1): (22 hash bits * p1) >> 22 (p1 <= 1024)
-__device__ __host__ __forceinline__ uint32_t place_g1(uint32_t l_lo, uint32_t l_hi, const Place& p) { return place_mul24(place_mix(l_lo, l_hi, PLACE_G1) >> 10, p.p1) >> 22; }
+// g1 scaled to [0, p1)
+__device__ __host__ __forceinline__ uint32_t place_g1(uint32_t l_lo, uint32_t l_hi, const Place& p) { return place_scale(place_mix(l_lo, l_hi, PLACE_G1), p.p1); }
 __device__ __host__ __forceinline__ uint32_t place_g2(uint32_t r_lo, uint32_t r_hi, const Place& p) { return p.l2e ? place_mix(r_lo, r_hi, PLACE_G2) >> (32 - p.l2e) : 0u; }
 // level-1 digit of a k-mer
 __device__ __host__ __forceinline__ uint32_t place_digit1_of(uint64_t key, const Place& p) {
@@ -190,11 +185,9 @@ __device__ __host__ __forceinline__ uint64_t place_key_d(uint32_t d1, uint32_t d
 }
 // ... from base1 = place_base1(d1) and y2 = d2 : rem
 __device__ __host__ __forceinline__ uint64_t place_key(uint64_t base1, uint64_t y2, const Place& p) { return place_key_d((uint32_t)base1, place_digit2(y2, p), y2 & p.mr, p); }
-// home offset inside a region of S slots from the remainder: 18 hash bits scaled with the full-rate multiply (regions have fewer
-// than 2^14 slots wherever a region is walked; the general form is for one-region tables of any size)
+// home offset inside a region of S slots from the remainder
 __device__ __host__ __forceinline__ uint32_t place_offset(uint64_t rem, const Place& p, uint32_t S) {
-    const uint32_t h = place_mix((uint32_t)rem, (uint32_t)(rem >> 32), PLACE_G3);
-    return S < (1u << 14) ? place_mul24(h >> 14, S) >> 18 : (uint32_t)(((uint64_t)h * S) >> 32);
+    return place_scale(place_mix((uint32_t)rem, (uint32_t)(rem >> 32), PLACE_G3), S);
 }
 
 struct Probe {

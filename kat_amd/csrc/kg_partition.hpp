@@ -1503,14 +1503,17 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                 // claimed (inline, or through the queue).  Lanes that are done take no part in the LDS operations.
 #pragma unroll
                 for (int rr = 0; rr < NR; ++rr) {
+                    // every lane reads and adds whether its k-mer is still looking or not (a settled one reads its last slot and adds
+                    // 0): an exec mask and a branch around each of the eight LDS operations of a round cost more issue slots than the
+                    // operations, and issue is what bounds this walk (cycle stamps, round 4)
                     unsigned long long seen[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) { seen[u] = 0; if (pend[u]) seen[u] = rk[slot[u]]; }
+                    for (int u = 0; u < U; ++u) seen[u] = rk[slot[u]];
                     bool claim[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const bool hit = pend[u] && seen[u] != 0 && (seen[u] >> cb) == rem[u];
-                        if (hit) add1(slot[u]);
+                        (void)__hip_atomic_fetch_add(&rk32[2 * slot[u]], hit ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         pend[u] = pend[u] && !hit;
                         claim[u] = pend[u] && seen[u] == 0;
                         slot[u] = (pend[u] && !claim[u]) ? next_slot(slot[u]) : slot[u];

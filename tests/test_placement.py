@@ -30,15 +30,14 @@ def model(key, k, p1, l2):
     rb = n1 - l2e
     L, H = key & ((1 << n1) - 1), key >> n1
     assert H < p1
-    d1 = (H + (((mix(L, G1) >> 10) * p1) >> 22)) % p1
+    d1 = (H + ((mix(L, G1) * p1) >> 32)) % p1
     L2, H2 = L & ((1 << rb) - 1), L >> rb
     d2 = H2 ^ ((mix(L2, G2) >> (32 - l2e)) if l2e else 0)
     return d1, d2, L2, rb
 
 
 def model_offset(rem, S):
-    h = mix(rem, G3)
-    return ((h >> 14) * S) >> 18 if S < (1 << 14) else (h * S) >> 32
+    return (mix(rem, G3) * S) >> 32
 
 
 CASES = [(27, 584, 10), (27, 1024, 9), (31, 777, 10), (32, 1000, 10), (32, 1, 0), (16, 5, 3), (15, 37, 6), (7, 1, 0), (5, 3, 2),
