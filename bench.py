@@ -43,8 +43,21 @@ WORKLOADS = {
     "comp-rr": (150_000_000, 1_000_000_000, 31, "kat comp reads-vs-reads"),
 }
 CONFIG_ALIAS = {2: "hist", 3: "gcp", 4: "comp", 5: "comp-rr"}
-PROFILE_JSON = {"comp": "profiles/r03_final_pmc_fetch_write.json", "hist": "profiles/r03_final_hist_pmc_fetch_write.json",
-                "gcp": "profiles/r03_final_gcp_pmc_fetch_write.json", "comp-rr": "profiles/r03_final_comp-rr_pmc_fetch_write.json"}
+PROFILE_JSON = {"comp": "profiles/r04_final_pmc_fetch_write.json", "hist": "profiles/r04_final_hist_pmc_fetch_write.json",
+                "gcp": "profiles/r04_final_gcp_pmc_fetch_write.json", "comp-rr": "profiles/r04_final_comp-rr_pmc_fetch_write.json"}
+# the sources the count stage's kernels are made of: a committed profile describes the kernels of ONE state of these files
+# (tools/profile_bench.sh records their digest next to the counters; pmc_traffic refuses a profile taken from other code)
+STAGE_SOURCES = ["kat_amd/csrc/kg_partition.hpp", "kat_amd/csrc/kg_device.hpp", "kat_amd/csrc/kg_l1_lean.hpp", "kat_amd/csrc/kg_kernels.hpp",
+                 "kat_amd/csrc/kg_count.hip", "kat_amd/csrc/kg_table.hip"]
+
+
+def stage_sources_digest():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in STAGE_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
 
 
 def parse_args():
@@ -112,9 +125,14 @@ def pmc_traffic(a, world):
     try:
         prof = json.load(open(path))
     except Exception:
-        return None, None
+        return None, "no committed counter profile (%s)" % PROFILE_JSON[a.workload]
+    have, want = prof.get("_stage_sources_sha256_16"), stage_sources_digest()
+    if have != want:                                     # counters of other kernels than the ones that just ran: not this run's traffic
+        return None, "%s was taken from other stage-kernel sources (digest %s, now %s): re-run tools/profile_bench.sh" % (PROFILE_JSON[a.workload], have, want)
     kb, rounds = 0.0, 0
     for name, e in prof.items():
+        if name.startswith("_"):
+            continue
         base = name.replace("kg::", "").replace("void ", "").split("<")[0].split("(")[0]
         if base.startswith(("k_p1", "k_p2", "k_p3", "k_s1", "k_s2", "k_s3", "k_insert_keys")):
             kb += 2.0 * e.get("FETCH_SIZE_KB_total", 0.0) + e.get("WRITE_SIZE_KB_total", 0.0)

@@ -52,7 +52,6 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
     resolve_pending(c);
     if (c->reserve_thread.joinable()) c->reserve_thread.join();
     scan_cache_release(c);
-    retired_maps_release(c, 0);
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
     if (c->arena) hipFree(c->arena);

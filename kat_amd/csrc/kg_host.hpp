@@ -61,10 +61,6 @@ struct katgpu_ctx {
     std::mutex pool_mu;                    // (the pool is reached from the caller's thread, a table's allocation thread and the reservation thread)
     std::thread reserve_thread;            // katgpu_reserve: memory of a table to come, being allocated beside the caller's work
     std::atomic<size_t> reserve_bytes{0};  // ... of this size (pool_alloc waits for it only when it could be what is asked for)
-    // Input files that were read through a mapping (kg_scan.hip: tmpfs) stay mapped until the context goes: taking the page tables of a
-    // 16 GB mapping down costs ~0.2 s under the process's mmap lock, which the next file's mapping and page faults would wait for
-    std::vector<std::pair<void*, size_t>> retired_maps;
-    size_t retired_map_bytes = 0;
     std::unordered_map<void*, size_t> block_bytes;      // real size of every live pooled-class allocation
     // scratch arena of the partitioned counter (level-1 / level-2 buffers, histograms); kept across calls
     uint8_t* arena = nullptr;
@@ -91,7 +87,6 @@ struct katgpu_ctx {
     } scan;
 };
 void scan_cache_release(katgpu_ctx* c);      // kg_scan.hip
-void retired_maps_release(katgpu_ctx* c, size_t keep_bytes);   // kg_scan.hip: unmap retired input mappings beyond keep_bytes (0: all)
 
 struct katgpu_table {
     katgpu_ctx* ctx = nullptr;

@@ -249,7 +249,7 @@ struct P1LdsT {
     uint32_t bad[P1_BLOCK + 2];
     uint32_t rcode[LEAN ? P1_BLOCK + 2 : 1];   // LEAN: word v = reverse complement of code word 511 - v (the tile read backwards on the other strand)
     uint32_t pad_[2];                   // (pos starts on a 16-byte boundary: the grouped copy-out reads it four entries at a time)
-    uint32_t pos[P1_TILE_BYTES + (SEG ? 3 * PB : 0)];   // per staged k-mer: bucket << 16 | strand << 15 (LEAN) | tile position; SEG: a bucket's run padded to whole groups of four
+    uint32_t pos[P1_TILE_BYTES + (SEG ? 3 * PB : 0) + (LEAN ? 32 : 0)];   // per staged k-mer: bucket << 16 | strand << 15 (LEAN) | tile position; SEG: a bucket's run padded to whole groups of four; LEAN: + 32 dump slots
 };
 constexpr uint32_t P1_PAD = 0xFFFFFFFFu;   // "no k-mer" in pos[] (the bucket field of an entry is at most 1023)
 
@@ -499,12 +499,24 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         }
         lds_barrier();
         // sweep 2: park the tile position of every k-mer in its bucket's run
+        if (LEAN) {
+            // (straight-line like sweep 1: every window reads its bucket's run start -- the bucket of a window without a k-mer is a valid
+            // index all the same -- and writes; those without a k-mer write into one of 32 dump slots behind the array)
+            constexpr uint32_t DUMP0 = sizeof(L.pos) / 4 - 32;
 #pragma unroll
-        for (int j = 0; j < PART_ITEMS; ++j)
-            if (valid >> (LEAN ? 15 - j : j) & 1) {
+            for (int j = 0; j < PART_ITEMS; ++j) {
                 const uint32_t run0 = L.off[br[j] >> 16];
-                L.pos[(grouped ? 4 * run0 : run0) + (br[j] & (LEAN ? 0x7FFFu : 0xFFFFu))] = (br[j] & (LEAN ? 0xFFFF8000u : 0xFFFF0000u)) | (tid * PART_ITEMS + j);
+                const bool ok = (valid >> (15 - j) & 1) != 0;
+                L.pos[ok ? (grouped ? 4 * run0 : run0) + (br[j] & 0x7FFFu) : DUMP0 + (tid & 31)] = (br[j] & 0xFFFF8000u) | (tid * PART_ITEMS + j);
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PART_ITEMS; ++j)
+                if (valid >> j & 1) {
+                    const uint32_t run0 = L.off[br[j] >> 16];
+                    L.pos[(grouped ? 4 * run0 : run0) + (br[j] & 0xFFFFu)] = (br[j] & 0xFFFF0000u) | (tid * PART_ITEMS + j);
+                }
+        }
         lds_barrier();
         // the k-mer of a staged entry (the chosen strand's, read off that strand's stream) from three code words
         auto entry_src = [&](uint32_t v, const uint32_t*& src, uint32_t& wd, uint32_t& o) {

@@ -22,7 +22,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/prof_$(echo $c | tr 'A-Z' 'a-z' | cut -d_ -f1)
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python "$root/bench.py" $quiet > /dev/null 2> "$out/${tag}_pmc_$c.err"
 done
-python - "$out/${tag}_pmc_fetch_write.json" <<'PY'
+python - "$out/${tag}_pmc_fetch_write.json" "$root" <<'PY'
 import csv, glob, json, re, sys
 agg = {}
 for d, name in (("/tmp/prof_fetch", "FETCH_SIZE"), ("/tmp/prof_write", "WRITE_SIZE")):
@@ -35,6 +35,10 @@ for d, name in (("/tmp/prof_fetch", "FETCH_SIZE"), ("/tmp/prof_write", "WRITE_SI
             e[name + "_KB_total"] = e.get(name + "_KB_total", 0.0) + float(row["Counter_Value"])
             if name == "FETCH_SIZE":
                 e["launches"] += 1
+sys.path.insert(0, sys.argv[2])
+import bench
+agg["_stage_sources_sha256_16"] = bench.stage_sources_digest()      # the kernels these counters belong to (bench.py checks it)
+agg["_stage_sources"] = bench.STAGE_SOURCES
 json.dump(agg, open(sys.argv[1], "w"), indent=1)
 PY
 for w in hist gcp comp-rr; do
