@@ -8,13 +8,12 @@
 # counters cannot be collected in one pass on gfx950 -- rocprofv3 aborts with "exceeds the capabilities of the hardware" and then hangs).
 # Then config 4 from files to files at full size (tools/e2e_config4.py) -> <tag>_e2e_config4.json.
 set -u
-tag=${1:-r03_final}
+tag=${1:-r04_final}
 root=$PWD
 out=$PWD/gpurun_out
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 quiet="--steps 1 --warmup 0 --no-cpu-baseline --no-e2e"
-timeout 900 python "$root/bench.py" --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 rm -rf /tmp/prof_stats /tmp/prof_fetch /tmp/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$root/bench.py" $quiet > /dev/null 2> "$out/${tag}_stats.err"
 find /tmp/prof_stats -name '*kernel_stats.csv' -exec cp {} "$out/${tag}_kernel_stats.csv" \;
@@ -41,14 +40,18 @@ agg["_stage_sources_sha256_16"] = bench.stage_sources_digest()      # the kernel
 agg["_stage_sources"] = bench.STAGE_SOURCES
 json.dump(agg, open(sys.argv[1], "w"), indent=1)
 PY
+# the plain line comes after the counters: its roofline.traffic is read from the profile that was just taken (same sources: bench.py checks)
+mkdir -p "$root/profiles" && cp "$out/${tag}_pmc_fetch_write.json" "$root/profiles/${tag}_pmc_fetch_write.json"
+timeout 900 python "$root/bench.py" --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 for w in hist gcp comp-rr; do
-  timeout 600 python "$root/bench.py" --workload $w --steps 3 --warmup 1 --no-e2e --no-cpu-baseline > "$out/${tag}_${w}_bench.json" 2> "$out/${tag}_${w}_bench.err"
   rm -rf /tmp/prof_w /tmp/prof_wp
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_w -- python "$root/bench.py" --workload $w $quiet > /dev/null 2> "$out/${tag}_${w}_stats.err"
   find /tmp/prof_w -name '*kernel_stats.csv' -exec cp {} "$out/${tag}_${w}_kernel_stats.csv" \;
   bash "$root/tools/profile_pmc_workload.sh" "$tag" $w
+  cp "$out/${tag}_${w}_pmc_fetch_write.json" "$root/profiles/${tag}_${w}_pmc_fetch_write.json"
+  timeout 600 python "$root/bench.py" --workload $w --steps 3 --warmup 1 --no-e2e --no-cpu-baseline > "$out/${tag}_${w}_bench.json" 2> "$out/${tag}_${w}_bench.err"
 done
-timeout 900 env KATGPU_SCAN_THREADS=32 python "$root/tools/e2e_config4.py" > "$out/${tag}_e2e_config4.json" 2> "$out/${tag}_e2e_config4.err"
+timeout 900 python "$root/tools/e2e_config4.py" > "$out/${tag}_e2e_config4.json" 2> "$out/${tag}_e2e_config4.err"
 # SQ view of the stage kernels (one partition round of a reduced config): wave cycles, waits, issue, LDS conflicts
 rm -rf /tmp/prof_sq
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d /tmp/prof_sq -- python "$root/bench.py" --reads 60000000 --genome 200000000 $quiet > /dev/null 2> "$out/${tag}_sq.err"
