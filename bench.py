@@ -359,16 +359,18 @@ def main():
             name = "count stage (partitioned): per round level-1 scatter (+ count/scan when exact), then level 2 + apply in passes"
             per_kernel = {n: {"launches": prof[n]["launches"], "avg_ms": round(prof[n]["ms"] / max(1, prof[n]["launches"]), 3)} for n in stage}
             # each stage kernel against the roofline of its OWN bytes (what it has to move, not what the PMC counters say it moved):
-            #   level 1: the ASCII stream in, an 8-byte item per k-mer out;  level 2: those in, (4 + hb)-byte remainders out (hb from the
+            #   level 1: the ASCII stream in, an item per k-mer out (6 bytes at k = 27);  level 2: those in, (4 + hb)-byte remainders out (hb from the
             #   table's remainder bits);  apply: the remainders in + the table swept in and out once per round (slot_bytes per slot)
             if k <= 32 and results.get("geo1") is not None:
                 p1_, p2_, slot_b1, slot_b2 = results["geo1"]
                 rb = int(kat_amd.binding.place_keys(k, p1_, max(0, p2_.bit_length() - 1), [])[4])
-                hb = 0 if rb <= 31 else 1 if rb <= 39 else 2 if rb <= 47 else 4
+                hi_bytes = lambda bits: 0 if bits <= 31 else 1 if bits <= 39 else 2 if bits <= 47 else 4
+                hb = hi_bytes(rb)
+                item1 = 4 + hi_bytes(2 * k - (p1_.bit_length() - 1))                   # a level-1 item: the k-mer below its level-1 digit
                 items = inst_reads + inst2_local
                 rounds1 = max(1, prof["part_l1_scatter"]["launches"] // a.steps - (1 if two_tables else 0))      # rounds of the first input
-                own = {"part_l1_scatter": (reads.nbytes + in2_bytes) + 8.0 * items,
-                       "part_l2": (8.0 + 4 + hb) * items,
+                own = {"part_l1_scatter": (reads.nbytes + in2_bytes) + float(item1) * items,
+                       "part_l2": (item1 + 4.0 + hb) * items,
                        "part_apply": (4.0 + hb) * items + 2.0 * slot_b1 * cap1 * rounds1 + 2.0 * slot_b2 * cap2}
                 for n, b in own.items():
                     ms = prof[n]["ms"] / a.steps

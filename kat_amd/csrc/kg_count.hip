@@ -97,6 +97,7 @@ static const uint64_t g_test_ap_seg = hook_u64("KATGPU_TEST_AP_SEG", 0) & ~3ULL;
 static const uint32_t g_apply_nr = (uint32_t)hook_u64("KATGPU_APPLY_NR", 2);            // A/B: probe rounds of the packed apply at the bench's shape (1, 2 or 3)
 static const uint32_t g_apply_min_q = (uint32_t)hook_u64("KATGPU_APPLY_MIN_Q", 72);     // A/B: queue entries per wave the SECOND workgroup of a CU must leave (>= 72)
 static const uint32_t g_apply_per_cu = (uint32_t)hook_u64("KATGPU_APPLY_PER_CU", 0);   // A/B: packed apply workgroups per CU (0: as many as the LDS holds)
+static const bool g_p2_stamp = hook_u64("KATGPU_P2_STAMP", 0) != 0;   // diagnostic: the bench-shape one-pass level 2 with cycle stamps (printed per pass)
 static const bool g_apply_stamp = hook_u64("KATGPU_APPLY_STAMP", 0) != 0;              // diagnostic: the bench-shape apply with cycle stamps (printed per pass)
 
 static const uint32_t g_test_hb = hook("KATGPU_TEST_HB") ? (uint32_t)strtoul(hook("KATGPU_TEST_HB"), nullptr, 10) : 0;   // A/B: wider level-2 items than needed (1, 2, 4)
@@ -499,6 +500,18 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); \
                             else hipLaunchKernelGGL((k_p2_fast<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); break;
+                    if (g.hb == 1 && g.hb1 != 4 && g_p2_stamp) {                       // diagnostic: the bench's shape with cycle stamps
+                        unsigned long long* stamps = spill_n + 16;
+                        HIPCHK(c, hipMemsetAsync(stamps, 0, 6 * sizeof(unsigned long long), c->stream));
+                        KG_LDS_ATTR((k_p2_fast<1, false, true>), sizeof(P2FLds<1>));
+                        hipLaunchKernelGGL((k_p2_fast<1, false, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<1>), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, stamps);
+                        unsigned long long st[6];
+                        HIPCHK(c, hipMemcpyAsync(st, stamps, sizeof st, hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        const double tot = (double)(st[0] + st[1] + st[2] + st[3] + st[4]);
+                        if (st[5]) fprintf(stderr, "[katgpu] level-2 stamps (lane 0 of every workgroup, cycles summed): wait for the tile %.0f %%  digit + rank %.0f %%  scan %.0f %%  staging %.0f %%  copy-out %.0f %%; %llu tiles, %.0f cycles per tile\n",
+                                           100 * st[0] / tot, 100 * st[1] / tot, 100 * st[2] / tot, 100 * st[3] / tot, 100 * st[4] / tot, st[5], tot / st[5]);
+                    } else
                     switch (g.hb) { KG_FOR_HB(KG_P2F) }
 #undef KG_P2F
                 }

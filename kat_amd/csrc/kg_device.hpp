@@ -529,6 +529,20 @@ __device__ __forceinline__ uint64_t lane_value(uint64_t v, int src) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP steps (row_shr 1, 2, 4, 8 inside the rows of sixteen, then row_bcast 15 / 31
+// across them): each step is a move through the data-parallel-primitive path of the VALU, a few cycles -- the __shfl_up form is six
+// dependent ds_bpermute round trips (~200 cycles each on gfx950), between two barriers of every level-1 and level-2 tile.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);     // row_shr:1 (zeros come in at a row's start)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);     // row_shr:8: every row holds its own scan
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3: lane 15 / 47's total
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3: lane 31's total
+    return (uint32_t)x;
+}
+
 // flush a per-lane "new distinct" tally: wave reduction, lane 0 adds into one of 64 stripes
 __device__ __forceinline__ void flush_distinct(const DevTable& t, uint32_t new_distinct) {
     uint32_t v = new_distinct;

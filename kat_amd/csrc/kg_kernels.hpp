@@ -24,19 +24,21 @@ constexpr int LANES_WITH_STARTS = CHUNK_STARTS / BASES_PER_LANE; // 254
 
 // 16 ASCII bytes -> 16 two-bit codes (MSB-first in a u32) + 16 "not ACGTacgt" flags (MSB-first in the low 16 bits).
 // code = x ^ (x >> 1) with x = (c >> 1) & 3 maps A,C,G,T (either case) to 0,1,2,3 (mer_dna.hpp:46-63).
+// Four bytes at a time (a byte-by-byte form was 200 of level 1's 1750 vector instructions per wave and tile): x per byte; the letter
+// that x stands for, looked up by v_perm_b32 with x as the selector; a byte that is not that letter (case folded) is flagged; the
+// four 2-bit codes / four flags of a word are gathered by one multiply each (the partial products land on distinct bits: no carries).
 __device__ __forceinline__ void encode16(const uint32_t w[4], uint32_t& code, uint32_t& bad) {
     code = 0; bad = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            uint32_t c = (w[q] >> (8 * b)) & 0xFF;
-            uint32_t u = c & 0xDF;                                   // fold case
-            uint32_t ok = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
-            uint32_t x = (c >> 1) & 3;
-            code = (code << 2) | (x ^ (x >> 1));
-            bad = (bad << 1) | (ok ^ 1);
-        }
+        const uint32_t v = w[q];
+        const uint32_t x = (v >> 1) & 0x03030303u;                                   // A, C, T, G -> 0, 1, 2, 3
+        const uint32_t c2 = x ^ ((x >> 1) & 0x01010101u);                            // A, C, G, T -> 0, 1, 2, 3
+        const uint32_t letter = __builtin_amdgcn_perm(0u, 0x67746361u, x);           // 'a', 'c', 't', 'g' by x
+        const uint32_t diff = (v | 0x20202020u) ^ letter;
+        const uint32_t nz = ((((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) >> 7) & 0x01010101u;    // 1 per byte that is no such letter
+        code = (code << 8) | ((c2 * 0x40100401u) >> 24);                             // byte 0 (the first base) into the top pair
+        bad = (bad << 4) | ((nz * 0x08040201u) >> 24);
     }
 }
 

@@ -146,9 +146,7 @@ static_assert(sizeof(P2Lds<0>) <= 160 * 1024 && sizeof(P2Lds<1>) <= 160 * 1024 &
 // exclusive prefix, *total gets the grand total.  Two barriers inside.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += o; }
+    const uint32_t inc = wave_inclusive_scan(v);
     if (lane == 63) wave_tot[wave] = inc;
     lds_barrier();
     uint32_t prefix = 0, tot = 0;
@@ -251,7 +249,7 @@ struct P1LdsT {
     uint32_t pad_[2];                   // (pos starts on a 16-byte boundary: the grouped copy-out reads it four entries at a time)
     uint32_t pos[P1_TILE_BYTES + (SEG ? 3 * PB : 0) + (LEAN ? 32 : 0)];   // per staged k-mer: bucket << 16 | strand << 15 (LEAN) | tile position; SEG: a bucket's run padded to whole groups of four; LEAN: + 32 dump slots
 };
-constexpr uint32_t P1_PAD = 0xFFFFFFFFu;   // "no k-mer" in pos[] (the bucket field of an entry is at most 1023)
+constexpr uint32_t P1_PAD = 0xFFFF0000u;   // "no k-mer" in pos[]: the bucket field of an entry is at most 1023, so the top bit says it; read as an entry it is tile position 0
 
 struct LaneWindow {                       // the 96-bit sliding window of kg_kernels.hpp's K1, as an object
     uint64_t hi, lo, m;
@@ -337,12 +335,7 @@ __device__ __forceinline__ void p1_tile_stage(P1LdsT<LEAN, SEG, PB>& L, const ui
 // exclusive scan over 2 * P1_BLOCK logical entries (entry b and b + 512 per lane); three barriers
 __device__ __forceinline__ void p1_scan_pair(uint32_t v0, uint32_t v1, uint32_t* wave_tot, uint32_t& e0, uint32_t& e1) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t i0 = v0, i1 = v1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t a = __shfl_up(i0, d, 64), b = __shfl_up(i1, d, 64);
-        if (lane >= (uint32_t)d) { i0 += a; i1 += b; }
-    }
+    const uint32_t i0 = wave_inclusive_scan(v0), i1 = wave_inclusive_scan(v1);
     lds_barrier();
     if (lane == 63) { wave_tot[wave] = i0; wave_tot[8 + wave] = i1; }
     lds_barrier();
@@ -503,11 +496,14 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
             // (straight-line like sweep 1: every window reads its bucket's run start -- the bucket of a window without a k-mer is a valid
             // index all the same -- and writes; those without a k-mer write into one of 32 dump slots behind the array)
             constexpr uint32_t DUMP0 = sizeof(L.pos) / 4 - 32;
+            uint32_t run0[PART_ITEMS];
+#pragma unroll
+            for (int j = 0; j < PART_ITEMS; ++j) run0[j] = L.off[br[j] >> 16];
 #pragma unroll
             for (int j = 0; j < PART_ITEMS; ++j) {
-                const uint32_t run0 = L.off[br[j] >> 16];
+                asm volatile("" : "+v"(run0[j]));               // (keeps the read where it is: sunk into the select below it becomes a branch and a wait per window)
                 const bool ok = (valid >> (15 - j) & 1) != 0;
-                L.pos[ok ? (grouped ? 4 * run0 : run0) + (br[j] & 0x7FFFu) : DUMP0 + (tid & 31)] = (br[j] & 0xFFFF8000u) | (tid * PART_ITEMS + j);
+                L.pos[ok ? (grouped ? 4 * run0[j] : run0[j]) + (br[j] & 0x7FFFu) : DUMP0 + (tid & 31)] = (br[j] & 0xFFFF8000u) | (tid * PART_ITEMS + j);
             }
         } else {
 #pragma unroll
@@ -519,16 +515,19 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         }
         lds_barrier();
         // the k-mer of a staged entry (the chosen strand's, read off that strand's stream) from three code words
-        auto entry_src = [&](uint32_t v, const uint32_t*& src, uint32_t& wd, uint32_t& o) {
-            uint32_t p = v & (LEAN ? 0x7FFFu : 0xFFFFu);
+        // A staged entry's window starts at base p of its strand's stream.  With q = p - 1: word wd = q >> 4 (-1 for p = 0: the word
+        // before the array, whose value does not matter) and a funnel shift by sh = 30 - 2 (q & 15) = 0 ... 30 -- no special case for a
+        // window that starts on a word boundary (v_alignbit_b32 takes its amount mod 32: a shift by 32 it cannot do).
+        auto entry_src = [&](uint32_t v, const uint32_t*& src, int32_t& wd, uint32_t& sh) {
+            const uint32_t p = v & (LEAN ? 0x7FFFu : 0xFFFFu);
+            int32_t q = (int32_t)p - 1;
             src = L.code;
-            if (LEAN && (v & 0x8000u)) { p = P1_TILE_BYTES - k - p; src = L.rcode; }   // the other strand's stream, read backwards
-            wd = p >> 4; o = p & 15;
+            if (LEAN && (v & 0x8000u)) { q = (int32_t)(P1_TILE_BYTES - 1 - k) - (int32_t)p; src = L.rcode; }   // the other strand's stream, read backwards
+            wd = q >> 4; sh = 2u * (~(uint32_t)q & 15u);
         };
-        auto entry_key = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t o) -> uint64_t {
-            // the 64 bits that start 2 o bits into c0 : c1 : c2 (v_alignbit_b32 shifts right by its amount mod 32)
-            const uint32_t sh = (32 - 2 * o) & 31;
-            const uint32_t h1 = o ? __builtin_amdgcn_alignbit(c0, c1, sh) : c0, h0 = o ? __builtin_amdgcn_alignbit(c1, c2, sh) : c1;
+        auto entry_key = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t sh) -> uint64_t {
+            // the 64 bits that start 32 - sh bits into c0 : c1 : c2
+            const uint32_t h1 = __builtin_amdgcn_alignbit(c0, c1, sh), h0 = __builtin_amdgcn_alignbit(c1, c2, sh);
             uint64_t key1 = (((uint64_t)h1 << 32) | h0) >> (64 - 2 * k);
             if (!LEAN) key1 = canon_if(key1, k, canonical);
             return key1;
@@ -545,22 +544,24 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                 const uint32_t b = e.x >> 16;                      // (a group's first entry is a k-mer)
                 uint32_t c0[4], c1[4], c2[4], o[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t* src; uint32_t wd;
-                    entry_src(ev[q] == P1_PAD ? 0u : ev[q], src, wd, o[q]);
+                for (int q = 0; q < 4; ++q) {                  // (a padding entry reads tile position 0 of the forward stream: harmless)
+                    const uint32_t* src; int32_t wd;
+                    entry_src(ev[q], src, wd, o[q]);
                     c0[q] = src[wd]; c1[q] = src[wd + 1]; c2[q] = src[wd + 2];
                 }
                 const uint32_t gahead = gi - L.off[b];
                 const uint32_t grel = ((uint32_t)L.cursor[b] >> 2) + gahead;              // group of the segment
+                uint32_t re = L.real[b];
+                asm volatile("" : "+v"(re));                   // (read with the other two, not in a branch of the test below)
                 // a segment takes seg_real k-mers at most (the groups of a run before this one are full ones)
-                const bool room = grel < seg_groups && L.real[b] + 4 * gahead + 4 <= seg_real;
+                const bool room = (grel < seg_groups) & (re + 4 * gahead + 4 <= seg_real);
                 uint32_t lo[4], hi[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint64_t r1 = entry_key(c0[q], c1[q], c2[q], o[q]) & g.pl.m1;
-                    const bool pad = ev[q] == P1_PAD;
-                    lo[q] = pad ? 0xFFFFFFFFu : (uint32_t)r1;
-                    hi[q] = pad ? 0xFFFFFFFFu : (uint32_t)(r1 >> 32);
+                    const uint32_t pad = (uint32_t)((int32_t)ev[q] >> 31);                // all ones for a padding entry
+                    lo[q] = (uint32_t)r1 | pad;
+                    hi[q] = (uint32_t)(r1 >> 32) | pad;
                 }
                 if (room) {
                     const u32x4 glo = {lo[0], lo[1], lo[2], lo[3]};
@@ -594,7 +595,7 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                 for (int u = 0; u < CU; ++u) { const uint32_t i = idx0 + u * P1_BLOCK; v[u] = L.pos[i < total ? i : idx0]; }
 #pragma unroll
                 for (int u = 0; u < CU; ++u) {
-                    const uint32_t* src; uint32_t wd;
+                    const uint32_t* src; int32_t wd;
                     entry_src(v[u], src, wd, o[u]);
                     c0[u] = src[wd]; c1[u] = src[wd + 1]; c2[u] = src[wd + 2];
                     const uint32_t b = v[u] >> 16;
@@ -995,6 +996,13 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
             L.cur[tid] = 0;
             off2[(uint64_t)b1 * g.P2 + tid] = obase + (uint64_t)tid * cap;
         }
+        // Cycle stamps at the bench's shape (round 4; 32.7 K cycles per tile): a third is the wait for the tile's loads, the rest rank 20 %,
+        // scan 13 % (before the DPP scan), staging 16 %, copy-out 17 %.  Issuing tile t + 1's loads earlier does not hide that wait: issued
+        // before the copy-out (registers free) the stores queue behind them and the copy-out takes what the wait took, and more (180 ms per
+        // step against 153); issued before the ranking they do not fit the registers at sixteen items per lane (19 spilled), and at twelve
+        // (no spill) the ranking grows by what the wait shrinks (a wave sits at the issue of its loads until the memory pipeline takes
+        // them) while the smaller tiles cost 8 ms in padding here and 6 in the apply.  The wait is a CU's read rate with one workgroup on
+        // it -- 9 bytes per clock --, not a latency another instruction order could cover.
         for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
             const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
             TileItems<N, W1> key;
@@ -1518,6 +1526,8 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                     // every lane reads and adds whether its k-mer is still looking or not (a settled one reads its last slot and adds
                     // 0): an exec mask and a branch around each of the eight LDS operations of a round cost more issue slots than the
                     // operations, and issue is what bounds this walk (cycle stamps, round 4)
+                    // (Two slots per round -- a slot and its successor in one ds_read2_b64, so that fewer k-mers go through the queue -- measured
+                    // 167 ms per step against 154.5: the second compare costs every k-mer more than the drains it saves.)
                     unsigned long long seen[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) seen[u] = rk[slot[u]];

@@ -30,9 +30,17 @@ def gc_count(keys, k):
     return g
 
 
-def gcp(keys, counts, k, bins=1000):
+def gc_count_popcount(keys, k):
+    """The same number for arrays of 10^9 k-mers (the loop above makes k passes): a base is G or C exactly when its two bits differ,
+    so the count is the number of set bits of (x ^ x >> 1) at the even positions below 2k.  tests check it against gc_count."""
+    x = np.asarray(keys, dtype=np.uint64)
+    even = np.uint64(sum(1 << (2 * i) for i in range(k)))
+    return np.bitwise_count((x ^ (x >> np.uint64(1))) & even).astype(np.int64)
+
+
+def gcp(keys, counts, k, bins=1000, gc=gc_count):
     """k rows (GC count 0 .. k-1: '# Rows:<k>'), bins + 1 columns (frequency 0 .. bins, the last a catch-all)."""
-    g = gc_count(keys, k)
+    g = gc(keys, k)
     c = np.minimum(np.asarray(counts, dtype=np.uint64), np.uint64(bins)).astype(np.int64)
     keep = g < k                                          # the matrix has k rows: a k-mer made of G and C only has no row
     flat = np.bincount(g[keep] * (bins + 1) + c[keep], minlength=k * (bins + 1))

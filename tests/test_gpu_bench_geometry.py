@@ -69,27 +69,16 @@ def _same_tables(tp, td, inst):
     assert np.array_equal(tp.hist(high=100000), td.hist(high=100000))
 
 
-def test_config4_geometry_partitioned_equals_direct(engine):
-    """k = 27, the table of config 4 (300 M reads vs 1 Gbp: 4.9 G slots), filled from 100 M reads of that library: one full
-    12.4 G-item round in two passes.  ~40 GB per table, ~15 GB of reads, the arena: fits one MI355X."""
-    k, genome, n_reads = 27, 1_000_000_000, 100_000_000
-    hint = int(_expected_distinct(300_000_000 * (L - k + 1), genome, k) / 0.62) + (1 << 20)     # bench.py's hint1
-    tp, td = _both_ways(engine, k, n_reads, genome, hint)
-    geo = tp.geometry()
-    assert (geo.p1, geo.p2) == (512, 1024) and geo.region_slots > 8192, (geo.p1, geo.p2, geo.region_slots)
-    _same_tables(tp, td, n_reads * (L - k + 1))
-    tp.free(); td.free()
-    engine.release_scratch()
-
-
 def test_config4_full_size_partitioned_equals_direct(engine):
     """The whole of config 4's read library -- 300 M reads, 37.2 G k-mer instances, the three partition rounds of the bench step -- against
     the direct kernel (one global atomic per k-mer, ~3 s).  The reads are generated in slices (the table, its twin and the arena
     leave no room for 45 GB of them at once): a slice is counted both ways, then the next."""
     k, genome, n_reads, step = 27, 1_000_000_000, 300_000_000, 100_000_000
-    hint = int(_expected_distinct(n_reads * (L - k + 1), genome, k) / 0.62) + (1 << 20)
+    hint = int(_expected_distinct(n_reads * (L - k + 1), genome, k) / 0.62) + (1 << 20)      # bench.py's hint1
     g = engine.synth_genome(genome, seed=20260927)
     tp = engine.table(k, True, size_hint=hint)
+    geo = tp.geometry()
+    assert (geo.p1, geo.p2) == (512, 1024) and geo.region_slots > 8192, (geo.p1, geo.p2, geo.region_slots)
     td = engine.table(k, True, size_hint=hint, like=tp)
     rec = L + 1
     for first in range(0, n_reads, step):
@@ -108,6 +97,50 @@ def test_config4_full_size_partitioned_equals_direct(engine):
     _same_tables(tp, td, n_reads * (L - k + 1))
     tp.free(); td.free()
     engine.release_scratch()
+
+
+def _count_config(engine, k, genome, n_reads):
+    """A whole config of BASELINE.json counted on the device the way `bench.py` does (same generator, seeds and size hint)."""
+    hint = int(_expected_distinct(n_reads * (L - k + 1), genome, k) / 0.62) + (1 << 20)
+    g = engine.synth_genome(genome, seed=20260927)
+    reads = engine.synth_reads(g, genome, first_read=0, n_reads=n_reads, read_len=L, frag_len=350, err_ppm=2000, seed=1)
+    g.free()
+    engine.profile_reset()
+    t = engine.table(k, True, size_hint=hint)
+    t.count_bases_device(reads.ptr, reads.nbytes)
+    reads.free()
+    prof = engine.profile()
+    assert prof["part_apply"]["launches"] > 0 and prof["count"]["launches"] == 0, prof
+    engine.release_scratch()
+    return t
+
+
+def test_config2_full_size_hist_against_the_second_restatement(engine):
+    """BASELINE.json's config 2 at its full size -- `kat hist`, 50 M reads, k = 27 -- : the table's multiset leaves the device, the sum of
+    its counts is the number of windows, and the histogram is the one tests/independent.py (written from the user documentation)
+    makes of the multiset."""
+    from tests import independent as ind
+    k, n_reads = 27, 50_000_000
+    t = _count_config(engine, k, 100_000_000, n_reads)
+    h = t.hist()
+    keys, counts = t.export()
+    assert keys.size == t.stats()["distinct"] and int(counts.sum(dtype=np.uint64)) == n_reads * (L - k + 1)
+    assert np.array_equal(h, ind.hist(counts))
+    t.free()
+
+
+def test_config3_full_size_gcp_against_the_second_restatement(engine):
+    """Config 3 at its full size -- `kat gcp`, 100 M reads, k = 27: the GC x coverage matrix against tests/independent.py from the
+    exported multiset (GC counts by the popcount form, itself checked against the base-by-base one on a sample)."""
+    from tests import independent as ind
+    k, n_reads = 27, 100_000_000
+    t = _count_config(engine, k, 200_000_000, n_reads)
+    gm = t.gcp()
+    keys, counts = t.export()
+    assert int(counts.sum(dtype=np.uint64)) == n_reads * (L - k + 1)
+    assert np.array_equal(ind.gc_count_popcount(keys[:2_000_000], k), ind.gc_count(keys[:2_000_000], k))
+    assert np.array_equal(gm, ind.gcp(keys, counts, k, gc=ind.gc_count_popcount))
+    t.free()
 
 
 def test_config4_geometry_prefix_against_the_oracle():

@@ -40,11 +40,10 @@ def kernels(tmp_path):
 def test_no_scratch_and_the_stage_kernels_keep_their_budgets(tmp_path):
     ks = kernels(tmp_path)
     assert len(ks) > 100
-    # No kernel of the library spills -- but for two shapes the register allocator lands one step past its budget on: the bench's
-    # level-1 scatter keeps ONE dword across its tile loop (a store and a load per 8160-start tile), the exact level 2 -- the
-    # fall-back of the one-pass edition -- a handful in its item-by-item copy-out, and the one-pass level 2 of 6-byte items from 6-byte
+    # No kernel of the library spills -- but for two shapes the register allocator lands one step past its budget on: the exact level 2 --
+    # the fall-back of the one-pass edition -- a handful in its item-by-item copy-out, and the one-pass level 2 of 6-byte items from 6-byte
     # items (remainders of 40-47 bits: not the bench's shape) four loop-invariant values.
-    allowed = {"k_p1v2_scatter<true, true, 512>": 8, "k_p2<": 40, "k_p2_fast<2, false": 24}
+    allowed = {"k_p2<": 40, "k_p2_fast<2, false": 24}
     spilled = {n: v for n, v in ks.items() if v["scratch"] > max([lim for pre, lim in allowed.items() if n.startswith(pre)], default=0)}
     assert not spilled, spilled
 
