@@ -149,10 +149,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     const uint32_t inc = wave_inclusive_scan(v);
     if (lane == 63) wave_tot[wave] = inc;
     lds_barrier();
-    uint32_t prefix = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < PART_BLOCK / 64; ++w) { uint32_t x = wave_tot[w]; if ((uint32_t)w < wave) prefix += x; tot += x; }
-    *total = tot;
+    // the sixteen wave totals: lane w of every wave takes wave w's and the same scan gives every wave all the prefixes (a loop over the
+    // waves with a comparison each kept sixteen lane masks alive across the kernel: scalar registers spilled into vector ones)
+    const uint32_t sc = wave_inclusive_scan(lane < PART_BLOCK / 64 ? wave_tot[lane] : 0u);
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    *total = lane_value(sc, PART_BLOCK / 64 - 1);
+    const uint32_t prefix = wv ? lane_value(sc, (int)wv - 1) : 0u;
     lds_barrier();
     return prefix + inc - v;
 }
@@ -339,11 +341,13 @@ __device__ __forceinline__ void p1_scan_pair(uint32_t v0, uint32_t v1, uint32_t*
     lds_barrier();
     if (lane == 63) { wave_tot[wave] = i0; wave_tot[8 + wave] = i1; }
     lds_barrier();
-    uint32_t p0 = 0, p1 = 0, t0 = 0;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) { uint32_t x = wave_tot[w], y = wave_tot[8 + w]; t0 += x; if ((uint32_t)w < wave) { p0 += x; p1 += y; } }
+    // the sixteen wave totals (eight of the first half, eight of the second) in one scan: lane w of every wave takes entry w
+    const uint32_t sc = wave_inclusive_scan(lane < 16 ? wave_tot[lane] : 0u);
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    const uint32_t p0 = wv ? lane_value(sc, (int)wv - 1) : 0u;           // first-half totals of the waves before this one
+    const uint32_t p1 = lane_value(sc, 7 + (int)wv);                       // all of the first half + second-half totals of the waves before
     e0 = p0 + i0 - v0;
-    e1 = t0 + p1 + i1 - v1;
+    e1 = p1 + i1 - v1;
 }
 
 static __global__ void __launch_bounds__(P1_BLOCK)
@@ -802,70 +806,109 @@ __device__ __forceinline__ void scatter_tile2(P2Lds<HB>& L, const PartGeom g, co
 // ---- the one-pass edition's tile ----
 // LDS carve of k_p2_fast.  A sub-bucket's run has a fixed start and capacity (run of digit b = groups [b * capg, (b + 1) * capg) of the
 // bucket's part of the level-2 buffer), so all a workgroup keeps per sub-bucket is how many groups it has written: 32 bits.
+// CARRY (all but 8-byte items, whose tiles leave no room): what a sub-bucket's k-mers of a tile leave of a group of four -- up to
+// three -- waits in LDS for the next tile instead of leaving as a padded group: the runs hold no padding but their last group's (it was
+// 9 % of the level-2 buffer at the bench's 16 k-mers per tile and sub-bucket: slots the apply had to read and skip).
 template <int HB>
 struct P2FLds {
+    static constexpr bool CARRY = HB != 4;
     uint32_t cur[MAX_PARTS];           // groups written into each sub-bucket's run so far
-    uint32_t hist[MAX_PARTS];          // k-mers of the tile per sub-bucket
-    uint32_t goff[MAX_PARTS];          // first staged group of the sub-bucket's k-mers of this tile
+    uint32_t hist[MAX_PARTS + 64];     // k-mers of the tile per sub-bucket (CARRY: + those carried over); + one dump counter per lane of a wave
+    uint32_t goff[MAX_PARTS];          // first staged group of the sub-bucket's k-mers of this tile (CARRY: | its whole groups << 16)
     uint32_t wave_tot[32];
     uint32_t pad_[32];                 // (st_lo starts on a 16-byte boundary)
-    uint32_t st_lo[L2Fmt<HB>::NS];     // staged remainders, grouped by sub-bucket: low words ...
-    typename HiWord<HB>::type st_hi[HB ? L2Fmt<HB>::NS : 4];   // ... high parts ...
+    static constexpr uint32_t CBASE = L2Fmt<HB>::NS;           // CARRY: sub-bucket b's carried k-mers are entries CBASE + 3 b, + 1, + 2 of the staging arrays
+    uint32_t st_lo[L2Fmt<HB>::NS + (CARRY ? 3 * MAX_PARTS : 0)];     // staged remainders, grouped by sub-bucket: low words ...
+    typename HiWord<HB>::type st_hi[HB ? L2Fmt<HB>::NS + (CARRY ? 3 * MAX_PARTS : 0) : 4];   // ... high parts ...
     uint16_t grp_b[L2Fmt<HB>::NS / 4]; // ... and the sub-bucket of every staged group
 };
-static_assert(sizeof(P2FLds<0>) <= 160 * 1024 && sizeof(P2FLds<1>) <= 160 * 1024 && sizeof(P2FLds<2>) <= 160 * 1024 && sizeof(P2FLds<4>) <= 160 * 1024, "LDS");
+static_assert(sizeof(P2FLds<0>) <= 160 * 1024 - 256 && sizeof(P2FLds<1>) <= 160 * 1024 - 256 && sizeof(P2FLds<2>) <= 160 * 1024 - 256 && sizeof(P2FLds<4>) <= 160 * 1024 - 256, "LDS");
 
-// Counting-sort one tile's k-mers of a bucket by their level-2 digit through LDS and append every digit's groups to its run: a digit's
-// k-mers of the tile are padded to whole groups of four in LDS ("no item") and leave as groups -- one 16-byte store of low words + one
-// of high parts per four k-mers; what does not fit its run goes to the overflow list as a k-mer (through the inverse).  All 1024
-// lanes must call it (barriers inside).  The copy-out works two groups per lane at once, so that the dependent LDS round trips of the
-// two overlap.
+// Counting-sort one tile's k-mers of a bucket by their level-2 digit through LDS and append every digit's whole groups to its run -- one
+// 16-byte store of low words + one of high parts per four k-mers; what does not fit its run goes to the overflow list as a k-mer
+// (through the inverse).  CARRY: `carry_n` is thread b's count of sub-bucket b's carried k-mers (in, and out for the next tile); they
+// rank first.  Without: a digit's k-mers of the tile are padded to whole groups in LDS ("no item").  All 1024 lanes must call it
+// (barriers inside).  The copy-out works two groups per lane at once, so that the dependent LDS round trips of the two overlap.
 template <int HB, bool W1, bool STAMP = false>
 __device__ __forceinline__ void scatter_tile2_fast(P2FLds<HB>& L, const PartGeom g, const uint32_t b1, const TileItems<L2Fmt<HB>::N, W1>& key, uint32_t valid,
                                                    uint8_t* __restrict__ out /* the bucket's first run */, uint32_t capg /* groups per run */,
-                                                   uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap,
+                                                   uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap, uint32_t& carry_n,
                                                    unsigned long long* st = nullptr /* STAMP: cycles of [1] hash + rank, [2] scan, [3] staging, [4] copy-out */) {
     constexpr int N = L2Fmt<HB>::N;
+    constexpr bool CARRY = P2FLds<HB>::CARRY;
     auto now = [&]() -> unsigned long long { return STAMP ? (unsigned long long)clock64() : 0ULL; };
     const unsigned long long t0 = now();
     typedef typename HiWord<HB>::type hi_t;
     const uint32_t tid = threadIdx.x;
     const uint32_t P = g.P2;
-    if (tid < MAX_PARTS) L.hist[tid] = 0;
+    if (tid < MAX_PARTS) L.hist[tid] = CARRY ? carry_n : 0u;
     lds_barrier();
     uint32_t br[N];                                           // digit << 16 | rank inside the tile's run
-    // (A branch per slot, each waiting for its rank: taking the ranks of every slot -- those without a k-mer in a dump counter, as level
-    // 1 does -- and looking at them later left the compiler with sixteen digits in flight and seventeen spilled registers at the
-    // bench's shape, and a spill costs this kernel a trip to memory per phase: 179 ms per step against 145-150.)
+    // Straight-line, as level 1's sweep: every slot takes a rank -- those without a k-mer in one of 64 dump counters behind the histogram
+    // -- and a rank is looked at two slots after its atomic was issued: three LDS round trips in flight per lane where a branch per slot
+    // waited for each.  (It fits the registers since the block scan stopped keeping sixteen lane masks alive; before, it spilled
+    // seventeen, and a spill costs this kernel a trip to memory per phase: 179 ms per step against 145-150.)
+    {
+        uint32_t rk[N];
+        const uint32_t dump = MAX_PARTS + (tid & 63);
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        br[j] = 0;
-        if (valid >> j & 1) {
-            const uint32_t b = place_digit2_of(key.r1(j), g.pl);   // (one 32-bit multiply)
-            br[j] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+        for (int j = 0; j < N; ++j) {
+            const uint32_t b = place_digit2_of(key.r1(j), g.pl) & (MAX_PARTS - 1);   // (one 32-bit multiply; the mask: a slot without a k-mer holds any bits)
+            rk[j] = atomicAdd(&L.hist[(valid >> j & 1) ? b : dump], 1u);
+            br[j] = b << 16;
+            if (j >= 2) br[j - 2] |= rk[j - 2];
         }
+#pragma unroll
+        for (int j = N - 2; j < N; ++j) br[j] |= rk[j];
     }
     lds_barrier();
     const unsigned long long t1 = now();
     uint32_t total;                                           // staged groups of the tile
-    const uint32_t mine = tid < P ? L.hist[tid] : 0, mygroups = (mine + 3) >> 2;
+    const uint32_t mine = tid < P ? L.hist[tid] : 0;
+    const uint32_t mygroups = CARRY ? mine >> 2 : (mine + 3) >> 2;      // CARRY: whole groups only
     const uint32_t excl = block_exclusive_scan(mygroups, L.wave_tot, &total);
-    if (tid < MAX_PARTS) L.goff[tid] = excl;
+    if (tid < MAX_PARTS) L.goff[tid] = CARRY ? excl | (mygroups << 16) : excl;      // (at most 4864 staged groups, at most 4096 of one sub-bucket)
     if (tid < P) {
-        // the last group of the run: what the k-mers leave is "no item"; and whose groups these are
-        for (uint32_t q = mine; q & 3; ++q) { L.st_lo[excl * 4 + q] = 0xFFFFFFFFu; if (HB) L.st_hi[excl * 4 + q] = (hi_t)~(hi_t)0; }
-        for (uint32_t gq = 0; gq < mygroups; ++gq) L.grp_b[excl + gq] = (uint16_t)tid;
+        if (CARRY) {
+            // the carried k-mers are the first of the run's first group -- when there is one; else they stay where they are
+            if (mygroups) for (uint32_t q = 0; q < carry_n; ++q) { L.st_lo[excl * 4 + q] = L.st_lo[P2FLds<HB>::CBASE + 3 * tid + q]; if (HB) L.st_hi[excl * 4 + q] = L.st_hi[P2FLds<HB>::CBASE + 3 * tid + q]; }
+        } else {
+            // the last group of the run: what the k-mers leave is "no item"
+            for (uint32_t q = mine; q & 3; ++q) { L.st_lo[excl * 4 + q] = 0xFFFFFFFFu; if (HB) L.st_hi[excl * 4 + q] = (hi_t)~(hi_t)0; }
+        }
+        for (uint32_t gq = 0; gq < mygroups; ++gq) L.grp_b[excl + gq] = (uint16_t)tid;      // whose groups these are
     }
     lds_barrier();
     const unsigned long long t2 = now();
+    // (the run starts of four slots are read in one go -- a slot without a k-mer has a valid digit all the same --: a read per slot inside
+    // its branch is a round trip per slot; all sixteen at once do not fit the registers)
+    constexpr int SB = N % 8 == 0 && !W1 ? 8 : 4;
+    static_assert(N % SB == 0, "batches");
+    uint32_t go[SB];
 #pragma unroll
-    for (int j = 0; j < N; ++j)
-        if (valid >> j & 1) {
-            const uint32_t slot = L.goff[br[j] >> 16] * 4u + (br[j] & 0xFFFF);
-            const uint64_t rem = key.r1(j) & g.pl.mr;
-            L.st_lo[slot] = (uint32_t)rem;
-            if (HB) L.st_hi[slot] = (hi_t)(rem >> 32);
+    for (int j = 0; j < N; ++j) {
+        if (j % SB == 0) {
+#pragma unroll
+            for (int q = 0; q < SB; ++q) go[q] = L.goff[br[j + q] >> 16];
+#pragma unroll
+            for (int q = 0; q < SB; ++q) asm volatile("" : "+v"(go[q]));          // (keeps the reads out of the branches below)
         }
+        if (valid >> j & 1) {
+            const uint32_t b = br[j] >> 16, r = br[j] & 0xFFFF, gf = go[j % SB];
+            const uint64_t rem = key.r1(j) & g.pl.mr;
+            if (CARRY) {
+                // rank r of the run: in one of its whole groups, or one of the up to three k-mers behind them, which wait for the next tile
+                const uint32_t whole = (gf >> 16) * 4u;
+                const uint32_t slot = r < whole ? (gf & 0xFFFFu) * 4u + r : P2FLds<HB>::CBASE + 3 * b + (r - whole);
+                L.st_lo[slot] = (uint32_t)rem;
+                if (HB) L.st_hi[slot] = (hi_t)(rem >> 32);
+            } else {
+                const uint32_t slot = gf * 4u + r;
+                L.st_lo[slot] = (uint32_t)rem;
+                if (HB) L.st_hi[slot] = (hi_t)(rem >> 32);
+            }
+        }
+    }
     lds_barrier();
     const unsigned long long t3 = now();
     // copy-out, one staged group per lane and step, two steps at a time: the steps are independent of each other
@@ -879,7 +922,7 @@ __device__ __forceinline__ void scatter_tile2_fast(P2FLds<HB>& L, const PartGeom
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const uint32_t gi = in[u] ? gi0 + u * PART_BLOCK : gi0;
-            ahead[u] = L.cur[b[u]] + (gi - L.goff[b[u]]);
+            ahead[u] = L.cur[b[u]] + (gi - (CARRY ? L.goff[b[u]] & 0xFFFFu : L.goff[b[u]]));
             lo[u] = *reinterpret_cast<const u32x4*>(&L.st_lo[gi * 4]);
             hi[u] = typename HiGroup<HB>::type{};
             if (HB) hi[u] = *reinterpret_cast<const typename HiGroup<HB>::type*>(&L.st_hi[gi * 4]);
@@ -902,7 +945,38 @@ __device__ __forceinline__ void scatter_tile2_fast(P2FLds<HB>& L, const PartGeom
     lds_barrier();
     if (STAMP && st) { const unsigned long long t4 = now(); st[1] += t1 - t0; st[2] += t2 - t1; st[3] += t3 - t2; st[4] += t4 - t3; }
     if (tid < P) { const uint32_t c = L.cur[tid] + mygroups; L.cur[tid] = c < capg ? c : capg; }
+    if (CARRY) carry_n = mine & 3;
     // (the next tile's first barrier orders the cursor update before the next use)
+}
+
+// CARRY: what a bucket's last tile left waiting -- up to three k-mers per sub-bucket -- as the run's last group, padded with "no item"
+template <int HB>
+__device__ __forceinline__ void flush_carry2(P2FLds<HB>& L, const PartGeom g, const uint32_t b1, uint8_t* __restrict__ out, uint32_t capg,
+                                             uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap, uint32_t carry_n) {
+    const uint32_t tid = threadIdx.x;
+    if (tid >= g.P2 || !carry_n) return;
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool have = (uint32_t)q < carry_n;                       // (q < 3 then)
+        lo[q] = have ? L.st_lo[P2FLds<HB>::CBASE + 3 * tid + (q < 3 ? q : 0)] : 0xFFFFFFFFu;
+        hi[q] = have && HB ? (uint32_t)L.st_hi[HB ? P2FLds<HB>::CBASE + 3 * tid + (q < 3 ? q : 0) : 0] : 0xFFFFFFFFu;
+    }
+    const uint32_t c = L.cur[tid];
+    if (c < capg) {
+        const u32x4 glo = {lo[0], lo[1], lo[2], lo[3]};
+        typename HiGroup<HB>::type ghi{};
+        if constexpr (HB == 1) ghi = (hi[0] & 0xFFu) | ((hi[1] & 0xFFu) << 8) | ((hi[2] & 0xFFu) << 16) | (hi[3] << 24);
+        if constexpr (HB == 2) { ghi.x = (hi[0] & 0xFFFFu) | (hi[1] << 16); ghi.y = (hi[2] & 0xFFFFu) | (hi[3] << 16); }
+        l2_store_group<HB>(out, (uint64_t)tid * capg + c, glo, ghi);
+        L.cur[tid] = c + 1;
+    } else {
+        for (uint32_t q = 0; q < carry_n; ++q) {
+            const uint64_t rem = ((uint64_t)(HB ? hi[q] & (HB == 1 ? 0xFFu : 0xFFFFu) : 0u) << 32) | lo[q];
+            const unsigned long long at = atomicAdd(ovf_n, 1ULL);
+            if (at < ovf_cap) ovf_buf[at] = place_key_d(b1, tid, rem, g.pl);
+        }
+    }
 }
 
 // first item of bucket b1's runs in the exact edition: every run may end on up to three padding items
@@ -992,6 +1066,7 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
         uint8_t* runs = l2_buf + (obase >> 2) * L2Fmt<HB>::GS;                  // run of sub-bucket b: groups [b * capg, (b + 1) * capg) from here
         const uint32_t capg = (uint32_t)(cap >> 2);                             // (< 2^32: host-checked through the buffer's size)
         lds_barrier();
+        uint32_t carry_n = 0;                                                   // thread b: k-mers of sub-bucket b that wait for their group to fill
         if (tid < g.P2) {
             L.cur[tid] = 0;
             off2[(uint64_t)b1 * g.P2 + tid] = obase + (uint64_t)tid * cap;
@@ -1010,9 +1085,10 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
             if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
             lds_barrier();
             if (STAMP) { st[0] += (unsigned long long)clock64() - ta; st[5] += 1; }
-            scatter_tile2_fast<HB, W1, STAMP>(L, g, b1, key, valid, runs, capg, ovf_buf, ovf_n, ovf_cap, st);
+            scatter_tile2_fast<HB, W1, STAMP>(L, g, b1, key, valid, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n, st);
         }
         lds_barrier();
+        if constexpr (P2FLds<HB>::CARRY) { flush_carry2<HB>(L, g, b1, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n); lds_barrier(); }
         if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = L.cur[tid] << 2;
     }
     if (STAMP && tid == 0 && stamps) for (int i = 0; i < 6; ++i) atomicAdd(&stamps[i], st[i]);
