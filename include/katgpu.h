@@ -54,6 +54,8 @@ typedef enum katgpu_status {
 /* ---- context ---------------------------------------------------------------------------------------- */
 /* device: HIP ordinal, or -1 for the current device. */
 int         katgpu_init(int device, katgpu_ctx** ctx);
+/* HIP devices this process sees (the runtime's count: *_VISIBLE_DEVICES honoured); 0 when there is none or no runtime. */
+int         katgpu_device_count(void);
 void        katgpu_shutdown(katgpu_ctx* ctx);
 const char* katgpu_last_error(const katgpu_ctx* ctx);
 const char* katgpu_version(void);

@@ -33,7 +33,7 @@ EXPORTS = (
     "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
     "katgpu_table_partition_wide", "katgpu_table_merge_device_wide", "katgpu_table_regrows",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
-    "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_place_keys", "katgpu_reserve",
+    "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_place_keys", "katgpu_reserve", "katgpu_device_count",
     "katgpu_count_files_sharded", "katgpu_table_slot_bytes", "katgpu_comm_unique_id", "katgpu_comm_init", "katgpu_comm_free", "katgpu_comm_rank", "katgpu_comm_world", "katgpu_comm_transport",
     "katgpu_comm_transport_note", "katgpu_comm_barrier", "katgpu_exchange_merge", "katgpu_allreduce_u64", "katgpu_comm_stats",
 )

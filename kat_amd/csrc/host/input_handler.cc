@@ -30,8 +30,10 @@ katgpu_ctx* Engine::ctx() {
         // --gpus N: rank r takes device r (mod the devices there are: ranks may share one -- the exchange then goes through /dev/shm)
         int dev = -1;
         if (dist_ && world_ > 1) {
-            const char* nd = getenv("KATGPU_VISIBLE_DEVICES");      // how many devices the launcher saw (kat_main.cc)
-            const int n = nd ? std::max(1, atoi(nd)) : 1;
+            // how many devices THIS process sees (after the fork: the HIP runtime's count, which honours HIP_ / ROCR_VISIBLE_DEVICES);
+            // KATGPU_VISIBLE_DEVICES overrides it (fewer devices than there are: ranks share)
+            const char* nd = getenv("KATGPU_VISIBLE_DEVICES");
+            const int n = std::max(1, nd && atoi(nd) > 0 ? atoi(nd) : katgpu_device_count());
             dev = rank_ % n;
         }
         const double t0 = timing_now_ms();

@@ -73,26 +73,11 @@ int main(int argc, char* argv[]) {
     if (!gpus_given) return guarded(mode, argc - 1, argv + 1);
     if (mode != "hist" && mode != "gcp" && mode != "comp") { std::cerr << "Error: Parsing Command Line: --gpus applies to hist, gcp and comp" << std::endl; return 1; }
 
-    char id_file[] = "/tmp/katgpu-comm-XXXXXX";
-    const int fd = mkstemp(id_file);
-    if (fd < 0) { std::cerr << "Error: cannot create a rendezvous file in /tmp" << std::endl; return 5; }
-    close(fd);
-    unlink(id_file);                                          // rank 0 re-creates it (atomically, with the id inside)
-    // how many devices there are, without initialising HIP in this process: the ROCm sysfs nodes (one per GPU with a gfx target)
-    int n_dev = 0;
-    if (const char* v = getenv("KATGPU_VISIBLE_DEVICES")) n_dev = atoi(v);
-    if (n_dev <= 0) {
-        for (int i = 0; i < 64; ++i) {
-            const std::string p = "/sys/class/kfd/kfd/topology/nodes/" + std::to_string(i) + "/properties";
-            FILE* f = fopen(p.c_str(), "r");
-            if (!f) break;
-            char line[256];
-            while (fgets(line, sizeof line, f)) { unsigned long long v = 0; if (sscanf(line, "simd_count %llu", &v) == 1 && v > 0) ++n_dev; }
-            fclose(f);
-        }
-        if (n_dev <= 0) n_dev = 1;
-        setenv("KATGPU_VISIBLE_DEVICES", std::to_string(n_dev).c_str(), 1);
-    }
+    // the rendezvous file lives in a directory of this run's own (0700, a fresh name): nobody else can plant a file or a link there
+    char id_dir[] = "/tmp/katgpu-comm-XXXXXX";
+    if (!mkdtemp(id_dir)) { std::cerr << "Error: cannot create a rendezvous directory in /tmp" << std::endl; return 5; }
+    const std::string id_file = std::string(id_dir) + "/id";
+    // (which device a rank takes is decided in the rank, after the fork: the HIP runtime's own count -- Engine::ctx)
     std::vector<pid_t> kids;
     for (int r = 0; r < gpus; ++r) {
         const pid_t pid = fork();
@@ -117,6 +102,8 @@ int main(int argc, char* argv[]) {
             for (pid_t o : kids) if (o != k) kill(o, SIGTERM);                    // the others would wait for it for ever
         }
     }
-    unlink(id_file);
+    unlink(id_file.c_str());
+    unlink((id_file + ".tmp").c_str());
+    rmdir(id_dir);
     return first_bad;
 }

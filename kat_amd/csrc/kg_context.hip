@@ -6,6 +6,8 @@
 
 extern "C" const char* katgpu_version(void) { return "katgpu 0.1 (gfx950)"; }
 
+extern "C" int katgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+
 extern "C" int katgpu_init(int device, katgpu_ctx** out) {
     if (!out) return KATGPU_ERR_INVALID_ARG;
     *out = nullptr;

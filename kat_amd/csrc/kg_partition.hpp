@@ -1076,8 +1076,11 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
         // before the copy-out (registers free) the stores queue behind them and the copy-out takes what the wait took, and more (180 ms per
         // step against 153); issued before the ranking they do not fit the registers at sixteen items per lane (19 spilled), and at twelve
         // (no spill) the ranking grows by what the wait shrinks (a wave sits at the issue of its loads until the memory pipeline takes
-        // them) while the smaller tiles cost 8 ms in padding here and 6 in the apply.  The wait is a CU's read rate with one workgroup on
-        // it -- 9 bytes per clock --, not a latency another instruction order could cover.
+        // them) while the smaller tiles cost 8 ms in padding here and 6 in the apply; issued a piece at a time across all four phases (no
+        // wave ever waits at an issue; fits the registers since the block scan stopped keeping sixteen lane masks alive) the wait is gone
+        // -- 3 % -- and the copy-out takes 47 % instead of 17: the kernel's time does not change (138-142 ms against 138-150).  What a tile
+        // needs is its 98 KB in and ~90 KB out (x 1.3-1.5 in partial sectors) through a memory system that 256 CUs doing the same load to
+        // ~4.5 TB/s: wherever the wait is taken, it is for that.
         for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
             const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
             TileItems<N, W1> key;
@@ -1682,31 +1685,44 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
             // ---- back to the invariant (kg_device.hpp: table_add_pk): a slot counts 1 .. half, the rest goes to the side table.  The walk
             // found every counter there and added less than half, so none has carried; each lane looks at the slots it filled. ----
             lds_barrier();                                        // every wave's adds of this segment are in (and no wave grabs chunks any more)
+            // (after the run's last segment -- the only one, normally -- the write-back below does this on its way: the same lane, the same slots)
+            if (sbeg + seg_len < end) {
 #pragma unroll 1
-            for (int u = 0; u < KP; ++u) {
-                const uint32_t i = (u * BLOCK + tid) * 2;
-                if (i >= S) break;
-                const u64x2 ww = *reinterpret_cast<const u64x2*>(rk + i);
-                if ((ww.x & cmask) <= half && (ww.y & cmask) <= half) continue;
+                for (int u = 0; u < KP; ++u) {
+                    const uint32_t i = (u * BLOCK + tid) * 2;
+                    if (i >= S) break;
+                    const u64x2 ww = *reinterpret_cast<const u64x2*>(rk + i);
+                    if ((ww.x & cmask) <= half && (ww.y & cmask) <= half) continue;
 #pragma unroll 1
-                for (uint32_t j = 0; j < 2; ++j) {
-                    const unsigned long long w = rk[i + j];
-                    const uint64_t c = w & cmask;
-                    if (c <= half) continue;
-                    const uint64_t keep = ((c - 1) & (half - 1)) + 1;
-                    rk[i + j] = w - (c - keep);
-                    ovf_add(t, base + i + j, c - keep);
+                    for (uint32_t j = 0; j < 2; ++j) {
+                        const unsigned long long w = rk[i + j];
+                        const uint64_t c = w & cmask;
+                        if (c <= half) continue;
+                        const uint64_t keep = ((c - 1) & (half - 1)) + 1;
+                        rk[i + j] = w - (c - keep);
+                        ovf_add(t, base + i + j, c - keep);
+                    }
                 }
             }
             if (STAMP) st[3] += now() - t_post;
         }
         if (PF && rn < r_hi) prefetch(rn);                     // in flight behind the write-back
 
-        // ---- write-back: LDS -> HBM, 16 bytes per lane and store ----
-        lds_barrier();
+        // ---- write-back: LDS -> HBM, 16 bytes per lane and store; and back to the invariant on the way ----
         const unsigned long long t_wb = now();
 #pragma unroll
-        for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(t.keys + base + i) = *reinterpret_cast<const u32x4*>(rk + i); }
+        for (int u = 0; u < KP; ++u) {
+            const uint32_t i = (u * BLOCK + tid) * 2;
+            if (i < S) {
+                u64x2 ww = *reinterpret_cast<const u64x2*>(rk + i);
+                if ((ww.x & cmask) > half || (ww.y & cmask) > half) {        // (rare: a counter in the upper half of its range)
+                    const uint64_t c0 = ww.x & cmask, c1 = ww.y & cmask;
+                    if (c0 > half) { const uint64_t keep = ((c0 - 1) & (half - 1)) + 1; ww.x -= c0 - keep; ovf_add(t, base + i, c0 - keep); }
+                    if (c1 > half) { const uint64_t keep = ((c1 - 1) & (half - 1)) + 1; ww.y -= c1 - keep; ovf_add(t, base + i + 1, c1 - keep); }
+                }
+                *reinterpret_cast<u64x2*>(t.keys + base + i) = ww;
+            }
+        }
         lds_barrier();
         if (STAMP) { st[4] += now() - t_wb; st[5] += 1; }
         r = rn;
