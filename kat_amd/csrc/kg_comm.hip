@@ -457,7 +457,7 @@ static size_t exchange_bytes(uint64_t total_send, uint64_t set_records) {
 static int exchange_merge_wide(katgpu_comm* m, katgpu_table* t) {
     katgpu_ctx* c = m->ctx;
     const int world = m->world, rank = m->rank;
-    const uint64_t mine[2] = {t->d.k, t->d.canonical};
+    const uint64_t mine[2] = {t->dev().k, t->dev().canonical};
     std::vector<uint64_t> all((size_t)world * 2);
     int rc = allgather_u64(m, mine, 2, all.data());
     if (rc) return rc;
@@ -515,7 +515,7 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
     if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = m->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    if (t->d.keys_b) return exchange_merge_wide(m, t);
+    if (t->dev().keys_b) return exchange_merge_wide(m, t);
     const int world = m->world, rank = m->rank;
     const double t_begin = wall_ms();
 

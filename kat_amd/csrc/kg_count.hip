@@ -24,15 +24,15 @@ static const uint64_t g_test_max_starts = hook("KATGPU_TEST_MAX_STARTS") ? strto
 // the large counters into the side table and reports the new maximum.
 static int maybe_sweep(katgpu_table* t, uint64_t next_starts) {
     katgpu_ctx* c = t->ctx;
-    if (t->d.cbits) return KATGPU_OK;                          // packed tables take the checked add (kg_device.hpp: table_inc)
+    if (t->dev().cbits) return KATGPU_OK;                          // packed tables take the checked add (kg_device.hpp: table_inc)
     const uint64_t limit = g_test_sweep_thr ? 2 * g_test_sweep_thr - 1 : 0xFFFFFFFFULL;
     if (t->count_bound + t->unchecked_adds + next_starts <= limit) return KATGPU_OK;
     const uint32_t thr = g_test_sweep_thr ? (uint32_t)g_test_sweep_thr : 0x80000000u;
-    unsigned long long* scratch = (unsigned long long*)&t->d.ctrs[CTR_SCRATCH];
+    unsigned long long* scratch = (unsigned long long*)&t->dev().ctrs[CTR_SCRATCH];
     HIPCHK(c, hipMemsetAsync(scratch, 0, sizeof(uint64_t), c->stream));
     {
-        ScopedTimer tm(c, KATGPU_K_REGROW, t->d.cap);
-        hipLaunchKernelGGL(k_sweep, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, thr, scratch);
+        ScopedTimer tm(c, KATGPU_K_REGROW, t->dev().cap);
+        hipLaunchKernelGGL(k_sweep, dim3(grid_for(c, t->dev().cap, 256, 8)), dim3(256), 0, c->stream, t->dev(), thr, scratch);
     }
     uint64_t mx = 0;
     HIPCHK(c, hipMemcpyAsync(&mx, scratch, sizeof mx, hipMemcpyDeviceToHost, c->stream));
@@ -44,15 +44,15 @@ static int maybe_sweep(katgpu_table* t, uint64_t next_starts) {
 
 static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
     katgpu_ctx* c = t->ctx;
-    if (n < t->d.k) return KATGPU_OK;
-    if (t->d.keys_b) {                                         // wide k-mers: checked adds, nothing to sweep
+    if (n < t->dev().k) return KATGPU_OK;
+    if (t->dev().keys_b) {                                         // wide k-mers: checked adds, nothing to sweep
         const uint64_t n_chunks = (n + WIDE_CHUNK_STARTS - 1) / WIDE_CHUNK_STARTS;
         const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * 4);
         ScopedTimer tm(c, KATGPU_K_COUNT, n);
         if ((reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0)
-            hipLaunchKernelGGL(k_count_w<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
+            hipLaunchKernelGGL(k_count_w<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->dev(), dev_bases, (uint64_t)n, n_chunks);
         else
-            hipLaunchKernelGGL(k_count_w<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
+            hipLaunchKernelGGL(k_count_w<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->dev(), dev_bases, (uint64_t)n, n_chunks);
         HIPCHK(c, hipGetLastError());
         return KATGPU_OK;
     }
@@ -65,9 +65,9 @@ static int launch_count(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
     const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * c->count_blocks_per_cu);
     ScopedTimer tm(c, KATGPU_K_COUNT, n);
     if ((reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0)
-        hipLaunchKernelGGL(k_count<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
+        hipLaunchKernelGGL(k_count<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->dev(), dev_bases, (uint64_t)n, n_chunks);
     else
-        hipLaunchKernelGGL(k_count<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, dev_bases, (uint64_t)n, n_chunks);
+        hipLaunchKernelGGL(k_count<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->dev(), dev_bases, (uint64_t)n, n_chunks);
     HIPCHK(c, hipGetLastError());
     return KATGPU_OK;
 }
@@ -136,9 +136,9 @@ static int grow_beside_arena(katgpu_table* t, uint64_t incoming, uint64_t min_ca
     for (auto& l : stash) n_stash += l.second;
     katgpu_ctx* c = t->ctx;
     auto grow = [&]() -> int {
-        if (min_cap > t->d.cap) {
+        if (min_cap > t->dev().cap) {
             if (t->disable_grow) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
-            uint64_t nc = t->d.cap; while (nc < min_cap) nc *= 2;
+            uint64_t nc = t->dev().cap; while (nc < min_cap) nc *= 2;
             return regrow(t, nc);
         }
         return ensure_room(t, incoming);
@@ -167,7 +167,7 @@ static int grow_beside_arena(katgpu_table* t, uint64_t incoming, uint64_t min_ca
             const size_t m = std::min(chunk, (size_t)n_stash - i);
             if (hipMemcpyAsync(d, host.data() + i, m * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(c, KATGPU_ERR_DEVICE, "spill upload"); break; }
             ScopedTimer tm(c, KATGPU_K_COUNT, m);
-            hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, m, 256, 6)), dim3(256), 0, c->stream, t->d, (const uint64_t*)d, (uint64_t)m);
+            hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, m, 256, 6)), dim3(256), 0, c->stream, t->dev(), (const uint64_t*)d, (uint64_t)m);
             if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, KATGPU_ERR_DEVICE, "spill insert");
         }
         pool_release(c, d);
@@ -218,9 +218,14 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
         const uint64_t seg_cap = (pk_half(g.cbits) - 1) & ~3ULL;                              // a walk adds less than half the count range
         const uint64_t seg_len = g_test_ap_seg ? std::min<uint64_t>(g_test_ap_seg, seg_cap) : std::min<uint64_t>(AP2_SEGMENT, seg_cap);
         const dim3 grid(std::min<uint32_t>(regions, n_cu * per_cu));
+        // A table whose slots have not been cleared yet (katgpu_table::zero_from): this pass is their first sweep when its regions are the
+        // next in line -- the kernel starts every region of the pass from zeros and writes every one back; else they are cleared now.
+        const uint64_t r_lo = (uint64_t)g.b_lo * g.P2, r_hi = (uint64_t)g.b_hi * g.P2;
+        uint32_t zero_fill = 0;
+        if (t->zero_from != ~0ULL) { if (t->zero_from == r_lo) zero_fill = 1; else t->zero_rest(); }
 #define KG_APK(B, KP, HB, INL, HK, PF, NR) do { KG_LDS_ATTR((k_p3_apply_pk<B, KP, HB, INL, HK, PF, NR>), LDS_BYTES - 256); \
-            hipLaunchKernelGGL((k_p3_apply_pk<B, KP, HB, INL, HK, PF, NR>), grid, dim3(B), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, \
-                               qcap, seg_len, g_test_spill_mod); } while (0)
+            hipLaunchKernelGGL((k_p3_apply_pk<B, KP, HB, INL, HK, PF, NR>), grid, dim3(B), lds, c->stream, t->dv, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, \
+                               qcap, seg_len, g_test_spill_mod, zero_fill); } while (0)
         // probe rounds before the queue: 2 (measured at the bench size, same box: 163 ms per step against 177 with 3 and 198 with inline
         // claims in every round); a table's first round claims inline and keeps 3
 #define KG_APK_SHAPE(HB) case HB: \
@@ -230,13 +235,14 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
             else if (HB == 1 && g_apply_nr == 1 && !fresh) KG_APK(512, 10, 1, false, false, false, 1); \
             else if (HB == 1 && g_apply_nr == 3 && !fresh) KG_APK(512, 10, 1, false, false, false, 3); \
             else if (HB == 1 && g_apply_stamp && !fresh) { KG_LDS_ATTR((k_p3_apply_pk<512, 10, 1, false, false, false, 2, true>), LDS_BYTES - 256); \
-                hipLaunchKernelGGL((k_p3_apply_pk<512, 10, 1, false, false, false, 2, true>), grid, dim3(512), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, qcap, seg_len, g_test_spill_mod); } \
+                hipLaunchKernelGGL((k_p3_apply_pk<512, 10, 1, false, false, false, 2, true>), grid, dim3(512), lds, c->stream, t->dv, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, qcap, seg_len, g_test_spill_mod, zero_fill); } \
             else { if (fresh) KG_APK(512, 10, HB, true, false, false, 3); else KG_APK(512, 10, HB, false, false, false, 2); } \
             break;
         switch (g.hb) { KG_APK_SHAPE(0) KG_APK_SHAPE(1) KG_APK_SHAPE(2) default: return fail(c, KATGPU_ERR_DEVICE, "packed apply: item width %u", g.hb); }
 #undef KG_APK_SHAPE
 #undef KG_APK
         HIPCHK(c, hipGetLastError());
+        if (zero_fill) t->zero_from = r_hi >= t->dv.n_regions ? ~0ULL : r_hi;      // (regions [r_lo, r_hi) have had their first sweep)
         return KATGPU_OK;
     }
     // KV12: as many workgroups per CU as the regions' LDS footprint (and the 2048-thread limit) admits
@@ -247,7 +253,7 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
     const dim3 grid(std::min<uint32_t>(regions, n_cu * per_cu));
     const uint64_t seg_len = g_test_ap_seg ? std::min<uint64_t>(g_test_ap_seg, AP2_SEGMENT) : AP2_SEGMENT;
 #define KG_AP2(B, KP, HB, INL, QC, HK) do { KG_LDS_ATTR((k_p3_apply2<B, KP, 4, 3, HB, false, INL, true, QC, HK>), LDS_BYTES - 256); \
-        hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, INL, true, QC, HK>), grid, dim3(B), lds, c->stream, t->d, g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, \
+        hipLaunchKernelGGL((k_p3_apply2<B, KP, 4, 3, HB, false, INL, true, QC, HK>), grid, dim3(B), lds, c->stream, t->dev(), g, off2, l2_buf, spill_buf, spill_n, run_len, bucket_end, \
                            (unsigned long long*)nullptr, g_test_spill_mod, seg_len); } while (0)
 #define KG_AP2_SHAPE(HB) case HB: \
         if (hooked) KG_AP2(1024, 5, HB, false, AP2_QCAP_BIG, true); \
@@ -267,15 +273,15 @@ static int launch_apply(katgpu_table* t, const PartGeom& g, const uint64_t* off2
 // (all of them unless the geometry stops fitting, in which case the caller finishes with the direct kernel).
 static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n, size_t* done) {
     katgpu_ctx* c = t->ctx;
-    const uint32_t k = t->d.k;
+    const uint32_t k = t->dv.k;
     const size_t n_starts = n - k + 1;
     *done = 0;
     c->arena_borrowed = false;                    // a borrowed arena is only promised until the next count call
     if (n < 64) return KATGPU_OK;                 // (the tile loader reads whole 16-byte pieces: direct path)
     // A table hopelessly small for this input (KAT's default -H against a whole run) would spill nearly every k-mer of the
     // first round: give it room for 1/16 of the starts first -- cheap while it is still small, and before the arena exists.
-    if (!g_test_round_items && !t->disable_grow && t->d.cap < n_starts / 16) {
-        uint64_t nc = t->d.cap; while (nc < n_starts / 16) nc *= 2;
+    if (!g_test_round_items && !t->disable_grow && t->dv.cap < n_starts / 16) {
+        uint64_t nc = t->dv.cap; while (nc < n_starts / 16) nc *= 2;
         int grc = regrow(t, nc);
         if (grc) return grc;
     }
@@ -297,7 +303,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     // 14.8 bytes per k-mer of a round at hb = 1 (k = 27 at the bench size), 18.5 at hb = 4 -- with one pass; the level-2 buffer
     // holds one PASS of level 2 + apply (a CU-full of buckets, see the rounds below): 11.7 bytes with two passes.
     PartGeom g0;
-    if (!part_geometry(t->d, &g0)) return KATGPU_OK;                              // direct path
+    if (!part_geometry(t->dv, &g0)) return KATGPU_OK;                              // direct path
     const uint32_t hb0 = g0.hb;                                                  // a table that grows has more regions: never more remainder bits
     const uint32_t passes0 = std::max<uint32_t>(1, g0.P1 / pass_buckets(g0.P1, (uint32_t)c->n_cu));   // (rounded down: the buffer never too small)
     const double per_item = arena_bytes_per_item(hb0, passes0);
@@ -357,26 +363,26 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     while (pos < n_starts) {
         int rc = refresh_counters(t);
         if (rc) return rc;
-        if ((double)t->distinct > 0.6 * (double)t->d.cap) {
+        if ((double)t->distinct > 0.6 * (double)t->dv.cap) {
             bool lost = false;
-            rc = grow_beside_arena(t, 0, t->d.cap * 2, KeyLists(), &lost);
+            rc = grow_beside_arena(t, 0, t->dv.cap * 2, KeyLists(), &lost);
             if (rc) return rc;
             if (lost) break;                                                      // the caller re-enters with a fresh arena
         }
         PartGeom g;
-        if (!part_geometry(t->d, &g)) break;                                      // table too large for two levels: direct path
+        if (!part_geometry(t->dv, &g)) break;                                      // table too large for two levels: direct path
         if (g.hb > hb0) break;                                                    // (cannot happen: see hb0) the level-2 carve would not hold these items
         // (the segmented level 1 sizes its segments from this ratio, so it wants it even when one round takes everything)
         if (!ratio_known && !g_test_round_items && (n_starts - pos > round_items || (l1_fast_ok && n_starts - pos >= ((size_t)64 << 20)))) {
             const size_t probe_m = std::min<size_t>(n_starts - pos, (size_t)64 << 20) / tile_starts * tile_starts;
             const uint64_t pt = probe_m / tile_starts, ptw = (pt + W - 1) / W;
-            hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, dev_bases + pos, (uint64_t)(probe_m + k - 1), pt, ptw, hist1);
+            hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->dv, g, dev_bases + pos, (uint64_t)(probe_m + k - 1), pt, ptw, hist1);
             hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
             uint64_t probe_items = 0;
             HIPCHK(c, hipMemcpyAsync(&probe_items, &l1_off[g.P1], sizeof probe_items, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             // (the probe's all-ones tally must not count twice: the real count pass over the same prefix follows)
-            if (t->d.k == 32 && !t->d.canonical) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            if (t->dv.k == 32 && !t->dv.canonical) HIPCHK(c, hipMemcpyAsync(&t->dv.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
             items_per_start = std::max(0.05, (double)probe_items / (double)probe_m);
             ratio_known = true;
         }
@@ -419,7 +425,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             items = est_items;                                                    // the exact number is not needed (and not known)
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
-#define KG_L1S(LEAN, PB) hipLaunchKernelGGL((k_p1v2_scatter<true, LEAN, PB>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, \
+#define KG_L1S(LEAN, PB) hipLaunchKernelGGL((k_p1v2_scatter<true, LEAN, PB>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->dv, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, \
                                                (const uint64_t*)nullptr, (const uint64_t*)nullptr, l1_buf, (uint32_t)seg_cap, bucket_stride, (uint32_t)cap_plain, ovf_buf, ovf_n, ovf_cap)
                 if (lean) { if (pb512) KG_L1S(true, 512); else KG_L1S(true, MAX_PARTS); }
                 else { if (pb512) KG_L1S(false, 512); else KG_L1S(false, MAX_PARTS); }
@@ -430,24 +436,24 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         } else {
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1, m);
-                hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
+                hipLaunchKernelGGL(k_p1v2_count, dim3(W), dim3(P1_BLOCK), 0, c->stream, t->dv, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, hist1);
                 hipLaunchKernelGGL(k_p1_scan, dim3(1), dim3(PART_BLOCK), 0, c->stream, g, W, hist1, offs, l1_off);
             }
             HIPCHK(c, hipMemcpyAsync(&items, &l1_off[g.P1], sizeof items, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (g_trace) fprintf(stderr, "[katgpu] partition round: %zu starts -> %llu items (buffer %zu items, arena %.1f GB, ratio %.3f)\n", m, (unsigned long long)items, round_items, c->arena_bytes / 1e9, items_per_start);
             if (items > round_items) {                      // denser than the prefix suggested: redo this round smaller
-                if (t->d.k == 32 && !t->d.canonical) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+                if (t->dv.k == 32 && !t->dv.canonical) HIPCHK(c, hipMemcpyAsync(&t->dv.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
                 items_per_start = std::min(1.0, (double)items / (double)m * 1.02);
                 continue;
             }
             if (items) {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
                 if (lean)
-                    hipLaunchKernelGGL((k_p1v2_scatter<false, true>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, (const uint64_t*)l1_off, l1_buf,
+                    hipLaunchKernelGGL((k_p1v2_scatter<false, true>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->dv, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, (const uint64_t*)l1_off, l1_buf,
                                        0u, 0u, 0u, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
                 else
-                    hipLaunchKernelGGL((k_p1v2_scatter<false, false>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->d, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, (const uint64_t*)l1_off, l1_buf,
+                    hipLaunchKernelGGL((k_p1v2_scatter<false, false>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->dv, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, (const uint64_t*)offs, (const uint64_t*)l1_off, l1_buf,
                                        0u, 0u, 0u, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0);
             }
         }
@@ -472,7 +478,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             while (step > 1 && !fits(step)) step = (step + 1) / 2;
             if (!fits(step)) {                                                      // (a single bucket beyond the buffer: direct path)
                 // this round's level 1 (either edition) has tallied the all-ones key of [pos, pos + m), which the direct kernel will count again
-                if (seg || (t->d.k == 32 && !t->d.canonical)) HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+                if (seg || (t->dv.k == 32 && !t->dv.canonical)) HIPCHK(c, hipMemcpyAsync(&t->dv.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
                 break;
             }
             // level 2: one pass over the bucket when the runs are predictable (k_p2_fast), else -- or when its overflow list did not
@@ -521,7 +527,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                     if (seg && ovf_l1 > ovf_cap) {               // the level-1 buffer itself is incomplete: this round again, exactly
                         if (g_trace) fprintf(stderr, "[katgpu] segmented level 1: %llu k-mers beyond their segments (list holds %llu): exact level 1 from here on\n", ovf_l1, (unsigned long long)ovf_cap);
                         l1_fast_ok = false;
-                        HIPCHK(c, hipMemcpyAsync(&t->d.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));   // the scatter tallied the all-ones key
+                        HIPCHK(c, hipMemcpyAsync(&t->dv.ctrs[CTR_ONES], &t->ones, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));   // the scatter tallied the all-ones key
                         redo_round = true;                       // (only ever in the first pass: nothing has been applied yet)
                         break;
                     }
@@ -574,7 +580,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 if (lost) { pos += m; break; }         // the lists went in from the host; the caller re-enters for the rest
                 for (auto& l : lists) {
                     ScopedTimer tm(c, KATGPU_K_COUNT, l.second);
-                    hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, l.second, 256, 6)), dim3(256), 0, c->stream, t->d, l.first, (uint64_t)l.second);
+                    hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(c, l.second, 256, 6)), dim3(256), 0, c->stream, t->dev(), l.first, (uint64_t)l.second);
                 }
             }
         }
@@ -593,16 +599,16 @@ static bool wide_part_geometry(const DevTable& d) {
 }
 static int count_partitioned_w(katgpu_table* t, const uint8_t* dev_bases, size_t n, size_t* done) {
     katgpu_ctx* c = t->ctx;
-    const uint32_t k = t->d.k;
+    const uint32_t k = t->dev().k;
     const size_t n_starts = n - k + 1;
     *done = 0;
     c->arena_borrowed = false;
-    if (n < 4096 || !wide_part_geometry(t->d)) return KATGPU_OK;               // direct path
-    if (!g_test_round_items && !t->disable_grow && t->d.cap < n_starts / 16) {     // (as count_partitioned: room for 1/16 of the starts first)
-        uint64_t nc = t->d.cap; while (nc < n_starts / 16) nc *= 2;
+    if (n < 4096 || !wide_part_geometry(t->dev())) return KATGPU_OK;               // direct path
+    if (!g_test_round_items && !t->disable_grow && t->dev().cap < n_starts / 16) {     // (as count_partitioned: room for 1/16 of the starts first)
+        uint64_t nc = t->dev().cap; while (nc < n_starts / 16) nc *= 2;
         int grc = regrow(t, nc);
         if (grc) return grc;
-        if (!wide_part_geometry(t->d)) return KATGPU_OK;
+        if (!wide_part_geometry(t->dev())) return KATGPU_OK;
     }
     const uint32_t W = (uint32_t)c->n_cu * 3;                                  // level-1 workgroups (512 threads, 12 KB of LDS)
     const size_t tile_starts = W1_TILE_STARTS;
@@ -642,14 +648,14 @@ static int count_partitioned_w(katgpu_table* t, const uint8_t* dev_bases, size_t
     while (pos < n_starts) {
         int rc = refresh_counters(t);
         if (rc) return rc;
-        if ((double)t->distinct > 0.6 * (double)t->d.cap) {
+        if ((double)t->distinct > 0.6 * (double)t->dev().cap) {
             bool lost = false;
-            rc = grow_beside_arena(t, 0, t->d.cap * 2, KeyLists(), &lost);
+            rc = grow_beside_arena(t, 0, t->dev().cap * 2, KeyLists(), &lost);
             if (rc) return rc;
             if (lost) break;                                                      // the caller re-enters with a fresh arena
         }
-        if (!wide_part_geometry(t->d)) break;
-        const DevTable d = t->d;
+        if (!wide_part_geometry(t->dev())) break;
+        const DevTable d = t->dev();
         size_t m = std::min(n_starts - pos, round_items);                          // items <= starts: a round always fits its buffers
         if (m < n_starts - pos) {
             const size_t rounds_left = (n_starts - pos + m - 1) / m;               // balance the remaining rounds
@@ -712,7 +718,7 @@ static int count_partitioned_w(katgpu_table* t, const uint8_t* dev_bases, size_t
                         const size_t mm = std::min(chunk, (size_t)spilled - i);
                         if (hipMemcpyAsync(dbuf, host.data() + 2 * i, mm * 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(c, KATGPU_ERR_DEVICE, "spill upload"); break; }
                         ScopedTimer tm(c, KATGPU_K_COUNT, mm);
-                        hipLaunchKernelGGL(k_insert_keys_w, dim3(grid_for(c, mm, 256, 6)), dim3(256), 0, c->stream, t->d, (const u64x2*)dbuf, (uint64_t)mm);
+                        hipLaunchKernelGGL(k_insert_keys_w, dim3(grid_for(c, mm, 256, 6)), dim3(256), 0, c->stream, t->dev(), (const u64x2*)dbuf, (uint64_t)mm);
                         if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, KATGPU_ERR_DEVICE, "spill insert");
                     }
                     pool_release(c, dbuf);
@@ -722,7 +728,7 @@ static int count_partitioned_w(katgpu_table* t, const uint8_t* dev_bases, size_t
                 }
                 if (rc) return rc;
                 ScopedTimer tm(c, KATGPU_K_COUNT, spilled);
-                hipLaunchKernelGGL(k_insert_keys_w, dim3(grid_for(c, spilled, 256, 6)), dim3(256), 0, c->stream, t->d, (const u64x2*)l1_buf, (uint64_t)spilled);
+                hipLaunchKernelGGL(k_insert_keys_w, dim3(grid_for(c, spilled, 256, 6)), dim3(256), 0, c->stream, t->dev(), (const u64x2*)l1_buf, (uint64_t)spilled);
                 HIPCHK(c, hipStreamSynchronize(c->stream));
             }
         }
@@ -735,20 +741,20 @@ static int count_partitioned_w(katgpu_table* t, const uint8_t* dev_bases, size_t
 // Count a resident base stream.  The stream is cut into sub-batches so that "distinct + sub-batch starts" stays under
 // the load limit (the table can then never fill in the middle of a launch); consecutive sub-batches overlap by k-1.
 int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
-    const uint32_t k = t->d.k;
+    const uint32_t k = t->dv.k;                              // (dv, not dev(): a table whose slots wait for their first sweep is left to the partitioned counter)
     if (n < k) return KATGPU_OK;
     size_t pos = 0;
     const size_t n_starts = n - k + 1;
     // Large, aligned inputs go through the partitioned counter (no global atomic per k-mer); whatever it leaves (nothing,
     // normally) and everything small goes through the direct kernel below.
-    while (!t->d.keys_b && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
+    while (!t->dv.keys_b && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
         size_t done = 0;                        // returns early (done < remaining) when a table growth cost it the arena
         int prc = count_partitioned(t, dev_bases + pos, n - pos, &done);
         if (prc) return prc;
         if (!done) break;
         pos += done;
     }
-    while (t->d.keys_b && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
+    while (t->dv.keys_b && n_starts - pos >= std::max<uint64_t>(g_part_min_starts, 1) && (reinterpret_cast<uintptr_t>(dev_bases + pos) & 15) == 0) {
         size_t done = 0;                        // wide tables: kg_partition_wide.hpp
         int prc = count_partitioned_w(t, dev_bases + pos, n - pos, &done);
         if (prc) return prc;
@@ -759,13 +765,13 @@ int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n) {
         int rc = refresh_counters(t);
         if (rc) return rc;
         // largest batch that provably fits; if even a minimal one does not, grow first
-        uint64_t room = (uint64_t)(load_limit(t->d) * (double)t->d.cap) > t->distinct ? (uint64_t)(load_limit(t->d) * (double)t->d.cap) - t->distinct : 0;
+        uint64_t room = (uint64_t)(load_limit(t->dev()) * (double)t->dev().cap) > t->distinct ? (uint64_t)(load_limit(t->dev()) * (double)t->dev().cap) - t->distinct : 0;
         uint64_t want = std::min<uint64_t>(n_starts - pos, (uint64_t)CHUNK_STARTS * 65536);   // <= 266 M starts per launch
         if (g_test_max_starts) want = std::min<uint64_t>(want, g_test_max_starts);
         // As the table fills, launches shrink to the remaining room (each adds far fewer distinct k-mers than window
         // starts on real coverage, so the room shrinks slowly); only when the room is down to 1/64 of the table do we grow.
-        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 64, CHUNK_STARTS))) {
-            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, CHUNK_STARTS)));
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->dev().cap / 64, CHUNK_STARTS))) {
+            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->dev().cap / 2, CHUNK_STARTS)));
             if (rc) return rc;
             continue;
         }
@@ -909,7 +915,7 @@ struct HostFeeder {
     }
     int flush() {                                     // pinned[cur][0, fill) -> the current ring (asynchronously)
         if (!fill) return KATGPU_OK;
-        const uint32_t want = t->d.k - 1;
+        const uint32_t want = t->dv.k - 1;
         size_t off = 0;
         while (off < fill) {
             if (ring_fill == c->ring_bytes) { int rc = submit_ring(); if (rc) return rc; }      // its head = `tail`, the k-1 bytes before `off`
@@ -997,7 +1003,7 @@ static int count_files_impl(katgpu_table* t, const char* const* paths, size_t n_
     int rc = f.begin(rest_bytes * 4); if (rc) return rc;           // (gzip inflates: be generous)
     // the group's other files -> one base stream (kg_ingest.hpp: thread team for large plain files, concurrent readers for gzip & co.)
     std::string err;
-    rc = kg::stream_group(rest.data(), rest.size(), trim5p ? rest_trim.data() : nullptr, t->d.k, [&](const uint8_t* p, size_t n) { return f.push(p, n); }, &err);
+    rc = kg::stream_group(rest.data(), rest.size(), trim5p ? rest_trim.data() : nullptr, t->dv.k, [&](const uint8_t* p, size_t n) { return f.push(p, n); }, &err);
     if (rc) return err.empty() ? rc : fail(c, rc, "%s", err.c_str());
     return f.finish();
 }
@@ -1028,15 +1034,17 @@ extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_pa
         HIPCHK(c, hipSetDevice(c->device));
         t = new katgpu_table();
         t->ctx = c; t->disable_grow = disable_grow;
-        t->d.k = k; t->d.canonical = canonical ? 1 : 0;                    // what the feeders' own threads look at before the slots exist
+        t->dv.k = k; t->dv.canonical = canonical ? 1 : 0;                    // what the feeders' own threads look at before the slots exist
         const uint64_t cap = std::max<uint64_t>(size_hint, 1024);
         const size_t arena_bytes = (size_t)16 << 30;
         t->alloc_thread = std::thread([c, t, k, canonical, cap]() {
             hipSetDevice(c->device);
             DevTable d{};
-            const int arc = alloc_dev_table(c, k, canonical, cap, &d);
+            bool lazy = false;
+            const int arc = alloc_dev_table(c, k, canonical, cap, &d, 0, 0, &lazy);
             if (arc) { t->alloc_rc = arc; t->alloc_err = c->err; return; }
-            t->d = d;
+            t->dv = d;
+            if (lazy) t->zero_from = 0;
             if (!c->arena && hipMalloc((void**)&c->arena, arena_bytes) == hipSuccess) c->arena_bytes = arena_bytes; else (void)hipGetLastError();
             if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] table and arena allocated (beside the feeders)\n", since_load());
         });

@@ -22,9 +22,9 @@ extern "C" int katgpu_place_keys(uint32_t k, uint32_t p1, uint32_t l2, const uin
 
 extern "C" int katgpu_table_geometry(const katgpu_table* t, katgpu_geometry* g) {
     if (!t || !g) return KATGPU_ERR_INVALID_ARG;
-    if (t->d.keys_b) return fail(t->ctx, KATGPU_ERR_K, "the multi-GPU exchange is not available for k > 32 (k = %u)", t->d.k);
-    g->k = t->d.k; g->canonical = t->d.canonical; g->n_regions = t->d.n_regions; g->region_slots = t->d.region_slots;
-    g->p1 = t->d.p1; g->p2 = t->d.p2; g->capacity = t->d.cap;
+    if (t->dv.keys_b) return fail(t->ctx, KATGPU_ERR_K, "the multi-GPU exchange is not available for k > 32 (k = %u)", t->dv.k);
+    g->k = t->dv.k; g->canonical = t->dv.canonical; g->n_regions = t->dv.n_regions; g->region_slots = t->dv.region_slots;
+    g->p1 = t->dv.p1; g->p2 = t->dv.p2; g->capacity = t->dv.cap;
     return KATGPU_OK;
 }
 
@@ -37,9 +37,9 @@ extern "C" int katgpu_table_extract_sizes(katgpu_table* t, uint32_t n_parts, uin
     unsigned long long* d_tot = nullptr;
     HIPCHK(c, hipMalloc(&d_tot, n_parts * 8));
     {
-        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
-        hipLaunchKernelGGL(k_extract_count, dim3(std::min<uint32_t>(t->d.n_regions, (uint32_t)c->n_cu * 8)), dim3(EXTRACT_BLOCK), 0, c->stream, t->d, n_parts, dev_region_counts);
-        hipLaunchKernelGGL(k_rows_scan, dim3(n_parts), dim3(1024), 0, c->stream, (const uint32_t*)dev_region_counts, t->d.n_regions, (uint64_t)t->d.n_regions,
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->dev().cap);
+        hipLaunchKernelGGL(k_extract_count, dim3(std::min<uint32_t>(t->dev().n_regions, (uint32_t)c->n_cu * 8)), dim3(EXTRACT_BLOCK), 0, c->stream, t->dev(), n_parts, dev_region_counts);
+        hipLaunchKernelGGL(k_rows_scan, dim3(n_parts), dim3(1024), 0, c->stream, (const uint32_t*)dev_region_counts, t->dev().n_regions, (uint64_t)t->dev().n_regions,
                            (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, 0, d_tot);
     }
     hipMemcpyAsync(part_sizes, d_tot, n_parts * 8, hipMemcpyDeviceToHost, c->stream);
@@ -57,7 +57,7 @@ extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uin
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
-    const uint32_t R = t->d.n_regions;
+    const uint32_t R = t->dev().n_regions;
     const uint32_t dev_big_cap = OVF_CAP + 8;
     uint8_t* tmp = nullptr;          // [off u64 n_parts*R | totals n_parts | base n_parts | big_n | big keys | big counts]
     const size_t off_bytes = (size_t)n_parts * R * 8;
@@ -72,7 +72,7 @@ extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uin
     std::vector<uint64_t> tot(n_parts), base(n_parts);
     hipError_t e = hipSuccess;
     {
-        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->dev().cap);
         hipLaunchKernelGGL(k_rows_scan, dim3(n_parts), dim3(1024), 0, c->stream, dev_region_counts, R, (uint64_t)R, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, 0, d_tot);
         hipMemcpyAsync(tot.data(), d_tot, n_parts * 8, hipMemcpyDeviceToHost, c->stream);
         e = hipStreamSynchronize(c->stream);
@@ -81,7 +81,7 @@ extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uin
         hipMemcpyAsync(d_base, base.data(), n_parts * 8, hipMemcpyHostToDevice, c->stream);
         hipMemsetAsync(d_bign, 0, 8, c->stream);
         hipLaunchKernelGGL(k_rows_scan, dim3(n_parts), dim3(1024), 0, c->stream, dev_region_counts, R, (uint64_t)R, (const uint64_t*)d_base, d_off, (uint64_t)R, 0, (unsigned long long*)nullptr);
-        hipLaunchKernelGGL(k_extract_write, dim3(std::min<uint32_t>(R, (uint32_t)c->n_cu * 8)), dim3(EXTRACT_BLOCK), 0, c->stream, t->d, t->n_ovf, n_parts, (const uint64_t*)d_off,
+        hipLaunchKernelGGL(k_extract_write, dim3(std::min<uint32_t>(R, (uint32_t)c->n_cu * 8)), dim3(EXTRACT_BLOCK), 0, c->stream, t->dev(), t->n_ovf, n_parts, (const uint64_t*)d_off,
                            dev_keys, dev_counts, d_bk, d_bc, d_bign, dev_big_cap);
     }
     unsigned long long nb = 0;
@@ -109,7 +109,7 @@ extern "C" int katgpu_table_clear(katgpu_table* t) {
     if (!t) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    DevTable& d = t->d;
+    DevTable& d = t->dev();
     HIPCHK(c, hipMemsetAsync(d.keys, d.cbits ? 0 : 0xFF, d.cap * sizeof(uint64_t) * (d.keys_b ? 2 : 1), c->stream));     // (wide: keys_b follows keys)
     if (d.counts) HIPCHK(c, hipMemsetAsync(d.counts, 0, d.cap * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
@@ -124,17 +124,17 @@ static int merge_direct32(katgpu_table* t, const uint64_t* dev_keys, const uint3
     size_t pos = 0;
     while (pos < n) {
         int rc = refresh_counters(t); if (rc) return rc;
-        uint64_t room = (uint64_t)(load_limit(t->d) * (double)t->d.cap) > t->distinct ? (uint64_t)(load_limit(t->d) * (double)t->d.cap) - t->distinct : 0;
+        uint64_t room = (uint64_t)(load_limit(t->dev()) * (double)t->dev().cap) > t->distinct ? (uint64_t)(load_limit(t->dev()) * (double)t->dev().cap) - t->distinct : 0;
         uint64_t want = n - pos;
-        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
-            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->dev().cap / 8, 1024))) {
+            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->dev().cap / 2, 1024)));
             if (rc) return rc;
             continue;
         }
         const uint64_t take = std::min(want, room);
         t->count_bound = 0xFFFFFFFFULL;
         ScopedTimer tm(c, KATGPU_K_MERGE, take);
-        hipLaunchKernelGGL(k_merge32, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->d, dev_keys + pos, dev_counts + pos, (uint64_t)take);
+        hipLaunchKernelGGL(k_merge32, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->dev(), dev_keys + pos, dev_counts + pos, (uint64_t)take);
         pos += take;
     }
     return refresh_counters(t);
@@ -160,14 +160,14 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_apply<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         c->merge_attr_set = true;
     }
-    const size_t slot_bytes = t->d.cbits ? 8 : 12;
+    const size_t slot_bytes = t->dev().cbits ? 8 : 12;
     // sources ordered by this table's regions go through LDS; the rest (another grid, or the table has changed its grid) directly
     std::vector<uint32_t> aligned, direct;
     for (uint32_t i = 0; i < n_src; ++i) {
         if (src[i].n_records == 0) continue;
         if (!src[i].dev_keys || !src[i].dev_counts) return KATGPU_ERR_INVALID_ARG;
-        const bool ok = !g_no_merge_apply && src[i].dev_region_counts && src[i].p1 == t->d.p1 && src[i].p2 == t->d.p2 && g_hi <= t->d.n_regions &&
-                        (size_t)t->d.region_slots * slot_bytes <= 150 * 1024;
+        const bool ok = !g_no_merge_apply && src[i].dev_region_counts && src[i].p1 == t->dev().p1 && src[i].p2 == t->dev().p2 && g_hi <= t->dev().n_regions &&
+                        (size_t)t->dev().region_slots * slot_bytes <= 150 * 1024;
         (ok ? aligned : direct).push_back(i);
     }
     const uint32_t n_reg = g_hi - g_lo;
@@ -193,11 +193,11 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
         t->count_bound = 0xFFFFFFFFULL;
         {
             ScopedTimer tm(c, KATGPU_K_MERGE, records);
-            const size_t lds = (size_t)t->d.region_slots * slot_bytes;
+            const size_t lds = (size_t)t->dev().region_slots * slot_bytes;
             const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2));
             const dim3 grid(std::min<uint32_t>(n_reg, (uint32_t)c->n_cu * per_cu));
-            if (t->d.cbits) hipLaunchKernelGGL((k_merge_apply<1024, true>), grid, dim3(1024), lds, c->stream, t->d, g_lo, g_hi, ms, d_def, d_ndef);
-            else hipLaunchKernelGGL((k_merge_apply<1024, false>), grid, dim3(1024), lds, c->stream, t->d, g_lo, g_hi, ms, d_def, d_ndef);
+            if (t->dev().cbits) hipLaunchKernelGGL((k_merge_apply<1024, true>), grid, dim3(1024), lds, c->stream, t->dev(), g_lo, g_hi, ms, d_def, d_ndef);
+            else hipLaunchKernelGGL((k_merge_apply<1024, false>), grid, dim3(1024), lds, c->stream, t->dev(), g_lo, g_hi, ms, d_def, d_ndef);
         }
         unsigned long long ndef = 0;
         hipMemcpyAsync(&ndef, d_ndef, 8, hipMemcpyDeviceToHost, c->stream);
@@ -218,22 +218,22 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
                 for (uint32_t q = 0; q < na; ++q) { const uint64_t* o = off.data() + (size_t)q * (n_reg + 1); in += o[g - g_lo + 1] - o[g - g_lo]; }
                 max_in = std::max(max_in, in);
             }
-            const uint64_t need_s = (uint64_t)(((double)t->d.region_slots + (double)max_in) / 0.7) + 1;
-            if (need_s > t->d.region_slots) {
+            const uint64_t need_s = (uint64_t)(((double)t->dev().region_slots + (double)max_in) / 0.7) + 1;
+            if (need_s > t->dev().region_slots) {
                 if (t->disable_grow) rc = fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
-                else rc = regrow(t, (uint64_t)t->d.n_regions * need_s);
+                else rc = regrow(t, (uint64_t)t->dev().n_regions * need_s);
             }
             if (rc == KATGPU_OK) {                    // one launch for all deferred regions: every region now has the room
                 ScopedTimer tm(c, KATGPU_K_MERGE, max_in * ndef);
                 hipLaunchKernelGGL(k_merge_deferred, dim3((unsigned)std::min<unsigned long long>(ndef, (unsigned long long)c->n_cu * 8)), dim3(256), 0, c->stream,
-                                   t->d, g_lo, ms, (const uint32_t*)d_def, (uint32_t)ndef);
+                                   t->dev(), g_lo, ms, (const uint32_t*)d_def, (uint32_t)ndef);
                 if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, KATGPU_ERR_DEVICE, "deferred merge");
                 else rc = refresh_counters(t);
             }
         }
         hipFree(tmp);
         if (rc) return rc;
-        if (ndef && (src[aligned[a0]].p1 != t->d.p1 || src[aligned[a0]].p2 != t->d.p2)) {      // the growth changed the grid: the rest goes direct
+        if (ndef && (src[aligned[a0]].p1 != t->dev().p1 || src[aligned[a0]].p2 != t->dev().p2)) {      // the growth changed the grid: the rest goes direct
             for (size_t a = a0 + na; a < aligned.size(); ++a) direct.push_back(aligned[a]);
             break;
         }

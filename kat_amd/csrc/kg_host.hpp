@@ -90,7 +90,20 @@ void scan_cache_release(katgpu_ctx* c);      // kg_scan.hip
 
 struct katgpu_table {
     katgpu_ctx* ctx = nullptr;
-    DevTable d{};
+    // The device-side table.  Every reader goes through dev(); `dv` itself is for those who know about the zeroing below.
+    // Lazy zeroing (packed tables of size, katgpu_table_create): the slots are NOT cleared when the table is made -- the partitioned
+    // counter's first round visits every region once, in order, and its apply starts a region from zeros in LDS instead of loading it
+    // (kg_partition.hpp: k_p3_apply_pk, zero_fill): the table's first sweep costs neither a memset nor a read.  zero_from = the first region
+    // that has not been zeroed yet (~0: all have); whoever else touches the table first -- dev() -- clears the rest.
+    mutable DevTable dv{};
+    mutable uint64_t zero_from = ~0ULL;
+    DevTable& dev() const { if (zero_from != ~0ULL) zero_rest(); return dv; }
+    void zero_rest() const {
+        const uint64_t from = zero_from;
+        zero_from = ~0ULL;
+        if (from < dv.n_regions && dv.keys && ctx)
+            (void)hipMemsetAsync(dv.keys + from * dv.region_slots, 0, (size_t)(dv.n_regions - from) * dv.region_slots * sizeof(uint64_t), ctx->stream);
+    }
     int disable_grow = 0;
     uint32_t n_ovf = 0;          // refreshed by refresh_counters()
     uint64_t distinct = 0;       // idem (slots in use + all-ones key)
@@ -119,7 +132,7 @@ inline int fail(katgpu_ctx* c, int code, const char* fmt, ...) {
 // entry points that handle one-word k-mers only (lookups by 64-bit key, .jf, the multi-GPU exchange, sect/cold profiles)
 #define NARROW_ONLY(t, what)                                                                             \
     do {                                                                                                 \
-        if ((t)->d.keys_b) return fail((t)->ctx, KATGPU_ERR_K, "%s is not available for k > 32 (k = %u)", what, (t)->d.k); \
+        if ((t)->dev().keys_b) return fail((t)->ctx, KATGPU_ERR_K, "%s is not available for k > 32 (k = %u)", what, (t)->dev().k); \
     } while (0)
 
 #define HIPCHK(c, expr)                                                                                  \
@@ -160,7 +173,8 @@ constexpr uint32_t AP2_MAX_SLOTS = 10240;           // the apply kernels: a regi
 constexpr int AP2_QCAP_BIG = 192;                   // KV12 apply: queue entries per wave for regions beyond 8192 slots
 
 // table life cycle (kg_table.hip)
-int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1 = 0, uint32_t like_p2 = 0);
+int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1 = 0, uint32_t like_p2 = 0,
+                    bool* lazy_zero = nullptr /* non-null: a packed table of size may leave its slots uncleared and say so (katgpu_table::zero_from) */);
 void free_dev_table(katgpu_ctx* c, DevTable& d);
 int refresh_counters(katgpu_table* t);
 int regrow(katgpu_table* t, uint64_t new_cap);

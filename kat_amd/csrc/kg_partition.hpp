@@ -1426,7 +1426,9 @@ __global__ void __launch_bounds__(BLOCK, 4)    // four waves per SIMD (128 VGPRs
 k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uint8_t* __restrict__ l2_buf,
               uint64_t* __restrict__ spill, unsigned long long* __restrict__ spill_n, const uint32_t* __restrict__ cnt2, const uint64_t* __restrict__ bend,
               uint32_t qcap /* queue entries per wave: what the region leaves of the LDS; >= 72 */, uint64_t seg_len /* k-mers per walk: a multiple of 4 below half the count range */,
-              uint32_t spill_mod) {
+              uint32_t spill_mod,
+              uint32_t zero_fill /* the table's first sweep (katgpu_table::zero_from): its slots hold whatever the memory held -- a region starts from zeros
+                                    in LDS instead of being loaded, and EVERY region of the launch is visited and written, a run or not */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int NW = BLOCK / 64, U = 4 * UG;
     constexpr uint32_t CH = 64 * U;
@@ -1446,10 +1448,11 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
     };
     auto next_region = [&](uint32_t from) {
         uint32_t r = from;
-        while (r < r_hi && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
+        while (r < r_hi && !zero_fill && (cnt2 ? cnt2[r] == 0 : off2[r] == run_end(r))) r += gridDim.x;
         return r;
     };
     auto prefetch = [&](uint32_t r) {
+        if (zero_fill) return;                                 // (nothing to load)
         const uint64_t base = (uint64_t)r * S;
 #pragma unroll
         for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; kq[u] = *reinterpret_cast<const u32x4*>(t.keys + base + (i < S ? i : 0)); }    // clamped, unconditional: stays in registers
@@ -1470,8 +1473,13 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
         const unsigned long long t_fill = now();
         // ---- fill: registers -> LDS ----
         if (!PF) prefetch(r);
+        if (zero_fill) {
 #pragma unroll
-        for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(rk + i) = kq[u]; }
+            for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(rk + i) = u32x4{0u, 0u, 0u, 0u}; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < KP; ++u) { const uint32_t i = (u * BLOCK + tid) * 2; if (i < S) *reinterpret_cast<u32x4*>(rk + i) = kq[u]; }
+        }
         const uint32_t rn = next_region(r + gridDim.x);
         // what spilling a k-mer (region full, test hook) needs: the region's digits give the k-mer back
         const uint32_t rd1 = r >> g.l2, rd2 = r & (g.P2 - 1);

@@ -23,13 +23,13 @@ extern "C" int katgpu_hist(katgpu_table* t, uint64_t base, uint64_t ceil_, uint6
     hipMemsetAsync(d, 0, nb * 8, c->stream);
     const uint32_t lds_bins = (uint32_t)std::min<uint64_t>(nb, 16384);          // 64 KB of u32 -> two blocks per CU
     {
-        ScopedTimer tm(c, KATGPU_K_HIST, t->d.cap);
-        if (t->d.cbits)
-            hipLaunchKernelGGL(k_hist<true>, dim3(grid_for(c, t->d.cap / 4, SCAN_BLOCK, 2)), dim3(SCAN_BLOCK), lds_bins * sizeof(uint32_t), c->stream,
-                               t->d, t->n_ovf, base, ceil_, inc, (uint64_t)nb, d, lds_bins);
+        ScopedTimer tm(c, KATGPU_K_HIST, t->dev().cap);
+        if (t->dev().cbits)
+            hipLaunchKernelGGL(k_hist<true>, dim3(grid_for(c, t->dev().cap / 4, SCAN_BLOCK, 2)), dim3(SCAN_BLOCK), lds_bins * sizeof(uint32_t), c->stream,
+                               t->dev(), t->n_ovf, base, ceil_, inc, (uint64_t)nb, d, lds_bins);
         else
-            hipLaunchKernelGGL(k_hist<false>, dim3(grid_for(c, t->d.cap / 4, SCAN_BLOCK, 2)), dim3(SCAN_BLOCK), lds_bins * sizeof(uint32_t), c->stream,
-                               t->d, t->n_ovf, base, ceil_, inc, (uint64_t)nb, d, lds_bins);
+            hipLaunchKernelGGL(k_hist<false>, dim3(grid_for(c, t->dev().cap / 4, SCAN_BLOCK, 2)), dim3(SCAN_BLOCK), lds_bins * sizeof(uint32_t), c->stream,
+                               t->dev(), t->n_ovf, base, ceil_, inc, (uint64_t)nb, d, lds_bins);
     }
     hipMemcpyAsync(out, d, nb * 8, hipMemcpyDeviceToHost, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -43,7 +43,7 @@ extern "C" int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, 
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
-    const size_t cells = (size_t)t->d.k * ((size_t)cvg_bins + 1);
+    const size_t cells = (size_t)t->dev().k * ((size_t)cvg_bins + 1);
     unsigned long long* d = nullptr;
     HIPCHK(c, hipMalloc(&d, cells * 8));
     hipMemsetAsync(d, 0, cells * 8, c->stream);
@@ -52,9 +52,9 @@ extern "C" int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, 
     const int per_cu = use_lds && lds > 75 * 1024 ? 1 : 2;
 #define KG_GCP(W, PK) do { \
         if (use_lds && lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_gcp<W, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        ScopedTimer tm(c, KATGPU_K_GCP, t->d.cap); \
-        hipLaunchKernelGGL((k_gcp<W, PK>), dim3(grid_for(c, t->d.cap / 4, SCAN_BLOCK, per_cu)), dim3(SCAN_BLOCK), use_lds ? lds : 0, c->stream, t->d, t->n_ovf, cvg_scale, cvg_bins, d, use_lds); } while (0)
-    if (t->d.keys_b) KG_GCP(true, false); else if (t->d.cbits) KG_GCP(false, true); else KG_GCP(false, false);
+        ScopedTimer tm(c, KATGPU_K_GCP, t->dev().cap); \
+        hipLaunchKernelGGL((k_gcp<W, PK>), dim3(grid_for(c, t->dev().cap / 4, SCAN_BLOCK, per_cu)), dim3(SCAN_BLOCK), use_lds ? lds : 0, c->stream, t->dev(), t->n_ovf, cvg_scale, cvg_bins, d, use_lds); } while (0)
+    if (t->dev().keys_b) KG_GCP(true, false); else if (t->dev().cbits) KG_GCP(false, true); else KG_GCP(false, false);
 #undef KG_GCP
     HIPCHK(c, hipGetLastError());
     hipMemcpyAsync(out, d, cells * 8, hipMemcpyDeviceToHost, c->stream);
@@ -70,12 +70,12 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     if (!t1 || !t2 || !main_mx || !counters || !spectra || d1_bins == 0 || d2_bins == 0) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t1->ctx;
     if (t1->ctx != t2->ctx) return fail(c, KATGPU_ERR_INVALID_ARG, "tables belong to different contexts");
-    if (t1->d.k != t2->d.k)
-        return fail(c, KATGPU_ERR_MISMATCH, "Cannot process hashes that were created with different K-mer lengths.  Expected: %u.  Key length was %u", t1->d.k, t2->d.k);
+    if (t1->dev().k != t2->dev().k)
+        return fail(c, KATGPU_ERR_MISMATCH, "Cannot process hashes that were created with different K-mer lengths.  Expected: %u.  Key length was %u", t1->dev().k, t2->dev().k);
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t1); if (rc) return rc;
     rc = refresh_counters(t2); if (rc) return rc;
-    const bool wide = t1->d.keys_b != nullptr;               // same k => same key width in both tables
+    const bool wide = t1->dev().keys_b != nullptr;               // same k => same key width in both tables
     const uint32_t ss = std::min(d1_bins, d2_bins);
     const size_t mx_cells = (size_t)d1_bins * d2_bins, total = mx_cells + 13 + 4 * (size_t)ss;
     unsigned long long* d = nullptr;
@@ -94,31 +94,31 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     // Join form (region r of one table against region r of the other, in LDS) whenever the two tables share the region grid
     // and the probe key equals the stored key; probe form (random HBM probes) otherwise.  Tables of one grid have one layout
     // (the remainder bits follow from k and the grid), so the join is KV12 against KV12 or packed against packed.
-    const bool pk = t1->d.cbits != 0;
-    const bool same_grid = !wide && t1->d.p1 == t2->d.p1 && t1->d.p2 == t2->d.p2 && t1->d.cbits == t2->d.cbits && t1->d.n_regions > 1 && !g_no_join;
-    const bool ident1 = t1->d.canonical || !canon2;          // pass 1 probes canonical(key) iff input 2 is canonical
-    const bool ident2 = t2->d.canonical != 0;                // pass 2 always probes canonical(key)
+    const bool pk = t1->dev().cbits != 0;
+    const bool same_grid = !wide && t1->dev().p1 == t2->dev().p1 && t1->dev().p2 == t2->dev().p2 && t1->dev().cbits == t2->dev().cbits && t1->dev().n_regions > 1 && !g_no_join;
+    const bool ident1 = t1->dev().canonical || !canon2;          // pass 1 probes canonical(key) iff input 2 is canonical
+    const bool ident2 = t2->dev().canonical != 0;                // pass 2 always probes canonical(key)
     const size_t sb = pk ? 8 : 12;                           // bytes per slot
-    const size_t join1 = ((lds1 + 15) & ~(size_t)15) + (size_t)t2->d.region_slots * sb, join2 = ((lds2 + 15) & ~(size_t)15) + (size_t)t1->d.region_slots * sb;
+    const size_t join1 = ((lds1 + 15) & ~(size_t)15) + (size_t)t2->dev().region_slots * sb, join2 = ((lds2 + 15) & ~(size_t)15) + (size_t)t1->dev().region_slots * sb;
     // the join streams BOTH tables (~2.2 TB/s measured); probing costs ~1.3 random sector reads per scanned k-mer (~55 G/s):
     // a small table scanned against a big one is cheaper probed, a big one against a small one is cheaper joined
     auto join_pays = [&](const katgpu_table* scan, const katgpu_table* probe) {
-        if (scan->d.cap + probe->d.cap < ((uint64_t)64 << 20)) return true;        // small either way: take the join
-        return (double)sb * (double)(scan->d.cap + probe->d.cap) / 2.2e12 < 1.3 * (double)scan->distinct / 55e9;
+        if (scan->dev().cap + probe->dev().cap < ((uint64_t)64 << 20)) return true;        // small either way: take the join
+        return (double)sb * (double)(scan->dev().cap + probe->dev().cap) / 2.2e12 < 1.3 * (double)scan->distinct / 55e9;
     };
     // Both tables packed, on one grid, canonical: ONE kernel does both passes (k_comp_fused), the table with fewer k-mers streaming
     // past the other one's regions in LDS.
     const bool swap = t1->distinct < t2->distinct;           // hash 1 is the smaller one: it streams, hash 2 is resident
-    const uint32_t s_res = swap ? t2->d.region_slots : t1->d.region_slots;
+    const uint32_t s_res = swap ? t2->dev().region_slots : t1->dev().region_slots;
     const size_t fused_lds = ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * (size_t)ss * 4 + 15) & ~(size_t)15) + (size_t)s_res * 8 + (size_t)((s_res + 31) / 32) * 4;
-    const bool fused = pk && same_grid && !g_no_fused && t1->d.canonical && t2->d.canonical && s_res <= (uint32_t)FUSED_KP * FUSED_BLOCK * 2 && fused_lds <= 160 * 1024 - 512;
+    const bool fused = pk && same_grid && !g_no_fused && t1->dev().canonical && t2->dev().canonical && s_res <= (uint32_t)FUSED_KP * FUSED_BLOCK * 2 && fused_lds <= 160 * 1024 - 512;
     // pass 1 as a join can leave a bit per slot of hash 2 ("hash 1 holds this k-mer"); pass 2 is then a scan of hash 2 (k_comp_seen)
     const bool join_1 = same_grid && ident1 && (g_force_join || join_pays(t1, t2));
-    const uint32_t wpr = (t2->d.region_slots + 31) / 32;
-    const bool marked = !fused && join_1 && !g_no_seen && t1->d.canonical && t2->d.canonical && t2->ones == 0 && join1 + (size_t)wpr * 4 <= 150 * 1024;
+    const uint32_t wpr = (t2->dev().region_slots + 31) / 32;
+    const bool marked = !fused && join_1 && !g_no_seen && t1->dev().canonical && t2->dev().canonical && t2->ones == 0 && join1 + (size_t)wpr * 4 <= 150 * 1024;
     uint32_t* seen_bits = nullptr;
     if (marked) {
-        if (pool_alloc(c, (void**)&seen_bits, (size_t)t2->d.n_regions * wpr * 4) != hipSuccess) { (void)hipGetLastError(); seen_bits = nullptr; }
+        if (pool_alloc(c, (void**)&seen_bits, (size_t)t2->dev().n_regions * wpr * 4) != hipSuccess) { (void)hipGetLastError(); seen_bits = nullptr; }
         a.seen = seen_bits; a.seen_wpr = wpr;
     }
     // unscaled matrices of more than COMP_TILE bins (KAT's defaults): the spectra of the k-mers that land in the LDS tile are its marginals
@@ -129,40 +129,40 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
         return std::min<uint32_t>(regions, (uint32_t)c->n_cu * (uint32_t)per_cu);
     };
     if (fused) {
-        ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap + t2->d.cap);
-        const uint32_t grid = std::min<uint32_t>(t1->d.n_regions, (uint32_t)c->n_cu);
+        ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->dev().cap + t2->dev().cap);
+        const uint32_t grid = std::min<uint32_t>(t1->dev().n_regions, (uint32_t)c->n_cu);
         if (swap) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-                    hipLaunchKernelGGL(k_comp_fused<true>, dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a); }
+                    hipLaunchKernelGGL(k_comp_fused<true>, dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, a); }
         else { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-               hipLaunchKernelGGL(k_comp_fused<false>, dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a); }
+               hipLaunchKernelGGL(k_comp_fused<false>, dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, a); }
     }
 #define KG_JOIN(PASS, TA, TB, LDS) do { \
         if (pk) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<PASS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-                  hipLaunchKernelGGL((k_comp_join<PASS, true>), dim3(join_grid(LDS, TA->d.n_regions)), dim3(jblk), LDS, c->stream, TA->d, TA->n_ovf, TB->d, TB->n_ovf, a); } \
+                  hipLaunchKernelGGL((k_comp_join<PASS, true>), dim3(join_grid(LDS, TA->dev().n_regions)), dim3(jblk), LDS, c->stream, TA->dev(), TA->n_ovf, TB->dev(), TB->n_ovf, a); } \
         else { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<PASS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-               hipLaunchKernelGGL((k_comp_join<PASS, false>), dim3(join_grid(LDS, TA->d.n_regions)), dim3(jblk), LDS, c->stream, TA->d, TA->n_ovf, TB->d, TB->n_ovf, a); } } while (0)
+               hipLaunchKernelGGL((k_comp_join<PASS, false>), dim3(join_grid(LDS, TA->dev().n_regions)), dim3(jblk), LDS, c->stream, TA->dev(), TA->n_ovf, TB->dev(), TB->n_ovf, a); } } while (0)
     if (!fused) {
-        ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap);
+        ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->dev().cap);
         if (join_1 && join1 <= 150 * 1024) {
             const size_t j1 = join1 + (a.seen ? (size_t)wpr * 4 : 0);
             KG_JOIN(1, t1, t2, j1);
         } else if (wide)
-            hipLaunchKernelGGL((k_comp<1, true>), dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
+            hipLaunchKernelGGL((k_comp<1, true>), dim3(reducer_grid(c, t1->dev().cap + 1, 4)), dim3(256), lds1, c->stream, t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, a);
         else
-            hipLaunchKernelGGL((k_comp<1, false>), dim3(reducer_grid(c, t1->d.cap + 1, 4)), dim3(256), lds1, c->stream, t1->d, t1->n_ovf, t2->d, t2->n_ovf, a);
+            hipLaunchKernelGGL((k_comp<1, false>), dim3(reducer_grid(c, t1->dev().cap + 1, 4)), dim3(256), lds1, c->stream, t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, a);
     }
     if (!fused) {
-        ScopedTimer tm(c, KATGPU_K_COMP_PASS2, t2->d.cap);
+        ScopedTimer tm(c, KATGPU_K_COMP_PASS2, t2->dev().cap);
         if (a.seen && join1 <= 150 * 1024) {
-            const uint32_t grid = std::min<uint32_t>(t2->d.n_regions, (uint32_t)c->n_cu * 4);
-            if (pk) hipLaunchKernelGGL(k_comp_seen<true>, dim3(grid), dim3(512), lds2, c->stream, t2->d, t2->n_ovf, a);
-            else hipLaunchKernelGGL(k_comp_seen<false>, dim3(grid), dim3(512), lds2, c->stream, t2->d, t2->n_ovf, a);
+            const uint32_t grid = std::min<uint32_t>(t2->dev().n_regions, (uint32_t)c->n_cu * 4);
+            if (pk) hipLaunchKernelGGL(k_comp_seen<true>, dim3(grid), dim3(512), lds2, c->stream, t2->dev(), t2->n_ovf, a);
+            else hipLaunchKernelGGL(k_comp_seen<false>, dim3(grid), dim3(512), lds2, c->stream, t2->dev(), t2->n_ovf, a);
         } else if (same_grid && ident2 && join2 <= 150 * 1024 && (g_force_join || join_pays(t2, t1))) {
             KG_JOIN(2, t2, t1, join2);
         } else if (wide)
-            hipLaunchKernelGGL((k_comp<2, true>), dim3(reducer_grid(c, t2->d.cap + 1, 4)), dim3(256), lds2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
+            hipLaunchKernelGGL((k_comp<2, true>), dim3(reducer_grid(c, t2->dev().cap + 1, 4)), dim3(256), lds2, c->stream, t2->dev(), t2->n_ovf, t1->dev(), t1->n_ovf, a);
         else
-            hipLaunchKernelGGL((k_comp<2, false>), dim3(reducer_grid(c, t2->d.cap + 1, 4)), dim3(256), lds2, c->stream, t2->d, t2->n_ovf, t1->d, t1->n_ovf, a);
+            hipLaunchKernelGGL((k_comp<2, false>), dim3(reducer_grid(c, t2->dev().cap + 1, 4)), dim3(256), lds2, c->stream, t2->dev(), t2->n_ovf, t1->dev(), t1->n_ovf, a);
     }
 #undef KG_JOIN
     HIPCHK(c, hipGetLastError());
@@ -184,8 +184,8 @@ extern "C" int katgpu_comp3(katgpu_table* t1, katgpu_table* t2, katgpu_table* t3
     if (rc) return rc;
     katgpu_ctx* c = t1->ctx;
     if (t3->ctx != c) return fail(c, KATGPU_ERR_INVALID_ARG, "tables belong to different contexts");
-    if (t3->d.k != t1->d.k)
-        return fail(c, KATGPU_ERR_MISMATCH, "Cannot process hashes that were created with different K-mer lengths.  Expected: %u.  Key length was %u", t1->d.k, t3->d.k);
+    if (t3->dev().k != t1->dev().k)
+        return fail(c, KATGPU_ERR_MISMATCH, "Cannot process hashes that were created with different K-mer lengths.  Expected: %u.  Key length was %u", t1->dev().k, t3->dev().k);
     rc = refresh_counters(t3); if (rc) return rc;
     const size_t cells = (size_t)d1_bins * d2_bins;
     unsigned long long* d = nullptr;
@@ -196,14 +196,14 @@ extern "C" int katgpu_comp3(katgpu_table* t1, katgpu_table* t2, katgpu_table* t3
     a.canon2 = canon2 ? 1 : 0; a.canon3 = canon3 ? 1 : 0;
     a.mx[0] = d; a.mx[1] = d + cells; a.mx[2] = d + 2 * cells;
     {
-        ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->d.cap);
-        if (t1->d.keys_b)
-            hipLaunchKernelGGL(k_comp3_pass1<true>, dim3(reducer_grid(c, t1->d.cap + 1, 3)), dim3(256), 3 * COMP_TILE * COMP_TILE * sizeof(uint32_t), c->stream,
-                               t1->d, t1->n_ovf, t2->d, t2->n_ovf, t3->d, t3->n_ovf, a);
+        ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->dev().cap);
+        if (t1->dev().keys_b)
+            hipLaunchKernelGGL(k_comp3_pass1<true>, dim3(reducer_grid(c, t1->dev().cap + 1, 3)), dim3(256), 3 * COMP_TILE * COMP_TILE * sizeof(uint32_t), c->stream,
+                               t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, t3->dev(), t3->n_ovf, a);
         else
-            hipLaunchKernelGGL(k_comp3_pass1<false>, dim3(reducer_grid(c, t1->d.cap + 1, 3)), dim3(256), 3 * COMP_TILE * COMP_TILE * sizeof(uint32_t), c->stream,
-                               t1->d, t1->n_ovf, t2->d, t2->n_ovf, t3->d, t3->n_ovf, a);
-        hipLaunchKernelGGL(k_comp3_pass3, dim3(reducer_grid(c, t3->d.cap + 1, 8)), dim3(256), 0, c->stream, t3->d, t3->n_ovf, d + 3 * cells);
+            hipLaunchKernelGGL(k_comp3_pass1<false>, dim3(reducer_grid(c, t1->dev().cap + 1, 3)), dim3(256), 3 * COMP_TILE * COMP_TILE * sizeof(uint32_t), c->stream,
+                               t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, t3->dev(), t3->n_ovf, a);
+        hipLaunchKernelGGL(k_comp3_pass3, dim3(reducer_grid(c, t3->dev().cap + 1, 8)), dim3(256), 0, c->stream, t3->dev(), t3->n_ovf, d + 3 * cells);
     }
     HIPCHK(c, hipGetLastError());
     uint64_t c3[13];

@@ -388,7 +388,7 @@ struct RawFeeder {
     }
     // hand acc[acc_cur] (HEAD + acc_fill bytes) to the worker and open the other buffer with the stream's last k-1 bytes in its head
     int submit(bool last) {
-        const uint32_t k = t->d.k;
+        const uint32_t k = t->dv.k;
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));          // every chunk emitted into it has landed
         const int other = acc_cur ^ 1;
         {
@@ -429,7 +429,7 @@ struct RawFeeder {
             if (outb.size() >= ((size_t)64 << 20) || off >= size) {
                 // (katgpu_count_bases_host would reset the table's carry: feed through the same rings by hand)
                 rc = count_host_stream(outb.data(), outb.size());
-                const size_t keep = std::min<size_t>(outb.size(), t->d.k - 1);
+                const size_t keep = std::min<size_t>(outb.size(), t->dv.k - 1);
                 std::vector<uint8_t> tailb(outb.end() - keep, outb.end());
                 outb.assign(tailb.begin(), tailb.end());
             }
@@ -440,7 +440,7 @@ struct RawFeeder {
     // a host piece of the base stream -> acc[0] -> count_resident (the fall-back is rare: no pipelining; the worker is idle by then)
     int count_host_stream(const uint8_t* p, size_t n) {
         size_t pos = 0;
-        const uint32_t k = t->d.k;
+        const uint32_t k = t->dv.k;
         while (pos < n && n - pos >= k) {
             const size_t take = std::min(n - pos, acc_bytes);
             uint8_t head[HEAD];
@@ -463,7 +463,7 @@ struct RawFeeder {
     }
 
     int run() {
-        const uint32_t k = t->d.k;
+        const uint32_t k = t->dv.k;
         const bool sharded = shard_world > 1;
         uint64_t cut_lo = 0;                                      // file offset where the next chunk starts: a proven record / line start
         uint8_t carry[HEAD]; uint32_t carry_n = 0;                // last k-1 bytes of the base stream so far (host copy, for the fall-back)

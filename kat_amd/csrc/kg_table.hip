@@ -9,7 +9,9 @@ static const bool g_no_packed = hook("KATGPU_NO_PACKED") != nullptr;   // tests 
 
 // like_p1/like_p2 != 0: adopt that region grid (so that comp can join region against region) and take up the capacity in the
 // region size, if a region of the resulting size still fits LDS.
-int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1, uint32_t like_p2) {
+static const bool g_no_lazy_zero = hook("KATGPU_NO_LAZY_ZERO") != nullptr;   // A/B: every table cleared when it is made
+static const uint64_t g_lazy_min_slots = hook_u64("KATGPU_TEST_LAZY_MIN_SLOTS", 1ULL << 26);   // tests: packed tables from this size on leave their clearing to the first sweep
+int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevTable* out, uint32_t like_p1, uint32_t like_p2, bool* lazy_zero) {
     DevTable d{};
     const uint64_t like_r = (uint64_t)like_p1 * like_p2;
     // slots per region: a wide slot is 20 bytes (two key words + the count), and the wide apply kernel holds a region in LDS like the
@@ -67,7 +69,10 @@ int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevT
         pool_release(c, d.keys); pool_release(c, d.counts); hipFree(d.ovf_keys); hipFree(d.ovf_hi); hipFree(d.ctrs);
         return fail(c, KATGPU_ERR_NOMEM, "device allocation of a %llu-slot table failed: %s", (unsigned long long)cap, hipGetErrorString(e));
     }
-    HIPCHK(c, hipMemsetAsync(d.keys, d.cbits ? 0 : 0xFF, key_bytes, c->stream));
+    // a packed table the partitioned counter will take (>= 64 M slots): cleared by its first round's apply, region by region (katgpu_table::zero_from)
+    const bool lazy = lazy_zero && !g_no_lazy_zero && d.cbits && !wide && cap >= g_lazy_min_slots;
+    if (lazy_zero) *lazy_zero = lazy;
+    if (!lazy) HIPCHK(c, hipMemsetAsync(d.keys, d.cbits ? 0 : 0xFF, key_bytes, c->stream));
     if (d.counts) HIPCHK(c, hipMemsetAsync(d.counts, 0, cap * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_hi, 0, OVF_CAP * sizeof(uint64_t), c->stream));
@@ -91,8 +96,10 @@ extern "C" int katgpu_table_create(katgpu_ctx* c, uint32_t k, int canonical, uin
     uint64_t cap = std::max<uint64_t>(size_hint ? size_hint : (1u << 20), 1024);
     katgpu_table* t = new katgpu_table();
     t->ctx = c; t->disable_grow = disable_grow;
-    int rc = alloc_dev_table(c, k, canonical, cap, &t->d);
+    bool lazy = false;
+    int rc = alloc_dev_table(c, k, canonical, cap, &t->dv, 0, 0, &lazy);
     if (rc) { delete t; return rc; }
+    if (lazy) t->zero_from = 0;
     *out = t;
     return KATGPU_OK;
 }
@@ -108,9 +115,11 @@ extern "C" int katgpu_table_create_like(katgpu_ctx* c, const katgpu_table* like,
     t->ctx = c; t->disable_grow = disable_grow;
     // (no common grid across key widths; none for wide tables either: nothing joins or merges them region by region, and a grid
     // handed down could make regions the wide apply kernel cannot hold)
-    int rc = k > 32 || like->d.k > 32 ? alloc_dev_table(c, k, canonical, cap, &t->d)
-                                      : alloc_dev_table(c, k, canonical, cap, &t->d, like->d.p1, like->d.p2);
+    bool lazy = false;
+    int rc = k > 32 || like->dv.k > 32 ? alloc_dev_table(c, k, canonical, cap, &t->dv, 0, 0, &lazy)
+                                       : alloc_dev_table(c, k, canonical, cap, &t->dv, like->dv.p1, like->dv.p2, &lazy);
     if (rc) { delete t; return rc; }
+    if (lazy) t->zero_from = 0;
     *out = t;
     return KATGPU_OK;
 }
@@ -127,20 +136,21 @@ extern "C" void katgpu_table_free(katgpu_table* t) {
     (void)table_wait(t);
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
-    free_dev_table(t->ctx, t->d);
+    t->zero_from = ~0ULL;                                  // (what was never cleared need not be now)
+    free_dev_table(t->ctx, t->dv);
     delete t;
 }
 
-extern "C" uint32_t katgpu_table_k(const katgpu_table* t) { return t ? t->d.k : 0; }
+extern "C" uint32_t katgpu_table_k(const katgpu_table* t) { return t ? t->dv.k : 0; }
 extern "C" uint32_t katgpu_table_regrows(const katgpu_table* t) { return t ? t->n_regrows : 0; }
-extern "C" uint32_t katgpu_table_slot_bytes(const katgpu_table* t) { return !t ? 0 : t->d.keys_b ? 20 : t->d.cbits ? 8 : 12; }
-extern "C" int katgpu_table_canonical(const katgpu_table* t) { return t ? (int)t->d.canonical : 0; }
+extern "C" uint32_t katgpu_table_slot_bytes(const katgpu_table* t) { return !t ? 0 : t->dv.keys_b ? 20 : t->dv.cbits ? 8 : 12; }
+extern "C" int katgpu_table_canonical(const katgpu_table* t) { return t ? (int)t->dv.canonical : 0; }
 
 // read the counter block back (one small D2H; synchronises the compute stream)
 int refresh_counters(katgpu_table* t) {
     katgpu_ctx* c = t->ctx;
     uint64_t h[CTR_WORDS];
-    HIPCHK(c, hipMemcpyAsync(h, t->d.ctrs, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h, t->dv.ctrs, sizeof h, hipMemcpyDeviceToHost, c->stream));      // (the counters only: a table whose slots wait for their first sweep stays that way)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint64_t d = 0;
     for (int i = 0; i < CTR_NSTRIPES; ++i) d += h[CTR_DISTINCT0 + i];
@@ -156,17 +166,17 @@ int refresh_counters(katgpu_table* t) {
 int regrow(katgpu_table* t, uint64_t new_cap) {
     katgpu_ctx* c = t->ctx;
     DevTable nd{};
-    int rc = alloc_dev_table(c, t->d.k, t->d.canonical, new_cap, &nd, t->d.n_regions > 1 ? t->d.p1 : 0, t->d.n_regions > 1 ? t->d.p2 : 0);
+    int rc = alloc_dev_table(c, t->dev().k, t->dev().canonical, new_cap, &nd, t->dev().n_regions > 1 ? t->dev().p1 : 0, t->dev().n_regions > 1 ? t->dev().p2 : 0);
     if (rc) return rc;
     {
-        ScopedTimer tm(c, KATGPU_K_REGROW, t->d.cap);
-        if (t->d.keys_b) hipLaunchKernelGGL(k_regrow_w, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, nd, t->d, t->n_ovf);
-        else hipLaunchKernelGGL(k_regrow, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, nd, t->d, t->n_ovf);
+        ScopedTimer tm(c, KATGPU_K_REGROW, t->dev().cap);
+        if (t->dev().keys_b) hipLaunchKernelGGL(k_regrow_w, dim3(grid_for(c, t->dev().cap, 256, 8)), dim3(256), 0, c->stream, nd, t->dev(), t->n_ovf);
+        else hipLaunchKernelGGL(k_regrow, dim3(grid_for(c, t->dev().cap, 256, 8)), dim3(256), 0, c->stream, nd, t->dev(), t->n_ovf);
     }
-    HIPCHK(c, hipMemcpyAsync(&nd.ctrs[CTR_ONES], &t->d.ctrs[CTR_ONES], sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&nd.ctrs[CTR_ONES], &t->dev().ctrs[CTR_ONES], sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_dev_table(c, t->d);
-    t->d = nd;
+    free_dev_table(c, t->dev());
+    t->dev() = nd;
     ++t->n_regrows;
     t->count_bound = 0xFFFFFFFFULL;           // full counts were folded back into the slots: the next unchecked launch sweeps first
     t->unchecked_adds = 0;
@@ -186,9 +196,9 @@ int ensure_room(katgpu_table* t, uint64_t incoming) {
     int rc = refresh_counters(t);
     if (rc) return rc;
     const uint64_t need = t->distinct + incoming;
-    if ((double)need <= load_limit(t->d) * (double)t->d.cap) return KATGPU_OK;
+    if ((double)need <= load_limit(t->dev()) * (double)t->dev().cap) return KATGPU_OK;
     if (t->disable_grow) return fail(t->ctx, KATGPU_ERR_TABLE_FULL, "Hash full");
-    uint64_t new_cap = t->d.cap;
+    uint64_t new_cap = t->dev().cap;
     while ((double)need > 0.5 * (double)new_cap) new_cap *= 2;
     return regrow(t, new_cap);
 }
@@ -199,11 +209,11 @@ extern "C" int katgpu_table_stats(katgpu_table* t, uint64_t* distinct, uint64_t*
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
     if (distinct) *distinct = t->distinct;
-    if (capacity) *capacity = t->d.cap;
+    if (capacity) *capacity = t->dev().cap;
     if (total) {
-        uint64_t* scratch = &t->d.ctrs[CTR_SCRATCH];
+        uint64_t* scratch = &t->dev().ctrs[CTR_SCRATCH];
         HIPCHK(c, hipMemsetAsync(scratch, 0, sizeof(uint64_t), c->stream));
-        hipLaunchKernelGGL(k_total, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, scratch);
+        hipLaunchKernelGGL(k_total, dim3(grid_for(c, t->dev().cap, 256, 8)), dim3(256), 0, c->stream, t->dev(), t->n_ovf, scratch);
         uint64_t s = 0;
         HIPCHK(c, hipMemcpyAsync(&s, scratch, sizeof s, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -223,7 +233,7 @@ extern "C" int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n,
     HIPCHK(c, hipMalloc(&dk, n * 8));
     if (hipMalloc(&dc, n * 8) != hipSuccess) { hipFree(dk); return fail(c, KATGPU_ERR_NOMEM, "lookup buffers"); }
     hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, c->stream);
-    hipLaunchKernelGGL(k_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, t->d, t->n_ovf, dk, (uint64_t)n, canonicalise, dc);
+    hipLaunchKernelGGL(k_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, t->dev(), t->n_ovf, dk, (uint64_t)n, canonicalise, dc);
     hipMemcpyAsync(counts, dc, n * 8, hipMemcpyDeviceToHost, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
     hipFree(dk); hipFree(dc);
@@ -233,28 +243,28 @@ extern "C" int katgpu_table_get(katgpu_table* t, const uint64_t* keys, size_t n,
 
 static int launch_profile(katgpu_table* t, const uint8_t* dev_bases, size_t n, int canonicalise, uint64_t* dev_counts) {
     katgpu_ctx* c = t->ctx;
-    const bool wide = t->d.keys_b != nullptr;
-    const uint64_t n_out = n - t->d.k + 1;
+    const bool wide = t->dev().keys_b != nullptr;
+    const uint64_t n_out = n - t->dev().k + 1;
     const uint64_t per_chunk = wide ? WIDE_CHUNK_STARTS : CHUNK_STARTS;
     const uint64_t n_chunks = (n_out + per_chunk - 1) / per_chunk;
     const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)c->n_cu * 8);
     const bool aligned = (reinterpret_cast<uintptr_t>(dev_bases) & 15) == 0 && (reinterpret_cast<uintptr_t>(dev_counts) & 15) == 0;
     ScopedTimer tm(c, KATGPU_K_PROFILE, n_out);
     if (wide && aligned)
-        hipLaunchKernelGGL(k_profile_w<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
+        hipLaunchKernelGGL(k_profile_w<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->dev(), t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
     else if (wide)
-        hipLaunchKernelGGL(k_profile_w<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
+        hipLaunchKernelGGL(k_profile_w<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->dev(), t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
     else if (aligned)
-        hipLaunchKernelGGL(k_profile<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
+        hipLaunchKernelGGL(k_profile<true>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->dev(), t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
     else
-        hipLaunchKernelGGL(k_profile<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->d, t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
+        hipLaunchKernelGGL(k_profile<false>, dim3(grid), dim3(COUNT_BLOCK), 0, c->stream, t->dev(), t->n_ovf, canonicalise, dev_bases, (uint64_t)n, n_chunks, dev_counts);
     HIPCHK(c, hipGetLastError());
     return KATGPU_OK;
 }
 
 extern "C" int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_bases, size_t n, int canonicalise, uint64_t* dev_counts) {
     if (!t || (n && (!dev_bases || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
-    if (n < t->d.k) return KATGPU_OK;
+    if (n < t->dev().k) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
@@ -265,7 +275,7 @@ extern "C" int katgpu_table_profile_device(katgpu_table* t, const uint8_t* dev_b
 // k-1 bases it shares with the next one), so any length fits next to the table.
 extern "C" int katgpu_table_profile_host(katgpu_table* t, const char* bases, size_t n, int canonicalise, uint64_t* counts) {
     if (!t || (n && (!bases || !counts))) return KATGPU_ERR_INVALID_ARG;
-    const uint32_t k = t->d.k;
+    const uint32_t k = t->dev().k;
     if (n < k) return KATGPU_OK;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -305,11 +315,11 @@ extern "C" int katgpu_table_partition_sizes(katgpu_table* t, uint32_t n_parts, u
     HIPCHK(c, hipMalloc(&d, n_parts * 8));
     hipMemsetAsync(d, 0, n_parts * 8, c->stream);
     {
-        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
-        if (t->d.keys_b)
-            hipLaunchKernelGGL(k_partition_w<0>, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr);
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->dev().cap);
+        if (t->dev().keys_b)
+            hipLaunchKernelGGL(k_partition_w<0>, dim3(grid_for(c, t->dev().cap, 256, 8)), dim3(256), 0, c->stream, t->dev(), t->n_ovf, n_parts, d, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr);
         else
-            hipLaunchKernelGGL(k_partition<0>, dim3(grid_for(c, t->d.cap + 1, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, (uint64_t*)nullptr, (uint64_t*)nullptr);
+            hipLaunchKernelGGL(k_partition<0>, dim3(grid_for(c, t->dev().cap + 1, 256, 8)), dim3(256), 0, c->stream, t->dev(), t->n_ovf, n_parts, d, (uint64_t*)nullptr, (uint64_t*)nullptr);
     }
     hipMemcpyAsync(sizes, d, n_parts * 8, hipMemcpyDeviceToHost, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -328,8 +338,8 @@ extern "C" int katgpu_table_partition(katgpu_table* t, uint32_t n_parts, const u
     HIPCHK(c, hipMalloc(&d, n_parts * 8));
     hipMemcpyAsync(d, offsets, n_parts * 8, hipMemcpyHostToDevice, c->stream);
     {
-        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
-        hipLaunchKernelGGL(k_partition<1>, dim3(grid_for(c, t->d.cap + 1, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, dev_keys, dev_counts);
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->dev().cap);
+        hipLaunchKernelGGL(k_partition<1>, dim3(grid_for(c, t->dev().cap + 1, 256, 8)), dim3(256), 0, c->stream, t->dev(), t->n_ovf, n_parts, d, dev_keys, dev_counts);
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     hipFree(d);
@@ -369,10 +379,10 @@ extern "C" int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_ke
     size_t pos = 0;
     while (pos < n) {
         int rc = refresh_counters(t); if (rc) return rc;
-        uint64_t room = (uint64_t)(load_limit(t->d) * (double)t->d.cap) > t->distinct ? (uint64_t)(load_limit(t->d) * (double)t->d.cap) - t->distinct : 0;
+        uint64_t room = (uint64_t)(load_limit(t->dev()) * (double)t->dev().cap) > t->distinct ? (uint64_t)(load_limit(t->dev()) * (double)t->dev().cap) - t->distinct : 0;
         uint64_t want = n - pos;
-        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
-            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->dev().cap / 8, 1024))) {
+            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->dev().cap / 2, 1024)));
             if (rc) return rc;
             continue;
         }
@@ -380,7 +390,7 @@ extern "C" int katgpu_table_merge_device(katgpu_table* t, const uint64_t* dev_ke
         t->count_bound = 0xFFFFFFFFULL;          // merged amounts are arbitrary: the next k_count launch sweeps first
         {
             ScopedTimer tm(c, KATGPU_K_MERGE, take);
-            hipLaunchKernelGGL(k_merge, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->d, dev_keys + pos, dev_counts + pos, take);
+            hipLaunchKernelGGL(k_merge, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->dev(), dev_keys + pos, dev_counts + pos, take);
         }
         pos += take;
     }
@@ -408,7 +418,7 @@ extern "C" int katgpu_table_merge_host(katgpu_table* t, const uint64_t* keys, co
 extern "C" int katgpu_table_export_wide(katgpu_table* t, uint64_t* keys_hi, uint64_t* keys_lo, uint64_t* counts, size_t cap, size_t* n_out) {
     if (!t || !n_out) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
-    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_export_wide is for k > 32 tables (k = %u): use katgpu_table_export", t->d.k);
+    if (!t->dev().keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_export_wide is for k > 32 tables (k = %u): use katgpu_table_export", t->dev().k);
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
     *n_out = (size_t)t->distinct;
@@ -420,7 +430,7 @@ extern "C" int katgpu_table_export_wide(katgpu_table* t, uint64_t* keys_hi, uint
     HIPCHK(c, hipMalloc(&d, (3 * n + 1) * 8));
     unsigned long long* cursor = (unsigned long long*)(d + 3 * n);
     hipMemsetAsync(cursor, 0, 8, c->stream);
-    hipLaunchKernelGGL(k_export_w, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, d, d + n, d + 2 * n, cursor);
+    hipLaunchKernelGGL(k_export_w, dim3(grid_for(c, t->dev().cap, 256, 8)), dim3(256), 0, c->stream, t->dev(), t->n_ovf, d, d + n, d + 2 * n, cursor);
     hipMemcpyAsync(keys_hi, d, n * 8, hipMemcpyDeviceToHost, c->stream);
     hipMemcpyAsync(keys_lo, d + n, n * 8, hipMemcpyDeviceToHost, c->stream);
     hipMemcpyAsync(counts, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->stream);
@@ -433,7 +443,7 @@ extern "C" int katgpu_table_export_wide(katgpu_table* t, uint64_t* keys_hi, uint
 extern "C" int katgpu_table_partition_wide(katgpu_table* t, uint32_t n_parts, const uint64_t* offsets, uint64_t* dev_hi, uint64_t* dev_lo, uint64_t* dev_counts) {
     if (!t || !offsets || n_parts == 0 || n_parts > 4096) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
-    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_partition_wide is for k > 32 tables (k = %u): use katgpu_table_partition", t->d.k);
+    if (!t->dev().keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_partition_wide is for k > 32 tables (k = %u): use katgpu_table_partition", t->dev().k);
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
     if (t->distinct && (!dev_hi || !dev_lo || !dev_counts)) return KATGPU_ERR_INVALID_ARG;
@@ -441,8 +451,8 @@ extern "C" int katgpu_table_partition_wide(katgpu_table* t, uint32_t n_parts, co
     HIPCHK(c, hipMalloc(&d, n_parts * 8));
     hipMemcpyAsync(d, offsets, n_parts * 8, hipMemcpyHostToDevice, c->stream);
     {
-        ScopedTimer tm(c, KATGPU_K_PARTITION, t->d.cap);
-        hipLaunchKernelGGL(k_partition_w<1>, dim3(grid_for(c, t->d.cap, 256, 8)), dim3(256), 0, c->stream, t->d, t->n_ovf, n_parts, d, dev_hi, dev_lo, dev_counts);
+        ScopedTimer tm(c, KATGPU_K_PARTITION, t->dev().cap);
+        hipLaunchKernelGGL(k_partition_w<1>, dim3(grid_for(c, t->dev().cap, 256, 8)), dim3(256), 0, c->stream, t->dev(), t->n_ovf, n_parts, d, dev_hi, dev_lo, dev_counts);
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     hipFree(d);
@@ -453,21 +463,21 @@ extern "C" int katgpu_table_partition_wide(katgpu_table* t, uint32_t n_parts, co
 extern "C" int katgpu_table_merge_device_wide(katgpu_table* t, const uint64_t* dev_hi, const uint64_t* dev_lo, const uint64_t* dev_counts, size_t n) {
     if (!t || (n && (!dev_hi || !dev_lo || !dev_counts))) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
-    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_merge_device_wide is for k > 32 tables (k = %u): use katgpu_table_merge_device", t->d.k);
+    if (!t->dev().keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_merge_device_wide is for k > 32 tables (k = %u): use katgpu_table_merge_device", t->dev().k);
     HIPCHK(c, hipSetDevice(c->device));
     size_t pos = 0;
     while (pos < n) {
         int rc = refresh_counters(t); if (rc) return rc;
-        const uint64_t room = (uint64_t)(load_limit(t->d) * (double)t->d.cap) > t->distinct ? (uint64_t)(load_limit(t->d) * (double)t->d.cap) - t->distinct : 0;
+        const uint64_t room = (uint64_t)(load_limit(t->dev()) * (double)t->dev().cap) > t->distinct ? (uint64_t)(load_limit(t->dev()) * (double)t->dev().cap) - t->distinct : 0;
         const uint64_t want = n - pos;
-        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 8, 1024))) {
-            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->d.cap / 2, 1024)));
+        if (room < std::min<uint64_t>(want, std::max<uint64_t>(t->dev().cap / 8, 1024))) {
+            rc = ensure_room(t, std::min<uint64_t>(want, std::max<uint64_t>(t->dev().cap / 2, 1024)));
             if (rc) return rc;
             continue;
         }
         const uint64_t take = std::min(want, room);
         ScopedTimer tm(c, KATGPU_K_MERGE, take);
-        hipLaunchKernelGGL(k_merge_w, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->d, dev_hi + pos, dev_lo + pos, dev_counts + pos, (uint64_t)take);
+        hipLaunchKernelGGL(k_merge_w, dim3(grid_for(c, take, 256, 8)), dim3(256), 0, c->stream, t->dev(), dev_hi + pos, dev_lo + pos, dev_counts + pos, (uint64_t)take);
         pos += take;
     }
     return refresh_counters(t);
@@ -476,10 +486,10 @@ extern "C" int katgpu_table_merge_device_wide(katgpu_table* t, const uint64_t* d
 extern "C" int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, const uint64_t* counts, size_t n) {
     if (!t || (n && (!keys_hi || !keys_lo || !counts))) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
-    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_merge_host_wide is for k > 32 tables (k = %u): use katgpu_table_merge_host", t->d.k);
+    if (!t->dev().keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_merge_host_wide is for k > 32 tables (k = %u): use katgpu_table_merge_host", t->dev().k);
     if (!n) return KATGPU_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    const uint32_t k = t->d.k;
+    const uint32_t k = t->dev().k;
     const uint64_t hi_mask = (1ULL << (2 * k - 64)) - 1;           // 2 <= 2k - 64 <= 62
     for (size_t i = 0; i < n; ++i)
         if (keys_hi[i] & ~hi_mask) return fail(c, KATGPU_ERR_INVALID_ARG, "record %zu: key wider than 2k = %u bits", i, 2 * k);
@@ -497,7 +507,7 @@ extern "C" int katgpu_table_merge_host_wide(katgpu_table* t, const uint64_t* key
 extern "C" int katgpu_table_get_wide(katgpu_table* t, const uint64_t* keys_hi, const uint64_t* keys_lo, size_t n, int canonicalise, uint64_t* counts) {
     if (!t || (n && (!keys_hi || !keys_lo || !counts))) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
-    if (!t->d.keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_get_wide is for k > 32 tables (k = %u): use katgpu_table_get", t->d.k);
+    if (!t->dev().keys_b) return fail(c, KATGPU_ERR_K, "katgpu_table_get_wide is for k > 32 tables (k = %u): use katgpu_table_get", t->dev().k);
     if (!n) return KATGPU_OK;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
@@ -505,7 +515,7 @@ extern "C" int katgpu_table_get_wide(katgpu_table* t, const uint64_t* keys_hi, c
     HIPCHK(c, hipMalloc(&d, 3 * n * 8));
     hipMemcpyAsync(d, keys_hi, n * 8, hipMemcpyHostToDevice, c->stream);
     hipMemcpyAsync(d + n, keys_lo, n * 8, hipMemcpyHostToDevice, c->stream);
-    hipLaunchKernelGGL(k_get_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, t->d, t->n_ovf, d, d + n, (uint64_t)n, canonicalise, d + 2 * n);
+    hipLaunchKernelGGL(k_get_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, t->dev(), t->n_ovf, d, d + n, (uint64_t)n, canonicalise, d + 2 * n);
     hipMemcpyAsync(counts, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
     hipFree(d);

@@ -50,7 +50,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     # l1_lean=0: level 1's ranking sweep and copy-out in their 64-bit form (the default is the 32-bit one of kg_l1_lean.hpp), both
     # editions of level 1
     (512, 100000, 0, {"KATGPU_L1_LEAN": "0"}), (1024, 3000000, 7, {"KATGPU_L1_LEAN": "0", "KATGPU_L1_FAST": "2"}),
-    (8192, 400000, 0, {"KATGPU_L1_LEAN": "0", "KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2"})])
+    (8192, 400000, 0, {"KATGPU_L1_LEAN": "0", "KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2"}),
+    # lazy_min_slots=1: every packed table leaves the clearing of its slots to its first sweep -- the first round's apply starts every
+    # region from zeros and visits all of them, pass by pass (production: tables of 2^26 slots and more); whatever else touches the table
+    # first (the direct path, a regrow, a reducer) clears what has not been swept yet
+    (512, 100000, 0, {"KATGPU_TEST_LAZY_MIN_SLOTS": "1"}), (1024, 3000000, 7, {"KATGPU_TEST_LAZY_MIN_SLOTS": "1", "KATGPU_P2_FAST": "2", "KATGPU_TEST_PASS_BUCKETS": "3"}),
+    (2048, 250000, 3, {"KATGPU_TEST_LAZY_MIN_SLOTS": "1", "KATGPU_TEST_GROW_NOMEM": "1"}), (512, 100000, 0, {"KATGPU_TEST_LAZY_MIN_SLOTS": "1", "KATGPU_TEST_AP_SEG": "64"}),
+    (256, 3000000, 5, {"KATGPU_TEST_LAZY_MIN_SLOTS": "1", "KATGPU_L1_FAST": "2", "KATGPU_P2_FAST": "2", "KATGPU_TEST_PASS_BUCKETS": "2"})])
 def test_partitioned_counter_matches_oracle(region_slots, round_items, spill_mod, extra):
     env = dict(os.environ, KATGPU_PART_MIN_STARTS="0", KATGPU_TEST_REGION_SLOTS=str(region_slots),
                KATGPU_TEST_ROUND_ITEMS=str(round_items), KATGPU_TEST_SPILL_MOD=str(spill_mod))

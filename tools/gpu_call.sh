@@ -4,8 +4,8 @@ set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export KATGPU_TESTING=1
-(timeout 900 python -m pytest tests/test_gpu_partition.py -m gpu -x -q --timeout=600 -p no:cacheprovider 2>&1 | tail -40) > gpurun_out/c15_tests.log 2>&1
-tail -6 gpurun_out/c15_tests.log | cut -c1-400
+(timeout 1200 python -m pytest tests/test_gpu_partition.py tests/test_gpu_bench_geometry.py -k "partitioned_counter or config4" -m gpu -x -q --timeout=900 --durations=8 -p no:cacheprovider 2>&1 | tail -40) > gpurun_out/c17_tests.log 2>&1
+tail -16 gpurun_out/c17_tests.log | cut -c1-400
 show() {
 python - "$1" "$2" <<PY
 import json, sys
@@ -19,12 +19,10 @@ PY
 }
 run() {  # tag, env...
   tag=$1; shift
-  env "$@" timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/c15_$tag.json 2> gpurun_out/c15_$tag.err
-  show $tag gpurun_out/c15_$tag.json
-  grep "stamps" gpurun_out/c15_$tag.err | head -2
+  env "$@" timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/c17_$tag.json 2> gpurun_out/c17_$tag.err
+  show $tag gpurun_out/c17_$tag.json
 }
-run def1 A=1
-run pf1 KATGPU_APPLY_PF=1
-run def2 A=1
-run pf2 KATGPU_APPLY_PF=1
-run apstamp KATGPU_APPLY_STAMP=1
+run lazy1 A=1
+run nolazy1 KATGPU_NO_LAZY_ZERO=1
+run lazy2 A=1
+run nolazy2 KATGPU_NO_LAZY_ZERO=1
