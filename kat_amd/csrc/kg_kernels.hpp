@@ -289,7 +289,8 @@ k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long lon
                 occ = g < k;                                   // the reference's matrix has k rows: GC == k never printed
                 cell = g * cols + (uint32_t)pos;
             }
-            if (use_lds) lds_inc_aggregated(s_bins, cell, occ);
+            if (use_lds == 2) { if (occ) (void)__hip_atomic_fetch_add(&s_bins[cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // (one atomic per lane: kg_reduce.hip, KATGPU_COMP_PLAIN_INC)
+            else if (use_lds) lds_inc_aggregated(s_bins, cell, occ);
             else if (occ) atomicAdd(&out[cell], 1ULL);
         }
     }
@@ -320,8 +321,13 @@ struct CompArgs {
     uint32_t* seen;                  // join pass 1 -> pass 2: one bit per slot of hash 2, set when hash 1 holds the slot's key (null: off);
     uint32_t seen_wpr;               // words per region of that bitmap
     uint32_t fold;                   // pass 1: spectra of the k-mers that land in the LDS tile are taken from the tile at the end (below)
+    uint32_t plain_inc;              // LDS increments as one no-return atomic per lane (the default) instead of ballot-aggregated per wave (kg_reduce.hip: KATGPU_COMP_PLAIN_INC)
 };
 
+__device__ __forceinline__ void comp_inc(const CompArgs& a, uint32_t* bins, uint32_t idx, bool active) {
+    if (a.plain_inc) { if (active) (void)__hip_atomic_fetch_add(&bins[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    else lds_inc_aggregated(bins, idx, active);
+}
 __device__ __forceinline__ uint32_t spectrum_bin(uint64_t c, uint32_t size) { return c >= size ? size - 1 : (uint32_t)c; }  // comp_counters.cc:130-140
 
 __device__ __forceinline__ void block_sum_u64(unsigned long long* s_acc, int slot, uint64_t v) {
@@ -357,17 +363,17 @@ __device__ __forceinline__ void comp_account(bool occ, uint64_t ca, uint64_t cb,
             cell = (uint32_t)s2;                                            // row 0 in both the tile and the matrix
         }
     }
-    lds_inc_aggregated(s_tile, cell, in_mx && in_tile);
+    comp_inc(a, s_tile, cell, in_mx && in_tile);
     if (in_mx && !in_tile) atomicAdd(&a.main_mx[cell], 1ULL);
     // CompArgs::fold (unscaled bins, more than COMP_TILE of them): a k-mer of pass 1 that lands in the tile has s1 == ca < 64 and
     // s2 == cb < 64, so spectrum1, shared_spectrum1 and shared_spectrum2 are marginals of the tile -- comp_flush adds them; one LDS
     // atomic per k-mer instead of four (the spectra's hot bins are the same few addresses for every lane of the chip)
     if (PASS == 1 && a.fold) occ = occ && !in_tile;
-    lds_inc_aggregated(s_spec, spectrum_bin(ca, a.spec_size), occ);                            // spectrum1 / spectrum2
+    comp_inc(a, s_spec, spectrum_bin(ca, a.spec_size), occ);                            // spectrum1 / spectrum2
     if (PASS == 1) {
         bool shared = occ && ca && cb;
-        lds_inc_aggregated(s_spec + a.spec_size, spectrum_bin(ca, a.spec_size), shared);         // shared_spectrum1
-        lds_inc_aggregated(s_spec + 2 * a.spec_size, spectrum_bin(cb, a.spec_size), shared);     // shared_spectrum2
+        comp_inc(a, s_spec + a.spec_size, spectrum_bin(ca, a.spec_size), shared);         // shared_spectrum1
+        comp_inc(a, s_spec + 2 * a.spec_size, spectrum_bin(cb, a.spec_size), shared);     // shared_spectrum2
     }
 }
 

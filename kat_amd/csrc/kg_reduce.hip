@@ -8,6 +8,11 @@ static const bool g_force_join = hook("KATGPU_FORCE_JOIN") != nullptr;  // tests
 static const bool g_no_join = hook("KATGPU_NO_JOIN") != nullptr;       // A/B switch: force comp's probe form
 static const bool g_no_seen = hook("KATGPU_NO_SEEN") != nullptr;       // A/B switch: pass 2 probes hash 1 even after a join pass 1
 static const bool g_no_fused = hook("KATGPU_NO_FUSED") != nullptr;     // A/B switch: comp as two passes even where the fused join applies
+// The comp and gcp kernels' LDS increments: one no-return atomic per lane (1), or aggregated per wave with ballots (0: a leader adds the
+// count of the lanes that hit its cell).  The aggregation saves LDS conflicts on the hot cells and costs every slot ~14 instructions of a
+// kernel that is bound by its instruction chain: same-box A/B (round 4) k_comp_fused 31.7 -> 27.9 ms at config 4, 46.8 -> 41.8 at config 5,
+// k_gcp 3.96 -> 3.22 ms at config 3 with plain increments.  (k_hist keeps the aggregation: nearly every lane of a wave hits ONE bucket there.)
+static const bool g_comp_plain_inc = hook_u64("KATGPU_COMP_PLAIN_INC", 1) != 0;
 static const bool g_no_fold = hook("KATGPU_NO_FOLD") != nullptr;       // A/B switch: spectra by their own LDS atomics even for the tile's k-mers
 static const uint32_t g_join_block = (uint32_t)hook_u64("KATGPU_JOIN_BLOCK", 512);   // A/B: threads per join workgroup (512 or 1024)
 
@@ -48,7 +53,7 @@ extern "C" int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, 
     HIPCHK(c, hipMalloc(&d, cells * 8));
     hipMemsetAsync(d, 0, cells * 8, c->stream);
     const size_t lds = cells * sizeof(uint32_t);
-    const uint32_t use_lds = lds <= 150 * 1024 ? 1 : 0;                         // 160 KB LDS per CU
+    const uint32_t use_lds = lds <= 150 * 1024 ? (g_comp_plain_inc ? 2 : 1) : 0;   // 160 KB LDS per CU
     const int per_cu = use_lds && lds > 75 * 1024 ? 1 : 2;
 #define KG_GCP(W, PK) do { \
         if (use_lds && lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_gcp<W, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -122,6 +127,7 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
         a.seen = seen_bits; a.seen_wpr = wpr;
     }
     // unscaled matrices of more than COMP_TILE bins (KAT's defaults): the spectra of the k-mers that land in the LDS tile are its marginals
+    a.plain_inc = g_comp_plain_inc ? 1 : 0;
     a.fold = !g_no_fold && d1_scale == 1.0 && d2_scale == 1.0 && d1_bins > COMP_TILE && d2_bins > COMP_TILE ? 1 : 0;
     const uint32_t jblk = g_join_block == 1024 ? 1024 : 512;
     auto join_grid = [&](size_t lds, uint32_t regions) {
