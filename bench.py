@@ -624,9 +624,12 @@ def end_to_end(eng, a, k, L):
                 rec["GB_per_s"] = round(rec["bytes"] / max(rec["wall_ms"], 1e-3) / 1e6, 2)
                 per_file.append(rec)
         accounted = sum(v for q, v in phases.items() if q != "total_ms")
+        in_files = sum(f.get("setup_ms", 0.0) + f.get("wall_ms", 0.0) for f in per_file)
         breakdown = {"process_wall_ms": round(dt * 1e3, 1), "phases": phases, "unaccounted_ms": round(dt * 1e3 - accounted, 1),
+                     # what the two count phases spent outside the files' passes: waiting for the table / arena allocations, the last counts
+                     "count_phases_outside_files_ms": round(phases.get("count_input_1_ms", 0.0) + phases.get("count_input_2_ms", 0.0) - in_files, 1),
                      "files": per_file,
-                     "reading": "per file: wall = the file's whole pass; reader_wait = the main thread waiting for file bytes to reach the device (reader threads: "
+                     "reading": "per file: setup = open + map + device / pinned buffers; wall = the file's whole pass; reader_wait = the main thread waiting for file bytes to reach the device (reader threads: "
                                 "pread into pinned memory, then their own H2D copy; pread / h2d per thread say which of the two it was); scan = the record scan "
                                 "on the device; counter_wait = waiting for the counting worker; counting = what the worker spent (hidden under the rest unless "
                                 "counter_wait says otherwise)"}
