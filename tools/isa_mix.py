@@ -3,13 +3,15 @@
 
   tools/isa_mix.py <file.s> <substring of the mangled kernel name> [--loops]
 
-Prints the kernel's VGPR / SGPR / LDS / scratch use and its instructions by class (VALU full rate, VALU quarter rate = 32-bit
-multiplies and 64-bit mads, LDS, global/flat, SALU, branches, waits), for the whole body and per basic block with --loops.  A VALU-bound
+Prints the kernel's VGPR / SGPR / LDS / scratch use and its instructions by class (VALU, 64-bit VALU, `valu_quarter` = 32-bit
+multiplies and 64-bit mads -- counted on their own, but full rate on gfx950: tools/ubench_valu.hip --, LDS, global/flat, SALU,
+branches, waits), for the whole body and per basic block with --loops.  A VALU-bound
 kernel's time goes with the weighted VALU count of its hot loop, which is what this is for: iterating on instruction count
 without a GPU."""
 import re
 import sys
 
+# (32-bit integer multiplies are FULL rate on gfx950 -- tools/ubench_valu.hip, round 4 --; the class is kept as a count, weighted 1)
 QUARTER = re.compile(r"^v_(mul_lo_u32|mul_hi_u32|mul_hi_i32|mul_lo_i32|mad_u64_u32|mad_i64_i32|mul_u64|mul_f64|fma_f64|add_f64|rcp_f64|div)")
 HALF64 = re.compile(r"^v_(lshlrev_b64|lshrrev_b64|ashrrev_i64|cmp_[a-z]+_[ui]64|cmpx_[a-z]+_[ui]64)")
 
@@ -76,7 +78,7 @@ def main():
             break
     print(name)
     print("  ", meta)
-    w = lambda d: d.get("valu", 0) + 2 * d.get("valu_64", 0) + 4 * d.get("valu_quarter", 0)
+    w = lambda d: d.get("valu", 0) + 2 * d.get("valu_64", 0) + d.get("valu_quarter", 0)
     print("   total:", dict(sorted(tot.items())), "weighted VALU:", w(tot))
     if per_block:
         for nm, d in blocks:
