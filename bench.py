@@ -14,12 +14,20 @@ Workloads (BASELINE.json configs[1..4]; --config N is an alias, N counted from 1
   --workload gcp       config 3: kat gcp, 100 M reads from a 200 Mbp genome, k = 27
   --workload comp-rr   config 5: kat comp, reads library 1 vs reads library 2 (75 M + 75 M reads per GPU), k = 31
 
-  python bench.py                                   # N = 1, config 4 at full size
-  python bench.py --gpus 8                          # launches its own 8 ranks (torch.distributed.run, one per GPU, RCCL)
+  python bench.py                                   # N = 1, config 4 at full size (+ `workloads`: configs 2, 3, 5's per-GPU shard, 3 steps each;
+                                                    #   + `end_to_end`: files -> files, config 4 at full size when /dev/shm has the room)
+  python bench.py --gpus 8                          # launches its own 8 ranks (torch.distributed.run, one per GPU, RCCL); weak scaling:
+                                                    #   300 M reads PER GPU
+  python bench.py --gpus 8 --scaling strong         # the metric's own config: 300 M reads IN TOTAL, sharded over the ranks
+  python bench.py --gpus 8 --workload comp-rr       # BASELINE.json configs[4] (config 5): 1.2 G reads vs reads, k = 31, 150 M per GPU
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N      # the driver's form: the same thing
+Ranks on distinct devices exchange over RCCL or not at all: a communicator that would have to stage through /dev/shm fails the run
+unless --allow-shm is given (the line's config.comm names the transport either way).
 """
 import argparse
+import copy
 import json
+import re
 import os
 import socket
 import subprocess
@@ -43,8 +51,8 @@ WORKLOADS = {
     "comp-rr": (150_000_000, 1_000_000_000, 31, "kat comp reads-vs-reads"),
 }
 CONFIG_ALIAS = {2: "hist", 3: "gcp", 4: "comp", 5: "comp-rr"}
-PROFILE_JSON = {"comp": "profiles/r04_final_pmc_fetch_write.json", "hist": "profiles/r04_final_hist_pmc_fetch_write.json",
-                "gcp": "profiles/r04_final_gcp_pmc_fetch_write.json", "comp-rr": "profiles/r04_final_comp-rr_pmc_fetch_write.json"}
+PROFILE_JSON = {"comp": "profiles/r05_final_pmc_fetch_write.json", "hist": "profiles/r05_final_hist_pmc_fetch_write.json",
+                "gcp": "profiles/r05_final_gcp_pmc_fetch_write.json", "comp-rr": "profiles/r05_final_comp-rr_pmc_fetch_write.json"}
 # the sources the count stage's kernels are made of: a committed profile describes the kernels of ONE state of these files
 # (tools/profile_bench.sh records their digest next to the counters; pmc_traffic refuses a profile taken from other code)
 STAGE_SOURCES = ["kat_amd/csrc/kg_partition.hpp", "kat_amd/csrc/kg_device.hpp", "kat_amd/csrc/kg_l1_lean.hpp", "kat_amd/csrc/kg_kernels.hpp",
@@ -77,9 +85,15 @@ def parse_args():
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> output files leg")
     ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end slice (written as FASTQ to a temp dir: 32 GB at the default)")
     ap.add_argument("--phases", action="store_true", help="sync + print per-phase wall time (diagnostic; perturbs the timing)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=16_000_000)
+    ap.add_argument("--cpu-sample-genome", type=int, default=200_000_000, help="genome of the CPU sample: its table must be much larger than the host's last-level cache")
     ap.add_argument("--load", type=float, default=0.62, help="load factor the tables are pre-sized for (expected distinct k-mers / slots)")
     ap.add_argument("--hint-scale", type=float, default=1.0, help="diagnostic: scale the tables' size hints (e.g. 0.02: grown on the way)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"), help="N > 1: weak = the workload's reads PER GPU (default); strong = the workload's reads in total, sharded")
+    ap.add_argument("--allow-shm", action="store_true", help="N > 1: let ranks on distinct devices stage the exchange through /dev/shm when RCCL cannot be had (the line says so)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` object (configs 2, 3 and 5's shard, 3 steps each) of the default run")
+    ap.add_argument("--with-workloads", action="store_true", help="diagnostic / tests: the `workloads` object at a reduced size too (each capped at --reads / --genome)")
+    ap.add_argument("--e2e-slice", action="store_true", help="files -> files on the --e2e-reads slice even when /dev/shm has room for the whole config")
     a = ap.parse_args()
     if a.config is not None:
         if a.workload is not None and a.workload != CONFIG_ALIAS[a.config]:
@@ -156,24 +170,31 @@ def main():
         # the exchange keeps its send list and receive buffers inside the arena and allocates nothing else; leave room for the
         # second table, RCCL's channel buffers and the small per-region count matrices (must be set before the library loads)
         os.environ.setdefault("KATGPU_ARENA_FRACTION", "0.75")
+        # a bench step is seconds: a single wait of ten minutes is a wedged link, and an error beats a hang (kg_comm.hip "Liveness")
+        os.environ.setdefault("KATGPU_COMM_MAX_WAIT_S", "600")
+        if a.allow_shm:
+            os.environ["KATGPU_COMM_ALLOW_SHM"] = "1"
     import torch
     import kat_amd
-    from kat_amd import dist as kdist
 
     L0 = a.read_len
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")                     # rendezvous, barriers and the timing all-reduce only: the data path is katgpu's own communicator
     eng = kat_amd.Engine(local_rank)
-    # The native communicator (kg_comm.hip behind the C ABI: RCCL over xGMI, /dev/shm when ranks share a device or RCCL cannot be had --
-    # the line says which).  One code path: a communicator that cannot be made, or whose first exchange fails, fails the run.
+    # The native communicator (kg_comm.hip behind the C ABI: RCCL over xGMI; /dev/shm only when the ranks share a device, or with
+    # --allow-shm -- the line says which).  One code path: a communicator that cannot be made, or whose first exchange fails, fails the run.
     comm, transport, comm_info = None, None, None
     if world > 1:
         ids = [kat_amd.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         comm = kat_amd.Comm(eng, rank, world, ids[0])
+        if comm.transport != "rccl" and comm.distinct_devices > 1 and not a.allow_shm:
+            sys.exit("bench: %d ranks on %d devices would exchange through /dev/shm (%s): not an xGMI measurement; pass --allow-shm to take it knowingly"
+                     % (world, comm.distinct_devices, comm.transport_note or "no RCCL"))
         transport = "katgpu native exchange over %s" % ("RCCL" if comm.transport == "rccl" else "/dev/shm (%s)" % (comm.transport_note or "no RCCL"))
         # first contact between the devices, on two tiny tables: a transport that cannot work says so here, not after minutes of counting
         gp = eng.synth_genome(200_000, seed=5)
@@ -182,9 +203,67 @@ def main():
         tp.count_bases_device(rp.ptr, rp.nbytes)
         comm.exchange_merge(tp)
         seen = comm.allreduce_u64([np.ones(1, dtype=np.uint64)])[0]
-        comm_info = {"transport": comm.transport, "note": comm.transport_note, "ranks_seen": int(seen[0])}
+        comm_info = {"transport": comm.transport, "note": comm.transport_note, "ranks_seen": int(seen[0]), "distinct_devices": comm.distinct_devices,
+                     "shm_allowed": bool(a.allow_shm)}
         for x in (tp, rp, gp):
             x.free()
+
+    # ---- the files -> output files leg goes first: a child process that allocates right after this one has freed a hundred GB
+    # of HBM would spend seconds in the driver's scrubbing of that memory -- an artefact of benchmarking, not of the tool ----
+    e2e = None
+    if rank == 0 and world == 1 and not a.no_e2e:
+        try:
+            e2e = end_to_end(eng, a, a.k, a.read_len)
+        except Exception as ex:                            # the engine number stands on its own; say why the leg is missing
+            e2e = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        eng.release_scratch()
+
+    ctx = {"rank": rank, "world": world, "comm": comm, "dist": dist, "transport": transport, "comm_info": comm_info, "torch": torch}
+    line, ok, what = measure(eng, a, ctx, want_cpu=True)
+    all_ok = ok
+    if rank == 0:
+        line["end_to_end"] = e2e
+    # ---- the other single-GPU configs of BASELINE.json, briefly, in the same line: configs 2, 3 and config 5's per-GPU shard ----
+    if world == 1 and a.workload == "comp" and (a.default_size or a.with_workloads) and not a.no_workloads:
+        extra = {}
+        for wl in ("hist", "gcp", "comp-rr"):
+            eng.release_scratch()                           # the previous workload's parked tables and arena go back to the driver
+            b = copy.copy(a)
+            b.workload, b.steps, b.warmup, b.phases = wl, 3, 1, False
+            b.reads, b.genome, b.k, _ = WORKLOADS[wl]
+            if not a.default_size:                          # (--with-workloads at a reduced size)
+                b.reads, b.genome = min(b.reads, a.reads), min(b.genome, a.genome)
+            try:
+                l2, ok2, what2 = measure(eng, b, ctx, want_cpu=False)
+                extra[wl] = {"config": l2["config"]["workload"], "value": l2["value"], "unit": l2["unit"], "steps": b.steps, "warmup": b.warmup,
+                             "ms_per_step": l2["ms_per_step"], "kmer_instances": l2["kmer_instances"],
+                             "roofline": {k_: l2["roofline"][k_] for k_ in ("achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms")},
+                             "kernel_ms_per_step": l2["kernel_ms_per_step"], "reducers": l2["reducers"],
+                             "result_accounts_for_every_kmer": bool(ok2), "result_check": what2}
+                all_ok = all_ok and ok2
+            except Exception as ex:
+                extra[wl] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        line["workloads"] = extra
+    if rank == 0:
+        print(json.dumps(line))
+    if comm is not None:
+        comm.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+    if not all_ok:
+        sys.exit("bench: a result does not account for every k-mer: %s" % what)
+    if rank == 0 and e2e and e2e.get("result_check") is False:
+        sys.exit("bench: the files -> files leg wrote other results than the resident path: %s" % e2e.get("result_check_detail"))
+
+
+def measure(eng, a, ctx, want_cpu):
+    """One workload: synthetic inputs generated in HBM (not timed), `a.warmup` untimed steps, `a.steps` timed ones between barriers, max
+    over ranks; returns (the JSON line as a dict -- filled on rank 0 --, result ok, what was checked)."""
+    import kat_amd
+    from kat_amd import dist as kdist
+    rank, world, comm, dist, torch = ctx["rank"], ctx["world"], ctx["comm"], ctx["dist"], ctx["torch"]
 
     def barrier():
         eng.sync()
@@ -196,25 +275,19 @@ def main():
     wl = a.workload
     k, L = a.k, a.read_len
     two_tables = wl in ("comp", "comp-rr")
-    # ---- the files -> output files leg goes first: a child process that allocates right after this one has freed a hundred GB
-    # of HBM would spend seconds in the driver's scrubbing of that memory -- an artefact of benchmarking, not of the tool ----
-    e2e = None
-    if rank == 0 and world == 1 and not a.no_e2e:
-        try:
-            e2e = end_to_end(eng, a, k, L)
-        except Exception as ex:                            # the engine number stands on its own; say why the leg is missing
-            e2e = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    strong = world > 1 and a.scaling == "strong"
+    reads_per_gpu = (a.reads // world) if strong else a.reads          # strong: the workload's reads in total, sharded by pair
     # ---- synthetic inputs, generated in HBM (not timed) ----
     g = eng.synth_genome(a.genome, seed=20260927)                               # genome the reads are sampled from
     if wl == "comp-rr":                                                         # two read libraries, half of --reads each
-        n_reads = (a.reads // 2) & ~1
+        n_reads = (reads_per_gpu // 2) & ~1
         reads = eng.synth_reads(g, a.genome, first_read=rank * n_reads, n_reads=n_reads, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=1)
         reads2 = eng.synth_reads(g, a.genome, first_read=rank * n_reads, n_reads=n_reads, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=2)
         in2_ptr, in2_bytes = reads2.ptr, reads2.nbytes
         inst_reads = n_reads * (L - k + 1)
         inst2_local, inst2_total = inst_reads, world * inst_reads
     else:
-        n_reads = a.reads & ~1
+        n_reads = reads_per_gpu & ~1
         reads = eng.synth_reads(g, a.genome, first_read=rank * n_reads, n_reads=n_reads, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=1)
         inst_reads = n_reads * (L - k + 1)
         inst2_local = inst2_total = 0
@@ -300,12 +373,14 @@ def main():
         step()
     barrier()
     eng.profile_reset()
+    comm_before = comm.stats() if comm is not None else None
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile()
+    comm_after = comm.stats() if comm is not None else None
 
     def allsum(v):
         if world == 1:
@@ -314,12 +389,22 @@ def main():
         dist.all_reduce(t)
         return int(t.item())
 
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def allmax(v):
+        if world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    dt = allmax(dt)
     d1_local, cap1, cap2 = results["distinct1_local"], results["cap1"], results.get("cap2", 0)
     distinct1, distinct2 = allsum(results["distinct1"]), allsum(results.get("distinct2", 0))
+    exch = None
+    if comm is not None:                                        # the exchange of the TIMED steps: slowest rank per phase, bytes of all ranks
+        exch = {"max_over_ranks_ms_per_step": {q: round(allmax(comm_after[q] - comm_before[q]) / a.steps, 3) for q in ("extract_ms", "exchange_ms", "merge_ms", "allreduce_ms")},
+                "bytes_sent_per_step_all_ranks": allsum(comm_after["bytes_sent"] - comm_before["bytes_sent"]) // a.steps,
+                "bytes_sent_per_step_this_rank": int(comm_after["bytes_sent"] - comm_before["bytes_sent"]) // a.steps,
+                "reading": "extract = table -> send list; exchange = posting the chunks + waiting for them (on the wire while the previous chunk is merged); merge = k_merge_apply; allreduce = the small results"}
 
     total_instances = world * inst_reads + inst2_total
     value = total_instances * a.steps / dt
@@ -341,6 +426,7 @@ def main():
 
     if a.phases and rank == 0:
         print("phases (s, summed over steps):", {n: round(v, 3) for n, v in phases.items()}, file=sys.stderr)
+    line = {}
     if rank == 0:
         # ---- roofline of the count stage, from HIP events recorded on katgpu's own stream ----
         # algorithmic bytes: per instance L/(L-k+1) B of ASCII + 8 B key read + 4 B count read + 4 B count
@@ -411,40 +497,32 @@ def main():
             v["frac"] = round(v["achieved_GBps"] / HBM_PEAK_GBPS, 4) if v["achieved_GBps"] else None
         kernels_ms = {n: round(v["ms"] / a.steps, 3) for n, v in prof.items() if v["launches"]}
         cpu = None
-        if not a.no_cpu_baseline and world == 1 and k <= 32:      # the host-core baseline is an N = 1 figure (the multi-threaded oracle port is one-word)
+        if want_cpu and not a.no_cpu_baseline and world == 1 and k <= 32:      # the host-core baseline is an N = 1 figure (the multi-threaded oracle port is one-word)
             cpu = cpu_baseline(eng, a, k, L)
         _, _, _, wl_name = WORKLOADS[wl]
+        per = "in total, sharded over %d GPUs" % world if strong else "per GPU"
         if wl == "comp":
-            desc = "%s: %d x %d bp PE reads per GPU (0.2%% subst. errors) vs %d bp assembly in %d bp contigs, k=%d, canonical" % (wl_name, n_reads, L, a.genome, a.contig, k)
+            desc = "%s: %d x %d bp PE reads %s (0.2%% subst. errors) vs %d bp assembly in %d bp contigs, k=%d, canonical" % (wl_name, n_reads * (world if strong else 1), L, per, a.genome, a.contig, k)
         elif wl == "comp-rr":
-            desc = "%s: library 1 (%d reads per GPU) vs library 2 (%d reads per GPU), %d bp PE, 0.2%% subst. errors, %d bp genome, k=%d, canonical" % (wl_name, n_reads, n_reads, L, a.genome, k)
+            desc = "%s: library 1 (%d reads %s) vs library 2 (%d reads %s), %d bp PE, 0.2%% subst. errors, %d bp genome, k=%d, canonical" % (
+                wl_name, n_reads * (world if strong else 1), per, n_reads * (world if strong else 1), per, L, a.genome, k)
         else:
-            desc = "%s: %d x %d bp PE reads per GPU (0.2%% subst. errors) from a %d bp genome, k=%d, canonical" % (wl_name, n_reads, L, a.genome, k)
+            desc = "%s: %d x %d bp PE reads %s (0.2%% subst. errors) from a %d bp genome, k=%d, canonical" % (wl_name, n_reads * (world if strong else 1), L, per, a.genome, k)
         line = {
             "metric": "k-mers/sec (whole node) for %s k=%d" % (wl_name, k),
             "value": round(value, 1), "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": desc, "reads_per_gpu": n_reads * (2 if wl == "comp-rr" else 1), "genome_bp": a.genome, "k": k,
-                       "parallelism": "reads sharded x%d, owner-partitioned merge: %s" % (world, transport) if world > 1 else "single GPU", "comm": comm_info},
+                       "parallelism": "reads sharded x%d, owner-partitioned merge: %s" % (world, ctx["transport"]) if world > 1 else "single GPU", "comm": ctx["comm_info"]},
             "kmer_instances": total_instances, "distinct_table1": distinct1, "distinct_table2": distinct2 if two_tables else None,
             "result_accounts_for_every_kmer": bool(ok), "result_check": what,
             "kernel_ms_per_step": kernels_ms,
-            "roofline": roof, "reducers": red, "cpu_baseline": cpu, "end_to_end": e2e,
+            "roofline": roof, "reducers": red, "cpu_baseline": cpu,
         }
-        if comm is not None:
-            st = comm.stats()
-            line["exchange_ms_per_step"] = {k_: round(v / (a.steps + a.warmup), 3) for k_, v in st.items() if k_.endswith("_ms")}
-            line["exchange_bytes_sent_per_step"] = int(st["bytes_sent"] / (a.steps + a.warmup))
-        print(json.dumps(line))
-    if comm is not None:
-        comm.free()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    eng.close()
-    if not ok:
-        sys.exit("bench: the result does not account for every k-mer: %s" % what)
+        if exch is not None:
+            line["exchange"] = exch
+    return line, ok, what
 
 
 def cpu_baseline(eng, a, k, L):
@@ -457,7 +535,7 @@ def cpu_baseline(eng, a, k, L):
     cores = os.cpu_count() or 1
     wl = a.workload
     n = min(a.cpu_sample_reads, a.reads) & ~1
-    gs = min(a.genome, 20_000_000)
+    gs = min(a.genome, a.cpu_sample_genome)                     # a table much larger than the host's last-level cache, as the full config's is
     g = eng.synth_genome(gs, seed=77)
     r = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=3)
     rh = r.download()
@@ -488,19 +566,41 @@ def cpu_baseline(eng, a, k, L):
             t1.gcp()
         return time.perf_counter() - t0
 
+    # the sweep starts where round 4's sweeps peaked (a shared CAS table stops scaling long before 256 threads) and stays within ~40 s
     sweep = {}
-    for th in sorted({t for t in (8, 16, 32, 64, 128, 256, cores) if t <= cores}):
+    for th in [t for t in (32, 64, 16, 128, 8) if t <= cores] or [cores]:
         sweep[th] = run(th)
         if sum(sweep.values()) > 40.0:                      # bounded: the default run stays within minutes
             break
     best = min(sweep, key=sweep.get)
+    table_mb = 12.0 * expected_distinct(n * (L - k + 1), gs, k, a.err_ppm) / 0.7 / 1e6
     return {"value": round(inst / sweep[best], 1), "unit": "k-mers/s", "cores": best, "kind": "port",
-            "sample": "%d reads x %d bp from a %d bp genome%s, k=%d; best of a thread sweep: %.2f s at %d threads" % (
-                n, L, gs, {"comp": " + that genome as assembly", "comp-rr": " + a second library of the same size"}.get(wl, ""), k, sweep[best], best),
-            "thread_sweep_kmers_per_s": {str(t): round(inst / s, 1) for t, s in sweep.items()},
-            "host_cores": cores,
+            "sample": "%d reads x %d bp from a %d bp genome%s, k=%d; best of a thread sweep: %.2f s at %d threads; the sample's table (~%.0f MB of keys + counts) against %s of last-level cache" % (
+                n, L, gs, {"comp": " + that genome as assembly", "comp-rr": " + a second library of the same size"}.get(wl, ""), k, sweep[best], best, table_mb, host_llc()),
+            "thread_sweep_kmers_per_s": {str(t): round(inst / s, 1) for t, s in sorted(sweep.items())},
+            "host_cores": cores, "host_last_level_cache": host_llc(),
+            "note": "a port of the reference's algorithm (oracle/koracle.c), not the reference binary (unbuildable here: DESIGN.md section 5).  The sample is sized so that its table is "
+                    "much larger than the last-level cache, like the full config's; a smaller sample would flatter the CPU.",
             "reference_scaled": {"value": REF_KMERS_PER_CORE * cores, "unit": "k-mers/s",
                                  "source": "SURVEY.md section 6: the reference's count phase ran at ~3 M k-mers/s/core (8-core Xeon, hand-built reference binary); x %d host cores, assuming it scales linearly (it does not: an upper bound)" % cores}}
+
+
+def host_llc():
+    """The host's last-level cache as the kernel reports it ("32768K x 16 instances" style), or "unknown"."""
+    try:
+        base = "/sys/devices/system/cpu/cpu0/cache"
+        best = None
+        for idx in sorted(os.listdir(base)):
+            lv = os.path.join(base, idx, "level")
+            if os.path.exists(lv):
+                level = int(open(lv).read())
+                if best is None or level >= best[0]:
+                    best = (level, open(os.path.join(base, idx, "size")).read().strip(), open(os.path.join(base, idx, "shared_cpu_list")).read().strip())
+        if best is None:
+            return "unknown"
+        return "L%d %s per instance (shared by CPUs %s)" % best
+    except Exception:
+        return "unknown"
 
 
 def write_fastq(f, bases, first_read, mate, read_len):
@@ -525,32 +625,87 @@ def write_fastq(f, bases, first_read, mate, read_len):
     f.write(rec.data)
 
 
+def parse_stats(text):
+    """The 13 counters of a `kat comp` .stats file (CompCounters::printCounts, lib/src/comp_counters.cc:144-206) in the order of the
+    device's counter block: totals 1-3, distinct 1-3, only-total 1-2, only-distinct 1-2, shared total 1-2, shared distinct."""
+    sec = {}
+    cur = None
+    for ln in text.splitlines():
+        if ln and not ln.startswith(" "):
+            cur = ln.strip().rstrip(":").strip()
+            sec[cur] = {}
+        elif cur is not None:
+            m = re.match(r"\s*-\s*(.+?):\s*(\d+)\s*$", ln)
+            if m:
+                sec[cur][m.group(1)] = int(m.group(2))
+    g = lambda s_, key: sec.get(s_, {}).get(key, 0)
+    return [g("Total K-mers in", "Hash 1"), g("Total K-mers in", "Hash 2"), g("Total K-mers in", "Hash 3"),
+            g("Distinct K-mers in", "Hash 1"), g("Distinct K-mers in", "Hash 2"), g("Distinct K-mers in", "Hash 3"),
+            g("Total K-mers only found in", "Hash 1"), g("Total K-mers only found in", "Hash 2"),
+            g("Distinct K-mers only found in", "Hash 1"), g("Distinct K-mers only found in", "Hash 2"),
+            g("Shared K-mers", "Total shared found in hash 1"), g("Shared K-mers", "Total shared found in hash 2"), g("Shared K-mers", "Distinct shared K-mers")]
+
+
+def parse_mx(path):
+    """The body of a .mx file (SparseMatrix::printMatrix, lib/include/kat/sparse_matrix.hpp:269-277) as a uint64 matrix."""
+    rows = []
+    with open(path, "rb") as f:
+        for ln in f:
+            if ln.startswith(b"#") or not ln.strip():
+                continue
+            rows.append(np.array(ln.split(), dtype=np.uint64))
+    return np.vstack(rows) if rows else np.zeros((0, 0), np.uint64)
+
+
+def parse_hist(path):
+    """`kat hist` output (Histogram::print, src/histogram.cc:131-144): "<count> <distinct k-mers>" per line after the # header."""
+    vals = []
+    with open(path, "rb") as f:
+        for ln in f:
+            if ln.startswith(b"#") or not ln.strip():
+                continue
+            vals.append(int(ln.split()[1]))
+    return np.array(vals, dtype=np.uint64)
+
+
 def end_to_end(eng, a, k, L):
-    """Files -> output files through the C++ host binary (kat_amd/bin/katgpu, the mirror of KAT's drivers over the C ABI) on a
-    bounded slice of the workload: the span of the reference's "Total runtime" (src/comp.cc:750; process start -> outputs
-    closed, no plots).  Inputs are written to a temp dir outside the timed span; the page cache is warm,
-    so this is parse + PCIe + count + reduce + write, not storage."""
+    """Files -> output files through the C++ host binary (kat_amd/bin/katgpu, the mirror of KAT's drivers over the C ABI): the span of
+    the reference's "Total runtime" (src/comp.cc:750; process start -> outputs closed, no plots).  At the workload's FULL size when
+    /dev/shm has the room for its files (config 4: 96 GB), else on a bounded slice (--e2e-reads); `config` says which ran.  Inputs are
+    written outside the timed span and stay in RAM, so this is parse + PCIe + count + reduce + write, not storage.
+    result_check: the files the binary wrote are parsed back and compared, number by number, with the result of counting the SAME
+    reads (same generator, same seeds) resident in HBM through the C ABI -- the path `value` times."""
+    import kat_amd
     exe = os.path.join(ROOT, "kat_amd", "bin", "katgpu")
     if not os.path.exists(exe):
         raise FileNotFoundError(exe)
     wl = a.workload
-    n = min(a.e2e_reads, a.reads) & ~1
-    gs = min(a.genome, max(10_000_000, n * 5))                               # ~30x coverage of the slice's genome
+    rec_bytes = 2 * L + 18                                                    # a FASTQ record as write_fastq writes it
+
+    def shm_room():
+        try:
+            st = os.statvfs("/dev/shm")
+            return st.f_bavail * st.f_frsize
+        except OSError:
+            return 0
+
+    def need_bytes(n_, gs_):
+        return int(n_ * rec_bytes * (2 if wl == "comp-rr" else 1) * 1.01) + (int(gs_ * 1.02) if wl == "comp" else 0) + (1 << 30)
+    n_full = a.reads & ~1
+    full = not a.e2e_slice and shm_room() > need_bytes(n_full, a.genome) + (16 << 30)
+    n = n_full if full else min(a.e2e_reads, a.reads) & ~1
+    if wl == "comp-rr":
+        n = (n // 2) & ~1                                                     # two libraries of half the reads each, as the resident leg
+    gs = a.genome if full else min(a.genome, max(10_000_000, n * 5))          # the slice: ~30x coverage of its genome
     # the inputs go where reading them back cannot depend on this process's own write-back: /dev/shm (RAM-backed by construction)
     # when it has the room, else the default temp dir (page cache; the line says which)
-    need = int(n * (2 * L + 14) * 1.02) + (gs if wl == "comp" else n * (2 * L + 14)) + (1 << 30)
-    tmp_root = None
-    try:
-        st = os.statvfs("/dev/shm")
-        if st.f_bavail * st.f_frsize > need + (8 << 30):
-            tmp_root = "/dev/shm"
-    except OSError:
-        pass
+    tmp_root = "/dev/shm" if shm_room() > need_bytes(n, gs) + (8 << 30) else None
     tmp = tempfile.mkdtemp(prefix="katgpu_e2e_", dir=tmp_root)
     t_e2e0 = time.perf_counter()
+    G_SEED, R_SEED, R2_SEED = 20260927, 1, 2                                  # the resident leg's generator seeds (measure())
     try:
-        g = eng.synth_genome(gs, seed=99)
-        files, inst, nbytes = [], 0, 0
+        g = eng.synth_genome(gs, seed=G_SEED)
+        inst, nbytes = 0, 0
 
         def library(seed, tag):                                                 # in slices of 8 M reads: the files are tens of GB
             paths = [os.path.join(tmp, "%s_R%d.fastq" % (tag, m + 1)) for m in (0, 1)]
@@ -566,14 +721,14 @@ def end_to_end(eng, a, k, L):
             for f in files:
                 f.close()
             return paths
-        lib1 = library(5, "lib1")
+        lib1 = library(R_SEED, "lib1")
         inst += n * (L - k + 1)
         second = None
+        clen = a.contig
         if wl == "comp":
-            asm = eng.synth_genome(gs, seed=99).download()
+            asm = g.download()
             second = os.path.join(tmp, "asm.fa")
             with open(second, "wb") as f:
-                clen = 1_000_000
                 for c in range((gs + clen - 1) // clen):
                     seq = asm[c * clen:(c + 1) * clen]
                     f.write(b">contig%d\n" % c)
@@ -582,8 +737,9 @@ def end_to_end(eng, a, k, L):
                     body = np.concatenate([lines, np.full((lines.shape[0], 1), ord("\n"), np.uint8)], axis=1).tobytes()
                     f.write(body.rstrip(b"\n") + b"\n")
                     inst += max(0, seq.size - k + 1)
+            del asm
         elif wl == "comp-rr":
-            second = " ".join(library(6, "lib2"))
+            second = " ".join(library(R2_SEED, "lib2"))
             inst += n * (L - k + 1)
         g.free()
         eng.sync()
@@ -591,11 +747,12 @@ def end_to_end(eng, a, k, L):
         for root, _, fs in os.walk(tmp):
             nbytes += sum(os.path.getsize(os.path.join(root, f)) for f in fs)
         hint = int(expected_distinct(n * (L - k + 1), gs, k, a.err_ppm) / 0.62) + (1 << 20)
+        hint2 = hint if wl == "comp-rr" else int(gs / 0.62) + (1 << 20)
         outp = os.path.join(tmp, "out")
         tool = {"hist": "hist", "gcp": "gcp"}.get(wl, "comp")
         cmd = [exe, tool, "-t", "16", "-m", str(k), "-H", str(hint), "-o", outp]
         if second is not None:                              # comp: -I sizes the second hash (KAT's -H / -I)
-            cmd += ["-I", str(hint if wl == "comp-rr" else int(gs / 0.62) + (1 << 20))]
+            cmd += ["-I", str(hint2)]
         if second is not None:                              # comp takes one (quoted) argument per input group, hist / gcp a list of files
             cmd += [" ".join(lib1), second]
         else:
@@ -608,13 +765,14 @@ def end_to_end(eng, a, k, L):
             raise RuntimeError("katgpu %s exited %d: %s" % (tool, pr.returncode, (pr.stderr or pr.stdout)[-400:]))
         outs = [f for f in os.listdir(tmp) if f.startswith("out")]
         # where the span went: the binary's own timing lines (KATGPU_TIMING=1): per phase of the run and per input file
-        phases, per_file = {}, []
+        phases, per_file, bad_lines = {}, [], 0
         for line in pr.stderr.splitlines():
             if not line.startswith("katgpu_timing "):
                 continue
             try:
                 rec = json.loads(line[len("katgpu_timing "):])
             except ValueError:
+                bad_lines += 1                              # (flagged below: a file missing from the breakdown overstates count_phases_outside_files_ms)
                 continue
             if "phase" in rec:
                 key = rec["phase"] if rec["phase"] != "count" else "count_input_%d" % (1 + sum(1 for q in phases if q.startswith("count_input_")))
@@ -628,14 +786,57 @@ def end_to_end(eng, a, k, L):
         breakdown = {"process_wall_ms": round(dt * 1e3, 1), "phases": phases, "unaccounted_ms": round(dt * 1e3 - accounted, 1),
                      # what the two count phases spent outside the files' passes: waiting for the table / arena allocations, the last counts
                      "count_phases_outside_files_ms": round(phases.get("count_input_1_ms", 0.0) + phases.get("count_input_2_ms", 0.0) - in_files, 1),
-                     "files": per_file,
+                     "files": per_file, "unparsable_timing_lines": bad_lines,
                      "reading": "per file: setup = open + map + device / pinned buffers; wall = the file's whole pass; reader_wait = the main thread waiting for file bytes to reach the device (reader threads: "
                                 "pread into pinned memory, then their own H2D copy; pread / h2d per thread say which of the two it was); scan = the record scan "
                                 "on the device; counter_wait = waiting for the counting worker; counting = what the worker spent (hidden under the rest unless "
                                 "counter_wait says otherwise)"}
         if os.environ.get("KATGPU_TRACE"):                 # diagnostic: the library's own time line of the run
             breakdown["trace"] = [l for l in pr.stderr.splitlines() if l.startswith("[katgpu")][:80]
-        return {"value": round(inst / dt, 1), "breakdown": breakdown, "inputs_in": tmp_root or tempfile.gettempdir(), "unit": "k-mers/s", "seconds": round(dt, 3), "input_bytes": nbytes,
+        # ---- result_check: what the binary wrote against the same reads counted resident through the C ABI ----
+        check, detail = None, None
+        try:
+            g = eng.synth_genome(gs, seed=G_SEED)
+            r1 = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=R_SEED)
+            t1 = eng.table(k, True, size_hint=hint)
+            t1.count_bases_device(r1.ptr, r1.nbytes)
+            r1.free()
+            if wl in ("comp", "comp-rr"):
+                if wl == "comp":
+                    in2 = eng.synth_genome(gs, seed=G_SEED, contig_len=clen)
+                else:
+                    in2 = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=R2_SEED)
+                t2 = eng.table(k, True, size_hint=hint2, like=t1)
+                t2.count_bases_device(in2.ptr, in2.nbytes)
+                in2.free()
+                mx, cc, sp = kat_amd.comp(t1, t2)
+                t2.free()
+                got_cc = parse_stats(open(outp + ".stats").read())
+                got_mx = parse_mx(outp + "-main.mx")
+                ok_cc = [int(x) for x in cc] == got_cc
+                ok_mx = got_mx.shape == mx.shape and bool(np.array_equal(got_mx, mx))
+                check = ok_cc and ok_mx and int(cc[0]) + int(cc[1]) == inst
+                detail = "out.stats: 13 counters %s the resident path's (hash1 total %d, distinct %d; hash2 total %d, distinct %d; shared distinct %d); out-main.mx: %dx%d body %s (sum %d); totals %s the %d instances written" % (
+                    "==" if ok_cc else "!=", got_cc[0], got_cc[3], got_cc[1], got_cc[4], got_cc[12], got_mx.shape[0], got_mx.shape[1] if got_mx.ndim == 2 else 0,
+                    "==" if ok_mx else "!=", int(got_mx.sum()), "==" if int(cc[0]) + int(cc[1]) == inst else "!=", inst)
+            elif wl == "hist":
+                want = t1.hist()
+                got = parse_hist(outp)
+                check = got.shape == want.shape and bool(np.array_equal(got, want))
+                detail = "hist file: %d bins %s the resident path's (distinct %d)" % (got.size, "==" if check else "!=", int(got.sum()))
+            else:
+                want = t1.gcp()
+                got = parse_mx(outp + ".mx")
+                check = got.shape == want.shape and bool(np.array_equal(got, want))
+                detail = "gcp matrix: %s body %s the resident path's (sum %d)" % ("x".join(map(str, got.shape)), "==" if check else "!=", int(got.sum()))
+            t1.free()
+            g.free()
+            eng.sync()
+        except Exception as ex:
+            check, detail = False, "check failed to run: %s: %s" % (type(ex).__name__, ex)
+        return {"value": round(inst / dt, 1), "config": ("the workload at FULL size" if full else "a slice of the workload") + ": %d reads x %d bp, %d bp genome" % (n * (2 if wl == "comp-rr" else 1), L, gs),
+                "full_size": bool(full), "result_check": check, "result_check_detail": detail,
+                "breakdown": breakdown, "inputs_in": tmp_root or tempfile.gettempdir(), "unit": "k-mers/s", "seconds": round(dt, 3), "input_bytes": nbytes,
                 "input_GB_per_s": round(nbytes / dt / 1e9, 2), "kmer_instances": inst,
                 "span": "process start -> output files closed (src/comp.cc:750 'Total runtime'), inputs in the page cache",
                 "files_written_in_s": round(t_gen, 1),

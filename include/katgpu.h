@@ -260,9 +260,12 @@ int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, ui
  *                katgpu_exchange_merge(comm, table) for every table; reduce (katgpu_hist / _gcp / _comp);
  *                katgpu_allreduce_u64(comm, result, n): every rank now holds the whole run's result.
  * Transport: RCCL (librccl is dlopen'ed when the first id is made; grouped ncclSend / ncclRecv on a stream of its own, chunk c on
- * the wire while chunk c-1 is merged) or, when RCCL cannot be had -- or ranks share a device, or KATGPU_COMM_TRANSPORT=shm -- files
- * in /dev/shm (one node).  katgpu_comm_transport() says which; _note() why it is not RCCL.  world == 1 is legal and runs the whole
- * protocol on the rank's own records. */
+ * the wire while chunk c-1 is merged) or, when ranks SHARE a device (RCCL refuses them) or KATGPU_COMM_TRANSPORT=shm asks for it,
+ * files in /dev/shm (one node).  Ranks on distinct devices that cannot have RCCL do NOT fall back on /dev/shm: katgpu_comm_init
+ * fails and says why (KATGPU_COMM_ALLOW_SHM=1 allows the fall-back).  katgpu_comm_transport() says which transport runs; _note()
+ * why it is not RCCL.  No wait inside a collective is bounded by a wall clock (ranks may arrive minutes apart); a peer that died
+ * is told from its heartbeat (KATGPU_COMM_TIMEOUT_S seconds of silence, default 60), a peer that failed from the abort flag it
+ * raised.  world == 1 is legal and runs the whole protocol on the rank's own records. */
 #define KATGPU_COMM_ID_BYTES 256
 typedef struct katgpu_comm katgpu_comm;
 int  katgpu_comm_unique_id(void* id_out /* KATGPU_COMM_ID_BYTES */);
@@ -272,6 +275,7 @@ int  katgpu_comm_rank(const katgpu_comm* comm);
 int  katgpu_comm_world(const katgpu_comm* comm);
 const char* katgpu_comm_transport(const katgpu_comm* comm);        /* "rccl" | "shm" */
 const char* katgpu_comm_transport_note(const katgpu_comm* comm);   /* "" or why RCCL is not in use */
+int  katgpu_comm_distinct_devices(const katgpu_comm* comm);        /* how many different devices the ranks run on (1: they share one) */
 int  katgpu_comm_barrier(katgpu_comm* comm);
 /* Route every record of `t` to its owner rank, in place: afterwards the table holds exactly the k-mers this rank owns, counts summed
  * over all ranks; it keeps its storage and its region grid.  Collective: every rank calls it, with tables of one k / strand mode.

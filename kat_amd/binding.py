@@ -35,7 +35,7 @@ EXPORTS = (
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
     "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_place_keys", "katgpu_reserve", "katgpu_device_count",
     "katgpu_count_files_sharded", "katgpu_table_slot_bytes", "katgpu_comm_unique_id", "katgpu_comm_init", "katgpu_comm_free", "katgpu_comm_rank", "katgpu_comm_world", "katgpu_comm_transport",
-    "katgpu_comm_transport_note", "katgpu_comm_barrier", "katgpu_exchange_merge", "katgpu_allreduce_u64", "katgpu_comm_stats",
+    "katgpu_comm_transport_note", "katgpu_comm_distinct_devices", "katgpu_comm_barrier", "katgpu_exchange_merge", "katgpu_allreduce_u64", "katgpu_comm_stats",
 )
 
 
@@ -641,6 +641,7 @@ class Comm:
         L.katgpu_comm_transport.restype = C.c_char_p
         L.katgpu_comm_transport_note.argtypes = [C.c_void_p]
         L.katgpu_comm_transport_note.restype = C.c_char_p
+        L.katgpu_comm_distinct_devices.argtypes = [C.c_void_p]
         L.katgpu_comm_barrier.argtypes = [C.c_void_p]
         L.katgpu_exchange_merge.argtypes = [C.c_void_p, C.c_void_p]
         L.katgpu_allreduce_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -657,6 +658,11 @@ class Comm:
     @property
     def transport_note(self):
         return self.engine.L.katgpu_comm_transport_note(self.h).decode()
+
+    @property
+    def distinct_devices(self):
+        """How many different devices the ranks run on (1: they all share one -- the /dev/shm transport's home ground)."""
+        return int(self.engine.L.katgpu_comm_distinct_devices(self.h))
 
     def barrier(self):
         self.engine._chk(self.engine.L.katgpu_comm_barrier(self.h))

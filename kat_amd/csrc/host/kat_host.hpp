@@ -26,7 +26,15 @@ namespace kat {
 inline double timing_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline void timing_line(const char* phase, double ms, const char* what = "") {
     static const bool on = getenv("KATGPU_TIMING") != nullptr;
-    if (on) fprintf(stderr, "katgpu_timing {\"phase\": \"%s\", \"what\": \"%s\", \"ms\": %.1f}\n", phase, what, ms);
+    if (!on) return;
+    std::string w;                                        // (`what` may carry a path: quotes, backslashes and control characters escaped)
+    for (const char* s = what; s && *s; ++s) {
+        const unsigned char ch = (unsigned char)*s;
+        if (ch == '"' || ch == '\\') { w += '\\'; w += (char)ch; }
+        else if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); w += b; }
+        else w += (char)ch;
+    }
+    fprintf(stderr, "katgpu_timing {\"phase\": \"%s\", \"what\": \"%s\", \"ms\": %.1f}\n", phase, w.c_str(), ms);
 }
 
 const uint16_t DEFAULT_MER_LEN = 27;            // lib/include/kat/jellyfish_helper.hpp:76

@@ -17,12 +17,21 @@
 // chunk on a stream of its own -- every peer at once, which is the shape xGMI's point-to-point links want -- and ncclAllGather /
 // ncclAllReduce for the small things.  SHM: ranks of one node stage their records through files in /dev/shm; slow, exact, needs
 // nothing but a shared file system -- it is what carries ranks that SHARE a GPU (the test suite on a one-GPU box: RCCL refuses two
-// ranks on one device) and what a run falls back to when RCCL cannot be loaded or refuses to initialise (KATGPU_COMM_TRANSPORT=
-// rccl | shm | auto).  The protocol above the transport is the same code.
+// ranks on one device).  Ranks on DISTINCT devices never take it by accident: a communicator that cannot have RCCL there fails
+// (katgpu_comm_init says why) unless the caller asked for the staging transport by name (KATGPU_COMM_TRANSPORT=shm) or allowed the
+// fall-back (KATGPU_COMM_ALLOW_SHM=1) -- a /dev/shm number must not pass for an xGMI one.  KATGPU_COMM_TRANSPORT = rccl | shm | auto.
+// The protocol above the transport is the same code.
+//
+// Liveness.  Ranks may reach a collective minutes apart (`kat --gpus N` deals whole .gz files rank by rank), so no wait is bounded by
+// a wall clock: every rank's communicator runs a heartbeat (a counter in the shared block, advanced every 50 ms by a thread of its
+// own), and a wait gives up only when a peer has raised the abort flag or when a peer's heartbeat has stood still for
+// KATGPU_COMM_TIMEOUT_S (default 60 s): a peer that died, not one that is busy.  KATGPU_COMM_MAX_WAIT_S (default: none) bounds a
+// single wait by the clock for harnesses that prefer an error to a wedged link (bench.py sets it).
 #include "kg_host.hpp"
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -85,10 +94,16 @@ struct ShmHeader {
     std::atomic<uint32_t> attached;
     uint32_t world;
     std::atomic<uint32_t> aborted;   // a rank that fails inside a collective raises it: its peers leave their barriers with an error instead of waiting for ever
+    uint32_t pad_[11];               // (the heartbeats start on a cache line of their own)
 };
-// how long a rank waits for its peers at a barrier or for a transfer to land before it gives up (a peer that died, a wedged link): the
-// run then ends with an error through katgpu_last_error instead of hanging until someone kills it
-static const double g_comm_timeout_ms = 1e3 * (getenv("KATGPU_COMM_TIMEOUT_S") ? std::max(1.0, atof(getenv("KATGPU_COMM_TIMEOUT_S"))) : 600.0);
+struct RankBeat { std::atomic<uint64_t> beat; std::atomic<uint32_t> gone; uint32_t pad_[13]; };   // one cache line per rank: its heartbeat; gone: it has left (katgpu_comm_free)
+static_assert(sizeof(ShmHeader) == 64 && sizeof(RankBeat) == 64, "shared block layout");
+// A wait for peers -- at a barrier, for a transfer -- ends with an error (through katgpu_last_error, not a hang) when a peer is DEAD:
+// its heartbeat has not moved for this long.  Not a bound on how long a healthy peer may take to get there.
+static const double g_comm_timeout_ms = 1e3 * (getenv("KATGPU_COMM_TIMEOUT_S") ? std::max(0.5, atof(getenv("KATGPU_COMM_TIMEOUT_S"))) : 60.0);
+// optional: no single wait longer than this, whatever the heartbeats say (0: unbounded)
+static const double g_comm_max_wait_ms = 1e3 * (getenv("KATGPU_COMM_MAX_WAIT_S") ? std::max(0.0, atof(getenv("KATGPU_COMM_MAX_WAIT_S"))) : 0.0);
+constexpr int BEAT_PERIOD_MS = 50;
 
 struct Msg { int peer; void* dev; size_t bytes; };          // one side of a point-to-point transfer (device memory)
 
@@ -102,7 +117,9 @@ struct katgpu_comm {
     hipStream_t stream = nullptr;             // transport stream: chunk c travels while chunk c-1 is merged on the context's stream
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::string token;
-    ShmHeader* hdr = nullptr; uint8_t* boxes = nullptr; size_t shm_bytes = 0;
+    ShmHeader* hdr = nullptr; RankBeat* beats = nullptr; uint8_t* boxes = nullptr; size_t shm_bytes = 0;
+    std::thread beat_thread; std::atomic<bool> beat_stop{false};
+    int distinct_devices = 1;                 // how many different devices the ranks run on (1: they all share one)
     uint64_t seq = 0;                         // names the shm files of successive transfers
     double ms_exchange = 0, ms_merge = 0, ms_extract = 0, ms_allreduce = 0;
     uint64_t bytes_sent = 0, merge_launches = 0;
@@ -131,7 +148,34 @@ std::string shm_name(const std::string& token, const char* what, uint64_t seq = 
     return buf;
 }
 
-// every rank of the communicator: wait until all have arrived -- or until a peer has failed (ShmHeader::aborted) or the time-out passed
+// What a waiting rank knows of its peers' health: each peer's last heartbeat value and when it was last seen to move.
+struct Liveness {
+    katgpu_comm* m; std::vector<uint64_t> last; std::vector<double> moved; double t0; char why[256];
+    explicit Liveness(katgpu_comm* m_) : m(m_), last((size_t)m_->world, 0), moved((size_t)m_->world, now_ms()), t0(now_ms()) {
+        why[0] = 0;
+        for (int r = 0; r < m->world; ++r) last[r] = m->beats[r].beat.load(std::memory_order_relaxed);
+    }
+    // false: this wait should end with an error (`why`): a peer failed, left, or its heartbeat stands still; or the optional wall-clock
+    // bound.  The caller looks once more at what it waits for before it gives up (a peer may leave right after it did its part).
+    bool ok() {
+        if (m->hdr->aborted.load(std::memory_order_acquire)) { snprintf(why, sizeof why, "a peer rank failed (rank %d gives up)", m->rank); return false; }
+        const double now = now_ms();
+        for (int r = 0; r < m->world; ++r) {
+            if (r == m->rank) continue;
+            const uint64_t b = m->beats[r].beat.load(std::memory_order_relaxed);
+            if (b != last[r]) { last[r] = b; moved[r] = now; continue; }
+            if (m->beats[r].gone.load(std::memory_order_acquire)) { snprintf(why, sizeof why, "rank %d has left the communicator while rank %d waits for it", r, m->rank); return false; }
+            if (now - moved[r] > g_comm_timeout_ms) {
+                snprintf(why, sizeof why, "no sign of life from rank %d for %.0f s (rank %d gives up; KATGPU_COMM_TIMEOUT_S)", r, (now - moved[r]) / 1e3, m->rank);
+                return false;
+            }
+        }
+        if (g_comm_max_wait_ms > 0 && now - t0 > g_comm_max_wait_ms) { snprintf(why, sizeof why, "rank %d waited %.0f s (KATGPU_COMM_MAX_WAIT_S)", m->rank, (now - t0) / 1e3); return false; }
+        return true;
+    }
+};
+
+// every rank of the communicator: wait until all have arrived -- or until a peer has failed (ShmHeader::aborted) or died (its heartbeat)
 int shm_barrier(katgpu_comm* m) {
     if (m->world == 1) return KATGPU_OK;
     if (m->hdr->aborted.load(std::memory_order_acquire)) return comm_fail(m, KATGPU_ERR_DEVICE, "a peer rank failed (rank %d leaves the barrier)", m->rank);
@@ -140,11 +184,13 @@ int shm_barrier(katgpu_comm* m) {
         m->hdr->arrived.store(0, std::memory_order_relaxed);
         m->hdr->generation.store(gen + 1, std::memory_order_release);
     } else {
-        const double t0 = now_ms();
+        Liveness live(m);
         for (uint32_t spins = 0; m->hdr->generation.load(std::memory_order_acquire) == gen; ++spins) {
             if (spins <= 1000) continue;
-            if (m->hdr->aborted.load(std::memory_order_acquire)) return comm_fail(m, KATGPU_ERR_DEVICE, "a peer rank failed (rank %d leaves the barrier)", m->rank);
-            if (now_ms() - t0 > g_comm_timeout_ms) return comm_fail(m, KATGPU_ERR_DEVICE, "rank %d waited %.0f s at a barrier for its peers (KATGPU_COMM_TIMEOUT_S)", m->rank, g_comm_timeout_ms / 1e3);
+            if ((spins & 255) == 0 && !live.ok()) {
+                if (m->hdr->generation.load(std::memory_order_acquire) != gen) break;          // everyone did arrive (and one has left since)
+                return comm_fail(m, KATGPU_ERR_DEVICE, "barrier: %s", live.why);
+            }
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     }
@@ -153,14 +199,17 @@ int shm_barrier(katgpu_comm* m) {
 // wait for the transport stream (or an event on it) the same way: a collective whose peer never posts its side would sit in
 // hipStreamSynchronize for ever
 int comm_wait(katgpu_comm* m, hipEvent_t ev /* or null: the whole stream */, const char* what) {
-    const double t0 = now_ms();
+    Liveness live(m);
+    auto query = [&]() { return ev ? hipEventQuery(ev) : hipStreamQuery(m->stream); };
     for (uint32_t spins = 0;; ++spins) {
-        const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(m->stream);
+        const hipError_t e = query();
         if (e == hipSuccess) return KATGPU_OK;
         if (e != hipErrorNotReady) return comm_fail(m, KATGPU_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
         if (spins < 2000) continue;
-        if (m->hdr && m->hdr->aborted.load(std::memory_order_acquire)) return comm_fail(m, KATGPU_ERR_DEVICE, "%s: a peer rank failed", what);
-        if (now_ms() - t0 > g_comm_timeout_ms) return comm_fail(m, KATGPU_ERR_DEVICE, "%s: rank %d waited %.0f s for the transfer (KATGPU_COMM_TIMEOUT_S)", what, m->rank, g_comm_timeout_ms / 1e3);
+        if ((spins & 255) == 0 && m->hdr && !live.ok()) {
+            if (query() == hipSuccess) return KATGPU_OK;
+            return comm_fail(m, KATGPU_ERR_DEVICE, "%s: %s", what, live.why);
+        }
         std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
 }
@@ -310,7 +359,9 @@ extern "C" void katgpu_comm_free(katgpu_comm* m) {
     for (auto& e : m->ev) if (e) hipEventDestroy(e);
     if (m->stream) hipStreamDestroy(m->stream);
     if (m->host_stage) hipHostFree(m->host_stage);
+    if (m->beat_thread.joinable()) { m->beat_stop.store(true); m->beat_thread.join(); }
     if (m->hdr) {
+        if (m->beats) m->beats[m->rank].gone.store(1, std::memory_order_release);          // a peer still waiting for this rank learns it at once, not from a silent heartbeat
         const bool last = m->hdr->attached.fetch_sub(1) == 1;
         munmap((void*)m->hdr, m->shm_bytes);
         if (last || m->rank == 0) ::unlink(shm_name(m->token, "hdr").c_str());
@@ -330,7 +381,7 @@ extern "C" int katgpu_comm_init(katgpu_ctx* c, int rank, int world, const void* 
     id.token[sizeof id.token - 1] = 0;
     m->token = id.token;
     // the rendezvous block: every rank maps it (rank order does not matter: O_CREAT, then ftruncate to the same size)
-    m->shm_bytes = sizeof(ShmHeader) + (size_t)world * MAILBOX;
+    m->shm_bytes = sizeof(ShmHeader) + (size_t)world * sizeof(RankBeat) + (size_t)world * MAILBOX;
     const std::string hname = shm_name(m->token, "hdr");
     const int fd = ::open(hname.c_str(), O_CREAT | O_RDWR, 0600);
     if (fd < 0 || ftruncate(fd, (off_t)m->shm_bytes) != 0) { if (fd >= 0) ::close(fd); delete m; return fail(c, KATGPU_ERR_IO, "cannot create %s", hname.c_str()); }
@@ -338,7 +389,16 @@ extern "C" int katgpu_comm_init(katgpu_ctx* c, int rank, int world, const void* 
     ::close(fd);
     if (p == MAP_FAILED) { delete m; return fail(c, KATGPU_ERR_IO, "cannot map %s", hname.c_str()); }
     m->hdr = (ShmHeader*)p;                       // (a fresh file is zero-filled: counters start at 0)
-    m->boxes = (uint8_t*)p + sizeof(ShmHeader);
+    m->beats = (RankBeat*)((uint8_t*)p + sizeof(ShmHeader));
+    m->boxes = (uint8_t*)p + sizeof(ShmHeader) + (size_t)world * sizeof(RankBeat);
+    // this rank's heartbeat: alive as long as the process is, whatever the main thread is busy with (counting a .gz for minutes)
+    m->beats[rank].beat.store(1, std::memory_order_relaxed);
+    m->beat_thread = std::thread([m, rank]() {
+        while (!m->beat_stop.load(std::memory_order_relaxed)) {
+            m->beats[rank].beat.fetch_add(1, std::memory_order_relaxed);
+            std::this_thread::sleep_for(std::chrono::milliseconds(BEAT_PERIOD_MS));
+        }
+    });
     m->hdr->attached.fetch_add(1);
     // wait for everyone (bounded: a rank that never shows up must not hang the others for ever)
     const double t0 = wall_ms();
@@ -355,22 +415,44 @@ extern "C" int katgpu_comm_init(katgpu_ctx* c, int rank, int world, const void* 
         for (auto& ev : m->ev) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e != hipSuccess) { katgpu_comm_free(m); return fail(c, KATGPU_ERR_DEVICE, "katgpu_comm_init: %s", hipGetErrorString(e)); }
     }
+    // which devices the ranks run on: ranks that share one cannot have RCCL (it refuses two ranks on a device) and stage through /dev/shm;
+    // ranks on devices of their own must not end up there by accident
+    int rc = KATGPU_OK;
+    {
+        char mine_id[64] = {0};
+        if (hipDeviceGetPCIBusId(mine_id, (int)sizeof mine_id - 1, c->device) != hipSuccess) { (void)hipGetLastError(); snprintf(mine_id, sizeof mine_id, "device-%d", c->device); }
+        std::vector<char> ids((size_t)world * sizeof mine_id);
+        rc = host_allgather(m, mine_id, sizeof mine_id, ids.data());
+        if (rc) { katgpu_comm_free(m); return rc; }
+        std::vector<std::string> uniq;
+        for (int r = 0; r < world; ++r) { std::string d(ids.data() + (size_t)r * sizeof mine_id); if (std::find(uniq.begin(), uniq.end(), d) == uniq.end()) uniq.push_back(d); }
+        m->distinct_devices = (int)uniq.size();
+    }
     // transport: RCCL when every rank can have it
     const char* tr = getenv("KATGPU_COMM_TRANSPORT");
-    const bool want_rccl = !(tr && !strcmp(tr, "shm")) && id.has_rccl && rccl().ok;
+    const bool asked_shm = tr && !strcmp(tr, "shm");
+    const bool want_rccl = !asked_shm && id.has_rccl && rccl().ok;
     uint32_t mine = 0;
     if (want_rccl) {
         ncclResult_t r = rccl().CommInitRank(&m->nccl, world, id.nccl, rank);
         if (r == ncclSuccess) mine = 1;
         else { m->nccl = nullptr; m->transport_note = std::string("RCCL refused to initialise (") + rccl().GetErrorString(r) + ")"; (void)hipGetLastError(); }
-    } else m->transport_note = tr && !strcmp(tr, "shm") ? "KATGPU_COMM_TRANSPORT=shm" : (id.has_rccl ? "librccl could not be loaded here" : "no RCCL id (librccl missing where the id was made)");
+    } else m->transport_note = asked_shm ? "KATGPU_COMM_TRANSPORT=shm" : (id.has_rccl ? "librccl could not be loaded here" : "no RCCL id (librccl missing where the id was made)");
     std::vector<uint32_t> all((size_t)world);
-    int rc = host_allgather(m, &mine, sizeof mine, all.data());
+    rc = host_allgather(m, &mine, sizeof mine, all.data());
     if (rc) { katgpu_comm_free(m); return rc; }
     m->use_rccl = true;
     for (uint32_t v : all) m->use_rccl = m->use_rccl && v;
     if (!m->use_rccl && m->nccl) { rccl().CommDestroy(m->nccl); m->nccl = nullptr; if (m->transport_note.empty()) m->transport_note = "a peer could not initialise RCCL"; }
     if (tr && !strcmp(tr, "rccl") && !m->use_rccl) { std::string why = m->transport_note; katgpu_comm_free(m); return fail(c, KATGPU_ERR_DEVICE, "KATGPU_COMM_TRANSPORT=rccl: %s", why.c_str()); }
+    // no silent fall-back between devices: /dev/shm staging is for ranks that share a device (or for whoever asked for it by name)
+    if (!m->use_rccl && world > 1 && m->distinct_devices > 1 && !asked_shm && !getenv("KATGPU_COMM_ALLOW_SHM")) {
+        std::string why = m->transport_note;
+        const int nd = m->distinct_devices;
+        katgpu_comm_free(m);
+        return fail(c, KATGPU_ERR_DEVICE, "katgpu_comm_init: %d ranks on %d devices, and RCCL is not to be had (%s): refusing to stage the exchange through /dev/shm "
+                    "(KATGPU_COMM_ALLOW_SHM=1 or KATGPU_COMM_TRANSPORT=shm to take it knowingly)", world, nd, why.c_str());
+    }
     if (g_trace) fprintf(stderr, "[katgpu] comm: rank %d of %d, transport %s%s%s\n", rank, world, m->use_rccl ? "RCCL" : "SHM (staged through /dev/shm)", m->transport_note.empty() ? "" : ": ", m->transport_note.c_str());
     *out = m;
     return KATGPU_OK;
@@ -380,6 +462,7 @@ extern "C" int katgpu_comm_rank(const katgpu_comm* m) { return m ? m->rank : -1;
 extern "C" int katgpu_comm_world(const katgpu_comm* m) { return m ? m->world : 0; }
 extern "C" const char* katgpu_comm_transport(const katgpu_comm* m) { return !m ? "" : m->use_rccl ? "rccl" : "shm"; }
 extern "C" const char* katgpu_comm_transport_note(const katgpu_comm* m) { return m ? m->transport_note.c_str() : ""; }
+extern "C" int katgpu_comm_distinct_devices(const katgpu_comm* m) { return m ? m->distinct_devices : 0; }
 
 extern "C" int katgpu_comm_barrier(katgpu_comm* m) {
     if (!m) return KATGPU_ERR_INVALID_ARG;

@@ -56,6 +56,7 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
     scan_cache_release(c);
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
+    if (c->reserved_p) hipFree(c->reserved_p);
     if (c->arena) hipFree(c->arena);
     for (auto e : c->event_pool) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
@@ -75,18 +76,25 @@ extern "C" void katgpu_shutdown(katgpu_ctx* c) {
 // its first input's last byte and its own first.  A hint: a table of another size simply does not find it (and a trim gives it back).
 extern "C" int katgpu_reserve(katgpu_ctx* c, uint32_t k, uint64_t size_hint) {
     if (!c || k < 1 || k > KATGPU_MAX_K) return KATGPU_ERR_INVALID_ARG;
-    if (c->reserve_thread.joinable()) c->reserve_thread.join();
     const uint64_t cap = std::max<uint64_t>(size_hint, 1024);
     // packed 8-byte slots are what every one-word table of size gets (kg_table.hip); a grid's rounding adds at most four slots per region
     const size_t bytes = (size_t)((cap + ((uint64_t)4 << 20)) * 8);
     if (k > 32 || bytes < ((size_t)1 << 30)) return KATGPU_OK;                   // (wide tables are three arrays; small ones cost nothing to allocate)
-    c->reserve_bytes.store(bytes);
+    // ONE reservation at a time, kept apart from the pool: it is for a table made "like" another (katgpu_table_create_like: `kat comp`'s
+    // second input), so the table being counted now -- often of the very same size, KAT's -H and -I share a default -- cannot walk
+    // off with it; a second call while one is pending or parked is a no-op (a third input allocates when its turn comes).
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        if (c->reserved_p || c->reserve_bytes.load()) return KATGPU_OK;
+        c->reserve_bytes.store(bytes);
+    }
+    if (c->reserve_thread.joinable()) c->reserve_thread.join();
     c->reserve_thread = std::thread([c, bytes]() {
         hipSetDevice(c->device);
         void* p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); c->reserve_bytes.store(0); return; }
         std::lock_guard<std::mutex> lk(c->pool_mu);
-        c->pool.push_back({p, bytes});
+        c->reserved_p = p;
     });
     return KATGPU_OK;
 }
@@ -96,8 +104,8 @@ extern "C" int katgpu_release_scratch(katgpu_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     scan_cache_release(c);
-    for (auto& b : c->pool) hipFree(b.p);
-    c->pool.clear();
+    if (c->reserve_thread.joinable()) c->reserve_thread.join();
+    pool_trim(c);                                                 // (the parked blocks and a parked reservation)
     if (c->arena) { hipFree(c->arena); c->arena = nullptr; c->arena_bytes = 0; }
     for (int i = 0; i < 2; ++i) if (c->ring[i]) { hipFree(c->ring[i]); c->ring[i] = nullptr; }
     c->ring_bytes = 0;
@@ -180,14 +188,15 @@ int grid_for(katgpu_ctx* c, uint64_t items, int block, int per_cu) {
 static void pool_trim_locked(katgpu_ctx* c) {
     for (auto& b : c->pool) hipFree(b.p);
     c->pool.clear();
+    if (c->reserved_p) { hipFree(c->reserved_p); c->reserved_p = nullptr; c->reserve_bytes.store(0); }      // (memory is short: the reservation was a hint)
 }
 void pool_trim(katgpu_ctx* c) {
     std::lock_guard<std::mutex> lk(c->pool_mu);
     pool_trim_locked(c);
 }
 
-hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes) {
-    {   // a reservation in flight that could be what is asked for: wait for it (katgpu_reserve)
+hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes, bool take_reservation) {
+    if (take_reservation) {   // a reservation in flight that could be what is asked for: wait for it (katgpu_reserve)
         const size_t rb = c->reserve_bytes.load();
         if (rb >= bytes && rb <= bytes + bytes / 4 && c->reserve_thread.joinable() && std::this_thread::get_id() != c->reserve_thread.get_id()) c->reserve_thread.join();
     }
@@ -196,6 +205,14 @@ hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes) {
     size_t* got_bytes = &got;
     struct Reg { katgpu_ctx* c; void** p; size_t* b; ~Reg() { if (*p) c->block_bytes[*p] = *b; } } reg{c, p, got_bytes};
     *p = nullptr;
+    if (take_reservation && c->reserved_p) {                      // the block katgpu_reserve set aside for this table: handed out once
+        const size_t rb = c->reserve_bytes.load();
+        if (rb >= bytes && rb <= bytes + bytes / 4) {
+            *p = c->reserved_p; *got_bytes = rb;
+            c->reserved_p = nullptr; c->reserve_bytes.store(0);
+            return hipSuccess;
+        }
+    }
     int best = -1;
     for (size_t i = 0; i < c->pool.size(); ++i)
         if (c->pool[i].bytes >= bytes && c->pool[i].bytes <= bytes + bytes / 4 && (best < 0 || c->pool[i].bytes < c->pool[best].bytes)) best = (int)i;

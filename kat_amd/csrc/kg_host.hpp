@@ -60,7 +60,8 @@ struct katgpu_ctx {
     std::vector<Block> pool;
     std::mutex pool_mu;                    // (the pool is reached from the caller's thread, a table's allocation thread and the reservation thread)
     std::thread reserve_thread;            // katgpu_reserve: memory of a table to come, being allocated beside the caller's work
-    std::atomic<size_t> reserve_bytes{0};  // ... of this size (pool_alloc waits for it only when it could be what is asked for)
+    std::atomic<size_t> reserve_bytes{0};  // ... of this size (0: none pending or parked)
+    void* reserved_p = nullptr;            // ... parked here, apart from the pool (pool_mu): only a table made "like" another takes it (pool_alloc's take_reservation)
     std::unordered_map<void*, size_t> block_bytes;      // real size of every live pooled-class allocation
     // scratch arena of the partitioned counter (level-1 / level-2 buffers, histograms); kept across calls
     uint8_t* arena = nullptr;
@@ -101,9 +102,13 @@ struct katgpu_table {
     void zero_rest() const {
         const uint64_t from = zero_from;
         zero_from = ~0ULL;
-        if (from < dv.n_regions && dv.keys && ctx)
-            (void)hipMemsetAsync(dv.keys + from * dv.region_slots, 0, (size_t)(dv.n_regions - from) * dv.region_slots * sizeof(uint64_t), ctx->stream);
+        if (from < dv.n_regions && dv.keys && ctx &&
+            hipMemsetAsync(dv.keys + from * dv.region_slots, 0, (size_t)(dv.n_regions - from) * dv.region_slots * sizeof(uint64_t), ctx->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            zero_failed = true;                  // the slots past `from` still hold what the memory held: refresh_counters() fails every result read from this table
+        }
     }
+    mutable bool zero_failed = false;
     int disable_grow = 0;
     uint32_t n_ovf = 0;          // refreshed by refresh_counters()
     uint64_t distinct = 0;       // idem (slots in use + all-ones key)
@@ -146,10 +151,21 @@ inline int fail(katgpu_ctx* c, int code, const char* fmt, ...) {
 void resolve_pending(katgpu_ctx* c);
 int grid_for(katgpu_ctx* c, uint64_t items, int block, int per_cu);
 void pool_trim(katgpu_ctx* c);
-hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes);
+hipError_t pool_alloc(katgpu_ctx* c, void** p, size_t bytes, bool take_reservation = false);
 void pool_release(katgpu_ctx* c, void* p);
 void release_arena(katgpu_ctx* c);
 
+// a string inside a JSON line (the katgpu_timing lines): quotes, backslashes and control characters escaped
+inline std::string json_escaped(const char* s) {
+    std::string o;
+    for (; s && *s; ++s) {
+        const unsigned char ch = (unsigned char)*s;
+        if (ch == '"' || ch == '\\') { o += '\\'; o += (char)ch; }
+        else if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); o += b; }
+        else o += (char)ch;
+    }
+    return o;
+}
 inline double now_ms() {
     timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;

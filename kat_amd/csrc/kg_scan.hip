@@ -242,7 +242,16 @@ struct RawFeeder {
                 const double ta = now_ms();
                 uint64_t got = 0;
                 if (map) {
-                    memcpy(mine, map + f0, (size_t)(f1 - f0)); got = f1 - f0;
+                    // (a mapping of a file that SHRINKS under the run faults with SIGBUS where pread returns short: the file's size is looked at
+                    // before and after every segment, so a truncation between segments is an I/O error like on the pread path; one that lands
+                    // inside the copy of a segment still kills the process -- INTEGRATION.md section 5 says so, KATGPU_SCAN_MMAP=0 avoids it)
+                    struct stat st0;
+                    if (fstat(fd, &st0) != 0 || (uint64_t)st0.st_size < f1) { ok = false; }
+                    else {
+                        memcpy(mine, map + f0, (size_t)(f1 - f0)); got = f1 - f0;
+                        if (fstat(fd, &st0) != 0 || (uint64_t)st0.st_size < f1) ok = false;
+                    }
+                    if (!ok) got = f1 - f0;                       // (no pread retry of a file that is being cut)
                     // this reader is through with these pages: their page-table entries go now, a segment at a time and on every reader
                     // at once (the pages stay in the page cache) -- left in place, the 8 M entries of a 32 GB run are taken down by one
                     // thread when the mapping or the process ends: 0.2 s per file under the mmap lock, or 0.6 s at exit (measured)
@@ -475,7 +484,7 @@ struct RawFeeder {
         struct Report { RawFeeder* f; double *w, *s, *n, t0; ~Report() {
             if (g_timing) fprintf(stderr, "katgpu_timing {\"file\": \"%s\", \"bytes\": %llu, \"setup_ms\": %.1f, \"wall_ms\": %.1f, \"reader_wait_ms\": %.1f, \"scan_ms\": %.1f, \"counter_wait_ms\": %.1f, \"counting_ms\": %.1f, "
                                   "\"reader_threads\": %u, \"pread_ms_per_thread\": %.1f, \"h2d_ms_per_thread\": %.1f, \"segment_MiB\": %zu, \"read_by\": \"%s\"}\n",
-                                  f->path, (unsigned long long)f->size, f->setup_ms, now_ms() - t0, *w, *s, *n, f->worker_ms, (unsigned)f->n_readers,
+                                  json_escaped(f->path).c_str(), (unsigned long long)f->size, f->setup_ms, now_ms() - t0, *w, *s, *n, f->worker_ms, (unsigned)f->n_readers,
                                   f->us_pread.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->us_h2d.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->segment >> 20,
                                   f->map ? "memcpy out of a mapping (tmpfs)" : "pread");
             if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] device scan of %s: %.1f GB in %.0f ms (%.1f GB/s): waiting for readers + H2D %.0f ms, scan %.0f ms, waiting for the counter %.0f ms (it counted for %.0f ms); %u reader threads, %zu MiB segments, %zu MiB accumulated per count\n",

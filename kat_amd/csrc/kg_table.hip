@@ -58,7 +58,7 @@ int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevT
     const double t0 = now_ms();
     const bool wide = k > 32;                                  // two key words per slot (kg_device.hpp "wide keys"), one block
     const size_t key_bytes = cap * sizeof(uint64_t) * (wide ? 2 : 1);
-    HIPCHK(c, pool_alloc(c, (void**)&d.keys, key_bytes));
+    HIPCHK(c, pool_alloc(c, (void**)&d.keys, key_bytes, /* take_reservation: a table made "like" another -- kat comp's later inputs */ like_p1 != 0 || like_p2 != 0));
     if (wide) d.keys_b = d.keys + cap;
     if (g_trace) fprintf(stderr, "[katgpu] alloc %s %.1f GB: %.1f ms\n", d.cbits ? "packed slots" : "keys", cap * 8 / 1e9, now_ms() - t0);
     hipError_t e = d.cbits ? hipSuccess : pool_alloc(c, (void**)&d.counts, cap * sizeof(uint32_t));
@@ -149,6 +149,7 @@ extern "C" int katgpu_table_canonical(const katgpu_table* t) { return t ? (int)t
 // read the counter block back (one small D2H; synchronises the compute stream)
 int refresh_counters(katgpu_table* t) {
     katgpu_ctx* c = t->ctx;
+    if (t->zero_failed) return fail(c, KATGPU_ERR_DEVICE, "the table's unswept slots could not be cleared (hipMemsetAsync failed): its contents are not to be trusted");
     uint64_t h[CTR_WORDS];
     HIPCHK(c, hipMemcpyAsync(h, t->dv.ctrs, sizeof h, hipMemcpyDeviceToHost, c->stream));      // (the counters only: a table whose slots wait for their first sweep stays that way)
     HIPCHK(c, hipStreamSynchronize(c->stream));

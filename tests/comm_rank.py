@@ -31,6 +31,9 @@ def main():
             time.sleep(0.01)
         cid = open(id_file, "rb").read()
     comm = kat_amd.Comm(eng, rank, world, cid)
+    if os.environ.get("KATGPU_TEST_STALL_RANK") == str(rank):                    # (test_a_dead_peer_is_told_from_its_heartbeat: alive, but not coming)
+        open(os.path.join(out_dir, "stalled.%d" % rank), "w").close()
+        time.sleep(float(os.environ.get("KATGPU_TEST_STALL_S", "600")))
     k = 31 if mode == "rr31" else 45 if mode == "wide45" else K
     wide = k > 32
     g = synth.genome(G, seed=11)
@@ -75,7 +78,7 @@ def main():
     assert st["merge_calls"] > 0 and (world == 1 or st["bytes_sent"] > 0)
     if rank == 0:
         np.savez(os.path.join(out_dir, "sharded.npz"), mx=mx, cc=cc, sp=sp, h=h, gm=gm)
-        print("transport:", comm.transport, "|", comm.transport_note, "|", st)
+        print("transport:", comm.transport, "|", comm.transport_note, "| devices:", comm.distinct_devices, "|", st)
     comm.barrier()
     comm.free()
     eng.close()

@@ -50,7 +50,8 @@ def _check(ko, tmp_path, world, mode):
 @pytest.mark.parametrize("world,mode,extra", [
     (2, "same", {}), (3, "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "7"}), (2, "mixed", {}), (2, "rr31", {}),
     (2, "same", {"KATGPU_TEST_REGION_SLOTS": "512"}),                     # packed tables on the wire's both ends
-    (3, "wide45", {})])                                                   # k = 45: the wide exchange (records all to all, table refilled)
+    (3, "wide45", {}),                                                    # k = 45: the wide exchange (records all to all, table refilled)
+    (4, "same", {}), (8, "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "5"})])  # the world sizes of the scaling run (1, 2, 4, 8)
 def test_native_exchange_ranks_sharing_one_gpu(ko, tmp_path, world, mode, extra):
     out = _run(tmp_path, world, mode, dict(extra, KATGPU_COMM_TRANSPORT="shm"))
     assert "transport: shm" in out
@@ -71,7 +72,8 @@ def fake_rccl(tmp_path_factory):
 
 @pytest.mark.parametrize("world,mode,extra", [
     (2, "same", {}), (3, "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "7"}), (2, "mixed", {}), (3, "rr31", {"KATGPU_TEST_EXCHANGE_CHUNKS": "3"}),
-    (2, "wide45", {})])
+    (2, "wide45", {}),
+    (4, "mixed", {}), (8, "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "5"}), (8, "wide45", {})])      # 8: the node's world size
 def test_native_exchange_rccl_branch_with_several_ranks(ko, tmp_path, fake_rccl, world, mode, extra):
     """The RCCL transport code of kg_comm.hip -- grouped ncclSend / ncclRecv per chunk on the transport stream, events, the chunk
     double-buffering against k_merge_apply, ncclAllGather of the sizes, ncclAllReduce of the results -- with 2 and 3 ranks: the
@@ -79,6 +81,38 @@ def test_native_exchange_rccl_branch_with_several_ranks(ko, tmp_path, fake_rccl,
     out = _run(tmp_path, world, mode, dict(extra, KATGPU_COMM_TRANSPORT="rccl", KATGPU_RCCL_LIB=fake_rccl, KATGPU_TESTING="1"))
     assert "transport: rccl" in out, out[-2000:]
     _check(ko, tmp_path, world, mode)
+
+
+def test_shared_device_is_told_and_auto_takes_shm_there(ko, tmp_path):
+    """KATGPU_COMM_TRANSPORT unset (auto) with two ranks on ONE device: real RCCL refuses them, the ranks are seen to share a device
+    (katgpu_comm_distinct_devices == 1), and the staging transport carries them -- its home ground, no flag needed."""
+    out = _run(tmp_path, 2, "same", {})
+    assert "transport: shm" in out and "devices: 1" in out, out[-2000:]
+    _check(ko, tmp_path, 2, "same")
+
+
+def test_a_dead_peer_is_told_from_its_heartbeat(tmp_path):
+    """A rank that dies without a word (killed) leaves its peer waiting at the exchange: the peer gives up when the dead rank's heartbeat
+    has stood still for KATGPU_COMM_TIMEOUT_S -- not before (a slow peer is not a dead one), and not never."""
+    import signal
+    import time
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", KATGPU_COMM_TRANSPORT="shm", KATGPU_COMM_TIMEOUT_S="4", KATGPU_TEST_STALL_RANK="1", KATGPU_TEST_STALL_S="600")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "comm_rank.py"), str(r), "2", str(tmp_path / "id.bin"), str(tmp_path), "same"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    try:
+        t0 = time.time()
+        while not (tmp_path / "stalled.1").exists():                     # rank 1 has joined the communicator and now sleeps (alive: its heartbeat runs)
+            assert time.time() - t0 < 300 and procs[1].poll() is None, "rank 1 never reached its stall"
+            time.sleep(0.05)
+        time.sleep(8.0)                                                  # twice the liveness bound: rank 0 waits for a LIVE peer all that time
+        assert procs[0].poll() is None, "rank 0 gave up on a peer that was alive: " + (procs[0].communicate()[0] or "")[-1500:]
+        procs[1].send_signal(signal.SIGKILL)
+        out0 = procs[0].communicate(timeout=120)[0]
+        assert procs[0].returncode != 0 and "no sign of life from rank 1" in out0, out0[-2000:]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
 
 
 @pytest.mark.parametrize("mode", ["same", "wide45"])
