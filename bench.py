@@ -759,7 +759,7 @@ def end_to_end(eng, a, k, L):
             cmd += lib1
         t_gen = time.perf_counter() - t_e2e0
         t0 = time.perf_counter()
-        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, KATGPU_TIMING="1"))
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, KATGPU_TIMING="1", KATGPU_TRACE="1"))
         dt = time.perf_counter() - t0
         if pr.returncode != 0:
             raise RuntimeError("katgpu %s exited %d: %s" % (tool, pr.returncode, (pr.stderr or pr.stdout)[-400:]))
@@ -791,7 +791,10 @@ def end_to_end(eng, a, k, L):
                                 "pread into pinned memory, then their own H2D copy; pread / h2d per thread say which of the two it was); scan = the record scan "
                                 "on the device; counter_wait = waiting for the counting worker; counting = what the worker spent (hidden under the rest unless "
                                 "counter_wait says otherwise)"}
-        if os.environ.get("KATGPU_TRACE"):                 # diagnostic: the library's own time line of the run
+        # the library's own time line of its allocations (KATGPU_TRACE): on some boxes the driver takes seconds to hand out tens of GB
+        # (files[0].setup_ms says so); these lines say which allocation it was
+        breakdown["alloc_trace"] = [l[:200] for l in pr.stderr.splitlines() if l.startswith("[katgpu") and any(w in l for w in ("alloc", "arena", "scan buffers", "context on"))][:16]
+        if os.environ.get("KATGPU_TRACE"):                 # diagnostic: the whole time line
             breakdown["trace"] = [l for l in pr.stderr.splitlines() if l.startswith("[katgpu")][:80]
         # ---- result_check: what the binary wrote against the same reads counted resident through the C ABI ----
         check, detail = None, None

@@ -91,6 +91,10 @@ extern "C" int katgpu_reserve(katgpu_ctx* c, uint32_t k, uint64_t size_hint) {
     if (c->reserve_thread.joinable()) c->reserve_thread.join();
     c->reserve_thread = std::thread([c, bytes]() {
         hipSetDevice(c->device);
+        // after what the count that follows needs sooner: its scan buffers, its table, its arena (katgpu_ctx::scan_waiting).  The caller
+        // reserves, then counts: a moment for that count to announce itself, then its turn.
+        { timespec ts{0, 100000000}; nanosleep(&ts, nullptr); }
+        alloc_turn(c, true, 8000.0);
         void* p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); c->reserve_bytes.store(0); return; }
         std::lock_guard<std::mutex> lk(c->pool_mu);

@@ -1037,8 +1037,12 @@ extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_pa
         t->dv.k = k; t->dv.canonical = canonical ? 1 : 0;                    // what the feeders' own threads look at before the slots exist
         const uint64_t cap = std::max<uint64_t>(size_hint, 1024);
         const size_t arena_bytes = (size_t)16 << 30;
+        c->scan_waiting.store(1, std::memory_order_release);                  // the scan buffers go first (katgpu_ctx::scan_waiting; lowered by the first feeder's setup)
+        c->big_alloc_running.store(1, std::memory_order_release);
         t->alloc_thread = std::thread([c, t, k, canonical, cap]() {
+            struct Done { katgpu_ctx* c; ~Done() { c->big_alloc_running.store(0, std::memory_order_release); } } done{c};
             hipSetDevice(c->device);
+            alloc_turn(c, false, 3000.0);
             DevTable d{};
             bool lazy = false;
             const int arc = alloc_dev_table(c, k, canonical, cap, &d, 0, 0, &lazy);
@@ -1053,6 +1057,7 @@ extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_pa
         rc = katgpu_table_create(c, k, canonical, size_hint, disable_grow, &t);
     if (rc) return rc;
     rc = katgpu_count_files(t, paths, n_paths, trim5p);
+    c->scan_waiting.store(0, std::memory_order_release);          // (a run whose files did not take the device scan after all)
     if (rc) { katgpu_table_free(t); return rc; }
     *out = t;
     return KATGPU_OK;

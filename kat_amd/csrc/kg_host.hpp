@@ -69,6 +69,12 @@ struct katgpu_ctx {
     std::unordered_set<const void*> lds_attr;   // kernels whose dynamic-LDS ceiling has been raised on this device
     bool part_attr_set = false, merge_attr_set = false;   // the dynamic-LDS attributes of the partition / merge kernels have been set on this device
     bool arena_busy = false;              // a partition round is using it: pool_alloc must not free it to satisfy a table growth
+    // Who allocates first when several threads ask the driver for tens of GB at once.  On some boxes a hipMalloc costs ~1 ms per 40 MB
+    // (the driver clears what it hands out) and the driver serves one request at a time: the 9 GB of scan buffers, which the readers
+    // need before a byte can move, waited 2.1 s behind the table's 39 GB and the arena -- measured, round 5 -- where they take 54 ms
+    // elsewhere.  So: scan buffers first (scan_waiting: katgpu_count raises it, the first feeder's setup lowers it), then the table and
+    // the arena (big_alloc_running), then a reservation (katgpu_reserve).  Waits are bounded: a hint about order, not a lock.
+    std::atomic<int> scan_waiting{0}, big_alloc_running{0};
     size_t arena_limit = 0;               // != 0: count calls size the arena to at most this (the file feeders: their rounds are bounded by what arrives)
     bool arena_borrowed = false;          // katgpu_scratch_acquire handed the arena out: it must not be freed behind the caller's back
     int count_blocks_per_cu = 6;
@@ -166,11 +172,21 @@ inline std::string json_escaped(const char* s) {
     }
     return o;
 }
+inline double now_ms();
+// (see katgpu_ctx::scan_waiting) wait, at most max_ms, until the allocations that should go first have been made
+inline void alloc_turn(katgpu_ctx* c, bool also_big, double max_ms);
 inline double now_ms() {
     timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
 }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline void alloc_turn(katgpu_ctx* c, bool also_big, double max_ms) {
+    const double t0 = now_ms();
+    while ((c->scan_waiting.load(std::memory_order_acquire) || (also_big && c->big_alloc_running.load(std::memory_order_acquire))) && now_ms() - t0 < max_ms) {
+        timespec ts{0, 1000000};
+        nanosleep(&ts, nullptr);
+    }
+}
 static const double g_t_loaded = now_ms();           // when the library was loaded: KATGPU_TRACE stamps are relative to it
 inline double since_load() { return now_ms() - g_t_loaded; }
 // Test hooks (KATGPU_TEST_*) and A/B switches are read only when KATGPU_TESTING is set: a production process ignores them, and the

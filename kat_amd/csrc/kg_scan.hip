@@ -184,7 +184,7 @@ struct RawFeeder {
         acc_bytes = std::max<size_t>(buf_bytes, std::min<size_t>(g_scan_acc, (size_t)((double)size / world * (type == SCAN_FASTQ ? 0.6 : 1.02)) + ((size_t)1 << 20)));
         if (g_test_scan_batch) acc_bytes = std::max<size_t>(buf_bytes, (size_t)hook_u64("KATGPU_TEST_SCAN_ACC", 3 * buf_bytes));
         const double t_acq = now_ms();
-        { int rc = acquire(my.size() > 1 ? 2 : 1, T); if (rc) { scan_cache_release(c); return rc; } }   // (a half-made cache must not pass for a whole one)
+        { int rc = acquire(my.size() > 1 ? 2 : 1, T); c->scan_waiting.store(0, std::memory_order_release); if (rc) { scan_cache_release(c); return rc; } }   // (a half-made cache must not pass for a whole one)
         if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] device scan buffers: %.0f ms\n", since_load(), now_ms() - t_acq);
         n_readers = T;
         for (unsigned i = 0; i < T; ++i) readers.emplace_back([this, i] { read_loop(i); });
@@ -583,8 +583,9 @@ void scan_cache_release(katgpu_ctx* c) {
 int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, bool* took, int rank, int world) {
     *took = false;
     uint64_t size = 0; uint8_t first = 0;
-    if (!device_scan_applies(path, trim5p, &size, &first)) return KATGPU_OK;
+    if (!device_scan_applies(path, trim5p, &size, &first)) { t->ctx->scan_waiting.store(0, std::memory_order_release); return KATGPU_OK; }
     katgpu_ctx* c = t->ctx;
+    struct Lower { katgpu_ctx* c; ~Lower() { c->scan_waiting.store(0, std::memory_order_release); } } lower{c};      // (whatever way this call ends, nobody keeps waiting for its buffers)
     if (!t->alloc_thread.joinable() && c->arena && !c->arena_busy && !c->arena_borrowed) {      // (not while katgpu_count's allocation thread is at work)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < ((size_t)6 << 30)) release_arena(c);    // the cached arena holds most of the free HBM: the batch buffers come first

@@ -32,7 +32,8 @@ def test_single_gpu_line_carries_workloads_and_a_checked_end_to_end_leg():
     e = line["end_to_end"]
     assert e.get("error") is None, e
     assert e["result_check"] is True, e["result_check_detail"]
-    assert e["full_size"] is False and "slice" in e["config"] and e["kmer_instances"] == 2000000 * 124 + (5000000 - 5 * 26)
+    # (--reads 2000000 IS this run's whole workload, and it fits /dev/shm: the leg runs it at full size and says so)
+    assert e["full_size"] is True and "FULL size" in e["config"] and e["kmer_instances"] == 2000000 * 124 + (5000000 - 5 * 26)
     assert e["breakdown"]["unparsable_timing_lines"] == 0
     w = line["workloads"]
     assert sorted(w) == ["comp-rr", "gcp", "hist"]
