@@ -115,6 +115,11 @@ int  katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** bases, size_
 int  katgpu_parse_files(const char* const* paths, size_t n_paths, const uint16_t* trim5p, uint32_t k,
                         uint8_t** bases, size_t* n, const char** err_msg);
 void katgpu_free_host(void* p);
+/* Host-only: what the reader threads of the large-FASTQ ingest do to a record-aligned piece of a plain four-line FASTQ file before it
+ * crosses PCIe (kg_ingest.hpp: strip_fastq_records) -- each record's sequence line followed by 'N'.  out holds n / 2 + 1 bytes.
+ * Returns KATGPU_OK, or KATGPU_ERR_FASTQ when the bytes are not whole plain four-line records (such pieces go through the host state
+ * machine, katgpu_parse_file's, instead: it alone knows what multi-line records and odd quality lengths mean). */
+int  katgpu_strip_fastq(const uint8_t* fastq, size_t n, uint8_t* out, size_t* out_n);
 
 /* The placement hash of one-word tables (kg_device.hpp "placement"; the counterpart of the invertible hash + remainder storage of
  * JF/include/jellyfish/large_hash_array.hpp:169-171), on the host, for a table of p1 x 2^l2 regions: per key the two region digits,

@@ -29,7 +29,7 @@ EXPORTS = (
     "katgpu_table_merge_host", "katgpu_table_geometry", "katgpu_table_extract_sizes", "katgpu_table_extract", "katgpu_table_clear",
     "katgpu_table_merge_device32", "katgpu_table_merge_regions", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
-    "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_parse_files", "katgpu_free_host",
+    "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_parse_files", "katgpu_free_host", "katgpu_strip_fastq",
     "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
     "katgpu_table_partition_wide", "katgpu_table_merge_device_wide", "katgpu_table_regrows",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
@@ -158,6 +158,17 @@ def parse_file(path, trim5p=0):
     out = np.frombuffer(C.string_at(p, n.value), dtype=np.uint8).copy() if n.value else np.zeros(0, np.uint8)
     L.katgpu_free_host(p)
     return out
+
+
+def strip_fastq(data):
+    """katgpu_strip_fastq: whole plain four-line FASTQ records -> their sequence lines, each followed by 'N' (bytes), or None when the
+    bytes are not exactly that."""
+    L = load_library()
+    L.katgpu_strip_fastq.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    out = C.create_string_buffer(len(data) // 2 + 1)
+    n = C.c_size_t()
+    rc = L.katgpu_strip_fastq(bytes(data), len(data), out, C.byref(n))
+    return out.raw[:n.value] if rc == 0 else None
 
 
 def parse_files(paths, k, trim5p=None):

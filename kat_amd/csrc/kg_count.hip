@@ -1027,7 +1027,8 @@ extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_pa
     // Big plain files: the table (and the feeders' arena) are allocated on a thread of their own while the device scan already reads
     // and parses into its accumulation buffers -- tens of GB of hipMalloc take about as long as the first GBs of the files take to arrive.
     uint64_t scan_bytes = 0;
-    for (size_t i = 0; i < n_paths; ++i) { uint64_t sz = 0; if (device_scan_applies(paths[i], trim5p ? trim5p[i] : 0, &sz, nullptr)) scan_bytes += sz; }
+    uint8_t scan_first = 0;
+    for (size_t i = 0; i < n_paths; ++i) { uint64_t sz = 0; uint8_t fb = 0; if (device_scan_applies(paths[i], trim5p ? trim5p[i] : 0, &sz, &fb)) { scan_bytes += sz; if (!scan_first) scan_first = fb; } }
     katgpu_table* t = nullptr;
     int rc;
     if (scan_bytes >= ((uint64_t)4 << 30) && k >= 1 && k <= KATGPU_MAX_K && !getenv("KATGPU_SYNC_ALLOC")) {
@@ -1036,10 +1037,10 @@ extern "C" int katgpu_count(katgpu_ctx* c, const char* const* paths, size_t n_pa
         t->ctx = c; t->disable_grow = disable_grow;
         t->dv.k = k; t->dv.canonical = canonical ? 1 : 0;                    // what the feeders' own threads look at before the slots exist
         const uint64_t cap = std::max<uint64_t>(size_hint, 1024);
-        const size_t arena_bytes = (size_t)16 << 30;
+        const size_t arena_bytes = scan_arena_bytes(scan_first);
         c->scan_waiting.store(1, std::memory_order_release);                  // the scan buffers go first (katgpu_ctx::scan_waiting; lowered by the first feeder's setup)
         c->big_alloc_running.store(1, std::memory_order_release);
-        t->alloc_thread = std::thread([c, t, k, canonical, cap]() {
+        t->alloc_thread = std::thread([c, t, k, canonical, cap, arena_bytes]() {
             struct Done { katgpu_ctx* c; ~Done() { c->big_alloc_running.store(0, std::memory_order_release); } } done{c};
             hipSetDevice(c->device);
             alloc_turn(c, false, 3000.0);

@@ -217,6 +217,7 @@ int table_wait(katgpu_table* t);               // the table's device arrays exis
 int count_resident(katgpu_table* t, const uint8_t* dev_bases, size_t n);
 // large plain FASTQ / FASTA files: raw bytes to the device, record scan there (kg_scan.hip).  *took = false: not a file for this path
 bool device_scan_applies(const char* path, uint32_t trim5p, uint64_t* size_out, uint8_t* first_byte);
+size_t scan_arena_bytes(uint8_t first_byte);   // the partition arena such a file's count calls will want (FASTQ stripped on the host: bigger rounds)
 int count_file_device_scan(katgpu_table* t, const char* path, uint32_t trim5p, bool* took, int rank = 0, int world = 1);   // world > 1: this rank's batches of a FASTQ file
 
 // HIP events around a launch on the ctx stream; elapsed time is collected lazily.

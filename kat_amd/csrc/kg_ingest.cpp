@@ -208,6 +208,34 @@ struct Segment {
 
 int64_t find_record_start(ParseState::Type type, const uint8_t* buf, int64_t buf_off, int64_t len, int64_t from) { return find_cut(type, buf, buf_off, len, from); }
 
+bool strip_fastq_records(const uint8_t* p, size_t n, uint8_t* out, size_t* out_n) {
+    const uint8_t* const end = p + n;
+    uint8_t* o = out;
+    while (p < end) {
+        if (*p != '@') return false;
+        const uint8_t* h = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));                      // end of the header line
+        if (!h) return false;
+        const uint8_t* s = h + 1;
+        const uint8_t* se = s < end ? (const uint8_t*)memchr(s, '\n', (size_t)(end - s)) : nullptr;  // end of the sequence line
+        if (!se) return false;
+        const size_t len = (size_t)(se - s);
+        if (len == 0) return false;                                                                  // (a record without bases: what the reference's loop does with it is the state machine's to say)
+        const uint8_t* pl = se + 1;
+        if (pl >= end || *pl != '+') return false;                                                   // (a second sequence line: not plain)
+        const uint8_t* ple = (const uint8_t*)memchr(pl, '\n', (size_t)(end - pl));                   // end of the '+' line
+        if (!ple) return false;
+        const uint8_t* q = ple + 1;
+        if ((size_t)(end - q) < len + 1 || q[len] != '\n') return false;                             // the quality line: exactly the sequence's length ...
+        if (memchr(q, '\n', len)) return false;                                                    // ... in ONE line
+        memcpy(o, s, len);
+        o += len;
+        *o++ = 'N';
+        p = q + len + 1;
+    }
+    *out_n = (size_t)(o - out);
+    return true;
+}
+
 // The conditions under which the team takes a file; *size_out / *first_byte for the caller that goes on.
 static bool team_applies_impl(const char* path, uint32_t trim5p, int64_t* size_out, uint8_t* first_byte) {
     if (trim5p) return false;                                // is.ignore(trim5p) swallows line starts: keep that case on the streaming path
@@ -698,6 +726,12 @@ int stream_group(const char* const* paths, size_t n_paths, const uint16_t* trim5
 }
 
 }  // namespace kg
+
+extern "C" int katgpu_strip_fastq(const uint8_t* fastq, size_t n, uint8_t* out, size_t* out_n) {
+    if ((n && !fastq) || !out || !out_n) return KATGPU_ERR_INVALID_ARG;
+    *out_n = 0;
+    return kg::strip_fastq_records(fastq, n, out, out_n) ? KATGPU_OK : KATGPU_ERR_FASTQ;
+}
 
 extern "C" int katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** bases, size_t* n, const char** err_msg) {
     static thread_local std::string last;

@@ -48,6 +48,16 @@ private:
 // machine's state at the end of the piece before, the device scan against the structure of every record of the chunk).
 int64_t find_record_start(ParseState::Type type, const uint8_t* buf, int64_t buf_off, int64_t len, int64_t from);
 
+// Whole PLAIN four-line FASTQ records in [p, p + n) -- '@' line, one sequence line, '+' line, one quality line of the sequence's
+// length, every line ended by '\n' -- stripped to what the counter reads: each record's sequence bytes (verbatim: IUPAC codes, '\r'
+// and the like break k-mers downstream, as in the reference) followed by one 'N', the base stream's record separator
+// (mer_overlap_sequence_parser.hpp:202,234).  out must hold n / 2 + 1 bytes.  Returns false -- and nothing of `out` is to be used --
+// when the bytes are not exactly that: multi-line records, a quality line of another length (the reference skips qualities by
+// LENGTH, parser.hpp:274-289: only the state machine above knows what such a file means), a record without bases, a missing final
+// newline, a stray byte.
+// The reader threads of kg_scan.hip run it on record-aligned pieces of large FASTQ files, so that only the bases cross PCIe.
+bool strip_fastq_records(const uint8_t* p, size_t n, uint8_t* out, size_t* out_n);
+
 class SeqFileParser {
 public:
     SeqFileParser();

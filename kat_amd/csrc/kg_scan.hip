@@ -11,6 +11,17 @@
 // A batch the device cannot vouch for (kg_scan.hpp lists what) is parsed by the host state machine from the batch's first byte,
 // which the batch before it has proven to be a record start -- and so is the rest of the file: the stream stays the streaming
 // parser's whatever the file looks like.
+//
+// FASTQ, round 5: ONLY THE BASES CROSS PCIe ("host strip", the default for FASTQ files here).  A FASTQ file is 47 % sequence; the rest --
+// headers, '+' lines, qualities -- went to the device only to be scanned over and dropped there, by kernels that shared the GPU with the
+// counter (a 47.7 GB file: 1.3 s, of it 0.97 s in the scan's launches and their synchronisation).  Now every reader thread takes an 8 MiB
+// segment of the file, finds the record starts at its two ends (kg_ingest: find_record_start -- the neighbour computes the same cuts from
+// the same bytes), checks that what lies between is plain four-line FASTQ and copies the sequence lines, each followed by 'N', into a
+// pinned buffer of its own (kg_ingest: strip_fastq_records: four memchr and one memcpy per record); the caller's thread takes the
+// segments IN FILE ORDER, checks that each begins where the one before ended, and issues its copy straight into the accumulation buffer the
+// counter will be handed.  No scan kernel runs and half the bytes travel.  A segment that is not plain four-line FASTQ (multi-line
+// records, odd quality lengths, a last line without its newline, a record longer than the look-ahead) stops the fast path there: what was
+// committed is counted, and the file's rest goes through the host state machine from the last proven record start -- as above.
 #include "kg_host.hpp"
 #include "kg_ingest.hpp"
 #include "kg_scan.hpp"
@@ -44,12 +55,18 @@ static const int g_scan_mmap = getenv("KATGPU_SCAN_MMAP") ? atoi(getenv("KATGPU_
 static const size_t g_test_scan_batch = (size_t)hook_u64("KATGPU_TEST_SCAN_BATCH", 0), g_test_scan_overlap = (size_t)hook_u64("KATGPU_TEST_SCAN_OVERLAP", 0);
 static const size_t g_test_scan_segment = (size_t)hook_u64("KATGPU_TEST_SCAN_SEGMENT", 0);
 static const uint64_t g_test_scan_fail_at = hook_u64("KATGPU_TEST_SCAN_FAIL_AT", ~0ULL);
+// FASTQ files: the readers strip to the sequence lines on the host (above); KATGPU_FASTQ_STRIP=0: the device scan as for FASTA
+static const bool g_fastq_strip = !(getenv("KATGPU_FASTQ_STRIP") && atoi(getenv("KATGPU_FASTQ_STRIP")) == 0);
+// tests: tiny segments / look-ahead for the strip path (little files cross many cuts); force the hand-over to the host parser at a segment
+static const size_t g_test_strip_segment = (size_t)hook_u64("KATGPU_TEST_STRIP_SEGMENT", 0), g_test_strip_overlap = (size_t)hook_u64("KATGPU_TEST_STRIP_OVERLAP", 0);
+static const uint64_t g_test_strip_fail_at = hook_u64("KATGPU_TEST_STRIP_FAIL_AT", ~0ULL);
+static const size_t g_strip_acc = (size_t)3 << 30;                // strip path: base stream per count call (one partition round of a 32 GB arena)
 
 bool device_scan_applies(const char* path, uint32_t trim5p, uint64_t* size_out, uint8_t* first_byte) {
     if (g_scan_off || trim5p) return false;                       // (a 5' trim swallows line starts the way is.ignore does: the host machine's job)
     struct stat st;
     if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return false;
-    if ((uint64_t)st.st_size < (g_test_scan_batch ? 1 : g_scan_min_bytes)) return false;
+    if ((uint64_t)st.st_size < (g_test_scan_batch || g_test_strip_segment ? 1 : g_scan_min_bytes)) return false;
     const int fd = ::open(path, O_RDONLY);
     if (fd < 0) return false;
     uint8_t head[2] = {0, 0};
@@ -60,6 +77,9 @@ bool device_scan_applies(const char* path, uint32_t trim5p, uint64_t* size_out, 
     if (first_byte) *first_byte = head[0];
     return true;
 }
+
+// the partition arena a file of this kind will ask for through this path (katgpu_count allocates it beside the feeders)
+size_t scan_arena_bytes(uint8_t first_byte) { return first_byte == '@' && g_fastq_strip ? (size_t)32 << 30 : (size_t)16 << 30; }
 
 namespace {
 
@@ -98,6 +118,14 @@ struct RawFeeder {
     size_t n_readers = 0;
     std::atomic<uint64_t> us_pread{0}, us_h2d{0};                 // summed over the reader threads: in pread / in their H2D copy (enqueue + landing)
     const uint8_t* map = nullptr;                                 // the file, mapped (tmpfs: see g_scan_mmap); null: pread
+    // ---- host strip (FASTQ): segments of the file stripped to their sequence lines by the readers, committed in file order ----
+    bool strip = false;
+    struct StripSeg { int state = 0 /* 0: not yet, 1: stripped, 2: not plain FASTQ / no certain cut, 3: read error */; uint64_t lo = 0, hi = 0; uint8_t* pin = nullptr; size_t out_n = 0; unsigned reader = 0; int half = 0; };
+    std::vector<StripSeg> ssegs;                                  // one per segment of `my_segs`
+    std::vector<uint64_t> my_segs;                                // the file segments this feeder takes (all of them; a rank's share when sharded)
+    uint64_t n_fsegs = 0, committed = 0, next_sseg = 0;           // segments of the file; of mine, how many the caller's thread has taken / the readers have claimed
+    std::vector<int> half_state;                                  // [2 * reader + half]: 0 free, 1 stripped and waiting for its copy to be issued, 2 copy issued (event recorded)
+    std::vector<hipEvent_t> half_ev;
 
     RawFeeder(katgpu_table* t_, const char* p) : t(t_), c(t_->ctx), path(p) {}
     ~RawFeeder() { shutdown(); release(); }
@@ -110,6 +138,8 @@ struct RawFeeder {
     }
     void release() {                                              // (the buffers stay with the context: scan_cache_release)
         for (auto st : c->scan.seg_stream) hipStreamSynchronize(st);
+        for (auto e : half_ev) if (e) hipEventDestroy(e);
+        half_ev.clear();
         if (map) { munmap(const_cast<uint8_t*>(map), (size_t)size); map = nullptr; }     // (cheap: the readers dropped their page-table entries as they went)
         if (fd >= 0) { ::close(fd); fd = -1; }
     }
@@ -117,9 +147,10 @@ struct RawFeeder {
     int acquire(int nb, unsigned threads) {
         katgpu_ctx::ScanCache& sc = c->scan;
         const size_t seg_bytes = PRE + segment + overlap + 64;
-        if (sc.buf_bytes < buf_bytes || sc.n_buf < nb || sc.pin_seg_bytes < seg_bytes || sc.pin_seg.size() < 2 * (size_t)threads || sc.acc_bytes < acc_bytes) {
+        // part A: what every mode needs -- the accumulation buffers, two pinned segments and a stream per reader
+        if (sc.pin_seg_bytes < seg_bytes || sc.pin_seg.size() < 2 * (size_t)threads || sc.acc_bytes < acc_bytes) {
             scan_cache_release(c);
-            sc.buf_bytes = buf_bytes; sc.n_buf = nb; sc.pin_seg_bytes = seg_bytes; sc.acc_bytes = acc_bytes;
+            sc.pin_seg_bytes = seg_bytes; sc.acc_bytes = acc_bytes;
             for (int i = 0; i < 2; ++i) HIPCHK(c, hipMalloc((void**)&sc.acc[i], HEAD + acc_bytes));
             for (unsigned i = 0; i < threads; ++i) {              // two pinned segments and one stream per reader; the readers pin their own
                 hipStream_t st = nullptr;                         // segments when they start (read_loop): 32 x 8 MiB pinned one after the other cost 80 ms
@@ -127,6 +158,13 @@ struct RawFeeder {
                 HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
                 sc.seg_stream.push_back(st);
             }
+        }
+        // part B: the device scan's own -- raw batch buffers and the scan's arrays (a FASTQ file stripped on the host needs none of them)
+        if (nb && (sc.buf_bytes < buf_bytes || sc.n_buf < nb)) {
+            for (int i = 0; i < 2; ++i) { hipFree(sc.raw[i]); sc.raw[i] = nullptr; }
+            hipFree(sc.raw_al); hipFree(sc.tile_cnt); hipFree(sc.NL); hipFree(sc.len_off); hipFree(sc.line_tile_sum); hipFree(sc.tile_off); hipFree(sc.line_tile_off); hipFree(sc.flags);
+            sc.raw_al = nullptr; sc.tile_cnt = sc.NL = sc.len_off = sc.line_tile_sum = nullptr; sc.tile_off = sc.line_tile_off = nullptr; sc.flags = nullptr;
+            sc.buf_bytes = 0; sc.n_buf = 0;
             for (int i = 0; i < nb; ++i) {
                 HIPCHK(c, hipMalloc((void**)&sc.raw[i], buf_bytes));
             }
@@ -140,12 +178,13 @@ struct RawFeeder {
             HIPCHK(c, hipMalloc((void**)&sc.line_tile_sum, (sc.cap_lines / SC_BLOCK + 2) * 4));
             HIPCHK(c, hipMalloc((void**)&sc.line_tile_off, (sc.cap_lines / SC_BLOCK + 3) * 8));
             HIPCHK(c, hipMalloc((void**)&sc.flags, SCF_WORDS * 8));
+            sc.buf_bytes = buf_bytes; sc.n_buf = nb;
         }
         for (int i = 0; i < 2; ++i) { raw[i] = sc.raw[i]; acc[i] = sc.acc[i]; }
         acc_bytes = sc.acc_bytes;
         raw_al = sc.raw_al; tile_cnt = sc.tile_cnt; tile_off = sc.tile_off; NL = sc.NL; len_off = sc.len_off;
         line_tile_sum = sc.line_tile_sum; line_tile_off = sc.line_tile_off; flags = sc.flags; cap_lines = sc.cap_lines;
-        buf_bytes = sc.buf_bytes;                                 // (possibly larger than asked for: only ever a bound)
+        if (nb) buf_bytes = sc.buf_bytes;                         // (possibly larger than asked for: only ever a bound)
         return KATGPU_OK;
     }
 
@@ -156,9 +195,12 @@ struct RawFeeder {
         size = file_size;
         type = first == '@' ? SCAN_FASTQ : SCAN_FASTA;
         shard_rank = rank; shard_world = world;
+        // FASTQ: stripped on the host (the old test hooks keep the device scan they were written for)
+        strip = type == SCAN_FASTQ && g_fastq_strip && (!g_test_scan_batch || g_test_strip_segment);
         batch = g_test_scan_batch ? g_test_scan_batch : g_scan_batch;
         segment = g_test_scan_segment ? g_test_scan_segment : std::min(g_scan_segment, batch);
         overlap = g_test_scan_overlap ? g_test_scan_overlap : g_scan_overlap_dflt;
+        if (strip && g_test_strip_segment) { segment = g_test_strip_segment; batch = std::max<size_t>(batch == g_scan_batch ? 4 * segment : batch, segment); overlap = g_test_strip_overlap ? g_test_strip_overlap : overlap; }
         batch = std::max<size_t>(batch, 64);
         segment = std::max<size_t>(16, std::min(segment, batch));
         batch = (batch + segment - 1) / segment * segment;
@@ -183,12 +225,109 @@ struct RawFeeder {
         // accumulation buffers: what the file will give (FASTQ: the sequence lines, a bit under half of it), within KATGPU_SCAN_ACC_MB each
         acc_bytes = std::max<size_t>(buf_bytes, std::min<size_t>(g_scan_acc, (size_t)((double)size / world * (type == SCAN_FASTQ ? 0.6 : 1.02)) + ((size_t)1 << 20)));
         if (g_test_scan_batch) acc_bytes = std::max<size_t>(buf_bytes, (size_t)hook_u64("KATGPU_TEST_SCAN_ACC", 3 * buf_bytes));
+        if (strip) {                                              // the file's segments, dealt to the ranks a batch's worth at a time (as the batches are)
+            n_fsegs = (size + segment - 1) / segment;
+            for (uint64_t sg = 0; sg < n_fsegs; ++sg) if ((sg / spb) % (uint64_t)world == (uint64_t)rank) my_segs.push_back(sg);
+            ssegs.assign(my_segs.size(), StripSeg{});
+            const size_t seg_out = (segment + overlap) / 2 + 64;          // a segment's sequence lines: at most half of its bytes
+            acc_bytes = std::max<size_t>(2 * seg_out, std::min<size_t>(getenv("KATGPU_SCAN_ACC_MB") ? g_scan_acc : g_strip_acc, (size_t)((double)size / world * 0.6) + ((size_t)1 << 20)));
+            if (g_test_strip_segment) acc_bytes = std::max<size_t>(2 * seg_out, (size_t)hook_u64("KATGPU_TEST_SCAN_ACC", 3 * seg_out));
+        }
         const double t_acq = now_ms();
-        { int rc = acquire(my.size() > 1 ? 2 : 1, T); c->scan_waiting.store(0, std::memory_order_release); if (rc) { scan_cache_release(c); return rc; } }   // (a half-made cache must not pass for a whole one)
+        { int rc = acquire(strip ? 0 : (my.size() > 1 ? 2 : 1), T); c->scan_waiting.store(0, std::memory_order_release); if (rc) { scan_cache_release(c); return rc; } }   // (a half-made cache must not pass for a whole one)
         if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] device scan buffers: %.0f ms\n", since_load(), now_ms() - t_acq);
         n_readers = T;
+        if (strip) {
+            half_state.assign(2 * (size_t)T, 0);
+            half_ev.assign(2 * (size_t)T, nullptr);
+            for (auto& e : half_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (unsigned i = 0; i < T; ++i) readers.emplace_back([this, i] { read_loop_strip(i); });
+            return KATGPU_OK;
+        }
         for (unsigned i = 0; i < T; ++i) readers.emplace_back([this, i] { read_loop(i); });
         return KATGPU_OK;
+    }
+
+    // ---- host strip: a reader takes the next segment of the file, strips it into one of its two pinned halves and reports; the
+    // caller's thread (run_strip) issues the copies in file order.  A half is the reader's again when its copy has landed. ----
+    void read_loop_strip(unsigned me) {
+        hipSetDevice(c->device);
+        bool ok_pin = true;
+        for (int h = 0; h < 2; ++h)
+            if (!c->scan.pin_seg[2 * me + h] &&
+                hipHostMalloc((void**)&c->scan.pin_seg[2 * me + h], c->scan.pin_seg_bytes, hipHostMallocNonCoherent) != hipSuccess) { c->scan.pin_seg[2 * me + h] = nullptr; ok_pin = false; }
+        std::vector<uint8_t> tmp;                                 // pread mode: the segment's bytes (a mapping is read in place)
+        for (int h = 0;; h ^= 1) {
+            // this half free again?  (1: stripped, the caller's thread has not taken it yet; 2: its copy is on its way)
+            int hs;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || io_error || half_state[2 * me + h] != 1; });
+                if (stop || io_error) break;
+                hs = half_state[2 * me + h];
+            }
+            if (hs == 2) {                                        // (only this thread moves a half out of state 2)
+                const double t0 = now_ms();
+                const bool landed = hipEventSynchronize(half_ev[2 * me + h]) == hipSuccess;
+                us_h2d += (uint64_t)((now_ms() - t0) * 1e3);
+                std::lock_guard<std::mutex> lk(mu);
+                if (!landed) { io_error = true; cv.notify_all(); break; }
+                half_state[2 * me + h] = 0;
+            }
+            uint64_t j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                // (not too far ahead of the caller's thread: it takes the segments in order, and every reader holds at most two)
+                cv.wait(lk, [&] { return stop || io_error || next_sseg >= my_segs.size() || next_sseg < committed + 4 * n_readers; });
+                if (stop || io_error || next_sseg >= my_segs.size()) break;
+                j = next_sseg++;
+            }
+            StripSeg sg;
+            sg.reader = me; sg.half = h; sg.pin = c->scan.pin_seg[2 * me + h];
+            const uint64_t f0 = my_segs[j] * (uint64_t)segment, f1 = std::min<uint64_t>(size, f0 + segment);
+            const uint64_t w0 = f0 ? f0 - 1 : 0, w1 = std::min<uint64_t>(size, f1 + overlap);      // the bytes the two cuts are looked for in ('\n' before a record start included)
+            const double ta = now_ms();
+            const uint8_t* buf = nullptr;
+            sg.state = 1;
+            if (!ok_pin) sg.state = 3;
+            else if (map) {
+                struct stat st0;                                  // (a file cut short under the run: KATGPU_ERR_IO between segments, SIGBUS inside one -- INTEGRATION.md)
+                if (fstat(fd, &st0) != 0 || (uint64_t)st0.st_size < w1) sg.state = 3; else buf = map + w0;
+            } else {
+                tmp.resize((size_t)(w1 - w0));
+                uint64_t got = 0;
+                while (got < w1 - w0) {
+                    const ssize_t r = pread(fd, tmp.data() + got, (size_t)std::min<uint64_t>(w1 - w0 - got, (uint64_t)1 << 30), (off_t)(w0 + got));
+                    if (r <= 0) { sg.state = 3; break; }
+                    got += (uint64_t)r;
+                }
+                buf = tmp.data();
+            }
+            if (sg.state == 1) {
+                const int64_t lo = f0 == 0 ? 0 : kg::find_record_start(kg::ParseState::FASTQ, buf, (int64_t)w0, (int64_t)(w1 - w0), (int64_t)f0);
+                const int64_t hi = f1 >= size ? (int64_t)size : kg::find_record_start(kg::ParseState::FASTQ, buf, (int64_t)w0, (int64_t)(w1 - w0), (int64_t)f1);
+                if (lo < 0 || hi < 0 || lo > hi || (uint64_t)(hi - lo) / 2 + 1 > c->scan.pin_seg_bytes) sg.state = 2;
+                else {
+                    sg.lo = (uint64_t)lo; sg.hi = (uint64_t)hi;
+                    if (!kg::strip_fastq_records(buf + (sg.lo - w0), (size_t)(sg.hi - sg.lo), sg.pin, &sg.out_n)) sg.state = 2;
+                }
+                if (map) {
+                    struct stat st0;
+                    if (fstat(fd, &st0) != 0 || (uint64_t)st0.st_size < w1) sg.state = 3;
+                    // this reader is through with these pages: their page-table entries go now (see read_loop)
+                    const uint64_t a0 = (f0 + 4095) & ~4095ULL, a1 = f1 & ~4095ULL;
+                    if (a1 > a0) madvise(const_cast<uint8_t*>(map) + a0, (size_t)(a1 - a0), MADV_DONTNEED);
+                }
+            }
+            us_pread += (uint64_t)((now_ms() - ta) * 1e3);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ssegs[j] = sg;
+                half_state[2 * me + h] = 1;
+            }
+            cv.notify_all();
+        }
+        // (copies still in flight from this reader's halves: the caller's thread synchronises the readers' streams before it moves on)
     }
 
     // file range of batch b as read: [base, hi_read) = [b * batch - PRE, min(size, (b + 1) * batch + overlap)); buffer byte 0 = file byte base
@@ -474,7 +613,95 @@ struct RawFeeder {
         return kg::find_record_start(kg::ParseState::FASTQ, buf, (int64_t)base, (int64_t)(lim - base), (int64_t)nominal);
     }
 
+    // every copy the readers' streams carry has landed (before an accumulation buffer changes hands, before the fall-back)
+    int flush_copies() {
+        for (auto st : c->scan.seg_stream) HIPCHK(c, hipStreamSynchronize(st));
+        return KATGPU_OK;
+    }
+
+    // The caller's thread of the host-strip path: the readers' segments in file order -> the accumulation buffers -> the counting worker.
+    int run_strip() {
+        const bool sharded = shard_world > 1;
+        double ms_wait = 0, ms_issue = 0, ms_count = 0;
+        const double t_run = now_ms();
+        struct Report { RawFeeder* f; double *w, *s, *n, t0; ~Report() {
+            if (g_timing) fprintf(stderr, "katgpu_timing {\"file\": \"%s\", \"bytes\": %llu, \"setup_ms\": %.1f, \"wall_ms\": %.1f, \"reader_wait_ms\": %.1f, \"scan_ms\": %.1f, \"counter_wait_ms\": %.1f, \"counting_ms\": %.1f, "
+                                  "\"reader_threads\": %u, \"pread_ms_per_thread\": %.1f, \"h2d_ms_per_thread\": %.1f, \"segment_MiB\": %zu, \"read_by\": \"%s\"}\n",
+                                  json_escaped(f->path).c_str(), (unsigned long long)f->size, f->setup_ms, now_ms() - t0, *w, *s, *n, f->worker_ms, (unsigned)f->n_readers,
+                                  f->us_pread.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->us_h2d.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->segment >> 20,
+                                  f->map ? "sequence lines stripped out of a mapping (tmpfs) on the host: only bases cross PCIe" : "pread, sequence lines stripped on the host: only bases cross PCIe");
+            if (g_trace) fprintf(stderr, "[katgpu +%.0f ms] host strip of %s: %.1f GB in %.0f ms (%.1f GB/s): waiting for the readers %.0f ms, issuing copies %.0f ms, waiting for the counter %.0f ms (it counted for %.0f ms); %u reader threads (read + strip %.0f ms, waiting for their copies %.0f ms each), %zu MiB segments, %zu MiB accumulated per count\n",
+                                 since_load(), f->path, f->size / 1e9, now_ms() - t0, f->size / 1e6 / std::max(1.0, now_ms() - t0), *w, *s, *n, f->worker_ms, (unsigned)f->n_readers,
+                                 f->us_pread.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->us_h2d.load() / 1e3 / std::max<size_t>(1, f->n_readers), f->segment >> 20, f->acc_bytes >> 20); } } report{this, &ms_wait, &ms_issue, &ms_count, t_run};
+        struct StopWorker { RawFeeder* f; ~StopWorker() { f->stop_worker(); } } stop_w{this};
+        worker = std::thread([this] { work(); });
+        struct Limit { katgpu_ctx* c; size_t old; ~Limit() { c->arena_limit = old; } } limit{c, c->arena_limit};
+        c->arena_limit = (size_t)32 << 30;                     // one round per accumulation buffer (3 GiB of base stream: 2.6 G k-mers)
+        HIPCHK(c, hipMemsetAsync(acc[0], 'N', HEAD, c->copy_stream));
+        acc_cur = 0; acc_fill = 0;
+        uint64_t prev_hi = 0;                                     // where the segment before ended: a proven record start
+        for (uint64_t j = 0; j < my_segs.size(); ++j) {
+            double t0 = now_ms();
+            StripSeg sg;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return io_error || ssegs[j].state != 0; });
+                if (io_error && ssegs[j].state == 0) return fail(c, KATGPU_ERR_IO, "read error on %s", path);
+                sg = ssegs[j];
+            }
+            ms_wait += now_ms() - t0;
+            if (sg.state == 3) return fail(c, KATGPU_ERR_IO, "read error on %s", path);
+            const bool follows = j > 0 && my_segs[j] == my_segs[j - 1] + 1;
+            const bool plain = sg.state == 1 && (!follows || sg.lo == prev_hi) && my_segs[j] < g_test_strip_fail_at;
+            if (!plain && sharded)
+                return fail(c, KATGPU_ERR_FASTQ, "%s: the bytes around offset %llu are not plain four-line FASTQ: such a file cannot be cut between GPUs -- run it on one", path,
+                            (unsigned long long)(my_segs[j] * (uint64_t)segment));
+            if (!plain) {
+                // not plain four-line FASTQ from here on (or no certain cut): what has been committed is counted, the rest of the file goes
+                // through the host state machine from the last proven record start
+                const uint64_t from = j == 0 ? 0 : prev_hi;
+                if (g_trace) fprintf(stderr, "[katgpu] host strip: %s is not plain four-line FASTQ around offset %llu: the host parser takes the file from offset %llu\n", path,
+                                     (unsigned long long)(my_segs[j] * (uint64_t)segment), (unsigned long long)from);
+                shutdown();
+                int rc = flush_copies();
+                if (rc) return rc;
+                rc = submit(true);
+                if (rc) return rc;
+                stop_worker();
+                rc = table_wait(t);
+                if (rc) return rc;
+                return host_rest(from, nullptr, 0);              // (the stream so far ended on a record's 'N': nothing to carry over)
+            }
+            t0 = now_ms();
+            if (acc_fill + sg.out_n > acc_bytes) {               // this segment opens the other buffer
+                int rc = flush_copies();
+                if (!rc) rc = submit(false);
+                if (rc) return rc;
+            }
+            ms_count += now_ms() - t0;
+            t0 = now_ms();
+            const hipStream_t st = c->scan.seg_stream[sg.reader];
+            if (sg.out_n) HIPCHK(c, hipMemcpyAsync(acc[acc_cur] + HEAD + acc_fill, sg.pin, sg.out_n, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipEventRecord(half_ev[2 * sg.reader + sg.half], st));
+            acc_fill += sg.out_n;
+            prev_hi = sg.hi;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                half_state[2 * sg.reader + sg.half] = 2;
+                ++committed;
+            }
+            cv.notify_all();
+            ms_issue += now_ms() - t0;
+        }
+        const double t0 = now_ms();
+        int rc = flush_copies();
+        if (!rc) rc = submit(true);
+        ms_count += now_ms() - t0;
+        return rc;
+    }
+
     int run() {
+        if (strip) return run_strip();
         const uint32_t k = t->dv.k;
         const bool sharded = shard_world > 1;
         uint64_t cut_lo = 0;                                      // file offset where the next chunk starts: a proven record / line start

@@ -183,7 +183,8 @@ def test_comp_stats_and_matrix_through_the_reference_code(engine, refdata, tmp_p
     t1.free(); t2.free()
 
 
-@pytest.mark.parametrize("gpus,env", [(1, {"KATGPU_COMM_TRANSPORT": "rccl"}), (2, {"KATGPU_COMM_TRANSPORT": "shm"}), (3, {"KATGPU_COMM_TRANSPORT": "shm"})])
+@pytest.mark.parametrize("gpus,env", [(1, {"KATGPU_COMM_TRANSPORT": "rccl"}), (2, {"KATGPU_COMM_TRANSPORT": "shm"}), (3, {"KATGPU_COMM_TRANSPORT": "shm"}),
+                                      (2, {"KATGPU_COMM_TRANSPORT": "shm", "KATGPU_TEST_STRIP_SEGMENT": "131072", "KATGPU_TEST_STRIP_OVERLAP": "8192"})])     # the ranks cut the FASTQ files between themselves on the host-strip path
 def test_gpus_switch_writes_the_single_gpu_files(tmp_path, gpus, env):
     """`katgpu <mode> --gpus N` (kat_main.cc forks N ranks; kg_comm.hip merges their tables by owner and sums the reducers' results):
     byte for byte the files of the plain run.  --gpus 1 takes the RCCL branch with one rank; 2 and 3 ranks share this box's one GPU, which

@@ -1,0 +1,66 @@
+"""kg_ingest: strip_fastq_records (C ABI: katgpu_strip_fastq) -- what the reader threads of the large-FASTQ ingest do to a record-aligned
+piece of a file before it crosses PCIe -- against the host state machine (katgpu_parse_file: the streaming parser, itself pinned to the
+reference's parser in tests/test_oracle_vs_reference.py): for plain four-line FASTQ the two give the SAME base stream, byte for byte; for
+anything else the strip refuses (and the ingest hands such files to the state machine).  No GPU."""
+import numpy as np
+import pytest
+
+import kat_amd
+from kat_amd import binding
+
+
+def _fastq(rng, n, lens=(1, 200), alphabet=b"ACGTNacgtRY", crlf=False, hdr=lambda i: b"@r%d x/1" % i):
+    out = []
+    for i in range(n):
+        ln = int(rng.integers(lens[0], lens[1] + 1))
+        seq = bytes(rng.choice(np.frombuffer(alphabet, np.uint8), size=ln)) if ln else b""
+        q = bytearray(rng.integers(33, 74, size=ln, dtype=np.uint8).tobytes())
+        if ln and i % 3 == 0:
+            q[0] = ord("@")                                   # a quality line that looks like a header
+        if ln and i % 5 == 0:
+            q[0] = ord("+")
+        out.append(hdr(i) + b"\n" + seq + b"\n+" + (b"" if i % 2 else b"r%d" % i) + b"\n" + bytes(q) + b"\n")
+    data = b"".join(out)
+    return data.replace(b"\n", b"\r\n") if crlf else data
+
+
+def _host_stream(tmp_path, data):
+    p = tmp_path / "x.fq"
+    p.write_bytes(data)
+    return bytes(kat_amd.parse_file(str(p)))
+
+
+@pytest.mark.parametrize("kw", [{}, {"lens": (150, 150), "alphabet": b"ACGT"}, {"lens": (1, 3)}, {"crlf": True}, {"hdr": lambda i: b"@"}])
+def test_plain_fastq_gives_the_host_machines_stream(tmp_path, kw):
+    data = _fastq(np.random.default_rng(11), 3000, **kw)
+    got = binding.strip_fastq(data)
+    assert got is not None
+    want = _host_stream(tmp_path, data)
+    # (the machine closes the FILE's stream without a trailing separator; the strip closes every record with one)
+    assert got == want or got == want + b"N", (got[:80], want[:80])
+    assert binding.strip_fastq(b"") == b""
+
+
+def test_what_is_not_plain_four_line_fastq_is_refused():
+    rng = np.random.default_rng(3)
+    good = _fastq(rng, 50, lens=(20, 60))
+    assert binding.strip_fastq(good) is not None
+    rec = b"@r\nACGTACGT\n+\nIIIIIIII\n"
+    bad = {
+        "multi-line sequence": b"@r\nACGT\nACGT\n+\nIIIIIIII\n",
+        "quality shorter": b"@r\nACGTACGT\n+\nIIIIIII\n" + rec,
+        "quality longer": b"@r\nACGTACGT\n+\nIIIIIIIII\n" + rec,
+        "quality over two lines": b"@r\nACGTACGT\n+\nIIII\nIIII\n",
+        "no final newline": rec + b"@r\nACGTACGT\n+\nIIIIIIII",
+        "blank line between records": rec + b"\n" + rec,
+        "does not start at a record": b"ACGT\n+\nIIII\n" + rec,
+        "no plus line": b"@r\nACGT\n@r2\nACGT\n",
+        "cut inside the header": rec + b"@r",
+        "cut after the sequence": rec + b"@r\nACGT\n",
+        "fasta": b">c\nACGT\n",
+        "a record without bases": rec + b"@r\n\n+\n\n" + rec,
+    }
+    for what, data in bad.items():
+        assert binding.strip_fastq(data) is None, what
+    # and embedded in a long valid piece
+    assert binding.strip_fastq(good + bad["quality shorter"] + good) is None
