@@ -789,7 +789,8 @@ def end_to_end(eng, a, k, L):
                      "files": per_file, "unparsable_timing_lines": bad_lines,
                      "reading": "per file: setup = open + map + device / pinned buffers; wall = the file's whole pass; reader_wait = the main thread waiting for file bytes to reach the device (reader threads: "
                                 "pread into pinned memory, then their own H2D copy; pread / h2d per thread say which of the two it was); scan = the record scan "
-                                "on the device; counter_wait = waiting for the counting worker; counting = what the worker spent (hidden under the rest unless "
+                                "on the device -- FASTQ files are stripped to their sequence lines by the reader threads instead (read_by says so): no scan kernel, scan = issuing their copies, "
+                                "pread = read + strip --; counter_wait = waiting for the counting worker; counting = what the worker spent (hidden under the rest unless "
                                 "counter_wait says otherwise)"}
         # the library's own time line of its allocations (KATGPU_TRACE): on some boxes the driver takes seconds to hand out tens of GB
         # (files[0].setup_ms says so); these lines say which allocation it was
