@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkatgpu.so")
+if os.environ.get("KATGPU_TESTING") and os.environ.get("KATGPU_LIB_PATH"):      # same-box A/B of two builds of the library (tools/; dead without KATGPU_TESTING)
+    LIB_PATH = os.environ["KATGPU_LIB_PATH"]
 
 KERNEL_CLASSES = ("count", "regrow", "hist", "gcp", "comp_pass1", "comp_pass2", "partition", "merge", "part_l1_count", "part_l2", "part_apply", "part_l1_scatter", "profile", "scan")
 

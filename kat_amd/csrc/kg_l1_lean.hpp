@@ -112,4 +112,23 @@ KG_LEAN_FN uint64_t lean_kmer_at(const uint32_t* code, uint32_t p, uint32_t k) {
     return (((uint64_t)h1 << 32) | h0) >> (64 - 2 * k);
 }
 
+// ---- what a staged entry of level 1 says about where its k-mer is read from (round 5) ----
+// The tile is staged as words of 16 bases: code[LEAN_BLOCK + 2], then the flags (16 bits per word of codes: half as many words), then
+// rcode[LEAN_BLOCK + 2] (the other strand's stream), one array U to the copy-out, counted from the word IN FRONT of code:
+// U[1 + w] = code[w], U[1 + LEAN_RCW + w] = rcode[w].  The k-mer whose
+// window starts q + 1 bases into a stream is read from the three words in front of / at / behind that base: with x = q + 16, word index
+// W = x >> 4 (+ LEAN_RCW on the other strand's stream) and funnel shift 2 (~q & 15) = 2 ((x ^ 15) & 15) -- one number, entry = (x ^ 15) << 1
+// (+ LEAN_RCW << 5): bits 5 .. 15 = W, bits 0 .. 4 = the shift (v_alignbit_b32 reads exactly those).  Window j of lane tid starts
+// 16 tid + j bases into the forward stream (q = 16 tid + j - 1) and T - k - (16 tid + j) bases into the other strand's (q = u - 16 tid,
+// u = T - 1 - k - j): 16 tid has no low nibble, so both entries are a constant of the window PLUS / MINUS 32 tid.
+constexpr uint32_t LEAN_BLOCK = 512, LEAN_RCW = (LEAN_BLOCK + 2) + (LEAN_BLOCK + 2) / 2;
+KG_LEAN_FN uint32_t lean_entry_fwd(int j) { return j ? 64u - 2u * (uint32_t)j : 0u; }                                    // + 32 tid
+KG_LEAN_FN uint32_t lean_entry_rc(uint32_t u) { return ((LEAN_RCW + (u >> 4) + 1u) << 5) | (2u * (~u & 15u)); }          // - 32 tid;  u = T - 1 - k - j
+// the k-mer an entry names, from U (what the copy-out does)
+KG_LEAN_FN uint64_t lean_entry_kmer(const uint32_t* U, uint32_t entry, uint32_t k) {
+    const uint32_t W = (entry >> 5) & 0x7FFu, sh = entry & 31u;
+    const uint32_t h1 = KG_ALIGNBIT(U[W], U[W + 1], sh), h0 = KG_ALIGNBIT(U[W + 1], U[W + 2], sh);
+    return (((uint64_t)h1 << 32) | h0) >> (64 - 2 * k);
+}
+
 }  // namespace kg

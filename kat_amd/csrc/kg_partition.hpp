@@ -22,6 +22,7 @@
 #include "kg_kernels.hpp"
 #include "kg_l1_lean.hpp"
 
+#include <cstddef>
 #include <type_traits>
 
 namespace kg {
@@ -243,20 +244,23 @@ struct P1LdsT {
     cursor_t cursor[PB];                // next item of each bucket's run, counted from the bucket's first item (exact edition) / inside the segment (segmented)
     uint32_t hist[PB + (LEAN ? 64 : 0)];   // (LEAN: + one dump counter per lane of a wave, for the windows that hold no k-mer)
     uint32_t real[SEG ? PB : 1];        // SEG: k-mers in each bucket's segment so far (the cursor counts slots: k-mers + group padding)
-    uint32_t off[PB];
+    uint32_t off[PB + (LEAN ? 64 : 0)];     // (LEAN: the dump counters' "runs" all start at the dump slots behind pos[]: a window without a k-mer is staged like any other, there)
     uint32_t wave_tot[16];
     uint32_t code[P1_BLOCK + 2];
-    uint32_t bad[P1_BLOCK + 2];
+    uint16_t bad[P1_BLOCK + 2];        // (sixteen flags per word of codes; 16-bit entries: the kilobyte that keeps three workgroups on a CU beside the dump slots)
     uint32_t rcode[LEAN ? P1_BLOCK + 2 : 1];   // LEAN: word v = reverse complement of code word 511 - v (the tile read backwards on the other strand)
     uint32_t pad_[2];                   // (pos starts on a 16-byte boundary: the grouped copy-out reads it four entries at a time)
-    uint32_t pos[P1_TILE_BYTES + (SEG ? 3 * PB : 0) + (LEAN ? 32 : 0)];   // per staged k-mer: bucket << 16 | strand << 15 (LEAN) | tile position; SEG: a bucket's run padded to whole groups of four; LEAN: + 32 dump slots
+    uint32_t pos[P1_TILE_BYTES + (SEG ? 3 * PB : 0) + (LEAN ? 128 : 0)];  // per staged k-mer: bucket << 16 | tile position (LEAN: | where the copy-out reads the k-mer from, kg_l1_lean.hpp lean_entry_*); SEG: a bucket's run padded to whole groups of four; LEAN: + 128 dump slots (a dump counter ranks at most 8 lanes x 16 windows per tile)
 };
+static_assert(P1_BLOCK == (int)LEAN_BLOCK, "kg_l1_lean.hpp: the staged entries' arithmetic is written for this tile");
+constexpr uint32_t P1_RCW = LEAN_RCW;     // LEAN: L.rcode lies this many words behind L.code (code | bad | rcode are one array to the copy-out: lean_entry_*)
 constexpr uint32_t P1_PAD = 0xFFFF0000u;   // "no k-mer" in pos[]: the bucket field of an entry is at most 1023, so the top bit says it; read as an entry it is tile position 0
 
 struct LaneWindow {                       // the 96-bit sliding window of kg_kernels.hpp's K1, as an object
     uint64_t hi, lo, m;
     uint32_t kshift, mshift;
-    __device__ __forceinline__ void init(const uint32_t* code, const uint32_t* bad, uint32_t w, uint32_t k) {
+    template <typename BadT>
+    __device__ __forceinline__ void init(const uint32_t* code, const BadT* bad, uint32_t w, uint32_t k) {
         hi = ((uint64_t)code[w] << 32) | code[w + 1];
         lo = (uint64_t)code[w + 2] << 32;
         m = ((uint64_t)bad[w] << 48) | ((uint64_t)bad[w + 1] << 32) | ((uint64_t)bad[w + 2] << 16);
@@ -328,7 +332,7 @@ __device__ __forceinline__ void p1_tile_stage(P1LdsT<LEAN, SEG, PB>& L, const ui
     uint32_t code, bad;
     encode16(w, code, bad);
     L.code[tid] = code;
-    L.bad[tid] = bad;
+    L.bad[tid] = (uint16_t)bad;
     if (LEAN) L.rcode[P1_BLOCK - 1 - tid] = lean_revcomp16(code);
     if (tid < 2) { L.code[P1_BLOCK + tid] = 0; L.bad[P1_BLOCK + tid] = 0xFFFF; if (LEAN) L.rcode[P1_BLOCK + tid] = 0; }
     lds_barrier();
@@ -414,6 +418,8 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
     __shared__ __attribute__((aligned(16))) P1LdsT<LEAN, SEG, PB> L;
     typedef typename P1LdsT<LEAN, SEG, PB>::cursor_t cursor_t;
+    typedef P1LdsT<LEAN, SEG, PB> P1Lds_t;
+    static_assert(!LEAN || offsetof(P1Lds_t, rcode) - offsetof(P1Lds_t, code) == 4 * P1_RCW, "the copy-out reads code | bad | rcode as one array");
     const uint32_t tid = threadIdx.x, P = g.P1, k = t.k;           // P <= PB (host-checked)
     const bool canonical = t.canonical != 0;
     const uint32_t hb1 = g.hb1, gs1 = 16 + 4 * hb1;
@@ -422,24 +428,27 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
     // SEG: this workgroup's segment of bucket b starts seg_off bytes into the bucket (whole groups)
     const uint64_t seg_off = SEG ? (uint64_t)blockIdx.x * (seg_cap >> 2) * gs1 : 0;
     for (uint32_t b = tid; b < P; b += P1_BLOCK) { L.cursor[b] = SEG ? (cursor_t)0 : (cursor_t)(offs[(uint64_t)blockIdx.x * P + b] - l1_off[b]); if (SEG) L.real[b] = 0; }
+    constexpr uint32_t DUMP0 = LEAN ? sizeof(L.pos) / 4 - 128 : 0;                 // LEAN: first dump slot of pos[] (a multiple of 4: a group boundary)
+    static_assert(DUMP0 % 4 == 0, "dump slots");
+    if (LEAN && tid < 64) L.off[PB + tid] = grouped ? DUMP0 / 4 : DUMP0;
     const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, n_tiles);
     u32x4 raw = p1_tile_issue(bases, n, (t0 < t1 ? t0 : 0) * P1_TILE_STARTS);
     for (uint64_t tile = t0; tile < t1; ++tile) {
         uint32_t w[4];
         p1_tile_fix(bases, n, tile * P1_TILE_STARTS, raw, w);
         lds_barrier();                                   // previous tile's copy-out / cursor update done
-        for (uint32_t b = tid; b < PB; b += P1_BLOCK) L.hist[b] = 0;
+        for (uint32_t b = tid; b < PB + (LEAN ? 64 : 0); b += P1_BLOCK) L.hist[b] = 0;     // (the dump counters too: their ranks are slots of the dump area)
         p1_tile_stage(L, w);                               // ends with a barrier
         // sweep 1: bucket and rank of every valid window of this lane
         uint32_t br[PART_ITEMS];
         uint32_t valid = 0;
-        if (LEAN && tid < P1_LANES_WITH_STARTS) {
+        if (LEAN) {                                           // (every lane: the tile's last two hold no window start -- sixteen windows "without a k-mer" each, like any other such window; sweep 2 is straight-line for all)
             // Straight-line: every window is worked whatever its flags say (a lane-divergent branch saves nothing), a window that
             // holds a flagged base ranks in one of 64 dump counters (hist[MAX_PARTS + lane]) instead of a bucket, and a rank is
             // looked at two windows after its atomic was issued: up to three LDS round trips in flight per lane where a branch per
             // window waited for each (sixteen serialised round trips per lane and tile).
             const LeanGeom lg = lean_geom(k, canonical, g.pl.n1);
-            const uint32_t v16 = lean_valid16(L.bad[tid], L.bad[tid + 1], L.bad[tid + 2], k);
+            const uint32_t v16 = tid < P1_LANES_WITH_STARTS ? lean_valid16(L.bad[tid], L.bad[tid + 1], L.bad[tid + 2], k) : 0u;
             LeanWin w{L.code[tid], L.code[tid + 1], L.code[tid + 2], 0, 0};
             uint32_t f_hi, f_lo;
             lean_fwd(w, lg, f_hi, f_lo);
@@ -454,8 +463,9 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                 bool took_rc;                                                // the reverse complement is the canonical form
                 const uint32_t b = lean_digit1(w, lg, g.pl, f_hi, f_lo, key_hi, key_lo, took_rc);
                 const bool ok = (v16 & (0x8000u >> j)) != 0;
-                rk[j] = atomicAdd(&L.hist[ok ? b : dump], 1u);
-                br[j] = (b << 16) | (took_rc ? 0x8000u : 0u);
+                const uint32_t sel = ok ? b : dump;                          // a window without a k-mer: a dump counter is its bucket from here on (sweep 2 stages it in the dump slots, nobody copies it out)
+                rk[j] = atomicAdd(&L.hist[sel], 1u);
+                br[j] = (sel << 16) | (took_rc ? 0x8000u : 0u);
                 if (j >= 2) br[j - 2] |= rk[j - 2];
             }
 #pragma unroll
@@ -497,17 +507,29 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         lds_barrier();
         // sweep 2: park the tile position of every k-mer in its bucket's run
         if (LEAN) {
-            // (straight-line like sweep 1: every window reads its bucket's run start -- the bucket of a window without a k-mer is a valid
-            // index all the same -- and writes; those without a k-mer write into one of 32 dump slots behind the array)
-            constexpr uint32_t DUMP0 = sizeof(L.pos) / 4 - 32;
+            // (straight-line like sweep 1: every window reads its bucket's run start and writes -- a window without a k-mer ranked in a dump
+            // counter, whose "run" is the dump slots behind the array: no test, no select)
             uint32_t run0[PART_ITEMS];
 #pragma unroll
             for (int j = 0; j < PART_ITEMS; ++j) run0[j] = L.off[br[j] >> 16];
+            // What is parked is not the window's tile position but WHERE ITS K-MER IS READ FROM at copy-out (kg_l1_lean.hpp: lean_entry_*): the word
+            // in front of its first code word and the funnel shift, on the stream of the strand sweep 1 chose.  Both are affine in the
+            // lane (a lane's windows start 16 tid + j bases into the tile; the other strand's stream runs backwards, so its word index falls
+            // with tid where the forward one rises, and its shift does not depend on the lane at all: 16 tid has no low nibble), so an entry
+            // costs sweep 2 four operations more than the position did -- and saves the copy-out eleven per staged k-mer (round 5: the
+            // copy-out derived all this from the position, per entry: 22 of its 26 VALU instructions per k-mer).
+            const uint32_t gshift = grouped ? 2u : 0u;          // (off[] counts groups when runs are staged as whole groups)
+            uint32_t base_f = tid * 32u;
+            asm volatile("" : "+v"(base_f));                    // (opaque per tile: sixteen per-lane constants hoisted out of the tile loop cost sixteen registers -- five of them spilled)
+            const uint32_t Q = (uint32_t)P1_TILE_BYTES - 1u - k;
 #pragma unroll
             for (int j = 0; j < PART_ITEMS; ++j) {
-                asm volatile("" : "+v"(run0[j]));               // (keeps the read where it is: sunk into the select below it becomes a branch and a wait per window)
-                const bool ok = (valid >> (15 - j) & 1) != 0;
-                L.pos[ok ? (grouped ? 4 * run0[j] : run0[j]) + (br[j] & 0x7FFFu) : DUMP0 + (tid & 31)] = (br[j] & 0xFFFF8000u) | (tid * PART_ITEMS + j);
+                asm volatile("" : "+v"(run0[j]));               // (keeps the read where it is)
+                const uint32_t cj = lean_entry_fwd(j), sj = lean_entry_rc(Q - (uint32_t)j);     // (wave-uniform)
+                uint32_t on_rc = (uint32_t)((int32_t)(br[j] << 16) >> 31);                      // all ones: the other strand's stream (v_bfe_i32)
+                asm volatile("" : "+v"(on_rc));                 // (a mask, not a condition: one v_bfi_b32 picks the strand's entry)
+                const uint32_t e = ((sj - base_f) & on_rc) | ((base_f + cj) & ~on_rc);
+                L.pos[(run0[j] << gshift) + (br[j] & 0x7FFFu)] = (br[j] & 0xFFFF0000u) | (e & 0xFFFFu);
             }
         } else {
 #pragma unroll
@@ -523,10 +545,14 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
         // before the array, whose value does not matter) and a funnel shift by sh = 30 - 2 (q & 15) = 0 ... 30 -- no special case for a
         // window that starts on a word boundary (v_alignbit_b32 takes its amount mod 32: a shift by 32 it cannot do).
         auto entry_src = [&](uint32_t v, const uint32_t*& src, int32_t& wd, uint32_t& sh) {
-            const uint32_t p = v & (LEAN ? 0x7FFFu : 0xFFFFu);
-            int32_t q = (int32_t)p - 1;
+            if (LEAN) {                                          // sweep 2 parked the answer (kg_l1_lean.hpp: lean_entry_*): two operations instead of thirteen
+                src = L.code - 1;                                // (word 0 = the word in front of L.code: a window that starts on the tile's first base shifts by 0 and never looks at it)
+                wd = (int32_t)((v >> 5) & 0x7FFu); sh = v;       // (v_alignbit_b32 takes its amount mod 32)
+                return;
+            }
+            const uint32_t p = v & 0xFFFFu;
+            const int32_t q = (int32_t)p - 1;
             src = L.code;
-            if (LEAN && (v & 0x8000u)) { q = (int32_t)(P1_TILE_BYTES - 1 - k) - (int32_t)p; src = L.rcode; }   // the other strand's stream, read backwards
             wd = q >> 4; sh = 2u * (~(uint32_t)q & 15u);
         };
         auto entry_key = [&](uint32_t c0, uint32_t c1, uint32_t c2, uint32_t sh) -> uint64_t {
@@ -562,10 +588,18 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
                 uint32_t lo[4], hi[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint64_t r1 = entry_key(c0[q], c1[q], c2[q], o[q]) & g.pl.m1;
                     const uint32_t pad = (uint32_t)((int32_t)ev[q] >> 31);                // all ones for a padding entry
-                    lo[q] = (uint32_t)r1 | pad;
-                    hi[q] = (uint32_t)(r1 >> 32) | pad;
+                    if (LEAN) {
+                        // the item = the k-mer's low n1 bits, n1 >= 32 on this path (lean_applies): the low word whole, n1 - 32 bits of the high
+                        // one -- on 32-bit halves: a funnel shift and a bit-field extract where the 64-bit form shifts and masks twice
+                        const uint32_t h1 = __builtin_amdgcn_alignbit(c0[q], c1[q], o[q]), h0 = __builtin_amdgcn_alignbit(c1[q], c2[q], o[q]);
+                        lo[q] = __builtin_amdgcn_alignbit(h1, h0, 64 - 2 * k) | pad;
+                        hi[q] = __builtin_amdgcn_ubfe(h1, 64 - 2 * k, g.pl.n1 - 32) | pad;
+                    } else {
+                        const uint64_t r1 = entry_key(c0[q], c1[q], c2[q], o[q]) & g.pl.m1;
+                        lo[q] = (uint32_t)r1 | pad;
+                        hi[q] = (uint32_t)(r1 >> 32) | pad;
+                    }
                 }
                 if (room) {
                     const u32x4 glo = {lo[0], lo[1], lo[2], lo[3]};

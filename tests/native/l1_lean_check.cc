@@ -86,6 +86,29 @@ int main() {
                 if (lean_kmer_at(rcode, T - k - p, k) != naive_revcomp(fw, k)) { printf("rc stream mismatch k=%u p=%u\n", k, p); return 1; }
                 ++checked;
             }
+        // what sweep 2 parks per staged k-mer and the copy-out reads the k-mer by (lean_entry_*): every window of every lane, both strands
+        static uint32_t U[1 + 3 * (W + 2)];
+        for (uint32_t& x : U) x = 0xA5A5A5A5u;                                   // (the word in front of code, the flags between the streams: looked at by nobody)
+        for (uint32_t w = 0; w < W + 2; ++w) { U[1 + w] = code[w]; U[1 + LEAN_RCW + w] = rcode[w]; }
+        static_assert(LEAN_BLOCK == W && LEAN_RCW == (W + 2) + (W + 2) / 2, "tile");
+        for (uint32_t k = 17; k <= 31; ++k)
+            for (uint32_t tid = 0; tid < W; ++tid)
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t p = 16 * tid + (uint32_t)j;
+                    if (p + k > T) continue;
+                    uint64_t fw = 0;
+                    for (uint32_t i = 0; i < k; ++i) fw = (fw << 2) | base[p + i];
+                    const uint32_t ef = (32u * tid + lean_entry_fwd(j)) & 0xFFFFu, er = (lean_entry_rc(T - 1 - k - (uint32_t)j) - 32u * tid) & 0xFFFFu;
+                    if (lean_entry_kmer(U, ef, k) != fw) { printf("entry (forward) mismatch k=%u tid=%u j=%d\n", k, tid, j); return 1; }
+                    if (lean_entry_kmer(U, er, k) != naive_revcomp(fw, k)) { printf("entry (other strand) mismatch k=%u tid=%u j=%d\n", k, tid, j); return 1; }
+                    // and through the arithmetic sweep 2 uses (one expression for both strands)
+                    for (uint32_t strand = 0; strand < 2; ++strand) {
+                        const uint32_t base_f = 32u * tid, cj = lean_entry_fwd(j), sj = lean_entry_rc(T - 1 - k - (uint32_t)j);
+                        const uint32_t e = (base_f + cj + strand * (sj - cj - 2u * base_f)) & 0xFFFFu;
+                        if (e != (strand ? er : ef)) { printf("entry arithmetic mismatch k=%u tid=%u j=%d strand=%u\n", k, tid, j, strand); return 1; }
+                    }
+                    ++checked;
+                }
     }
     printf("l1 lean ok: %llu windows\n", (unsigned long long)checked);
     return 0;
