@@ -13,7 +13,8 @@
  *   - one caller thread per ctx; a table is immutable once counting has finished, so reducers may be
  *     called in any order, any number of times;
  *   - k-mers are 2-bit packed, first base in the most significant bits, A=0 C=1 G=2 T=3
- *     (JF/include/jellyfish/mer_dna.hpp:46-63,330-353).  This build supports 1 <= k <= 32.
+ *     (JF/include/jellyfish/mer_dna.hpp:46-63,330-353).  1 <= k <= KATGPU_MAX_K = 63: one 64-bit word up to k = 32,
+ *     two 63-bit words beyond ("wide" tables); k >= 64 gives KATGPU_ERR_K.
  *   - there is NO CPU fallback: without a gfx950 device katgpu_init fails with KATGPU_ERR_DEVICE.
  */
 #ifndef KATGPU_H

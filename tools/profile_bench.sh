@@ -6,9 +6,9 @@
 # --kernel-trace --stats (per-kernel durations), and two --pmc passes (FETCH_SIZE, WRITE_SIZE; counters are collected in their own
 # runs, with --kernel-trace only).  The other workloads: plain, --kernel-trace --stats, and the same two --pmc passes (tools/profile_pmc_workload.sh: the two
 # counters cannot be collected in one pass on gfx950 -- rocprofv3 aborts with "exceeds the capabilities of the hardware" and then hangs).
-# Then config 4 from files to files at full size (tools/e2e_config4.py) -> <tag>_e2e_config4.json.
+# Config 4 from files to files at full size is the plain line's `end_to_end` leg (bench.py; tools/e2e_config4.py runs it on its own).
 set -u
-tag=${1:-r04_final}
+tag=${1:-r05_final}
 root=$PWD
 out=$PWD/gpurun_out
 mkdir -p "$out"
@@ -51,7 +51,7 @@ for w in hist gcp comp-rr; do
   cp "$out/${tag}_${w}_pmc_fetch_write.json" "$root/profiles/${tag}_${w}_pmc_fetch_write.json"
   timeout 600 python "$root/bench.py" --workload $w --steps 3 --warmup 1 --no-e2e --no-cpu-baseline > "$out/${tag}_${w}_bench.json" 2> "$out/${tag}_${w}_bench.err"
 done
-timeout 900 python "$root/tools/e2e_config4.py" > "$out/${tag}_e2e_config4.json" 2> "$out/${tag}_e2e_config4.err"
+# (config 4 from files to files at full size is part of the plain line above since round 5: end_to_end, with its result_check)
 # SQ view of the stage kernels (one partition round of a reduced config): wave cycles, waits, issue, LDS conflicts
 rm -rf /tmp/prof_sq
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d /tmp/prof_sq -- python "$root/bench.py" --reads 60000000 --genome 200000000 $quiet > /dev/null 2> "$out/${tag}_sq.err"
