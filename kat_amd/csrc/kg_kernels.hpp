@@ -336,12 +336,20 @@ __device__ __forceinline__ void block_sum_u64(unsigned long long* s_acc, int slo
 }
 
 // Per-lane running sums of one comp pass
-struct CompAcc { uint64_t a_total = 0, a_distinct = 0, a_only_total = 0, a_only_distinct = 0, sh_a = 0, sh_b = 0, sh_n = 0; };
+// (the tallies of k-mers are per lane: a lane sees fewer than 2^32 slots of any table that fits the device; the sums of counts stay 64-bit)
+struct CompAcc { uint64_t a_total = 0, a_only_total = 0, sh_a = 0, sh_b = 0; uint32_t a_distinct = 0, a_only_distinct = 0, sh_n = 0; };
+
+// The two increments nearly every lane of a wave wants at once: "seen once here, absent there" and "count 1" -- the sequencing-error
+// k-mers of a read set, the unique k-mers of an assembly.  As LDS atomics they are 64 lanes on ONE address, served one lane a cycle
+// (24 % of k_comp_fused's cycles at config 4 were LDS bank-conflict cycles); a CompHot keeps them as a per-lane tally instead, added to
+// the tile / the spectrum once at the end of the kernel (comp_hot_flush).  Which cell and bin those are follows from the scales, so the
+// kernel asks comp_cell for them rather than assuming (1, 0).
+struct CompHot { uint32_t tile_cell = 0xFFFFFFFFu, spec_bin = 0xFFFFFFFFu, n_tile = 0, n_spec = 0; };
 
 // What one k-mer of the scanned table contributes once its count in the other table (cb) is known.  All lanes of the
 // wave call this together (the LDS increments are wave-aggregated with ballots); occ says whether the lane holds a k-mer.
-template <int PASS>
-__device__ __forceinline__ void comp_account(bool occ, uint64_t ca, uint64_t cb, const CompArgs& a, uint32_t* s_tile, uint32_t* s_spec, CompAcc& acc) {
+template <int PASS, bool HOT = false>
+__device__ __forceinline__ void comp_account(bool occ, uint64_t ca, uint64_t cb, const CompArgs& a, uint32_t* s_tile, uint32_t* s_spec, CompAcc& acc, CompHot* hot = nullptr) {
     uint32_t cell = 0;
     bool in_tile = false, in_mx = false;
     if (occ) {
@@ -363,17 +371,46 @@ __device__ __forceinline__ void comp_account(bool occ, uint64_t ca, uint64_t cb,
             cell = (uint32_t)s2;                                            // row 0 in both the tile and the matrix
         }
     }
-    comp_inc(a, s_tile, cell, in_mx && in_tile);
+    bool to_tile = in_mx && in_tile;
+    if constexpr (HOT) { const bool h = to_tile && cell == hot->tile_cell; hot->n_tile += h ? 1u : 0u; to_tile = to_tile && !h; }
+    comp_inc(a, s_tile, cell, to_tile);
     if (in_mx && !in_tile) atomicAdd(&a.main_mx[cell], 1ULL);
     // CompArgs::fold (unscaled bins, more than COMP_TILE of them): a k-mer of pass 1 that lands in the tile has s1 == ca < 64 and
     // s2 == cb < 64, so spectrum1, shared_spectrum1 and shared_spectrum2 are marginals of the tile -- comp_flush adds them; one LDS
     // atomic per k-mer instead of four (the spectra's hot bins are the same few addresses for every lane of the chip)
     if (PASS == 1 && a.fold) occ = occ && !in_tile;
-    comp_inc(a, s_spec, spectrum_bin(ca, a.spec_size), occ);                            // spectrum1 / spectrum2
+    const uint32_t sbin = spectrum_bin(ca, a.spec_size);
+    bool to_spec = occ;
+    if constexpr (HOT) { const bool h = to_spec && sbin == hot->spec_bin; hot->n_spec += h ? 1u : 0u; to_spec = to_spec && !h; }
+    comp_inc(a, s_spec, sbin, to_spec);                                                 // spectrum1 / spectrum2
     if (PASS == 1) {
         bool shared = occ && ca && cb;
         comp_inc(a, s_spec + a.spec_size, spectrum_bin(ca, a.spec_size), shared);         // shared_spectrum1
         comp_inc(a, s_spec + 2 * a.spec_size, spectrum_bin(cb, a.spec_size), shared);     // shared_spectrum2
+    }
+}
+
+// the tile cell comp_account<PASS> gives a k-mer of these counts (0xFFFFFFFF: none, or outside the tile): where a CompHot listens
+template <int PASS>
+__device__ __forceinline__ uint32_t comp_tile_cell(uint64_t ca, uint64_t cb, const CompArgs& a) {
+    if (PASS == 1) {
+        uint64_t s1 = scale_count(ca, a.d1_scale), s2 = scale_count(cb, a.d2_scale);
+        if (s1 >= a.d1_bins) s1 = a.d1_bins - 1;
+        if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
+        return s1 < COMP_TILE && s2 < COMP_TILE ? (uint32_t)(s1 * COMP_TILE + s2) : 0xFFFFFFFFu;
+    }
+    if (cb) return 0xFFFFFFFFu;
+    uint64_t s2 = scale_count(ca, a.d2_scale);
+    if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
+    return s2 < COMP_TILE ? (uint32_t)s2 : 0xFFFFFFFFu;
+}
+// a CompHot's tallies into the tile and the spectrum they were kept out of: one LDS atomic per wave and target (before comp_flush)
+__device__ __forceinline__ void comp_hot_flush(const CompHot& h, uint32_t* s_tile, uint32_t* s_spec) {
+    uint32_t nt = h.n_tile, ns = h.n_spec;
+    for (int off = 32; off > 0; off >>= 1) { nt += __shfl_down(nt, off, 64); ns += __shfl_down(ns, off, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (nt) atomicAdd(&s_tile[h.tile_cell], nt);
+        if (ns) atomicAdd(&s_spec[h.spec_bin], ns);
     }
 }
 
@@ -625,9 +662,16 @@ k_comp_seen(DevTable ta /* hash 2 */, uint32_t na_ovf, CompArgs a) {
 //   SWAP = true:  hash 2 resident, hash 1 streamed.  A streamed k-mer is pass 1's item (count in 1, count in 2 or 0); the sweep is
 //                 pass 2: every k-mer of hash 2, found or not.
 // LDS: 16 u64 accumulators (0-6 pass 1, 8-11 pass 2) | tile 64 x 64 u32 | spectra 3 x ss (pass 1) | spectrum ss (pass 2) | the
-// resident region's S words | S / 32 mark words.
-constexpr int FUSED_BLOCK = 1024, FUSED_KP = 5;               // 5 x 1024 x 2 slots: resident regions of up to 10240 slots
-template <bool SWAP>
+// resident region's S words + FUSED_STEP | S / 32 mark words.
+constexpr int FUSED_BLOCK = 1024, FUSED_KP = 5;               // 5 x 1024 x 2 slots: regions of up to 10240 slots (resident and streamed)
+constexpr int FUSED_STEP = 4;                                 // slots per step of the walk through the resident region (two ds_read2_b64)
+typedef uint64_t u64x2a8 __attribute__((ext_vector_type(2), aligned(8)));
+// JP: 16-byte pairs of streamed slots per lane -- the WHOLE streamed region sits in registers, loaded one region ahead: pair u of the
+// next region is requested the moment pair u of this one has been taken out of its registers, so every HBM request has a region's
+// worth of work (the other pairs, the sweep, the next store) to land behind.  (Round 4's form loaded 4 slots per lane, waited the full
+// HBM latency and worked them off, two to three times per region: half of every wave's cycles were that wait.)  Wave-items past the
+// region's end are skipped by the wave, not masked: a region of 6256 slots is 3.05 pairs per lane, not 4.
+template <bool SWAP, int JP>
 __global__ void __launch_bounds__(FUSED_BLOCK)
 k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -640,78 +684,104 @@ k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArg
     const uint32_t nr_ovf = SWAP ? n2_ovf : n1_ovf, ns_ovf = SWAP ? n1_ovf : n2_ovf;
     const uint32_t Sr = tr.region_slots, Ss = ts.region_slots, cb = tr.cbits;          // one grid: one remainder width, one cbits
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(s_raw + ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * a.spec_size * 4 + 15) & ~15u));
-    uint32_t* s_mark = reinterpret_cast<uint32_t*>(rk + Sr);
+    uint32_t* s_mark = reinterpret_cast<uint32_t*>(rk + Sr + FUSED_STEP);            // (rk[Sr ..]: the region's first slots again)
     const uint32_t mark_words = (Sr + 31) / 32;
     const uint32_t tid = threadIdx.x;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid & ~63u);                 // this wave's first lane, as a scalar
     comp_lds_init(a, 1, s_acc, s_tile, s_spec1);
     for (uint32_t i = tid; i < a.spec_size; i += blockDim.x) s_spec2[i] = 0;
     CompAcc acc1, acc2;
+    // what the streamed k-mers and the swept ones mostly are: count 1, absent from the other table (CompHot)
+    CompHot hot_s, hot_r;
+    hot_s.tile_cell = SWAP ? comp_tile_cell<1>(1, 0, a) : comp_tile_cell<2>(1, 0, a);
+    hot_r.tile_cell = SWAP ? comp_tile_cell<2>(1, 0, a) : comp_tile_cell<1>(1, 0, a);
+    hot_s.spec_bin = hot_r.spec_bin = spectrum_bin(1, a.spec_size);
     const Place pl = place_make(tr.k, tr.p1, tr.n1, tr.l2);
     const uint32_t R = tr.n_regions;
-    u32x4s kq[FUSED_KP];
+    u32x4s kq[FUSED_KP], wq[JP];
     auto prefetch = [&](uint32_t r) {                          // the resident region, 16 bytes per lane and load, clamped and unconditional
         const uint64_t base = (uint64_t)r * Sr;
 #pragma unroll
         for (int u = 0; u < FUSED_KP; ++u) { const uint32_t i = (u * FUSED_BLOCK + tid) * 2; kq[u] = *reinterpret_cast<const u32x4s*>(tr.keys + base + (i < Sr ? i : 0)); }
     };
-    if (blockIdx.x < R) prefetch(blockIdx.x);
+    auto stream_pair = [&](uint32_t r, int u) {                // pair u of the streamed region (both region sizes are multiples of 4)
+        const uint32_t i = (u * FUSED_BLOCK + tid) * 2;
+        return *reinterpret_cast<const u32x4s*>(ts.keys + (uint64_t)r * Ss + (i < Ss ? i : 0));
+    };
+    if (blockIdx.x < R) {
+        prefetch(blockIdx.x);
+#pragma unroll
+        for (int u = 0; u < JP; ++u) wq[u] = stream_pair(blockIdx.x, u);
+    }
     for (uint32_t r = blockIdx.x; r < R; r += gridDim.x) {
         __syncthreads();                                       // the previous region's sweep is through
 #pragma unroll
         for (int u = 0; u < FUSED_KP; ++u) { const uint32_t i = (u * FUSED_BLOCK + tid) * 2; if (i < Sr) *reinterpret_cast<u32x4s*>(rk + i) = kq[u]; }
+        if (tid * 2 < FUSED_STEP) *reinterpret_cast<u32x4s*>(rk + Sr + tid * 2) = kq[0];         // slots 0 .. FUSED_STEP - 1 once more, behind the last
         for (uint32_t i = tid; i < mark_words; i += blockDim.x) s_mark[i] = 0;
         __syncthreads();
-        if (r + gridDim.x < R) prefetch(r + gridDim.x);          // the next one: in flight behind this region's work
+        const uint32_t rn = r + gridDim.x < R ? r + gridDim.x : r;   // (the last region asks for itself again: the loads stay unconditional)
+        prefetch(rn);                                          // the next one: in flight behind this region's work
         const uint64_t rbase = (uint64_t)r * Sr, sbase = (uint64_t)r * Ss;
-        constexpr int JB = 4;
-        for (uint32_t i0 = 0; i0 < Ss; i0 += JB * blockDim.x) {            // uniform trip count: ballots inside comp_account
-            uint64_t w[JB];
 #pragma unroll
-            for (int u = 0; u < JB; ++u) {
-                const uint32_t i = i0 + u * blockDim.x + tid;
-                w[u] = ts.keys[sbase + (i < Ss ? i : Ss - 1)];
-                if (i >= Ss) w[u] = 0;
-            }
-#pragma unroll
-            for (int u = 0; u < JB; ++u) {
-                const bool occ = w[u] != 0;
+        for (int u = 0; u < JP; ++u) {
+            const u32x4s x = wq[u];
+            wq[u] = stream_pair(rn, u);
+            if ((u * FUSED_BLOCK + wave0) * 2 >= Ss) continue;               // nothing of the region left for this wave (uniform in the wave)
+            const uint32_t i = (u * FUSED_BLOCK + tid) * 2;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {                                   // (a loop, not two copies: the body is ~1000 instructions with its cold paths)
+                const uint64_t w = i < Ss ? ((uint64_t)(h ? x.w : x.y) << 32) | (h ? x.z : x.x) : 0ULL;
+                const bool occ = w != 0;
                 uint64_t cs = 0, cr = 0;                                     // count in the streamed table, in the resident one
                 if (occ) {
-                    const uint32_t i = i0 + u * blockDim.x + tid;
-                    cs = pk_count(w[u], cb);
-                    if (ns_ovf) cs += ovf_get(ts, sbase + i);
-                    const uint64_t rem = pk_rem(w[u], cb);
+                    cs = pk_count(w, cb);
+                    if (ns_ovf) cs += ovf_get(ts, sbase + i + h);
+                    const uint64_t rem = pk_rem(w, cb);
                     uint32_t s = place_offset(rem, pl, Sr);
-                    for (uint32_t probe = 0; probe < Sr; ++probe) {
-                        const unsigned long long cur = rk[s];
-                        if (cur == 0) break;
-                        if ((cur >> cb) == rem) {
-                            cr = pk_count(cur, cb);
-                            if (nr_ovf) cr += ovf_get(tr, rbase + s);
-                            atomicOr(&s_mark[s >> 5], 1u << (s & 31));
-                            break;
+                    // the walk, FUSED_STEP slots per LDS round trip (the region is followed by a copy of its first slots, so a step never
+                    // wraps): what bounds a wave is its longest walk times the LDS latency -- 3.6 slots on average for a k-mer the resident
+                    // table does not hold, some thirty for the unluckiest of 64 lanes
+                    for (uint32_t probe = 0; probe < Sr; probe += FUSED_STEP) {
+                        const u64x2a8 c01 = *reinterpret_cast<const u64x2a8*>(rk + s), c23 = *reinterpret_cast<const u64x2a8*>(rk + s + 2);
+                        const unsigned long long c[FUSED_STEP] = {c01.x, c01.y, c23.x, c23.y};
+                        int hit = -1; bool stop = false;                      // the first slot that is empty (stop) or holds the k-mer (hit)
+#pragma unroll
+                        for (int j = FUSED_STEP - 1; j >= 0; --j) {
+                            const bool e = c[j] == 0, m = (c[j] >> cb) == rem;
+                            if (e) { stop = true; hit = -1; } else if (m) { stop = true; hit = j; }
                         }
-                        s = s + 1 == Sr ? 0 : s + 1;
+                        if (hit >= 0) {
+                            const unsigned long long cur = hit == 0 ? c[0] : hit == 1 ? c[1] : hit == 2 ? c[2] : c[3];
+                            uint32_t at = s + (uint32_t)hit; at = at >= Sr ? at - Sr : at;
+                            cr = pk_count(cur, cb);
+                            if (nr_ovf) cr += ovf_get(tr, rbase + at);
+                            atomicOr(&s_mark[at >> 5], 1u << (at & 31));
+                        }
+                        if (stop) break;
+                        s += FUSED_STEP; s = s >= Sr ? s - Sr : s;
                     }
                 }
-                if (SWAP) comp_account<1>(occ, cs, cr, a, s_tile, s_spec1, acc1);                       // streamed = hash 1
+                if (SWAP) comp_account<1, true>(occ, cs, cr, a, s_tile, s_spec1, acc1, &hot_s);         // streamed = hash 1
                 else {
                     comp_account<1>(occ && cr != 0, cr, cs, a, s_tile, s_spec1, acc1);                   // the pair, seen from hash 1
-                    comp_account<2>(occ, cs, cr, a, s_tile, s_spec2, acc2);                              // streamed = hash 2
+                    comp_account<2, true>(occ, cs, cr, a, s_tile, s_spec2, acc2, &hot_s);                // streamed = hash 2
                 }
             }
         }
         __syncthreads();                                       // every mark is in
-        for (uint32_t i0 = 0; i0 < Sr; i0 += blockDim.x) {                 // uniform trip count
+        for (uint32_t i0 = 0; i0 + wave0 < Sr; i0 += blockDim.x) {        // (trip count uniform in the wave: ballots inside comp_account)
             const uint32_t i = i0 + tid;
             const unsigned long long cur = i < Sr ? rk[i] : 0ULL;
             const bool marked = i < Sr && ((s_mark[i >> 5] >> (i & 31)) & 1u);
             uint64_t cr = 0;
             if (cur != 0) { cr = pk_count(cur, cb); if (nr_ovf) cr += ovf_get(tr, rbase + i); }
-            if (SWAP) comp_account<2>(cur != 0, cr, marked ? 1ULL : 0ULL, a, s_tile, s_spec2, acc2);     // resident = hash 2: all of it
-            else comp_account<1>(cur != 0 && !marked, cr, 0ULL, a, s_tile, s_spec1, acc1);               // resident = hash 1: what hash 2 lacks
+            if (SWAP) comp_account<2, true>(cur != 0, cr, marked ? 1ULL : 0ULL, a, s_tile, s_spec2, acc2, &hot_r);     // resident = hash 2: all of it
+            else comp_account<1, true>(cur != 0 && !marked, cr, 0ULL, a, s_tile, s_spec1, acc1, &hot_r);               // resident = hash 1: what hash 2 lacks
         }
     }
+    comp_hot_flush(hot_s, s_tile, SWAP ? s_spec1 : s_spec2);
+    comp_hot_flush(hot_r, s_tile, SWAP ? s_spec2 : s_spec1);
     __syncthreads();
     comp_flush<1>(a, s_acc, s_tile, s_spec1, acc1);
     __syncthreads();

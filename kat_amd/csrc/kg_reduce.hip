@@ -115,8 +115,10 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     // past the other one's regions in LDS.
     const bool swap = t1->distinct < t2->distinct;           // hash 1 is the smaller one: it streams, hash 2 is resident
     const uint32_t s_res = swap ? t2->dev().region_slots : t1->dev().region_slots;
-    const size_t fused_lds = ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * (size_t)ss * 4 + 15) & ~(size_t)15) + (size_t)s_res * 8 + (size_t)((s_res + 31) / 32) * 4;
-    const bool fused = pk && same_grid && !g_no_fused && t1->dev().canonical && t2->dev().canonical && s_res <= (uint32_t)FUSED_KP * FUSED_BLOCK * 2 && fused_lds <= 160 * 1024 - 512;
+    const size_t fused_lds = ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * (size_t)ss * 4 + 15) & ~(size_t)15) + ((size_t)s_res + FUSED_STEP) * 8 + (size_t)((s_res + 31) / 32) * 4;
+    const uint32_t s_str = swap ? t1->dev().region_slots : t2->dev().region_slots;
+    const bool fused = pk && same_grid && !g_no_fused && t1->dev().canonical && t2->dev().canonical && s_res <= (uint32_t)FUSED_KP * FUSED_BLOCK * 2 &&
+                       s_str <= (uint32_t)FUSED_KP * FUSED_BLOCK * 2 && fused_lds <= 160 * 1024 - 512;
     // pass 1 as a join can leave a bit per slot of hash 2 ("hash 1 holds this k-mer"); pass 2 is then a scan of hash 2 (k_comp_seen)
     const bool join_1 = same_grid && ident1 && (g_force_join || join_pays(t1, t2));
     const uint32_t wpr = (t2->dev().region_slots + 31) / 32;
@@ -137,10 +139,14 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     if (fused) {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->dev().cap + t2->dev().cap);
         const uint32_t grid = std::min<uint32_t>(t1->dev().n_regions, (uint32_t)c->n_cu);
-        if (swap) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-                    hipLaunchKernelGGL(k_comp_fused<true>, dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, a); }
-        else { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-               hipLaunchKernelGGL(k_comp_fused<false>, dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, a); }
+        // the streamed region in registers, 16-byte pairs of slots per lane: 3, 4 or 5 of them (kg_kernels.hpp: k_comp_fused)
+        const int jp = s_str <= 3 * FUSED_BLOCK * 2 ? 3 : s_str <= 4 * FUSED_BLOCK * 2 ? 4 : 5;
+#define KG_FUSED(SWAP, JP) do { \
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_fused<SWAP, JP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); \
+            hipLaunchKernelGGL((k_comp_fused<SWAP, JP>), dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, a); } while (0)
+        if (swap) { if (jp == 3) KG_FUSED(true, 3); else if (jp == 4) KG_FUSED(true, 4); else KG_FUSED(true, 5); }
+        else { if (jp == 3) KG_FUSED(false, 3); else if (jp == 4) KG_FUSED(false, 4); else KG_FUSED(false, 5); }
+#undef KG_FUSED
     }
 #define KG_JOIN(PASS, TA, TB, LDS) do { \
         if (pk) { HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_join<PASS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
