@@ -12,6 +12,7 @@
 // none of it is a contraction, so no MFMA anywhere.
 #pragma once
 #include "kg_device.hpp"
+#include <type_traits>
 
 namespace kg {
 
@@ -246,6 +247,13 @@ __device__ __forceinline__ uint64_t scale_count(uint64_t c, double scale) {
     if (scale == 1.0) return c;            // (the default; uniform.  Every caller clamps to its bins, so counts beyond 2^53 end up the same)
     return c == 0 ? 0 : (uint64_t)ceil((double)c * scale);
 }
+// the same on a count known to fit 32 bits (a packed slot's, with no side-table entries): saturates, and every caller clamps to its bins
+__device__ __forceinline__ uint32_t scale_count(uint32_t c, double scale) {
+    if (scale == 1.0) return c;
+    if (c == 0) return 0;
+    const double v = ceil((double)c * scale);
+    return v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v;
+}
 
 // K4.  Gcp::analyseSlice (src/gcp.cc:179-197): row = popcount-based GC count, column = min(ceil(count*scale), bins).
 // The whole k x (bins+1) matrix is privatised in LDS as u32 when it fits (27 x 1001 x 4 B = 108 KB of the 160 KB).
@@ -329,6 +337,7 @@ __device__ __forceinline__ void comp_inc(const CompArgs& a, uint32_t* bins, uint
     else lds_inc_aggregated(bins, idx, active);
 }
 __device__ __forceinline__ uint32_t spectrum_bin(uint64_t c, uint32_t size) { return c >= size ? size - 1 : (uint32_t)c; }  // comp_counters.cc:130-140
+__device__ __forceinline__ uint32_t spectrum_bin(uint32_t c, uint32_t size) { return c >= size ? size - 1 : c; }
 
 __device__ __forceinline__ void block_sum_u64(unsigned long long* s_acc, int slot, uint64_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -348,8 +357,8 @@ struct CompHot { uint32_t tile_cell = 0xFFFFFFFFu, spec_bin = 0xFFFFFFFFu, n_til
 
 // What one k-mer of the scanned table contributes once its count in the other table (cb) is known.  All lanes of the
 // wave call this together (the LDS increments are wave-aggregated with ballots); occ says whether the lane holds a k-mer.
-template <int PASS, bool HOT = false>
-__device__ __forceinline__ void comp_account(bool occ, uint64_t ca, uint64_t cb, const CompArgs& a, uint32_t* s_tile, uint32_t* s_spec, CompAcc& acc, CompHot* hot = nullptr) {
+template <int PASS, bool HOT = false, typename T = uint64_t /* the counts' type: uint32_t where the caller knows they fit (k_comp_fused without side-table entries) */>
+__device__ __forceinline__ void comp_account(bool occ, T ca, T cb, const CompArgs& a, uint32_t* s_tile, uint32_t* s_spec, CompAcc& acc, CompHot* hot = nullptr) {
     uint32_t cell = 0;
     bool in_tile = false, in_mx = false;
     if (occ) {
@@ -357,14 +366,14 @@ __device__ __forceinline__ void comp_account(bool occ, uint64_t ca, uint64_t cb,
         if (!cb) { acc.a_only_total += ca; acc.a_only_distinct += 1; }
         if (PASS == 1) {
             if (ca && cb) { acc.sh_a += ca; acc.sh_b += cb; acc.sh_n += 1; }
-            uint64_t s1 = scale_count(ca, a.d1_scale), s2 = scale_count(cb, a.d2_scale);
+            T s1 = scale_count(ca, a.d1_scale), s2 = scale_count(cb, a.d2_scale);
             if (s1 >= a.d1_bins) s1 = a.d1_bins - 1;
             if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
             in_mx = true;
             in_tile = s1 < COMP_TILE && s2 < COMP_TILE;
-            cell = in_tile ? (uint32_t)(s1 * COMP_TILE + s2) : (uint32_t)(s1 * a.d2_bins + s2);
+            cell = in_tile ? (uint32_t)s1 * COMP_TILE + (uint32_t)s2 : (uint32_t)s1 * a.d2_bins + (uint32_t)s2;
         } else if (!cb) {                                                  // only k-mers absent from hash 1 (src/comp.cc:453-462)
-            uint64_t s2 = scale_count(ca, a.d2_scale);
+            T s2 = scale_count(ca, a.d2_scale);
             if (s2 >= a.d2_bins) s2 = a.d2_bins - 1;
             in_mx = true;
             in_tile = s2 < COMP_TILE;
@@ -671,7 +680,9 @@ typedef uint64_t u64x2a8 __attribute__((ext_vector_type(2), aligned(8)));
 // worth of work (the other pairs, the sweep, the next store) to land behind.  (Round 4's form loaded 4 slots per lane, waited the full
 // HBM latency and worked them off, two to three times per region: half of every wave's cycles were that wait.)  Wave-items past the
 // region's end are skipped by the wave, not masked: a region of 6256 slots is 3.05 pairs per lane, not 4.
-template <bool SWAP, int JP>
+// OVF: some count of either table continues in its side table (katgpu_table::n_ovf); without, a count is the low cbits <= 32 bits of its
+// slot and the whole account runs on 32-bit counts (the kernel is bound by VALU issue: ~230 instructions per streamed + swept slot).
+template <bool SWAP, int JP, bool OVF>
 __global__ void __launch_bounds__(FUSED_BLOCK)
 k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -681,7 +692,8 @@ k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArg
     uint32_t* s_spec2 = s_spec1 + 3 * a.spec_size;
     const DevTable& tr = SWAP ? t2 : t1;                      // resident
     const DevTable& ts = SWAP ? t1 : t2;                      // streamed
-    const uint32_t nr_ovf = SWAP ? n2_ovf : n1_ovf, ns_ovf = SWAP ? n1_ovf : n2_ovf;
+    const uint32_t nr_ovf = OVF ? (SWAP ? n2_ovf : n1_ovf) : 0u, ns_ovf = OVF ? (SWAP ? n1_ovf : n2_ovf) : 0u;
+    typedef typename std::conditional<OVF, uint64_t, uint32_t>::type CT;                // a count
     const uint32_t Sr = tr.region_slots, Ss = ts.region_slots, cb = tr.cbits;          // one grid: one remainder width, one cbits
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(s_raw + ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * a.spec_size * 4 + 15) & ~15u));
     uint32_t* s_mark = reinterpret_cast<uint32_t*>(rk + Sr + FUSED_STEP);            // (rk[Sr ..]: the region's first slots again)
@@ -695,7 +707,7 @@ k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArg
     CompHot hot_s, hot_r;
     hot_s.tile_cell = SWAP ? comp_tile_cell<1>(1, 0, a) : comp_tile_cell<2>(1, 0, a);
     hot_r.tile_cell = SWAP ? comp_tile_cell<2>(1, 0, a) : comp_tile_cell<1>(1, 0, a);
-    hot_s.spec_bin = hot_r.spec_bin = spectrum_bin(1, a.spec_size);
+    hot_s.spec_bin = hot_r.spec_bin = spectrum_bin(1u, a.spec_size);
     const Place pl = place_make(tr.k, tr.p1, tr.n1, tr.l2);
     const uint32_t R = tr.n_regions;
     u32x4s kq[FUSED_KP], wq[JP];
@@ -733,10 +745,10 @@ k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArg
             for (int h = 0; h < 2; ++h) {                                   // (a loop, not two copies: the body is ~1000 instructions with its cold paths)
                 const uint64_t w = i < Ss ? ((uint64_t)(h ? x.w : x.y) << 32) | (h ? x.z : x.x) : 0ULL;
                 const bool occ = w != 0;
-                uint64_t cs = 0, cr = 0;                                     // count in the streamed table, in the resident one
+                CT cs = 0, cr = 0;                                           // count in the streamed table, in the resident one
                 if (occ) {
-                    cs = pk_count(w, cb);
-                    if (ns_ovf) cs += ovf_get(ts, sbase + i + h);
+                    cs = (CT)pk_count(w, cb);
+                    if (OVF && ns_ovf) cs += (CT)ovf_get(ts, sbase + i + h);
                     const uint64_t rem = pk_rem(w, cb);
                     uint32_t s = place_offset(rem, pl, Sr);
                     // the walk, FUSED_STEP slots per LDS round trip (the region is followed by a copy of its first slots, so a step never
@@ -754,8 +766,8 @@ k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArg
                         if (hit >= 0) {
                             const unsigned long long cur = hit == 0 ? c[0] : hit == 1 ? c[1] : hit == 2 ? c[2] : c[3];
                             uint32_t at = s + (uint32_t)hit; at = at >= Sr ? at - Sr : at;
-                            cr = pk_count(cur, cb);
-                            if (nr_ovf) cr += ovf_get(tr, rbase + at);
+                            cr = (CT)pk_count(cur, cb);
+                            if (OVF && nr_ovf) cr += (CT)ovf_get(tr, rbase + at);
                             atomicOr(&s_mark[at >> 5], 1u << (at & 31));
                         }
                         if (stop) break;
@@ -774,10 +786,10 @@ k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArg
             const uint32_t i = i0 + tid;
             const unsigned long long cur = i < Sr ? rk[i] : 0ULL;
             const bool marked = i < Sr && ((s_mark[i >> 5] >> (i & 31)) & 1u);
-            uint64_t cr = 0;
-            if (cur != 0) { cr = pk_count(cur, cb); if (nr_ovf) cr += ovf_get(tr, rbase + i); }
-            if (SWAP) comp_account<2, true>(cur != 0, cr, marked ? 1ULL : 0ULL, a, s_tile, s_spec2, acc2, &hot_r);     // resident = hash 2: all of it
-            else comp_account<1, true>(cur != 0 && !marked, cr, 0ULL, a, s_tile, s_spec1, acc1, &hot_r);               // resident = hash 1: what hash 2 lacks
+            CT cr = 0;
+            if (cur != 0) { cr = (CT)pk_count(cur, cb); if (OVF && nr_ovf) cr += (CT)ovf_get(tr, rbase + i); }
+            if (SWAP) comp_account<2, true>(cur != 0, cr, (CT)(marked ? 1 : 0), a, s_tile, s_spec2, acc2, &hot_r);     // resident = hash 2: all of it
+            else comp_account<1, true>(cur != 0 && !marked, cr, (CT)0, a, s_tile, s_spec1, acc1, &hot_r);               // resident = hash 1: what hash 2 lacks
         }
     }
     comp_hot_flush(hot_s, s_tile, SWAP ? s_spec1 : s_spec2);

@@ -139,13 +139,15 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     if (fused) {
         ScopedTimer tm(c, KATGPU_K_COMP_PASS1, t1->dev().cap + t2->dev().cap);
         const uint32_t grid = std::min<uint32_t>(t1->dev().n_regions, (uint32_t)c->n_cu);
-        // the streamed region in registers, 16-byte pairs of slots per lane: 3, 4 or 5 of them (kg_kernels.hpp: k_comp_fused)
-        const int jp = s_str <= 3 * FUSED_BLOCK * 2 ? 3 : s_str <= 4 * FUSED_BLOCK * 2 ? 4 : 5;
-#define KG_FUSED(SWAP, JP) do { \
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_fused<SWAP, JP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); \
-            hipLaunchKernelGGL((k_comp_fused<SWAP, JP>), dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, a); } while (0)
-        if (swap) { if (jp == 3) KG_FUSED(true, 3); else if (jp == 4) KG_FUSED(true, 4); else KG_FUSED(true, 5); }
-        else { if (jp == 3) KG_FUSED(false, 3); else if (jp == 4) KG_FUSED(false, 4); else KG_FUSED(false, 5); }
+        // the streamed region in registers, 16-byte pairs of slots per lane (4 or 5: regions of up to 8192 / 10240 slots); 64-bit counts only
+        // where a side table holds some (kg_kernels.hpp: k_comp_fused)
+        const bool five = s_str > 4 * FUSED_BLOCK * 2, ovf = t1->n_ovf != 0 || t2->n_ovf != 0;
+#define KG_FUSED(SWAP, JP, OVF) do { \
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_comp_fused<SWAP, JP, OVF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); \
+            hipLaunchKernelGGL((k_comp_fused<SWAP, JP, OVF>), dim3(grid), dim3(FUSED_BLOCK), fused_lds, c->stream, t1->dev(), t1->n_ovf, t2->dev(), t2->n_ovf, a); } while (0)
+#define KG_FUSED_S(SWAP) do { if (five) { if (ovf) KG_FUSED(SWAP, 5, true); else KG_FUSED(SWAP, 5, false); } else { if (ovf) KG_FUSED(SWAP, 4, true); else KG_FUSED(SWAP, 4, false); } } while (0)
+        if (swap) KG_FUSED_S(true); else KG_FUSED_S(false);
+#undef KG_FUSED_S
 #undef KG_FUSED
     }
 #define KG_JOIN(PASS, TA, TB, LDS) do { \
