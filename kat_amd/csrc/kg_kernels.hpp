@@ -671,9 +671,10 @@ k_comp_seen(DevTable ta /* hash 2 */, uint32_t na_ovf, CompArgs a) {
 //   SWAP = true:  hash 2 resident, hash 1 streamed.  A streamed k-mer is pass 1's item (count in 1, count in 2 or 0); the sweep is
 //                 pass 2: every k-mer of hash 2, found or not.
 // LDS: 16 u64 accumulators (0-6 pass 1, 8-11 pass 2) | tile 64 x 64 u32 | spectra 3 x ss (pass 1) | spectrum ss (pass 2) | the
-// resident region's S words + FUSED_STEP | S / 32 mark words.
+// resident region's S words + FUSED_STEP | per wave, FUSED_QCAP queue entries (8 + 4 bytes) | S / 32 mark words.
 constexpr int FUSED_BLOCK = 1024, FUSED_KP = 5;               // 5 x 1024 x 2 slots: regions of up to 10240 slots (resident and streamed)
 constexpr int FUSED_STEP = 4;                                 // slots per step of the walk through the resident region (two ds_read2_b64)
+constexpr int FUSED_QCAP = 192;                               // entries of a wave's queue: fewer than 64 left over + the 128 slots of a pair
 typedef uint64_t u64x2a8 __attribute__((ext_vector_type(2), aligned(8)));
 // JP: 16-byte pairs of streamed slots per lane -- the WHOLE streamed region sits in registers, loaded one region ahead: pair u of the
 // next region is requested the moment pair u of this one has been taken out of its registers, so every HBM request has a region's
@@ -696,9 +697,11 @@ k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArg
     typedef typename std::conditional<OVF, uint64_t, uint32_t>::type CT;                // a count
     const uint32_t Sr = tr.region_slots, Ss = ts.region_slots, cb = tr.cbits;          // one grid: one remainder width, one cbits
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(s_raw + ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * a.spec_size * 4 + 15) & ~15u));
-    uint32_t* s_mark = reinterpret_cast<uint32_t*>(rk + Sr + FUSED_STEP);            // (rk[Sr ..]: the region's first slots again)
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    unsigned long long* q_w = rk + Sr + FUSED_STEP + (tid >> 6) * FUSED_QCAP;          // (rk[Sr ..]: the region's first slots again) this wave's queue: slot words
+    uint32_t* q_i = reinterpret_cast<uint32_t*>(rk + Sr + FUSED_STEP + (FUSED_BLOCK / 64) * FUSED_QCAP) + (tid >> 6) * FUSED_QCAP;   // ... and where they were
+    uint32_t* s_mark = reinterpret_cast<uint32_t*>(rk + Sr + FUSED_STEP + (FUSED_BLOCK / 64) * FUSED_QCAP) + (FUSED_BLOCK / 64) * FUSED_QCAP;
     const uint32_t mark_words = (Sr + 31) / 32;
-    const uint32_t tid = threadIdx.x;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid & ~63u);                 // this wave's first lane, as a scalar
     comp_lds_init(a, 1, s_acc, s_tile, s_spec1);
     for (uint32_t i = tid; i < a.spec_size; i += blockDim.x) s_spec2[i] = 0;
@@ -735,20 +738,23 @@ k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArg
         const uint32_t rn = r + gridDim.x < R ? r + gridDim.x : r;   // (the last region asks for itself again: the loads stay unconditional)
         prefetch(rn);                                          // the next one: in flight behind this region's work
         const uint64_t rbase = (uint64_t)r * Sr, sbase = (uint64_t)r * Ss;
-#pragma unroll
-        for (int u = 0; u < JP; ++u) {
-            const u32x4s x = wq[u];
-            wq[u] = stream_pair(rn, u);
-            if ((u * FUSED_BLOCK + wave0) * 2 >= Ss) continue;               // nothing of the region left for this wave (uniform in the wave)
-            const uint32_t i = (u * FUSED_BLOCK + tid) * 2;
+        // ---- the streamed region: its occupied slots, 64 at a time ----
+        // One streamed k-mer with its walk and its two accounts is ~170 instructions, and the kernel is bound by their issue.  A wave-item
+        // of 64 consecutive slots holds as many k-mers as the table's load says: 19 of an assembly's (load 0.3), 40 of a read set's -- the
+        // other lanes would sit through every instruction.  So the slots go through the wave's queue first (a ballot, a bit count and one
+        // store each) and the walk takes them from there, every lane busy.
+        uint32_t q_n = 0;                                      // entries in the queue (uniform in the wave)
+        auto stream_drain = [&](uint32_t need) {
 #pragma unroll 1
-            for (int h = 0; h < 2; ++h) {                                   // (a loop, not two copies: the body is ~1000 instructions with its cold paths)
-                const uint64_t w = i < Ss ? ((uint64_t)(h ? x.w : x.y) << 32) | (h ? x.z : x.x) : 0ULL;
-                const bool occ = w != 0;
+            while (q_n >= need) {
+                const uint32_t cnt = q_n < 64 ? q_n : 64;
+                q_n -= cnt;
+                const bool occ = lane < cnt;
+                const uint64_t w = occ ? q_w[q_n + lane] : 0ULL;
                 CT cs = 0, cr = 0;                                           // count in the streamed table, in the resident one
                 if (occ) {
                     cs = (CT)pk_count(w, cb);
-                    if (OVF && ns_ovf) cs += (CT)ovf_get(ts, sbase + i + h);
+                    if (OVF && ns_ovf) cs += (CT)ovf_get(ts, sbase + q_i[q_n + lane]);
                     const uint64_t rem = pk_rem(w, cb);
                     uint32_t s = place_offset(rem, pl, Sr);
                     // the walk, FUSED_STEP slots per LDS round trip (the region is followed by a copy of its first slots, so a step never
@@ -780,16 +786,56 @@ k_comp_fused(DevTable t1, uint32_t n1_ovf, DevTable t2, uint32_t n2_ovf, CompArg
                     comp_account<2, true>(occ, cs, cr, a, s_tile, s_spec2, acc2, &hot_s);                // streamed = hash 2
                 }
             }
+        };
+#pragma unroll
+        for (int u = 0; u < JP; ++u) {
+            const u32x4s x = wq[u];
+            wq[u] = stream_pair(rn, u);
+            if ((u * FUSED_BLOCK + wave0) * 2 < Ss) {                       // (else: nothing of the region left for this wave)
+                const uint32_t i = (u * FUSED_BLOCK + tid) * 2;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint64_t w = i < Ss ? ((uint64_t)(h ? x.w : x.y) << 32) | (h ? x.z : x.x) : 0ULL;
+                    const unsigned long long m = __ballot(w != 0);
+                    if (m) {
+                        const uint32_t at = q_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                        if (w != 0) { q_w[at] = w; if (OVF) q_i[at] = i + h; }
+                        q_n += (uint32_t)__popcll(m);
+                    }
+                }
+            }
+            stream_drain(u == JP - 1 ? 1u : 64u);                           // (the last pair leaves nothing behind)
         }
         __syncthreads();                                       // every mark is in
-        for (uint32_t i0 = 0; i0 + wave0 < Sr; i0 += blockDim.x) {        // (trip count uniform in the wave: ballots inside comp_account)
-            const uint32_t i = i0 + tid;
-            const unsigned long long cur = i < Sr ? rk[i] : 0ULL;
-            const bool marked = i < Sr && ((s_mark[i >> 5] >> (i & 31)) & 1u);
-            CT cr = 0;
-            if (cur != 0) { cr = (CT)pk_count(cur, cb); if (OVF && nr_ovf) cr += (CT)ovf_get(tr, rbase + i); }
-            if (SWAP) comp_account<2, true>(cur != 0, cr, (CT)(marked ? 1 : 0), a, s_tile, s_spec2, acc2, &hot_r);     // resident = hash 2: all of it
-            else comp_account<1, true>(cur != 0 && !marked, cr, (CT)0, a, s_tile, s_spec1, acc1, &hot_r);               // resident = hash 1: what hash 2 lacks
+        // ---- the resident region: what of it the accounts want (hash 1 resident: the k-mers nobody found; hash 2: all), the same way ----
+#pragma unroll 1
+        for (uint32_t i0 = 0; ; i0 += blockDim.x) {
+            const bool more = i0 + wave0 < Sr;                 // (uniform in the wave)
+            if (more) {
+                const uint32_t i = i0 + tid;
+                const unsigned long long cur = i < Sr ? rk[i] : 0ULL;
+                const bool marked = i < Sr && ((s_mark[i >> 5] >> (i & 31)) & 1u);
+                const bool want = cur != 0 && (SWAP || !marked);
+                const unsigned long long m = __ballot(want);
+                if (m) {
+                    const uint32_t at = q_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    if (want) { q_w[at] = cur; if (OVF || SWAP) q_i[at] = i | (marked ? 0x80000000u : 0u); }
+                    q_n += (uint32_t)__popcll(m);
+                }
+            }
+#pragma unroll 1
+            while (q_n >= (more ? 64u : 1u)) {
+                const uint32_t cnt = q_n < 64 ? q_n : 64;
+                q_n -= cnt;
+                const bool occ = lane < cnt;
+                const unsigned long long cur = occ ? q_w[q_n + lane] : 0ULL;
+                const uint32_t qi = (OVF || SWAP) && occ ? q_i[q_n + lane] : 0u;
+                CT cr = 0;
+                if (occ) { cr = (CT)pk_count(cur, cb); if (OVF && nr_ovf) cr += (CT)ovf_get(tr, rbase + (qi & 0x7FFFFFFFu)); }
+                if (SWAP) comp_account<2, true>(occ, cr, (CT)(qi >> 31), a, s_tile, s_spec2, acc2, &hot_r);            // resident = hash 2: all of it
+                else comp_account<1, true>(occ, cr, (CT)0, a, s_tile, s_spec1, acc1, &hot_r);                          // resident = hash 1: what hash 2 lacks
+            }
+            if (!more) break;
         }
     }
     comp_hot_flush(hot_s, s_tile, SWAP ? s_spec1 : s_spec2);

@@ -115,7 +115,7 @@ extern "C" int katgpu_comp(katgpu_table* t1, katgpu_table* t2, int canon1, int c
     // past the other one's regions in LDS.
     const bool swap = t1->distinct < t2->distinct;           // hash 1 is the smaller one: it streams, hash 2 is resident
     const uint32_t s_res = swap ? t2->dev().region_slots : t1->dev().region_slots;
-    const size_t fused_lds = ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * (size_t)ss * 4 + 15) & ~(size_t)15) + ((size_t)s_res + FUSED_STEP) * 8 + (size_t)((s_res + 31) / 32) * 4;
+    const size_t fused_lds = ((16 * 8 + COMP_TILE * COMP_TILE * 4 + 4 * (size_t)ss * 4 + 15) & ~(size_t)15) + ((size_t)s_res + FUSED_STEP) * 8 + (size_t)(FUSED_BLOCK / 64) * FUSED_QCAP * 12 + (size_t)((s_res + 31) / 32) * 4;
     const uint32_t s_str = swap ? t1->dev().region_slots : t2->dev().region_slots;
     const bool fused = pk && same_grid && !g_no_fused && t1->dev().canonical && t2->dev().canonical && s_res <= (uint32_t)FUSED_KP * FUSED_BLOCK * 2 &&
                        s_str <= (uint32_t)FUSED_KP * FUSED_BLOCK * 2 && fused_lds <= 160 * 1024 - 512;
