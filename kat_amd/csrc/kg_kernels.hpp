@@ -188,23 +188,31 @@ typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
 struct Slots4 { uint64_t w[4]; uint64_t cnt[4]; bool occ[4]; };     // w: the k-mer (KV12, wide: its first word) or the packed word
 // (the loads are unconditional, from a clamped address, and the lanes beyond the range are masked afterwards: loads issued inside
 // a branch make hipcc wait for them at the end of the branch, which turns every prefetch into a stall)
+struct Raw4 { u64x2 a, b; u32x4s c; };                               // four slots as they come from HBM (c: KV12 counts)
 template <bool PK>
-__device__ __forceinline__ Slots4 load_slots4(const DevTable& t, uint64_t i4 /* first slot, multiple of 4 */, bool in_range) {
-    Slots4 r;
+__device__ __forceinline__ Raw4 load_raw4(const DevTable& t, uint64_t i4 /* first slot, multiple of 4 */, bool in_range) {
+    Raw4 r;
     const uint64_t at = in_range ? i4 : 0;
-    const u64x2 a = *reinterpret_cast<const u64x2*>(t.keys + at), b = *reinterpret_cast<const u64x2*>(t.keys + at + 2);
-    r.w[0] = a.x; r.w[1] = a.y; r.w[2] = b.x; r.w[3] = b.y;
+    r.a = *reinterpret_cast<const u64x2*>(t.keys + at); r.b = *reinterpret_cast<const u64x2*>(t.keys + at + 2);
+    if constexpr (!PK) r.c = *reinterpret_cast<const u32x4s*>(t.counts + at); else r.c = u32x4s{0u, 0u, 0u, 0u};
+    return r;
+}
+template <bool PK>
+__device__ __forceinline__ Slots4 decode_slots4(const DevTable& t, const Raw4& raw, bool in_range) {
+    Slots4 r;
+    r.w[0] = raw.a.x; r.w[1] = raw.a.y; r.w[2] = raw.b.x; r.w[3] = raw.b.y;
     if constexpr (PK) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { r.occ[j] = in_range && r.w[j] != 0; r.cnt[j] = pk_count(r.w[j], t.cbits); }
     } else {
-        const u32x4s c = *reinterpret_cast<const u32x4s*>(t.counts + at);
-        r.cnt[0] = c.x; r.cnt[1] = c.y; r.cnt[2] = c.z; r.cnt[3] = c.w;
+        r.cnt[0] = raw.c.x; r.cnt[1] = raw.c.y; r.cnt[2] = raw.c.z; r.cnt[3] = raw.c.w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.occ[j] = in_range && r.w[j] != EMPTY;
     }
     return r;
 }
+template <bool PK>
+__device__ __forceinline__ Slots4 load_slots4(const DevTable& t, uint64_t i4, bool in_range) { return decode_slots4<PK>(t, load_raw4<PK>(t, i4, in_range), in_range); }
 
 template <bool PK>
 __global__ void __launch_bounds__(SCAN_BLOCK)
@@ -266,10 +274,15 @@ k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long lon
     const uint64_t quads = t.cap / 4, stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t rounds = (quads + stride - 1) / stride;
+    // The next round's slots are asked for before this round's are worked on: with the matrix in LDS a CU holds ONE workgroup, 16 waves,
+    // and a load per wave in flight is 32 KB per CU -- 8 MB on the chip, what 3.5 TB/s keep in flight (k_hist, two workgroups: 5.7 TB/s).
+    Raw4 ahead = load_raw4<PK>(t, first * 4, first < quads);
     for (uint64_t r = 0; r < rounds; ++r) {
         const uint64_t q = first + r * stride;
         const bool in_range = q < quads;
-        const Slots4 s4 = load_slots4<PK>(t, q * 4, in_range);
+        const Raw4 raw = ahead;
+        ahead = load_raw4<PK>(t, (q + stride) * 4, q + stride < quads);
+        const Slots4 s4 = decode_slots4<PK>(t, raw, in_range);
         uint64_t kb[4] = {0, 0, 0, 0};
         RegionPlace rp{};
         if constexpr (PK) {                                // the quad lies in one region (regions are whole quads): its digits once
@@ -304,6 +317,65 @@ k_gcp(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long lon
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t v = t.ctrs[CTR_ONES];                     // all-T 32-mer: GC count 0
+        if (v) { uint64_t pos = scale_count(v, scale); if (pos > bins) pos = bins; atomicAdd(&out[pos], 1ULL); }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x)
+            if (s_bins[i]) atomicAdd(&out[i], (unsigned long long)s_bins[i]);
+    }
+}
+
+// K4 for packed tables: a WAVE takes a region at a time (quads of four slots, 64 lanes wide, the next load in flight behind the work on
+// this one).  The k-mer of a packed slot is its remainder joined with the region's two digits (key_in): per region those are scalars,
+// where the flat scan above found them per quad through region_of_pos (a double multiply and two 64-bit checks), and the count is the
+// slot's low 32 bits unless the table has side-table entries (n_ovf, uniform).  3.25 -> 3.07 ms from the load ahead alone at config 3.
+static __global__ void __launch_bounds__(SCAN_BLOCK)
+k_gcp_pk(DevTable t, uint32_t n_ovf, double scale, uint32_t bins, unsigned long long* __restrict__ out, uint32_t use_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bins[];
+    const uint32_t cols = bins + 1, k = t.k, cells = k * cols;
+    if (use_lds) { for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) s_bins[i] = 0; __syncthreads(); }
+    const uint32_t lane = threadIdx.x & 63, S = t.region_slots, R = t.n_regions, qpr = S / 4;      // (S is a multiple of 4)
+    const uint32_t n_waves = gridDim.x * (SCAN_BLOCK / 64);
+    uint32_t reg = __builtin_amdgcn_readfirstlane(blockIdx.x * (SCAN_BLOCK / 64) + (threadIdx.x >> 6)), q0 = 0;
+    RegionPlace rp{};
+    rp.pl = place_make(t.k, t.p1, t.n1, t.l2);
+    const uint32_t cmask32 = (uint32_t)pk_cmask(t.cbits);                                      // cbits <= 32
+    auto load_at = [&](uint32_t rg, uint32_t qq) { const uint32_t q = qq + lane; return load_raw4<true>(t, (uint64_t)rg * S + (uint64_t)(q < qpr ? q : 0) * 4, true); };
+    Raw4 ahead{};
+    if (reg < R) ahead = load_at(reg, 0);
+    while (reg < R) {
+        uint32_t nreg = reg, nq0 = q0 + 64;
+        if (nq0 >= qpr) { nq0 = 0; nreg = reg + n_waves; }
+        const Raw4 raw = ahead;
+        ahead = load_at(nreg < R ? nreg : reg, nq0);
+        rp.d1 = reg >> t.l2; rp.d2 = reg & (t.p2 - 1);
+        const uint32_t q = q0 + lane;
+        const bool in_range = q < qpr;
+        const uint64_t w4[4] = {raw.a.x, raw.a.y, raw.b.x, raw.b.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool occ = in_range && w4[j] != 0;
+            uint32_t cell = 0;
+            if (occ) {
+                const uint32_t g = kmer_gc(key_in(pk_rem(w4[j], t.cbits), rp), k);
+                uint32_t pos;
+                if (n_ovf == 0) { pos = scale_count((uint32_t)w4[j] & cmask32, scale); pos = pos > bins ? bins : pos; }
+                else {
+                    uint64_t p64 = scale_count(slot_total(t, (uint64_t)reg * S + (uint64_t)q * 4 + j, w4[j], pk_count(w4[j], t.cbits), n_ovf), scale);
+                    pos = p64 > bins ? bins : (uint32_t)p64;
+                }
+                occ = g < k;                                   // the reference's matrix has k rows: GC == k never printed
+                cell = g * cols + pos;
+            }
+            if (use_lds == 2) { if (occ) (void)__hip_atomic_fetch_add(&s_bins[cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            else if (use_lds) lds_inc_aggregated(s_bins, cell, occ);
+            else if (occ) atomicAdd(&out[cell], 1ULL);
+        }
+        reg = nreg; q0 = nq0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {             // (a packed table keeps every k-mer in a slot; the counter is read as the flat scan reads it)
+        uint64_t v = t.ctrs[CTR_ONES];
         if (v) { uint64_t pos = scale_count(v, scale); if (pos > bins) pos = bins; atomicAdd(&out[pos], 1ULL); }
     }
     if (use_lds) {

@@ -59,7 +59,14 @@ extern "C" int katgpu_gcp(katgpu_table* t, double cvg_scale, uint32_t cvg_bins, 
         if (use_lds && lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_gcp<W, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         ScopedTimer tm(c, KATGPU_K_GCP, t->dev().cap); \
         hipLaunchKernelGGL((k_gcp<W, PK>), dim3(grid_for(c, t->dev().cap / 4, SCAN_BLOCK, per_cu)), dim3(SCAN_BLOCK), use_lds ? lds : 0, c->stream, t->dev(), t->n_ovf, cvg_scale, cvg_bins, d, use_lds); } while (0)
-    if (t->dev().keys_b) KG_GCP(true, false); else if (t->dev().cbits) KG_GCP(false, true); else KG_GCP(false, false);
+    if (t->dev().keys_b) KG_GCP(true, false);
+    else if (t->dev().cbits) {                                  // packed: a wave per region (kg_kernels.hpp: k_gcp_pk)
+        if (use_lds && lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_gcp_pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ScopedTimer tm(c, KATGPU_K_GCP, t->dev().cap);
+        const uint32_t want = (t->dev().n_regions + SCAN_BLOCK / 64 - 1) / (SCAN_BLOCK / 64);
+        hipLaunchKernelGGL(k_gcp_pk, dim3(std::min<uint32_t>(want, (uint32_t)c->n_cu * per_cu)), dim3(SCAN_BLOCK), use_lds ? lds : 0, c->stream, t->dev(), t->n_ovf, cvg_scale, cvg_bins, d, use_lds);
+    }
+    else KG_GCP(false, false);
 #undef KG_GCP
     HIPCHK(c, hipGetLastError());
     hipMemcpyAsync(out, d, cells * 8, hipMemcpyDeviceToHost, c->stream);
