@@ -34,6 +34,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 #include <dlfcn.h>
@@ -79,6 +82,26 @@ Rccl& rccl() {
 #undef KG_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather && r.AllReduce && r.GetErrorString;
     return r;
+}
+
+// RCCL's two bootstrap calls (ncclGetUniqueId, ncclCommInitRank) open sockets and look for network interfaces, and have been seen not
+// to come back on a box (round 5: one `--gpus 1` run of 200 sat in there for its caller's whole 300 s).  They run on a thread of their
+// own; the caller waits KATGPU_COMM_INIT_TIMEOUT_S (default 120 s) and then reports an error instead of hanging -- the thread is left
+// behind (it owns its state through the shared_ptr), the process is about to fail anyway.
+static const double g_comm_init_timeout_s = getenv("KATGPU_COMM_INIT_TIMEOUT_S") ? std::max(1.0, atof(getenv("KATGPU_COMM_INIT_TIMEOUT_S"))) : 120.0;
+struct BootCall { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclUniqueId id; ncclComm_t comm = nullptr; };
+// false: the call has not returned within the limit
+template <typename F>
+static bool rccl_boot_call(int device, F&& f, std::shared_ptr<BootCall> st) {
+    std::thread([device, f, st]() {
+        (void)hipSetDevice(device);
+        const ncclResult_t r = f(*st);
+        std::lock_guard<std::mutex> lk(st->mu);
+        st->r = r; st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(st->mu);
+    return st->cv.wait_for(lk, std::chrono::duration<double>(g_comm_init_timeout_s), [&] { return st->done; });
 }
 
 // ---- the id ranks share: [magic | 16 bytes of token (names the /dev/shm objects) | has_rccl | ncclUniqueId] ----
@@ -346,7 +369,15 @@ extern "C" int katgpu_comm_unique_id(void* id_out) {
     if (f) { if (fread(rnd, 1, sizeof rnd, f) != sizeof rnd) rnd[0] = (uint8_t)getpid(); fclose(f); }
     snprintf(id.token, sizeof id.token, "%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", rnd[0], rnd[1], rnd[2], rnd[3], rnd[4], rnd[5], rnd[6], rnd[7], rnd[8], rnd[9]);
     const char* tr = getenv("KATGPU_COMM_TRANSPORT");
-    if (!(tr && !strcmp(tr, "shm")) && rccl().ok && rccl().GetUniqueId(&id.nccl) == ncclSuccess) id.has_rccl = 1;
+    if (!(tr && !strcmp(tr, "shm")) && rccl().ok) {
+        int dev = 0; (void)hipGetDevice(&dev);
+        auto st = std::make_shared<BootCall>();
+        if (!rccl_boot_call(dev, [](BootCall& b) { return rccl().GetUniqueId(&b.id); }, st)) {
+            fprintf(stderr, "[katgpu] ncclGetUniqueId did not return within %.0f s (KATGPU_COMM_INIT_TIMEOUT_S)\n", g_comm_init_timeout_s);
+            return KATGPU_ERR_DEVICE;
+        }
+        if (st->r == ncclSuccess) { id.nccl = st->id; id.has_rccl = 1; }
+    }
     memset(id_out, 0, KATGPU_COMM_ID_BYTES);
     memcpy(id_out, &id, sizeof id);
     return KATGPU_OK;
@@ -434,8 +465,15 @@ extern "C" int katgpu_comm_init(katgpu_ctx* c, int rank, int world, const void* 
     const bool want_rccl = !asked_shm && id.has_rccl && rccl().ok;
     uint32_t mine = 0;
     if (want_rccl) {
-        ncclResult_t r = rccl().CommInitRank(&m->nccl, world, id.nccl, rank);
-        if (r == ncclSuccess) mine = 1;
+        auto st = std::make_shared<BootCall>();
+        st->id = id.nccl;
+        if (!rccl_boot_call(c->device, [world, rank](BootCall& b) { return rccl().CommInitRank(&b.comm, world, b.id, rank); }, st)) {
+            m->beats[rank].gone.store(1, std::memory_order_release);
+            // (the communicator is NOT taken apart: the thread inside RCCL may still touch what it was given; the process is to end)
+            return fail(c, KATGPU_ERR_DEVICE, "katgpu_comm_init: ncclCommInitRank did not return within %.0f s on rank %d of %d (KATGPU_COMM_INIT_TIMEOUT_S)", g_comm_init_timeout_s, rank, world);
+        }
+        const ncclResult_t r = st->r;
+        if (r == ncclSuccess) { m->nccl = st->comm; mine = 1; }
         else { m->nccl = nullptr; m->transport_note = std::string("RCCL refused to initialise (") + rccl().GetErrorString(r) + ")"; (void)hipGetLastError(); }
     } else m->transport_note = asked_shm ? "KATGPU_COMM_TRANSPORT=shm" : (id.has_rccl ? "librccl could not be loaded here" : "no RCCL id (librccl missing where the id was made)");
     std::vector<uint32_t> all((size_t)world);

@@ -112,6 +112,7 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
 
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
     if (!comm || nranks < 1 || rank < 0 || rank >= nranks || strncmp(id.internal, "fake", 4) != 0) return ncclInvalidArgument;
+    if (getenv("FAKE_RCCL_HANG_INIT")) for (;;) sleep(1);                // a bootstrap that never comes back (test_gpu_comm.py: the init deadline)
     FakeComm* c = new FakeComm();
     c->token.assign(id.internal, strnlen(id.internal, 24));
     c->rank = rank; c->world = nranks;

@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"KATGPU_NO_FUSED": "1", "KATGPU_NO_SEEN": "1", "KATGPU_FORCE_JOIN": "1", "KATGPU_NO_FOLD": "1", "KATGPU_JOIN_BLOCK": "1024"},   # join form for pass 2 as well
     {"KATGPU_NO_PACKED": "1"},                                              # KV12 slots: the 12-byte join
     {"KATGPU_NO_JOIN": "1"},                                                # HBM probes only
-    {"KATGPU_TEST_REGION_SLOTS": "9000"}])                                  # regions of the size the large tables have: the fused join's five-pair shape
+    {"KATGPU_TEST_REGION_SLOTS": "9000"},                                   # regions of the size the large tables have: the fused join's five-pair shape
+    {"KATGPU_COMP_PLAIN_INC": "0"}])                                        # LDS increments aggregated per wave (ballots inside the queue drains)
 def test_comp_forms_match_oracle(extra):
     env = dict(os.environ, KATGPU_TEST_REGION_SLOTS="512")
     env.update(extra)
