@@ -14,6 +14,7 @@ out=$PWD/gpurun_out
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 quiet="--steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-workloads"
+if [ "${SKIP_MAIN:-0}" != 1 ]; then        # (SKIP_MAIN=1: only the other workloads and the SQ view, after an ONLY_MAIN=1 run)
 rm -rf /tmp/prof_stats /tmp/prof_fetch /tmp/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$root/bench.py" $quiet > /dev/null 2> "$out/${tag}_stats.err"
 find /tmp/prof_stats -name '*kernel_stats.csv' -exec cp {} "$out/${tag}_kernel_stats.csv" \;
@@ -43,6 +44,7 @@ PY
 # the plain line comes after the counters: its roofline.traffic is read from the profile that was just taken (same sources: bench.py checks)
 mkdir -p "$root/profiles" && cp "$out/${tag}_pmc_fetch_write.json" "$root/profiles/${tag}_pmc_fetch_write.json"
 timeout 900 python "$root/bench.py" --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
+fi
 [ "${ONLY_MAIN:-0}" = 1 ] && { ls -la "$out" | grep "$tag"; exit 0; }
 for w in hist gcp comp-rr; do
   rm -rf /tmp/prof_w /tmp/prof_wp
