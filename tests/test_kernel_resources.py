@@ -67,9 +67,12 @@ def test_no_scratch_and_the_stage_kernels_keep_their_budgets(tmp_path):
     every("k_p3_apply2<", vgpr=128)
     # the packed shape the bench runs must leave room for its partner on the CU
     every("k_p3_apply_pk<512, 10, 1, false, false, false, 2, false, 1>", vgpr=128, lds=64)
-    every("k_comp_fused<", vgpr=128)
+    every("k_comp_fused<", vgpr=128)           # one 1024-thread workgroup per CU: all eight shapes (resident table, pairs per lane, side-table counts)
+    assert len([n for n in ks if n.startswith("k_comp_fused<")]) == 8
     every("k_merge_apply<", vgpr=128)
     every("k_w3_apply", vgpr=128)
     every("k_w1<", vgpr=128, lds=16 * 1024)
     # the streaming reducers run two 1024-thread workgroups per CU (hist) or one beside a 108 KB matrix (gcp)
     every("k_hist<", vgpr=64)
+    every("k_gcp_pk", vgpr=64)
+    every("k_gcp<", vgpr=64)
