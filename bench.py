@@ -237,7 +237,7 @@ def main():
                 l2, ok2, what2 = measure(eng, b, ctx, want_cpu=False)
                 extra[wl] = {"config": l2["config"]["workload"], "value": l2["value"], "unit": l2["unit"], "steps": b.steps, "warmup": b.warmup,
                              "ms_per_step": l2["ms_per_step"], "kmer_instances": l2["kmer_instances"],
-                             "roofline": {k_: l2["roofline"][k_] for k_ in ("achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms")},
+                             "roofline": {k_: l2["roofline"][k_] for k_ in ("achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "ms_per_step")},
                              "kernel_ms_per_step": l2["kernel_ms_per_step"], "reducers": l2["reducers"],
                              "result_accounts_for_every_kmer": bool(ok2), "result_check": what2}
                 all_ok = all_ok and ok2
@@ -455,9 +455,10 @@ def measure(eng, a, ctx, want_cpu):
                 item1 = 4 + hi_bytes(2 * k - (p1_.bit_length() - 1))                   # a level-1 item: the k-mer below its level-1 digit
                 items = inst_reads + inst2_local
                 rounds1 = max(1, prof["part_l1_scatter"]["launches"] // a.steps - (1 if two_tables else 0))      # rounds of the first input
+                item2 = 64.0 / 12.0 if hb == 1 else 4.0 + hb                           # a level-2 item: 5-byte remainders travel in 64-byte blocks of twelve
                 own = {"part_l1_scatter": (reads.nbytes + in2_bytes) + float(item1) * items,
-                       "part_l2": (item1 + 4.0 + hb) * items,
-                       "part_apply": (4.0 + hb) * items + 2.0 * slot_b1 * cap1 * rounds1 + 2.0 * slot_b2 * cap2}
+                       "part_l2": (item1 + item2) * items,
+                       "part_apply": item2 * items + 2.0 * slot_b1 * cap1 * rounds1 + 2.0 * slot_b2 * cap2}
                 for n, b in own.items():
                     ms = prof[n]["ms"] / a.steps
                     if ms > 0:
@@ -473,6 +474,10 @@ def measure(eng, a, ctx, want_cpu):
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": rounds, "avg_launch_ms": round(stage_ms / rounds, 3),
                 "alg_bytes_per_launch": int(alg_bytes_step * a.steps / rounds), "per_kernel": per_kernel}
+        # which kernel moved, in the object the driver keeps: milliseconds per step of the three stage kernels and of the reducer
+        red_ms = prof[wl]["ms"] if wl in ("hist", "gcp") else prof["comp_pass1"]["ms"] + prof["comp_pass2"]["ms"]
+        roof["ms_per_step"] = {"l1": round((prof["part_l1_count"]["ms"] + prof["part_l1_scatter"]["ms"]) / a.steps, 3), "l2": round(prof["part_l2"]["ms"] / a.steps, 3),
+                               "apply": round(prof["part_apply"]["ms"] / a.steps, 3), "direct": round(direct_ms / a.steps, 3), "reduce": round(red_ms / a.steps, 3)}
         # the reducers' own roofline.  SURVEY.md 8(d) prices them at 12 B per slot (hist / gcp: 12 B x C; comp: 12 B x (C1 + C2) scan
         # + 12 B x (D1 + D2) probes) -- the reference's key + count.  A packed table stores 8 B per slot and the fused join probes in
         # LDS, so the kernels MOVE less than the formula: `frac` is priced on the bytes the slots really hold (slot_bytes x slots, the
@@ -568,16 +573,19 @@ def cpu_baseline(eng, a, k, L):
 
     # the sweep starts where round 4's sweeps peaked (a shared CAS table stops scaling long before 256 threads) and stays within ~40 s
     sweep = {}
-    for th in [t for t in (32, 64, 16, 128, 8) if t <= cores] or [cores]:
+    plan = [t for t in (32, 64, 16, 128, 8) if t <= cores] or [cores]
+    for th in plan:
         sweep[th] = run(th)
         if sum(sweep.values()) > 40.0:                      # bounded: the default run stays within minutes
             break
+    skipped = [t for t in plan if t not in sweep]             # thread counts the time bound cut off: the line says so (the headline ratio is tied to reference_scaled anyway)
     best = min(sweep, key=sweep.get)
     table_mb = 12.0 * expected_distinct(n * (L - k + 1), gs, k, a.err_ppm) / 0.7 / 1e6
     return {"value": round(inst / sweep[best], 1), "unit": "k-mers/s", "cores": best, "kind": "port",
             "sample": "%d reads x %d bp from a %d bp genome%s, k=%d; best of a thread sweep: %.2f s at %d threads; the sample's table (~%.0f MB of keys + counts) against %s of last-level cache" % (
                 n, L, gs, {"comp": " + that genome as assembly", "comp-rr": " + a second library of the same size"}.get(wl, ""), k, sweep[best], best, table_mb, host_llc()),
             "thread_sweep_kmers_per_s": {str(t): round(inst / s, 1) for t, s in sorted(sweep.items())},
+            "sweep_truncated": bool(skipped), "sweep_skipped_threads": skipped, "sweep_order": plan,
             "host_cores": cores, "host_last_level_cache": host_llc(),
             "note": "a port of the reference's algorithm (oracle/koracle.c), not the reference binary (unbuildable here: DESIGN.md section 5).  The sample is sized so that its table is "
                     "much larger than the last-level cache, like the full config's; a smaller sample would flatter the CPU.",

@@ -3,6 +3,7 @@
 #include "kat_host.hpp"
 
 #include <csignal>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -72,6 +73,10 @@ int main(int argc, char* argv[]) {
     if (gpus_given && (gpus < 1 || gpus > 256)) { std::cerr << "Error: Parsing Command Line: --gpus takes 1 .. 256" << std::endl; return 1; }
     if (!gpus_given) return guarded(mode, argc - 1, argv + 1);
     if (mode != "hist" && mode != "gcp" && mode != "comp") { std::cerr << "Error: Parsing Command Line: --gpus applies to hist, gcp and comp" << std::endl; return 1; }
+    // A peer that is alive but wedged (its heartbeat thread still ticking) would hang the run for ever: no single wait inside a collective
+    // lasts longer than this (two hours -- a rank dealt a whole-genome .gz reaches the exchange many minutes after the others), unless the
+    // caller says otherwise.  The library reads it at its first wait.
+    setenv("KATGPU_COMM_MAX_WAIT_S", "7200", 0);
 
     // the rendezvous file lives in a directory of this run's own (0700, a fresh name): nobody else can plant a file or a link there
     char id_dir[] = "/tmp/katgpu-comm-XXXXXX";

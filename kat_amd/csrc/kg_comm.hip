@@ -125,7 +125,9 @@ static_assert(sizeof(ShmHeader) == 64 && sizeof(RankBeat) == 64, "shared block l
 // its heartbeat has not moved for this long.  Not a bound on how long a healthy peer may take to get there.
 static const double g_comm_timeout_ms = 1e3 * (getenv("KATGPU_COMM_TIMEOUT_S") ? std::max(0.5, atof(getenv("KATGPU_COMM_TIMEOUT_S"))) : 60.0);
 // optional: no single wait longer than this, whatever the heartbeats say (0: unbounded)
-static const double g_comm_max_wait_ms = 1e3 * (getenv("KATGPU_COMM_MAX_WAIT_S") ? std::max(0.0, atof(getenv("KATGPU_COMM_MAX_WAIT_S"))) : 0.0);
+static const double g_comm_gone_grace_ms = 1e3 * (getenv("KATGPU_COMM_GONE_GRACE_S") ? std::max(0.0, atof(getenv("KATGPU_COMM_GONE_GRACE_S"))) : 5.0);
+// (read at the first wait, not when the library is loaded: the host binary gives it a finite default in main(), host/kat_main.cc)
+static double comm_max_wait_ms() { static const double v = 1e3 * (getenv("KATGPU_COMM_MAX_WAIT_S") ? std::max(0.0, atof(getenv("KATGPU_COMM_MAX_WAIT_S"))) : 0.0); return v; }
 constexpr int BEAT_PERIOD_MS = 50;
 
 struct Msg { int peer; void* dev; size_t bytes; };          // one side of a point-to-point transfer (device memory)
@@ -173,8 +175,8 @@ std::string shm_name(const std::string& token, const char* what, uint64_t seq = 
 
 // What a waiting rank knows of its peers' health: each peer's last heartbeat value and when it was last seen to move.
 struct Liveness {
-    katgpu_comm* m; std::vector<uint64_t> last; std::vector<double> moved; double t0; char why[256];
-    explicit Liveness(katgpu_comm* m_) : m(m_), last((size_t)m_->world, 0), moved((size_t)m_->world, now_ms()), t0(now_ms()) {
+    katgpu_comm* m; std::vector<uint64_t> last; std::vector<double> moved, gone_at; double t0; char why[256];
+    explicit Liveness(katgpu_comm* m_) : m(m_), last((size_t)m_->world, 0), moved((size_t)m_->world, now_ms()), gone_at((size_t)m_->world, 0.0), t0(now_ms()) {
         why[0] = 0;
         for (int r = 0; r < m->world; ++r) last[r] = m->beats[r].beat.load(std::memory_order_relaxed);
     }
@@ -187,13 +189,20 @@ struct Liveness {
             if (r == m->rank) continue;
             const uint64_t b = m->beats[r].beat.load(std::memory_order_relaxed);
             if (b != last[r]) { last[r] = b; moved[r] = now; continue; }
-            if (m->beats[r].gone.load(std::memory_order_acquire)) { snprintf(why, sizeof why, "rank %d has left the communicator while rank %d waits for it", r, m->rank); return false; }
+            // A peer that has LEFT (katgpu_comm_free) is not yet a failure: a rank that finished its side of the last collective may free
+            // its communicator while a slower rank's transfer is still landing (ncclAllReduce returns per rank).  It becomes one when what
+            // this rank waits for has not happened a grace period later (KATGPU_COMM_GONE_GRACE_S, 5 s).
+            if (m->beats[r].gone.load(std::memory_order_acquire)) {
+                if (gone_at[r] == 0.0) gone_at[r] = now;
+                if (now - gone_at[r] > g_comm_gone_grace_ms) { snprintf(why, sizeof why, "rank %d has left the communicator while rank %d waits for it", r, m->rank); return false; }
+                continue;
+            }
             if (now - moved[r] > g_comm_timeout_ms) {
                 snprintf(why, sizeof why, "no sign of life from rank %d for %.0f s (rank %d gives up; KATGPU_COMM_TIMEOUT_S)", r, (now - moved[r]) / 1e3, m->rank);
                 return false;
             }
         }
-        if (g_comm_max_wait_ms > 0 && now - t0 > g_comm_max_wait_ms) { snprintf(why, sizeof why, "rank %d waited %.0f s (KATGPU_COMM_MAX_WAIT_S)", m->rank, (now - t0) / 1e3); return false; }
+        if (comm_max_wait_ms() > 0 && now - t0 > comm_max_wait_ms()) { snprintf(why, sizeof why, "rank %d waited %.0f s (KATGPU_COMM_MAX_WAIT_S)", m->rank, (now - t0) / 1e3); return false; }
         return true;
     }
 };

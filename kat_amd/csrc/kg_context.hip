@@ -83,11 +83,20 @@ extern "C" int katgpu_reserve(katgpu_ctx* c, uint32_t k, uint64_t size_hint) {
     // ONE reservation at a time, kept apart from the pool: it is for a table made "like" another (katgpu_table_create_like: `kat comp`'s
     // second input), so the table being counted now -- often of the very same size, KAT's -H and -I share a default -- cannot walk
     // off with it; a second call while one is pending or parked is a no-op (a third input allocates when its turn comes).
+    void* stale = nullptr;
     {
         std::lock_guard<std::mutex> lk(c->pool_mu);
-        if (c->reserved_p || c->reserve_bytes.load()) return KATGPU_OK;
+        const size_t have = c->reserve_bytes.load();
+        if (have) {
+            // the same size, give or take what pool_alloc accepts (up to a quarter more than asked for): the hint stands.  A PARKED block
+            // of another size -- left by an earlier run, never matched by a create_like -- would sit in HBM (tens of GB) until a NOMEM
+            // trim: it is given back and the new hint takes its place.  A reservation still on its way is left alone.
+            if (!c->reserved_p || (have >= bytes && have <= bytes + bytes / 4)) return KATGPU_OK;
+            stale = c->reserved_p; c->reserved_p = nullptr;
+        }
         c->reserve_bytes.store(bytes);
     }
+    if (stale) hipFree(stale);
     if (c->reserve_thread.joinable()) c->reserve_thread.join();
     c->reserve_thread = std::thread([c, bytes]() {
         hipSetDevice(c->device);

@@ -122,7 +122,7 @@ static uint32_t pass_buckets(uint32_t p1, uint32_t n_cu) {
     return n_cu && p1 > n_cu && p1 % n_cu == 0 ? n_cu : p1;
 }
 // ... of which the level-2 buffer holds one pass = 1 / passes of a round
-static double arena_bytes_per_item(uint32_t hb, uint32_t passes) { return 8.0 * (1 + 1.0 / 24) + (4.0 + hb) * (1 + 1.0 / 24) * l2_items_per_l1_item(hb) / passes + 0.25 + 0.02; }
+static double arena_bytes_per_item(uint32_t hb, uint32_t passes) { return 8.0 * (1 + 1.0 / 24) + l2_bytes_per_item(hb) * (1 + 1.0 / 24) * l2_items_per_l1_item(hb) / passes + 0.25 + 0.02; }
 
 static const bool g_test_grow_nomem = hook("KATGPU_TEST_GROW_NOMEM") != nullptr;   // tests: table growth "fails" while the arena is busy
 
@@ -290,8 +290,8 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const size_t tile_starts = P1_TILE_STARTS;
 #define KG_FOR_HB(M) M(0) M(1) M(2) M(4)
     if (!c->part_attr_set) {
-#define KG_ATTR_HB(HB) KG_LDS_ATTR((k_p2<HB, false>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, false>), sizeof(P2FLds<HB>)); \
-                       KG_LDS_ATTR((k_p2<HB, true>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, true>), sizeof(P2FLds<HB>));
+#define KG_ATTR_HB(HB) KG_LDS_ATTR((k_p2<HB, false>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, false>), sizeof(P2FastLds<HB>::type)); \
+                       KG_LDS_ATTR((k_p2<HB, true>), sizeof(P2Lds<HB>)); KG_LDS_ATTR((k_p2_fast<HB, true>), sizeof(P2FastLds<HB>::type));
         KG_FOR_HB(KG_ATTR_HB)
 #undef KG_ATTR_HB
         c->part_attr_set = true;
@@ -309,7 +309,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     const double per_item = arena_bytes_per_item(hb0, passes0);
     constexpr size_t SEG_PAD = 64;
     const size_t fixed_l1 = (size_t)W * MAX_PARTS * SEG_PAD;
-    const size_t fixed_l2 = (size_t)((double)fixed_l1 * l2_items_per_l1_item(hb0) / passes0) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 8192;
+    const size_t fixed_l2 = (size_t)((double)fixed_l1 * l2_items_per_l1_item(hb0) / passes0) + (size_t)MAX_PARTS * MAX_PARTS * P2_RUN_SLACK + 8192;
     const size_t small_bytes = align_up((size_t)W * MAX_PARTS * 4, 256) + align_up((size_t)W * MAX_PARTS * 8, 256) +   /* W <= 4 * CUs */
                                align_up((MAX_PARTS + 1) * 8, 256) + align_up(((size_t)MAX_PARTS * MAX_PARTS + 1) * 8, 256) +
                                align_up((size_t)MAX_PARTS * MAX_PARTS * 4, 256) + align_up((size_t)MAX_PARTS * 8, 256) + align_up((size_t)MAX_PARTS * 4, 256) + 256 +
@@ -346,11 +346,11 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
     unsigned long long* ovf_n = spill_n + 1;      a += 256;
     if (g_apply_stamp) HIPCHK(c, hipMemset(spill_n + 8, 0, 7 * sizeof(unsigned long long)));
     const size_t round_items = std::min<size_t>(want_items, (size_t)((double)(c->arena_bytes - small_bytes) / per_item));
-    const size_t l1_items = round_items + round_items / 24 + fixed_l1;
-    const size_t l2_items = ((size_t)((double)l1_items * l2_items_per_l1_item(hb0) / passes0) + (size_t)MAX_PARTS * MAX_PARTS * 32 + 4096 + 3) & ~(size_t)3;
+    const size_t l1_items = (round_items + round_items / 24 + fixed_l1 + 15) & ~(size_t)15;      // (a multiple of 16: the level-2 buffer starts on a 128-byte boundary)
+    const size_t l2_items = ((size_t)((double)l1_items * l2_items_per_l1_item(hb0) / passes0) + (size_t)MAX_PARTS * MAX_PARTS * P2_RUN_SLACK + 4096 + 11) / 12 * 12;
     uint8_t* l1_buf = a;                                                            // level-1 items, groups of 4, 8 bytes of room per item (kg_partition.hpp "the level-1 buffer")
-    uint8_t* l2_buf = l1_buf + l1_items * 8;                                        // level-2 items, groups of 4
-    uint64_t* ovf_buf = (uint64_t*)(l2_buf + align_up(l2_items / 4 * l2_group_bytes(hb0), 16));
+    uint8_t* l2_buf = l1_buf + l1_items * 8;                                        // level-2 items, groups of 4 (5-byte items: 64-byte blocks of 12)
+    uint64_t* ovf_buf = (uint64_t*)(l2_buf + align_up(l2_buffer_bytes(hb0, l2_items), 16));
     const uint64_t ovf_cap = g_test_p2_ovf_cap ? g_test_p2_ovf_cap : round_items / 32 + 1024;
     bool p2_fast_ok = g_p2_fast != 0, l1_fast_ok = g_l1_fast != 0;
     if (!g_test_round_items && round_items < ((size_t)1 << 20) && round_items < n_starts) return KATGPU_OK;
@@ -470,7 +470,7 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             const uint32_t tile2 = l2_tile_items(g.hb);
             auto pass_extent = [&](uint32_t b_lo, uint32_t b_hi) -> uint64_t {       // bound of what level 2 writes for these buckets, in items (either edition)
                 const uint64_t nn = lbeg(b_hi) - lbeg(b_lo);
-                return nn + nn / 16 + 2ULL * g.P2 * (nn / tile2 + 1) + (uint64_t)(b_hi - b_lo) * g.P2 * 32 + 64;
+                return nn + nn / 16 + 2ULL * g.P2 * (nn / tile2 + 1) + (uint64_t)(b_hi - b_lo) * g.P2 * P2_RUN_SLACK + 64;
             };
             if (seg) HIPCHK(c, hipStreamSynchronize(c->stream));                   // ovf_l1 has arrived
             uint32_t step = pass_buckets(g.P1, (uint32_t)c->n_cu);
@@ -502,15 +502,15 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
                 if (try_fast) {
                     ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
-#define KG_P2F(HB) case HB: if (g.hb1 == 4) hipLaunchKernelGGL((k_p2_fast<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+#define KG_P2F(HB) case HB: if (g.hb1 == 4) hipLaunchKernelGGL((k_p2_fast<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FastLds<HB>::type), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); \
-                            else hipLaunchKernelGGL((k_p2_fast<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, \
+                            else hipLaunchKernelGGL((k_p2_fast<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FastLds<HB>::type), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); break;
                     if (g.hb == 1 && g.hb1 != 4 && g_p2_stamp) {                       // diagnostic: the bench's shape with cycle stamps
                         unsigned long long* stamps = spill_n + 16;
                         HIPCHK(c, hipMemsetAsync(stamps, 0, 6 * sizeof(unsigned long long), c->stream));
-                        KG_LDS_ATTR((k_p2_fast<1, false, true>), sizeof(P2FLds<1>));
-                        hipLaunchKernelGGL((k_p2_fast<1, false, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FLds<1>), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, stamps);
+                        KG_LDS_ATTR((k_p2_fast<1, false, true>), sizeof(P2FastLds<1>::type));
+                        hipLaunchKernelGGL((k_p2_fast<1, false, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FastLds<1>::type), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, stamps);
                         unsigned long long st[6];
                         HIPCHK(c, hipMemcpyAsync(st, stamps, sizeof st, hipMemcpyDeviceToHost, c->stream));
                         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -219,7 +219,7 @@ bool strip_fastq_records(const uint8_t* p, size_t n, uint8_t* out, size_t* out_n
         const uint8_t* se = s < end ? (const uint8_t*)memchr(s, '\n', (size_t)(end - s)) : nullptr;  // end of the sequence line
         if (!se) return false;
         const size_t len = (size_t)(se - s);
-        if (len == 0) return false;                                                                  // (a record without bases: what the reference's loop does with it is the state machine's to say)
+        if (len == 0 || *s == '+') return false;                                                     // (a record without bases, or a "sequence" line that the reference's loop takes for the '+' line of one -- it stops reading bases at the first line that begins with '+', mer_overlap_sequence_parser.hpp:226-233 --: the state machine's to say, it words the reference's error)
         const uint8_t* pl = se + 1;
         if (pl >= end || *pl != '+') return false;                                                   // (a second sequence line: not plain)
         const uint8_t* ple = (const uint8_t*)memchr(pl, '\n', (size_t)(end - pl));                   // end of the '+' line

@@ -76,32 +76,44 @@ template <int HB> struct L2Fmt {
     static constexpr uint32_t GS = 16 + 4 * HB;              // bytes of a group
     static constexpr uint64_t NONE = HB == 4 ? ~0ULL : (1ULL << (32 + 8 * HB)) - 1;
 };
-__device__ __host__ __forceinline__ uint32_t l2_group_bytes(uint32_t hb) { return 16 + 4 * hb; }
 __device__ __host__ __forceinline__ uint32_t l2_tile_items(uint32_t hb) { return hb == 4 ? 12 * 1024 : 16 * 1024; }
+// ---- 5-byte items (HB = 1: the bench's tables) live in 64-BYTE BLOCKS OF TWELVE (round 6) ----
+// block = [12 low words: 48 B | 12 high bytes | 4 B unused], 64-byte aligned; group g of the buffer (four items, still the unit of the
+// readers: a lane of the apply takes one) is part g % 3 of block g / 3: its low words 16 bytes at 16 (g % 3), its high bytes the dword at
+// 48 + 4 (g % 3).  Why: what a memory request LOOKS like decides what a store costs here (tools/ubench_l1_tlb.hip, ubench_l2_layout.hip, round
+// 6).  A sub-bucket's piece of a tile as 20-byte groups at dword alignment (two store instructions per group, every piece ending in
+// partial lines) moves level 2's pattern at 22.2 ms per launch; whole 64-byte blocks stored by ONE lane each (four instructions per line:
+// round 5's "C") 19.0; the same blocks stored by a QUAD of lanes in one instruction -- sixteen bytes each, a whole line per request --
+// 16.6, stores alone 7.4 against 13.0.  So the one-pass level 2 keeps an incomplete block per sub-bucket in LDS until it is full
+// (scatter_tile2_blk) and everything else addresses groups through these two functions.
+__device__ __host__ __forceinline__ constexpr bool l2_blocked(uint32_t hb) { return hb == 1; }
+constexpr uint32_t L2_BLOCK_ITEMS = 12, L2_BLOCK_BYTES = 64;
+template <int HB> __device__ __host__ __forceinline__ uint64_t l2_lo_at(uint64_t grp) {          // byte offset of group grp's four low words
+    if (l2_blocked(HB)) { const uint64_t b = grp / 3; return b * L2_BLOCK_BYTES + (grp - 3 * b) * 16; }
+    return grp * L2Fmt<HB>::GS;
+}
+template <int HB> __device__ __host__ __forceinline__ uint64_t l2_hi_at(uint64_t grp) {          // ... of its four high parts
+    if (l2_blocked(HB)) { const uint64_t b = grp / 3; return b * L2_BLOCK_BYTES + 48 + (grp - 3 * b) * 4; }
+    return grp * L2Fmt<HB>::GS + 16;
+}
+// bytes the level-2 buffer takes for `items` items (a multiple of 4) + the granule runs are aligned to, in items
+__device__ __host__ __forceinline__ uint64_t l2_buffer_bytes(uint32_t hb, uint64_t items) { return l2_blocked(hb) ? (items / L2_BLOCK_ITEMS + 2) * L2_BLOCK_BYTES : items / 4 * (16 + 4 * hb); }
+__device__ __host__ __forceinline__ double l2_bytes_per_item(uint32_t hb) { return l2_blocked(hb) ? (double)L2_BLOCK_BYTES / L2_BLOCK_ITEMS : 4.0 + hb; }
+__device__ __host__ __forceinline__ uint32_t l2_run_align(uint32_t hb) { return l2_blocked(hb) ? L2_BLOCK_ITEMS : 4u; }
 template <int HB> struct HiWord { typedef uint32_t type; };
 template <> struct HiWord<1> { typedef uint8_t type; };
 template <> struct HiWord<2> { typedef uint16_t type; };
 // one item (slow paths: the exact level 2, the first-edition apply)
 template <int HB>
 __device__ __forceinline__ void l2_put(uint8_t* __restrict__ buf, uint64_t i, uint64_t rem) {
-    uint8_t* grp = buf + (i >> 2) * L2Fmt<HB>::GS;
-    reinterpret_cast<uint32_t*>(grp)[i & 3] = (uint32_t)rem;
-    if (HB) reinterpret_cast<typename HiWord<HB>::type*>(grp + 16)[i & 3] = (typename HiWord<HB>::type)(rem >> 32);
+    reinterpret_cast<uint32_t*>(buf + l2_lo_at<HB>(i >> 2))[i & 3] = (uint32_t)rem;
+    if (HB) reinterpret_cast<typename HiWord<HB>::type*>(buf + l2_hi_at<HB>(i >> 2))[i & 3] = (typename HiWord<HB>::type)(rem >> 32);
 }
 template <int HB>
 __device__ __forceinline__ uint64_t l2_get(const uint8_t* __restrict__ buf, uint64_t i) {
-    const uint8_t* grp = buf + (i >> 2) * L2Fmt<HB>::GS;
-    const uint32_t l = reinterpret_cast<const uint32_t*>(grp)[i & 3];
-    const uint32_t h = HB ? (uint32_t)reinterpret_cast<const typename HiWord<HB>::type*>(grp + 16)[i & 3] : 0u;
+    const uint32_t l = reinterpret_cast<const uint32_t*>(buf + l2_lo_at<HB>(i >> 2))[i & 3];
+    const uint32_t h = HB ? (uint32_t)reinterpret_cast<const typename HiWord<HB>::type*>(buf + l2_hi_at<HB>(i >> 2))[i & 3] : 0u;
     return ((uint64_t)h << 32) | l;
-}
-__device__ __forceinline__ uint64_t l2_get_any(uint32_t hb, const uint8_t* __restrict__ buf, uint64_t i, bool& none) {
-    uint64_t v;
-    if (hb == 0) { v = l2_get<0>(buf, i); none = v == L2Fmt<0>::NONE; }
-    else if (hb == 1) { v = l2_get<1>(buf, i); none = v == L2Fmt<1>::NONE; }
-    else if (hb == 2) { v = l2_get<2>(buf, i); none = v == L2Fmt<2>::NONE; }
-    else { v = l2_get<4>(buf, i); none = v == L2Fmt<4>::NONE; }
-    return v;
 }
 // one group: four low words + four high parts (HB = 4: the high parts are a second 16-byte piece)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a native vector: stays in registers where HIP's uint4 struct went to scratch
@@ -117,18 +129,36 @@ template <> __device__ __forceinline__ uint32_t hi_of_group<0>(const uint32_t&, 
 template <> __device__ __forceinline__ uint32_t hi_of_group<1>(const uint32_t& h, int q) { return (h >> (8 * q)) & 0xFF; }
 template <> __device__ __forceinline__ uint32_t hi_of_group<2>(const u32x2& h, int q) { return ((q < 2 ? h.x : h.y) >> (16 * (q & 1))) & 0xFFFF; }
 template <> __device__ __forceinline__ uint32_t hi_of_group<4>(const u32x4& h, int q) { return q == 0 ? h.x : q == 1 ? h.y : q == 2 ? h.z : h.w; }
-template <int HB>
-__device__ __forceinline__ void l2_load_group(const uint8_t* __restrict__ buf, uint64_t grp, u32x4& lo, typename HiGroup<HB>::type& hi) {
-    const uint8_t* p = buf + grp * L2Fmt<HB>::GS;
-    lo = *reinterpret_cast<const u32x4_a4*>(p);
-    if (HB) hi = *reinterpret_cast<const typename HiGroup<HB>::mem*>(p + 16);
-}
+// a group in the PLAIN layout (16 + 4 HB contiguous bytes): the level-1 buffer's groups, and the level-2 buffer's unless its items are blocked
 template <int HB>
 __device__ __forceinline__ void l2_store_group(uint8_t* __restrict__ buf, uint64_t grp, const u32x4& lo, const typename HiGroup<HB>::type& hi) {
     uint8_t* p = buf + grp * L2Fmt<HB>::GS;
     *reinterpret_cast<u32x4_a4*>(p) = lo;
     if (HB) *reinterpret_cast<typename HiGroup<HB>::mem*>(p + 16) = hi;
 }
+// A run of the level-2 buffer as the apply kernels read it: groups counted from group g0 of the buffer (32-bit from there: a walk covers fewer
+// than 2^31 k-mers).  Blocked items: g0 = 3 q0 + r0, group gi of the run is part (r0 + gi) % 3 of block q0 + (r0 + gi) / 3 -- a multiply-high.
+template <int HB>
+struct L2Run {
+    const uint8_t* p;
+    uint32_t r0;
+    __device__ __forceinline__ L2Run(const uint8_t* __restrict__ buf, uint64_t g0) {
+        if constexpr (l2_blocked(HB)) { const uint64_t q0 = g0 / 3; r0 = (uint32_t)(g0 - 3 * q0); p = buf + q0 * L2_BLOCK_BYTES; }
+        else { r0 = 0; p = buf + g0 * L2Fmt<HB>::GS; }
+    }
+    __device__ __forceinline__ void load(uint32_t gi, u32x4& lo, typename HiGroup<HB>::type& hi) const {
+        if constexpr (l2_blocked(HB)) {
+            const uint32_t x = r0 + gi, blk = __umulhi(x, 0xAAAAAAABu) >> 1, part = x - 3 * blk;
+            const uint8_t* q = p + ((uint64_t)blk << 6);
+            lo = *reinterpret_cast<const u32x4*>(q + 16 * part);                    // (16-byte aligned: the buffer starts on a 64-byte boundary)
+            hi = *reinterpret_cast<const uint32_t*>(q + 48 + 4 * part);
+        } else {
+            const uint8_t* q = p + (uint64_t)gi * L2Fmt<HB>::GS;
+            lo = *reinterpret_cast<const u32x4_a4*>(q);
+            if (HB) hi = *reinterpret_cast<const typename HiGroup<HB>::mem*>(q + 16);
+        }
+    }
+};
 
 // LDS carve of the exact level-2 kernel k_p2 (dynamic shared memory, 16-byte aligned base; the one-pass edition: P2FLds below)
 template <int HB>
@@ -739,8 +769,9 @@ __device__ __forceinline__ uint32_t p2_tile_load_wide(const uint8_t* __restrict_
     for (int u = 0; u < N / 2; ++u) {
         const uint32_t i0 = 2 * ((uint32_t)u * PART_BLOCK + threadIdx.x);
         it.lo[2 * u] = w[u].x; it.hi[2 * u] = w[u].y; it.lo[2 * u + 1] = w[u].z; it.hi[2 * u + 1] = w[u].w;
-        valid |= (i0 < t_items && (w[u].x & w[u].y) != 0xFFFFFFFFu) ? 1u << (2 * u) : 0u;
-        valid |= (i0 + 1 < t_items && (w[u].z & w[u].w) != 0xFFFFFFFFu) ? 1u << (2 * u + 1) : 0u;
+        uint32_t t0 = (i0 < t_items && (w[u].x & w[u].y) != 0xFFFFFFFFu) ? 1u : 0u, t1 = (i0 + 1 < t_items && (w[u].z & w[u].w) != 0xFFFFFFFFu) ? 1u : 0u;
+        asm volatile("" : "+v"(t0), "+v"(t1));                // (0 / 1 shifted into place, as in the narrow form)
+        valid |= (t0 << (2 * u)) | (t1 << (2 * u + 1));
     }
     return valid;
 }
@@ -750,39 +781,53 @@ __device__ __forceinline__ uint32_t p2_tile_load_wide(const uint8_t* __restrict_
 // -- mapped, ignored; loads are unconditional because a load inside a branch is waited for at the end of the branch), and one
 // v_perm_b32 per register puts the high parts where TileItems
 // wants them, its selector chosen by HB1 (wave-uniform).
+// In two steps, so that a tile's loads can be in flight while the tile before it is worked on (the block edition of the one-pass level 2):
+// `issue` is the unconditional loads, `decode` looks at them when they are needed.
+template <int N> struct RawTile { u32x4 lo[N / 4]; u32x2 hi[N / 4]; };
 template <int N>
-__device__ __forceinline__ uint32_t p2_tile_load_narrow(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, false>& it) {
+__device__ __forceinline__ void p2_tile_issue_narrow(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, RawTile<N>& r) {
     static_assert(N % 4 == 0, "whole groups");
-    const uint32_t gs1 = 16 + 4 * hb1, hi_none = hb1 == 0 ? 0u : hb1 == 1 ? 0xFFu : 0xFFFFu;
+    const uint32_t gs1 = 16 + 4 * hb1;
+    const uint8_t* tile = bucket + (tbeg >> 2) * gs1;                          // (wave-uniform; the lane's part is a 32-bit offset: one register to keep, not two)
+    const uint32_t mine = threadIdx.x * gs1;
+#pragma unroll
+    for (int u = 0; u < N / 4; ++u) {
+        const uint8_t* p = tile + (mine + (uint32_t)u * PART_BLOCK * gs1);
+        r.lo[u] = *reinterpret_cast<const u32x4_a4*>(p);
+        r.hi[u] = *reinterpret_cast<const u32x2_a4*>(p + 16);
+    }
+}
+template <int N>
+__device__ __forceinline__ uint32_t p2_tile_decode_narrow(uint32_t hb1, uint64_t tbeg, uint64_t n_items, const RawTile<N>& r, TileItems<N, false>& it) {
+    const uint32_t hi_none = hb1 == 0 ? 0u : hb1 == 1 ? 0xFFu : 0xFFFFu;
     // v_perm_b32(y, x, sel): selector bytes 0-3 take x's bytes, 4-7 y's, 0x0C gives 0.  HB1 = 2: (x, y) are the pairs already; HB1 = 1:
     // x holds four bytes -> {x0, 0, x1, 0}, {x2, 0, x3, 0}; HB1 = 0: nothing
     const uint32_t sel0 = hb1 == 2 ? 0x03020100u : hb1 == 1 ? 0x0C010C00u : 0x0C0C0C0Cu, sel1 = hb1 == 2 ? 0x07060504u : hb1 == 1 ? 0x0C030C02u : 0x0C0C0C0Cu;
-    const uint64_t left = n_items - tbeg;                                      // (tbeg < n_items)
+    const uint64_t left = tbeg < n_items ? n_items - tbeg : 0;
     const uint32_t t_items = left < (uint64_t)N * PART_BLOCK ? (uint32_t)left : (uint32_t)N * PART_BLOCK;
-    const uint8_t* mine = bucket + ((tbeg >> 2) + threadIdx.x) * gs1;
-    u32x4 lo[N / 4];
-    u32x2 hi[N / 4];
-#pragma unroll
-    for (int u = 0; u < N / 4; ++u) {
-        const uint8_t* p = mine + (uint64_t)u * PART_BLOCK * gs1;
-        lo[u] = *reinterpret_cast<const u32x4_a4*>(p);
-        hi[u] = *reinterpret_cast<const u32x2_a4*>(p + 16);
-    }
     uint32_t valid = 0;
 #pragma unroll
     for (int u = 0; u < N / 4; ++u) {
         const uint32_t i0 = 4 * ((uint32_t)u * PART_BLOCK + threadIdx.x);
-        const uint32_t h01 = __builtin_amdgcn_perm(hi[u].y, hi[u].x, sel0), h23 = __builtin_amdgcn_perm(hi[u].y, hi[u].x, sel1);
+        const uint32_t h01 = __builtin_amdgcn_perm(r.hi[u].y, r.hi[u].x, sel0), h23 = __builtin_amdgcn_perm(r.hi[u].y, r.hi[u].x, sel1);
         it.hi[2 * u] = h01; it.hi[2 * u + 1] = h23;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t l = q == 0 ? lo[u].x : q == 1 ? lo[u].y : q == 2 ? lo[u].z : lo[u].w;
+            const uint32_t l = q == 0 ? r.lo[u].x : q == 1 ? r.lo[u].y : q == 2 ? r.lo[u].z : r.lo[u].w;
             const uint32_t h = ((q < 2 ? h01 : h23) >> (16 * (q & 1))) & 0xFFFFu;
             it.lo[4 * u + q] = l;
-            valid |= (i0 + q < t_items && !(l == 0xFFFFFFFFu && h == hi_none)) ? 1u << (4 * u + q) : 0u;
+            uint32_t there = (i0 + q < t_items && !(l == 0xFFFFFFFFu && h == hi_none)) ? 1u : 0u;
+            asm volatile("" : "+v"(there));                   // (a 0 / 1 shifted into place: as a select of 1 << j the sixteen masks sat in sixteen registers for the whole kernel)
+            valid |= there << (4 * u + q);
         }
     }
     return valid;
+}
+template <int N>
+__device__ __forceinline__ uint32_t p2_tile_load_narrow(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, false>& it) {
+    RawTile<N> r;
+    p2_tile_issue_narrow<N>(hb1, bucket, tbeg, r);
+    return p2_tile_decode_narrow<N>(hb1, tbeg, n_items, r, it);
 }
 template <int N, bool W1>
 __device__ __forceinline__ uint32_t p2_tile_load(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, W1>& it) {
@@ -1013,6 +1058,165 @@ __device__ __forceinline__ void flush_carry2(P2FLds<HB>& L, const PartGeom g, co
     }
 }
 
+// ---- the one-pass edition for blocked items (HB = 1): whole 64-byte lines, a quad of lanes per line ----
+// LDS carve.  Per sub-bucket a 64-byte BLOCK IMAGE (cb): the items that wait for their block to fill -- up to eleven -- already where the
+// block wants them (low words 0 .. 11, high bytes at 48 .. 59); its last dword counts the blocks the sub-bucket's run has received.  A tile's
+// k-mers rank behind the waiting ones; ranks below twelve complete the image, which then leaves as it stands (four lanes, sixteen bytes each,
+// ONE store instruction: a whole line per request), ranks beyond fill whole blocks in the staging arrays (st_lo / st_hi, block-ordered, no
+// padding), and what is left over -- again up to eleven -- goes into the image once it has left (phase C, after the copy-out's barrier).
+struct P2BLds {
+    static constexpr int TILE = L2Fmt<1>::TILE;
+    uint32_t hist[MAX_PARTS + 64];     // k-mers of the tile per sub-bucket, counted from the waiting ones; + one dump counter per lane of a wave
+    uint32_t goff[MAX_PARTS];          // first staged block of the sub-bucket's k-mers of this tile | blocks it completes this tile << 16
+    uint32_t wave_tot[32];
+    uint32_t pad_[32];                 // (cb starts on a 64-byte boundary)
+    uint32_t cb[MAX_PARTS * 16];       // the block images
+    uint32_t st_lo[TILE];              // staged whole blocks: low words (block s: entries 12 s ...)
+    uint8_t st_hi[TILE + 16];          // ... high bytes
+    uint16_t blk_b[TILE / 12 + 2];     // ... and whose they are
+};
+static_assert(sizeof(P2BLds) <= 160 * 1024 - 256 && offsetof(P2BLds, cb) % 64 == 0 && offsetof(P2BLds, st_lo) % 16 == 0 && offsetof(P2BLds, st_hi) % 4 == 0, "LDS");
+template <int HB> struct P2FastLds { typedef P2FLds<HB> type; };
+template <> struct P2FastLds<1> { typedef P2BLds type; };
+
+// a block of run `b` that found the run full: its k-mers to the overflow list (lows in `lo`, the high byte of item q from `hi8(q)`)
+template <typename HiFn>
+__device__ __forceinline__ void blk_overflow(const PartGeom& g, uint32_t b1, uint32_t b, const u32x4& lo, HiFn hi8, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t rem = ((uint64_t)hi8(q) << 32) | (q == 0 ? lo.x : q == 1 ? lo.y : q == 2 ? lo.z : lo.w);
+        if (rem == L2Fmt<1>::NONE) continue;
+        const unsigned long long at = atomicAdd(ovf_n, 1ULL);
+        if (at < ovf_cap) ovf_buf[at] = place_key_d(b1, b, rem, g.pl);
+    }
+}
+
+// One tile.  `carry_n` is thread b's count of sub-bucket b's waiting k-mers (in, and out for the next tile).  `out`: the bucket's first run;
+// run b = blocks [b * capb, (b + 1) * capb) from there.  All 1024 lanes must call it (barriers inside).
+template <bool W1, bool STAMP = false, typename Prefetch>
+__device__ __forceinline__ void scatter_tile2_blk(P2BLds& L, const PartGeom g, const uint32_t b1, const TileItems<16, W1>& key, uint32_t valid,
+                                                  uint8_t* __restrict__ out, uint32_t capb, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap,
+                                                  uint32_t& carry_n, unsigned long long* st, Prefetch prefetch /* issues the NEXT tile's loads: called once the ranking has let go of its registers */) {
+    constexpr int N = 16;
+    auto now = [&]() -> unsigned long long { return STAMP ? (unsigned long long)clock64() : 0ULL; };
+    const unsigned long long t0 = now();
+    const uint32_t tid = threadIdx.x, P = g.P2;
+    uint8_t* const cb8 = reinterpret_cast<uint8_t*>(L.cb);
+    L.hist[tid] = carry_n;                                    // (PART_BLOCK == MAX_PARTS: thread b is sub-bucket b)
+    lds_barrier();
+    uint32_t br[N];                                           // digit << 16 | rank in the sub-bucket's line-up (the waiting ones first)
+    {
+        uint32_t rk[N];
+        const uint32_t dump = MAX_PARTS + (tid & 63);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {                         // (straight-line, as scatter_tile2_fast: slots without a k-mer rank in a dump counter)
+            const uint32_t b = place_digit2_of(key.r1(j), g.pl) & (MAX_PARTS - 1);
+            rk[j] = atomicAdd(&L.hist[(valid >> j & 1) ? b : dump], 1u);
+            br[j] = b << 16;
+            if (j >= 2) br[j - 2] |= rk[j - 2];
+        }
+#pragma unroll
+        for (int j = N - 2; j < N; ++j) br[j] |= rk[j];
+    }
+    lds_barrier();
+    const unsigned long long t1 = now();
+    prefetch();
+    const uint32_t avail = tid < P ? L.hist[tid] : 0;         // waiting + new (< 2^15)
+    const uint32_t nblk = __umulhi(avail, 0xAAAAAAABu) >> 3;  // avail / 12: blocks that complete
+    const uint32_t nstg = nblk ? nblk - 1 : 0;                // ... of which the first is the image, the others are staged
+    uint32_t total;                                           // staged blocks of the tile
+    const uint32_t excl = block_exclusive_scan(nstg, L.wave_tot, &total);
+    L.goff[tid] = excl | (nblk << 16);
+    for (uint32_t q = 0; q < nstg; ++q) L.blk_b[excl + q] = (uint16_t)tid;
+    lds_barrier();
+    const unsigned long long t2 = now();
+    // phase A: ranks below twelve into the image, whole blocks' worth into the staging arrays; the rest waits for phase C
+    {
+        constexpr int SB = 4;
+        uint32_t go[SB];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j % SB == 0) {
+#pragma unroll
+                for (int q = 0; q < SB; ++q) go[q] = L.goff[br[j + q] >> 16];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) asm volatile("" : "+v"(go[q]));
+            }
+            uint32_t later = 0;
+            if (valid >> j & 1) {
+                const uint32_t b = br[j] >> 16, v = br[j] & 0xFFFF, gf = go[j % SB], whole = (gf >> 16) * 12u;
+                const uint64_t rem = key.r1(j) & g.pl.mr;
+                if (v < 12) { L.cb[b * 16 + v] = (uint32_t)rem; cb8[b * 64 + 48 + v] = (uint8_t)(rem >> 32); }
+                else if (v < whole) { const uint32_t slot = (gf & 0xFFFFu) * 12u + (v - 12); L.st_lo[slot] = (uint32_t)rem; L.st_hi[slot] = (uint8_t)(rem >> 32); }
+                else later = 0x80000000u | (b << 4) | (v - whole);
+            }
+            br[j] = later;
+        }
+    }
+    lds_barrier();
+    const unsigned long long t3 = now();
+    // copy-out: a quad of lanes per block.  First the images that are full ...
+    for (uint32_t qi = tid; qi < 4 * P; qi += PART_BLOCK) {
+        const uint32_t b = qi >> 2, w = qi & 3;
+        const uint32_t nb = L.goff[b] >> 16, cur = L.cb[b * 16 + 15];
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&L.cb[b * 16 + 4 * w]);
+        if (nb) {
+            if (cur < capb) *reinterpret_cast<u32x4*>(out + (((uint64_t)b * capb + cur) << 6) + 16 * w) = v;
+            else if (w < 3) blk_overflow(g, b1, b, v, [&](int q) -> uint32_t { return cb8[b * 64 + 48 + 4 * w + q]; }, ovf_buf, ovf_n, ovf_cap);
+        }
+    }
+    // ... then the staged ones, which follow their sub-bucket's image
+    for (uint32_t qi = tid; qi < 4 * total; qi += PART_BLOCK) {
+        const uint32_t s = qi >> 2, w = qi & 3;
+        const uint32_t b = L.blk_b[s];
+        const uint32_t gf = L.goff[b], cur = L.cb[b * 16 + 15];
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(&L.st_lo[12 * s + 4 * (w < 3 ? w : 0)]);
+        const uint32_t* h = reinterpret_cast<const uint32_t*>(&L.st_hi[12 * s]);
+        const u32x4 hv = {h[0], h[1], h[2], 0xFFFFFFFFu};
+        const uint32_t dst = cur + 1 + (s - (gf & 0xFFFFu));
+        if (dst < capb) *reinterpret_cast<u32x4*>(out + (((uint64_t)b * capb + dst) << 6) + 16 * w) = w < 3 ? lo : hv;
+        else if (w < 3) blk_overflow(g, b1, b, lo, [&](int q) -> uint32_t { return L.st_hi[12 * s + 4 * w + q]; }, ovf_buf, ovf_n, ovf_cap);
+    }
+    lds_barrier();
+    // phase C: what is left over takes the image's first places; the run has its blocks
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        if (br[j] & 0x80000000u) {
+            const uint32_t b = (br[j] >> 4) & (MAX_PARTS - 1), v = br[j] & 15u;
+            const uint64_t rem = key.r1(j) & g.pl.mr;
+            L.cb[b * 16 + v] = (uint32_t)rem; cb8[b * 64 + 48 + v] = (uint8_t)(rem >> 32);
+        }
+    if (tid < P) { const uint32_t c = L.cb[tid * 16 + 15] + nblk; L.cb[tid * 16 + 15] = c < capb ? c : capb; }
+    carry_n = avail - 12 * nblk;
+    if (STAMP && st) { const unsigned long long t4 = now(); st[1] += t1 - t0; st[2] += t2 - t1; st[3] += t3 - t2; st[4] += t4 - t3; }
+    // (the next tile's first barrier orders phase C before the next ranks are looked at)
+}
+
+// what a bucket's last tile left waiting -- up to eleven k-mers per sub-bucket -- as the run's last block, padded with "no item";
+// returns (to thread b) the blocks run b holds.  All 1024 lanes must call it.
+__device__ __forceinline__ uint32_t flush_carry_blk(P2BLds& L, const PartGeom g, const uint32_t b1, uint8_t* __restrict__ out, uint32_t capb,
+                                                    uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n, uint64_t ovf_cap, uint32_t carry_n) {
+    const uint32_t tid = threadIdx.x, P = g.P2;
+    uint8_t* const cb8 = reinterpret_cast<uint8_t*>(L.cb);
+    lds_barrier();                                            // the last tile's phase C is through
+    if (tid < P && carry_n) for (uint32_t q = carry_n; q < 12; ++q) { L.cb[tid * 16 + q] = 0xFFFFFFFFu; cb8[tid * 64 + 48 + q] = 0xFF; }
+    L.goff[tid] = carry_n;
+    lds_barrier();
+    for (uint32_t qi = tid; qi < 4 * P; qi += PART_BLOCK) {
+        const uint32_t b = qi >> 2, w = qi & 3;
+        const uint32_t cn = L.goff[b], cur = L.cb[b * 16 + 15];
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&L.cb[b * 16 + 4 * w]);
+        if (cn) {
+            if (cur < capb) *reinterpret_cast<u32x4*>(out + (((uint64_t)b * capb + cur) << 6) + 16 * w) = v;
+            else if (w < 3) blk_overflow(g, b1, b, v, [&](int q) -> uint32_t { return cb8[b * 64 + 48 + 4 * w + q]; }, ovf_buf, ovf_n, ovf_cap);
+        }
+    }
+    lds_barrier();
+    uint32_t blocks = 0;
+    if (tid < P) { const uint32_t c = L.cb[tid * 16 + 15]; blocks = carry_n && c < capb ? c + 1 : c; }
+    return blocks;
+}
+
 // first item of bucket b1's runs in the exact edition: every run may end on up to three padding items
 __device__ __host__ __forceinline__ uint64_t p2_exact_base(uint64_t beg, uint32_t b1, uint32_t P2) { return (beg + 4 * ((uint64_t)P2 + 1) * b1 + 3) & ~3ULL; }
 
@@ -1074,9 +1278,16 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict_
 // inserts through the direct path; if even that list overflows, the host redoes the round with the exact kernel
 // (the level-1 buffer is only read here) and stays exact for the rest of the call.
 // Both in ITEMS, both multiples of 4.  p2_out_base(beg + n) - p2_out_base(beg) >= P2 * p2_region_cap(n): buckets do not overlap.
-__device__ __host__ __forceinline__ uint64_t p2_region_cap(uint64_t n_b, uint32_t P2, uint32_t tile) { return ((n_b + (n_b >> 4)) / P2 + 2 * (n_b / tile + 1) + 16 + 3) & ~3ULL; }
-__device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t b1, uint32_t P2, uint32_t tile) {
-    return (beg + (beg >> 4) + 2 * (uint64_t)P2 * (beg / tile) + (uint64_t)b1 * P2 * 32 + 3) & ~3ULL;
+// (`al`: l2_run_align -- 4, or 12 where the items are blocked: runs start and end on block boundaries there; the 48 items of slack per run
+// in p2_out_base cover the rounding of either.)
+constexpr uint32_t P2_RUN_SLACK = 48;
+__device__ __host__ __forceinline__ uint64_t p2_region_cap(uint64_t n_b, uint32_t P2, uint32_t tile, uint32_t al = 4) {
+    const uint64_t c = ((n_b + (n_b >> 4)) >> (31 - __builtin_clz(P2))) + 2 * (n_b / tile + 1) + 16;      // (P2 is a power of two: a 64-bit division here kept its reciprocal in two spilled registers)
+    return (c + al - 1) / al * al;
+}
+__device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t b1, uint32_t P2, uint32_t tile, uint32_t al = 4) {
+    const uint64_t o = beg + (beg >> 4) + 2 * (uint64_t)P2 * (beg / tile) + (uint64_t)b1 * P2 * P2_RUN_SLACK;
+    return (o + al - 1) / al * al;
 }
 
 template <int HB, bool W1, bool STAMP = false>
@@ -1087,23 +1298,28 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
     // STAMP (diagnostic, KATGPU_P2_STAMP): cycles of wave 0: [0] tile loads, [1] hash + rank, [2] scan, [3] staging, [4] copy-out, [5] tiles
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    P2FLds<HB>& L = *reinterpret_cast<P2FLds<HB>*>(lds_raw);
+    typedef typename P2FastLds<HB>::type Lds;
+    Lds& L = *reinterpret_cast<Lds*>(lds_raw);
     constexpr int N = L2Fmt<HB>::N;
+    constexpr bool BLK = l2_blocked(HB);                                        // 64-byte blocks of twelve, a quad of lanes per block (scatter_tile2_blk)
+    constexpr uint32_t AL = BLK ? L2_BLOCK_ITEMS : 4;
     const uint32_t tid = threadIdx.x;
     uint64_t beg0, n0, nr0;
     l1_bucket_range(g, l1_off, seg_slots, g.b_lo, beg0, n0, nr0);
     for (uint32_t b1 = g.b_lo + blockIdx.x; b1 < g.b_hi; b1 += gridDim.x) {
         uint64_t beg, n_items, n_real;
         const uint8_t* bucket = l1_buf + l1_bucket_range(g, l1_off, seg_slots, b1, beg, n_items, n_real);
-        const uint64_t cap = p2_region_cap(n_real, g.P2, L2Fmt<HB>::TILE);
-        const uint64_t obase = p2_out_base(beg, b1, g.P2, L2Fmt<HB>::TILE) - p2_out_base(beg0, g.b_lo, g.P2, L2Fmt<HB>::TILE);   // the level-2 buffer holds this pass only
-        uint8_t* runs = l2_buf + (obase >> 2) * L2Fmt<HB>::GS;                  // run of sub-bucket b: groups [b * capg, (b + 1) * capg) from here
-        const uint32_t capg = (uint32_t)(cap >> 2);                             // (< 2^32: host-checked through the buffer's size)
+        const uint64_t cap = p2_region_cap(n_real, g.P2, L2Fmt<HB>::TILE, AL);
+        const uint64_t obase = p2_out_base(beg, b1, g.P2, L2Fmt<HB>::TILE, AL) - p2_out_base(beg0, g.b_lo, g.P2, L2Fmt<HB>::TILE, AL);   // the level-2 buffer holds this pass only
+        uint8_t* runs = l2_buf + l2_lo_at<HB>(obase >> 2);                      // run of sub-bucket b: groups [b * capg, (b + 1) * capg) from here (blocked: blocks [b * capg, ...): capg counts blocks)
+        const uint32_t capg = (uint32_t)(cap / AL);                             // (< 2^32: host-checked through the buffer's size)
         lds_barrier();
-        uint32_t carry_n = 0;                                                   // thread b: k-mers of sub-bucket b that wait for their group to fill
+        uint32_t carry_n = 0;                                                   // thread b: k-mers of sub-bucket b that wait for their group / block to fill
+        uint32_t tid_b = tid;
+        asm volatile("" : "+v"(tid_b));                                        // (per bucket: a per-lane pointer hoisted out of the bucket loop is two registers the tile loop spills)
         if (tid < g.P2) {
-            L.cur[tid] = 0;
-            off2[(uint64_t)b1 * g.P2 + tid] = obase + (uint64_t)tid * cap;
+            if constexpr (BLK) L.cb[tid * 16 + 15] = 0; else L.cur[tid] = 0;
+            off2[(uint64_t)b1 * g.P2 + tid_b] = obase + (uint64_t)tid * cap;
         }
         // Cycle stamps at the bench's shape (round 4; 32.7 K cycles per tile): a third is the wait for the tile's loads, the rest rank 20 %,
         // scan 13 % (before the DPP scan), staging 16 %, copy-out 17 %.  Issuing tile t + 1's loads earlier does not hide that wait: issued
@@ -1115,6 +1331,25 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
         // -- 3 % -- and the copy-out takes 47 % instead of 17: the kernel's time does not change (138-142 ms against 138-150).  What a tile
         // needs is its 98 KB in and ~90 KB out (x 1.3-1.5 in partial sectors) through a memory system that 256 CUs doing the same load to
         // ~4.5 TB/s: wherever the wait is taken, it is for that.
+        if constexpr (BLK && !W1) {
+            // The block edition, pipelined: tile t + 1's loads are issued inside tile t's routine, right behind its ranking.  (Round 4 measured
+            // three ways of doing this and kept none: with a sub-bucket's piece leaving as 20-byte groups the memory system took a tile's 98 KB in
+            // and ~90 KB out at its own pace -- 22 ms per launch for the bare pattern, the kernel's own time -- wherever the wait was taken.  Whole
+            // lines from a quad of lanes lower that floor to 16.6 ms (tools/ubench_l2_layout.hip): now there is something to overlap with.)
+            RawTile<N> raw;
+            p2_tile_issue_narrow<N>(g.hb1, bucket, 0, raw);
+            for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
+                const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
+                TileItems<N, W1> key;
+                const uint32_t valid = p2_tile_decode_narrow<N>(g.hb1, tbeg, n_items, raw, key);
+                if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
+                lds_barrier();
+                if (STAMP) { st[0] += (unsigned long long)clock64() - ta; st[5] += 1; }
+                // (the last tile's prefetch reads what lies behind the bucket: the next bucket, or the level-2 buffer -- mapped, never decoded)
+                scatter_tile2_blk<W1, STAMP>(L, g, b1, key, valid, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n, st,
+                                             [&]() { p2_tile_issue_narrow<N>(g.hb1, bucket, tbeg + L2Fmt<HB>::TILE, raw); });
+            }
+        } else
         for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
             const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
             TileItems<N, W1> key;
@@ -1122,11 +1357,18 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
             if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
             lds_barrier();
             if (STAMP) { st[0] += (unsigned long long)clock64() - ta; st[5] += 1; }
-            scatter_tile2_fast<HB, W1, STAMP>(L, g, b1, key, valid, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n, st);
+            if constexpr (BLK) scatter_tile2_blk<W1, STAMP>(L, g, b1, key, valid, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n, st, []() {});
+            else scatter_tile2_fast<HB, W1, STAMP>(L, g, b1, key, valid, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n, st);
         }
-        lds_barrier();
-        if constexpr (P2FLds<HB>::CARRY) { flush_carry2<HB>(L, g, b1, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n); lds_barrier(); }
-        if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = L.cur[tid] << 2;
+        if constexpr (BLK) {
+            const uint32_t blocks = flush_carry_blk(L, g, b1, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n);
+            asm volatile("" : "+v"(tid_b));
+            if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid_b] = blocks * L2_BLOCK_ITEMS;
+        } else {
+            lds_barrier();
+            if constexpr (P2FLds<HB>::CARRY) { flush_carry2<HB>(L, g, b1, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n); lds_barrier(); }
+            if (tid < g.P2) cnt2[(uint64_t)b1 * g.P2 + tid] = L.cur[tid] << 2;
+        }
     }
     if (STAMP && tid == 0 && stamps) for (int i = 0; i < 6; ++i) atomicAdd(&stamps[i], st[i]);
 }
@@ -1307,7 +1549,8 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
             u32x4 c_lo, n_lo;
             typename HiGroup<HB>::type c_hi{}, n_hi{};
             bool c_in, n_in;                                      // the lane's group lies inside the run
-            { const uint64_t gi = (uint64_t)wave * 64 + lane; c_in = gi < n_grp; l2_load_group<HB>(l2_buf, g0 + (c_in ? gi : 0), c_lo, c_hi); }
+            const L2Run<HB> run(l2_buf, g0);
+            { const uint64_t gi = (uint64_t)wave * 64 + lane; c_in = gi < n_grp; run.load(c_in ? (uint32_t)gi : 0u, c_lo, c_hi); }
             // (static round-robin left the workgroup waiting ~12 K cycles per region for its slowest wave: the drains vary)
             auto grab = [&]() -> uint64_t {
                 unsigned long long v = 0;
@@ -1320,7 +1563,7 @@ k_p3_apply2(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const uin
                 {                                             // next chunk: in flight behind this one (unconditional loads from a clamped index: a load inside a branch is waited for at the end of the branch)
                     const uint64_t gi = c_next * 64 + lane;
                     n_in = gi < n_grp;
-                    l2_load_group<HB>(l2_buf, g0 + (n_in ? gi : 0), n_lo, n_hi);
+                    run.load(n_in ? (uint32_t)gi : 0u, n_lo, n_hi);
                 }
                 uint32_t slot[U];
                 bool pend[U];                                     // k-mer u still to be placed (lane masks in SGPRs)
@@ -1612,11 +1855,12 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
             u32x4 c_lo[UG], n_lo[UG];
             typename HiGroup<HB>::type c_hi[UG], n_hi[UG];
             bool c_in[UG], n_in[UG];                              // the lane's group lies inside the run
+            const L2Run<HB> run(l2_buf, g0);
 #pragma unroll
             for (int gq = 0; gq < UG; ++gq) {
                 const uint64_t gi = ((uint64_t)wave * UG + gq) * 64 + lane;
                 c_in[gq] = gi < n_grp; c_hi[gq] = typename HiGroup<HB>::type{}; n_hi[gq] = typename HiGroup<HB>::type{};
-                l2_load_group<HB>(l2_buf, g0 + (c_in[gq] ? gi : 0), c_lo[gq], c_hi[gq]);
+                run.load(c_in[gq] ? (uint32_t)gi : 0u, c_lo[gq], c_hi[gq]);
             }
             auto grab = [&]() -> uint64_t {
                 unsigned long long v = 0;
@@ -1629,7 +1873,7 @@ k_p3_apply_pk(DevTable t, PartGeom g, const uint64_t* __restrict__ off2, const u
                 for (int gq = 0; gq < UG; ++gq) {             // next chunk: in flight behind this one (unconditional loads from a clamped index)
                     const uint64_t gi = (c_next * UG + gq) * 64 + lane;
                     n_in[gq] = gi < n_grp;
-                    l2_load_group<HB>(l2_buf, g0 + (n_in[gq] ? gi : 0), n_lo[gq], n_hi[gq]);
+                    run.load(n_in[gq] ? (uint32_t)gi : 0u, n_lo[gq], n_hi[gq]);
                 }
                 uint64_t rem[U];
                 uint32_t slot[U];

@@ -151,7 +151,7 @@ struct RawFeeder {
         if (sc.pin_seg_bytes < seg_bytes || sc.pin_seg.size() < 2 * (size_t)threads || sc.acc_bytes < acc_bytes) {
             scan_cache_release(c);
             sc.pin_seg_bytes = seg_bytes; sc.acc_bytes = acc_bytes;
-            for (int i = 0; i < 2; ++i) HIPCHK(c, hipMalloc((void**)&sc.acc[i], HEAD + acc_bytes));
+            for (int i = 0; i < 2; ++i) HIPCHK(c, hipMalloc((void**)&sc.acc[i], HEAD + acc_bytes + 256));      // (+ 256 bytes behind the buffer that nothing counts: the reader streams' warm-up writes land there)
             for (unsigned i = 0; i < threads; ++i) {              // two pinned segments and one stream per reader; the readers pin their own
                 hipStream_t st = nullptr;                         // segments when they start (read_loop): 32 x 8 MiB pinned one after the other cost 80 ms
                 sc.pin_seg.push_back(nullptr); sc.pin_seg.push_back(nullptr);
@@ -258,7 +258,9 @@ struct RawFeeder {
                 hipHostMalloc((void**)&c->scan.pin_seg[2 * me + h], c->scan.pin_seg_bytes, hipHostMallocNonCoherent) != hipSuccess) { c->scan.pin_seg[2 * me + h] = nullptr; ok_pin = false; }
         // The stream's first submission makes its hardware queue (~10 ms): paid here, by all readers at once, and not by the caller's
         // thread on its first sixteen copies one after the other (measured: 180 ms of a first file's pass).
-        if (c->scan.acc[0] && hipMemsetAsync(c->scan.acc[0], 'N', 16, c->scan.seg_stream[me]) == hipSuccess) hipStreamSynchronize(c->scan.seg_stream[me]);     // (inside HEAD: 'N' is what it holds)
+        // (the write goes BEHIND the accumulation buffer, into bytes of its own: the buffer's HEAD is written by the copy stream -- the carry of the
+        // stretch before, up to k - 1 = 62 bytes -- and a warm-up that lands late must not race with it)
+        if (c->scan.acc[0] && hipMemsetAsync(c->scan.acc[0] + HEAD + c->scan.acc_bytes, 'N', 16, c->scan.seg_stream[me]) == hipSuccess) hipStreamSynchronize(c->scan.seg_stream[me]);
         std::vector<uint8_t> tmp;                                 // pread mode: the segment's bytes (a mapping is read in place)
         for (int h = 0;; h ^= 1) {
             // this half free again?  (1: stripped, the caller's thread has not taken it yet; 2: its copy is on its way)

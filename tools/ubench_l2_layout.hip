@@ -69,6 +69,18 @@ __global__ void __launch_bounds__(1024) k_l2(const uint8_t* __restrict__ in, uin
                     *reinterpret_cast<u32x4*>(p) = lo[u];
                     *reinterpret_cast<u32x4*>(p + 16) = u32x4{lo[u].y, lo[u].z, hi[u].x, hi[u].y};
                 }
+            } else if (MODE == 4) {
+                // Q (round 6): C's blocks, but a QUAD of lanes writes a block in ONE instruction (16 bytes each: a whole 64-byte line per request)
+                const uint32_t nb = (t % 3 == 2) ? 2 : 1;
+                for (uint32_t u = 0; u < nb; ++u) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const uint32_t qi = (u * 4 + h) * 1024 + tid, gi = qi >> 2, w = qi & 3;
+                        const uint32_t b = gi / nb, q = gi - b * nb;
+                        uint8_t* p = runs + (uint64_t)b * run_cap_bytes + cur + q * 64;
+                        *reinterpret_cast<u32x4*>(p + 16 * w) = lo[(u + h) & 3];
+                    }
+                }
             } else {
                 // 16 items per run and tile = 1.33 blocks of twelve: 1, 1, 2 blocks over three tiles
                 const uint32_t nb = (t % 3 == 2) ? 2 : 1;
@@ -80,7 +92,7 @@ __global__ void __launch_bounds__(1024) k_l2(const uint8_t* __restrict__ in, uin
                 }
             }
         }
-        cur += MODE == 0 || MODE == 3 ? 80u : MODE == 1 ? ((t % 3 == 2) ? 64u : 96u) : ((t % 3 == 2) ? 128u : 64u);
+        cur += MODE == 0 || MODE == 3 ? 80u : MODE == 1 ? ((t % 3 == 2) ? 64u : 96u) : ((t % 3 == 2) ? 128u : 64u);      // (modes 2 and 4: blocks of twelve)
     }
     if (acc == 0x12345678u) *sink = acc;
 }
@@ -124,5 +136,7 @@ int main() {
     RUND(256, true, true, "D loads + stores: chunks of 256 groups");
     RUN(1, true, true, "B loads + stores", items * 32.0 / 6.0);
     RUN(2, true, true, "C loads + stores", items * 64.0 / 12.0);
+    RUN(4, false, true, "Q stores only: 64 B blocks, a quad each", items * 64.0 / 12.0);
+    RUN(4, true, true, "Q loads + stores", items * 64.0 / 12.0);
     return 0;
 }
