@@ -453,6 +453,8 @@ def measure(eng, a, ctx, want_cpu):
                 hi_bytes = lambda bits: 0 if bits <= 31 else 1 if bits <= 39 else 2 if bits <= 47 else 4
                 hb = hi_bytes(rb)
                 item1 = 4 + hi_bytes(2 * k - (p1_.bit_length() - 1))                   # a level-1 item: the k-mer below its level-1 digit
+                if item1 == 6 and p1_ <= 512 and 17 <= k <= 31:
+                    item1 = 6.4                                                        # ... which travel in 64-byte blocks of ten (kg_l1_blocks.hpp)
                 items = inst_reads + inst2_local
                 rounds1 = max(1, prof["part_l1_scatter"]["launches"] // a.steps - (1 if two_tables else 0))      # rounds of the first input
                 item2 = 64.0 / 12.0 if hb == 1 else 4.0 + hb                           # a level-2 item: 5-byte remainders travel in 64-byte blocks of twelve

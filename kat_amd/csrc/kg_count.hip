@@ -90,6 +90,7 @@ static const uint32_t g_apply_block = hook("KATGPU_APPLY_BLOCK") ? (uint32_t)str
 static const uint32_t g_test_l1_cpb = hook("KATGPU_TEST_L1_CPB") ? (uint32_t)strtoul(hook("KATGPU_TEST_L1_CPB"), nullptr, 10) : 0;   // tests: segment capacity (forces overflow)
 static const bool g_l1_lean = hook_u64("KATGPU_L1_LEAN", 1) != 0;   // A/B: 0 = level 1's ranking sweep in its 64-bit form (kg_l1_lean.hpp is the 32-bit one)
 static const uint32_t g_l1_fast = hook("KATGPU_L1_FAST") ? (uint32_t)strtoul(hook("KATGPU_L1_FAST"), nullptr, 10) : 1;
+static const bool g_l1_blocks = hook_u64("KATGPU_L1_BLOCKS", 1) != 0;   // A/B: 0 = the group edition of the segmented level 1 where the block edition (kg_l1_blocks.hpp) would run
 static const uint32_t g_p2_fast = hook("KATGPU_P2_FAST") ? (uint32_t)strtoul(hook("KATGPU_P2_FAST"), nullptr, 10) : 1;
 static const uint64_t g_test_p2_ovf_cap = hook("KATGPU_TEST_P2_OVF_CAP") ? strtoull(hook("KATGPU_TEST_P2_OVF_CAP"), nullptr, 10) : 0;
 static const uint32_t g_test_spill_mod = hook("KATGPU_TEST_SPILL_MOD") ? (uint32_t)strtoul(hook("KATGPU_TEST_SPILL_MOD"), nullptr, 10) : 0;
@@ -97,6 +98,7 @@ static const uint64_t g_test_ap_seg = hook_u64("KATGPU_TEST_AP_SEG", 0) & ~3ULL;
 static const uint32_t g_apply_nr = (uint32_t)hook_u64("KATGPU_APPLY_NR", 2);            // A/B: probe rounds of the packed apply at the bench's shape (1, 2 or 3)
 static const uint32_t g_apply_min_q = (uint32_t)hook_u64("KATGPU_APPLY_MIN_Q", 72);     // A/B: queue entries per wave the SECOND workgroup of a CU must leave (>= 72)
 static const uint32_t g_apply_per_cu = (uint32_t)hook_u64("KATGPU_APPLY_PER_CU", 0);   // A/B: packed apply workgroups per CU (0: as many as the LDS holds)
+static const bool g_l1b_stamp = hook_u64("KATGPU_L1B_STAMP", 0) != 0;   // diagnostic: level 1's block edition with cycle stamps (printed per round)
 static const bool g_p2_stamp = hook_u64("KATGPU_P2_STAMP", 0) != 0;   // diagnostic: the bench-shape one-pass level 2 with cycle stamps (printed per pass)
 static const bool g_apply_stamp = hook_u64("KATGPU_APPLY_STAMP", 0) != 0;              // diagnostic: the bench-shape apply with cycle stamps (printed per pass)
 
@@ -402,22 +404,30 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
         // Level 1.  Segmented edition (one pass, fixed-capacity segments) when the round is big enough for its fixed costs; the
         // exact edition (count + scan + scatter) otherwise, and for the rest of the call once a segmented round overflowed.
         const uint64_t est_items = (uint64_t)((double)m * items_per_start);
-        uint64_t seg_cap = est_items / ((uint64_t)W * g.P1);
-        seg_cap += seg_cap / 24 + SEG_PAD;
-        if (g_test_l1_cpb) seg_cap = std::min<uint64_t>(seg_cap, g_test_l1_cpb);
-        const uint64_t cap_plain = seg_cap;                                         // k-mers a segment is expected to take at most (what the spill list must hold: 8 bytes each)
-        // groups (kg_partition.hpp: k_p1v2_scatter): a bucket's k-mers of a tile are padded to whole groups, 1.5 items per tile and bucket on average
-        if (g.hb1 != 4 && !g_test_l1_cpb) seg_cap += std::min<uint64_t>(3 * seg_cap, 2 * tiles_per_wg);
-        seg_cap = (seg_cap + 3) & ~3ULL;                                            // whole groups
-        const uint64_t stride64 = std::max<uint64_t>(8 * (uint64_t)W * cap_plain, (uint64_t)(4 + g.hb1) * W * seg_cap) + 32;   // bytes of a bucket (l1_bucket_base's + 32)
-        const bool seg = l1_fast_ok && (g_l1_fast == 2 || (ratio_known && est_items >= ((uint64_t)64 << 20))) && stride64 * g.P1 <= (uint64_t)l1_items * 8 &&
-                         seg_cap < (1u << 24) && stride64 <= 0xFFFFFFFFULL /* the kernel's segment arithmetic: 24 x 8 and 32 x 32 -> 64 bits */;
-        const uint64_t seg_slots = seg ? (uint64_t)W * seg_cap : 0;                // items of one bucket
-        const uint32_t bucket_stride = (uint32_t)stride64;
-        g.l1_stride = seg ? stride64 : 0;
-        g.l1_real = seg ? (uint64_t)W * cap_plain : 0;
         const bool lean = g_l1_lean && lean_applies(k, g.pl.n1);
         const bool pb512 = g.P1 <= 512;
+        // The segmented edition's BLOCK form (kg_l1_blocks.hpp): 6-byte items in 64-byte blocks of ten, one 1024-thread workgroup per CU, 16 K-base tiles.
+        const bool l1b = g_l1_blocks && lean && pb512 && g.hb1 == 2;
+        const uint32_t Ws = l1b ? (uint32_t)c->n_cu : W;                            // workgroups of the segmented edition (<= W: the small arrays hold them)
+        const uint64_t n_tiles_s = l1b ? (m + L1B_TILE_STARTS - 1) / L1B_TILE_STARTS : n_tiles;
+        const uint64_t tiles_per_wg_s = (n_tiles_s + Ws - 1) / Ws;
+        uint64_t seg_cap = est_items / ((uint64_t)Ws * g.P1);
+        seg_cap += seg_cap / 24 + SEG_PAD;
+        if (g_test_l1_cpb) seg_cap = std::min<uint64_t>(seg_cap, g_test_l1_cpb);
+        if (l1b) seg_cap = (seg_cap + L1B_ITEMS - 1) / L1B_ITEMS * L1B_ITEMS;       // whole blocks: every slot may hold a k-mer
+        const uint64_t cap_plain = seg_cap;                                         // k-mers a segment is expected to take at most (what the spill list must hold: 8 bytes each)
+        // groups (kg_partition.hpp: k_p1v2_scatter): a bucket's k-mers of a tile are padded to whole groups, 1.5 items per tile and bucket on average
+        if (!l1b && g.hb1 != 4 && !g_test_l1_cpb) seg_cap += std::min<uint64_t>(3 * seg_cap, 2 * tiles_per_wg_s);
+        if (!l1b) seg_cap = (seg_cap + 3) & ~3ULL;                                  // whole groups
+        const uint64_t stride64 = l1b ? align_up(8 * (uint64_t)Ws * cap_plain + 32, 64)      // (blocks start on 64-byte boundaries; 6.4 bytes per item lie inside the 8)
+                                      : std::max<uint64_t>(8 * (uint64_t)Ws * cap_plain, (uint64_t)(4 + g.hb1) * Ws * seg_cap) + 32;   // bytes of a bucket (l1_bucket_base's + 32)
+        const bool seg = l1_fast_ok && (g_l1_fast == 2 || (ratio_known && est_items >= ((uint64_t)64 << 20))) && stride64 * g.P1 <= (uint64_t)l1_items * 8 &&
+                         seg_cap < (1u << 24) && stride64 <= 0xFFFFFFFFULL /* the kernel's segment arithmetic: 24 x 8 and 32 x 32 -> 64 bits */;
+        const uint64_t seg_slots = seg ? (uint64_t)Ws * seg_cap : 0;               // items of one bucket
+        const uint32_t bucket_stride = (uint32_t)stride64;
+        g.l1_stride = seg ? stride64 : 0;
+        g.l1_real = seg ? (uint64_t)Ws * cap_plain : 0;
+        const bool l1_blocked = seg && l1b;                                         // what level 2 reads this round: blocks of ten, or groups
         uint64_t items = 0;
         unsigned long long ovf_l1 = 0;
         HIPCHK(c, hipMemsetAsync(spill_n, 0, 2 * sizeof(unsigned long long), c->stream));          // spill_n, ovf_n
@@ -425,14 +435,34 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
             items = est_items;                                                    // the exact number is not needed (and not known)
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1S, items);
-#define KG_L1S(LEAN, PB) hipLaunchKernelGGL((k_p1v2_scatter<true, LEAN, PB>), dim3(W), dim3(P1_BLOCK), 0, c->stream, t->dv, g, p, (uint64_t)nb, n_tiles, tiles_per_wg, \
+#define KG_L1S(LEAN, PB) hipLaunchKernelGGL((k_p1v2_scatter<true, LEAN, PB>), dim3(Ws), dim3(P1_BLOCK), 0, c->stream, t->dv, g, p, (uint64_t)nb, n_tiles_s, tiles_per_wg_s, \
                                                (const uint64_t*)nullptr, (const uint64_t*)nullptr, l1_buf, (uint32_t)seg_cap, bucket_stride, (uint32_t)cap_plain, ovf_buf, ovf_n, ovf_cap)
+                if (l1b) {
+                    if (g_l1b_stamp) {                                             // diagnostic: wave 0's cycles per phase
+                        unsigned long long* stamps = spill_n + 16;
+                        HIPCHK(c, hipMemsetAsync(stamps, 0, 10 * sizeof(unsigned long long), c->stream));
+                        KG_LDS_ATTR(k_p1b_scatter<true>, sizeof(P1BLds));
+                        hipLaunchKernelGGL(k_p1b_scatter<true>, dim3(Ws), dim3(L1B_THREADS), sizeof(P1BLds), c->stream, t->dv, g, p, (uint64_t)nb, n_tiles_s, tiles_per_wg_s,
+                                           l1_buf, (uint32_t)(seg_cap / L1B_ITEMS), bucket_stride, ovf_buf, ovf_n, ovf_cap, stamps);
+                        unsigned long long st[10];
+                        HIPCHK(c, hipMemcpyAsync(st, stamps, sizeof st, hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        double tot = 0;
+                        for (int i = 0; i < 9; ++i) tot += (double)st[i];
+                        if (st[9]) fprintf(stderr, "[katgpu] level-1 (blocks) stamps (wave 0 of every workgroup, cycles summed): codes %.1f %%  blocks out %.1f %% (+ barrier %.1f %%)  sweep %.1f %% (+ %.1f %%)  per bucket %.1f %% (+ %.1f %%)  placing %.1f %% (+ %.1f %%); %llu tiles, %.0f cycles per tile\n",
+                                           100 * st[0] / tot, 100 * st[1] / tot, 100 * st[2] / tot, 100 * st[3] / tot, 100 * st[4] / tot, 100 * st[5] / tot, 100 * st[6] / tot, 100 * st[7] / tot, 100 * st[8] / tot, st[9], tot / st[9]);
+                    } else {
+                        KG_LDS_ATTR(k_p1b_scatter<false>, sizeof(P1BLds));
+                        hipLaunchKernelGGL(k_p1b_scatter<false>, dim3(Ws), dim3(L1B_THREADS), sizeof(P1BLds), c->stream, t->dv, g, p, (uint64_t)nb, n_tiles_s, tiles_per_wg_s,
+                                           l1_buf, (uint32_t)(seg_cap / L1B_ITEMS), bucket_stride, ovf_buf, ovf_n, ovf_cap, (unsigned long long*)nullptr);
+                    }
+                } else
                 if (lean) { if (pb512) KG_L1S(true, 512); else KG_L1S(true, MAX_PARTS); }
                 else { if (pb512) KG_L1S(false, 512); else KG_L1S(false, MAX_PARTS); }
 #undef KG_L1S
             }
             HIPCHK(c, hipMemcpyAsync(&ovf_l1, ovf_n, sizeof ovf_l1, hipMemcpyDeviceToHost, c->stream));      // read at the next synchronisation
-            if (g_trace) fprintf(stderr, "[katgpu] partition round (segmented level 1): %zu starts, ~%llu items, %llu k-mers per segment (arena %.1f GB)\n", m, (unsigned long long)items, (unsigned long long)seg_cap, c->arena_bytes / 1e9);
+            if (g_trace) fprintf(stderr, "[katgpu] partition round (segmented level 1%s): %zu starts, ~%llu items, %llu k-mers per segment (arena %.1f GB)\n", l1b ? ", blocks of ten" : "", m, (unsigned long long)items, (unsigned long long)seg_cap, c->arena_bytes / 1e9);
         } else {
             {
                 ScopedTimer tm(c, KATGPU_K_PART_L1, m);
@@ -502,6 +532,9 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                 HIPCHK(c, hipMemsetAsync(spill_n, 0, sizeof(unsigned long long), c->stream));
                 if (try_fast) {
                     ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
+#define KG_P2F_B(HB) case HB: KG_LDS_ATTR((k_p2_fast<HB, false, false, true>), sizeof(P2FastLds<HB>::type)); \
+                            hipLaunchKernelGGL((k_p2_fast<HB, false, false, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FastLds<HB>::type), c->stream, g, l1_off, l1_buf, l2_buf, \
+                                               off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); break;
 #define KG_P2F(HB) case HB: if (g.hb1 == 4) hipLaunchKernelGGL((k_p2_fast<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FastLds<HB>::type), c->stream, g, l1_off, l1_buf, l2_buf, \
                                                off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr); \
                             else hipLaunchKernelGGL((k_p2_fast<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FastLds<HB>::type), c->stream, g, l1_off, l1_buf, l2_buf, \
@@ -510,6 +543,9 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                         unsigned long long* stamps = spill_n + 16;
                         HIPCHK(c, hipMemsetAsync(stamps, 0, 6 * sizeof(unsigned long long), c->stream));
                         KG_LDS_ATTR((k_p2_fast<1, false, true>), sizeof(P2FastLds<1>::type));
+                        KG_LDS_ATTR((k_p2_fast<1, false, true, true>), sizeof(P2FastLds<1>::type));
+                        if (l1_blocked) hipLaunchKernelGGL((k_p2_fast<1, false, true, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FastLds<1>::type), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, stamps);
+                        else
                         hipLaunchKernelGGL((k_p2_fast<1, false, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2FastLds<1>::type), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, stamps);
                         unsigned long long st[6];
                         HIPCHK(c, hipMemcpyAsync(st, stamps, sizeof st, hipMemcpyDeviceToHost, c->stream));
@@ -517,9 +553,12 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                         const double tot = (double)(st[0] + st[1] + st[2] + st[3] + st[4]);
                         if (st[5]) fprintf(stderr, "[katgpu] level-2 stamps (lane 0 of every workgroup, cycles summed): wait for the tile %.0f %%  digit + rank %.0f %%  scan %.0f %%  staging %.0f %%  copy-out %.0f %%; %llu tiles, %.0f cycles per tile\n",
                                            100 * st[0] / tot, 100 * st[1] / tot, 100 * st[2] / tot, 100 * st[3] / tot, 100 * st[4] / tot, st[5], tot / st[5]);
+                    } else if (l1_blocked) {
+                        switch (g.hb) { KG_P2F_B(0) KG_P2F_B(1) KG_P2F_B(2) default: return fail(c, KATGPU_ERR_DEVICE, "level 2 from blocked level-1 items: item width %u", g.hb); }
                     } else
                     switch (g.hb) { KG_FOR_HB(KG_P2F) }
 #undef KG_P2F
+#undef KG_P2F_B
                 }
                 if (try_fast || (seg && b_lo == 0)) {
                     HIPCHK(c, hipMemcpyAsync(&overflowed, ovf_n, sizeof overflowed, hipMemcpyDeviceToHost, c->stream));
@@ -543,8 +582,13 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                     ScopedTimer tm(c, KATGPU_K_PART_L2, pass_items);
 #define KG_P2(HB) case HB: if (g.hb1 == 4) hipLaunchKernelGGL((k_p2<HB, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, off2, seg_slots, bend); \
                            else hipLaunchKernelGGL((k_p2<HB, false>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, off2, seg_slots, bend); break;
+#define KG_P2_B(HB) case HB: KG_LDS_ATTR((k_p2<HB, false, true>), sizeof(P2Lds<HB>)); \
+                           hipLaunchKernelGGL((k_p2<HB, false, true>), dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2Lds<HB>), c->stream, g, l1_off, l1_buf, l2_buf, off2, seg_slots, bend); break;
+                    if (l1_blocked) { switch (g.hb) { KG_P2_B(0) KG_P2_B(1) KG_P2_B(2) default: return fail(c, KATGPU_ERR_DEVICE, "level 2 from blocked level-1 items: item width %u", g.hb); } }
+                    else
                     switch (g.hb) { KG_FOR_HB(KG_P2) }
 #undef KG_P2
+#undef KG_P2_B
                 }
                 ovf_total = overflowed;
                 const uint64_t* bucket_end = !run_len ? bend : nullptr;             // exact level 2: a bucket's runs stop short of the next bucket's

@@ -723,6 +723,10 @@ k_p1v2_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64
     }
 }
 
+}  // namespace kg
+#include "kg_l1_blocks.hpp"
+namespace kg {
+
 // bucket b1 of the level-1 buffer: its first item and number of items (in items of the round; segment and group padding
 // included) and the byte its groups start at.  Exact layout (l1_off) or segmented (seg_slots = workgroups x seg_cap items per bucket,
 // "no item"-padded, buckets l1_stride bytes apart).
@@ -829,9 +833,44 @@ __device__ __forceinline__ uint32_t p2_tile_load_narrow(uint32_t hb1, const uint
     p2_tile_issue_narrow<N>(hb1, bucket, tbeg, r);
     return p2_tile_decode_narrow<N>(hb1, tbeg, n_items, r, it);
 }
-template <int N, bool W1>
+// The level-1 buffer's BLOCKED form (kg_l1_blocks.hpp: 6-byte items in 64-byte blocks of five pair records): a lane takes N / 2 pairs, each with
+// ONE 12-byte load -- {low a, low b, high a | high b << 16} is what TileItems keeps: no permute.  Pair p of the bucket lies 12 (p % 5) bytes into
+// block p / 5.
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+template <int N> struct RawTileB { u32x3 v[N / 2]; };
+template <int N>
+__device__ __forceinline__ void p2_tile_issue_l1b(const uint8_t* __restrict__ bucket, uint64_t tbeg, RawTileB<N>& r) {
+    const uint32_t p0 = (uint32_t)(tbeg >> 1) + threadIdx.x;                   // (a bucket holds fewer than 2^32 bytes)
+    uint32_t blk = __umulhi(p0, 0xCCCCCCCDu) >> 2, part = p0 - 5 * blk;
+#pragma unroll
+    for (int u = 0; u < N / 2; ++u) {
+        // (a 32-bit offset from the bucket's wave-uniform base: one register per load in flight, not two)
+        r.v[u] = *reinterpret_cast<const u32x3_a4*>(bucket + (uint32_t)((blk << 6) + 12 * part));
+        blk += PART_BLOCK / 5; part += PART_BLOCK % 5;                          // the lane's next pair is 1024 pairs on: 204 blocks and 4 pairs
+        if (part >= 5) { part -= 5; ++blk; }
+    }
+}
+template <int N>
+__device__ __forceinline__ uint32_t p2_tile_decode_l1b(uint64_t tbeg, uint64_t n_items, const RawTileB<N>& r, TileItems<N, false>& it) {
+    const uint64_t left = tbeg < n_items ? n_items - tbeg : 0;
+    const uint32_t t_items = left < (uint64_t)N * PART_BLOCK ? (uint32_t)left : (uint32_t)N * PART_BLOCK;
+    uint32_t valid = 0;
+#pragma unroll
+    for (int u = 0; u < N / 2; ++u) {
+        const uint32_t i0 = 2 * ((uint32_t)u * PART_BLOCK + threadIdx.x);
+        it.lo[2 * u] = r.v[u].x; it.lo[2 * u + 1] = r.v[u].y; it.hi[u] = r.v[u].z;
+        uint32_t ta = (i0 < t_items && !(r.v[u].x == 0xFFFFFFFFu && (r.v[u].z & 0xFFFFu) == 0xFFFFu)) ? 1u : 0u;
+        uint32_t tb = (i0 + 1 < t_items && !(r.v[u].y == 0xFFFFFFFFu && (r.v[u].z >> 16) == 0xFFFFu)) ? 1u : 0u;
+        asm volatile("" : "+v"(ta), "+v"(tb));
+        valid |= (ta << (2 * u)) | (tb << (2 * u + 1));
+    }
+    return valid;
+}
+template <int N, bool W1, bool L1B = false>
 __device__ __forceinline__ uint32_t p2_tile_load(uint32_t hb1, const uint8_t* __restrict__ bucket, uint64_t tbeg, uint64_t n_items, TileItems<N, W1>& it) {
     if constexpr (W1) return p2_tile_load_wide<N>(bucket, tbeg, n_items, it);
+    else if constexpr (L1B) { RawTileB<N> r; p2_tile_issue_l1b<N>(bucket, tbeg, r); return p2_tile_decode_l1b<N>(tbeg, n_items, r, it); }
     else return p2_tile_load_narrow<N>(hb1, bucket, tbeg, n_items, it);
 }
 
@@ -1131,6 +1170,8 @@ __device__ __forceinline__ void scatter_tile2_blk(P2BLds& L, const PartGeom g, c
     lds_barrier();
     const unsigned long long t2 = now();
     // phase A: ranks below twelve into the image, whole blocks' worth into the staging arrays; the rest waits for phase C
+    // (a branch-free form -- one index into the carve for either destination, as level 1's block edition has it -- needs registers this kernel
+    // does not have next to the tile in flight: nineteen spilled, some of them inside the tile loop)
     {
         constexpr int SB = 4;
         uint32_t go[SB];
@@ -1222,7 +1263,7 @@ __device__ __host__ __forceinline__ uint64_t p2_exact_base(uint64_t beg, uint32_
 
 // The exact edition: one workgroup per level-1 bucket: histogram by digit, scan, scatter.  off2[r] = start of region r's run (a
 // multiple of 4: runs begin on group boundaries; the up to three items between a run's last k-mer and the next run are "no item").
-template <int HB, bool W1 /* level-1 items of more than 48 bits (HB1 = 4) */>
+template <int HB, bool W1 /* level-1 items of more than 48 bits (HB1 = 4) */, bool L1B = false /* the level-1 buffer holds blocks of ten (kg_l1_blocks.hpp) */>
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
      uint64_t* __restrict__ off2, uint64_t seg_slots, uint64_t* __restrict__ bend /* end of bucket b1's last run: the next bucket's runs start later */) {
@@ -1244,7 +1285,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict_
         lds_barrier();
         for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
             TileItems<N, W1> key;
-            const uint32_t valid = p2_tile_load<N, W1>(g.hb1, bucket, tbeg, n_items, key);
+            const uint32_t valid = p2_tile_load<N, W1, L1B>(g.hb1, bucket, tbeg, n_items, key);
 #pragma unroll
             for (int j = 0; j < N; ++j)
                 if (valid >> j & 1) atomicAdd(&h64[place_digit2_of(key.r1(j), g.pl)], 1ULL);
@@ -1262,7 +1303,7 @@ k_p2(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict_
         if (bend && tid == g.P2 - 1) bend[b1] = obeg + excl + ((mine + 3) & ~3ULL);             // the runs of a bucket stop short of the next bucket's
         for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {                     // pass B
             TileItems<N, W1> key;
-            const uint32_t valid = p2_tile_load<N, W1>(g.hb1, bucket, tbeg, n_items, key);
+            const uint32_t valid = p2_tile_load<N, W1, L1B>(g.hb1, bucket, tbeg, n_items, key);
             lds_barrier();
             scatter_tile2<HB, W1>(L, g, key, valid, l2_buf);
         }
@@ -1290,7 +1331,7 @@ __device__ __host__ __forceinline__ uint64_t p2_out_base(uint64_t beg, uint32_t 
     return (o + al - 1) / al * al;
 }
 
-template <int HB, bool W1, bool STAMP = false>
+template <int HB, bool W1, bool STAMP = false, bool L1B = false /* the level-1 buffer holds blocks of ten (kg_l1_blocks.hpp) */>
 __global__ void __launch_bounds__(PART_BLOCK)
 k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __restrict__ l1_buf, uint8_t* __restrict__ l2_buf,
           uint64_t* __restrict__ off2, uint32_t* __restrict__ cnt2, uint64_t* __restrict__ ovf_buf, unsigned long long* __restrict__ ovf_n,
@@ -1336,24 +1377,26 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
             // three ways of doing this and kept none: with a sub-bucket's piece leaving as 20-byte groups the memory system took a tile's 98 KB in
             // and ~90 KB out at its own pace -- 22 ms per launch for the bare pattern, the kernel's own time -- wherever the wait was taken.  Whole
             // lines from a quad of lanes lower that floor to 16.6 ms (tools/ubench_l2_layout.hip): now there is something to overlap with.)
-            RawTile<N> raw;
-            p2_tile_issue_narrow<N>(g.hb1, bucket, 0, raw);
+            typename std::conditional<L1B, RawTileB<N>, RawTile<N>>::type raw;
+            auto issue = [&](uint64_t at) { if constexpr (L1B) p2_tile_issue_l1b<N>(bucket, at, raw); else p2_tile_issue_narrow<N>(g.hb1, bucket, at, raw); };
+            issue(0);
             for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
                 const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
                 TileItems<N, W1> key;
-                const uint32_t valid = p2_tile_decode_narrow<N>(g.hb1, tbeg, n_items, raw, key);
+                uint32_t valid;
+                if constexpr (L1B) valid = p2_tile_decode_l1b<N>(tbeg, n_items, raw, key); else valid = p2_tile_decode_narrow<N>(g.hb1, tbeg, n_items, raw, key);
                 if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
                 lds_barrier();
                 if (STAMP) { st[0] += (unsigned long long)clock64() - ta; st[5] += 1; }
                 // (the last tile's prefetch reads what lies behind the bucket: the next bucket, or the level-2 buffer -- mapped, never decoded)
                 scatter_tile2_blk<W1, STAMP>(L, g, b1, key, valid, runs, capg, ovf_buf, ovf_n, ovf_cap, carry_n, st,
-                                             [&]() { p2_tile_issue_narrow<N>(g.hb1, bucket, tbeg + L2Fmt<HB>::TILE, raw); });
+                                             [&]() { issue(tbeg + L2Fmt<HB>::TILE); });
             }
         } else
         for (uint64_t tbeg = 0; tbeg < n_items; tbeg += L2Fmt<HB>::TILE) {
             const unsigned long long ta = STAMP ? (unsigned long long)clock64() : 0ULL;
             TileItems<N, W1> key;
-            const uint32_t valid = p2_tile_load<N, W1>(g.hb1, bucket, tbeg, n_items, key);
+            const uint32_t valid = p2_tile_load<N, W1, L1B>(g.hb1, bucket, tbeg, n_items, key);
             if (STAMP) { __builtin_amdgcn_s_waitcnt(0); }
             lds_barrier();
             if (STAMP) { st[0] += (unsigned long long)clock64() - ta; st[5] += 1; }
