@@ -211,11 +211,16 @@ k_p1b_scatter(DevTable t, PartGeom g, const uint8_t* __restrict__ bases, uint64_
                     const bool ok = (v16 & (0x8000u >> j)) != 0;
                     const uint32_t v = (rk2[j >> 1] >> (16 * (j & 1))) & 0xFFFFu, lf = G[u].x >> 16;
                     const uint32_t q = __umulhi(v, 0xCCCCCCCDu) >> 3;
-                    uint32_t s_p = v - L1B_ITEMS * q, s_l = v - lf, B_p = G[u].y + q;
-                    asm volatile("" : "+v"(s_p), "+v"(s_l), "+v"(B_p));           // (both candidates computed: the choice is two selects, not a branch per item)
+                    uint32_t s = v - L1B_ITEMS * q, B_p = G[u].y + q;              // (what is left over has q = nblk: its slot in the waiting image is v - 10 q as well)
+                    asm volatile("" : "+v"(s), "+v"(B_p));                         // (both candidates computed: the choice is a select, not a branch per item)
                     const bool placed = v < (G[u].x & 0xFFFFu), later = v >= lf;
-                    const uint32_t B = (later ? hs[j] >> 16 : B_p) * 16, s = later ? s_l : s_p;
-                    if (ok && (placed || later)) { L.img[l1b_lo_at(B, s)] = lo[j]; img16[l1b_hi_at(B, s)] = (uint16_t)hs[j]; }
+                    const uint32_t B = later ? hs[j] >> 16 : B_p, odd = s & 1u;
+                    // slot s of image B, in bytes: low word at 64 B + 12 (s >> 1) + 4 (s & 1) = 64 B + 6 s - 2 odd, high half 8 - 2 odd behind it
+                    const uint32_t lo_at = (B << 6) + 6u * s - 2u * odd;
+                    if (ok && (placed || later)) {
+                        *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(L.img) + lo_at) = lo[j];
+                        *reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(L.img) + lo_at + 8u - 2u * odd) = (uint16_t)hs[j];
+                    }
                     lostm |= (ok && !placed && !later) ? 1u << j : 0u;
                 }
             }
