@@ -50,6 +50,7 @@ static const bool g_scan_off = getenv("KATGPU_DEVICE_SCAN") && atoi(getenv("KATG
 // is what a run pays): page-cache files pread at 230-330 GB/s, but tmpfs files at 16-27 GB/s (and no faster with more threads: every
 // page's first pread moves it between the kernel's shared-memory LRU lists, under one lock), where the same bytes come out of a
 // mapping at 120 GB/s.  KATGPU_SCAN_MMAP=0 / 1 forces one or the other.
+static const bool g_scan_populate = getenv("KATGPU_SCAN_POPULATE") ? atoi(getenv("KATGPU_SCAN_POPULATE")) != 0 : false;   // strip readers: MADV_POPULATE_READ on a segment before it is looked at
 static const int g_scan_mmap = getenv("KATGPU_SCAN_MMAP") ? atoi(getenv("KATGPU_SCAN_MMAP")) : -1;
 // tests: small batches / overlaps (bytes) so that little files cross many cuts; force the host fall-back from batch N on
 static const size_t g_test_scan_batch = (size_t)hook_u64("KATGPU_TEST_SCAN_BATCH", 0), g_test_scan_overlap = (size_t)hook_u64("KATGPU_TEST_SCAN_OVERLAP", 0);
@@ -298,6 +299,9 @@ struct RawFeeder {
             else if (map) {
                 struct stat st0;                                  // (a file cut short under the run: KATGPU_ERR_IO between segments, SIGBUS inside one -- INTEGRATION.md)
                 if (fstat(fd, &st0) != 0 || (uint64_t)st0.st_size < w1) sg.state = 3; else buf = map + w0;
+                // the segment's page-table entries in ONE call instead of a fault per sixteen pages (the faults of sixteen readers into one address
+                // space were two thirds of a reader's time: DESIGN.md section 4)
+                if (sg.state == 1 && g_scan_populate) { const uint64_t a0 = w0 & ~4095ULL; (void)madvise(const_cast<uint8_t*>(map) + a0, (size_t)(w1 - a0), 22 /* MADV_POPULATE_READ, Linux 5.14 (an older kernel says EINVAL: the faults do it) */); }
             } else {
                 tmp.resize((size_t)(w1 - w0));
                 uint64_t got = 0;
