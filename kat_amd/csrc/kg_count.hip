@@ -99,6 +99,8 @@ static const uint32_t g_apply_nr = (uint32_t)hook_u64("KATGPU_APPLY_NR", 2);    
 static const uint32_t g_apply_min_q = (uint32_t)hook_u64("KATGPU_APPLY_MIN_Q", 72);     // A/B: queue entries per wave the SECOND workgroup of a CU must leave (>= 72)
 static const uint32_t g_apply_per_cu = (uint32_t)hook_u64("KATGPU_APPLY_PER_CU", 0);   // A/B: packed apply workgroups per CU (0: as many as the LDS holds)
 static const bool g_l1b_stamp = hook_u64("KATGPU_L1B_STAMP", 0) != 0;   // diagnostic: level 1's block edition with cycle stamps (printed per round)
+static const bool g_p2x = hook_u64("KATGPU_P2X", 1) != 0;   // A/B: 0 = k_p2_fast's block edition where kg_l2_blocks.hpp's kernel would run
+static const bool g_p2x_stamp = hook_u64("KATGPU_P2X_STAMP", 0) != 0;   // diagnostic: that kernel with cycle stamps (printed per pass)
 static const bool g_p2_stamp = hook_u64("KATGPU_P2_STAMP", 0) != 0;   // diagnostic: the bench-shape one-pass level 2 with cycle stamps (printed per pass)
 static const bool g_apply_stamp = hook_u64("KATGPU_APPLY_STAMP", 0) != 0;              // diagnostic: the bench-shape apply with cycle stamps (printed per pass)
 
@@ -553,6 +555,23 @@ static int count_partitioned(katgpu_table* t, const uint8_t* dev_bases, size_t n
                         const double tot = (double)(st[0] + st[1] + st[2] + st[3] + st[4]);
                         if (st[5]) fprintf(stderr, "[katgpu] level-2 stamps (lane 0 of every workgroup, cycles summed): wait for the tile %.0f %%  digit + rank %.0f %%  scan %.0f %%  staging %.0f %%  copy-out %.0f %%; %llu tiles, %.0f cycles per tile\n",
                                            100 * st[0] / tot, 100 * st[1] / tot, 100 * st[2] / tot, 100 * st[3] / tot, 100 * st[4] / tot, st[5], tot / st[5]);
+                    } else if (l1_blocked && g.hb == 1 && g_p2x) {                   // the bench's shape: kg_l2_blocks.hpp
+                        if (g_p2x_stamp) {
+                            unsigned long long* stamps = spill_n + 16;
+                            HIPCHK(c, hipMemsetAsync(stamps, 0, 10 * sizeof(unsigned long long), c->stream));
+                            KG_LDS_ATTR(k_p2x_fast<true>, sizeof(P2XLds));
+                            hipLaunchKernelGGL(k_p2x_fast<true>, dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2XLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, stamps);
+                            unsigned long long st[10];
+                            HIPCHK(c, hipMemcpyAsync(st, stamps, sizeof st, hipMemcpyDeviceToHost, c->stream));
+                            HIPCHK(c, hipStreamSynchronize(c->stream));
+                            double tot = 0;
+                            for (int i = 0; i < 9; ++i) tot += (double)st[i];
+                            if (st[9]) fprintf(stderr, "[katgpu] level-2 (blocks in, blocks out) stamps (wave 0 of every workgroup, cycles summed): wait for the tile %.1f %% (+ barrier %.1f %%)  ranking + blocks out %.1f %% (+ %.1f %%)  per sub-bucket %.1f %% (+ %.1f %%)  placing %.1f %%; %llu tiles, %.0f cycles per tile\n",
+                                               100 * st[0] / tot, 100 * st[1] / tot, 100 * st[2] / tot, 100 * st[3] / tot, 100 * st[4] / tot, 100 * st[5] / tot, 100 * st[6] / tot, st[9], tot / st[9]);
+                        } else {
+                            KG_LDS_ATTR(k_p2x_fast<false>, sizeof(P2XLds));
+                            hipLaunchKernelGGL(k_p2x_fast<false>, dim3(grid_l2), dim3(PART_BLOCK), sizeof(P2XLds), c->stream, g, l1_off, l1_buf, l2_buf, off2, cnt2, ovf_buf, ovf_n, ovf_cap, seg_slots, (unsigned long long*)nullptr);
+                        }
                     } else if (l1_blocked) {
                         switch (g.hb) { KG_P2F_B(0) KG_P2F_B(1) KG_P2F_B(2) default: return fail(c, KATGPU_ERR_DEVICE, "level 2 from blocked level-1 items: item width %u", g.hb); }
                     } else

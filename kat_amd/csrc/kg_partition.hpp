@@ -1416,6 +1416,10 @@ k_p2_fast(PartGeom g, const uint64_t* __restrict__ l1_off, const uint8_t* __rest
     if (STAMP && tid == 0 && stamps) for (int i = 0; i < 6; ++i) atomicAdd(&stamps[i], st[i]);
 }
 
+}  // namespace kg
+#include "kg_l2_blocks.hpp"
+namespace kg {
+
 // ---- level 3: apply a region's run to the region, in LDS (KV12 tables: keys[S] u64 | counts[S] u32) ----
 // A walk with one probe chain per lane inside a divergent loop (round 1's kernel) is bound by dependent LDS round trips, not by LDS
 // or VALU throughput (profiles/r01_partitioned_sq_counters.txt: waves parked 67 % of their cycles, LDS array 15 % busy).

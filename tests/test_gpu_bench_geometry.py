@@ -37,7 +37,8 @@ def _both_ways(engine, k, n_reads, genome, hint):
     tp = engine.table(k, True, size_hint=hint)
     tp.count_bases_device(reads.ptr, reads.nbytes)
     prof = engine.profile()
-    assert prof["part_apply"]["launches"] > 0 and prof["part_l1_scatter"]["launches"] > 0 and prof["count"]["launches"] == 0, prof
+    # (the direct kernel: at most what level 2's pool of block images had no room for, a millionth of the k-mers -- kg_l2_blocks.hpp)
+    assert prof["part_apply"]["launches"] > 0 and prof["part_l1_scatter"]["launches"] > 0 and prof["count"]["units"] <= 1e-6 * n_reads * (L - k + 1), prof
     engine.profile_reset()
     td = engine.table(k, True, size_hint=hint, like=tp)
     rec = L + 1
@@ -86,7 +87,9 @@ def test_config4_full_size_partitioned_equals_direct(engine):
         engine.profile_reset()
         tp.count_bases_device(reads.ptr, reads.nbytes)
         prof = engine.profile()
-        assert prof["part_apply"]["launches"] > 0 and prof["count"]["launches"] == 0, prof
+        # (the direct kernel takes what level 2's pool of block images had no room for: a tile whose waiting items complete 4.4 sigma more blocks
+        # than the mean -- a few hundred k-mers of a round's 12.4 G, kg_l2_blocks.hpp; anything more means the partitioned path is not what ran)
+        assert prof["part_apply"]["launches"] > 0 and prof["count"]["units"] <= 1e-6 * step * (L - k + 1), prof
         engine.profile_reset()
         for a in range(0, step, 100_000):                      # 15.1 M window starts per call: below the partitioned counter's threshold
             td.count_bases_device(reads.ptr + a * rec, min(100_000, step - a) * rec)
