@@ -48,7 +48,10 @@ def test_no_scratch_and_the_stage_kernels_keep_their_budgets(tmp_path):
     # bucket (1479 tiles at the bench's size) -- the tile loop itself touches no scratch (read from the ISA: the reload sits at loop depth 1).
     # Its form that reads level 1's blocks of ten (the last template argument) spills six such pairs -- the per-lane addresses of a bucket's first
     # tile, again before the tile loop and reloaded once per bucket.
-    allowed = {"k_p2<": 40, "k_p2_fast<2, false": 24, "k_p2_fast<1, false": 16, "k_p2_fast<1, false, false, true": 64, "k_p2_fast<1, false, true, true": 64}
+    # kg_l2_blocks.hpp's kernel (the bench's shape since round 6) spills four address pairs of a bucket's FIRST tile request, before the tile loop
+    # (twice per workgroup and pass); inside the loop the requests are base + 32-bit offset and nothing touches scratch (read from the ISA).
+    allowed = {"k_p2<": 40, "k_p2_fast<2, false": 24, "k_p2_fast<1, false": 16, "k_p2_fast<1, false, false, true": 64, "k_p2_fast<1, false, true, true": 64,
+               "k_p2x_fast<": 40}
     spilled = {n: v for n, v in ks.items() if v["scratch"] > max([lim for pre, lim in allowed.items() if n.startswith(pre)], default=0)}
     assert not spilled, spilled
 
@@ -70,6 +73,7 @@ def test_no_scratch_and_the_stage_kernels_keep_their_budgets(tmp_path):
     assert all(v["scratch"] == 0 for n, v in ks.items() if n.startswith("k_p1b_scatter<")), {n: v for n, v in ks.items() if n.startswith("k_p1b_scatter<")}
     # level 2: one 1024-thread workgroup per CU = four waves per SIMD
     every("k_p2_fast<", vgpr=128)
+    every("k_p2x_fast<", vgpr=128)
     every("k_p2<", vgpr=128)
     # the applies: four waves per SIMD (two 512-thread workgroups, or one of 1024 threads)
     every("k_p3_apply_pk<", vgpr=128)
