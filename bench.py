@@ -404,6 +404,11 @@ def measure(eng, a, ctx, want_cpu):
         exch = {"max_over_ranks_ms_per_step": {q: round(allmax(comm_after[q] - comm_before[q]) / a.steps, 3) for q in ("extract_ms", "exchange_ms", "merge_ms", "allreduce_ms")},
                 "bytes_sent_per_step_all_ranks": allsum(comm_after["bytes_sent"] - comm_before["bytes_sent"]) // a.steps,
                 "bytes_sent_per_step_this_rank": int(comm_after["bytes_sent"] - comm_before["bytes_sent"]) // a.steps,
+                # the records themselves (not the count matrices, not the all-reduce): 9 bytes each -- what a slot holds of the k-mer + its count --
+                # between ranks whose tables have one region grid, 12 (key + count) otherwise
+                "records_sent_per_step_all_ranks": allsum(comm_after["records_sent"] - comm_before["records_sent"]) // a.steps,
+                "record_bytes_per_record": round(allsum(comm_after["record_bytes_sent"] - comm_before["record_bytes_sent"]) / max(1, allsum(comm_after["records_sent"] - comm_before["records_sent"])), 3),
+                "records_packed": bool(comm_after["records_packed"]),
                 "reading": "extract = table -> send list; exchange = posting the chunks + waiting for them (on the wire while the previous chunk is merged); merge = k_merge_apply; allreduce = the small results"}
 
     total_instances = world * inst_reads + inst2_total

@@ -254,6 +254,20 @@ int katgpu_table_merge_device32(katgpu_table* t, const uint64_t* dev_keys, const
  * by region in LDS, the others through the direct path.  Exact either way. */
 typedef struct { const uint64_t* dev_keys; const uint32_t* dev_counts; const uint32_t* dev_region_counts; uint64_t n_records; uint32_t p1, p2; } katgpu_merge_source;
 int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source* src);
+/* The same records in 9 bytes instead of 12, for owners that share the sender's region grid: a record is what a packed slot holds of
+ * the k-mer -- the remainder below the two placement digits, rb <= 44 bits -- below its count, 72 bits cut into dev_rem_lo (u32),
+ * dev_rem_hi (u8) and dev_counts (u32: for rb > 40 its low rb - 40 bits are the remainder's top ones and the count has the >= 28 bits above
+ * them; a count that does not fit travels in the big list, its record carrying 0); the region it lies in
+ * says the rest (the merged hashes of KAT's workers travel as whole k-mers, lib/include/kat/sparse_matrix.hpp:324-335 and
+ * lib/src/comp_counters.cc:230-254 sum in one address space: this is the wire format of their replacement).  katgpu_table_packed_records:
+ * 1 when the table can give such records (a packed table: k <= 32 and >= 2^(2k - 44) regions, every table of size).  A merge
+ * source of this form MUST carry its region counts and the sender's grid; if the receiving table has another grid by then (it grew), the
+ * k-mers are rebuilt from the sender's grid and go through the direct path.  Exact either way. */
+int katgpu_table_packed_records(const katgpu_table* t);
+int katgpu_table_extract_packed(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint32_t* dev_rem_lo, uint8_t* dev_rem_hi,
+                                uint32_t* dev_counts, uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big);
+typedef struct { const uint32_t* dev_rem_lo; const uint8_t* dev_rem_hi; const uint32_t* dev_counts; const uint32_t* dev_region_counts; uint64_t n_records; uint32_t p1, p2; } katgpu_merge_source_packed;
+int katgpu_table_merge_regions_packed(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source_packed* src);
 
 /* ---- the exchange itself, over RCCL: one process per GPU (kat_amd/csrc/kg_comm.hip) ----
  * Replaces, across GPUs, what the reference does across threads of one process at the end of a run:
@@ -292,6 +306,9 @@ int  katgpu_allreduce_u64(katgpu_comm* comm, uint64_t* buf, size_t n);
 /* wall time spent so far in extraction / on the wire (posting + waiting) / merging / all-reducing (ms), bytes sent, merge calls */
 int  katgpu_comm_stats(katgpu_comm* comm, double* ms_extract, double* ms_exchange, double* ms_merge, double* ms_allreduce,
                        uint64_t* bytes_sent, uint64_t* merge_launches);
+/* the records katgpu_exchange_merge has sent so far, their bytes, and the form of the last exchange's (1: remainder + count, 9 bytes --
+ * every rank's table had one grid; 0: key + count, 12 bytes) */
+int  katgpu_comm_wire(katgpu_comm* comm, uint64_t* records_sent, uint64_t* record_bytes_sent, int* packed);
 
 /* ---- measurement ------------------------------------------------------------------------------------- */
 /* HIP-event timing of the kernels this ctx launched, per kernel class, accumulated since the last reset. */

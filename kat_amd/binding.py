@@ -38,6 +38,7 @@ EXPORTS = (
     "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_place_keys", "katgpu_reserve", "katgpu_device_count",
     "katgpu_count_files_sharded", "katgpu_table_slot_bytes", "katgpu_comm_unique_id", "katgpu_comm_init", "katgpu_comm_free", "katgpu_comm_rank", "katgpu_comm_world", "katgpu_comm_transport",
     "katgpu_comm_transport_note", "katgpu_comm_distinct_devices", "katgpu_comm_barrier", "katgpu_exchange_merge", "katgpu_allreduce_u64", "katgpu_comm_stats",
+    "katgpu_table_packed_records", "katgpu_table_extract_packed", "katgpu_table_merge_regions_packed", "katgpu_comm_wire",
 )
 
 
@@ -48,6 +49,11 @@ class Geometry(C.Structure):
 
 class MergeSource(C.Structure):
     _fields_ = [("dev_keys", C.c_void_p), ("dev_counts", C.c_void_p), ("dev_region_counts", C.c_void_p), ("n_records", C.c_uint64),
+                ("p1", C.c_uint32), ("p2", C.c_uint32)]
+
+
+class MergeSourcePacked(C.Structure):
+    _fields_ = [("dev_rem_lo", C.c_void_p), ("dev_rem_hi", C.c_void_p), ("dev_counts", C.c_void_p), ("dev_region_counts", C.c_void_p), ("n_records", C.c_uint64),
                 ("p1", C.c_uint32), ("p2", C.c_uint32)]
 
 
@@ -117,6 +123,9 @@ def load_library():
     L.katgpu_table_clear.argtypes = [vp]
     L.katgpu_table_merge_device32.argtypes = [vp, vp, vp, sz]
     L.katgpu_table_merge_regions.argtypes = [vp, u32, u32, u32, vp]
+    L.katgpu_table_packed_records.argtypes = [vp]
+    L.katgpu_table_extract_packed.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, u32, C.POINTER(u32)]
+    L.katgpu_table_merge_regions_packed.argtypes = [vp, u32, u32, u32, vp]
     L.katgpu_profile_reset.argtypes = [vp]
     L.katgpu_profile_get.argtypes = [vp, C.c_int, pu64, C.POINTER(C.c_double), pu64]
     L.katgpu_dev_alloc.argtypes = [vp, sz, pp]
@@ -596,6 +605,23 @@ class Table:
                                                             bk.ctypes.data, bc.ctypes.data, BIG_CAP, C.byref(nb)))
         return bk[:nb.value].copy(), bc[:nb.value].copy()
 
+    def packed_records(self):
+        """True when the table can give 9-byte records (remainder + count): katgpu_table_extract_packed."""
+        return bool(self.engine.L.katgpu_table_packed_records(self.h))
+
+    def extract_packed(self, n_parts, dev_region_counts_ptr, dev_rem_lo_ptr, dev_rem_hi_ptr, dev_counts_ptr):
+        bk, bc, nb = np.zeros(BIG_CAP, np.uint64), np.zeros(BIG_CAP, np.uint64), C.c_uint32()
+        self.engine._chk(self.engine.L.katgpu_table_extract_packed(self.h, n_parts, dev_region_counts_ptr, dev_rem_lo_ptr, dev_rem_hi_ptr, dev_counts_ptr,
+                                                                   bk.ctypes.data, bc.ctypes.data, BIG_CAP, C.byref(nb)))
+        return bk[:nb.value].copy(), bc[:nb.value].copy()
+
+    def merge_regions_packed(self, g_lo, g_hi, sources):
+        """sources: (dev_rem_lo_ptr, dev_rem_hi_ptr, dev_counts_ptr, dev_region_counts_ptr, n_records, p1, p2) per sender."""
+        arr = (MergeSourcePacked * len(sources))()
+        for i, src in enumerate(sources):
+            arr[i] = MergeSourcePacked(*src)
+        self.engine._chk(self.engine.L.katgpu_table_merge_regions_packed(self.h, g_lo, g_hi, len(sources), C.cast(arr, C.c_void_p)))
+
     def clear(self):
         self.engine._chk(self.engine.L.katgpu_table_clear(self.h))
 
@@ -659,6 +685,7 @@ class Comm:
         L.katgpu_exchange_merge.argtypes = [C.c_void_p, C.c_void_p]
         L.katgpu_allreduce_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.katgpu_comm_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_uint64)] * 2
+        L.katgpu_comm_wire.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         h = C.c_void_p()
         assert len(comm_id) == COMM_ID_BYTES
         engine._chk(L.katgpu_comm_init(engine.h, rank, world, comm_id, C.byref(h)))
@@ -700,8 +727,12 @@ class Comm:
         d = [C.c_double() for _ in range(4)]
         u = [C.c_uint64() for _ in range(2)]
         self.engine._chk(self.engine.L.katgpu_comm_stats(self.h, *[C.byref(x) for x in d], *[C.byref(x) for x in u]))
+        w = [C.c_uint64(), C.c_uint64()]
+        pk = C.c_int()
+        self.engine._chk(self.engine.L.katgpu_comm_wire(self.h, C.byref(w[0]), C.byref(w[1]), C.byref(pk)))
         return {"extract_ms": d[0].value, "exchange_ms": d[1].value, "merge_ms": d[2].value, "allreduce_ms": d[3].value,
-                "bytes_sent": u[0].value, "merge_calls": u[1].value}
+                "bytes_sent": u[0].value, "merge_calls": u[1].value,
+                "records_sent": w[0].value, "record_bytes_sent": w[1].value, "records_packed": bool(pk.value)}
 
     def free(self):
         if getattr(self, "h", None) and getattr(self.engine, "h", None):

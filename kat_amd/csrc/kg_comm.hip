@@ -148,6 +148,8 @@ struct katgpu_comm {
     uint64_t seq = 0;                         // names the shm files of successive transfers
     double ms_exchange = 0, ms_merge = 0, ms_extract = 0, ms_allreduce = 0;
     uint64_t bytes_sent = 0, merge_launches = 0;
+    uint64_t records_sent = 0, record_bytes_sent = 0;          // what katgpu_exchange_merge put on the wire as records (not the count matrices, not the all-reduce)
+    bool wire_packed = false;                                  // the last exchange's records: 9 bytes (remainder + count) or 12 (key + count)
     std::string transport_note;
     uint8_t* host_stage = nullptr; size_t host_stage_bytes = 0;
 };
@@ -518,6 +520,14 @@ extern "C" int katgpu_comm_barrier(katgpu_comm* m) {
     return shm_barrier(m);
 }
 
+extern "C" int katgpu_comm_wire(katgpu_comm* m, uint64_t* records_sent, uint64_t* record_bytes_sent, int* packed) {
+    if (!m) return KATGPU_ERR_INVALID_ARG;
+    if (records_sent) *records_sent = m->records_sent;
+    if (record_bytes_sent) *record_bytes_sent = m->record_bytes_sent;
+    if (packed) *packed = m->wire_packed ? 1 : 0;
+    return KATGPU_OK;
+}
+
 extern "C" int katgpu_comm_stats(katgpu_comm* m, double* ms_extract, double* ms_exchange, double* ms_merge, double* ms_allreduce, uint64_t* bytes_sent, uint64_t* merge_launches) {
     if (!m) return KATGPU_ERR_INVALID_ARG;
     if (ms_extract) *ms_extract = m->ms_extract;
@@ -575,10 +585,14 @@ extern "C" int katgpu_allreduce_u64(katgpu_comm* m, uint64_t* buf, size_t n) {
 // ------------------------------------------------------------------ the exchange ----------------------
 
 static size_t xalign(size_t n, size_t a = 256) { return (n + a - 1) / a * a; }
+// (sized for key + count records; packed records -- 4 + 1 + 4 bytes -- are carved out of the same room)
 static size_t exchange_bytes(uint64_t total_send, uint64_t set_records) {
     return xalign(8 * std::max<uint64_t>(total_send, 1)) + xalign(4 * std::max<uint64_t>(total_send, 1)) +
            2 * (xalign(8 * std::max<uint64_t>(set_records, 1)) + xalign(4 * std::max<uint64_t>(set_records, 1))) + 256;
 }
+static const bool g_comm_trace = getenv("KATGPU_COMM_TRACE") != nullptr;      // one stderr line per stage of katgpu_exchange_merge, per rank: where a run of many ranks stands
+#define CTRACE(m, ...) do { if (g_comm_trace) { fprintf(stderr, "[katgpu comm %d/%d +%.0f ms] ", (m)->rank, (m)->world, wall_ms() - t_begin); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
+static const bool g_wire_packed = !getenv("KATGPU_COMM_PACKED_RECORDS") || atoi(getenv("KATGPU_COMM_PACKED_RECORDS")) != 0;   // A/B + tests: 0 = key + count records (12 bytes) even between ranks that share the grid
 
 // Wide tables (k > 32): the simple exchange -- records (hi, lo, count) grouped by owner, all to all, the table emptied and refilled
 // with what arrived.  Not region-ordered: the wide table's hash is not one to one and its slots are 20 bytes in three arrays, which the
@@ -657,6 +671,7 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
     std::vector<uint64_t> geos((size_t)world * 6);
     rc = allgather_u64(m, g_mine, 6, geos.data());
     if (rc) return rc;
+    CTRACE(m, "geometries known: R %u slots %u p1 %u p2 %u", geo.n_regions, geo.region_slots, geo.p1, geo.p2);
     for (int s = 0; s < world; ++s)
         if (geos[(size_t)s * 6] != geo.k || geos[(size_t)s * 6 + 1] != geo.canonical) return fail(c, KATGPU_ERR_MISMATCH, "katgpu_exchange_merge: ranks disagree on k / canonical");
     auto R_of = [&](int s) { return (uint32_t)geos[(size_t)s * 6 + 2]; };
@@ -676,6 +691,7 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
     std::vector<uint64_t> s_all((size_t)world * world);
     rc = allgather_u64(m, sizes.data(), (size_t)world, s_all.data());
     if (rc) return rc;
+    CTRACE(m, "sizes known: %llu records to send", (unsigned long long)total_send);
     std::vector<uint64_t> recv_from((size_t)world);
     for (int s = 0; s < world; ++s) recv_from[s] = s_all[(size_t)s * world + rank];         // what each peer holds for me
     // the region counts of what I will receive: row `rank` of every peer's matrix
@@ -693,6 +709,7 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
         if (!rc) rc = transfer_wait(m, m->ev[0]);
         if (rc) return rc;
     }
+    CTRACE(m, "region counts exchanged");
     // prefix sums on the host (cnt: mine, per owner; rcnt: per sender, of the records it holds for me)
     std::vector<std::vector<uint64_t>> cnt_cum((size_t)world), rcnt_cum((size_t)world);
     {
@@ -751,20 +768,40 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
     }
 
     // ---- pass 2: the send list; the emptied table becomes the owner table ----
+    // Records: key + count (12 bytes) -- or, when EVERY rank's table has this one's grid and can give them, what a slot holds of the k-mer
+    // + count (4 + 1 + 4 = 9 bytes: katgpu_table_extract_packed); the region a record lies in says the rest, and the chunks are region ranges.
+    bool packed = g_wire_packed && katgpu_table_packed_records(t) != 0;
+    for (int s = 0; s < world; ++s) packed = packed && geos[(size_t)s * 6 + 4] == geo.p1 && geos[(size_t)s * 6 + 5] == geo.p2 && R_of(s) == R;
+    {
+        uint64_t mine_ok = packed ? 1 : 0;                        // (what a rank CAN give depends on its table alone: all must agree before one sends)
+        std::vector<uint64_t> all((size_t)world);
+        rc = allgather_u64(m, &mine_ok, 1, all.data());
+        if (rc) return rc;
+        for (uint64_t v : all) packed = packed && v != 0;
+    }
+    m->wire_packed = packed;
+    CTRACE(m, "%u chunks, records of %d bytes", C, packed ? 9 : 12);
     uint8_t* a = (uint8_t*)arena;
-    uint64_t* skeys = (uint64_t*)a;           a += xalign(8 * std::max<uint64_t>(total_send, 1));
+    uint64_t* skeys = (uint64_t*)a;           a += xalign(8 * std::max<uint64_t>(total_send, 1));     // (packed: the low words, then the high bytes, in the same room)
     uint32_t* scounts = (uint32_t*)a;         a += xalign(4 * std::max<uint64_t>(total_send, 1));
-    uint64_t* rkeys[2]; uint32_t* rcounts[2];
-    for (int i = 0; i < 2; ++i) { rkeys[i] = (uint64_t*)a; a += xalign(8 * set_records); rcounts[i] = (uint32_t*)a; a += xalign(4 * set_records); }
+    uint32_t* const srem_lo = (uint32_t*)skeys;
+    uint8_t* const srem_hi = (uint8_t*)skeys + xalign(4 * std::max<uint64_t>(total_send, 1));
+    uint64_t* rkeys[2]; uint32_t* rcounts[2]; uint32_t* rrem_lo[2]; uint8_t* rrem_hi[2];
+    for (int i = 0; i < 2; ++i) {
+        rkeys[i] = (uint64_t*)a; rrem_lo[i] = (uint32_t*)a; rrem_hi[i] = a + xalign(4 * set_records); a += xalign(8 * set_records);
+        rcounts[i] = (uint32_t*)a; a += xalign(4 * set_records);
+    }
     constexpr uint32_t BIG = 4200;
     std::vector<uint64_t> big_keys(BIG), big_counts(BIG);
     uint32_t n_big = 0;
-    rc = katgpu_table_extract(t, (uint32_t)world, d_cnt, skeys, scounts, big_keys.data(), big_counts.data(), BIG, &n_big);
+    rc = packed ? katgpu_table_extract_packed(t, (uint32_t)world, d_cnt, srem_lo, srem_hi, scounts, big_keys.data(), big_counts.data(), BIG, &n_big)
+                : katgpu_table_extract(t, (uint32_t)world, d_cnt, skeys, scounts, big_keys.data(), big_counts.data(), BIG, &n_big);
     if (rc) return rc;
     rc = katgpu_table_clear(t);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));                   // the send list is complete before the transport stream reads it
     m->ms_extract += wall_ms() - t_begin;
+    CTRACE(m, "send list written, table emptied");
 
     struct Layout { int s; uint64_t o, n; };
     auto post = [&](uint32_t ch, std::vector<Layout>& layout) -> int {
@@ -774,9 +811,18 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
         for (int s = 0; s < world; ++s) {
             if (s == rank) continue;
             const uint64_t a0 = send_off[s][ch], n_out = send_off[s][ch + 1] - a0;
-            if (n_out) { sends.push_back({s, skeys + a0, (size_t)n_out * 8}); sends.push_back({s, scounts + a0, (size_t)n_out * 4}); }
+            if (n_out) {
+                if (packed) { sends.push_back({s, srem_lo + a0, (size_t)n_out * 4}); sends.push_back({s, srem_hi + a0, (size_t)n_out}); }
+                else sends.push_back({s, skeys + a0, (size_t)n_out * 8});
+                sends.push_back({s, scounts + a0, (size_t)n_out * 4});
+                m->records_sent += n_out; m->record_bytes_sent += n_out * (packed ? 9 : 12);
+            }
             const uint64_t n_in = recv_sz[s][ch];
-            if (n_in) { recvs.push_back({s, rkeys[ch & 1] + o, (size_t)n_in * 8}); recvs.push_back({s, rcounts[ch & 1] + o, (size_t)n_in * 4}); }
+            if (n_in) {
+                if (packed) { recvs.push_back({s, rrem_lo[ch & 1] + o, (size_t)n_in * 4}); recvs.push_back({s, rrem_hi[ch & 1] + o, (size_t)n_in}); }
+                else recvs.push_back({s, rkeys[ch & 1] + o, (size_t)n_in * 8});
+                recvs.push_back({s, rcounts[ch & 1] + o, (size_t)n_in * 4});
+            }
             layout.push_back({s, o, n_in});
             o += n_in;
         }
@@ -784,8 +830,16 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
     };
     auto merge = [&](uint32_t ch, const std::vector<Layout>& layout) -> int {
         const uint32_t my_lo = (uint32_t)bounds[rank][ch], my_hi = (uint32_t)bounds[rank][ch + 1];
-        std::vector<katgpu_merge_source> src;
         const uint64_t a0 = send_off[rank][ch], n_own = send_off[rank][ch + 1] - a0;
+        if (packed) {                                             // (every rank has this table's grid -- as it was when the exchange began: the sources say so)
+            std::vector<katgpu_merge_source_packed> src;
+            if (n_own) src.push_back({srem_lo + a0, srem_hi + a0, scounts + a0, d_rcnt[rank] + my_lo, n_own, geo.p1, geo.p2});
+            for (auto& l : layout) if (l.n) src.push_back({rrem_lo[ch & 1] + l.o, rrem_hi[ch & 1] + l.o, rcounts[ch & 1] + l.o, d_rcnt[l.s] + my_lo, l.n, geo.p1, geo.p2});
+            if (src.empty()) return KATGPU_OK;
+            ++m->merge_launches;
+            return katgpu_table_merge_regions_packed(t, my_lo, my_hi, (uint32_t)src.size(), src.data());
+        }
+        std::vector<katgpu_merge_source> src;
         if (n_own) src.push_back({skeys + a0, scounts + a0, d_rcnt[rank] + my_lo, n_own, geo.p1, geo.p2});
         for (auto& l : layout) {
             if (!l.n) continue;
@@ -810,9 +864,11 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
             if (rc) return rc;
             m->ms_exchange += wall_ms() - t0;
             t0 = wall_ms();
+            CTRACE(m, "chunk %u arrived", ch - 1);
             rc = merge(ch - 1, lay[(ch - 1) & 1]);
             if (rc) return rc;
             m->ms_merge += wall_ms() - t0;
+            CTRACE(m, "chunk %u merged", ch - 1);
         }
     }
 
@@ -830,6 +886,7 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
     }
     if (!ok_keys.empty()) { rc = katgpu_table_merge_host(t, ok_keys.data(), ok_counts.data(), ok_keys.size()); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    CTRACE(m, "out-of-band records done");
     rc = shm_barrier(m);                                          // nobody reuses its arena while a peer may still be reading from it
     return rc ? rc : refresh_counters(t);
 }

@@ -49,9 +49,30 @@ extern "C" int katgpu_table_extract_sizes(katgpu_table* t, uint32_t n_parts, uin
     return KATGPU_OK;
 }
 
+extern "C" int katgpu_table_packed_records(const katgpu_table* t) {
+    if (!t || t->dv.keys_b) return 0;
+    return t->dv.cbits != 0;                                      // (a packed slot's remainder has at most 64 - PACK_MIN_CBITS = 44 bits: rec_xs <= 4, counts to 2^28 in the record)
+}
+
+static int extract_records(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint64_t* dev_keys, uint32_t* dev_rem_lo, uint8_t* dev_rem_hi, uint32_t* dev_counts,
+                           uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big);
+
 extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint64_t* dev_keys, uint32_t* dev_counts,
                                     uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big) {
-    if (!t || !dev_region_counts || !dev_keys || !dev_counts || !n_big || n_parts == 0 || n_parts > MAX_EXCHANGE_PARTS || (big_cap && (!big_keys || !big_counts)))
+    if (!dev_keys) return KATGPU_ERR_INVALID_ARG;
+    return extract_records(t, n_parts, dev_region_counts, dev_keys, nullptr, nullptr, dev_counts, big_keys, big_counts, big_cap, n_big);
+}
+
+extern "C" int katgpu_table_extract_packed(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint32_t* dev_rem_lo, uint8_t* dev_rem_hi, uint32_t* dev_counts,
+                                           uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big) {
+    if (!t || !dev_rem_lo || !dev_rem_hi) return KATGPU_ERR_INVALID_ARG;
+    if (!katgpu_table_packed_records(t)) return fail(t->ctx, KATGPU_ERR_INVALID_ARG, "katgpu_table_extract_packed: not a packed table");
+    return extract_records(t, n_parts, dev_region_counts, nullptr, dev_rem_lo, dev_rem_hi, dev_counts, big_keys, big_counts, big_cap, n_big);
+}
+
+static int extract_records(katgpu_table* t, uint32_t n_parts, const uint32_t* dev_region_counts, uint64_t* dev_keys, uint32_t* dev_rem_lo, uint8_t* dev_rem_hi, uint32_t* dev_counts,
+                           uint64_t* big_keys, uint64_t* big_counts, uint32_t big_cap, uint32_t* n_big) {
+    if (!t || !dev_region_counts || !dev_counts || !n_big || n_parts == 0 || n_parts > MAX_EXCHANGE_PARTS || (big_cap && (!big_keys || !big_counts)))
         return KATGPU_ERR_INVALID_ARG;
     NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
@@ -81,8 +102,10 @@ extern "C" int katgpu_table_extract(katgpu_table* t, uint32_t n_parts, const uin
         hipMemcpyAsync(d_base, base.data(), n_parts * 8, hipMemcpyHostToDevice, c->stream);
         hipMemsetAsync(d_bign, 0, 8, c->stream);
         hipLaunchKernelGGL(k_rows_scan, dim3(n_parts), dim3(1024), 0, c->stream, dev_region_counts, R, (uint64_t)R, (const uint64_t*)d_base, d_off, (uint64_t)R, 0, (unsigned long long*)nullptr);
-        hipLaunchKernelGGL(k_extract_write, dim3(std::min<uint32_t>(R, (uint32_t)c->n_cu * 8)), dim3(EXTRACT_BLOCK), 0, c->stream, t->dev(), t->n_ovf, n_parts, (const uint64_t*)d_off,
-                           dev_keys, dev_counts, d_bk, d_bc, d_bign, dev_big_cap);
+        if (dev_keys) hipLaunchKernelGGL(k_extract_write<false>, dim3(std::min<uint32_t>(R, (uint32_t)c->n_cu * 8)), dim3(EXTRACT_BLOCK), 0, c->stream, t->dev(), t->n_ovf, n_parts, (const uint64_t*)d_off,
+                                         dev_keys, (uint32_t*)nullptr, (uint8_t*)nullptr, dev_counts, d_bk, d_bc, d_bign, dev_big_cap);
+        else hipLaunchKernelGGL(k_extract_write<true>, dim3(std::min<uint32_t>(R, (uint32_t)c->n_cu * 8)), dim3(EXTRACT_BLOCK), 0, c->stream, t->dev(), t->n_ovf, n_parts, (const uint64_t*)d_off,
+                                (uint64_t*)nullptr, dev_rem_lo, dev_rem_hi, dev_counts, d_bk, d_bc, d_bign, dev_big_cap);
     }
     unsigned long long nb = 0;
     hipMemcpyAsync(&nb, d_bign, 8, hipMemcpyDeviceToHost, c->stream);
@@ -149,8 +172,33 @@ extern "C" int katgpu_table_merge_device32(katgpu_table* t, const uint64_t* dev_
 
 static const bool g_no_merge_apply = hook("KATGPU_NO_MERGE_APPLY") != nullptr;    // A/B switch + tests: every source through the direct path
 
+// a source of either form: keys + counts, or packed records (rem_lo + rem_hi + counts: keys == null; their region counts are what orders them)
+struct GSrc { const uint64_t* dev_keys; const uint32_t* dev_rem_lo; const uint8_t* dev_rem_hi; const uint32_t* dev_counts; const uint32_t* dev_region_counts; uint64_t n_records; uint32_t p1, p2; };
+static int merge_regions_impl(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const GSrc* src);
+
 extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source* src) {
     if (!t || !src || n_src == 0 || g_lo > g_hi) return KATGPU_ERR_INVALID_ARG;
+    std::vector<GSrc> g(n_src);
+    for (uint32_t i = 0; i < n_src; ++i) {
+        if (src[i].n_records && (!src[i].dev_keys || !src[i].dev_counts)) return KATGPU_ERR_INVALID_ARG;
+        g[i] = GSrc{src[i].dev_keys, nullptr, nullptr, src[i].dev_counts, src[i].dev_region_counts, src[i].n_records, src[i].p1, src[i].p2};
+    }
+    return merge_regions_impl(t, g_lo, g_hi, n_src, g.data());
+}
+
+extern "C" int katgpu_table_merge_regions_packed(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const katgpu_merge_source_packed* src) {
+    if (!t || !src || n_src == 0 || g_lo > g_hi) return KATGPU_ERR_INVALID_ARG;
+    if (!t->dv.cbits || t->dv.keys_b) return fail(t->ctx, KATGPU_ERR_INVALID_ARG, "katgpu_table_merge_regions_packed: not a packed table");
+    std::vector<GSrc> g(n_src);
+    for (uint32_t i = 0; i < n_src; ++i) {
+        if (src[i].n_records && (!src[i].dev_rem_lo || !src[i].dev_rem_hi || !src[i].dev_counts || !src[i].dev_region_counts || !src[i].p1 || !src[i].p2 || (src[i].p2 & (src[i].p2 - 1))))
+            return KATGPU_ERR_INVALID_ARG;                    // (a packed record is nothing without its region: the counts and the grid are not optional)
+        g[i] = GSrc{nullptr, src[i].dev_rem_lo, src[i].dev_rem_hi, src[i].dev_counts, src[i].dev_region_counts, src[i].n_records, src[i].p1, src[i].p2};
+    }
+    return merge_regions_impl(t, g_lo, g_hi, n_src, g.data());
+}
+
+static int merge_regions_impl(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uint32_t n_src, const GSrc* src) {
     NARROW_ONLY(t, "the multi-GPU exchange");
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -165,7 +213,6 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
     std::vector<uint32_t> aligned, direct;
     for (uint32_t i = 0; i < n_src; ++i) {
         if (src[i].n_records == 0) continue;
-        if (!src[i].dev_keys || !src[i].dev_counts) return KATGPU_ERR_INVALID_ARG;
         const bool ok = !g_no_merge_apply && src[i].dev_region_counts && src[i].p1 == t->dev().p1 && src[i].p2 == t->dev().p2 && g_hi <= t->dev().n_regions &&
                         (size_t)t->dev().region_slots * slot_bytes <= 150 * 1024;
         (ok ? aligned : direct).push_back(i);
@@ -181,12 +228,13 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
         unsigned long long* d_ndef = (unsigned long long*)(tmp + off_bytes + (size_t)n_reg * 4);
         MergeSrcs ms{};
         ms.n = na;
+        ms.src_p1 = src[aligned[a0]].p1; ms.src_n1 = place_n1(t->dev().k, ms.src_p1); ms.src_l2 = (uint32_t)__builtin_ctz(src[aligned[a0]].p2);   // (aligned sources share one grid: this table's)
         uint64_t records = 0;
         for (uint32_t q = 0; q < na; ++q) {
-            const katgpu_merge_source& s = src[aligned[a0 + q]];
+            const GSrc& s = src[aligned[a0 + q]];
             hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, c->stream, s.dev_region_counts, n_reg, (uint64_t)n_reg, (const uint64_t*)nullptr,
                                d_off + (size_t)q * (n_reg + 1), (uint64_t)(n_reg + 1), 1, (unsigned long long*)nullptr);
-            ms.s[q] = MergeSrc{s.dev_keys, s.dev_counts, d_off + (size_t)q * (n_reg + 1)};
+            ms.s[q] = MergeSrc{s.dev_keys, s.dev_counts, d_off + (size_t)q * (n_reg + 1), s.dev_rem_lo, s.dev_rem_hi};
             records += s.n_records;
         }
         hipMemsetAsync(d_ndef, 0, 8, c->stream);
@@ -238,9 +286,68 @@ extern "C" int katgpu_table_merge_regions(katgpu_table* t, uint32_t g_lo, uint32
             break;
         }
     }
-    for (uint32_t i : direct) {
-        rc = merge_direct32(t, src[i].dev_keys, src[i].dev_counts, (size_t)src[i].n_records);
+    // The sources that go in directly are runs of CONSECUTIVE regions of their sender's grid (a chunk of the exchange): the same share of the
+    // hash space as [g_lo, g_hi) is of this table's, since every grid orders its regions by the leading digits of one hash.  They fill that
+    // share of the table, not the table: the fill limit has to hold there (the table's load as a whole says nothing about it -- a rank whose
+    // own input was small receives far more than it held).  Senders' records may coincide, so this is an upper bound; growth keeps the grid.
+    if (!direct.empty() && n_reg && n_reg < t->dev().n_regions && g_hi <= t->dev().n_regions) {
+        rc = refresh_counters(t);
         if (rc) return rc;
+        uint64_t direct_total = 0;
+        for (uint32_t i : direct) direct_total += src[i].n_records;
+        const double share = (double)n_reg / (double)t->dev().n_regions;
+        unsigned long long occupied = 0;                          // what these regions hold already: counted (an exchange fills an emptied table share by share)
+        {
+            uint64_t* scratch = &t->dev().ctrs[CTR_SCRATCH];
+            const uint64_t lo = (uint64_t)g_lo * t->dev().region_slots, hi = (uint64_t)g_hi * t->dev().region_slots;
+            HIPCHK(c, hipMemsetAsync(scratch, 0, sizeof(uint64_t), c->stream));
+            hipLaunchKernelGGL(k_occupied, dim3(grid_for(c, hi - lo, 256, 8)), dim3(256), 0, c->stream, t->dev(), lo, hi, (unsigned long long*)scratch);
+            HIPCHK(c, hipMemcpyAsync(&occupied, scratch, sizeof occupied, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        const double present = (double)occupied;
+        if (present + (double)direct_total > load_limit(t->dev()) * (double)t->dev().cap * share) {
+            if (t->disable_grow) return fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
+            uint64_t new_cap = t->dev().cap;
+            while (present + (double)direct_total > 0.5 * (double)new_cap * share) new_cap *= 2;
+            if (g_trace) fprintf(stderr, "[katgpu] merge: %llu record(s) for %u of %u regions: the table grows from %llu to %llu slots first\n", (unsigned long long)direct_total, n_reg,
+                                 t->dev().n_regions, (unsigned long long)t->dev().cap, (unsigned long long)new_cap);
+            rc = regrow(t, new_cap);
+            if (rc) return rc;
+        }
+    }
+    for (uint32_t i : direct) {
+        if (src[i].dev_keys) { rc = merge_direct32(t, src[i].dev_keys, src[i].dev_counts, (size_t)src[i].n_records); if (rc) return rc; continue; }
+        // packed records of another grid than the table's (it has grown since they were cut): the k-mer comes back from the SENDER's grid,
+        // region by region, and goes through the direct path
+        if (!n_reg) continue;
+        rc = refresh_counters(t);
+        if (rc) return rc;
+        {
+            const uint64_t lim = (uint64_t)(load_limit(t->dev()) * (double)t->dev().cap), room = lim > t->distinct ? lim - t->distinct : 0;
+            if (room < src[i].n_records) { rc = ensure_room(t, src[i].n_records); if (rc) return rc; }
+        }
+        t->count_bound = 0xFFFFFFFFULL;
+        uint8_t* tmp = nullptr;        // [off: (n_reg + 1) u64 | regions: n_reg u32]
+        const size_t off_bytes = (size_t)(n_reg + 1) * 8;
+        HIPCHK(c, hipMalloc((void**)&tmp, off_bytes + (size_t)n_reg * 4));
+        uint64_t* d_off = (uint64_t*)tmp;
+        uint32_t* d_regs = (uint32_t*)(tmp + off_bytes);
+        std::vector<uint32_t> regs(n_reg);
+        for (uint32_t g = 0; g < n_reg; ++g) regs[g] = g_lo + g;
+        hipError_t e = hipMemcpyAsync(d_regs, regs.data(), (size_t)n_reg * 4, hipMemcpyHostToDevice, c->stream);
+        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, c->stream, src[i].dev_region_counts, n_reg, (uint64_t)n_reg, (const uint64_t*)nullptr, d_off, (uint64_t)(n_reg + 1), 1, (unsigned long long*)nullptr);
+        MergeSrcs ms{};
+        ms.n = 1;
+        ms.src_p1 = src[i].p1; ms.src_n1 = place_n1(t->dev().k, src[i].p1); ms.src_l2 = (uint32_t)__builtin_ctz(src[i].p2);
+        ms.s[0] = MergeSrc{nullptr, src[i].dev_counts, d_off, src[i].dev_rem_lo, src[i].dev_rem_hi};
+        {
+            ScopedTimer tm(c, KATGPU_K_MERGE, src[i].n_records);
+            hipLaunchKernelGGL(k_merge_deferred, dim3(std::min<uint32_t>(n_reg, (uint32_t)c->n_cu * 8)), dim3(256), 0, c->stream, t->dev(), g_lo, ms, (const uint32_t*)d_regs, n_reg);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(tmp);
+        if (e != hipSuccess) return fail(c, KATGPU_ERR_DEVICE, "%s", hipGetErrorString(e));
     }
     return refresh_counters(t);
 }

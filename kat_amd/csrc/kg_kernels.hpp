@@ -162,6 +162,19 @@ k_total(DevTable t, uint32_t n_ovf, uint64_t* out) {
     if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long*)out, (unsigned long long)s);
 }
 
+// occupied slots of [pos_lo, pos_hi): what a share of the table holds, when the table's load as a whole does not say (merge_regions_impl)
+static __global__ void __launch_bounds__(256)
+k_occupied(DevTable t, uint64_t pos_lo, uint64_t pos_hi, unsigned long long* out) {
+    uint32_t s = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = pos_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pos_hi; i += stride) {
+        const uint64_t w = t.keys[i];
+        s += (t.cbits ? w != 0 : w != EMPTY) ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, (unsigned long long)s);
+}
+
 // LDS-privatised increment with wave-level aggregation: lanes that hit the same bin as the wave's first active
 // lane are folded into one LDS atomic (ballot + popcount); the rest fall through to their own atomic.  K-mer
 // spectra are dominated by a handful of bins (singletons!), so this removes most same-address serialisation.
@@ -1153,8 +1166,23 @@ k_rows_scan(const uint32_t* __restrict__ m, uint32_t n_cols, uint64_t row_stride
 
 // pass 2: write the records.  off[p * R + g] = global index of the first record of (part p, region g).  Counts that do
 // not fit 32 bits travel in the `big` list (their record carries count 0, which a merge skips).
+// PACKED: a record is what a packed slot holds of the k-mer -- the remainder (rb <= 44 bits) -- below its count, 72 bits cut into a u32, a u8
+// and a u32: 9 bytes where key + count take 12.  The third word's low rb - 40 bits (none for rb <= 40) are the
+// remainder's top ones; the count has the 32 - (rb - 40) >= 28 above them, and what does not fit travels in the `big` list like a count
+// beyond 32 bits does.  The region the record lies in says the rest of the k-mer: the form for owners that share the sender's region grid.
+__device__ __host__ __forceinline__ uint32_t rec_xs(uint32_t rb) { return rb > 40 ? rb - 40 : 0; }
+struct PackedRec { uint64_t rem; uint32_t c; };
+__device__ __forceinline__ PackedRec packed_rec(const uint32_t* __restrict__ lo, const uint8_t* __restrict__ hi, const uint32_t* __restrict__ cw, uint64_t i, uint32_t xs) {
+    const uint32_t w = cw[i];
+    PackedRec r;
+    r.c = w >> xs;
+    r.rem = r.c ? (((uint64_t)(w & ((1u << xs) - 1)) << 40) | ((uint64_t)hi[i] << 32) | lo[i]) : 0;     // (count 0: a record whose count travels out of band, skipped)
+    return r;
+}
+template <bool PACKED>
 static __global__ void __launch_bounds__(EXTRACT_BLOCK)
 k_extract_write(DevTable t, uint32_t n_ovf, uint32_t n_parts, const uint64_t* __restrict__ off, uint64_t* __restrict__ out_keys,
+                uint32_t* __restrict__ out_rem_lo, uint8_t* __restrict__ out_rem_hi,
                 uint32_t* __restrict__ out_counts, uint64_t* __restrict__ big_keys, uint64_t* __restrict__ big_counts,
                 unsigned long long* __restrict__ big_n, uint32_t big_cap) {
     __shared__ uint32_t s_cur[MAX_EXCHANGE_PARTS];
@@ -1171,20 +1199,32 @@ k_extract_write(DevTable t, uint32_t n_ovf, uint32_t n_parts, const uint64_t* __
             const uint32_t p = n_parts > 1 ? owner_of(key, t.k, n_parts) : 0;
             const uint64_t at = off[(uint64_t)p * t.n_regions + g] + atomicAdd(&s_cur[p], 1u);
             uint64_t c = slot_total(t, base + i, key, v.cnt, n_ovf);
-            if (c > 0xFFFFFFFFULL) {
+            const uint32_t xs = PACKED ? rec_xs(rp.pl.rb) : 0;
+            if (c > (0xFFFFFFFFULL >> xs)) {
                 const unsigned long long b = atomicAdd(big_n, 1ULL);
                 if (b < big_cap) { big_keys[b] = key; big_counts[b] = c; }
                 c = 0;
             }
-            out_keys[at] = key;
-            out_counts[at] = (uint32_t)c;
+            if constexpr (PACKED) {
+                const uint64_t rem = rem_in(key, rp);
+                out_rem_lo[at] = (uint32_t)rem; out_rem_hi[at] = (uint8_t)(rem >> 32);
+                out_counts[at] = c ? ((uint32_t)c << xs) | (uint32_t)(rem >> 40) : 0u;
+            } else { out_keys[at] = key; out_counts[at] = (uint32_t)c; }
         }
         __syncthreads();
     }
 }
 
-struct MergeSrc { const uint64_t* keys; const uint32_t* counts; const uint64_t* off; };   // off: u64[regions + 1], relative to keys / counts
-struct MergeSrcs { MergeSrc s[MAX_MERGE_SRC]; uint32_t n; };
+struct MergeSrc { const uint64_t* keys; const uint32_t* counts; const uint64_t* off; const uint32_t* rem_lo; const uint8_t* rem_hi; };   // off: u64[regions + 1], relative to the record arrays; keys == null: packed records (rem_lo / rem_hi)
+struct MergeSrcs { MergeSrc s[MAX_MERGE_SRC]; uint32_t n; uint32_t src_p1, src_n1, src_l2; };      // src_*: the grid packed records were cut from (the table's, unless it has grown since)
+// the k-mer of record i of region g of a source (packed records: from the SENDER's grid)
+__device__ __forceinline__ uint64_t merge_src_key(const DevTable& t, const MergeSrcs& srcs, const MergeSrc& s, uint32_t g, uint64_t i, uint32_t& c) {
+    if (s.keys) { c = s.counts[i]; return s.keys[i]; }
+    const Place pl = place_make(t.k, srcs.src_p1, srcs.src_n1, srcs.src_l2);
+    const PackedRec r = packed_rec(s.rem_lo, s.rem_hi, s.counts, i, rec_xs(pl.rb));
+    c = r.c;
+    return place_key_d(g >> srcs.src_l2, g & ((1u << srcs.src_l2) - 1), r.rem, pl);
+}
 
 // Owner side: regions [g_lo, g_hi).  LDS: keys[S] (u64) | counts[S] (u32) (KV12) or the S packed words (PK); the protocol of the
 // apply kernels with arbitrary 32-bit amounts.  A region that could overflow (occupied + incoming > S) is not touched: its index
@@ -1225,11 +1265,13 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
         for (uint32_t s = 0; s < srcs.n; ++s) {
             const uint64_t beg = srcs.s[s].off[j], end = srcs.s[s].off[j + 1];
             for (uint64_t i = beg + tid; i < end; i += BLOCK) {
-                const uint32_t c = srcs.s[s].counts[i];
+                uint32_t c;
+                uint64_t rem = 0;
+                if (PK && !srcs.s[s].keys) { const PackedRec r = packed_rec(srcs.s[s].rem_lo, srcs.s[s].rem_hi, srcs.s[s].counts, i, rec_xs(rp.pl.rb)); c = r.c; rem = r.rem; }   // (packed records: this table's grid is the sender's -- the host checked)
+                else c = srcs.s[s].counts[i];
                 if (!c) continue;
-                const unsigned long long key = srcs.s[s].keys[i];
                 if constexpr (PK) {
-                    const uint64_t rem = rem_in(key, rp);
+                    if (srcs.s[s].keys) rem = rem_in(srcs.s[s].keys[i], rp);
                     uint32_t slot = place_offset(rem, rp.pl, S);
                     uint64_t q, r;
                     pk_split((uint64_t)c, cb, q, r);
@@ -1256,6 +1298,7 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
                         slot = slot + 1 == S ? 0 : slot + 1;
                     }
                 } else {
+                    const unsigned long long key = srcs.s[s].keys[i];            // (KV12 tables: never packed records)
                     uint32_t slot = home_offset_in(key, rp);
                     for (uint32_t probe = 0; probe < S; ++probe) {               // cannot fail: occupied + incoming <= S
                         unsigned long long cur = rk[slot];
@@ -1290,8 +1333,9 @@ k_merge_deferred(DevTable t, uint32_t g_lo, MergeSrcs srcs, const uint32_t* __re
         for (uint32_t s = 0; s < srcs.n; ++s) {
             const uint64_t beg = srcs.s[s].off[j], end = srcs.s[s].off[j + 1];
             for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
-                const uint32_t c = srcs.s[s].counts[i];
-                if (c) table_add(t, srcs.s[s].keys[i], (uint64_t)c, new_distinct);
+                uint32_t c;
+                const uint64_t key = merge_src_key(t, srcs, srcs.s[s], deferred[d], i, c);
+                if (c) table_add(t, key, (uint64_t)c, new_distinct);
             }
         }
     }

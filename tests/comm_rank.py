@@ -64,6 +64,9 @@ def main():
         g1 = t1.geometry()
         before = t1.dump_sorted() if world == 1 else None
         comm.exchange_merge(t1)
+        w1 = comm.stats()
+        if rank == 0:                                                            # (the first table's records alone: test_records_travel_in_nine_bytes_...)
+            print("wire after table 1:", {q: w1[q] for q in ("records_sent", "record_bytes_sent", "records_packed")})
         comm.exchange_merge(t2)
         assert (t1.geometry().p1, t1.geometry().p2) == (g1.p1, g1.p2)
         keys, counts = t1.dump_sorted()

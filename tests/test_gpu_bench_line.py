@@ -59,11 +59,25 @@ def fake_rccl(tmp_path_factory):
     return so
 
 
-@pytest.mark.parametrize("workload,scaling", [("comp", "strong"), ("comp-rr", "weak")])
-def test_eight_ranks_through_the_rccl_branch(fake_rccl, workload, scaling):
-    """`bench.py --gpus 8` (it launches its own torch.distributed.run): 8 ranks, the communicator's RCCL branch, the line's comm block."""
+@pytest.mark.parametrize("workload,scaling,tiny_regions", [("comp", "strong", False), ("comp-rr", "weak", False), ("comp-rr", "weak", True), ("comp", "weak", True)])
+def test_eight_ranks_through_the_rccl_branch(fake_rccl, workload, scaling, tiny_regions):
+    """`bench.py --gpus 8` (it launches its own torch.distributed.run): 8 ranks, the communicator's RCCL branch, the line's comm block.
+    With regions of 128 slots the test's small tables are what the bench's large ones are -- packed -- and
+    the records of two read libraries (config 5's shape: both tables on one grid) cross the wire in 9 bytes each; `comp` at this size has
+    fewer contigs than ranks, so some ranks' assembly tables are empty ones of another grid that receive far more than they held: key +
+    count records through the direct path, room made for each share of the table as it arrives."""
     env = {"KATGPU_TESTING": "1", "KATGPU_RCCL_LIB": fake_rccl, "KATGPU_COMM_TRANSPORT": "rccl", "KATGPU_ARENA_FRACTION": "0.08"}
-    line = _bench(["--gpus", "8", "--workload", workload, "--scaling", scaling] + SMALL, env, timeout=1500)
+    if tiny_regions:
+        env["KATGPU_TEST_REGION_SLOTS"] = "128"
+    # (comp-rr: k = 29, where these small tables have what config 5's k = 31 tables of 39 GB have -- packed slots, a remainder of more than 40 bits)
+    line = _bench(["--gpus", "8", "--workload", workload, "--scaling", scaling] + SMALL + (["--k", "29"] if tiny_regions and workload == "comp-rr" else []), env, timeout=1500)
+    if tiny_regions:
+        x = {q: line["exchange"][q] for q in ("records_sent_per_step_all_ranks", "record_bytes_per_record", "records_packed")}
+        assert x["records_sent_per_step_all_ranks"] > 0, x
+        if workload == "comp-rr":
+            assert x["records_packed"] and x["record_bytes_per_record"] <= 9.1, x
+        else:
+            assert 9.0 < x["record_bytes_per_record"] < 12.0, x                 # (the reads' table in 9-byte records, the assembly's in 12)
     assert line["n_gpus"] == 8 and line["scaling"] == scaling and line["result_accounts_for_every_kmer"], line["result_check"]
     c = line["config"]["comm"]
     assert c["transport"] == "rccl" and c["ranks_seen"] == 8 and c["distinct_devices"] == 1
@@ -73,7 +87,7 @@ def test_eight_ranks_through_the_rccl_branch(fake_rccl, workload, scaling):
     if workload == "comp":
         assert line["kmer_instances"] == 8 * (per_gpu & ~1) * 124 + (5000000 - 5 * 26)
     else:
-        assert line["kmer_instances"] == 2 * 8 * ((per_gpu // 2) & ~1) * 120
+        assert line["kmer_instances"] == 2 * 8 * ((per_gpu // 2) & ~1) * (150 - line["config"]["k"] + 1)
 
 
 def test_ranks_on_one_device_refuse_nothing_but_say_so():

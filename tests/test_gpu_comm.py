@@ -61,6 +61,25 @@ def test_native_exchange_ranks_sharing_one_gpu(ko, tmp_path, world, mode, extra)
     _check(ko, tmp_path, world, mode)
 
 
+@pytest.mark.parametrize("world,transport,extra,packed", [
+    (2, "shm", {}, True), (4, "shm", {"KATGPU_TEST_EXCHANGE_CHUNKS": "6"}, True), (8, "rccl", {"KATGPU_TEST_EXCHANGE_CHUNKS": "5"}, True),
+    (3, "rccl", {"KATGPU_COMM_PACKED_RECORDS": "0"}, False)])
+def test_records_travel_in_nine_bytes_between_ranks_that_share_the_grid(ko, tmp_path, fake_rccl, world, transport, extra, packed):
+    """Ranks whose tables have one region grid (regions of 128 slots here, so that small tables are packed ones, as every table of size is) exchange what a slot holds of the k-mer + its count: 9 bytes per record, not key + count's 12
+    (katgpu_comm_wire); the merged result is the oracle's either way."""
+    import re
+    env = dict(extra, KATGPU_COMM_TRANSPORT=transport, KATGPU_TESTING="1", KATGPU_TEST_REGION_SLOTS="128")
+    if transport == "rccl":
+        env["KATGPU_RCCL_LIB"] = fake_rccl
+    out = _run(tmp_path, world, "same", env)
+    assert "transport: %s" % transport in out, out[-2000:]
+    m = re.search(r"wire after table 1: \{'records_sent': (\d+), 'record_bytes_sent': (\d+), 'records_packed': (True|False)", out)      # (the second table of these runs is a small KV12 one: key + count either way)
+    assert m, out[-2000:]
+    records, nbytes = int(m.group(1)), int(m.group(2))
+    assert records > 0 and (m.group(3) == "True") == packed and nbytes == records * (9 if packed else 12), m.group(0)
+    _check(ko, tmp_path, world, "same")
+
+
 @pytest.fixture(scope="module")
 def fake_rccl(tmp_path_factory):
     """tests/native/fake_rccl.cc built into a shared library: the ten nccl* entry points kg_comm.hip resolves, over /dev/shm + hipMemcpy,

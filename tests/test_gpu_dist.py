@@ -97,3 +97,17 @@ def test_merge_regions_overflowing_regions_take_the_direct_path(engine, ko):
     for x in (cnt, dk, dc):
         x.free()
     a.free(); b.free()
+
+
+
+def test_packed_records_case_in_a_process_with_tiny_regions():
+    """katgpu_table_extract_packed / _merge_regions_packed (9-byte records: what a slot holds of the k-mer + its count): tests/packed_records_case.py,
+    run with regions of 128 slots so that small tables are packed ones -- what every table of size is."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, KATGPU_TESTING="1", KATGPU_TEST_REGION_SLOTS="128")
+    r = subprocess.run([sys.executable, os.path.join(here, "packed_records_case.py")], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "packed records ok" in r.stdout
