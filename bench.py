@@ -79,6 +79,7 @@ def parse_args():
     ap.add_argument("--genome", type=int, default=None, help="genome / assembly length in bp (shared by all ranks)")
     ap.add_argument("--contig", type=int, default=1_000_000)
     ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--no-exchange-overlap", action="store_true", help="N > 1, two tables: katgpu_exchange_merge for both instead of counting input 2 while table 1 travels")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--err-ppm", type=int, default=2000, help="substitution errors per million bases (0.2 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -334,17 +335,27 @@ def measure(eng, a, ctx, want_cpu):
         tp = mark("alloc1", tp)
         t1.count_bases_device(reads.ptr, reads.nbytes)
         tp = mark("count_reads", tp)
+        overlap = world > 1 and two_tables and not a.no_exchange_overlap
+        if overlap:                                         # table 1's records travel while input 2 is counted (katgpu_exchange_begin / _finish)
+            results["distinct1_local"] = t1.stats(want_total=False)["distinct"]
+            comm.exchange_begin(t1)
+            tp = mark("exchange_begin", tp)
         t2 = None
         if two_tables:
             t2 = eng.table(k, True, size_hint=hint2, like=t1)
             t2.count_bases_device(in2_ptr, in2_bytes)
             tp = mark("alloc2+count_2", tp)
-        results["distinct1_local"] = t1.stats(want_total=False)["distinct"]
+        if not overlap:
+            results["distinct1_local"] = t1.stats(want_total=False)["distinct"]
         if k <= 32:
             g1_ = t1.geometry()
             results["geo1"] = (int(g1_.p1), int(g1_.p2), t1.slot_bytes(), t2.slot_bytes() if t2 is not None else 0)
         if world > 1:
-            t1 = exchange(t1)
+            if overlap:
+                eng.sync()
+                comm.exchange_finish(t1)
+            else:
+                t1 = exchange(t1)
             if t2 is not None:
                 t2 = exchange(t2)
             tp = mark("exchange", tp)
@@ -409,6 +420,7 @@ def measure(eng, a, ctx, want_cpu):
                 "records_sent_per_step_all_ranks": allsum(comm_after["records_sent"] - comm_before["records_sent"]) // a.steps,
                 "record_bytes_per_record": round(allsum(comm_after["record_bytes_sent"] - comm_before["record_bytes_sent"]) / max(1, allsum(comm_after["records_sent"] - comm_before["records_sent"])), 3),
                 "records_packed": bool(comm_after["records_packed"]),
+                "second_input_counted_while_table_1_travels": bool(two_tables and not a.no_exchange_overlap),
                 "reading": "extract = table -> send list; exchange = posting the chunks + waiting for them (on the wire while the previous chunk is merged); merge = k_merge_apply; allreduce = the small results"}
 
     total_instances = world * inst_reads + inst2_total

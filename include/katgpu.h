@@ -301,6 +301,15 @@ int  katgpu_comm_barrier(katgpu_comm* comm);
  * over all ranks; it keeps its storage and its region grid.  Collective: every rank calls it, with tables of one k / strand mode.
  * Wide tables (k > 32) take the simple route: records grouped by owner, all to all, the table emptied and refilled (it may grow). */
 int  katgpu_exchange_merge(katgpu_comm* comm, katgpu_table* t);
+/* The same exchange in two calls, so that the next input is counted while this table's records are on the wire (kat comp: the second
+ * hash is counted while the first one's merge travels; the reference has nothing to overlap -- its merges are memory operations of one
+ * process, lib/include/kat/sparse_matrix.hpp:324-335): begin extracts the records, empties the table and posts every chunk, from and
+ * into a buffer of the exchange's own (send list + what arrives: ~2 x 9..12 bytes per record; the context's scratch arena stays the
+ * counter's); finish waits chunk by chunk and applies.  Between the two calls `t` must not be touched and no other collective of `comm`
+ * may run; counting into OTHER tables of the context is what the gap is for.  When a rank has no room for the buffer -- all ranks agree
+ * on that -- and for wide tables, begin runs the whole exchange and finish returns at once.  Same result as katgpu_exchange_merge. */
+int  katgpu_exchange_begin(katgpu_comm* comm, katgpu_table* t);
+int  katgpu_exchange_finish(katgpu_comm* comm, katgpu_table* t);
 /* buf[i] = sum over ranks of buf[i], on every rank (host memory; collective) */
 int  katgpu_allreduce_u64(katgpu_comm* comm, uint64_t* buf, size_t n);
 /* wall time spent so far in extraction / on the wire (posting + waiting) / merging / all-reducing (ms), bytes sent, merge calls */

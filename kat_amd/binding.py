@@ -38,7 +38,7 @@ EXPORTS = (
     "katgpu_jf_write_records_wide", "katgpu_jf_read_records_wide", "katgpu_place_keys", "katgpu_reserve", "katgpu_device_count",
     "katgpu_count_files_sharded", "katgpu_table_slot_bytes", "katgpu_comm_unique_id", "katgpu_comm_init", "katgpu_comm_free", "katgpu_comm_rank", "katgpu_comm_world", "katgpu_comm_transport",
     "katgpu_comm_transport_note", "katgpu_comm_distinct_devices", "katgpu_comm_barrier", "katgpu_exchange_merge", "katgpu_allreduce_u64", "katgpu_comm_stats",
-    "katgpu_table_packed_records", "katgpu_table_extract_packed", "katgpu_table_merge_regions_packed", "katgpu_comm_wire",
+    "katgpu_table_packed_records", "katgpu_table_extract_packed", "katgpu_table_merge_regions_packed", "katgpu_comm_wire", "katgpu_exchange_begin", "katgpu_exchange_finish",
 )
 
 
@@ -683,6 +683,8 @@ class Comm:
         L.katgpu_comm_distinct_devices.argtypes = [C.c_void_p]
         L.katgpu_comm_barrier.argtypes = [C.c_void_p]
         L.katgpu_exchange_merge.argtypes = [C.c_void_p, C.c_void_p]
+        L.katgpu_exchange_begin.argtypes = [C.c_void_p, C.c_void_p]
+        L.katgpu_exchange_finish.argtypes = [C.c_void_p, C.c_void_p]
         L.katgpu_allreduce_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.katgpu_comm_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_uint64)] * 2
         L.katgpu_comm_wire.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
@@ -710,6 +712,15 @@ class Comm:
     def exchange_merge(self, table):
         """In place: afterwards `table` holds the k-mers this rank owns, counts summed over all ranks."""
         self.engine._chk(self.engine.L.katgpu_exchange_merge(self.h, table.h))
+        return table
+
+    def exchange_begin(self, table):
+        """The exchange in two calls: the table's records go on the wire; count the next input, then exchange_finish(table)."""
+        self.engine._chk(self.engine.L.katgpu_exchange_begin(self.h, table.h))
+        return table
+
+    def exchange_finish(self, table):
+        self.engine._chk(self.engine.L.katgpu_exchange_finish(self.h, table.h))
         return table
 
     def allreduce_u64(self, arrays):

@@ -76,8 +76,11 @@ katgpu_comm* Engine::comm() {
     return g_comm;
 }
 
-void Engine::exchange(katgpu_table* t) { if (dist_) check(katgpu_exchange_merge(comm(), t)); }
-void Engine::allreduce(uint64_t* buf, size_t n) { if (dist_) check(katgpu_allreduce_u64(comm(), buf, n)); }
+static katgpu_table* g_pending = nullptr;                                   // the table of an exchange begun and not yet finished
+void Engine::finishPending() { if (g_pending) { katgpu_table* t = g_pending; g_pending = nullptr; check(katgpu_exchange_finish(comm(), t)); } }
+void Engine::exchange(katgpu_table* t) { if (dist_) { finishPending(); check(katgpu_exchange_merge(comm(), t)); } }
+void Engine::exchangeBegin(katgpu_table* t) { if (dist_) { finishPending(); check(katgpu_exchange_begin(comm(), t)); g_pending = t; } }
+void Engine::allreduce(uint64_t* buf, size_t n) { if (dist_) { finishPending(); check(katgpu_allreduce_u64(comm(), buf, n)); } }
 
 void Engine::shutdown() {
     if (g_comm) { katgpu_comm_free(g_comm); g_comm = nullptr; }
@@ -165,7 +168,8 @@ std::string InputHandler::fileName() const {                                // l
 
 // `like` (comp only): the hash this one will be compared with; the new table adopts its region grid so that the
 // comparison can join region against region on the device (katgpu_table_create_like).
-void InputHandler::count(uint16_t threads, const katgpu_table* like) {      // lib/src/input_handler.cc:180-202
+// `more_to_count` (comp): another input is counted right after this one -- this table's merge across GPUs travels meanwhile (Engine::exchangeBegin).
+void InputHandler::count(uint16_t threads, const katgpu_table* like, bool more_to_count) {      // lib/src/input_handler.cc:180-202
     (void)threads;          // -t sized the reference's std::thread team; the GPU engine owns its own parallelism
     auto t0 = std::chrono::steady_clock::now();
     std::cout << "Input " << index << " is a sequence file.  Counting kmers for input " << index << " (" << pathString() << ") ...";
@@ -178,7 +182,7 @@ void InputHandler::count(uint16_t threads, const katgpu_table* like) {      // l
         if (like) Engine::check(katgpu_table_create_like(Engine::ctx(), like, merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
         else Engine::check(katgpu_table_create(Engine::ctx(), merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
         Engine::check(katgpu_count_files_sharded(hash, paths.data(), paths.size(), trim5p.data(), Engine::rank(), Engine::world()));
-        Engine::exchange(hash);
+        if (more_to_count) Engine::exchangeBegin(hash); else Engine::exchange(hash);
     } else if (like) {
         Engine::check(katgpu_table_create_like(Engine::ctx(), like, merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
         Engine::check(katgpu_count_files(hash, paths.data(), paths.size(), trim5p.data()));

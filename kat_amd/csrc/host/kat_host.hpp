@@ -72,6 +72,8 @@ public:
     static bool speaker() { return rank_ == 0; }    // writes the output files
     static katgpu_comm* comm();                     // made on first use (rank 0 publishes the id through id_file)
     static void exchange(katgpu_table* t);          // no-op without --gpus
+    static void exchangeBegin(katgpu_table* t);     // the same in two steps: the table's records travel while the caller counts its next input ...
+    static void finishPending();                    // ... and are applied here (katgpu_exchange_begin / _finish); every other collective finishes it first
     static void allreduce(uint64_t* buf, size_t n); // idem
 private:
     static int rank_, world_;
@@ -126,7 +128,7 @@ public:
     std::string fileName() const;
     void set5pTrim(const std::vector<uint16_t>& trim_list);
     void validateInput();                        // throws if an input is missing; sets mode
-    void count(uint16_t threads, const katgpu_table* like = nullptr);   // *** the drop-in boundary: katgpu_count ***
+    void count(uint16_t threads, const katgpu_table* like = nullptr, bool more_to_count = false);   // *** the drop-in boundary: katgpu_count ***
     void loadHeader() {}                         // the header travels with katgpu_jf_load (lib/src/input_handler.cc:139-143)
     void loadHash();                             // lib/src/input_handler.cc:204-219 -> katgpu_jf_load
     void validateMerLen(uint16_t merLen);        // lib/src/input_handler.cc:145-158

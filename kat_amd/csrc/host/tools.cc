@@ -229,8 +229,11 @@ void Comp::execute() {                                                          
         if (input[i].mode == InputHandler::COUNT && !(Engine::dist() && Engine::world() > 1)) katgpu_reserve(Engine::ctx(), getMerLen(), input[i].hashSize);
     for (size_t i = 0; i < inputSize(); i++) {                  // sequentially, one input after the other (:139-143)
         InputHandler& in = input[i];
-        if (in.mode == InputHandler::COUNT) in.count(threads, i > 0 ? input[0].hash : nullptr);
+        bool more = false;                                      // (--gpus N: this input's merge travels while the next one is counted)
+        for (size_t j = i + 1; j < inputSize(); j++) more = more || input[j].mode == InputHandler::COUNT;
+        if (in.mode == InputHandler::COUNT) in.count(threads, i > 0 ? input[0].hash : nullptr, more);
     }
+    Engine::finishPending();
     bool anyLoad = false, allLoad = true;                        // :146-167
     for (size_t i = 0; i < inputSize(); i++) {
         if (input[i].mode == InputHandler::LOAD) { input[i].loadHeader(); anyLoad = true; }

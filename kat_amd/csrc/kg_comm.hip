@@ -149,6 +149,7 @@ struct katgpu_comm {
     double ms_exchange = 0, ms_merge = 0, ms_extract = 0, ms_allreduce = 0;
     uint64_t bytes_sent = 0, merge_launches = 0;
     uint64_t records_sent = 0, record_bytes_sent = 0;          // what katgpu_exchange_merge put on the wire as records (not the count matrices, not the all-reduce)
+    void* pending = nullptr;                                   // an Exchange begun (katgpu_exchange_begin) and not yet finished
     bool wire_packed = false;                                  // the last exchange's records: 9 bytes (remainder + count) or 12 (key + count)
     std::string transport_note;
     uint8_t* host_stage = nullptr; size_t host_stage_bytes = 0;
@@ -394,9 +395,11 @@ extern "C" int katgpu_comm_unique_id(void* id_out) {
     return KATGPU_OK;
 }
 
+static void drop_pending(katgpu_comm* m);                        // (an exchange begun and never finished: its buffers go with the communicator)
 extern "C" void katgpu_comm_free(katgpu_comm* m) {
     if (!m) return;
     if (m->ctx) hipSetDevice(m->ctx->device);
+    drop_pending(m);
     if (m->nccl) rccl().CommDestroy(m->nccl);
     for (auto& e : m->ev) if (e) hipEventDestroy(e);
     if (m->stream) hipStreamDestroy(m->stream);
@@ -655,157 +658,220 @@ static int exchange_merge_wide(katgpu_comm* m, katgpu_table* t) {
 // summed over all ranks.  It keeps its storage and its region grid (a second table created "like" the first still joins with it
 // region by region).  Every rank of the communicator calls this, with tables of one k / one strand mode.  world == 1 runs the whole
 // protocol on the rank's own send list (extraction, clear, region-by-region merge): the table comes back as it was.
-extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
-    if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
-    katgpu_ctx* c = m->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (t->dev().keys_b) return exchange_merge_wide(m, t);
-    const int world = m->world, rank = m->rank;
-    const double t_begin = wall_ms();
-
-    // ---- geometry of every rank's table: which senders are ordered by MY regions ----
-    katgpu_geometry geo;
-    int rc = katgpu_table_geometry(t, &geo);
-    if (rc) return rc;
-    const uint64_t g_mine[6] = {geo.k, geo.canonical, geo.n_regions, geo.region_slots, geo.p1, geo.p2};
-    std::vector<uint64_t> geos((size_t)world * 6);
-    rc = allgather_u64(m, g_mine, 6, geos.data());
-    if (rc) return rc;
-    CTRACE(m, "geometries known: R %u slots %u p1 %u p2 %u", geo.n_regions, geo.region_slots, geo.p1, geo.p2);
-    for (int s = 0; s < world; ++s)
-        if (geos[(size_t)s * 6] != geo.k || geos[(size_t)s * 6 + 1] != geo.canonical) return fail(c, KATGPU_ERR_MISMATCH, "katgpu_exchange_merge: ranks disagree on k / canonical");
-    auto R_of = [&](int s) { return (uint32_t)geos[(size_t)s * 6 + 2]; };
-    const uint32_t R = geo.n_regions;
-    uint32_t R_min = R;
-    for (int s = 0; s < world; ++s) R_min = std::min(R_min, R_of(s));
-
-    // ---- pass 1: how many records go where, per region ----
+//
+// Two shapes of one protocol (struct Exchange):
+//   pipelined (katgpu_exchange_merge): the send list and TWO receive sets in the context's arena; chunk c on the wire while chunk c - 1
+//       is applied;
+//   split (katgpu_exchange_begin ... katgpu_exchange_finish): the send list and a receive set PER CHUNK in a buffer of the exchange's own
+//       (the arena is the counter's: the caller counts its next input in between), every chunk posted at once; finish waits chunk by
+//       chunk and applies.  When a rank cannot have that buffer, all ranks run the pipelined shape inside begin and finish has nothing to do.
+struct Exchange {
+    katgpu_comm* m; katgpu_table* t; katgpu_ctx* c;
+    int world, rank;
+    double t_begin;
+    katgpu_geometry geo{};
+    std::vector<uint64_t> geos;
+    uint32_t R = 0, R_min = 0;
     uint32_t* d_cnt = nullptr;                                    // [world x R] u32: records of region g owned by part p (small: outside the arena)
-    HIPCHK(c, hipMalloc((void**)&d_cnt, (size_t)world * R * 4 + 64));
-    struct Free { void* p; ~Free() { hipFree(p); } } free_cnt{d_cnt};
-    std::vector<uint64_t> sizes((size_t)world);
-    rc = katgpu_table_extract_sizes(t, (uint32_t)world, d_cnt, sizes.data());
-    if (rc) return rc;
-    uint64_t total_send = 0;
-    for (uint64_t s : sizes) total_send += s;
-    std::vector<uint64_t> s_all((size_t)world * world);
-    rc = allgather_u64(m, sizes.data(), (size_t)world, s_all.data());
-    if (rc) return rc;
-    CTRACE(m, "sizes known: %llu records to send", (unsigned long long)total_send);
-    std::vector<uint64_t> recv_from((size_t)world);
-    for (int s = 0; s < world; ++s) recv_from[s] = s_all[(size_t)s * world + rank];         // what each peer holds for me
-    // the region counts of what I will receive: row `rank` of every peer's matrix
-    std::vector<uint32_t*> d_rcnt((size_t)world, nullptr);
-    struct FreeAll { std::vector<uint32_t*>& v; int self; ~FreeAll() { for (size_t i = 0; i < v.size(); ++i) if ((int)i != self) hipFree(v[i]); } } free_rcnt{d_rcnt, rank};
-    {
-        std::vector<Msg> sends, recvs;
-        for (int p = 0; p < world; ++p) {
-            if (p == rank) { d_rcnt[p] = d_cnt + (size_t)rank * R; continue; }
-            HIPCHK(c, hipMalloc((void**)&d_rcnt[p], (size_t)R_of(p) * 4 + 64));
-            sends.push_back({p, d_cnt + (size_t)p * R, (size_t)R * 4});
-            recvs.push_back({p, d_rcnt[p], (size_t)R_of(p) * 4});
-        }
-        rc = transfer(m, sends, recvs, m->ev[0]);
-        if (!rc) rc = transfer_wait(m, m->ev[0]);
-        if (rc) return rc;
-    }
-    CTRACE(m, "region counts exchanged");
-    // prefix sums on the host (cnt: mine, per owner; rcnt: per sender, of the records it holds for me)
-    std::vector<std::vector<uint64_t>> cnt_cum((size_t)world), rcnt_cum((size_t)world);
-    {
-        std::vector<uint32_t> h;
-        for (int p = 0; p < world; ++p) {
-            h.resize(R);
-            HIPCHK(c, hipMemcpy(h.data(), d_cnt + (size_t)p * R, (size_t)R * 4, hipMemcpyDeviceToHost));
-            cnt_cum[p].assign((size_t)R + 1, 0);
-            for (uint32_t g = 0; g < R; ++g) cnt_cum[p][g + 1] = cnt_cum[p][g] + h[g];
-            h.resize(R_of(p));
-            HIPCHK(c, hipMemcpy(h.data(), d_rcnt[p], (size_t)R_of(p) * 4, hipMemcpyDeviceToHost));
-            rcnt_cum[p].assign((size_t)R_of(p) + 1, 0);
-            for (uint32_t g = 0; g < R_of(p); ++g) rcnt_cum[p][g + 1] = rcnt_cum[p][g] + h[g];
-        }
-    }
-    std::vector<uint64_t> part_base((size_t)world + 1, 0);
-    for (int p = 0; p < world; ++p) part_base[p + 1] = part_base[p] + sizes[p];
+    std::vector<uint32_t*> d_rcnt;                                // per sender: the region counts of what it holds for me (d_rcnt[rank] points into d_cnt)
+    std::vector<uint64_t> sizes, recv_from, part_base;
+    uint64_t total_send = 0, recv_other = 0;
+    std::vector<std::vector<uint64_t>> cnt_cum, rcnt_cum, bounds, recv_sz, send_off;
+    uint32_t C = 1;
+    bool split = false, packed = false, done = false;
+    void* own_buf = nullptr;                                      // split: the exchange's own buffer
+    uint64_t* skeys = nullptr; uint32_t* scounts = nullptr; uint32_t* srem_lo = nullptr; uint8_t* srem_hi = nullptr;
+    struct Set { uint64_t* keys; uint32_t* rem_lo; uint8_t* rem_hi; uint32_t* counts; };
+    std::vector<Set> sets;                                        // pipelined: 2 (chunk & 1); split: one per chunk
+    std::vector<hipEvent_t> evs;                                  // split: one per chunk (pipelined: the communicator's two)
+    static constexpr uint32_t BIG = 4200;
+    std::vector<uint64_t> big_keys, big_counts;
+    uint32_t n_big = 0;
+    struct Layout { int s; uint64_t o, n; };
+    std::vector<std::vector<Layout>> lay;
 
-    // ---- chunks of consecutive regions, as few as the exchange scratch allows (>= 4 for the overlap) ----
-    uint64_t recv_other = 0;
-    for (int s = 0; s < world; ++s) if (s != rank) recv_other += recv_from[s];
-    uint32_t C = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)hook_u64("KATGPU_TEST_EXCHANGE_CHUNKS", 4), R_min));
-    void* arena = nullptr; size_t cap = 0;
-    {
-        const size_t want = exchange_bytes(total_send, (recv_other + C - 1) / C * 5 / 4);
-        rc = katgpu_scratch_acquire(c, 0, &arena, &cap);
-        if (!rc && cap < want && katgpu_scratch_acquire(c, want, &arena, &cap) != KATGPU_OK) rc = katgpu_scratch_acquire(c, 0, &arena, &cap);   // (keeps the old arena when the larger one cannot be had)
-        if (rc) return rc;
+    Exchange(katgpu_comm* m_, katgpu_table* t_) : m(m_), t(t_), c(m_->ctx), world(m_->world), rank(m_->rank), t_begin(wall_ms()), big_keys(BIG), big_counts(BIG) {}
+    ~Exchange() {
+        for (size_t i = 0; i < d_rcnt.size(); ++i) if ((int)i != rank && d_rcnt[i]) hipFree(d_rcnt[i]);
+        if (d_cnt) hipFree(d_cnt);
+        if (own_buf) hipFree(own_buf);
+        for (auto e : evs) if (e) hipEventDestroy(e);
     }
-    std::vector<std::vector<uint64_t>> bounds((size_t)world);    // region boundaries of the chunks, per sender's grid
-    std::vector<std::vector<uint64_t>> recv_sz((size_t)world);   // [sender][chunk]
-    uint64_t set_records = 1;
-    for (;;) {
+    uint32_t R_of(int s) const { return (uint32_t)geos[(size_t)s * 6 + 2]; }
+    Set& set_of(uint32_t ch) { return sets[split ? ch : (ch & 1)]; }
+    hipEvent_t ev_of(uint32_t ch) { return split ? evs[ch] : m->ev[ch & 1]; }
+    int agree(bool mine, bool* all_agree) {                       // (what a rank can do depends on its own table / memory: all must agree before one acts)
+        uint64_t v = mine ? 1 : 0;
+        std::vector<uint64_t> all((size_t)world);
+        int rc = allgather_u64(m, &v, 1, all.data());
+        if (rc) return rc;
+        bool ok = true;
+        for (uint64_t x : all) ok = ok && x != 0;
+        *all_agree = ok;
+        return KATGPU_OK;
+    }
+
+    // geometry of every rank's table, how many records go where per region, the region counts of what I will receive
+    int prepare() {
+        int rc = katgpu_table_geometry(t, &geo);
+        if (rc) return rc;
+        const uint64_t g_mine[6] = {geo.k, geo.canonical, geo.n_regions, geo.region_slots, geo.p1, geo.p2};
+        geos.resize((size_t)world * 6);
+        rc = allgather_u64(m, g_mine, 6, geos.data());
+        if (rc) return rc;
+        CTRACE(m, "geometries known: R %u slots %u p1 %u p2 %u", geo.n_regions, geo.region_slots, geo.p1, geo.p2);
+        for (int s = 0; s < world; ++s)
+            if (geos[(size_t)s * 6] != geo.k || geos[(size_t)s * 6 + 1] != geo.canonical) return fail(c, KATGPU_ERR_MISMATCH, "katgpu_exchange_merge: ranks disagree on k / canonical");
+        R = geo.n_regions;
+        R_min = R;
+        for (int s = 0; s < world; ++s) R_min = std::min(R_min, R_of(s));
+
+        // ---- pass 1: how many records go where, per region ----
+        HIPCHK(c, hipMalloc((void**)&d_cnt, (size_t)world * R * 4 + 64));
+        sizes.resize((size_t)world);
+        rc = katgpu_table_extract_sizes(t, (uint32_t)world, d_cnt, sizes.data());
+        if (rc) return rc;
+        for (uint64_t s : sizes) total_send += s;
+        std::vector<uint64_t> s_all((size_t)world * world);
+        rc = allgather_u64(m, sizes.data(), (size_t)world, s_all.data());
+        if (rc) return rc;
+        CTRACE(m, "sizes known: %llu records to send", (unsigned long long)total_send);
+        recv_from.resize((size_t)world);
+        for (int s = 0; s < world; ++s) recv_from[s] = s_all[(size_t)s * world + rank];         // what each peer holds for me
+        // the region counts of what I will receive: row `rank` of every peer's matrix
+        d_rcnt.assign((size_t)world, nullptr);
+        {
+            std::vector<Msg> sends, recvs;
+            for (int p = 0; p < world; ++p) {
+                if (p == rank) { d_rcnt[p] = d_cnt + (size_t)rank * R; continue; }
+                HIPCHK(c, hipMalloc((void**)&d_rcnt[p], (size_t)R_of(p) * 4 + 64));
+                sends.push_back({p, d_cnt + (size_t)p * R, (size_t)R * 4});
+                recvs.push_back({p, d_rcnt[p], (size_t)R_of(p) * 4});
+            }
+            rc = transfer(m, sends, recvs, m->ev[0]);
+            if (!rc) rc = transfer_wait(m, m->ev[0]);
+            if (rc) return rc;
+        }
+        CTRACE(m, "region counts exchanged");
+        // prefix sums on the host (cnt: mine, per owner; rcnt: per sender, of the records it holds for me)
+        cnt_cum.resize((size_t)world); rcnt_cum.resize((size_t)world);
+        {
+            std::vector<uint32_t> h;
+            for (int p = 0; p < world; ++p) {
+                h.resize(R);
+                HIPCHK(c, hipMemcpy(h.data(), d_cnt + (size_t)p * R, (size_t)R * 4, hipMemcpyDeviceToHost));
+                cnt_cum[p].assign((size_t)R + 1, 0);
+                for (uint32_t g = 0; g < R; ++g) cnt_cum[p][g + 1] = cnt_cum[p][g] + h[g];
+                h.resize(R_of(p));
+                HIPCHK(c, hipMemcpy(h.data(), d_rcnt[p], (size_t)R_of(p) * 4, hipMemcpyDeviceToHost));
+                rcnt_cum[p].assign((size_t)R_of(p) + 1, 0);
+                for (uint32_t g = 0; g < R_of(p); ++g) rcnt_cum[p][g + 1] = rcnt_cum[p][g] + h[g];
+            }
+        }
+        part_base.assign((size_t)world + 1, 0);
+        for (int p = 0; p < world; ++p) part_base[p + 1] = part_base[p] + sizes[p];
+        for (int s = 0; s < world; ++s) if (s != rank) recv_other += recv_from[s];
+        return KATGPU_OK;
+    }
+    void cut(uint32_t chunks) {                                   // chunks of consecutive regions, per sender's grid; what each brings me
+        C = chunks;
+        bounds.resize((size_t)world); recv_sz.resize((size_t)world);
         for (int s = 0; s < world; ++s) {
             bounds[s].resize((size_t)C + 1);
             for (uint32_t i = 0; i <= C; ++i) bounds[s][i] = (uint64_t)i * R_of(s) / C;
             recv_sz[s].resize(C);
             for (uint32_t i = 0; i < C; ++i) recv_sz[s][i] = rcnt_cum[s][bounds[s][i + 1]] - rcnt_cum[s][bounds[s][i]];
         }
-        set_records = 1;
-        for (uint32_t i = 0; i < C; ++i) { uint64_t x = 0; for (int s = 0; s < world; ++s) if (s != rank) x += recv_sz[s][i]; set_records = std::max(set_records, x); }
-        uint64_t fits = exchange_bytes(total_send, set_records) <= cap ? 1 : 0;
-        std::vector<uint64_t> all((size_t)world);
-        rc = allgather_u64(m, &fits, 1, all.data());
-        if (rc) return rc;
-        bool ok = true;
-        for (uint64_t v : all) ok = ok && v;
-        if (ok) break;
-        if (C >= R_min) return fail(c, KATGPU_ERR_NOMEM, "katgpu_exchange_merge: the send list and one region's receive buffers do not fit the exchange scratch");
-        C = std::min(C * 2, R_min);
     }
-    std::vector<std::vector<uint64_t>> send_off((size_t)world);  // [owner][chunk boundary]: index into the send list
-    for (int p = 0; p < world; ++p) {
-        send_off[p].resize((size_t)C + 1);
-        for (uint32_t i = 0; i <= C; ++i) send_off[p][i] = part_base[p] + cnt_cum[p][bounds[rank][i]];
-    }
+    uint64_t chunk_in(uint32_t i) const { uint64_t x = 0; for (int s = 0; s < world; ++s) if (s != rank) x += recv_sz[s][i]; return x; }
 
-    // ---- pass 2: the send list; the emptied table becomes the owner table ----
-    // Records: key + count (12 bytes) -- or, when EVERY rank's table has this one's grid and can give them, what a slot holds of the k-mer
-    // + count (4 + 1 + 4 = 9 bytes: katgpu_table_extract_packed); the region a record lies in says the rest, and the chunks are region ranges.
-    bool packed = g_wire_packed && katgpu_table_packed_records(t) != 0;
-    for (int s = 0; s < world; ++s) packed = packed && geos[(size_t)s * 6 + 4] == geo.p1 && geos[(size_t)s * 6 + 5] == geo.p2 && R_of(s) == R;
-    {
-        uint64_t mine_ok = packed ? 1 : 0;                        // (what a rank CAN give depends on its table alone: all must agree before one sends)
-        std::vector<uint64_t> all((size_t)world);
-        rc = allgather_u64(m, &mine_ok, 1, all.data());
-        if (rc) return rc;
-        for (uint64_t v : all) packed = packed && v != 0;
-    }
-    m->wire_packed = packed;
-    CTRACE(m, "%u chunks, records of %d bytes", C, packed ? 9 : 12);
-    uint8_t* a = (uint8_t*)arena;
-    uint64_t* skeys = (uint64_t*)a;           a += xalign(8 * std::max<uint64_t>(total_send, 1));     // (packed: the low words, then the high bytes, in the same room)
-    uint32_t* scounts = (uint32_t*)a;         a += xalign(4 * std::max<uint64_t>(total_send, 1));
-    uint32_t* const srem_lo = (uint32_t*)skeys;
-    uint8_t* const srem_hi = (uint8_t*)skeys + xalign(4 * std::max<uint64_t>(total_send, 1));
-    uint64_t* rkeys[2]; uint32_t* rcounts[2]; uint32_t* rrem_lo[2]; uint8_t* rrem_hi[2];
-    for (int i = 0; i < 2; ++i) {
-        rkeys[i] = (uint64_t*)a; rrem_lo[i] = (uint32_t*)a; rrem_hi[i] = a + xalign(4 * set_records); a += xalign(8 * set_records);
-        rcounts[i] = (uint32_t*)a; a += xalign(4 * set_records);
-    }
-    constexpr uint32_t BIG = 4200;
-    std::vector<uint64_t> big_keys(BIG), big_counts(BIG);
-    uint32_t n_big = 0;
-    rc = packed ? katgpu_table_extract_packed(t, (uint32_t)world, d_cnt, srem_lo, srem_hi, scounts, big_keys.data(), big_counts.data(), BIG, &n_big)
-                : katgpu_table_extract(t, (uint32_t)world, d_cnt, skeys, scounts, big_keys.data(), big_counts.data(), BIG, &n_big);
-    if (rc) return rc;
-    rc = katgpu_table_clear(t);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));                   // the send list is complete before the transport stream reads it
-    m->ms_extract += wall_ms() - t_begin;
-    CTRACE(m, "send list written, table emptied");
+    // the buffers, the send list; the emptied table becomes the owner table
+    int plan(bool want_split) {
+        int rc;
+        const uint32_t C0 = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)hook_u64("KATGPU_TEST_EXCHANGE_CHUNKS", 4), R_min));
+        uint8_t* a = nullptr;
+        if (want_split) {                                         // a buffer of the exchange's own: the send list + a receive set per chunk
+            cut(C0);
+            size_t bytes = xalign(8 * std::max<uint64_t>(total_send, 1)) + xalign(4 * std::max<uint64_t>(total_send, 1)) + 256;
+            for (uint32_t i = 0; i < C; ++i) bytes += xalign(8 * std::max<uint64_t>(chunk_in(i), 1)) + xalign(4 * std::max<uint64_t>(chunk_in(i), 1));
+            const bool got = !hook("KATGPU_TEST_EXCHANGE_NO_SPLIT") && hipMalloc(&own_buf, bytes) == hipSuccess;
+            if (!got) { (void)hipGetLastError(); own_buf = nullptr; }
+            bool all = false;
+            rc = agree(got, &all);
+            if (rc) return rc;
+            if (!all && own_buf) { hipFree(own_buf); own_buf = nullptr; }
+            split = all;
+            if (split) {
+                a = (uint8_t*)own_buf;
+                evs.assign(C, nullptr);
+                for (auto& e : evs) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            } else if (g_trace || g_comm_trace) fprintf(stderr, "[katgpu comm %d/%d] no buffer of %.1f GB for a split exchange on some rank: the pipelined one, now\n", rank, world, bytes / 1e9);
+        }
+        uint64_t set_records = 1;
+        if (!split) {                                             // the arena: as few chunks as it allows (>= 4 for the overlap)
+            void* arena = nullptr; size_t cap = 0;
+            {
+                const size_t want = exchange_bytes(total_send, (recv_other + C0 - 1) / C0 * 5 / 4);
+                rc = katgpu_scratch_acquire(c, 0, &arena, &cap);
+                if (!rc && cap < want && katgpu_scratch_acquire(c, want, &arena, &cap) != KATGPU_OK) rc = katgpu_scratch_acquire(c, 0, &arena, &cap);   // (keeps the old arena when the larger one cannot be had)
+                if (rc) return rc;
+            }
+            uint32_t chunks = C0;
+            for (;;) {
+                cut(chunks);
+                set_records = 1;
+                for (uint32_t i = 0; i < C; ++i) set_records = std::max(set_records, chunk_in(i));
+                bool ok = false;
+                rc = agree(exchange_bytes(total_send, set_records) <= cap, &ok);
+                if (rc) return rc;
+                if (ok) break;
+                if (C >= R_min) return fail(c, KATGPU_ERR_NOMEM, "katgpu_exchange_merge: the send list and one region's receive buffers do not fit the exchange scratch");
+                chunks = std::min(C * 2, R_min);
+            }
+            a = (uint8_t*)arena;
+        }
+        send_off.resize((size_t)world);                           // [owner][chunk boundary]: index into the send list
+        for (int p = 0; p < world; ++p) {
+            send_off[p].resize((size_t)C + 1);
+            for (uint32_t i = 0; i <= C; ++i) send_off[p][i] = part_base[p] + cnt_cum[p][bounds[rank][i]];
+        }
 
-    struct Layout { int s; uint64_t o, n; };
-    auto post = [&](uint32_t ch, std::vector<Layout>& layout) -> int {
+        // ---- pass 2: the send list ----
+        // Records: key + count (12 bytes) -- or, when EVERY rank's table has this one's grid and can give them, what a slot holds of the k-mer
+        // + count (4 + 1 + 4 = 9 bytes: katgpu_table_extract_packed); the region a record lies in says the rest, and the chunks are region ranges.
+        bool mine = g_wire_packed && katgpu_table_packed_records(t) != 0;
+        for (int s = 0; s < world; ++s) mine = mine && geos[(size_t)s * 6 + 4] == geo.p1 && geos[(size_t)s * 6 + 5] == geo.p2 && R_of(s) == R;
+        rc = agree(mine, &packed);
+        if (rc) return rc;
+        m->wire_packed = packed;
+        CTRACE(m, "%u chunks (%s), records of %d bytes", C, split ? "all on the wire at once" : "one travels while one is applied", packed ? 9 : 12);
+        skeys = (uint64_t*)a;           a += xalign(8 * std::max<uint64_t>(total_send, 1));     // (packed: the low words, then the high bytes, in the same room)
+        scounts = (uint32_t*)a;         a += xalign(4 * std::max<uint64_t>(total_send, 1));
+        srem_lo = (uint32_t*)skeys;
+        srem_hi = (uint8_t*)skeys + xalign(4 * std::max<uint64_t>(total_send, 1));
+        sets.resize(split ? C : 2);
+        for (size_t i = 0; i < sets.size(); ++i) {
+            const uint64_t n = split ? std::max<uint64_t>(chunk_in((uint32_t)i), 1) : set_records;
+            sets[i].keys = (uint64_t*)a; sets[i].rem_lo = (uint32_t*)a; sets[i].rem_hi = a + xalign(4 * n); a += xalign(8 * n);
+            sets[i].counts = (uint32_t*)a; a += xalign(4 * n);
+        }
+        rc = packed ? katgpu_table_extract_packed(t, (uint32_t)world, d_cnt, srem_lo, srem_hi, scounts, big_keys.data(), big_counts.data(), BIG, &n_big)
+                    : katgpu_table_extract(t, (uint32_t)world, d_cnt, skeys, scounts, big_keys.data(), big_counts.data(), BIG, &n_big);
+        if (rc) return rc;
+        rc = katgpu_table_clear(t);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));               // the send list is complete before the transport stream reads it
+        m->ms_extract += wall_ms() - t_begin;
+        CTRACE(m, "send list written, table emptied");
+        lay.resize(split ? C : 2);
+        return KATGPU_OK;
+    }
+    std::vector<Layout>& lay_of(uint32_t ch) { return lay[split ? ch : (ch & 1)]; }
+
+    int post(uint32_t ch) {
         std::vector<Msg> sends, recvs;
+        std::vector<Layout>& layout = lay_of(ch);
+        Set& rs = set_of(ch);
         uint64_t o = 0;
         layout.clear();
         for (int s = 0; s < world; ++s) {
@@ -819,22 +885,24 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
             }
             const uint64_t n_in = recv_sz[s][ch];
             if (n_in) {
-                if (packed) { recvs.push_back({s, rrem_lo[ch & 1] + o, (size_t)n_in * 4}); recvs.push_back({s, rrem_hi[ch & 1] + o, (size_t)n_in}); }
-                else recvs.push_back({s, rkeys[ch & 1] + o, (size_t)n_in * 8});
-                recvs.push_back({s, rcounts[ch & 1] + o, (size_t)n_in * 4});
+                if (packed) { recvs.push_back({s, rs.rem_lo + o, (size_t)n_in * 4}); recvs.push_back({s, rs.rem_hi + o, (size_t)n_in}); }
+                else recvs.push_back({s, rs.keys + o, (size_t)n_in * 8});
+                recvs.push_back({s, rs.counts + o, (size_t)n_in * 4});
             }
             layout.push_back({s, o, n_in});
             o += n_in;
         }
-        return transfer(m, sends, recvs, m->ev[ch & 1]);
-    };
-    auto merge = [&](uint32_t ch, const std::vector<Layout>& layout) -> int {
+        return transfer(m, sends, recvs, ev_of(ch));
+    }
+    int merge(uint32_t ch) {
+        const std::vector<Layout>& layout = lay_of(ch);
+        Set& rs = set_of(ch);
         const uint32_t my_lo = (uint32_t)bounds[rank][ch], my_hi = (uint32_t)bounds[rank][ch + 1];
         const uint64_t a0 = send_off[rank][ch], n_own = send_off[rank][ch + 1] - a0;
         if (packed) {                                             // (every rank has this table's grid -- as it was when the exchange began: the sources say so)
             std::vector<katgpu_merge_source_packed> src;
             if (n_own) src.push_back({srem_lo + a0, srem_hi + a0, scounts + a0, d_rcnt[rank] + my_lo, n_own, geo.p1, geo.p2});
-            for (auto& l : layout) if (l.n) src.push_back({rrem_lo[ch & 1] + l.o, rrem_hi[ch & 1] + l.o, rcounts[ch & 1] + l.o, d_rcnt[l.s] + my_lo, l.n, geo.p1, geo.p2});
+            for (auto& l : layout) if (l.n) src.push_back({rs.rem_lo + l.o, rs.rem_hi + l.o, rs.counts + l.o, d_rcnt[l.s] + my_lo, l.n, geo.p1, geo.p2});
             if (src.empty()) return KATGPU_OK;
             ++m->merge_launches;
             return katgpu_table_merge_regions_packed(t, my_lo, my_hi, (uint32_t)src.size(), src.data());
@@ -844,49 +912,112 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
         for (auto& l : layout) {
             if (!l.n) continue;
             const bool same_regions = bounds[l.s][ch] == my_lo && bounds[l.s][ch + 1] == my_hi && geos[(size_t)l.s * 6 + 4] == geo.p1 && geos[(size_t)l.s * 6 + 5] == geo.p2;
-            src.push_back({rkeys[ch & 1] + l.o, rcounts[ch & 1] + l.o, same_regions ? d_rcnt[l.s] + my_lo : nullptr, l.n, (uint32_t)geos[(size_t)l.s * 6 + 4], (uint32_t)geos[(size_t)l.s * 6 + 5]});
+            src.push_back({rs.keys + l.o, rs.counts + l.o, same_regions ? d_rcnt[l.s] + my_lo : nullptr, l.n, (uint32_t)geos[(size_t)l.s * 6 + 4], (uint32_t)geos[(size_t)l.s * 6 + 5]});
         }
         if (src.empty()) return KATGPU_OK;
         ++m->merge_launches;
         return katgpu_table_merge_regions(t, my_lo, my_hi, (uint32_t)src.size(), src.data());
-    };
-    std::vector<Layout> lay[2];
-    for (uint32_t ch = 0; ch <= C; ++ch) {
-        if (ch < C) {                                             // chunk ch goes on the wire ...
-            const double t0 = wall_ms();
-            rc = post(ch, lay[ch & 1]);
-            if (rc) return rc;
-            m->ms_exchange += wall_ms() - t0;
-        }
-        if (ch > 0) {                                             // ... while chunk ch - 1 is applied
-            double t0 = wall_ms();
-            rc = transfer_wait(m, m->ev[(ch - 1) & 1]);
-            if (rc) return rc;
-            m->ms_exchange += wall_ms() - t0;
-            t0 = wall_ms();
-            CTRACE(m, "chunk %u arrived", ch - 1);
-            rc = merge(ch - 1, lay[(ch - 1) & 1]);
-            if (rc) return rc;
-            m->ms_merge += wall_ms() - t0;
-            CTRACE(m, "chunk %u merged", ch - 1);
-        }
     }
+    int arrived_then_merge(uint32_t ch) {
+        double t0 = wall_ms();
+        int rc = transfer_wait(m, ev_of(ch));
+        if (rc) return rc;
+        m->ms_exchange += wall_ms() - t0;
+        t0 = wall_ms();
+        CTRACE(m, "chunk %u arrived", ch);
+        rc = merge(ch);
+        if (rc) return rc;
+        m->ms_merge += wall_ms() - t0;
+        CTRACE(m, "chunk %u merged", ch);
+        return KATGPU_OK;
+    }
+    // out-of-band records: counts beyond the record's field and the all-ones k-mer (a handful)
+    int tail() {
+        std::vector<uint64_t> mine((size_t)1 + 2 * BIG, 0), everyone((size_t)world * (1 + 2 * BIG));
+        mine[0] = n_big;
+        for (uint32_t i = 0; i < n_big; ++i) { mine[1 + i] = big_keys[i]; mine[1 + BIG + i] = big_counts[i]; }
+        int rc = allgather_u64(m, mine.data(), mine.size(), everyone.data());
+        if (rc) return rc;
+        std::vector<uint64_t> ok_keys, ok_counts;
+        for (int s = 0; s < world; ++s) {
+            const uint64_t* e = everyone.data() + (size_t)s * (1 + 2 * BIG);
+            for (uint64_t i = 0; i < e[0] && i < BIG; ++i)
+                if (host_owner_of(e[1 + i], geo.k, (uint32_t)world) == (uint32_t)rank) { ok_keys.push_back(e[1 + i]); ok_counts.push_back(e[1 + BIG + i]); }
+        }
+        if (!ok_keys.empty()) { rc = katgpu_table_merge_host(t, ok_keys.data(), ok_counts.data(), ok_keys.size()); if (rc) return rc; }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        CTRACE(m, "out-of-band records done");
+        rc = shm_barrier(m);                                      // nobody reuses its buffers while a peer may still be reading from them
+        done = true;
+        return rc ? rc : refresh_counters(t);
+    }
+    int pipelined() {
+        for (uint32_t ch = 0; ch <= C; ++ch) {
+            if (ch < C) {                                         // chunk ch goes on the wire ...
+                const double t0 = wall_ms();
+                int rc = post(ch);
+                if (rc) return rc;
+                m->ms_exchange += wall_ms() - t0;
+            }
+            if (ch > 0) { int rc = arrived_then_merge(ch - 1); if (rc) return rc; }     // ... while chunk ch - 1 is applied
+        }
+        return tail();
+    }
+    int begin(bool want_split) {
+        int rc = prepare();
+        if (!rc) rc = plan(want_split);
+        if (rc) return rc;
+        if (!split) return pipelined();
+        const double t0 = wall_ms();
+        for (uint32_t ch = 0; ch < C && !rc; ++ch) rc = post(ch);
+        m->ms_exchange += wall_ms() - t0;
+        return rc;
+    }
+    int finish() {
+        if (done) return KATGPU_OK;
+        t_begin = wall_ms();
+        for (uint32_t ch = 0; ch < C; ++ch) { int rc = arrived_then_merge(ch); if (rc) return rc; }
+        return tail();
+    }
+};
 
-    // ---- out-of-band records: counts above 32 bits and the all-ones k-mer (a handful) ----
-    std::vector<uint64_t> mine((size_t)1 + 2 * BIG, 0), everyone((size_t)world * (1 + 2 * BIG));
-    mine[0] = n_big;
-    for (uint32_t i = 0; i < n_big; ++i) { mine[1 + i] = big_keys[i]; mine[1 + BIG + i] = big_counts[i]; }
-    rc = allgather_u64(m, mine.data(), mine.size(), everyone.data());
-    if (rc) return rc;
-    std::vector<uint64_t> ok_keys, ok_counts;
-    for (int s = 0; s < world; ++s) {
-        const uint64_t* e = everyone.data() + (size_t)s * (1 + 2 * BIG);
-        for (uint64_t i = 0; i < e[0] && i < BIG; ++i)
-            if (host_owner_of(e[1 + i], geo.k, (uint32_t)world) == (uint32_t)rank) { ok_keys.push_back(e[1 + i]); ok_counts.push_back(e[1 + BIG + i]); }
-    }
-    if (!ok_keys.empty()) { rc = katgpu_table_merge_host(t, ok_keys.data(), ok_counts.data(), ok_keys.size()); if (rc) return rc; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    CTRACE(m, "out-of-band records done");
-    rc = shm_barrier(m);                                          // nobody reuses its arena while a peer may still be reading from it
-    return rc ? rc : refresh_counters(t);
+static void drop_pending(katgpu_comm* m) { if (m->pending) { delete (Exchange*)m->pending; m->pending = nullptr; } }
+
+extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
+    if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = m->ctx;
+    if (m->pending) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_merge: an exchange begun with katgpu_exchange_begin has not been finished");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (t->dev().keys_b) return exchange_merge_wide(m, t);
+    Exchange x(m, t);
+    return x.begin(false);
+}
+
+// The same exchange in two calls, so that the caller's next input is counted while this table's records travel: begin extracts, empties
+// the table and puts every chunk on the wire (from and into a buffer of the exchange's own -- the arena stays the counter's); finish waits
+// for the chunks and applies them.  Between the two the table is not to be touched and no other collective of this communicator may run.
+// Wide tables (k > 32) and ranks without room for the buffer do the whole exchange in begin.
+extern "C" int katgpu_exchange_begin(katgpu_comm* m, katgpu_table* t) {
+    if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
+    katgpu_ctx* c = m->ctx;
+    if (m->pending) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_begin: the previous exchange has not been finished");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (t->dev().keys_b) return exchange_merge_wide(m, t);
+    Exchange* x = new Exchange(m, t);
+    const int rc = x->begin(true);
+    if (rc || x->done) { delete x; return rc; }
+    m->pending = x;
+    return KATGPU_OK;
+}
+extern "C" int katgpu_exchange_finish(katgpu_comm* m, katgpu_table* t) {
+    if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
+    if (!m->pending) return KATGPU_OK;                            // (begin did it all)
+    katgpu_ctx* c = m->ctx;
+    Exchange* x = (Exchange*)m->pending;
+    if (x->t != t) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_finish: not the table katgpu_exchange_begin was given");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = x->finish();
+    m->pending = nullptr;
+    delete x;
+    return rc;
 }

@@ -48,9 +48,25 @@ def main():
     rb.upload(reads)
     ab.upload(asm)
     hint = (1 << 22) if not (mode == "mixed" and rank == 1) else (1 << 24)      # "mixed": rank 1's grid differs: its records take the direct path
+    split = os.environ.get("KATGPU_TEST_SPLIT_EXCHANGE") == "1"                  # katgpu_exchange_begin ... count the second input ... katgpu_exchange_finish
     t1 = eng.table(k, True, size_hint=hint).count_bases_device(rb.ptr, reads.size)
-    t2 = eng.table(k, True, size_hint=1 << 20, like=None if wide else t1).count_bases_device(ab.ptr, asm.size)
-    if wide:                                                                     # k > 32: records (hi, lo, count) all to all, the table refilled
+    if split:
+        if wide:
+            t1.merge_host_wide([0], [12345], [(1 << 33) + rank])
+        else:
+            t1.merge_host(np.array([12345], np.uint64), np.array([(1 << 33) + rank], np.uint64))
+        g1 = None if wide else t1.geometry()
+        comm.exchange_begin(t1)                                                  # table 1's records travel ...
+    t2 = eng.table(k, True, size_hint=1 << 20, like=None if wide else t1).count_bases_device(ab.ptr, asm.size)     # ... while input 2 is counted (in the arena)
+    if split:
+        eng.sync()
+        comm.exchange_finish(t1)
+        comm.exchange_merge(t2)
+        if not wide:
+            assert (t1.geometry().p1, t1.geometry().p2) == (g1.p1, g1.p2)
+            keys, counts = t1.dump_sorted()
+            assert (kdist.owner_of(keys, k, world) == rank).all()
+    elif wide:                                                                   # k > 32: records (hi, lo, count) all to all, the table refilled
         t1.merge_host_wide([0], [12345], [(1 << 33) + rank])
         before = t1.dump_sorted_wide() if world == 1 else None
         comm.exchange_merge(t1)

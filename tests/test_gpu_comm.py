@@ -80,6 +80,24 @@ def test_records_travel_in_nine_bytes_between_ranks_that_share_the_grid(ko, tmp_
     _check(ko, tmp_path, world, "same")
 
 
+@pytest.mark.parametrize("world,transport,mode,extra,want", [
+    (2, "shm", "same", {}, "all on the wire at once"), (4, "rccl", "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "6", "KATGPU_TEST_REGION_SLOTS": "128"}, "all on the wire at once"),
+    (8, "rccl", "rr31", {}, "all on the wire at once"), (2, "rccl", "mixed", {}, "all on the wire at once"),
+    (3, "rccl", "same", {"KATGPU_TEST_EXCHANGE_NO_SPLIT": "1"}, "the pipelined one, now"), (2, "shm", "wide45", {}, None)])
+def test_the_second_input_is_counted_while_the_first_table_travels(ko, tmp_path, fake_rccl, world, transport, mode, extra, want):
+    """katgpu_exchange_begin(table 1) -- the second input counted, in the arena the exchange no longer uses -- katgpu_exchange_finish(table 1):
+    the result is the oracle's, as katgpu_exchange_merge's is; a rank without room for the exchange's own buffer (here: a hook) makes every
+    rank run the pipelined exchange inside begin; wide tables do it all in begin."""
+    env = dict(extra, KATGPU_COMM_TRANSPORT=transport, KATGPU_TESTING="1", KATGPU_TEST_SPLIT_EXCHANGE="1", KATGPU_COMM_TRACE="1")
+    if transport == "rccl":
+        env["KATGPU_RCCL_LIB"] = fake_rccl
+    out = _run(tmp_path, world, mode, env)
+    assert "transport: %s" % transport in out, out[-2000:]
+    if want:
+        assert want in out, out[-3000:]
+    _check(ko, tmp_path, world, mode)
+
+
 @pytest.fixture(scope="module")
 def fake_rccl(tmp_path_factory):
     """tests/native/fake_rccl.cc built into a shared library: the ten nccl* entry points kg_comm.hip resolves, over /dev/shm + hipMemcpy,
