@@ -121,6 +121,13 @@ void katgpu_free_host(void* p);
  * Returns KATGPU_OK, or KATGPU_ERR_FASTQ when the bytes are not whole plain four-line records (such pieces go through the host state
  * machine, katgpu_parse_file's, instead: it alone knows what multi-line records and odd quality lengths mean). */
 int  katgpu_strip_fastq(const uint8_t* fastq, size_t n, uint8_t* out, size_t* out_n);
+/* The inflated bytes of ONE ordinary gzip stream through the thread team that katgpu_count_files / katgpu_parse_file use for .gz
+ * files of size (kg_pgzip.cpp: the file cut into chunks, each entered at a deflate block start found by search and decoded without
+ * its 32 KiB of history, stitched and resolved in order; every member's CRC-32 and ISIZE checked) -- for tests and tools: the
+ * reference reads every input through one zlib stream (deps/jellyfish-2.2.0/include/jellyfish/stream_manager.hpp:41-51,133-145).
+ * *out is malloc'ed (katgpu_free_host).  KATGPU_PGZ_THREADS / KATGPU_PGZ_CHUNK (bytes of compressed input per chunk) size the team.
+ * KATGPU_ERR_FORMAT: not a gzip file; KATGPU_ERR_IO ("read error on <path>"): corrupt or truncated. */
+int  katgpu_inflate_file(const char* path, uint8_t** out, size_t* n, const char** err_msg);
 
 /* The placement hash of one-word tables (kg_device.hpp "placement"; the counterpart of the invertible hash + remainder storage of
  * JF/include/jellyfish/large_hash_array.hpp:169-171), on the host, for a table of p1 x 2^l2 regions: per key the two region digits,

@@ -31,7 +31,7 @@ EXPORTS = (
     "katgpu_table_merge_host", "katgpu_table_geometry", "katgpu_table_extract_sizes", "katgpu_table_extract", "katgpu_table_clear",
     "katgpu_table_merge_device32", "katgpu_table_merge_regions", "katgpu_profile_reset", "katgpu_profile_get", "katgpu_dev_alloc",
     "katgpu_dev_free", "katgpu_dev_upload", "katgpu_dev_download", "katgpu_dev_mem_info",
-    "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_parse_files", "katgpu_free_host", "katgpu_strip_fastq",
+    "katgpu_synth_genome_device", "katgpu_synth_reads_device", "katgpu_parse_file", "katgpu_parse_files", "katgpu_free_host", "katgpu_strip_fastq", "katgpu_inflate_file",
     "katgpu_table_get_wide", "katgpu_table_export_wide", "katgpu_table_merge_host_wide",
     "katgpu_table_partition_wide", "katgpu_table_merge_device_wide", "katgpu_table_regrows",
     "katgpu_jf_load", "katgpu_jf_dump", "katgpu_jf_write_records", "katgpu_jf_read_records", "katgpu_jf_last_error",
@@ -169,6 +169,23 @@ def parse_file(path, trim5p=0):
     out = np.frombuffer(C.string_at(p, n.value), dtype=np.uint8).copy() if n.value else np.zeros(0, np.uint8)
     L.katgpu_free_host(p)
     return out
+
+
+def inflate_file(path, keep=True):
+    """katgpu_inflate_file: the bytes of one gzip stream, inflated by the thread team (kg_pgzip.cpp); keep=False: their number (the bytes are
+    inflated and checked, not kept).  Needs no GPU."""
+    L = load_library()
+    L.katgpu_inflate_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)]
+    p, n, msg = C.c_void_p(), C.c_size_t(), C.c_char_p()
+    rc = L.katgpu_inflate_file(os.fsencode(path), C.byref(p) if keep else None, C.byref(n), C.byref(msg))
+    if rc:
+        raise KatGpuError(rc, (msg.value or b"").decode(errors="replace"))
+    if not keep:
+        return n.value
+    try:
+        return C.string_at(p.value, n.value)
+    finally:
+        L.katgpu_free_host(p)
 
 
 def strip_fastq(data):

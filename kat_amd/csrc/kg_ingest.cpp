@@ -697,10 +697,11 @@ int stream_group(const char* const* paths, size_t n_paths, const uint16_t* trim5
     size_t i = 0;
     while (i < n_paths) {
         const uint32_t trim = trim5p ? trim5p[i] : 0;
-        if (team_applies(paths[i], trim) || bgzf_applies(paths[i])) {
-            // a large plain file or a BGZF file: its thread team (same bytes out as the streaming parser)
+        if (team_applies(paths[i], trim) || bgzf_applies(paths[i]) || pgz_applies(paths[i], trim)) {
+            // a large plain file, a BGZF file or one gzip stream of size: its thread team (same bytes out as the streaming parser)
             int rc = parse_file_parallel(paths[i], trim, sink, err);
             if (rc < 0) rc = parse_bgzf_parallel(paths[i], trim, sink, err);
+            if (rc < 0) rc = parse_gz_parallel(paths[i], trim, sink, err);
             if (rc > 0) return rc;
             if (rc < 0) { rc = stream_one(paths[i], trim, sink, err); if (rc) return rc; }    // it changed under us: stream it
             rc = sink(&sep, 1);
@@ -709,7 +710,7 @@ int stream_group(const char* const* paths, size_t n_paths, const uint16_t* trim5
             continue;
         }
         size_t j = i + 1;                                    // the run of streaming files that starts here
-        while (j < n_paths && !team_applies(paths[j], trim5p ? trim5p[j] : 0) && !bgzf_applies(paths[j])) ++j;
+        while (j < n_paths && !team_applies(paths[j], trim5p ? trim5p[j] : 0) && !bgzf_applies(paths[j]) && !pgz_applies(paths[j], trim5p ? trim5p[j] : 0)) ++j;
         const unsigned readers = (unsigned)std::min<size_t>(max_readers, j - i);
         int rc;
         if (readers <= 1) {
@@ -742,6 +743,7 @@ extern "C" int katgpu_parse_file(const char* path, uint32_t trim5p, uint8_t** ba
     auto collect = [&](const uint8_t* p, size_t got) { all.insert(all.end(), p, p + got); return 0; };
     int rc = kg::parse_file_parallel(path, trim5p, collect, &last);
     if (rc < 0) rc = kg::parse_bgzf_parallel(path, trim5p, collect, &last);
+    if (rc < 0) rc = kg::parse_gz_parallel(path, trim5p, collect, &last);
     if (rc < 0) {
         all.clear();
         kg::SeqFileParser parser;

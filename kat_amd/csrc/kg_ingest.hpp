@@ -96,6 +96,15 @@ bool team_applies(const char* path, uint32_t trim5p);      // would parse_file_p
 int parse_bgzf_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err);
 bool bgzf_applies(const char* path);
 
+// ONE ordinary gzip stream (what `gzip`, `pigz` and every sequencer's pipeline write) inflated by a thread team: kg_pgzip.cpp.  The
+// compressed file is cut into chunks; each is entered at a deflate block start found by search and decoded without its 32 KiB of
+// history (unknown bytes travel as markers), the chunks are stitched where a decoder ends exactly on the next one's entry, the
+// markers resolved in order, and the inflated chunks go through the state machine from guessed record starts, as parse_file_parallel's
+// pieces do.  Byte-identical to the streaming parser for any input (every guess is checked); CRC-32 / ISIZE of every member verified.
+// Returns a katgpu_status, or -1 when the file is not taken (not gzip, BGZF, small, 5' trim).
+int parse_gz_parallel(const char* path, uint32_t trim5p, const std::function<int(const uint8_t*, size_t)>& sink, std::string* err);
+bool pgz_applies(const char* path, uint32_t trim5p);
+
 // One input group (InputHandler::count's file list) -> the base stream the counter consumes, handed to `sink` piece by piece.
 // Files never join (mer_overlap_sequence_parser.hpp:151-155), so the stream is a sequence of file pieces with an 'N' wherever
 // the source changes.  Large plain files and BGZF files go through their thread teams, one file after the other.  Runs of files that have to
