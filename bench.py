@@ -94,6 +94,10 @@ def parse_args():
     ap.add_argument("--allow-shm", action="store_true", help="N > 1: let ranks on distinct devices stage the exchange through /dev/shm when RCCL cannot be had (the line says so)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` object (configs 2, 3 and 5's shard, 3 steps each) of the default run")
     ap.add_argument("--with-workloads", action="store_true", help="diagnostic / tests: the `workloads` object at a reduced size too (each capped at --reads / --genome)")
+    ap.add_argument("--no-e2e-gz", action="store_true", help="skip the .fastq.gz edition of the files -> output files leg")
+    ap.add_argument("--e2e-gz-reads", type=int, default=60_000_000, help="reads of the .fastq.gz edition, the first of the leg's own files (default: a fifth of config 4 -- writing the two .gz files at "
+                    "gzip's level 6 is what takes the time, ~1.4 s per million reads on the 16 CPUs a GPU box grants; 150000000, half of config 4: profiles/r06_e2e_gz.txt)")
+    ap.add_argument("--e2e-gz-level", type=int, default=6, help="deflate level of the .fastq.gz files (6: gzip's default)")
     ap.add_argument("--e2e-slice", action="store_true", help="files -> files on the --e2e-reads slice even when /dev/shm has room for the whole config")
     a = ap.parse_args()
     if a.config is not None:
@@ -223,6 +227,7 @@ def main():
     line, ok, what = measure(eng, a, ctx, want_cpu=True)
     all_ok = ok
     if rank == 0:
+        line["end_to_end_gz"] = e2e.pop("gz", None) if isinstance(e2e, dict) else None      # the same leg from .fastq.gz files (one gzip member each)
         line["end_to_end"] = e2e
     # ---- the other single-GPU configs of BASELINE.json, briefly, in the same line: configs 2, 3 and config 5's per-GPU shard ----
     if world == 1 and a.workload == "comp" and (a.default_size or a.with_workloads) and not a.no_workloads:
@@ -695,6 +700,126 @@ def parse_hist(path):
     return np.array(vals, dtype=np.uint64)
 
 
+def _gf2_times(mat, vec):
+    s, i = 0, 0
+    while vec:
+        if vec & 1:
+            s ^= mat[i]
+        vec >>= 1
+        i += 1
+    return s
+
+
+def crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (Python's zlib module does not export it): the CRC-32 of A + B from those of A and B and len(B)."""
+    if len2 <= 0:
+        return crc1
+    sq = lambda m: [_gf2_times(m, m[n]) for n in range(32)]
+    odd = [0xedb88320] + [1 << n for n in range(31)]
+    even = sq(odd)
+    odd = sq(even)
+    while True:
+        even = sq(odd)
+        if len2 & 1:
+            crc1 = _gf2_times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = sq(even)
+        if len2 & 1:
+            crc1 = _gf2_times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
+
+
+def effective_cpus():
+    """CPUs this process may really use: os.cpu_count() cut down to the affinity mask and to the cgroup's CPU quota (the GPU boxes show 256
+    CPUs; what a container gets of them is in cpu.max)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+_GZ_Q = None
+
+
+def _gz_quals(read_len):
+    global _GZ_Q
+    if _GZ_Q is None or _GZ_Q.shape[1] != read_len:
+        rng = np.random.default_rng(12345)
+        _GZ_Q = np.frombuffer(b"F:,#", np.uint8)[rng.choice(4, size=(4099, read_len), p=[0.86, 0.08, 0.04, 0.02])]
+    return _GZ_Q
+
+
+def _gz_block(job):
+    """One block of gzip_records_file, in a worker process: records [lo, hi) of the file deflated with the 32 KiB before them as dictionary."""
+    import zlib
+    src, n_records, rec_bytes, read_len, level, lo, hi = job
+    back = (32768 + rec_bytes - 1) // rec_bytes
+    lo0 = max(0, lo - back)
+    mm = np.memmap(src, dtype=np.uint8, mode="r", shape=(n_records, rec_bytes))
+    rec = np.array(mm[lo0:hi])
+    del mm
+    q0 = 14 + read_len + 3
+    rec[:, q0:q0 + read_len] = _gz_quals(read_len)[(np.arange(lo0, hi) * 2654435761 % 4099)]
+    raw = rec.reshape(-1).tobytes()
+    cut = (lo - lo0) * rec_bytes
+    data = memoryview(raw)[cut:]
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, raw[max(0, cut - 32768):cut]) if cut else zlib.compressobj(level, zlib.DEFLATED, -15, 9)
+    out = co.compress(data) + co.flush(zlib.Z_FINISH if hi == n_records else zlib.Z_SYNC_FLUSH)
+    return out, zlib.crc32(data), len(data)
+
+
+def gzip_records_file(src, dst, n_records, rec_bytes, read_len, level, workers, pool=None):
+    """The first n_records fixed-size FASTQ records of `src` as ONE gzip member in `dst`, the way pigz writes one: blocks of records
+    deflated by a pool of worker processes, each with the 32 KiB before it as its dictionary and closed by a sync flush, CRC-32s combined
+    -- a single deflate stream with copies across the block borders, no member boundaries to cut at.  Quality lines (write_fastq's are all
+    'I') are re-drawn from four symbols, as binned Illumina qualities are, so that the stream is not unrealistically compressible; no
+    reader looks at them.  Returns (compressed bytes, plain bytes)."""
+    import multiprocessing as mp
+    per_block = max(256, (16 << 20) // rec_bytes)
+    jobs = [(src, n_records, rec_bytes, read_len, level, lo, min(n_records, lo + per_block)) for lo in range(0, n_records, per_block)]
+    own = pool is None
+    if own:
+        pool = mp.get_context("forkserver").Pool(max(1, min(workers, len(jobs))))     # (not fork: this process has the HIP runtime's threads)
+    crc, total, written = 0, 0, 0
+    try:
+        with open(dst, "wb") as f:
+            hdr = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03"
+            f.write(hdr)
+            written += len(hdr)
+            for out, c, n in pool.imap(_gz_block, jobs, chunksize=1):
+                f.write(out)
+                written += len(out)
+                crc = crc32_combine(crc, c, n) if total else c
+                total += n
+            tail = (crc & 0xFFFFFFFF).to_bytes(4, "little") + (total & 0xFFFFFFFF).to_bytes(4, "little")
+            f.write(tail)
+            written += len(tail)
+    finally:
+        if own:
+            pool.close()
+            pool.join()
+    return written, total
+
+
 def end_to_end(eng, a, k, L):
     """Files -> output files through the C++ host binary (kat_amd/bin/katgpu, the mirror of KAT's drivers over the C ABI): the span of
     the reference's "Total runtime" (src/comp.cc:750; process start -> outputs closed, no plots).  At the workload's FULL size when
@@ -825,46 +950,131 @@ def end_to_end(eng, a, k, L):
         if os.environ.get("KATGPU_TRACE"):                 # diagnostic: the whole time line
             breakdown["trace"] = [l for l in pr.stderr.splitlines() if l.startswith("[katgpu")][:80]
         # ---- result_check: what the binary wrote against the same reads counted resident through the C ABI ----
-        check, detail = None, None
-        try:
-            g = eng.synth_genome(gs, seed=G_SEED)
-            r1 = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=R_SEED)
-            t1 = eng.table(k, True, size_hint=hint)
-            t1.count_bases_device(r1.ptr, r1.nbytes)
-            r1.free()
-            if wl in ("comp", "comp-rr"):
-                if wl == "comp":
-                    in2 = eng.synth_genome(gs, seed=G_SEED, contig_len=clen)
+        def resident_check(n, outp, inst):
+            check, detail = None, None
+            try:
+                g = eng.synth_genome(gs, seed=G_SEED)
+                r1 = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=R_SEED)
+                t1 = eng.table(k, True, size_hint=hint)
+                t1.count_bases_device(r1.ptr, r1.nbytes)
+                r1.free()
+                if wl in ("comp", "comp-rr"):
+                    if wl == "comp":
+                        in2 = eng.synth_genome(gs, seed=G_SEED, contig_len=clen)
+                    else:
+                        in2 = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=R2_SEED)
+                    t2 = eng.table(k, True, size_hint=hint2, like=t1)
+                    t2.count_bases_device(in2.ptr, in2.nbytes)
+                    in2.free()
+                    mx, cc, sp = kat_amd.comp(t1, t2)
+                    t2.free()
+                    got_cc = parse_stats(open(outp + ".stats").read())
+                    got_mx = parse_mx(outp + "-main.mx")
+                    ok_cc = [int(x) for x in cc] == got_cc
+                    ok_mx = got_mx.shape == mx.shape and bool(np.array_equal(got_mx, mx))
+                    check = ok_cc and ok_mx and int(cc[0]) + int(cc[1]) == inst
+                    detail = "out.stats: 13 counters %s the resident path's (hash1 total %d, distinct %d; hash2 total %d, distinct %d; shared distinct %d); out-main.mx: %dx%d body %s (sum %d); totals %s the %d instances written" % (
+                        "==" if ok_cc else "!=", got_cc[0], got_cc[3], got_cc[1], got_cc[4], got_cc[12], got_mx.shape[0], got_mx.shape[1] if got_mx.ndim == 2 else 0,
+                        "==" if ok_mx else "!=", int(got_mx.sum()), "==" if int(cc[0]) + int(cc[1]) == inst else "!=", inst)
+                elif wl == "hist":
+                    want = t1.hist()
+                    got = parse_hist(outp)
+                    check = got.shape == want.shape and bool(np.array_equal(got, want))
+                    detail = "hist file: %d bins %s the resident path's (distinct %d)" % (got.size, "==" if check else "!=", int(got.sum()))
                 else:
-                    in2 = eng.synth_reads(g, gs, first_read=0, n_reads=n, read_len=L, frag_len=350, err_ppm=a.err_ppm, seed=R2_SEED)
-                t2 = eng.table(k, True, size_hint=hint2, like=t1)
-                t2.count_bases_device(in2.ptr, in2.nbytes)
-                in2.free()
-                mx, cc, sp = kat_amd.comp(t1, t2)
-                t2.free()
-                got_cc = parse_stats(open(outp + ".stats").read())
-                got_mx = parse_mx(outp + "-main.mx")
-                ok_cc = [int(x) for x in cc] == got_cc
-                ok_mx = got_mx.shape == mx.shape and bool(np.array_equal(got_mx, mx))
-                check = ok_cc and ok_mx and int(cc[0]) + int(cc[1]) == inst
-                detail = "out.stats: 13 counters %s the resident path's (hash1 total %d, distinct %d; hash2 total %d, distinct %d; shared distinct %d); out-main.mx: %dx%d body %s (sum %d); totals %s the %d instances written" % (
-                    "==" if ok_cc else "!=", got_cc[0], got_cc[3], got_cc[1], got_cc[4], got_cc[12], got_mx.shape[0], got_mx.shape[1] if got_mx.ndim == 2 else 0,
-                    "==" if ok_mx else "!=", int(got_mx.sum()), "==" if int(cc[0]) + int(cc[1]) == inst else "!=", inst)
-            elif wl == "hist":
-                want = t1.hist()
-                got = parse_hist(outp)
-                check = got.shape == want.shape and bool(np.array_equal(got, want))
-                detail = "hist file: %d bins %s the resident path's (distinct %d)" % (got.size, "==" if check else "!=", int(got.sum()))
-            else:
-                want = t1.gcp()
-                got = parse_mx(outp + ".mx")
-                check = got.shape == want.shape and bool(np.array_equal(got, want))
-                detail = "gcp matrix: %s body %s the resident path's (sum %d)" % ("x".join(map(str, got.shape)), "==" if check else "!=", int(got.sum()))
-            t1.free()
-            g.free()
+                    want = t1.gcp()
+                    got = parse_mx(outp + ".mx")
+                    check = got.shape == want.shape and bool(np.array_equal(got, want))
+                    detail = "gcp matrix: %s body %s the resident path's (sum %d)" % ("x".join(map(str, got.shape)), "==" if check else "!=", int(got.sum()))
+                t1.free()
+                g.free()
+                eng.sync()
+            except Exception as ex:
+                check, detail = False, "check failed to run: %s: %s" % (type(ex).__name__, ex)
+            return check, detail
+        check, detail = resident_check(n, outp, inst)
+
+        # ---- the same run from .fastq.gz: what the reference reads every day (one zlib stream per file there: stream_manager.hpp:133-145) ----
+        def gz_leg():
+            import zlib
+            n_gz = min(n, a.e2e_gz_reads) & ~1
+            if n_gz < 2:
+                return None
+            import multiprocessing as mp
+            threads = max(1, min(effective_cpus(), 192))
+            t_c0 = time.perf_counter()
+            gz_paths, gz_bytes, plain_bytes = [], 0, 0
+            pool = mp.get_context("forkserver").Pool(threads)                   # (one pool for both files; not fork: this process has the HIP runtime's threads)
+            try:
+                for src in lib1:
+                    dst = src + ".gz"
+                    w, t = gzip_records_file(src, dst, n_gz // 2, rec_bytes, L, a.e2e_gz_level, threads, pool)
+                    gz_paths.append(dst)
+                    gz_bytes += w
+                    plain_bytes += t
+            finally:
+                pool.close()
+                pool.join()
+            t_comp = time.perf_counter() - t_c0
+            # one zlib stream on a bounded sample of the first file: what a single inflate thread does on this host
+            dco, got, t_z0 = zlib.decompressobj(31), 0, time.perf_counter()
+            with open(gz_paths[0], "rb") as f:
+                fed = 0
+                while fed < (192 << 20):
+                    piece = f.read(8 << 20)
+                    if not piece:
+                        break
+                    fed += len(piece)
+                    got += len(dco.decompress(piece))
+            t_z = time.perf_counter() - t_z0
             eng.sync()
-        except Exception as ex:
-            check, detail = False, "check failed to run: %s: %s" % (type(ex).__name__, ex)
+            eng.release_scratch()                           # (the resident check's tables and arena: the child process needs the device memory)
+            outg = os.path.join(tmp, "outgz")
+            inst_gz = n_gz * (L - k + 1) + (inst - n * (L - k + 1) if wl == "comp" else 0)
+            hint_gz = int(expected_distinct(n_gz * (L - k + 1), gs, k, a.err_ppm) / 0.62) + (1 << 20)
+            cmd_gz = [exe, tool, "-t", "16", "-m", str(k), "-H", str(hint_gz), "-o", outg]
+            if second is not None:
+                cmd_gz += ["-I", str(hint2), " ".join(gz_paths), second]
+            else:
+                cmd_gz += gz_paths
+            t_g0 = time.perf_counter()
+            pg = subprocess.run(cmd_gz, capture_output=True, text=True, timeout=1800, env=dict(os.environ, KATGPU_TIMING="1", KATGPU_TRACE="1"))
+            dt_gz = time.perf_counter() - t_g0
+            if pg.returncode != 0:
+                raise RuntimeError("katgpu %s on .gz inputs exited %d: %s" % (tool, pg.returncode, (pg.stderr or pg.stdout)[-400:]))
+            nonlocal hint
+            keep_hint, hint = hint, hint_gz
+            try:
+                ok, why = resident_check(n_gz, outg, inst_gz)
+            finally:
+                hint = keep_hint
+            teams = [l[:520] for l in pg.stderr.splitlines() if "one gzip stream" in l]
+            files = []
+            for line in pg.stderr.splitlines():
+                if line.startswith("katgpu_timing ") and '"file"' in line:
+                    try:
+                        rec = json.loads(line[len("katgpu_timing "):])
+                        files.append({"file": os.path.basename(rec["file"]), "wall_ms": rec.get("wall_ms"), "bytes": rec.get("bytes")})
+                    except ValueError:
+                        pass
+            gz_file_ms = sum(f_["wall_ms"] or 0.0 for f_ in files if f_["file"].endswith(".gz"))
+            one = fed / max(t_z, 1e-9) / 1e9
+            return {"seconds": round(dt_gz, 3), "value": round(inst_gz / dt_gz, 1), "unit": "k-mers/s", "result_check": ok, "result_check_detail": why,
+                    "config": "%d reads x %d bp as two .fastq.gz files (ONE gzip member each, pigz-shaped: deflate level %d, blocks that copy across their borders), %.1f GB compressed, %.1f GB of FASTQ%s" % (
+                        n_gz, L, a.e2e_gz_level, gz_bytes / 1e9, plain_bytes / 1e9, " + the %d bp FASTA assembly (plain)" % gs if wl == "comp" else ""),
+                    "compressed_GB_per_s_whole_run": round(gz_bytes / dt_gz / 1e9, 3),
+                    "compressed_GB_per_s_while_reading_the_gz_files": round(gz_bytes / max(gz_file_ms, 1e-3) / 1e6, 3) if gz_file_ms else None,
+                    "fastq_GB_per_s_while_reading_the_gz_files": round(plain_bytes / max(gz_file_ms, 1e-3) / 1e6, 3) if gz_file_ms else None,
+                    "one_zlib_stream_GB_per_s": {"compressed": round(one, 3), "fastq": round(got / max(t_z, 1e-9) / 1e9, 3), "sample": "the first %d MB of the first file through zlib.decompressobj, one thread" % (fed >> 20)},
+                    "times_one_zlib_stream": round(gz_bytes / max(gz_file_ms, 1e-3) / 1e6 / max(one, 1e-9), 1) if gz_file_ms else None,
+                    "files": files, "teams": teams[:4], "files_compressed_in_s": round(t_comp, 1), "compress_workers": threads, "cpus_usable": effective_cpus(), "cpus_shown": os.cpu_count(),
+                    **({"trace": [l[:300] for l in pg.stderr.splitlines() if l.startswith("[katgpu")][:120]} if os.environ.get("KATGPU_TRACE") else {})}
+        gz = None
+        if not a.no_e2e_gz and wl != "comp-rr":
+            try:
+                gz = gz_leg()
+            except Exception as ex:
+                gz = {"error": "%s: %s" % (type(ex).__name__, ex)}
         return {"value": round(inst / dt, 1), "config": ("the workload at FULL size" if full else "a slice of the workload") + ": %d reads x %d bp, %d bp genome" % (n * (2 if wl == "comp-rr" else 1), L, gs),
                 "full_size": bool(full), "result_check": check, "result_check_detail": detail,
                 "breakdown": breakdown, "inputs_in": tmp_root or tempfile.gettempdir(), "unit": "k-mers/s", "seconds": round(dt, 3), "input_bytes": nbytes,
@@ -873,7 +1083,8 @@ def end_to_end(eng, a, k, L):
                 "files_written_in_s": round(t_gen, 1),
                 "command": "katgpu %s -t 16 -m %d -H %d on %d reads x %d bp (2 FASTQ files%s)" % (
                     tool, k, hint, n, L, {"comp": " + a %d bp FASTA assembly" % gs, "comp-rr": " + a second library"}.get(wl, "")),
-                "outputs": sorted(outs), "phases": [l.strip() for l in pr.stdout.splitlines() if "Time taken" in l or "Total runtime" in l][:8]}
+                "outputs": sorted(outs), "phases": [l.strip() for l in pr.stdout.splitlines() if "Time taken" in l or "Total runtime" in l][:8],
+                "gz": gz}
     finally:
         for root, _, fs in os.walk(tmp, topdown=False):
             for f in fs:

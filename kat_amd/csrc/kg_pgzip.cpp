@@ -21,6 +21,7 @@
 #include "../../include/katgpu.h"
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -28,11 +29,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -47,6 +50,30 @@ uint64_t penv(const char* name, uint64_t def) {
     char* e = nullptr;
     const unsigned long long x = strtoull(v, &e, 10);
     return e && *e == 0 ? (uint64_t)x : def;
+}
+
+// CPUs this process may really use: the hardware's, cut down to the scheduler affinity and to the cgroup's CPU quota (a container
+// that shows 256 CPUs and is throttled to 16 CPU-seconds per second runs a team of 64 slower than a team of 12 -- and everything
+// beside the team slower still: measured, profiles/r06_pgz_host.txt)
+unsigned effective_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, (unsigned)c); }
+    auto quota = [&](const char* path_max, const char* path_q, const char* path_p) {
+        double q = -1, per = 100000;
+        if (FILE* f = fopen(path_max, "r")) {                   // cgroup v2: "max 100000" | "1600000 100000"
+            char a[64] = {0};
+            if (fscanf(f, "%63s %lf", a, &per) >= 1 && strcmp(a, "max") != 0) q = atof(a);
+            fclose(f);
+        } else if (FILE* f1 = fopen(path_q, "r")) {             // cgroup v1
+            if (fscanf(f1, "%lf", &q) != 1) q = -1;
+            fclose(f1);
+            if (FILE* f2 = fopen(path_p, "r")) { if (fscanf(f2, "%lf", &per) != 1) per = 100000; fclose(f2); }
+        }
+        if (q > 0 && per > 0) n = std::min(n, (unsigned)std::max(1.0, q / per + 0.5));
+    };
+    quota("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    return n;
 }
 
 // ------------------------------------------------------------------ bits ------------------------------------------------
@@ -213,19 +240,32 @@ const Codes& fixed_codes() {
 // ------------------------------------------------------------------ one chunk's output ----------------------------------
 constexpr uint32_t WIN = 32768;
 struct MemberEnd { uint64_t at; uint32_t crc, isize; };        // a member ends after `at` symbols of this chunk's output
-// a buffer that is not cleared when it grows (first touches of fresh memory serialise on the process's address space: the buffers are reused)
+// a buffer that is not cleared when it grows: anonymous memory the kernel is asked to back with huge pages (first touches of fresh
+// memory serialise on the process's address space -- 512 times fewer of them --; the buffers are reused besides)
 template <class T> struct Raw {
     T* p = nullptr; size_t cap = 0;
     Raw() = default;
     Raw(Raw&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
-    Raw& operator=(Raw&& o) noexcept { if (this != &o) { free(p); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    Raw& operator=(Raw&& o) noexcept { if (this != &o) { drop(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
     Raw(const Raw&) = delete; Raw& operator=(const Raw&) = delete;
-    ~Raw() { free(p); }
+    ~Raw() { drop(); }
+    void drop() { if (p) munmap((void*)p, bytes_of(cap)); p = nullptr; cap = 0; }
+    static size_t bytes_of(size_t n) { return (n * sizeof(T) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); }
     T* data() { return p; }
     const T* data() const { return p; }
     size_t size() const { return cap; }
     size_t capacity() const { return cap; }
-    bool reserve(size_t n) { if (n <= cap) return true; T* q = (T*)realloc(p, n * sizeof(T)); if (!q) return false; p = q; cap = n; return true; }
+    bool reserve(size_t n, size_t keep = ~(size_t)0) {          // keep: how many elements are worth copying
+        if (n <= cap) return true;
+        const size_t bytes = bytes_of(n);
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) return false;
+        static const bool huge = penv("KATGPU_PGZ_HUGE", 1) != 0;
+        if (huge) madvise(m, bytes, MADV_HUGEPAGE);
+        if (p) { memcpy(m, p, std::min(keep, cap) * sizeof(T)); munmap((void*)p, bytes_of(cap)); }
+        p = (T*)m; cap = bytes / sizeof(T);
+        return true;
+    }
     T& operator[](size_t i) { return p[i]; }
 };
 struct Out {
@@ -234,7 +274,7 @@ struct Out {
     int64_t floor = 0;             // no copy may reach below this index (the member's first byte; -WIN while the history is the unknown window)
     std::vector<MemberEnd> members;
     bool oom = false;
-    void room(size_t more) { if (v.size() < n + more && !v.reserve(std::max<size_t>(v.size() + v.size() / 2, n + more + (1 << 20)))) oom = true; }
+    void room(size_t more) { if (v.size() < n + more && !v.reserve(std::max<size_t>(v.size() + v.size() / 2, n + more + (1 << 20)), n)) oom = true; }
 };
 enum Stop { S_BLOCK_END, S_ERROR };
 
@@ -473,8 +513,37 @@ struct Inflater {
             cv.notify_all();
         }
     }
-    void start(unsigned T) { for (unsigned i = 0; i < T; ++i) workers.emplace_back([this] { work(); }); }
-    void stop() { { std::lock_guard<std::mutex> g(mu); quit.store(true); } cv.notify_all(); for (auto& t : workers) t.join(); workers.clear(); }
+    // the chunks' second jobs (markers -> bytes, CRC, parse): threads of their own that stay (a thread per job would map and unmap a stack
+    // each time, behind every page fault of the team)
+    std::mutex job_mu; std::condition_variable job_cv; std::deque<std::function<void()>> job_q; std::vector<std::thread> job_threads; bool job_quit = false;
+    void job_loop() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(job_mu);
+                job_cv.wait(lk, [&] { return job_quit || !job_q.empty(); });
+                if (job_q.empty()) return;
+                f = std::move(job_q.front());
+                job_q.pop_front();
+            }
+            f();
+        }
+    }
+    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> g(job_mu); job_q.push_back(std::move(f)); } job_cv.notify_one(); }
+    void start(unsigned T) {
+        for (unsigned i = 0; i < T; ++i) workers.emplace_back([this] { work(); });
+        for (unsigned i = 0; i < T / 2 + 1; ++i) job_threads.emplace_back([this] { job_loop(); });
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> g(mu); quit.store(true); }
+        cv.notify_all();
+        for (auto& t : workers) t.join();
+        workers.clear();
+        { std::lock_guard<std::mutex> g(job_mu); job_quit = true; }
+        job_cv.notify_all();
+        for (auto& t : job_threads) t.join();
+        job_threads.clear();
+    }
     void wait_done(size_t j) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return chunks[j].done.load(std::memory_order_acquire) != 0; }); }
     void move_horizon(size_t h) { { std::lock_guard<std::mutex> g(mu); if (h > horizon.load()) horizon.store(h); } cv.notify_all(); }
 };
@@ -496,11 +565,114 @@ struct Mapped {
     }
 };
 
+// CRC-32 (the gzip polynomial) by carry-less multiplication where the host has it: four 128-bit lanes folded per 64 bytes, then 128 -> 64 ->
+// 32 bits with a Barrett reduction (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ", Intel 2009; the
+// constants are x^(64 k) mod P for the fold distances, P's bit-reflected form).  zlib 1.2.11's table walk does ~1 GB/s per thread --
+// as much time as inflating the bytes; this does ~10.  Checked against zlib's at start-up: a host where it disagrees keeps zlib's.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("pclmul,sse4.1")))
+uint32_t crc32_clmul(const uint8_t* buf, size_t len /* a multiple of 16, >= 64 */, uint32_t crc) {
+    static const uint64_t __attribute__((aligned(16))) k1k2[] = {0x0154442bd4ULL, 0x01c6e41596ULL};
+    static const uint64_t __attribute__((aligned(16))) k3k4[] = {0x01751997d0ULL, 0x00ccaa009eULL};
+    static const uint64_t __attribute__((aligned(16))) k5k0[] = {0x0163cd6124ULL, 0x0000000000ULL};
+    static const uint64_t __attribute__((aligned(16))) poly[] = {0x01db710641ULL, 0x01f7011641ULL};
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i*)(buf + 0x00));
+    x2 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i*)(buf + 0x20));
+    x4 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    x0 = _mm_load_si128((const __m128i*)k1k2);
+    buf += 64; len -= 64;
+    while (len >= 64) {
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i*)(buf + 0x00)); y6 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i*)(buf + 0x20)); y8 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7); x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64; len -= 64;
+    }
+    x0 = _mm_load_si128((const __m128i*)k3k4);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16) {
+        x2 = _mm_loadu_si128((const __m128i*)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; len -= 16;
+    }
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64((const __m128i*)k5k0);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, x3);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_load_si128((const __m128i*)poly);
+    x2 = _mm_and_si128(x1, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+bool clmul_ok() {
+    static const bool ok = [] {
+        if (!__builtin_cpu_supports("pclmul") || !__builtin_cpu_supports("sse4.1")) return false;
+        uint8_t t[1024 + 16];
+        for (size_t i = 0; i < sizeof t; ++i) t[i] = (uint8_t)(i * 131 + (i >> 3) * 7 + 5);
+        for (size_t len : {(size_t)64, (size_t)80, (size_t)512, (size_t)1024}) {
+            const uint32_t seed = 0x12345678u ^ (uint32_t)len;
+            if (~crc32_clmul(t + 1, len, ~seed) != (uint32_t)crc32(seed, t + 1, (uInt)len)) return false;
+        }
+        return true;
+    }();
+    return ok;
+}
+#else
+bool clmul_ok() { return false; }
+uint32_t crc32_clmul(const uint8_t*, size_t, uint32_t c) { return c; }
+#endif
+// crc32(crc, p, n) of zlib, faster
+uint32_t fast_crc32(uint32_t crc, const uint8_t* p, size_t n) {
+    if (n >= 256 && clmul_ok()) {
+        const size_t body = n & ~(size_t)15;
+        crc = ~crc32_clmul(p, body, ~crc);
+        p += body; n -= body;
+    }
+    for (; n; ) { const uInt m = (uInt)std::min<size_t>(n, (size_t)1 << 30); crc = (uint32_t)crc32(crc, p, m); p += m; n -= m; }
+    return crc;
+}
+
 // markers -> bytes with the WIN bytes before the chunk (win[WIN - have, WIN) are known)
 bool translate(const uint16_t* v, uint64_t n, const uint8_t* win, uint32_t have, uint8_t* out) {
     const uint32_t lo = 256 + (WIN - have);
     uint32_t bad = 0;
-    for (uint64_t i = 0; i < n; ++i) {
+    uint64_t i = 0;
+    for (; i + 8 <= n; i += 8) {                                 // eight symbols at a time: past a chunk's first tens of KB hardly any is a marker
+        uint64_t a, b;
+        memcpy(&a, v + i, 8);
+        memcpy(&b, v + i + 4, 8);
+        if (((a | b) & 0xFF00FF00FF00FF00ULL) == 0) {
+            a = (a | (a >> 8)) & 0x0000FFFF0000FFFFULL; a = (a | (a >> 16)) & 0xFFFFFFFFULL;
+            b = (b | (b >> 8)) & 0x0000FFFF0000FFFFULL; b = (b | (b >> 16)) & 0xFFFFFFFFULL;
+            const uint64_t w = a | (b << 32);
+            memcpy(out + i, &w, 8);
+            continue;
+        }
+        for (unsigned q = 0; q < 8; ++q) {
+            const uint32_t s = v[i + q];
+            if (s < 256) out[i + q] = (uint8_t)s;
+            else { bad |= s < lo; out[i + q] = win[s - 256]; }
+        }
+    }
+    for (; i < n; ++i) {
         const uint32_t s = v[i];
         if (s < 256) out[i] = (uint8_t)s;
         else { bad |= s < lo; out[i] = win[s - 256]; }
@@ -538,20 +710,22 @@ bool pgz_applies(const char* path, uint32_t trim5p) {
 }
 
 // The inflated file, chunk by chunk in order, to `on_piece(piece, window of the bytes before it)`; parse_type NONE: bytes only.
-static int inflate_team(const char* path, bool parse, const std::function<int(Piece&)>& on_piece, std::string* err) {
+static int inflate_team(const char* path, bool parse, const std::function<int(Piece&, std::string*)>& on_piece, std::string* err) {
     Mapped f;
     if (!f.open(path)) return -1;
     const size_t data0 = gzip_header(f.d, f.size, 0);
     if (!data0) return -1;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(penv("KATGPU_PGZ_THREADS", std::min(hw, 64u)), 256));
+    // decoders; their second jobs take about a third of a decoder's time per chunk (start(): T / 2 + 1 threads); the walk and what
+    // takes the pieces are two more
+    const unsigned cpus = effective_cpus();
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(penv("KATGPU_PGZ_THREADS", std::min(32u, std::max(2u, cpus > 6 ? (cpus - 2) * 2 / 3 : cpus / 2))), 256));
     Inflater inf;
     inf.d = f.d; inf.size = f.size;
     inf.CB = (size_t)std::max<uint64_t>(1 << 16, penv("KATGPU_PGZ_CHUNK", (uint64_t)4 << 20));
     inf.n_chunks = (f.size + inf.CB - 1) / inf.CB;
     inf.chunks.reset(new Chunk[inf.n_chunks]);
     inf.chunks[0].sync = (uint64_t)data0 * 8; inf.chunks[0].sync_known.store(1); inf.chunks[0].known_start = true;
-    const size_t ahead = 2 * (size_t)T + 4;
+    const size_t ahead = (size_t)T + 4;                          // (chunks in flight: every one owns tens of MB of buffers -- few enough that they are reused early)
     inf.move_horizon(ahead);
     inf.start(T);
     struct Stopper { Inflater& i; ~Stopper() { i.stop(); } } stopper{inf};
@@ -561,20 +735,57 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
     std::vector<uint8_t> window(WIN, 0);
     uint32_t have = 0;                                          // known bytes at the window's end (a member's first WIN bytes have less history)
     ParseState::Type ptype = ParseState::NONE;
+    // The pieces, in order, to whoever takes them -- on a thread of its own: what takes them (the state machine between the chunks' cuts,
+    // the sink's copy towards the device, its waits for the counter) must not hold up the walk that lets the decoders on.
     std::deque<std::future<std::unique_ptr<Piece>>> jobs;
+    std::mutex jq_mu; std::condition_variable jq_cv;
+    bool jq_closed = false;
+    std::atomic<int> drain_rc{KATGPU_OK};
+    std::string drain_err;
     size_t live = 0, dropped = 0;
     int rc = KATGPU_OK;
-    auto finish_front = [&]() -> int {
-        std::unique_ptr<Piece> p = jobs.front().get();
-        jobs.pop_front();
-        if (p->bad_window) { *err = std::string("read error on ") + path; return KATGPU_ERR_IO; }
-        const int r = on_piece(*p);
-        inf.put_bytes(std::move(p->buf));
-        return r;
+    double t_job = 0, t_piece = 0, t_full = 0;
+    const size_t max_jobs = 2 * (size_t)T + 4;
+    auto clock_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::thread drain([&] {
+        for (;;) {
+            std::future<std::unique_ptr<Piece>> f;
+            {
+                std::unique_lock<std::mutex> lk(jq_mu);
+                jq_cv.wait(lk, [&] { return jq_closed || !jobs.empty(); });
+                if (jobs.empty()) return;
+                f = std::move(jobs.front());
+                jobs.pop_front();
+            }
+            jq_cv.notify_all();
+            const double t0 = clock_ms();
+            std::unique_ptr<Piece> p = f.get();
+            const double t1 = clock_ms();
+            t_job += t1 - t0;
+            if (drain_rc.load() == KATGPU_OK) {                  // (after an error the rest is only waited for)
+                if (p->bad_window) { drain_err = std::string("read error on ") + path; drain_rc.store(KATGPU_ERR_IO); }
+                else {
+                    std::string e;
+                    const int r = on_piece(*p, &e);
+                    if (r) { drain_err = e; drain_rc.store(r); }
+                }
+            }
+            inf.put_bytes(std::move(p->buf));
+            t_piece += clock_ms() - t1;
+        }
+    });
+    auto close_drain = [&] {
+        { std::lock_guard<std::mutex> g(jq_mu); jq_closed = true; }
+        jq_cv.notify_all();
+        if (drain.joinable()) drain.join();
     };
+    struct DrainGuard { std::function<void()> f; ~DrainGuard() { f(); } } drain_guard{close_drain};
     int64_t j = 0;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double ms_wait_decode = 0, ms_wait_job = 0, ms_piece = 0, ms_launch = 0;
+    const double t_start = now_ms();
     while (j >= 0) {
-        inf.wait_done((size_t)j);
+        { const double t0 = now_ms(); inf.wait_done((size_t)j); ms_wait_decode += now_ms() - t0; }
         Chunk& c = inf.chunks[(size_t)j];
         if (c.error || c.next_live == -2) { *err = std::string("read error on ") + path; rc = KATGPU_ERR_IO; break; }
         ++live;
@@ -585,6 +796,7 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
             if (ptype == ParseState::NONE) { *err = "Unsupported format"; rc = KATGPU_ERR_FORMAT; break; }
         }
         // the job: markers -> bytes with a copy of the window as it stands; CRCs; the state machine between the guessed cuts
+        const double t_l0 = now_ms();
         auto win = std::make_shared<std::vector<uint8_t>>(window);
         const uint32_t have_now = have;
         std::shared_ptr<Out> op(new Out(std::move(o)));
@@ -608,10 +820,10 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
             have = nhave;
         }
         Inflater* infp = &inf;
-        jobs.push_back(std::async(std::launch::async, [op, win, have_now, ptype, verify, infp]() {
+        auto task = std::make_shared<std::packaged_task<std::unique_ptr<Piece>()>>([op, win, have_now, ptype, verify, infp]() {
             std::unique_ptr<Piece> p(new Piece);
             p->buf = infp->get_bytes();
-            if (!p->buf.reserve(op->n + 64)) { p->bad_window = true; return p; }
+            if (!p->buf.reserve(std::max<size_t>(op->n + 64, infp->CB * 5), 0)) { p->bad_window = true; return p; }      // (with room to spare: the next chunk it serves is a little larger as often as not)
             p->n_bytes = op->n;
             p->bytes = Piece::View{p->buf.data(), p->n_bytes};
             p->bad_window = !translate(op->v.data(), op->n, win->data(), have_now, p->buf.data());
@@ -622,9 +834,7 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
                 uint64_t a = 0;
                 for (size_t m = 0; m <= p->members.size(); ++m) {
                     const uint64_t e = m < p->members.size() ? p->members[m].at : p->bytes.size();
-                    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-                    for (uint64_t q = a; q < e; q += (uint64_t)1 << 30) crc = (uint32_t)crc32(crc, p->bytes.data() + q, (uInt)std::min<uint64_t>((uint64_t)1 << 30, e - q));
-                    p->crcs.push_back(crc);
+                    p->crcs.push_back(fast_crc32((uint32_t)crc32(0L, Z_NULL, 0), p->bytes.data() + a, (size_t)(e - a)));
                     a = e;
                 }
             }
@@ -643,16 +853,28 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
                 }
             }
             return p;
-        }));
+        });
+        {
+            const double t0 = clock_ms();
+            std::unique_lock<std::mutex> lk(jq_mu);
+            jq_cv.wait(lk, [&] { return jobs.size() < max_jobs; });
+            t_full += clock_ms() - t0;
+            jobs.push_back(task->get_future());
+        }
+        jq_cv.notify_all();
+        inf.submit([task] { (*task)(); });
+        ms_launch += now_ms() - t_l0;
         if (c.next_live > j + 1) dropped += (size_t)(c.next_live - j - 1);      // (chunks passed over: what their decoders make is never looked at)
         j = c.next_live;
         inf.move_horizon((size_t)(j < 0 ? inf.n_chunks : j) + ahead);
-        while (jobs.size() > (size_t)T + 2) { rc = finish_front(); if (rc) break; }
-        if (rc) break;
+        if (drain_rc.load() != KATGPU_OK) break;
     }
-    while (!rc && !jobs.empty()) rc = finish_front();
-    for (auto& jb : jobs) if (jb.valid()) jb.wait();
-    if (trace) fprintf(stderr, "[katgpu] ingest %s: one gzip stream, %zu chunk(s) of %zu MB by a team of %u, %zu passed over\n", path, live, inf.CB >> 20, T, dropped);
+    close_drain();                                              // every piece handed over has been taken (or waited for)
+    if (!rc && drain_rc.load() != KATGPU_OK) { rc = drain_rc.load(); *err = drain_err; }
+    ms_wait_job = t_job; ms_piece = t_piece;
+    if (trace) fprintf(stderr, "[katgpu] ingest %s: one gzip stream, %zu chunk(s) of %zu MB by a team of %u (%u CPUs to use), %zu passed over, CRC-32 by %s; %.0f ms: the walk waited %.0f ms for decoders and %.0f ms for room behind it, spent %.0f ms handing chunks to their second jobs; "
+                               "behind it %.0f ms were waits for those jobs and %.0f ms went into what takes the pieces\n", path, live, inf.CB >> 20, T, cpus, dropped, !verify ? "nobody" : clmul_ok() ? "carry-less multiplication" : "zlib", now_ms() - t_start,
+                       ms_wait_decode, t_full, ms_launch, ms_wait_job, ms_piece);
     return rc;
 }
 
@@ -674,7 +896,7 @@ int parse_gz_parallel(const char* path, uint32_t trim5p, const std::function<int
         if (!out.empty()) { const int rc = sink(out.data(), out.size()); if (rc) { err->clear(); return rc; } }
         return KATGPU_OK;
     };
-    const int rc = inflate_team(path, true, [&](Piece& p) -> int {
+    auto take = [&](Piece& p) -> int {
         if (verify) {                                           // every member's CRC-32 and length, as zlib checks them
             uint64_t a = 0;
             for (size_t m = 0; m <= p.members.size(); ++m) {
@@ -701,7 +923,8 @@ int parse_gz_parallel(const char* path, uint32_t trim5p, const std::function<int
             return serial(p.bytes.data() + p.s, n - (size_t)p.s);           // it does not (or the piece is bad: the machine words the error)
         }
         return serial(p.bytes.data(), n);
-    }, err);
+    };
+    const int rc = inflate_team(path, true, [&](Piece& p, std::string* e_out) -> int { const int r = take(p); if (r) *e_out = *err; return r; }, err);
     if (rc) return rc;
     if (begun && !state.end_ok()) { *err = "Invalid fastq sequence"; return KATGPU_ERR_FASTQ; }
     return KATGPU_OK;
@@ -722,7 +945,7 @@ extern "C" int katgpu_inflate_file(const char* path, uint8_t** out, size_t* n, c
     uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
     uint64_t member_bytes = 0;
     bool crc_bad = false;
-    const int rc = kg::inflate_team(path, false, [&](kg::Piece& p) -> int {
+    const int rc = kg::inflate_team(path, false, [&](kg::Piece& p, std::string*) -> int {
         uint64_t a = 0;
         for (size_t m = 0; m <= p.members.size() && !p.crcs.empty(); ++m) {
             const uint64_t e = m < p.members.size() ? p.members[m].at : p.bytes.size();

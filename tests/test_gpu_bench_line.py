@@ -26,7 +26,7 @@ def _bench(args, env_extra=None, timeout=900):
 
 
 def test_single_gpu_line_carries_workloads_and_a_checked_end_to_end_leg():
-    line = _bench(SMALL + ["--e2e-reads", "2000000", "--with-workloads"])
+    line = _bench(SMALL + ["--e2e-reads", "2000000", "--with-workloads"], {"KATGPU_PGZ_CHUNK": str(1 << 20)})
     assert line["result_accounts_for_every_kmer"] and line["n_gpus"] == 1 and line["scaling"] == "weak"
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
     e = line["end_to_end"]
@@ -35,6 +35,10 @@ def test_single_gpu_line_carries_workloads_and_a_checked_end_to_end_leg():
     # (--reads 2000000 IS this run's whole workload, and it fits /dev/shm: the leg runs it at full size and says so)
     assert e["full_size"] is True and "FULL size" in e["config"] and e["kmer_instances"] == 2000000 * 124 + (5000000 - 5 * 26)
     assert e["breakdown"]["unparsable_timing_lines"] == 0
+    z = line["end_to_end_gz"]                                                 # the same run from two .fastq.gz files, one gzip member each, inflated by the team
+    assert z.get("error") is None, z
+    assert z["result_check"] is True, z["result_check_detail"]
+    assert len(z["teams"]) == 2 and all("one gzip stream" in t for t in z["teams"]) and z["compressed_GB_per_s_whole_run"] > 0, z
     w = line["workloads"]
     assert sorted(w) == ["comp-rr", "gcp", "hist"]
     for name, x in w.items():
