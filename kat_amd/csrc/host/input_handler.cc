@@ -80,6 +80,7 @@ static katgpu_table* g_pending = nullptr;                                   // t
 void Engine::finishPending() { if (g_pending) { katgpu_table* t = g_pending; g_pending = nullptr; check(katgpu_exchange_finish(comm(), t)); } }
 void Engine::exchange(katgpu_table* t) { if (dist_) { finishPending(); check(katgpu_exchange_merge(comm(), t)); } }
 void Engine::exchangeBegin(katgpu_table* t) { if (dist_) { finishPending(); check(katgpu_exchange_begin(comm(), t)); g_pending = t; } }
+void Engine::barrier() { if (dist_) { finishPending(); check(katgpu_comm_barrier(comm())); } }
 void Engine::allreduce(uint64_t* buf, size_t n) { if (dist_) { finishPending(); check(katgpu_allreduce_u64(comm(), buf, n)); } }
 
 void Engine::shutdown() {
@@ -225,21 +226,65 @@ void InputHandler::validateMerLen(uint16_t expected) {                      // l
                                  ".  Key length was " + std::to_string(katgpu_table_k(hash)) + " for : " + input[0]);
 }
 
+// --gpus N: every rank holds the k-mers it owns.  The ranks are processes of one node (kat_main.cc forks them): the others leave their
+// records in a file beside the output, rank 0 puts them together with its own and writes the one sorted .jf the reference writes.
+static int dump_gathered(katgpu_table* hash, const std::string& outputPath) {
+    const int rank = Engine::rank(), world = Engine::world();
+    const bool wide = katgpu_table_k(hash) > 32;
+    size_t n = 0;
+    int rc = wide ? katgpu_table_export_wide(hash, nullptr, nullptr, nullptr, 0, &n) : katgpu_table_export(hash, nullptr, nullptr, 0, &n);
+    if (rc) return rc;
+    std::vector<uint64_t> hi(wide ? std::max<size_t>(n, 1) : 0), lo(std::max<size_t>(n, 1)), counts(std::max<size_t>(n, 1));
+    if (n) rc = wide ? katgpu_table_export_wide(hash, hi.data(), lo.data(), counts.data(), n, &n) : katgpu_table_export(hash, lo.data(), counts.data(), n, &n);
+    if (rc) return rc;
+    lo.resize(n); counts.resize(n);
+    if (wide) hi.resize(n);
+    auto part = [&](int r) { return outputPath + ".rank" + std::to_string(r) + ".part"; };
+    int io_bad = 0;
+    if (rank != 0) {
+        FILE* f = fopen(part(rank).c_str(), "wb");
+        const uint64_t n64 = n;
+        io_bad = !f || fwrite(&n64, 8, 1, f) != 1 || (wide && n && fwrite(hi.data(), 8, n, f) != n) || (n && fwrite(lo.data(), 8, n, f) != n) || (n && fwrite(counts.data(), 8, n, f) != n);
+        if (f && fclose(f) != 0) io_bad = 1;
+    }
+    Engine::barrier();                                                      // every part is on disk
+    if (rank == 0) {
+        for (int r = 1; r < world && !io_bad; ++r) {
+            FILE* f = fopen(part(r).c_str(), "rb");
+            uint64_t m = 0;
+            if (!f || fread(&m, 8, 1, f) != 1) { io_bad = 1; if (f) fclose(f); break; }
+            const size_t at = n;
+            if (wide) hi.resize(at + m);
+            lo.resize(at + m); counts.resize(at + m);
+            io_bad = (wide && m && fread(hi.data() + at, 8, m, f) != m) || (m && fread(lo.data() + at, 8, m, f) != m) || (m && fread(counts.data() + at, 8, m, f) != m);
+            fclose(f);
+            n = at + m;
+        }
+        for (int r = 1; r < world; ++r) unlink(part(r).c_str());
+        if (!io_bad) rc = wide ? katgpu_jf_write_records_wide(outputPath.c_str(), katgpu_table_k(hash), katgpu_table_canonical(hash), hi.data(), lo.data(), counts.data(), n)
+                               : katgpu_jf_write_records(outputPath.c_str(), katgpu_table_k(hash), katgpu_table_canonical(hash), lo.data(), counts.data(), n);
+    }
+    uint64_t bad = (uint64_t)(io_bad || rc);
+    Engine::allreduce(&bad, 1);                                             // (and nobody leaves before rank 0 has read the parts)
+    if (bad) throw FileSystemException("Could not gather the ranks' k-mers for " + outputPath);
+    return KATGPU_OK;
+}
+
 void InputHandler::dump(const std::string& outputPath, uint16_t threads) {  // lib/src/input_handler.cc:221-243
     (void)threads;
     struct stat st;
-    if (lstat(outputPath.c_str(), &st) == 0) unlink(outputPath.c_str());
+    if (Engine::speaker() && lstat(outputPath.c_str(), &st) == 0) unlink(outputPath.c_str());
     if (mode == COUNT) {
         auto t0 = std::chrono::steady_clock::now();
         std::cout << "Dumping hash to " << outputPath << " ...";
         std::cout.flush();
-        int rc = katgpu_jf_dump(hash, outputPath.c_str());
+        int rc = Engine::dist() && Engine::world() > 1 ? dump_gathered(hash, outputPath) : katgpu_jf_dump(hash, outputPath.c_str());
         if (rc) throw JellyfishException(*katgpu_jf_last_error() ? katgpu_jf_last_error() : katgpu_last_error(Engine::ctx()));
         std::cout << " done.";
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         char buf[64]; snprintf(buf, sizeof buf, "  Time taken: %.1fs\n\n", s);
         std::cout << buf;
-    } else if (symlink(getSingleInput().c_str(), outputPath.c_str()) != 0) {
+    } else if (Engine::speaker() && symlink(getSingleInput().c_str(), outputPath.c_str()) != 0) {
         throw FileSystemException("Could not create symlink " + outputPath);
     }
 }

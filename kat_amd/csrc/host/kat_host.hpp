@@ -75,6 +75,7 @@ public:
     static void exchangeBegin(katgpu_table* t);     // the same in two steps: the table's records travel while the caller counts its next input ...
     static void finishPending();                    // ... and are applied here (katgpu_exchange_begin / _finish); every other collective finishes it first
     static void allreduce(uint64_t* buf, size_t n); // idem
+    static void barrier();                          // idem
 private:
     static int rank_, world_;
     static bool dist_;

@@ -51,7 +51,6 @@ void Histogram::execute() {                                                     
     else { input.loadHeader(); input.loadHash(); }
     data.assign(nb_buckets, 0);
     bin();
-    if (input.dumpHash && Engine::dist() && Engine::world() > 1) throw OptionError("-d (dump hash) cannot be combined with --gpus > 1: every rank holds only the k-mers it owns");
     if (input.dumpHash) input.dump(outputPrefix + "-hash.jf" + std::to_string(input.merLen), threads);      // :105-108
     // merge(): nothing to do -- the device reduces into one array (the reference sums T per-thread histograms, :146-160)
 }
@@ -132,7 +131,6 @@ void Gcp::execute() {                                                           
     // header->key_len() / 2 rows == k rows: GC count == k has no row (src/gcp.cc:93)
     gcp_mx = Matrix64(katgpu_table_k(input.hash), (uint32_t)cvgBins + 1);
     analyse();
-    if (input.dumpHash && Engine::dist() && Engine::world() > 1) throw OptionError("-d (dump hash) cannot be combined with --gpus > 1: every rank holds only the k-mers it owns");
     if (input.dumpHash) input.dump(outputPrefix + "-hash.jf" + std::to_string(input.merLen), threads);      // :102-105
 }
 
@@ -244,7 +242,6 @@ void Comp::execute() {                                                          
     if (allLoad) setMerLen((uint8_t)katgpu_table_k(input[0].hash));
     for (size_t i = 0; i < inputSize(); i++) input[i].validateMerLen(getMerLen());
     compare();
-    if (input[0].dumpHash && Engine::dist() && Engine::world() > 1) throw OptionError("-d (dump hashes) cannot be combined with --gpus > 1: every rank holds only the k-mers it owns");
     if (input[0].dumpHash)                                       // :174-179
         for (size_t i = 0; i < inputSize(); i++)
             input[i].dump(outputPrefix + "-hash" + std::to_string(input[i].index) + ".jf" + std::to_string(getMerLen()), threads);

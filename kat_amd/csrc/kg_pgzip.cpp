@@ -499,50 +499,33 @@ struct Inflater {
         }
     }
 
+    // One team for both kinds of work: a thread takes a chunk's second job (markers -> bytes, CRC, parse) if one waits -- they free
+    // buffers and let the walk on -- and the next chunk to decode otherwise: whatever the two cost against each other, every CPU is busy.
+    std::deque<std::function<void()>> job_q;
     void work() {
         for (;;) {
-            size_t j;
+            std::function<void()> f;
+            size_t j = ~(size_t)0;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return quit.load() || (next_chunk.load() < n_chunks && next_chunk.load() < horizon.load()); });
-                if (quit.load()) return;
-                j = next_chunk.fetch_add(1);
+                cv.wait(lk, [&] { return quit.load() || !job_q.empty() || (next_chunk.load() < n_chunks && next_chunk.load() < horizon.load()); });
+                if (!job_q.empty()) { f = std::move(job_q.front()); job_q.pop_front(); }
+                else if (quit.load()) return;
+                else j = next_chunk.fetch_add(1);
             }
+            if (f) { f(); continue; }
             decode(j);
             { std::lock_guard<std::mutex> g(mu); chunks[j].done.store(1, std::memory_order_release); }
             cv.notify_all();
         }
     }
-    // the chunks' second jobs (markers -> bytes, CRC, parse): threads of their own that stay (a thread per job would map and unmap a stack
-    // each time, behind every page fault of the team)
-    std::mutex job_mu; std::condition_variable job_cv; std::deque<std::function<void()>> job_q; std::vector<std::thread> job_threads; bool job_quit = false;
-    void job_loop() {
-        for (;;) {
-            std::function<void()> f;
-            {
-                std::unique_lock<std::mutex> lk(job_mu);
-                job_cv.wait(lk, [&] { return job_quit || !job_q.empty(); });
-                if (job_q.empty()) return;
-                f = std::move(job_q.front());
-                job_q.pop_front();
-            }
-            f();
-        }
-    }
-    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> g(job_mu); job_q.push_back(std::move(f)); } job_cv.notify_one(); }
-    void start(unsigned T) {
-        for (unsigned i = 0; i < T; ++i) workers.emplace_back([this] { work(); });
-        for (unsigned i = 0; i < T / 2 + 1; ++i) job_threads.emplace_back([this] { job_loop(); });
-    }
-    void stop() {
+    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> g(mu); job_q.push_back(std::move(f)); } cv.notify_all(); }
+    void start(unsigned T) { for (unsigned i = 0; i < T; ++i) workers.emplace_back([this] { work(); }); }
+    void stop() {                                               // (every job handed over has been run by then: the pieces' taker waits for them first)
         { std::lock_guard<std::mutex> g(mu); quit.store(true); }
         cv.notify_all();
         for (auto& t : workers) t.join();
         workers.clear();
-        { std::lock_guard<std::mutex> g(job_mu); job_quit = true; }
-        job_cv.notify_all();
-        for (auto& t : job_threads) t.join();
-        job_threads.clear();
     }
     void wait_done(size_t j) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return chunks[j].done.load(std::memory_order_acquire) != 0; }); }
     void move_horizon(size_t h) { { std::lock_guard<std::mutex> g(mu); if (h > horizon.load()) horizon.store(h); } cv.notify_all(); }
@@ -715,10 +698,9 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
     if (!f.open(path)) return -1;
     const size_t data0 = gzip_header(f.d, f.size, 0);
     if (!data0) return -1;
-    // decoders; their second jobs take about a third of a decoder's time per chunk (start(): T / 2 + 1 threads); the walk and what
-    // takes the pieces are two more
+    // the team: every CPU this process may use but two (the walk, and what takes the pieces)
     const unsigned cpus = effective_cpus();
-    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(penv("KATGPU_PGZ_THREADS", std::min(32u, std::max(2u, cpus > 6 ? (cpus - 2) * 2 / 3 : cpus / 2))), 256));
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(penv("KATGPU_PGZ_THREADS", std::min(48u, std::max(2u, cpus > 4 ? cpus - 2 : cpus))), 256));
     Inflater inf;
     inf.d = f.d; inf.size = f.size;
     inf.CB = (size_t)std::max<uint64_t>(1 << 16, penv("KATGPU_PGZ_CHUNK", (uint64_t)4 << 20));

@@ -222,6 +222,12 @@ def test_gpus_switch_writes_the_single_gpu_files(tmp_path, gpus, env):
     go(["comp", "--gpus", str(gpus), "-m41", "-H", "3000000", "-o", "w_many", "lib_R?.fq", "asm.fa"], "comp k=41 --gpus", e)
     assert (tmp_path / "w_one-main.mx").read_bytes().replace(b"w_one", b"w_many") == (tmp_path / "w_many-main.mx").read_bytes()
     assert (tmp_path / "w_one.stats").read_text() == (tmp_path / "w_many.stats").read_text()
-    r = subprocess.run([EXE, "hist", "--gpus", "2", "-d", "-m27", "-o", "x.hist", "lib_R1.fq"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
-                       env=dict(e, KATGPU_COMM_TRANSPORT="shm"))
-    assert r.returncode == 1 and "--gpus" in r.stderr
+    # -d: the ranks' owned k-mers gathered into the one sorted .jf the plain run writes (InputHandler::dump, lib/src/input_handler.cc:221-243)
+    go(["hist", "-d", "-m27", "-H", "3000000", "-o", "d_one.hist", "lib_R1.fq"], "hist -d", base_env)
+    go(["hist", "--gpus", str(gpus), "-d", "-m27", "-H", "3000000", "-o", "d_many.hist", "lib_R1.fq"], "hist -d --gpus", e)
+    assert (tmp_path / "d_one.hist-hash.jf27").read_bytes() == (tmp_path / "d_many.hist-hash.jf27").read_bytes()
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".part")]
+    go(["comp", "-d", "-m41", "-H", "3000000", "-o", "dw_one", "lib_R1.fq", "asm.fa"], "comp -d k=41", base_env)
+    go(["comp", "--gpus", str(gpus), "-d", "-m41", "-H", "3000000", "-o", "dw_many", "lib_R1.fq", "asm.fa"], "comp -d k=41 --gpus", e)
+    for i in (1, 2):
+        assert (tmp_path / ("dw_one-hash%d.jf41" % i)).read_bytes() == (tmp_path / ("dw_many-hash%d.jf41" % i)).read_bytes()
