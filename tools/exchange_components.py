@@ -17,15 +17,17 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--genome", type=int, default=1_000_000_000)
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--err-ppm", type=int, default=2000)
     a = ap.parse_args()
     eng = kat_amd.Engine(0)
     comm = kat_amd.Comm(eng, 0, 1, kat_amd.Comm.unique_id())
     g = eng.synth_genome(a.genome, seed=20260927)
-    reads = eng.synth_reads(g, a.genome, first_read=0, n_reads=a.reads, read_len=150, frag_len=350, err_ppm=10000, seed=1)
+    reads = eng.synth_reads(g, a.genome, first_read=0, n_reads=a.reads, read_len=150, frag_len=350, err_ppm=a.err_ppm, seed=1)
     g.free()
     for packed in ("1", "0"):
         os.environ["KATGPU_COMM_PACKED_RECORDS"] = packed      # (read when the library is loaded: the second pass only says so if it could not)
-        t = eng.table(a.k, True, size_hint=int(a.reads * (150 - a.k + 1) * 0.17) + (1 << 20))
+        import bench
+        t = eng.table(a.k, True, size_hint=int(bench.expected_distinct(a.reads * (150 - a.k + 1), a.genome, a.k, a.err_ppm) / 0.62) + (1 << 20))     # (as bench.py sizes config 5's tables)
         t.count_bases_device(reads.ptr, reads.nbytes)
         eng.sync()
         st = t.stats(want_total=False)
