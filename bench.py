@@ -51,8 +51,8 @@ WORKLOADS = {
     "comp-rr": (150_000_000, 1_000_000_000, 31, "kat comp reads-vs-reads"),
 }
 CONFIG_ALIAS = {2: "hist", 3: "gcp", 4: "comp", 5: "comp-rr"}
-PROFILE_JSON = {"comp": "profiles/r05_final_pmc_fetch_write.json", "hist": "profiles/r05_final_hist_pmc_fetch_write.json",
-                "gcp": "profiles/r05_final_gcp_pmc_fetch_write.json", "comp-rr": "profiles/r05_final_comp-rr_pmc_fetch_write.json"}
+PROFILE_JSON = {"comp": "profiles/r06_final_pmc_fetch_write.json", "hist": "profiles/r06_final_hist_pmc_fetch_write.json",
+                "gcp": "profiles/r06_final_gcp_pmc_fetch_write.json", "comp-rr": "profiles/r06_final_comp-rr_pmc_fetch_write.json"}
 # the sources the count stage's kernels are made of: a committed profile describes the kernels of ONE state of these files
 # (tools/profile_bench.sh records their digest next to the counters; pmc_traffic refuses a profile taken from other code)
 STAGE_SOURCES = ["kat_amd/csrc/kg_partition.hpp", "kat_amd/csrc/kg_device.hpp", "kat_amd/csrc/kg_l1_lean.hpp", "kat_amd/csrc/kg_kernels.hpp",

@@ -36,6 +36,7 @@ def main():
                                                                                                       geo.n_regions, geo.region_slots), flush=True)
         for r in range(a.repeats):
             b = comm.stats()
+            eng.profile_reset()
             t0 = time.perf_counter()
             comm.exchange_merge(t)
             eng.sync()
@@ -44,6 +45,8 @@ def main():
             print("  exchange of one rank's own records (%s-byte records asked for: %s): %.1f ms -- extract %.1f, merge %.1f, wire calls %.1f; %d merge calls" % (
                 "9" if packed == "1" else "12", "packed" if c["records_packed"] else "key + count", dt, c["extract_ms"] - b["extract_ms"], c["merge_ms"] - b["merge_ms"],
                 c["exchange_ms"] - b["exchange_ms"], c["merge_calls"] - b["merge_calls"]), flush=True)
+            pr = eng.profile()
+            print("      of that in kernels (HIP events): " + ", ".join("%s %.1f ms in %d launches" % (q, pr[q]["ms"], pr[q]["launches"]) for q in pr if pr[q]["launches"]), flush=True)
         assert t.stats(want_total=False)["distinct"] == st["distinct"]
         t.free()
         eng.release_scratch()
