@@ -155,7 +155,7 @@ def pmc_traffic(a, world):
         base = name.replace("kg::", "").replace("void ", "").split("<")[0].split("(")[0]
         if base.startswith(("k_p1", "k_p2", "k_p3", "k_s1", "k_s2", "k_s3", "k_insert_keys")):
             kb += 2.0 * e.get("FETCH_SIZE_KB_total", 0.0) + e.get("WRITE_SIZE_KB_total", 0.0)
-            if base.startswith(("k_p1v2_scatter", "k_s1")):          # one per round
+            if base.startswith(("k_p1v2_scatter", "k_p1b_scatter", "k_s1")):          # one per round (the group and the block edition of level 1; wide tables' k_s1)
                 rounds += e.get("launches", 0)
     if not rounds:
         return None, None
