@@ -356,13 +356,15 @@ def measure(eng, a, ctx, want_cpu):
             g1_ = t1.geometry()
             results["geo1"] = (int(g1_.p1), int(g1_.p2), t1.slot_bytes(), t2.slot_bytes() if t2 is not None else 0)
         if world > 1:
-            if overlap:
+            if overlap:                                     # table 2's records travel while table 1's are applied
                 eng.sync()
+                comm.exchange_begin(t2)
                 comm.exchange_finish(t1)
+                comm.exchange_finish(t2)
             else:
                 t1 = exchange(t1)
-            if t2 is not None:
-                t2 = exchange(t2)
+                if t2 is not None:
+                    t2 = exchange(t2)
             tp = mark("exchange", tp)
         if wl == "hist":
             out = [t1.hist()]

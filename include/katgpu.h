@@ -312,8 +312,10 @@ int  katgpu_exchange_merge(katgpu_comm* comm, katgpu_table* t);
  * hash is counted while the first one's merge travels; the reference has nothing to overlap -- its merges are memory operations of one
  * process, lib/include/kat/sparse_matrix.hpp:324-335): begin extracts the records, empties the table and posts every chunk, from and
  * into a buffer of the exchange's own (send list + what arrives: ~2 x 9..12 bytes per record; the context's scratch arena stays the
- * counter's); finish waits chunk by chunk and applies.  Between the two calls `t` must not be touched and no other collective of `comm`
- * may run; counting into OTHER tables of the context is what the gap is for.  When a rank has no room for the buffer -- all ranks agree
+ * counter's); finish waits chunk by chunk and applies.  Between the two calls `t` must not be touched; counting into OTHER tables of the
+ * context is what the gap is for.  Two exchanges may be under way at once -- begin(t1), count input 2, begin(t2), finish(t1), finish(t2):
+ * table 2's records travel while table 1's are applied -- and are finished in the order they were begun; no other collective of `comm`
+ * (katgpu_exchange_merge, katgpu_allreduce_u64) may run until all are finished.  When a rank has no room for the buffer -- all ranks agree
  * on that -- and for wide tables, begin runs the whole exchange and finish returns at once.  Same result as katgpu_exchange_merge. */
 int  katgpu_exchange_begin(katgpu_comm* comm, katgpu_table* t);
 int  katgpu_exchange_finish(katgpu_comm* comm, katgpu_table* t);

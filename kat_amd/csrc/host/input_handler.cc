@@ -76,10 +76,12 @@ katgpu_comm* Engine::comm() {
     return g_comm;
 }
 
-static katgpu_table* g_pending = nullptr;                                   // the table of an exchange begun and not yet finished
-void Engine::finishPending() { if (g_pending) { katgpu_table* t = g_pending; g_pending = nullptr; check(katgpu_exchange_finish(comm(), t)); } }
+static std::vector<katgpu_table*> g_pending;                               // the tables of exchanges begun and not yet finished, oldest first (at most two)
+static void finish_oldest() { katgpu_table* t = g_pending.front(); g_pending.erase(g_pending.begin()); Engine::check(katgpu_exchange_finish(Engine::comm(), t)); }
+void Engine::finishPending() { while (!g_pending.empty()) finish_oldest(); }
+bool Engine::exchangesUnderWay() { return !g_pending.empty(); }
 void Engine::exchange(katgpu_table* t) { if (dist_) { finishPending(); check(katgpu_exchange_merge(comm(), t)); } }
-void Engine::exchangeBegin(katgpu_table* t) { if (dist_) { finishPending(); check(katgpu_exchange_begin(comm(), t)); g_pending = t; } }
+void Engine::exchangeBegin(katgpu_table* t) { if (dist_) { while (g_pending.size() >= 2) finish_oldest(); check(katgpu_exchange_begin(comm(), t)); g_pending.push_back(t); } }
 void Engine::barrier() { if (dist_) { finishPending(); check(katgpu_comm_barrier(comm())); } }
 void Engine::allreduce(uint64_t* buf, size_t n) { if (dist_) { finishPending(); check(katgpu_allreduce_u64(comm(), buf, n)); } }
 
@@ -183,7 +185,7 @@ void InputHandler::count(uint16_t threads, const katgpu_table* like, bool more_t
         if (like) Engine::check(katgpu_table_create_like(Engine::ctx(), like, merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
         else Engine::check(katgpu_table_create(Engine::ctx(), merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
         Engine::check(katgpu_count_files_sharded(hash, paths.data(), paths.size(), trim5p.data(), Engine::rank(), Engine::world()));
-        if (more_to_count) Engine::exchangeBegin(hash); else Engine::exchange(hash);
+        if (more_to_count || Engine::exchangesUnderWay()) Engine::exchangeBegin(hash); else Engine::exchange(hash);     // (comp's last input: its records travel while the one before is applied)
     } else if (like) {
         Engine::check(katgpu_table_create_like(Engine::ctx(), like, merLen, canonical ? 1 : 0, hashSize, disableHashGrow ? 1 : 0, &hash));
         Engine::check(katgpu_count_files(hash, paths.data(), paths.size(), trim5p.data()));

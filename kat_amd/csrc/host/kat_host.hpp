@@ -73,6 +73,7 @@ public:
     static katgpu_comm* comm();                     // made on first use (rank 0 publishes the id through id_file)
     static void exchange(katgpu_table* t);          // no-op without --gpus
     static void exchangeBegin(katgpu_table* t);     // the same in two steps: the table's records travel while the caller counts its next input ...
+    static bool exchangesUnderWay();
     static void finishPending();                    // ... and are applied here (katgpu_exchange_begin / _finish); every other collective finishes it first
     static void allreduce(uint64_t* buf, size_t n); // idem
     static void barrier();                          // idem

@@ -149,7 +149,7 @@ struct katgpu_comm {
     double ms_exchange = 0, ms_merge = 0, ms_extract = 0, ms_allreduce = 0;
     uint64_t bytes_sent = 0, merge_launches = 0;
     uint64_t records_sent = 0, record_bytes_sent = 0;          // what katgpu_exchange_merge put on the wire as records (not the count matrices, not the all-reduce)
-    void* pending = nullptr;                                   // an Exchange begun (katgpu_exchange_begin) and not yet finished
+    std::vector<void*> pending;                                // Exchanges begun (katgpu_exchange_begin) and not yet finished, oldest first (at most two)
     bool wire_packed = false;                                  // the last exchange's records: 9 bytes (remainder + count) or 12 (key + count)
     std::string transport_note;
     uint8_t* host_stage = nullptr; size_t host_stage_bytes = 0;
@@ -981,12 +981,12 @@ struct Exchange {
     }
 };
 
-static void drop_pending(katgpu_comm* m) { if (m->pending) { delete (Exchange*)m->pending; m->pending = nullptr; } }
+static void drop_pending(katgpu_comm* m) { for (void* p : m->pending) delete (Exchange*)p; m->pending.clear(); }
 
 extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
     if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = m->ctx;
-    if (m->pending) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_merge: an exchange begun with katgpu_exchange_begin has not been finished");
+    if (!m->pending.empty()) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_merge: an exchange begun with katgpu_exchange_begin has not been finished");
     HIPCHK(c, hipSetDevice(c->device));
     if (t->dev().keys_b) return exchange_merge_wide(m, t);
     Exchange x(m, t);
@@ -995,29 +995,35 @@ extern "C" int katgpu_exchange_merge(katgpu_comm* m, katgpu_table* t) {
 
 // The same exchange in two calls, so that the caller's next input is counted while this table's records travel: begin extracts, empties
 // the table and puts every chunk on the wire (from and into a buffer of the exchange's own -- the arena stays the counter's); finish waits
-// for the chunks and applies them.  Between the two the table is not to be touched and no other collective of this communicator may run.
+// for the chunks and applies them.  Between the two the table is not to be touched.  TWO exchanges may be under way: the second table's
+// begin (its collectives queue behind the first one's transfers, long landed by then) before the first one's finish, so that the second
+// table's records travel while the first one's are applied; they are finished in the order they were begun.
 // Wide tables (k > 32) and ranks without room for the buffer do the whole exchange in begin.
 extern "C" int katgpu_exchange_begin(katgpu_comm* m, katgpu_table* t) {
     if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = m->ctx;
-    if (m->pending) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_begin: the previous exchange has not been finished");
+    if (m->pending.size() >= 2) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_begin: two exchanges are under way already: finish the older one first");
+    for (void* p : m->pending) if (((Exchange*)p)->t == t) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_begin: this table's exchange has not been finished");
     HIPCHK(c, hipSetDevice(c->device));
     if (t->dev().keys_b) return exchange_merge_wide(m, t);
     Exchange* x = new Exchange(m, t);
     const int rc = x->begin(true);
     if (rc || x->done) { delete x; return rc; }
-    m->pending = x;
+    m->pending.push_back(x);
     return KATGPU_OK;
 }
 extern "C" int katgpu_exchange_finish(katgpu_comm* m, katgpu_table* t) {
     if (!m || !t || t->ctx != m->ctx) return KATGPU_ERR_INVALID_ARG;
-    if (!m->pending) return KATGPU_OK;                            // (begin did it all)
     katgpu_ctx* c = m->ctx;
-    Exchange* x = (Exchange*)m->pending;
-    if (x->t != t) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_finish: not the table katgpu_exchange_begin was given");
+    // (every rank finishes its exchanges in the order it began them: the tails are collectives)
+    if (m->pending.empty() || ((Exchange*)m->pending.front())->t != t) {
+        for (void* p : m->pending) if (((Exchange*)p)->t == t) return fail(c, KATGPU_ERR_INVALID_ARG, "katgpu_exchange_finish: an older exchange has to be finished first");
+        return KATGPU_OK;                                          // (begin did it all)
+    }
+    Exchange* x = (Exchange*)m->pending.front();
     HIPCHK(c, hipSetDevice(c->device));
     const int rc = x->finish();
-    m->pending = nullptr;
+    m->pending.erase(m->pending.begin());
     delete x;
     return rc;
 }

@@ -132,8 +132,15 @@ extern "C" int katgpu_table_clear(katgpu_table* t) {
     if (!t) return KATGPU_ERR_INVALID_ARG;
     katgpu_ctx* c = t->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    DevTable& d = t->dev();
-    HIPCHK(c, hipMemsetAsync(d.keys, d.cbits ? 0 : 0xFF, d.cap * sizeof(uint64_t) * (d.keys_b ? 2 : 1), c->stream));     // (wide: keys_b follows keys)
+    // A packed table of size is not cleared here: the region-ordered merge that refills it (katgpu_table_merge_regions*: the exchange)
+    // starts every region from zeros in LDS and writes every one back -- neither the memset nor the merge's read of it; whoever else
+    // touches the table first clears what has not been swept (katgpu_table::zero_from, as for a new table).
+    DevTable& d = t->dv;
+    if (table_may_stay_uncleared(d)) t->zero_from = 0;
+    else {
+        t->zero_from = ~0ULL;
+        HIPCHK(c, hipMemsetAsync(d.keys, d.cbits ? 0 : 0xFF, d.cap * sizeof(uint64_t) * (d.keys_b ? 2 : 1), c->stream));     // (wide: keys_b follows keys)
+    }
     if (d.counts) HIPCHK(c, hipMemsetAsync(d.counts, 0, d.cap * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_keys, 0xFF, OVF_CAP * sizeof(uint64_t), c->stream));
     HIPCHK(c, hipMemsetAsync(d.ovf_hi, 0, OVF_CAP * sizeof(uint64_t), c->stream));
@@ -204,17 +211,17 @@ static int merge_regions_impl(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uin
     HIPCHK(c, hipSetDevice(c->device));
     int rc = refresh_counters(t); if (rc) return rc;
     if (!c->merge_attr_set) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_apply<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_apply<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_apply<MERGE_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_apply<MERGE_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         c->merge_attr_set = true;
     }
-    const size_t slot_bytes = t->dev().cbits ? 8 : 12;
+    const size_t slot_bytes = t->dv.cbits ? 8 : 12;
     // sources ordered by this table's regions go through LDS; the rest (another grid, or the table has changed its grid) directly
     std::vector<uint32_t> aligned, direct;
     for (uint32_t i = 0; i < n_src; ++i) {
         if (src[i].n_records == 0) continue;
-        const bool ok = !g_no_merge_apply && src[i].dev_region_counts && src[i].p1 == t->dev().p1 && src[i].p2 == t->dev().p2 && g_hi <= t->dev().n_regions &&
-                        (size_t)t->dev().region_slots * slot_bytes <= 150 * 1024;
+        const bool ok = !g_no_merge_apply && src[i].dev_region_counts && src[i].p1 == t->dv.p1 && src[i].p2 == t->dv.p2 && g_hi <= t->dv.n_regions &&
+                        (size_t)t->dv.region_slots * slot_bytes <= 150 * 1024;
         (ok ? aligned : direct).push_back(i);
     }
     const uint32_t n_reg = g_hi - g_lo;
@@ -228,7 +235,7 @@ static int merge_regions_impl(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uin
         unsigned long long* d_ndef = (unsigned long long*)(tmp + off_bytes + (size_t)n_reg * 4);
         MergeSrcs ms{};
         ms.n = na;
-        ms.src_p1 = src[aligned[a0]].p1; ms.src_n1 = place_n1(t->dev().k, ms.src_p1); ms.src_l2 = (uint32_t)__builtin_ctz(src[aligned[a0]].p2);   // (aligned sources share one grid: this table's)
+        ms.src_p1 = src[aligned[a0]].p1; ms.src_n1 = place_n1(t->dv.k, ms.src_p1); ms.src_l2 = (uint32_t)__builtin_ctz(src[aligned[a0]].p2);   // (aligned sources share one grid: this table's)
         uint64_t records = 0;
         for (uint32_t q = 0; q < na; ++q) {
             const GSrc& s = src[aligned[a0 + q]];
@@ -239,14 +246,24 @@ static int merge_regions_impl(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uin
         }
         hipMemsetAsync(d_ndef, 0, 8, c->stream);
         t->count_bound = 0xFFFFFFFFULL;
+        // A table whose slots wait for their first sweep (katgpu_table_clear left them): this launch is that sweep for [g_lo, g_hi) when those
+        // are the next regions in line and every aligned source is in it -- each region starts from zeros in LDS and each is written back;
+        // else what is left is cleared now.
+        uint32_t zero_fill = 0;
+        if (t->zero_from != ~0ULL) {
+            if (t->dv.cbits && t->zero_from == g_lo && a0 == 0 && na == aligned.size()) zero_fill = 1;
+            else { if (g_trace) fprintf(stderr, "[katgpu] merge: regions from %llu on cleared now (this merge begins at %u)\n", (unsigned long long)t->zero_from, g_lo); t->zero_rest(); }
+        }
+        if (g_trace && zero_fill) fprintf(stderr, "[katgpu] merge: regions [%u, %u) start from zeros in LDS (the table was left uncleared)\n", g_lo, g_hi);
         {
             ScopedTimer tm(c, KATGPU_K_MERGE, records);
-            const size_t lds = (size_t)t->dev().region_slots * slot_bytes;
+            const size_t lds = (size_t)t->dv.region_slots * slot_bytes;
             const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / (lds + 512), 2));
             const dim3 grid(std::min<uint32_t>(n_reg, (uint32_t)c->n_cu * per_cu));
-            if (t->dev().cbits) hipLaunchKernelGGL((k_merge_apply<1024, true>), grid, dim3(1024), lds, c->stream, t->dev(), g_lo, g_hi, ms, d_def, d_ndef);
-            else hipLaunchKernelGGL((k_merge_apply<1024, false>), grid, dim3(1024), lds, c->stream, t->dev(), g_lo, g_hi, ms, d_def, d_ndef);
+            if (t->dv.cbits) hipLaunchKernelGGL((k_merge_apply<MERGE_BLOCK, true>), grid, dim3(MERGE_BLOCK), lds, c->stream, t->dv, g_lo, g_hi, ms, d_def, d_ndef, zero_fill);
+            else hipLaunchKernelGGL((k_merge_apply<MERGE_BLOCK, false>), grid, dim3(MERGE_BLOCK), lds, c->stream, t->dv, g_lo, g_hi, ms, d_def, d_ndef, 0u);
         }
+        if (zero_fill) t->zero_from = g_hi >= t->dv.n_regions ? ~0ULL : g_hi;       // (regions [g_lo, g_hi) have had their sweep)
         unsigned long long ndef = 0;
         hipMemcpyAsync(&ndef, d_ndef, 8, hipMemcpyDeviceToHost, c->stream);
         hipError_t e = hipStreamSynchronize(c->stream);
@@ -266,22 +283,22 @@ static int merge_regions_impl(katgpu_table* t, uint32_t g_lo, uint32_t g_hi, uin
                 for (uint32_t q = 0; q < na; ++q) { const uint64_t* o = off.data() + (size_t)q * (n_reg + 1); in += o[g - g_lo + 1] - o[g - g_lo]; }
                 max_in = std::max(max_in, in);
             }
-            const uint64_t need_s = (uint64_t)(((double)t->dev().region_slots + (double)max_in) / 0.7) + 1;
-            if (need_s > t->dev().region_slots) {
+            const uint64_t need_s = (uint64_t)(((double)t->dv.region_slots + (double)max_in) / 0.7) + 1;
+            if (need_s > t->dv.region_slots) {
                 if (t->disable_grow) rc = fail(c, KATGPU_ERR_TABLE_FULL, "Hash full");
-                else rc = regrow(t, (uint64_t)t->dev().n_regions * need_s);
+                else rc = regrow(t, (uint64_t)t->dv.n_regions * need_s);
             }
             if (rc == KATGPU_OK) {                    // one launch for all deferred regions: every region now has the room
                 ScopedTimer tm(c, KATGPU_K_MERGE, max_in * ndef);
                 hipLaunchKernelGGL(k_merge_deferred, dim3((unsigned)std::min<unsigned long long>(ndef, (unsigned long long)c->n_cu * 8)), dim3(256), 0, c->stream,
-                                   t->dev(), g_lo, ms, (const uint32_t*)d_def, (uint32_t)ndef);
+                                   t->dv, g_lo, ms, (const uint32_t*)d_def, (uint32_t)ndef);
                 if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, KATGPU_ERR_DEVICE, "deferred merge");
                 else rc = refresh_counters(t);
             }
         }
         hipFree(tmp);
         if (rc) return rc;
-        if (ndef && (src[aligned[a0]].p1 != t->dev().p1 || src[aligned[a0]].p2 != t->dev().p2)) {      // the growth changed the grid: the rest goes direct
+        if (ndef && (src[aligned[a0]].p1 != t->dv.p1 || src[aligned[a0]].p2 != t->dv.p2)) {      // the growth changed the grid: the rest goes direct
             for (size_t a = a0 + na; a < aligned.size(); ++a) direct.push_back(aligned[a]);
             break;
         }

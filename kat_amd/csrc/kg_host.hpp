@@ -143,7 +143,7 @@ inline int fail(katgpu_ctx* c, int code, const char* fmt, ...) {
 // entry points that handle one-word k-mers only (lookups by 64-bit key, .jf, the multi-GPU exchange, sect/cold profiles)
 #define NARROW_ONLY(t, what)                                                                             \
     do {                                                                                                 \
-        if ((t)->dev().keys_b) return fail((t)->ctx, KATGPU_ERR_K, "%s is not available for k > 32 (k = %u)", what, (t)->dev().k); \
+        if ((t)->dv.keys_b) return fail((t)->ctx, KATGPU_ERR_K, "%s is not available for k > 32 (k = %u)", what, (t)->dv.k);      /* (dv: metadata only -- a table left uncleared stays that way) */ \
     } while (0)
 
 #define HIPCHK(c, expr)                                                                                  \
@@ -210,6 +210,7 @@ int alloc_dev_table(katgpu_ctx* c, uint32_t k, int canonical, uint64_t cap, DevT
 void free_dev_table(katgpu_ctx* c, DevTable& d);
 int refresh_counters(katgpu_table* t);
 int regrow(katgpu_table* t, uint64_t new_cap);
+bool table_may_stay_uncleared(const DevTable& d);
 double load_limit(const DevTable& d);
 int ensure_room(katgpu_table* t, uint64_t incoming);
 int table_wait(katgpu_table* t);               // the table's device arrays exist (katgpu_count allocates them asynchronously)

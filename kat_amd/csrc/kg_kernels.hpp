@@ -1110,8 +1110,11 @@ k_partition(DevTable t, uint32_t n_ovf, uint32_t n_parts, unsigned long long* __
 // order; the owner then applies, per region, the runs it received from every rank to that region in LDS -- no
 // global atomic per record and no re-partitioning on the receiving side.
 constexpr int EXTRACT_BLOCK = 256;
+constexpr int EXTRACT_UNROLL = 4;            // 16-byte loads a lane of the extraction kernels has in flight (packed tables)
 constexpr uint32_t MAX_EXCHANGE_PARTS = 256;
 constexpr int MAX_MERGE_SRC = 16;
+constexpr int MERGE_BATCH = 8;
+constexpr int MERGE_BLOCK = 512;             // threads of a k_merge_apply workgroup               // records a thread of k_merge_apply fetches before it applies the first
 
 // pass 1: rcnt[p * R + g] = number of records of region g owned by part p.  One workgroup per region.
 static __global__ void __launch_bounds__(EXTRACT_BLOCK)
@@ -1123,9 +1126,28 @@ k_extract_count(DevTable t, uint32_t n_parts, uint32_t* __restrict__ rcnt) {
         __syncthreads();
         const uint64_t base = (uint64_t)g * S;
         const RegionPlace rp = region_place(t, g);
-        for (uint32_t i = tid; i < S; i += EXTRACT_BLOCK) {
-            const SlotView v = slot_view_in(t, rp, base + i);
-            if (v.occ) atomicAdd(&s_cnt[n_parts > 1 ? owner_of(v.key, t.k, n_parts) : 0], 1u);
+        if (t.cbits) {
+            // packed slots: four 16-byte loads per lane in flight before the first is looked at (the kernel waits for memory 0.63 of its
+            // wave cycles with one 8-byte load per lane: profiles/r06_exchange_components.txt) -- regions are multiples of four slots
+            const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(t.keys + base);
+            const uint32_t n2 = S >> 1;
+            for (uint32_t i0 = 0; i0 < n2; i0 += EXTRACT_BLOCK * EXTRACT_UNROLL) {
+                ulonglong2 w[EXTRACT_UNROLL];
+#pragma unroll
+                for (int u = 0; u < EXTRACT_UNROLL; ++u) { const uint32_t i = i0 + u * EXTRACT_BLOCK + tid; w[u] = i < n2 ? w2[i] : make_ulonglong2(0, 0); }
+#pragma unroll
+                for (int u = 0; u < EXTRACT_UNROLL; ++u)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint64_t x = h ? w[u].y : w[u].x;
+                        if (x) atomicAdd(&s_cnt[n_parts > 1 ? owner_of(key_in(pk_rem(x, t.cbits), rp), t.k, n_parts) : 0], 1u);
+                    }
+            }
+        } else {
+            for (uint32_t i = tid; i < S; i += EXTRACT_BLOCK) {
+                const SlotView v = slot_view_in(t, rp, base + i);
+                if (v.occ) atomicAdd(&s_cnt[n_parts > 1 ? owner_of(v.key, t.k, n_parts) : 0], 1u);
+            }
         }
         __syncthreads();
         for (uint32_t p = tid; p < n_parts; p += EXTRACT_BLOCK) rcnt[(uint64_t)p * t.n_regions + g] = s_cnt[p];
@@ -1192,13 +1214,10 @@ k_extract_write(DevTable t, uint32_t n_ovf, uint32_t n_parts, const uint64_t* __
         __syncthreads();
         const uint64_t base = (uint64_t)g * S;
         const RegionPlace rp = region_place(t, g);
-        for (uint32_t i = tid; i < S; i += EXTRACT_BLOCK) {
-            const SlotView v = slot_view_in(t, rp, base + i);
-            if (!v.occ) continue;
-            const uint64_t key = v.key;
+        auto emit = [&](uint64_t pos, uint64_t key, uint64_t in_slot) {
             const uint32_t p = n_parts > 1 ? owner_of(key, t.k, n_parts) : 0;
             const uint64_t at = off[(uint64_t)p * t.n_regions + g] + atomicAdd(&s_cur[p], 1u);
-            uint64_t c = slot_total(t, base + i, key, v.cnt, n_ovf);
+            uint64_t c = slot_total(t, pos, key, in_slot, n_ovf);
             const uint32_t xs = PACKED ? rec_xs(rp.pl.rb) : 0;
             if (c > (0xFFFFFFFFULL >> xs)) {
                 const unsigned long long b = atomicAdd(big_n, 1ULL);
@@ -1210,6 +1229,27 @@ k_extract_write(DevTable t, uint32_t n_ovf, uint32_t n_parts, const uint64_t* __
                 out_rem_lo[at] = (uint32_t)rem; out_rem_hi[at] = (uint8_t)(rem >> 32);
                 out_counts[at] = c ? ((uint32_t)c << xs) | (uint32_t)(rem >> 40) : 0u;
             } else { out_keys[at] = key; out_counts[at] = (uint32_t)c; }
+        };
+        if (t.cbits) {                                             // (packed slots: as k_extract_count, four 16-byte loads per lane in flight)
+            const ulonglong2* w2 = reinterpret_cast<const ulonglong2*>(t.keys + base);
+            const uint32_t n2 = S >> 1;
+            for (uint32_t i0 = 0; i0 < n2; i0 += EXTRACT_BLOCK * EXTRACT_UNROLL) {
+                ulonglong2 w[EXTRACT_UNROLL];
+#pragma unroll
+                for (int u = 0; u < EXTRACT_UNROLL; ++u) { const uint32_t i = i0 + u * EXTRACT_BLOCK + tid; w[u] = i < n2 ? w2[i] : make_ulonglong2(0, 0); }
+#pragma unroll
+                for (int u = 0; u < EXTRACT_UNROLL; ++u)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint64_t x = h ? w[u].y : w[u].x;
+                        if (x) emit(base + 2 * (uint64_t)(i0 + u * EXTRACT_BLOCK + tid) + h, key_in(pk_rem(x, t.cbits), rp), pk_count(x, t.cbits));
+                    }
+            }
+        } else {
+            for (uint32_t i = tid; i < S; i += EXTRACT_BLOCK) {
+                const SlotView v = slot_view_in(t, rp, base + i);
+                if (v.occ) emit(base + i, v.key, v.cnt);
+            }
         }
         __syncthreads();
     }
@@ -1230,8 +1270,10 @@ __device__ __forceinline__ uint64_t merge_src_key(const DevTable& t, const Merge
 // apply kernels with arbitrary 32-bit amounts.  A region that could overflow (occupied + incoming > S) is not touched: its index
 // goes to `deferred` and the host sends its runs through the direct path after making room.
 template <int BLOCK, bool PK>
-__global__ void __launch_bounds__(BLOCK)
-k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t* __restrict__ deferred, unsigned long long* __restrict__ n_deferred) {
+__global__ void __launch_bounds__(BLOCK, 4)     // 512 threads, four waves per SIMD (<= 128 VGPRs: a batch of records in registers): two workgroups per CU, a region of <= 77 KB each
+k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t* __restrict__ deferred, unsigned long long* __restrict__ n_deferred,
+              uint32_t zero_fill /* PK: the regions hold whatever the memory held (katgpu_table::zero_from): each starts from zeros in LDS instead of being loaded,
+                                    and EVERY region of [g_lo, g_hi) is written -- one that nothing arrives for, or that is deferred, as zeros */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ uint32_t s_occ;
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(lds_raw);
@@ -1243,16 +1285,27 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
         const uint32_t j = g - g_lo;
         uint64_t incoming = 0;
         for (uint32_t s = 0; s < srcs.n; ++s) incoming += srcs.s[s].off[j + 1] - srcs.s[s].off[j];
-        if (incoming == 0) continue;                                             // uniform over the workgroup
+        const uint64_t base = (uint64_t)g * S;
+        if (incoming == 0 || (zero_fill && incoming > S)) {                      // uniform over the workgroup
+            if (zero_fill) {                                                     // (S % 4 == 0: regions are 32-byte aligned)
+                ulonglong2* z = reinterpret_cast<ulonglong2*>(t.keys + base);
+                for (uint32_t i = tid; i < (S >> 1); i += BLOCK) z[i] = make_ulonglong2(0, 0);
+            }
+            if (incoming && tid == 0) deferred[atomicAdd(n_deferred, 1ULL)] = g;
+            continue;
+        }
         if (tid == 0) s_occ = 0;
         __syncthreads();
-        const uint64_t base = (uint64_t)g * S;
         const RegionPlace rp = region_place(t, g);
         uint32_t occ = 0;
-        for (uint32_t i = tid; i < S; i += BLOCK) {
-            const uint64_t key = t.keys[base + i];
-            rk[i] = key;
-            if constexpr (PK) occ += key != 0; else { rc[i] = t.counts[base + i]; occ += key != EMPTY; }
+        if (PK && zero_fill) {
+            for (uint32_t i = tid; i < S; i += BLOCK) rk[i] = 0;
+        } else {
+            for (uint32_t i = tid; i < S; i += BLOCK) {
+                const uint64_t key = t.keys[base + i];
+                rk[i] = key;
+                if constexpr (PK) occ += key != 0; else { rc[i] = t.counts[base + i]; occ += key != EMPTY; }
+            }
         }
         for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
         if ((tid & 63) == 0 && occ) atomicAdd(&s_occ, occ);
@@ -1264,14 +1317,31 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
         }
         for (uint32_t s = 0; s < srcs.n; ++s) {
             const uint64_t beg = srcs.s[s].off[j], end = srcs.s[s].off[j + 1];
-            for (uint64_t i = beg + tid; i < end; i += BLOCK) {
-                uint32_t c;
-                uint64_t rem = 0;
-                if (PK && !srcs.s[s].keys) { const PackedRec r = packed_rec(srcs.s[s].rem_lo, srcs.s[s].rem_hi, srcs.s[s].counts, i, rec_xs(rp.pl.rb)); c = r.c; rem = r.rem; }   // (packed records: this table's grid is the sender's -- the host checked)
-                else c = srcs.s[s].counts[i];
+            // A thread has a handful of records per region and source, and applying one is a chain of LDS round trips behind three loads: the
+            // loads of MERGE_BATCH records are issued before the first is applied (the kernel waited for memory 0.71 of its wave cycles
+            // fetching them one at a time).
+            // A source's run of a region is in slot order (the extraction walks the region): lanes that took CONSECUTIVE records would all claim
+            // slots of one neighbourhood at once and a wave would wait for the longest chain of claims among them, step after step (24 of the
+            // kernel's 28 ms).  A thread takes a BLOCK of consecutive records instead: a wave's lanes work a dozen slots apart.
+            const uint64_t per_thread = (end - beg + BLOCK - 1) / BLOCK;
+            const uint64_t t_beg = beg + (uint64_t)tid * per_thread, t_end = t_beg + per_thread < end ? t_beg + per_thread : end;
+            for (uint64_t i0 = t_beg; i0 < t_end; i0 += MERGE_BATCH) {
+              uint32_t bc[MERGE_BATCH]; uint64_t brem[MERGE_BATCH];
+#pragma unroll
+              for (int u = 0; u < MERGE_BATCH; ++u) {
+                const uint64_t i = i0 + (uint64_t)u;
+                bc[u] = 0; brem[u] = 0;
+                if (i < t_end) {
+                    if (PK && !srcs.s[s].keys) { const PackedRec r = packed_rec(srcs.s[s].rem_lo, srcs.s[s].rem_hi, srcs.s[s].counts, i, rec_xs(rp.pl.rb)); bc[u] = r.c; brem[u] = r.rem; }   // (packed records: this table's grid is the sender's -- the host checked)
+                    else { bc[u] = srcs.s[s].counts[i]; brem[u] = PK ? rem_in(srcs.s[s].keys[i], rp) : srcs.s[s].keys[i]; }
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < MERGE_BATCH; ++u) {
+                const uint32_t c = bc[u];
+                uint64_t rem = brem[u];
                 if (!c) continue;
                 if constexpr (PK) {
-                    if (srcs.s[s].keys) rem = rem_in(srcs.s[s].keys[i], rp);
                     uint32_t slot = place_offset(rem, rp.pl, S);
                     uint64_t q, r;
                     pk_split((uint64_t)c, cb, q, r);
@@ -1298,7 +1368,7 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
                         slot = slot + 1 == S ? 0 : slot + 1;
                     }
                 } else {
-                    const unsigned long long key = srcs.s[s].keys[i];            // (KV12 tables: never packed records)
+                    const unsigned long long key = rem;                          // (KV12 tables: never packed records; brem holds the key)
                     uint32_t slot = home_offset_in(key, rp);
                     for (uint32_t probe = 0; probe < S; ++probe) {               // cannot fail: occupied + incoming <= S
                         unsigned long long cur = rk[slot];
@@ -1314,9 +1384,15 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
                         slot = slot + 1 == S ? 0 : slot + 1;
                     }
                 }
+              }
             }
         }
         __syncthreads();
+        if constexpr (PK) {                                        // (16-byte stores: S % 4 == 0)
+            ulonglong2* o2 = reinterpret_cast<ulonglong2*>(t.keys + base);
+            const ulonglong2* r2 = reinterpret_cast<const ulonglong2*>(rk);
+            for (uint32_t i = tid; i < (S >> 1); i += BLOCK) o2[i] = r2[i];
+        } else
         for (uint32_t i = tid; i < S; i += BLOCK) { t.keys[base + i] = rk[i]; if constexpr (!PK) t.counts[base + i] = rc[i]; }
         __syncthreads();
     }

@@ -147,6 +147,9 @@ extern "C" uint32_t katgpu_table_slot_bytes(const katgpu_table* t) { return !t ?
 extern "C" int katgpu_table_canonical(const katgpu_table* t) { return t ? (int)t->dv.canonical : 0; }
 
 // read the counter block back (one small D2H; synchronises the compute stream)
+// may this table's slots be left uncleared for a first sweep to clear (katgpu_table::zero_from)?  What alloc_dev_table asks of a new table.
+bool table_may_stay_uncleared(const DevTable& d) { return !g_no_lazy_zero && d.cbits && !d.keys_b && d.n_regions > 1 && d.cap >= g_lazy_min_slots; }
+
 int refresh_counters(katgpu_table* t) {
     katgpu_ctx* c = t->ctx;
     if (t->zero_failed) return fail(c, KATGPU_ERR_DEVICE, "the table's unswept slots could not be cleared (hipMemsetAsync failed): its contents are not to be trusted");

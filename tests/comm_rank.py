@@ -60,8 +60,13 @@ def main():
     t2 = eng.table(k, True, size_hint=1 << 20, like=None if wide else t1).count_bases_device(ab.ptr, asm.size)     # ... while input 2 is counted (in the arena)
     if split:
         eng.sync()
-        comm.exchange_finish(t1)
-        comm.exchange_merge(t2)
+        if os.environ.get("KATGPU_TEST_SPLIT_TWO") == "1":                       # ... and table 2's records travel while table 1's are applied
+            comm.exchange_begin(t2)
+            comm.exchange_finish(t1)
+            comm.exchange_finish(t2)
+        else:
+            comm.exchange_finish(t1)
+            comm.exchange_merge(t2)
         if not wide:
             assert (t1.geometry().p1, t1.geometry().p2) == (g1.p1, g1.p2)
             keys, counts = t1.dump_sorted()

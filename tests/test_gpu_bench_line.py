@@ -73,6 +73,7 @@ def test_eight_ranks_through_the_rccl_branch(fake_rccl, workload, scaling, tiny_
     env = {"KATGPU_TESTING": "1", "KATGPU_RCCL_LIB": fake_rccl, "KATGPU_COMM_TRANSPORT": "rccl", "KATGPU_ARENA_FRACTION": "0.08"}
     if tiny_regions:
         env["KATGPU_TEST_REGION_SLOTS"] = "128"
+        env["KATGPU_TEST_LAZY_MIN_SLOTS"] = "1024"            # (the exchanged tables are left uncleared, the merge is their first sweep: what tables of size do)
     # (comp-rr: k = 29, where these small tables have what config 5's k = 31 tables of 39 GB have -- packed slots, a remainder of more than 40 bits)
     line = _bench(["--gpus", "8", "--workload", workload, "--scaling", scaling] + SMALL + (["--k", "29"] if tiny_regions and workload == "comp-rr" else []), env, timeout=1500)
     if tiny_regions:

@@ -62,7 +62,8 @@ def test_native_exchange_ranks_sharing_one_gpu(ko, tmp_path, world, mode, extra)
 
 
 @pytest.mark.parametrize("world,transport,extra,packed", [
-    (2, "shm", {}, True), (4, "shm", {"KATGPU_TEST_EXCHANGE_CHUNKS": "6"}, True), (8, "rccl", {"KATGPU_TEST_EXCHANGE_CHUNKS": "5"}, True),
+    (2, "shm", {}, True), (4, "shm", {"KATGPU_TEST_EXCHANGE_CHUNKS": "6", "KATGPU_TEST_LAZY_MIN_SLOTS": "1024"}, True),      # (lazy: the emptied table is not cleared, the merge is its first sweep -- as for every table of size)
+    (8, "rccl", {"KATGPU_TEST_EXCHANGE_CHUNKS": "5", "KATGPU_TEST_LAZY_MIN_SLOTS": "1024"}, True),
     (3, "rccl", {"KATGPU_COMM_PACKED_RECORDS": "0"}, False)])
 def test_records_travel_in_nine_bytes_between_ranks_that_share_the_grid(ko, tmp_path, fake_rccl, world, transport, extra, packed):
     """Ranks whose tables have one region grid (regions of 128 slots here, so that small tables are packed ones, as every table of size is) exchange what a slot holds of the k-mer + its count: 9 bytes per record, not key + count's 12
@@ -81,8 +82,9 @@ def test_records_travel_in_nine_bytes_between_ranks_that_share_the_grid(ko, tmp_
 
 
 @pytest.mark.parametrize("world,transport,mode,extra,want", [
-    (2, "shm", "same", {}, "all on the wire at once"), (4, "rccl", "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "6", "KATGPU_TEST_REGION_SLOTS": "128"}, "all on the wire at once"),
-    (8, "rccl", "rr31", {}, "all on the wire at once"), (2, "rccl", "mixed", {}, "all on the wire at once"),
+    (2, "shm", "same", {}, "all on the wire at once"), (4, "rccl", "same", {"KATGPU_TEST_EXCHANGE_CHUNKS": "6", "KATGPU_TEST_REGION_SLOTS": "128", "KATGPU_TEST_LAZY_MIN_SLOTS": "1024"}, "all on the wire at once"),
+    (8, "rccl", "rr31", {"KATGPU_TEST_SPLIT_TWO": "1"}, "all on the wire at once"), (2, "rccl", "mixed", {}, "all on the wire at once"),
+    (3, "shm", "same", {"KATGPU_TEST_SPLIT_TWO": "1", "KATGPU_TEST_LAZY_MIN_SLOTS": "1024"}, "all on the wire at once"),        # (two exchanges under way: begin(t2) before finish(t1))
     (3, "rccl", "same", {"KATGPU_TEST_EXCHANGE_NO_SPLIT": "1"}, "the pipelined one, now"), (2, "shm", "wide45", {}, None)])
 def test_the_second_input_is_counted_while_the_first_table_travels(ko, tmp_path, fake_rccl, world, transport, mode, extra, want):
     """katgpu_exchange_begin(table 1) -- the second input counted, in the arena the exchange no longer uses -- katgpu_exchange_finish(table 1):

@@ -107,7 +107,10 @@ def test_packed_records_case_in_a_process_with_tiny_regions():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, KATGPU_TESTING="1", KATGPU_TEST_REGION_SLOTS="128")
-    r = subprocess.run([sys.executable, os.path.join(here, "packed_records_case.py")], env=env, capture_output=True, text=True, timeout=420)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "packed records ok" in r.stdout
+    for lazy in ("0", "1"):                                # 1: a cleared table keeps its slots as they are and the merge is their first sweep (every table of size)
+        env = dict(os.environ, KATGPU_TESTING="1", KATGPU_TEST_REGION_SLOTS="128")
+        if lazy == "1":
+            env["KATGPU_TEST_LAZY_MIN_SLOTS"] = "1024"
+        r = subprocess.run([sys.executable, os.path.join(here, "packed_records_case.py")], env=env, capture_output=True, text=True, timeout=420)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert "packed records ok" in r.stdout
