@@ -314,8 +314,11 @@ bool inflate_block(Bits& b, const Codes& c, Out& o, uint64_t max_symbols) {
                 if (from < o.floor) return false;                // too far back
                 if (from >= 0) {
                     const uint16_t* src = out + from;
-                    if (dist >= len) memcpy(out + n, src, (size_t)len * 2);
-                    else for (uint32_t i = 0; i < len; ++i) out[n + i] = src[i];
+                    uint16_t* dst = out + n;
+                    if (dist >= 8) {                              // eight symbols at a time, past the match's end if need be (the buffer has the slack;
+                        uint32_t i = 0;                           //  FASTQ is mostly short matches: a libc memcpy per match costs more than the copy)
+                        do { uint64_t a, b2; memcpy(&a, src + i, 8); memcpy(&b2, src + i + 4, 8); memcpy(dst + i, &a, 8); memcpy(dst + i + 4, &b2, 8); i += 8; } while (i < len);
+                    } else for (uint32_t i = 0; i < len; ++i) dst[i] = src[i];
                     n += len;
                 } else {
                     for (uint32_t i = 0; i < len; ++i) { const int64_t f = from + i; out[n + i] = f < 0 ? (uint16_t)(256 + WIN + f) : out[f]; }
