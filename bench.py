@@ -55,8 +55,8 @@ PROFILE_JSON = {"comp": "profiles/r06_final_pmc_fetch_write.json", "hist": "prof
                 "gcp": "profiles/r06_final_gcp_pmc_fetch_write.json", "comp-rr": "profiles/r06_final_comp-rr_pmc_fetch_write.json"}
 # the sources the count stage's kernels are made of: a committed profile describes the kernels of ONE state of these files
 # (tools/profile_bench.sh records their digest next to the counters; pmc_traffic refuses a profile taken from other code)
-STAGE_SOURCES = ["kat_amd/csrc/kg_partition.hpp", "kat_amd/csrc/kg_device.hpp", "kat_amd/csrc/kg_l1_lean.hpp", "kat_amd/csrc/kg_kernels.hpp",
-                 "kat_amd/csrc/kg_count.hip", "kat_amd/csrc/kg_table.hip"]
+STAGE_SOURCES = ["kat_amd/csrc/kg_partition.hpp", "kat_amd/csrc/kg_l1_blocks.hpp", "kat_amd/csrc/kg_l2_blocks.hpp", "kat_amd/csrc/kg_device.hpp",
+                 "kat_amd/csrc/kg_l1_lean.hpp", "kat_amd/csrc/kg_kernels.hpp", "kat_amd/csrc/kg_count.hip", "kat_amd/csrc/kg_table.hip"]
 
 
 def stage_sources_digest():
