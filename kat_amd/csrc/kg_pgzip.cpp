@@ -706,7 +706,7 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
     const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(penv("KATGPU_PGZ_THREADS", std::min(48u, std::max(2u, cpus > 4 ? cpus - 2 : cpus))), 256));
     Inflater inf;
     inf.d = f.d; inf.size = f.size;
-    inf.CB = (size_t)std::max<uint64_t>(1 << 16, penv("KATGPU_PGZ_CHUNK", (uint64_t)4 << 20));
+    inf.CB = (size_t)std::max<uint64_t>(1 << 16, penv("KATGPU_PGZ_CHUNK", (uint64_t)8 << 20));
     inf.n_chunks = (f.size + inf.CB - 1) / inf.CB;
     inf.chunks.reset(new Chunk[inf.n_chunks]);
     inf.chunks[0].sync = (uint64_t)data0 * 8; inf.chunks[0].sync_known.store(1); inf.chunks[0].known_start = true;
