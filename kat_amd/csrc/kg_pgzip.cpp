@@ -766,8 +766,8 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
     };
     struct DrainGuard { std::function<void()> f; ~DrainGuard() { f(); } } drain_guard{close_drain};
     int64_t j = 0;
-    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double ms_wait_decode = 0, ms_wait_job = 0, ms_piece = 0, ms_launch = 0;
+    auto now_ms = clock_ms;
+    double ms_wait_decode = 0, ms_launch = 0;
     const double t_start = now_ms();
     while (j >= 0) {
         { const double t0 = now_ms(); inf.wait_done((size_t)j); ms_wait_decode += now_ms() - t0; }
@@ -882,10 +882,9 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
     }
     close_drain();                                              // every piece handed over has been taken (or waited for)
     if (!rc && drain_rc.load() != KATGPU_OK) { rc = drain_rc.load(); *err = drain_err; }
-    ms_wait_job = t_job; ms_piece = t_piece;
     if (trace) fprintf(stderr, "[katgpu] ingest %s: one gzip stream, %zu chunk(s) of %zu MB by a team of %u (%u CPUs to use), %zu passed over, CRC-32 by %s; %.0f ms: the walk waited %.0f ms for decoders and %.0f ms for room behind it, spent %.0f ms handing chunks to their second jobs; "
                                "behind it %.0f ms were waits for those jobs and %.0f ms went into what takes the pieces\n", path, live, inf.CB >> 20, T, cpus, dropped, !verify ? "nobody" : clmul_ok() ? "carry-less multiplication" : "zlib", now_ms() - t_start,
-                       ms_wait_decode, t_full, ms_launch, ms_wait_job, ms_piece);
+                       ms_wait_decode, t_full, ms_launch, t_job, t_piece);
     return rc;
 }
 
