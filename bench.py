@@ -612,7 +612,8 @@ def cpu_baseline(eng, a, k, L):
                 n, L, gs, {"comp": " + that genome as assembly", "comp-rr": " + a second library of the same size"}.get(wl, ""), k, sweep[best], best, table_mb, host_llc()),
             "thread_sweep_kmers_per_s": {str(t): round(inst / s, 1) for t, s in sorted(sweep.items())},
             "sweep_truncated": bool(skipped), "sweep_skipped_threads": skipped, "sweep_order": plan,
-            "host_cores": cores, "host_last_level_cache": host_llc(),
+            "host_cores": cores, "host_cpus_granted": effective_cpus(),       # (what the container may really use of them: affinity, cgroup cpu.max -- the GPU boxes show 256 and grant 16, which is why the sweep peaks at 16-32 threads)
+            "host_last_level_cache": host_llc(),
             "note": "a port of the reference's algorithm (oracle/koracle.c), not the reference binary (unbuildable here: DESIGN.md section 5).  The sample is sized so that its table is "
                     "much larger than the last-level cache, like the full config's; a smaller sample would flatter the CPU.",
             "reference_scaled": {"value": REF_KMERS_PER_CORE * cores, "unit": "k-mers/s",
