@@ -1345,13 +1345,12 @@ k_merge_apply(DevTable t, uint32_t g_lo, uint32_t g_hi, MergeSrcs srcs, uint32_t
                     uint32_t slot = place_offset(rem, rp.pl, S);
                     uint64_t q, r;
                     pk_split((uint64_t)c, cb, q, r);
+                    const uint64_t in = r ? r : half, qq0 = r ? q : q - 1;
+                    const unsigned long long claim = (unsigned long long)((rem << cb) | in);
                     for (uint32_t probe = 0; probe < S; ++probe) {               // cannot fail: occupied + incoming <= S
-                        unsigned long long w = rk[slot];
-                        if (w == 0) {
-                            const uint64_t in = r ? r : half, qq = r ? q : q - 1;
-                            w = atomicCAS(&rk[slot], 0ULL, (unsigned long long)((rem << cb) | in));
-                            if (w == 0) { ++new_distinct; if (qq) ovf_add(t, base + slot, qq * half); break; }
-                        }
+                        // the claim is tried outright: what it returns is what a read would have (one LDS round trip per step, not two)
+                        unsigned long long w = atomicCAS(&rk[slot], 0ULL, claim);
+                        if (w == 0) { ++new_distinct; if (qq0) ovf_add(t, base + slot, qq0 * half); break; }
                         if ((w >> cb) == rem) {
                             if (r) {
                                 for (;;) {
