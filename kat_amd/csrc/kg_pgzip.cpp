@@ -710,6 +710,18 @@ static int inflate_team(const char* path, bool parse, const std::function<int(Pi
     inf.n_chunks = (f.size + inf.CB - 1) / inf.CB;
     inf.chunks.reset(new Chunk[inf.n_chunks]);
     inf.chunks[0].sync = (uint64_t)data0 * 8; inf.chunks[0].sync_known.store(1); inf.chunks[0].known_start = true;
+    // A stream that offers no way in -- stored or fixed-Huffman blocks only, data that is not text -- would have the first chunk's decoder
+    // go through the whole file alone, its output growing with it: look for ONE entry point in the first megabytes behind chunk 0 before
+    // anything is started; a file without one is left to zlib's single stream (nothing has been handed on yet).
+    if (inf.n_chunks > 1 && penv("KATGPU_PGZ_PROBE", 1) != 0) {
+        bool any = false;
+        const size_t probe_chunks = std::min<size_t>(inf.n_chunks - 1, std::max<size_t>(2, ((size_t)4 << 20) / inf.CB));
+        for (size_t q = 1; q <= probe_chunks && !any; ++q) any = inf.get_sync(q) != NONE;
+        if (!any) {
+            if (getenv("KATGPU_TRACE")) fprintf(stderr, "[katgpu] ingest %s: no deflate block of text starts in the %zu chunk(s) behind the first: one zlib stream\n", path, probe_chunks);
+            return -1;
+        }
+    }
     const size_t ahead = (size_t)T + 4;                          // (chunks in flight: every one owns tens of MB of buffers -- few enough that they are reused early)
     inf.move_horizon(ahead);
     inf.start(T);

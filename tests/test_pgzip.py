@@ -60,6 +60,8 @@ SHAPES = {
 @pytest.mark.parametrize("chunk", [1 << 16, 300_000, 4 << 20])
 def test_the_bytes_are_zlibs(tmp_path, monkeypatch, shape, chunk):
     monkeypatch.setenv("KATGPU_PGZ_CHUNK", str(chunk))
+    if shape in ("stored", "fixed"):
+        monkeypatch.setenv("KATGPU_PGZ_PROBE", "0")                          # (no way into such a stream: the team is made to take it anyway -- the first decoder goes through it alone)
     data = fastq_bytes(12000, seed=3)
     p = tmp_path / "x.fastq.gz"
     p.write_bytes(deflate(data, **SHAPES[shape]))
@@ -96,6 +98,7 @@ def test_data_that_is_not_text(tmp_path, monkeypatch, kind):
     """No block of such a file passes for an entry point (its literals are not text): the first chunk's decoder goes through the whole
     file, alone -- slow, and right.  Long runs: copies that overlap their own output, output hundreds of times the input."""
     monkeypatch.setenv("KATGPU_PGZ_CHUNK", str(1 << 16))
+    monkeypatch.setenv("KATGPU_PGZ_PROBE", "0")
     rng = np.random.default_rng(5)
     data = {"random": lambda: rng.integers(0, 256, 700000, dtype=np.uint8).tobytes(), "zeros": lambda: bytes(30_000_000),
             "runs": lambda: b"".join(bytes([int(x)]) * int(n) for x, n in zip(rng.integers(0, 256, 4000), rng.integers(1, 6000, 4000)))}[kind]()
@@ -106,6 +109,7 @@ def test_data_that_is_not_text(tmp_path, monkeypatch, kind):
 
 def test_text_runs_expand_beyond_any_first_guess_of_the_buffers(tmp_path, monkeypatch):
     monkeypatch.setenv("KATGPU_PGZ_CHUNK", str(1 << 16))
+    monkeypatch.setenv("KATGPU_PGZ_PROBE", "0")                              # (blocks of millions of symbols are not entry points the search accepts: the team is made to take the file)
     data = (b"ACGT" * 25 + b"\n") * 600000                                  # 60 MB from ~200 KB: every chunk's output outgrows its buffer
     p = tmp_path / "r.gz"
     p.write_bytes(gzip.compress(data, 6, mtime=0))
@@ -151,6 +155,7 @@ def test_the_base_stream_is_the_streaming_parsers(ko, tmp_path, monkeypatch, cap
     crlf = tmp_path / "crlf.fq"
     crlf.write_bytes(fastq_bytes(6000, seed=seed, crlf=True)[:-1])            # (and no final newline)
     files += [clean, crlf]
+    took = 0
     for f in files:
         plain = f.read_bytes()
         want = kat_amd.parse_file(str(f)).tobytes()
@@ -160,11 +165,14 @@ def test_the_base_stream_is_the_streaming_parsers(ko, tmp_path, monkeypatch, cap
             gz.write_bytes(gzip.compress(plain, level, mtime=0))
             capfd.readouterr()
             got = kat_amd.parse_file(str(gz)).tobytes()
-            assert "one gzip stream" in capfd.readouterr().err              # (the team took it)
+            err = capfd.readouterr().err                                    # (the team took it -- or found no way into so small a stream and said so)
+            assert "one gzip stream" in err or "one zlib stream" in err, err[-400:]
+            took += "one gzip stream" in err
             assert got == want, (f.name, level)
             monkeypatch.setenv("KATGPU_PGZ", "0")
             assert kat_amd.parse_file(str(gz)).tobytes() == want            # zlib's stream: the same
             monkeypatch.delenv("KATGPU_PGZ")
+    assert took >= 6                                                        # (most of the ten files are the team's)
 
 
 def test_which_files_the_team_takes(tmp_path, monkeypatch, capfd):
@@ -186,3 +194,25 @@ def test_which_files_the_team_takes(tmp_path, monkeypatch, capfd):
     gz2.write_bytes(gzip.compress(fastq_bytes(2000, seed=8), 1, mtime=0))
     both = kat_amd.parse_files([str(gz), str(gz2)], 21).tobytes()
     assert both == want + b"N" + kat_amd.parse_file(str(gz2)).tobytes() + b"N"
+
+
+def test_a_stream_without_a_way_in_is_left_to_zlib(tmp_path, monkeypatch, capfd):
+    """Fixed-Huffman or stored blocks only: no block start the search accepts, so the first chunk's decoder would go through the whole file
+    alone, its output growing with it.  The team looks for one entry point behind the first chunk before it starts and declines such a file:
+    the parser reads it through zlib's stream, the same bytes; katgpu_inflate_file says it is not a file the team takes."""
+    monkeypatch.setenv("KATGPU_PGZ_CHUNK", str(1 << 16))
+    monkeypatch.setenv("KATGPU_TRACE", "1")
+    data = fastq_bytes(9000, seed=6)
+    plain = tmp_path / "p.fastq"
+    plain.write_bytes(data)
+    want = kat_amd.parse_file(str(plain)).tobytes()
+    for shape in ("fixed", "stored"):
+        gz = tmp_path / (shape + ".fastq.gz")
+        gz.write_bytes(deflate(data, **SHAPES[shape]))
+        capfd.readouterr()
+        assert kat_amd.parse_file(str(gz)).tobytes() == want
+        err = capfd.readouterr().err
+        assert "one zlib stream" in err and "by a team of" not in err, err[-600:]
+        with pytest.raises(kat_amd.KatGpuError) as e:
+            kb.inflate_file(str(gz))
+        assert e.value.code == 3
