@@ -172,9 +172,10 @@ def main():
     a.gpus = world
 
     if world > 1:
-        # the exchange keeps its send list and receive buffers inside the arena and allocates nothing else; leave room for the
-        # second table, RCCL's channel buffers and the small per-region count matrices (must be set before the library loads)
-        os.environ.setdefault("KATGPU_ARENA_FRACTION", "0.75")
+        # leave room beside the counter's arena for the second table, RCCL's channel buffers and the buffers of TWO exchanges under way
+        # (send list + what arrives: ~18 bytes per record sent, 50 GB for config 4's table) -- with them the second input is counted while
+        # the first table travels; without room the ranks agree on the one-call exchange inside the arena (must be set before the library loads)
+        os.environ.setdefault("KATGPU_ARENA_FRACTION", "0.55")
         # a bench step is seconds: a single wait of ten minutes is a wedged link, and an error beats a hang (kg_comm.hip "Liveness")
         os.environ.setdefault("KATGPU_COMM_MAX_WAIT_S", "600")
         if a.allow_shm:
